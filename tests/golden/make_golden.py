@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the *reference* implementation on CPU.
+
+Runs only in the build container (needs /root/reference, read-only). The reference
+hard-codes ``device('cuda')`` (problems.py:11, solver.py:36,947); it is redirected to
+CPU without touching the reference by swapping the module-local name ``pt`` for a
+proxy that forwards everything to torch except ``device(...)``.
+
+What is written under tests/golden/ is data only: the case configuration (inputs)
+and the reference's outputs (loss_log, control on a probe grid, parameter
+checksums, noise fingerprint).  No reference source text is stored.
+
+Usage:  python tests/golden/make_golden.py            (rewrites tests/golden/*.json)
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("PSP_REFERENCE_DIR", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+class _PtProxy(types.ModuleType):
+    """torch with device(...) pinned to CPU."""
+
+    def __init__(self):
+        super().__init__("pt_cpu_proxy")
+
+    def __getattr__(self, name):
+        if name == "device":
+            return lambda *a, **k: torch.device("cpu")
+        return getattr(torch, name)
+
+
+import function_space as ref_fs  # noqa: E402
+import problems as ref_pb  # noqa: E402
+import utilities as ref_ut  # noqa: E402
+import solver as ref_sv  # noqa: E402
+
+_proxy = _PtProxy()
+for _m in (ref_fs, ref_pb, ref_ut, ref_sv):
+    _m.pt = _proxy
+ref_pb.device = torch.device("cpu")
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def f32list(t):
+    return [float(v) for v in t.detach().reshape(-1).to(torch.float32).tolist()]
+
+
+def param_fingerprint(module):
+    """Order-stable checksums of a module's parameters (fp64 sums of fp32 values)."""
+    out = []
+    for name, p in module.named_parameters():
+        q = p.detach().to(torch.float64)
+        out.append({"name": name, "shape": list(p.shape), "sum": float(q.sum()),
+                    "abs_sum": float(q.abs().sum()),
+                    "head": f32list(p.detach().reshape(-1)[:4])})
+    return out
+
+
+def wide_tanh_mlp(d_in, d_out, widths, lr, seed):
+    """A reference MySequential whose hidden widths are replaced.
+
+    function_space.py:181 hard-codes [d_in,30,30,d_out]; the benchmark configs ask
+    for 2x64.  The object is built by the reference class, then its layers are
+    rebuilt with the same RNG recipe the reference constructor uses
+    (function_space.py:180-188: manual_seed, Linear ctor per layer, then
+    normal_(0,0.01) on weight and bias layer by layer) so that the init stream is
+    the one a width-configurable MySequential would have produced.
+    """
+    net = ref_fs.MySequential(d_in=d_in, d_out=d_out, lr=lr, seed=seed)
+    torch.manual_seed(seed)
+    dims = [d_in] + list(widths) + [d_out]
+    net.nn_dims = dims
+    net.linears = torch.nn.ModuleList(
+        [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+    net.activations = torch.nn.ModuleList([torch.nn.Tanh() for _ in range(len(dims) - 2)])
+    net.optim = torch.optim.Adam(net.parameters(), lr=lr)
+    for lin in net.linears:
+        torch.nn.init.normal_(lin.weight, 0, 0.01)
+        torch.nn.init.normal_(lin.bias, 0, 0.01)
+    return net
+
+
+def make_problem(spec):
+    kind = spec["kind"]
+    kw = dict(spec["kwargs"])
+    return getattr(ref_pb, kind)(**kw)
+
+
+def probe_points(d, n=5, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, d, generator=g)
+
+
+def run_solver_case(case):
+    problem = make_problem(case["problem"])
+    skw = dict(case["solver"])
+    model = ref_sv.Solver(name=case["name"], problem=problem, verbose=False, **skw)
+    net = case.get("net")
+    if net is not None:
+        if net["kind"] == "tanh_mlp":
+            model.z_n = wide_tanh_mlp(problem.d + 1, problem.d, net["widths"], skw["lr"], net["seed"])
+        elif net["kind"] == "densenet":
+            model.z_n = ref_fs.DenseNet(d_in=problem.d + 1, d_out=problem.d, lr=skw["lr"],
+                                        arch=net["arch"], seed=net["seed"])
+        model.update_Phis()
+    init_fp = param_fingerprint(model.z_n) if not isinstance(model.z_n, list) else None
+    model.train()
+    xp = probe_points(problem.d)
+    probes = []
+    for t in case.get("probe_times", [0.0]):
+        with torch.no_grad():
+            z = model.Z_n(xp, torch.tensor(t))
+        probes.append({"t": t, "minus_Z": f32list(-z)})
+    res = {
+        "N": model.N, "p": int(model.p),
+        "loss_log": [float(v) for v in model.loss_log],
+        "u_L2_loss": [float(v) for v in model.u_L2_loss],
+        "Y_0_log": [float(v) for v in model.Y_0_log],
+        "init_params": init_fp,
+        "final_params": param_fingerprint(model.z_n) if not isinstance(model.z_n, list) else None,
+        "y_0_final": float(model.y_0.Y_0.detach()[0]) if hasattr(model, "y_0") else None,
+        "probe_x": f32list(xp), "probes": probes,
+    }
+    return res
+
+
+def run_general_case(case):
+    problem = make_problem(case["problem"])
+    skw = dict(case["solver"])
+    model = ref_sv.GeneralSolver(problem=problem, name=case["name"], verbose=False, **skw)
+    net = case.get("net")
+    if net is not None:
+        model.V = ref_fs.DenseNet(d_in=problem.d + 1, d_out=1, lr=skw["lr"], arch=net["arch"],
+                                  seed=net["seed"])
+    init_fp = param_fingerprint(model.V)
+    model.train()
+    xp = probe_points(problem.d)
+    tp = torch.full((xp.shape[0], 1), 0.5 * problem.T)
+    with torch.no_grad():
+        v = model.V(torch.cat([xp, tp], 1)).squeeze()
+    return {
+        "loss_log": [float(v_) for v_ in model.loss_log],
+        "K_log": [int(v_) for v_ in model.K_log],
+        "init_params": init_fp, "final_params": param_fingerprint(model.V),
+        "probe_x": f32list(xp), "probe_t": 0.5 * problem.T, "probe_V": f32list(v),
+    }
+
+
+HJB = dict(loss_method="log-variance", time_approx="inner", adaptive_forward_process=True,
+           detach_forward=True, early_stopping_time=None)
+
+CASES = [
+    # BASELINE.json configs[0]: d=2 HJB-LQ, K=128, N=20, log-variance
+    dict(name="lqgc_d2_logvar", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
+         solver=dict(HJB, L=6, lr=0.01, seed=42, delta_t=0.05, K=128), probe_times=[0.0, 0.5]),
+    # same without the per-step u_true logging
+    dict(name="lqgc_d2_logvar_noul2", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
+         solver=dict(HJB, L=6, lr=0.01, seed=42, delta_t=0.05, K=128, u_l2_error_flag=False)),
+    # BASELINE.json configs[1] shape with the reference's default 2x30 net
+    dict(name="llgc_d100_h30_logvar", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=0.5, seed=42)),
+         solver=dict(HJB, L=4, lr=0.001, seed=42, delta_t=0.01, K=1024, u_l2_error_flag=False)),
+    # BASELINE.json configs[1]: d=100, K=1024, N=50, 2x64 tanh MLP
+    dict(name="llgc_d100_h64_logvar", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=0.5, seed=42)),
+         solver=dict(HJB, L=4, lr=0.001, seed=42, delta_t=0.01, K=1024, u_l2_error_flag=False),
+         net=dict(kind="tanh_mlp", widths=[64, 64], seed=123), probe_times=[0.0, 0.25]),
+    # DenseNet swapped in as the control net (notebook extension point)
+    dict(name="llgc_d100_densenet64_logvar", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=0.5, seed=42)),
+         solver=dict(HJB, L=3, lr=0.001, seed=42, delta_t=0.01, K=1024, u_l2_error_flag=False),
+         net=dict(kind="densenet", arch=[64, 64], seed=42)),
+    # elementwise double-well drift, B = I
+    dict(name="dw_d10_logvar", family="solver",
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=10, d_1=5, d_2=5, T=0.5, eta=0.5, kappa=2.0)),
+         solver=dict(HJB, L=4, lr=0.005, seed=42, delta_t=0.01, K=256, u_l2_error_flag=False)),
+    # structured OU: A=-I, B=I (off_diag=0)
+    dict(name="llgc_d20_diag_logvar", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=20, off_diag=0.0, T=0.3, seed=42)),
+         solver=dict(HJB, L=4, lr=0.002, seed=42, delta_t=0.01, K=200, u_l2_error_flag=False)),
+    # moment loss with learnable Y_0
+    dict(name="lqgc_d2_moment", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
+         solver=dict(HJB, loss_method="moment", learn_Y_0=True, L=5, lr=0.01, seed=42, delta_t=0.05,
+                     K=128, u_l2_error_flag=False)),
+    # random initial points
+    dict(name="lqgc_d4_randx0", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=4, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
+         solver=dict(HJB, L=4, lr=0.01, seed=3, delta_t=0.05, K=96, random_X_0=True,
+                     u_l2_error_flag=False)),
+    # uncontrolled forward process (c = 0): gradient keeps the Z*dt term
+    dict(name="llgc_d8_nonadaptive", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=8, off_diag=0.05, T=0.4, seed=42)),
+         solver=dict(HJB, adaptive_forward_process=False, L=4, lr=0.003, seed=42, delta_t=0.02, K=160,
+                     u_l2_error_flag=False)),
+    # default time_approx='outer' (one DenseNet per step) -- composite plan only
+    dict(name="lqgc_d2_outer", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
+         solver=dict(loss_method="log-variance", time_approx="outer", adaptive_forward_process=True,
+                     detach_forward=True, early_stopping_time=None, L=3, lr=0.01, seed=42,
+                     delta_t=0.05, K=64, u_l2_error_flag=False)),
+    # GeneralSolver, diffusion loss, unbounded square
+    dict(name="dwgen_d10_diffusion", family="general",
+         problem=dict(kind="DoubleWell_multidim_for_general_solver",
+                      kwargs=dict(d=10, d_1=5, d_2=5, T=0.3, eta=1, kappa=1, modus="HJB")),
+         solver=dict(seed=42, delta_t=0.01, N=12, lr=0.001, L=3, K=96, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
+         net=dict(arch=[32, 32], seed=42)),
+    dict(name="dwgen_d10_bsde", family="general",
+         problem=dict(kind="DoubleWell_multidim_for_general_solver",
+                      kwargs=dict(d=10, d_1=5, d_2=5, T=0.1, eta=1, kappa=1, modus="HJB")),
+         solver=dict(seed=42, delta_t=0.01, N=14, lr=0.001, L=3, K=64, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="BSDE"),
+         net=dict(arch=[32, 32], seed=42)),
+    dict(name="allencahn_d10_diffusion", family="general",
+         problem=dict(kind="AllenCahn", kwargs=dict(d=10, T=0.3, seed=42, modus="pt")),
+         solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=80, K_boundary=16,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
+         net=dict(arch=[24, 24], seed=42)),
+    dict(name="heat_d6_diffusion", family="general",
+         problem=dict(kind="HeatEquation", kwargs=dict(d=6, T=0.5, seed=42)),
+         solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=72, K_boundary=16,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion")),
+]
+
+
+def main():
+    torch.set_num_threads(1)
+    index = {"torch": torch.__version__, "numpy": np.__version__, "cases": []}
+    torch.manual_seed(42)
+    index["noise_fingerprint"] = {"seed": 42, "shape": [4, 3, 2],
+                                  "values": f32list(torch.randn(4, 3, 2))}
+    only = set(sys.argv[1:])
+    for case in CASES:
+        if only and case["name"] not in only:
+            continue
+        print("running", case["name"], flush=True)
+        res = run_solver_case(case) if case["family"] == "solver" else run_general_case(case)
+        rec = {"case": case, "expected": res, "torch": torch.__version__}
+        with open(os.path.join(OUT, case["name"] + ".json"), "w") as fh:
+            json.dump(rec, fh, indent=1)
+        index["cases"].append(case["name"])
+        print("   loss_log", res["loss_log"])
+    if not only:
+        with open(os.path.join(OUT, "index.json"), "w") as fh:
+            json.dump(index, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
