@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-space hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" = one full training iteration of Solver.train (forward SDE rollout over N_t time
+steps, log-variance loss, analytic backward, Adam) on synthetic d-dimensional HJB data with
+random-init weights.  Metric = trajectory-timesteps/s = K_traj * N_t * steps / wall time,
+inputs resident in HBM, on-device Philox noise.  For --gpus N > 1 the script is
+launched by torch.distributed.run (one rank per GPU, RCCL); every rank keeps the same
+per-GPU trajectory count (weak scaling) and the value is the whole-job aggregate.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- dominant kernel: algorithmic flops per launch / mean launch time (HIP events
+                  recorded on the launch stream inside the timed region) against the fp32
+                  MFMA peak of MI355X (157.3 TFLOP/s).
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm, oracle/) timed on the
+                  host cores of this box on a bounded sample of the same workload; reported
+                  baseline, not the optimisation target.  Rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json north-star target shape: d=100 HJB (LLGC, dense A and B), K=65536, N=100, 2x64 MLP
+    "hjb_llgc_d100_K65536_N100_h64": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.01),
+    # BASELINE.json configs[1]
+    "hjb_llgc_d100_K1024_N50_h64": dict(d=100, H=64, K=1024, T=0.5, dt=0.01, off_diag=0.01),
+    # structured variant A=-I, B=I (reported separately)
+    "hjb_llgc_d100_K65536_N100_h64_diag": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.0),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+
+def alg_flops_per_traj_step(d, H, dense):
+    """algorithmic flops per trajectory-timestep of the training iteration."""
+    f_fwd = 2 * ((d + 1) * H + H * H + H * d)
+    f_bwd = f_fwd + 2 * (H * H + H * d)
+    f_sde = 2 * d * d * (3 if dense else 0)
+    return dict(fwd_kernel=f_fwd + f_sde + 12 * d, bwd_kernel=f_bwd, total=f_fwd + f_bwd + f_sde + 12 * d)
+
+
+def cpu_baseline(w, seconds_budget=20.0):
+    """Times oracle/pathspace_oracle.py (torch-CPU port of the reference iteration, including its
+    duplicate control evaluation and dense sigma products) on K=4096 trajectories of the workload."""
+    from oracle import pathspace_oracle as orc
+    Kc = min(4096, w["K"])
+    prob = orc.make_problem("LLGC", d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42)
+    threads = torch.get_num_threads()
+    cfg = orc.HJBConfig(K=Kc, delta_t=w["dt"], lr=1e-3, L=1, seed=42, adaptive_forward_process=True,
+                        detach_forward=True)
+    z = orc.TanhMLP(w["d"] + 1, w["d"], 1e-3, seed=123, widths=(w["H"], w["H"]))
+    _, y0, N = orc.hjb_build(prob, cfg)
+    orc.hjb_train(prob, cfg, step_models=(z, y0, N))          # warm-up iteration
+    iters, t0 = 0, time.time()
+    while True:
+        orc.hjb_train(prob, cfg, step_models=(z, y0, N))
+        iters += 1
+        el = time.time() - t0
+        if el > seconds_budget or iters >= 12:
+            break
+    rate = Kc * N * iters / el
+    return dict(value=rate, unit="trajectory-timesteps/s", cores=threads, kind="port",
+                sample="oracle hjb_train, K=%d of %d trajectories, N=%d, %d iterations, %.1f s, torch %s"
+                       % (Kc, w["K"], N, iters, el, torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="hjb_llgc_d100_K65536_N100_h64", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import path_space_pde_solver_amd as psp
+    w = WORKLOADS[args.workload]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world:
+        print("note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)"
+              % (args.gpus, world), file=sys.stderr)
+
+    K_global = w["K"] * world                           # weak scaling: fixed trajectories per GPU
+    prob = psp.LLGC(d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42, device=dev)
+    total = args.warmup + args.steps
+    model = psp.Solver("bench", prob, lr=1e-3, L=total, K=K_global, delta_t=w["dt"], loss_method="log-variance",
+                       time_approx="inner", adaptive_forward_process=True, detach_forward=True,
+                       u_l2_error_flag=False, verbose=False, seed=42, device=dev, backend="native",
+                       noise="philox", widths=(w["H"], w["H"]))
+    plan = model._choose_plan()
+    assert model.plan_name == "native"
+    N_t = model.N
+    losses = torch.zeros(total, dtype=torch.float32, device=dev)
+    for l in range(args.warmup):
+        plan.iteration(l, losses)
+
+    plan.events = []                                     # (fwd_start, fwd_end, bwd_start, bwd_end) per step
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for l in range(args.warmup, total):
+        plan.iteration(l, losses)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in plan.events) / max(1, len(plan.events))
+    bwd_ms = sum(e[2].elapsed_time(e[3]) for e in plan.events) / max(1, len(plan.events))
+    loss_vals = losses.cpu().tolist()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    dense = w["off_diag"] != 0.0
+    fl = alg_flops_per_traj_step(w["d"], w["H"], dense)
+    units_local = w["K"] * N_t                           # trajectory-timesteps per launch on one GPU
+    dom = "hjb_bwd_kernel" if bwd_ms >= fwd_ms else "hjb_fwd_kernel"
+    dom_ms = max(bwd_ms, fwd_ms)
+    dom_flops = (fl["bwd_kernel"] if dom == "hjb_bwd_kernel" else fl["fwd_kernel"]) * units_local
+    achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+    value = K_global * N_t * args.steps / elapsed
+    out = {
+        "metric": "trajectory-timesteps/sec (K*N/s), d=100 HJB log-variance training iteration",
+        "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "problem": "LLGC", "d": w["d"], "K_per_gpu": w["K"],
+                   "K_global": K_global, "N": N_t, "mlp": "%d-%d-%d-%d tanh" % (w["d"] + 1, w["H"], w["H"], w["d"]),
+                   "loss": "log-variance", "noise": "on-device Philox4x32-10",
+                   "parallelism": "trajectory-sharded x%d" % world},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "alg_flops_per_traj_step": fl, "units_per_launch": units_local,
+                     "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
+                     "whole_step_tflops": fl["total"] * units_local / (1e-3 * (1e3 * elapsed / args.steps)) / 1e12},
+        "loss_first_last": [loss_vals[0], loss_vals[-1]],
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

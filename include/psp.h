@@ -1,0 +1,146 @@
+/*
+ * psp.h -- C ABI of the MI355X-native path-space hot path (libpsp_hip.so).
+ *
+ * The reference (lorenzrichter/path-space-PDE-solver) is pure Python and exposes no
+ * FFI; its boundary is the duck-typed Solver / Problem / FunctionSpace API.  This
+ * library sits underneath this repo's Python mirror of that API and replaces the
+ * body of Solver.train (reference solver.py:420-557) for the supported catalogue:
+ *   approx_method='control', time_approx='inner' (one tanh MLP, two hidden layers),
+ *   detach_forward=True, loss_method in {'log-variance','moment'}.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every device buffer is owned by the caller
+ *    (torch tensors on the Python side); nothing here allocates or frees.
+ *  - all functions are asynchronous on the given hipStream_t (passed as void*),
+ *    return 0 on success and a negative code on failure; psp_last_error() gives text.
+ *  - everything is fp32 ("dtype f32"); partial sums of D are fp64.
+ *  - parameters / gradients use the torch nn.Linear flat layout of the control net:
+ *        [W1 (H x (d+1)), b1 (H), W2 (H x H), b2 (H), W3 (d x H), b3 (d)]
+ *    where input column 0 of W1 is the time feature (reference solver.py:355).
+ */
+#ifndef PSP_H_
+#define PSP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSP_VERSION 100 /* 0.1.0 */
+
+/* drift b(x): reference problems.py:36-37,154-155 (dense), :311-315 (double well) */
+enum { PSP_DRIFT_ZERO = 0, PSP_DRIFT_DENSE = 1, PSP_DRIFT_DIAG = 2, PSP_DRIFT_DOUBLE_WELL = 3 };
+/* sigma(x) = B constant: problems.py:39-40,157-158,317-318 */
+enum { PSP_SIGMA_IDENTITY = 0, PSP_SIGMA_DENSE = 1, PSP_SIGMA_SCALED_IDENTITY = 2 };
+/* running cost f(x) inside h = -0.5|z|^2 - f(x): problems.py:46 (zero), :161,167 (x'Px, diagonal P) */
+enum { PSP_RUNCOST_ZERO = 0, PSP_RUNCOST_DIAG_QUAD = 1 };
+/* terminal cost g(x): problems.py:49 (alpha.x), :164 (x'Rx, diagonal R), :334 (sum eta_j (x_j-1)^2) */
+enum { PSP_TERM_LINEAR = 0, PSP_TERM_DIAG_QUAD = 1, PSP_TERM_SHIFTED_QUAD = 2 };
+/* loss: solver.py:167-168 (log-variance), :165-166 (moment) */
+enum { PSP_LOSS_LOG_VARIANCE = 0, PSP_LOSS_MOMENT = 1 };
+/* Brownian increments: supplied = the reference's host-generated xi (solver.py:381), philox = on device */
+enum { PSP_NOISE_SUPPLIED = 0, PSP_NOISE_PHILOX = 1 };
+
+/* POD description of one HJB rollout problem on one rank. */
+typedef struct psp_hjb_config {
+    int32_t d;            /* state dimension                                    */
+    int32_t H;            /* hidden width of the control MLP (two hidden layers) */
+    int32_t K_local;      /* trajectories on this rank                           */
+    int32_t N;            /* time steps, floor(T/dt) (solver.py:41)              */
+    int64_t K_global;     /* trajectories over all ranks (loss normalisation)    */
+    int64_t k_offset;     /* global index of local trajectory 0 (Philox counter) */
+    float dt;             /* fp32 step (solver.py:39)                            */
+    float sqrt_dt;        /* fp32 sqrt(dt) (solver.py:40)                        */
+    int32_t drift_kind;
+    int32_t sigma_kind;
+    int32_t runcost_kind;
+    int32_t term_kind;
+    int32_t adaptive;     /* 1: c = -Z (solver.py:456), 0: c = 0 (solver.py:451) */
+    int32_t loss_kind;
+    int32_t noise_mode;
+    int32_t store_path;   /* 1: keep X_n for the backward pass, 0: forward only  */
+    float sigma_scale;    /* PSP_SIGMA_SCALED_IDENTITY                            */
+    int32_t reserved;
+    const float* drift;   /* DENSE: A (d*d row-major); DIAG: a (d); DOUBLE_WELL: kappa (d) */
+    const float* sigma;   /* DENSE: B (d*d row-major); else NULL                  */
+    const float* runcost; /* DIAG_QUAD: p (d); else NULL                          */
+    const float* term;    /* alpha / r / eta (d)                                  */
+} psp_hjb_config;
+
+/* Sizes of the caller-owned scratch buffers for a config. */
+typedef struct psp_hjb_sizes {
+    int64_t path_bytes;       /* X_n store for the backward pass (0 if !store_path)  */
+    int64_t fwd_partial_bytes;/* per-workgroup (sum D, sum D^2) fp64 pairs            */
+    int64_t grad_partial_bytes;/* per-workgroup partial gradients                     */
+    int32_t n_params;         /* p = (d+1)H+H + H*H+H + H*d+d                         */
+    int32_t fwd_workgroups;
+    int32_t bwd_workgroups;
+    int32_t reserved;
+} psp_hjb_sizes;
+
+int psp_version(void);
+const char* psp_last_error(void);
+
+/* 1 if a compiled kernel instantiation exists for (d, H), else 0. */
+int psp_hjb_supported(int32_t d, int32_t H);
+
+/* Fills *out; returns <0 if the config is not supported. */
+int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out);
+
+/*
+ * Forward rollout: replaces the n-loop of Solver.train (solver.py:440-478) plus
+ * initialize_training_data (:364-382) and D = Y - g(X_N) of loss_function (:167-168).
+ *   params   : flat control-net parameters (device)
+ *   x0       : initial states, x0_stride = 0 -> one (d) vector broadcast (solver.py:365),
+ *              x0_stride = d -> (K_local, d) row-major (random_X_0, solver.py:367)
+ *   y0       : device pointer to the learnable scalar Y_0 (solver.py:372-373) or NULL (Y=0)
+ *   xi       : PSP_NOISE_SUPPLIED: (N+1, K_local, d) fp32, slice n+1 drives step n
+ *              (the reference's (K,d,N+1) tensor permuted); ignored for PHILOX
+ *   seed,iter: Philox key / iteration counter
+ *   path     : X_n store (path_bytes) or NULL
+ *   D_out    : (K_local) fp32, D_k = Y_k - g(X_N,k)
+ *   XN_out   : optional (K_local, d) final states or NULL
+ *   fwd_partial: fwd_partial_bytes scratch
+ */
+int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const float* x0, int32_t x0_stride,
+                        const float* y0, const float* xi, uint64_t seed, uint32_t iter, float* path,
+                        float* D_out, float* XN_out, double* fwd_partial, void* stream);
+
+/* Sums the per-workgroup partials in a fixed order: sums_out[0] = sum_k D_k, sums_out[1] = sum_k D_k^2
+ * over this rank's trajectories (fp64, device).  The caller all-reduces sums_out across ranks. */
+int psp_hjb_terminal_reduce(const psp_hjb_config* cfg, const double* fwd_partial, double* sums_out, void* stream);
+
+/*
+ * Backward pass: replaces loss.backward() of solver.py:221 with the analytic gradient
+ * (detach_forward=True: dL/dZ_n[k] = w_k ((Z_n + c) dt + xi_{n+1} sqrt(dt)),
+ *  w_k = (2/K)(D_k - mean D) for log-variance, (2/K) D_k for moment).
+ *   sums     : GLOBAL (sum D, sum D^2), fp64 on device (after the all-reduce)
+ *   grad_partial : grad_partial_bytes scratch (per-workgroup partial gradients)
+ *   grad_out : flat gradient (n_params fp32) for this rank's trajectories, summed in a fixed
+ *              order (bitwise reproducible).  The gradient of the learnable Y_0 (moment loss)
+ *              is (2/K) sum_k D_k and is formed by the caller from `sums`.
+ */
+int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const float* xi, uint64_t seed,
+                        uint32_t iter, const float* path, const float* D, const double* sums,
+                        float* grad_partial, float* grad_out, void* stream);
+
+/* torch.optim.Adam(lr, betas=(b1,b2), eps, weight_decay=0, amsgrad=False) on a flat buffer
+ * (function_space.py:185, solver.py:198-200).  step is 1-based. */
+int psp_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  int32_t step, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* Materialises the device noise stream exactly as the rollout kernels consume it:
+ * out is (N+1, K_local, d) fp32 with slice 0 zero.  Test / diagnostics helper. */
+int psp_philox_normal_fill(float* out, int32_t N, int32_t K_local, int32_t d, int64_t k_offset,
+                           uint64_t seed, uint32_t iter, void* stream);
+
+/* Control evaluation u = -Z on a batch (solver.py:349-362): out (K, d) = -MLP([t, X]). */
+int psp_hjb_control_eval(int32_t d, int32_t H, const float* params, const float* X, int32_t K, float t,
+                         float* minus_Z_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSP_H_ */

@@ -1,0 +1,21 @@
+"""MI355X-native hot path of the path-space PDE solver.
+
+The directory can be used in two ways:
+  * as a package:      ``from path_space_pde_solver_amd import Solver, LLGC``
+    (``path_space_pde_solver_amd/`` at the repo root is a thin import shim because this
+    directory's name is not a valid Python identifier);
+  * flat, like the reference: put this directory on ``sys.path`` and
+    ``from solver import Solver``; ``from problems import LLGC`` -- the module names the
+    reference's notebooks import.
+"""
+from .function_space import (Affine, Constant, DenseNet, DenseNet_tanh, Linear, MySequential,  # noqa: F401
+                             SingleParam)
+from .problems import (LLGC, LQGC, AllenCahn, DoubleWell_multidim,  # noqa: F401
+                       DoubleWell_multidim_for_general_solver, HeatEquation)
+from .solver import Solver  # noqa: F401
+from .plan_native import PlanUnsupported  # noqa: F401
+from . import native  # noqa: F401
+
+__all__ = ['Solver', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
+           'AllenCahn', 'HeatEquation', 'MySequential', 'DenseNet', 'DenseNet_tanh', 'SingleParam',
+           'Constant', 'Linear', 'Affine', 'PlanUnsupported', 'native']

@@ -1,0 +1,98 @@
+"""In-tree build of libpsp_hip.so (hipcc, gfx950 only).
+
+    python path-space-pde-solver_amd/build.py [--force] [-j N]
+
+One translation unit per (d, H) line of csrc/instances.def plus csrc/psp_api.hip, linked
+into csrc/libpsp_hip.so next to the sources so the library travels with the tree.
+hipcc cross-compiles without a GPU.
+"""
+import argparse
+import hashlib
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(CSRC, "libpsp_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def instances():
+    out = []
+    with open(os.path.join(CSRC, "instances.def")) as fh:
+        for line in fh:
+            m = re.match(r"\s*X\(\s*(\d+)\s*,\s*(\d+)\s*\)", line)
+            if m:
+                out.append((int(m.group(1)), int(m.group(2))))
+    return out
+
+
+def _digest(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _compile(src, obj, defs, deps, force):
+    stamp = obj + ".sha"
+    dig = _digest(deps, " ".join(FLAGS + defs))
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + defs + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return obj, True
+
+
+def build(force=False, jobs=None, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr = os.path.join(CSRC, "hjb_kernels.h")
+    inc = os.path.join(HERE, "..", "include", "psp.h")
+    idef = os.path.join(CSRC, "instances.def")
+    inst_src = os.path.join(CSRC, "hjb_instance.hip")
+    api_src = os.path.join(CSRC, "psp_api.hip")
+    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, inc, idef])]
+    for d, H in instances():
+        tasks.append((inst_src, os.path.join(OBJ, "inst_%d_%d.o" % (d, H)),
+                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [inst_src, hdr]))
+    jobs = jobs or min(6, os.cpu_count() or 2)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        results = list(ex.map(lambda t: _compile(t[0], t[1], t[2], t[3], force), tasks))
+    objs = [r[0] for r in results]
+    rebuilt = any(r[1] for r in results)
+    # drop objects of instances that were removed from instances.def
+    keep = set(os.path.basename(o) for o in objs)
+    for f in os.listdir(OBJ):
+        if f.endswith(".o") and f not in keep:
+            os.remove(os.path.join(OBJ, f))
+            rebuilt = True
+    if rebuilt or force or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stderr))
+        if verbose:
+            print("built", LIB)
+    elif verbose:
+        print("up to date:", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-j", type=int, default=None)
+    a = ap.parse_args()
+    build(force=a.force, jobs=a.j)
+    sys.exit(0)

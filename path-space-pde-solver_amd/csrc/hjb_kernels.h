@@ -1,0 +1,803 @@
+// hjb_kernels.h -- CDNA4 (gfx950) kernels for the controlled-SDE rollout of the HJB /
+// log-variance training step.  Included by the per-(d,H) instantiation units.
+//
+// Data layout ("T layout", trajectory-on-lane).  One wavefront owns 16 trajectories.
+// A (features x 16 trajectories) panel lives in registers as one f32x4 per block of 16
+// features: lane l = j + 16 q (j = trajectory 0..15, q = 0..3), component r of block b
+// holds feature 16 b + 4 r + q.  This is exactly the C/D layout of
+// v_mfma_f32_16x16x4_f32 (col = lane&15, row = 4 (lane>>4) + reg) when the weight rows
+// fed as the A operand are permuted by rowmap(i) = 4 (i&3) + (i>>2); and component r of
+// a block is, unchanged, the B operand of k-step 4 b + r (k = q <-> feature 4 (4b+r) + q).
+// So every layer  out^T = W . in^T  chains register-to-register with no LDS round trip
+// for activations; only the weights (shared by all waves) are staged in LDS, pre-permuted
+// so that each A operand is one lane-linear ds_read_b32.
+//
+// fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision), which is what lets
+// the loss match the reference's fp32 CPU path to ~1e-6.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct HjbArgs {
+    const float* params;
+    const float* x0;
+    const float* y0;
+    const float* xi;
+    float* path;
+    float* D;
+    float* XN;
+    double* fwd_partial;
+    const float* drift;
+    const float* sigma;
+    const float* runcost;
+    const float* term;
+    const double* sums;
+    float* grad_partial;
+    long long k_offset;
+    long long K_global;
+    int x0_stride;
+    int K_local;
+    int N;
+    int ntile16;
+    float dt, sqdt, sigma_scale;
+    int drift_kind, sigma_kind, runcost_kind, term_kind, adaptive, loss_kind, noise_mode, store_path;
+    uint32_t seed_lo, seed_hi, iter;
+};
+
+// ---- enums mirrored from include/psp.h (kept numeric here to avoid including C header in device code)
+enum { DRIFT_ZERO = 0, DRIFT_DENSE = 1, DRIFT_DIAG = 2, DRIFT_DWELL = 3 };
+enum { SIGMA_IDENT = 0, SIGMA_DENSE = 1, SIGMA_SCALE = 2 };
+enum { RUN_ZERO = 0, RUN_DIAGQ = 1 };
+enum { TERM_LINEAR = 0, TERM_DIAGQ = 1, TERM_SHIFTQ = 2 };
+enum { LOSS_LOGVAR = 0, LOSS_MOMENT = 1 };
+enum { NOISE_SUPPLIED = 0, NOISE_PHILOX = 1 };
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Makes a pointer value opaque to the optimiser at this program point.  Used inside the time /
+// sample loops so that loop-invariant LDS reads (bias vectors, cost vectors) are re-issued per
+// iteration instead of being hoisted out of the loop and kept live (which spills ~160 VGPRs).
+template <class T>
+__device__ __forceinline__ const T* opaque(const T* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter = (global trajectory, step, call index, iteration)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// two Box-Muller pairs -> four N(0,1) values
+__device__ __forceinline__ f32x4 normal4(const uint32_t (&r)[4]) {
+    const float s24 = 1.0f / 16777216.0f;
+    const float u0 = ((float)(r[0] >> 8) + 0.5f) * s24;
+    const float u1 = ((float)(r[1] >> 8) + 0.5f) * s24;
+    const float u2 = ((float)(r[2] >> 8) + 0.5f) * s24;
+    const float u3 = ((float)(r[3] >> 8) + 0.5f) * s24;
+    // -2 ln u = -2 ln2 * log2 u ; sin/cos hardware ops take revolutions
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    f32x4 z;
+    z[0] = ra * __builtin_amdgcn_cosf(u1);
+    z[1] = ra * __builtin_amdgcn_sinf(u1);
+    z[2] = rb * __builtin_amdgcn_cosf(u3);
+    z[3] = rb * __builtin_amdgcn_sinf(u3);
+    return z;
+}
+
+// Noise for block b of the T layout: lane (j,q) gets features 16b+4r+q, r=0..3, from ONE
+// Philox call with index 4b+q.  (k, n, idx, iter) -> the same values in fwd, bwd and fill.
+__device__ __forceinline__ f32x4 philox_block(uint32_t kglob, uint32_t step, uint32_t idx, uint32_t iter,
+                                              uint32_t seed_lo, uint32_t seed_hi) {
+    uint32_t r[4];
+    philox4x32_10(kglob, step, idx, iter, seed_lo, seed_hi, r);
+    return normal4(r);
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS staging of pre-permuted A operands and per-feature vectors
+// ---------------------------------------------------------------------------------------
+// dst[(mb*KS + ks)*64 + lane], lane = i + 16 q  <-  src(row = 16 mb + rowmap(i), col = 4 ks + q)
+template <class F>
+__device__ __forceinline__ void stage_aop(float* dst, int MB, int KS, int tid, int nthr, F src) {
+    const int total = MB * KS * 64;
+    for (int idx = tid; idx < total; idx += nthr) {
+        const int lane = idx & 63, t = idx >> 6;
+        const int ks = t % KS, mb = t / KS;
+        const int i = lane & 15, q = lane >> 4;
+        dst[idx] = src(16 * mb + 4 * (i & 3) + (i >> 2), 4 * ks + q);
+    }
+}
+// dst[(b*4 + q)*4 + r] <- v(16 b + 4 r + q)   (one f32x4 per lane-q and block)
+template <class F>
+__device__ __forceinline__ void stage_vec(float* dst, int NBLK, int tid, int nthr, F v) {
+    for (int idx = tid; idx < NBLK * 16; idx += nthr) {
+        const int r = idx & 3, q = (idx >> 2) & 3, b = idx >> 4;
+        dst[idx] = v(16 * b + 4 * r + q);
+    }
+}
+
+// out^T (MB blocks) += W (A operand table in LDS) . in^T (KS k-steps held in registers)
+//
+// Software-pipelined by hand: the A operands of chunk c+1 (CH k-steps x MB blocks) are fetched
+// while the MFMAs of chunk c issue, and a scheduling fence after every chunk stops hipcc from
+// hoisting the remaining ds_reads of the GEMM (up to MB*KS registers) to the top.  The fence
+// mask lets VALU / SALU / VMEM cross (tanh, Philox, address math fill the MFMA shadows) but not
+// DS reads or MFMAs.  Prefetch distance = CH*MB MFMAs x 32 cycles >= one LDS round trip.
+constexpr int kFenceMask = 0x1 | 0x2 | 0x4 | 0x10 | 0x20 | 0x40;
+template <int MB, int KS, int INB>
+__device__ __forceinline__ void gemm_T(f32x4 (&acc)[MB], const float* __restrict__ wlds,
+                                       const f32x4 (&in)[INB], int lane) {
+    static_assert(INB * 4 >= KS, "input panel too small");
+    constexpr int CH = (MB >= 4) ? 2 : 4;
+    constexpr int NCH = cdiv(KS, CH);
+    float buf[2][CH * MB];
+#pragma unroll
+    for (int kk = 0; kk < CH; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            if (kk < KS) buf[0][kk * MB + mb] = wlds[(mb * KS + kk) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int kk = 0; kk < CH; ++kk)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int ks = (c + 1) * CH + kk;
+                    if (ks < KS) buf[(c + 1) & 1][kk * MB + mb] = wlds[(mb * KS + ks) * 64 + lane];
+                }
+        }
+#pragma unroll
+        for (int kk = 0; kk < CH; ++kk) {
+            const int ks = c * CH + kk;
+            if (ks < KS) {
+                const float bop = in[ks >> 2][ks & 3];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma16(buf[c & 1][kk * MB + mb], bop, acc[mb]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(kFenceMask);
+    }
+}
+
+__device__ __forceinline__ float qsum(float v) {  // sum over the 4 q-lanes of a trajectory
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ double jsum(double v) {  // sum over the 16 trajectories of a wave (q fixed)
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+// Branch-free fp32 tanh (ocml tanhf is a two-way divergent branch per call).
+//   |x| <  0.35 : odd Taylor series to x^11 (truncation < 5e-9 relative)
+//   |x| >= 0.35 : 1 - 2 / (exp(2|x|) + 1), exp via v_exp_f32, 1/x via v_rcp_f32 (~1 ulp each)
+// Max error vs fp64 tanh ~3e-7 relative (tests/test_gpu_kernels.py checks it on the device).
+__device__ __forceinline__ float tanh_f32(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    float p = -1382.0f / 155925.0f;
+    p = fmaf(p, x2, 62.0f / 2835.0f);
+    p = fmaf(p, x2, -17.0f / 315.0f);
+    p = fmaf(p, x2, 2.0f / 15.0f);
+    p = fmaf(p, x2, -1.0f / 3.0f);
+    const float small = fmaf(x * x2, p, x);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);        // exp(2|x|)
+    const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);    // saturates to 1 for large |x|
+    return ax < 0.35f ? small : copysignf(big, x);
+}
+__device__ __forceinline__ f32x4 tanh4(f32x4 v) {
+    f32x4 o;
+    o[0] = tanh_f32(v[0]); o[1] = tanh_f32(v[1]); o[2] = tanh_f32(v[2]); o[3] = tanh_f32(v[3]);
+    return o;
+}
+
+// Geometry of one (D, H) instantiation
+template <int D, int H>
+struct Geo {
+    static constexpr int DB = cdiv(D, 16), HB = cdiv(H, 16);
+    static constexpr int KSD = cdiv(D, 4), KSH = cdiv(H, 4);
+    // torch flat parameter offsets
+    static constexpr int oW1 = 0, ob1 = H * (D + 1), oW2 = ob1 + H, ob2 = oW2 + H * H, oW3 = ob2 + H,
+                         ob3 = oW3 + D * H, P = ob3 + D;
+    // forward LDS carve (floats)
+    static constexpr int fW1 = 0, fW2 = fW1 + HB * KSD * 64, fW3 = fW2 + HB * KSH * 64,
+                         fVec = fW3 + DB * KSH * 64;
+    // vectors: b1, w1t, b2 (HB*16 each), b3, driftv, runv, termv (DB*16 each)
+    static constexpr int vb1 = fVec, vw1t = vb1 + HB * 16, vb2 = vw1t + HB * 16, vb3 = vb2 + HB * 16,
+                         vdr = vb3 + DB * 16, vrun = vdr + DB * 16, vterm = vrun + DB * 16,
+                         fRed = vterm + DB * 16;           // 2 doubles per wave, 16 waves max
+    static constexpr int fA = fRed + 64;
+    static constexpr int fB_dense_off = DB * KSD * 64;      // size of one dense d x d table
+    static int fwd_lds_floats(int drift_kind, int sigma_kind) {
+        return fA + (drift_kind == DRIFT_DENSE ? fB_dense_off : 0) + (sigma_kind == SIGMA_DENSE ? fB_dense_off : 0);
+    }
+    // backward LDS carve (floats)
+    static constexpr int gW1 = 0, gW2 = gW1 + HB * KSD * 64, gW2T = gW2 + HB * KSH * 64,
+                         gW3T = gW2T + HB * KSH * 64, gVec = gW3T + HB * KSD * 64;
+    static constexpr int gb1 = gVec, gw1t = gb1 + HB * 16, gb2 = gw1t + HB * 16, gb3 = gb2 + HB * 16,
+                         gScr = gb3 + DB * 16;
+    static constexpr int SCR_HALF = (DB > HB ? DB : HB);    // tiles per operand side
+    static constexpr int SCR_TILES = 2 * SCR_HALF;          // per-wave transposition scratch (1 KiB tiles)
+    static constexpr int gW3 = gScr + 4 * SCR_TILES * 256;  // only when !adaptive
+    // register-native accumulator image used for the cross-wave reduction
+    static constexpr int NT3 = DB * HB, NT2 = HB * HB, NT1 = HB * DB;
+    static constexpr int ACC_FLOATS = (NT3 + NT2 + NT1) * 256 + (DB + 3 * HB) * 16;
+    static int bwd_lds_floats(int adaptive) {
+        int a = gW3 + (adaptive ? 0 : DB * KSH * 64);
+        return a > ACC_FLOATS ? a : ACC_FLOATS;
+    }
+};
+
+// =======================================================================================
+// Forward rollout kernel: Euler-Maruyama + control MLP + running cost, all N steps.
+// Reference: solver.py:440-478 (step), :364-382 (init), :167-168 (D = Y - g).
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    const int j = lane & 15, q = lane >> 4;
+
+    // ---- stage weights (once per workgroup; parameters are constant during an iteration)
+    const float* __restrict__ P = a.params;
+    stage_aop(lds + G::fW1, HB, KSD, tid, nthr, [&](int row, int col) {
+        return (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f; });
+    stage_aop(lds + G::fW2, HB, KSH, tid, nthr, [&](int row, int col) {
+        return (row < H && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
+    stage_aop(lds + G::fW3, DB, KSH, tid, nthr, [&](int row, int col) {
+        return (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f; });
+    float* ldsA = lds + G::fA;
+    float* ldsB = ldsA + (a.drift_kind == DRIFT_DENSE ? G::fB_dense_off : 0);
+    if (a.drift_kind == DRIFT_DENSE) {
+        const float dt = a.dt;
+        const float* __restrict__ A = a.drift;
+        stage_aop(ldsA, DB, KSD, tid, nthr, [&](int row, int col) {
+            return (row < D && col < D) ? dt * A[row * D + col] : 0.f; });
+    }
+    if (a.sigma_kind == SIGMA_DENSE) {
+        const float* __restrict__ B = a.sigma;
+        stage_aop(ldsB, DB, KSD, tid, nthr, [&](int row, int col) {
+            return (row < D && col < D) ? B[row * D + col] : 0.f; });
+    }
+    stage_vec(lds + G::vb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
+    stage_vec(lds + G::vw1t, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW1 + f * (D + 1)] : 0.f; });
+    stage_vec(lds + G::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
+    stage_vec(lds + G::vb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
+    stage_vec(lds + G::vdr, DB, tid, nthr, [&](int f) {
+        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+    stage_vec(lds + G::vrun, DB, tid, nthr, [&](int f) {
+        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+    stage_vec(lds + G::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
+    __syncthreads();
+
+    const int t16 = blockIdx.x * nwave + wave;        // 16-trajectory tile owned by this wave
+    const bool wave_valid = t16 < a.ntile16;
+    const int k = t16 * 16 + j;                        // local trajectory of this lane
+    const bool kvalid = wave_valid && k < a.K_local;
+    const uint32_t kglob = (uint32_t)(a.k_offset + k);
+    const float dt = a.dt, sqdt = a.sqdt;
+
+    double sD = 0.0, sD2 = 0.0;
+    if (wave_valid) {
+        // per-lane-q views of the staged vectors
+        const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::fVec) + q;   // index by block*4
+        const f32x4* vterm = vecs0 + (G::vterm - G::fVec) / 4;
+
+        // ---- X_0 (solver.py:365-367) in T layout
+        f32x4 X[DB];
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * b + 4 * r + q;
+                const float v = a.x0[(size_t)(kvalid ? k : 0) * a.x0_stride + (f < D ? f : D - 1)];
+                X[b][r] = (f < D && kvalid) ? v : 0.f;
+            }
+        }
+        float Y = a.y0 ? a.y0[0] : 0.f;               // solver.py:368 / :373
+
+        for (int n = 0; n < a.N; ++n) {
+            const float tn = (float)n * dt;            // solver.py:355: ones * n * delta_t
+            const f32x4* vecs = opaque(vecs0);         // re-read the small vectors each step (no hoisting)
+            const f32x4* vb1 = vecs + (G::vb1 - G::fVec) / 4;
+            const f32x4* vw1t = vecs + (G::vw1t - G::fVec) / 4;
+            const f32x4* vb2 = vecs + (G::vb2 - G::fVec) / 4;
+            const f32x4* vb3 = vecs + (G::vb3 - G::fVec) / 4;
+            const f32x4* vdr = vecs + (G::vdr - G::fVec) / 4;
+            const f32x4* vrun = vecs + (G::vrun - G::fVec) / 4;
+            if (a.store_path) {
+                float* dst = a.path + ((size_t)n * a.ntile16 + t16) * (size_t)(KSD * 64) + lane;
+#pragma unroll
+                for (int ks = 0; ks < KSD; ++ks) dst[ks * 64] = X[ks >> 2][ks & 3];
+            }
+            // ---- control net: Z = W3 tanh(W2 tanh(W1 [t,x] + b1) + b2) + b3 (function_space.py:190-195)
+            f32x4 h1[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
+            gemm_T<HB, KSD, DB>(h1, lds + G::fW1, X, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h1[m] = tanh4(h1[m]);
+            f32x4 h2[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
+            gemm_T<HB, KSH, HB>(h2, lds + G::fW2, h1, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
+            f32x4 Z[DB];
+#pragma unroll
+            for (int m = 0; m < DB; ++m) Z[m] = vb3[m * 4];
+            gemm_T<DB, KSH, HB>(Z, lds + G::fW3, h2, lane);
+
+            // ---- Brownian increment xi_{n+1} and the two row sums |Z|^2, Z.xi (solver.py:477-478)
+            float S = 0.f, Pz = 0.f;
+#pragma unroll
+            for (int b = 0; b < DB; ++b) {
+                f32x4 xi;
+                if (a.noise_mode == NOISE_PHILOX) {
+                    xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
+                } else {
+                    // unconditional clamped loads + select: no per-element branch around the load
+                    const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 16 * b + 4 * r + q;
+                        const float v = xrow[f < D ? f : D - 1];
+                        xi[r] = (f < D && kvalid) ? v : 0.f;
+                    }
+                }
+                if (16 * b + 16 > D) {                 // partial last block: keep padded features at zero
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    S = fmaf(Z[b][r], Z[b][r], S);
+                    Pz = fmaf(Z[b][r], xi[r], Pz);
+                }
+                // v = c dt + xi sqrt(dt), c = -Z (adaptive) or 0  (solver.py:451-456,471-472)
+                Z[b] = a.adaptive ? (sqdt * xi - dt * Z[b]) : (sqdt * xi);
+            }
+            S = qsum(S);
+            Pz = qsum(Pz);
+
+            // ---- X_{n+1} = X + b(X) dt + sigma v      (solver.py:471-472)
+            f32x4 Tn[DB];
+#pragma unroll
+            for (int b = 0; b < DB; ++b) Tn[b] = X[b];
+            if (a.drift_kind == DRIFT_DENSE) {
+                gemm_T<DB, KSD, DB>(Tn, ldsA, X, lane);          // + (dt A) X
+            } else if (a.drift_kind == DRIFT_DIAG) {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) Tn[b] += dt * (vdr[b * 4] * X[b]);
+            } else if (a.drift_kind == DRIFT_DWELL) {            // b = -4 kappa x (x^2 - 1), problems.py:311-315
+#pragma unroll
+                for (int b = 0; b < DB; ++b) Tn[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
+            }
+            if (a.sigma_kind == SIGMA_DENSE) {
+                gemm_T<DB, KSD, DB>(Tn, ldsB, Z, lane);          // + B v
+            } else if (a.sigma_kind == SIGMA_SCALE) {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) Tn[b] += a.sigma_scale * Z[b];
+            } else {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) Tn[b] += Z[b];
+            }
+#pragma unroll
+            for (int b = 0; b < DB; ++b) X[b] = Tn[b];
+
+            // ---- running cost f(X_{n+1}) (h sees the UPDATED state, solver.py:477) and Y update
+            float fX = 0.f;
+            if (a.runcost_kind == RUN_DIAGQ) {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    const f32x4 pv = vrun[b * 4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fX = fmaf(pv[r] * X[b][r], X[b][r], fX);
+                }
+                fX = qsum(fX);
+            }
+            // Y += (-h + Z.c) dt + Z.xi sqrt(dt);  -h = 0.5|Z|^2 + f ; Z.c = -|Z|^2 (adaptive) or 0
+            const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
+            Y = Y + drift_y * dt + Pz * sqdt;
+        }
+
+        // ---- terminal cost g(X_N) and D = Y - g  (problems.py:49,164,334; solver.py:167-168)
+        float g = 0.f;
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            const f32x4 tv = vterm[b * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = X[b][r];
+                if (a.term_kind == TERM_LINEAR) g = fmaf(tv[r], x, g);
+                else if (a.term_kind == TERM_DIAGQ) g = fmaf(tv[r] * x, x, g);
+                else g = fmaf(tv[r] * (x - 1.0f), (x - 1.0f), g);
+            }
+        }
+        g = qsum(g);
+        const float Dk = Y - g;
+        if (kvalid && q == 0) a.D[k] = Dk;
+        if (a.XN && kvalid) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * b + 4 * r + q;
+                    if (f < D) a.XN[(size_t)k * D + f] = X[b][r];
+                }
+        }
+        if (kvalid && q == 0) { sD = (double)Dk; sD2 = (double)Dk * (double)Dk; }
+    }
+    // ---- per-workgroup partial (sum D, sum D^2) in fp64, fixed order
+    sD = jsum(sD); sD2 = jsum(sD2);
+    double* red = reinterpret_cast<double*>(lds + G::fRed);
+    if (lane == 0) { red[2 * wave] = sD; red[2 * wave + 1] = sD2; }
+    __syncthreads();
+    if (tid == 0) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int w = 0; w < nwave; ++w) { t0 += red[2 * w]; t1 += red[2 * w + 1]; }
+        a.fwd_partial[2 * blockIdx.x] = t0;
+        a.fwd_partial[2 * blockIdx.x + 1] = t1;
+    }
+}
+
+// =======================================================================================
+// Backward kernel: analytic gradient of the loss w.r.t. the control-net parameters.
+// With detach_forward=True the state path carries no gradient (solver.py:468-472), so
+//   dL/dZ_n[k,:] = w_k ((Z_n + c) dt + xi_{n+1} sqrt(dt)),  (Z + c = 0 when adaptive)
+// and the parameter gradient is one batched MLP backward over all (n, k) samples.
+// Hidden activations are recomputed from the stored X_n (no activation store).
+// Weight gradients: each wave transposes its 16-sample panels through a private LDS tile
+// into "feature-on-lane" form and contracts over samples with MFMA into persistent
+// register accumulators; waves are summed through LDS, workgroups through grad_partial.
+// =======================================================================================
+__device__ __forceinline__ void tile_put(float* tile, f32x4 v, int lane) {
+    tile[lane] = v[0]; tile[64 + lane] = v[1]; tile[128 + lane] = v[2]; tile[192 + lane] = v[3];
+}
+__device__ __forceinline__ f32x4 tile_get(const float* tile, int lane) {
+    return *reinterpret_cast<const f32x4*>(tile + (lane & 15) * 16 + 4 * (lane >> 4));
+}
+
+// acc[ob][ib] += sum_samples A_F[ob] (feature o, sample) * B_F[ib] (feature i, sample);  bsum[ob] += sum_s A
+template <int OB, int IB>
+__device__ __forceinline__ void wgrad(f32x4 (&acc)[OB][IB], float (&bsum)[OB], const float* tilesA,
+                                      const float* tilesB, int lane) {
+    f32x4 av[OB], bv[IB];
+#pragma unroll
+    for (int o = 0; o < OB; ++o) av[o] = tile_get(tilesA + o * 256, lane);
+#pragma unroll
+    for (int i = 0; i < IB; ++i) bv[i] = tile_get(tilesB + i * 256, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int o = 0; o < OB; ++o)
+#pragma unroll
+            for (int i = 0; i < IB; ++i) acc[o][i] = mfma16(av[o][r], bv[i][r], acc[o][i]);
+#pragma unroll
+    for (int o = 0; o < OB; ++o) bsum[o] += (av[o][0] + av[o][1]) + (av[o][2] + av[o][3]);
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(256) void hjb_bwd_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const float* __restrict__ P = a.params;
+
+    stage_aop(lds + G::gW1, HB, KSD, tid, nthr, [&](int row, int col) {
+        return (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f; });
+    stage_aop(lds + G::gW2, HB, KSH, tid, nthr, [&](int row, int col) {
+        return (row < H && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
+    // transposed tables for the data-gradient GEMMs: da1 = W2^T dz2, da2 = W3^T G
+    stage_aop(lds + G::gW2T, HB, KSH, tid, nthr, [&](int row, int col) {
+        return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
+    stage_aop(lds + G::gW3T, HB, KSD, tid, nthr, [&](int row, int col) {
+        return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+    if (!a.adaptive)
+        stage_aop(lds + G::gW3, DB, KSH, tid, nthr, [&](int row, int col) {
+            return (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f; });
+    stage_vec(lds + G::gb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
+    stage_vec(lds + G::gw1t, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW1 + f * (D + 1)] : 0.f; });
+    stage_vec(lds + G::gb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
+    stage_vec(lds + G::gb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
+    __syncthreads();
+
+    const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::gVec) + q;
+    float* scr = lds + G::gScr + wave * (G::SCR_TILES * 256);   // two sides of SCR_HALF tiles each
+    float* scrA = scr;
+    float* scrB = scr + G::SCR_HALF * 256;
+
+    // persistent accumulators (register-resident for the whole kernel)
+    f32x4 acc3[DB][HB], acc2[HB][HB], acc1[HB][DB];
+    float bs3[DB], bs2[HB], bs1[HB], bt1[HB];
+#pragma unroll
+    for (int o = 0; o < DB; ++o) { bs3[o] = 0.f;
+#pragma unroll
+        for (int i = 0; i < HB; ++i) acc3[o][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int o = 0; o < HB; ++o) { bs2[o] = 0.f; bs1[o] = 0.f; bt1[o] = 0.f;
+#pragma unroll
+        for (int i = 0; i < HB; ++i) acc2[o][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < DB; ++i) acc1[o][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const double invK = 1.0 / (double)a.K_global;
+    const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
+    const float coef = (float)(2.0 * invK);
+    const float dt = a.dt, sqdt = a.sqdt;
+
+    const long long nblk = (long long)a.N * a.ntile16;
+    const long long wstride = (long long)gridDim.x * nwave;
+    for (long long blk = (long long)blockIdx.x * nwave + wave; blk < nblk; blk += wstride) {
+        const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
+        const int k = t16 * 16 + j;
+        const bool kvalid = k < a.K_local;
+        const uint32_t kglob = (uint32_t)(a.k_offset + k);
+        const float tn = (float)n * dt;
+        const f32x4* vecs = opaque(vecs0);
+        const f32x4* vb1 = vecs + (G::gb1 - G::gVec) / 4;
+        const f32x4* vw1t = vecs + (G::gw1t - G::gVec) / 4;
+        const f32x4* vb2 = vecs + (G::gb2 - G::gVec) / 4;
+        const f32x4* vb3 = vecs + (G::gb3 - G::gVec) / 4;
+
+        // ---- reload X_n (T layout, lane-linear) and recompute hidden activations
+        f32x4 X[DB];
+        {
+            const float* src = a.path + (size_t)blk * (size_t)(KSD * 64) + lane;
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[b][r] = (4 * b + r < KSD) ? src[(4 * b + r) * 64] : 0.f;
+        }
+        f32x4 h1[HB], h2[HB];
+#pragma unroll
+        for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
+        gemm_T<HB, KSD, DB>(h1, lds + G::gW1, X, lane);
+#pragma unroll
+        for (int m = 0; m < HB; ++m) h1[m] = tanh4(h1[m]);
+#pragma unroll
+        for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
+        gemm_T<HB, KSH, HB>(h2, lds + G::gW2, h1, lane);
+#pragma unroll
+        for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
+
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- upstream gradient G = w_k ((Z + c) dt + xi sqrt(dt))   (T layout)
+        const float wk = kvalid ? coef * (a.D[k] - meanD) : 0.f;
+        f32x4 Gt[DB];
+#pragma unroll
+        for (int m = 0; m < DB; ++m) Gt[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!a.adaptive) {                                       // c = 0: the Z dt term survives
+#pragma unroll
+            for (int m = 0; m < DB; ++m) Gt[m] = vb3[m * 4];
+            gemm_T<DB, KSH, HB>(Gt, lds + G::gW3, h2, lane);     // Z
+        }
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            f32x4 xi;
+            if (a.noise_mode == NOISE_PHILOX) {
+                xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
+            } else {
+                const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * b + 4 * r + q;
+                    const float v = xrow[f < D ? f : D - 1];
+                    xi[r] = (f < D && kvalid) ? v : 0.f;
+                }
+            }
+            if (16 * b + 16 > D) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
+            }
+            Gt[b] = wk * (dt * Gt[b] + sqdt * xi);
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- layer 3: da2 = W3^T G ; dW3 += G^T h2 ; db3 += sum G
+        f32x4 dz2[HB];
+#pragma unroll
+        for (int m = 0; m < HB; ++m) dz2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gemm_T<HB, KSD, DB>(dz2, lds + G::gW3T, Gt, lane);
+#pragma unroll
+        for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+#pragma unroll
+        for (int b = 0; b < DB; ++b) tile_put(scrA + b * 256, Gt[b], lane);
+#pragma unroll
+        for (int m = 0; m < HB; ++m) tile_put(scrB + m * 256, h2[m], lane);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        wgrad<DB, HB>(acc3, bs3, scrA, scrB, lane);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- layer 2: da1 = W2^T dz2 ; dW2 += dz2^T h1 ; db2 += sum dz2
+        f32x4 dz1[HB];
+#pragma unroll
+        for (int m = 0; m < HB; ++m) dz1[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gemm_T<HB, KSH, HB>(dz1, lds + G::gW2T, dz2, lane);
+#pragma unroll
+        for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
+#pragma unroll
+        for (int m = 0; m < HB; ++m) tile_put(scrA + m * 256, dz2[m], lane);
+#pragma unroll
+        for (int m = 0; m < HB; ++m) tile_put(scrB + m * 256, h1[m], lane);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        wgrad<HB, HB>(acc2, bs2, scrA, scrB, lane);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- layer 1: dW1[:,1:] += dz1^T X ; db1 += sum dz1 ; dW1[:,0] += t_n sum dz1
+        {   // X_n is re-read (L2-hot) rather than held in 4*DB registers across the whole block
+            const float* src = opaque(a.path + (size_t)blk * (size_t)(KSD * 64) + lane);
+#pragma unroll
+            for (int ks = 0; ks < 4 * DB; ++ks)
+                scrA[ks * 64 + lane] = (ks < KSD) ? src[ks * 64] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < HB; ++m) tile_put(scrB + m * 256, dz1[m], lane);
+        __builtin_amdgcn_wave_barrier();
+        float bsl[HB];
+#pragma unroll
+        for (int m = 0; m < HB; ++m) bsl[m] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        wgrad<HB, DB>(acc1, bsl, scrB, scrA, lane);
+#pragma unroll
+        for (int m = 0; m < HB; ++m) { bs1[m] += bsl[m]; bt1[m] = fmaf(tn, bsl[m], bt1[m]); }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- cross-wave reduction through LDS in register-native order (deterministic), then
+    //      scatter into the torch flat layout of this workgroup's partial gradient
+    __syncthreads();                                   // weights / scratch no longer needed
+    float* img = lds;                                  // ACC_FLOATS
+    float* img3 = img, *img2 = img3 + G::NT3 * 256, *img1 = img2 + G::NT2 * 256;
+    float* imgb = img1 + G::NT1 * 256;                 // bs3 (DB*16) bs2 bs1 bt1 (HB*16 each)
+#pragma unroll
+    for (int o = 0; o < DB; ++o) bs3[o] = qsum(bs3[o]);
+#pragma unroll
+    for (int o = 0; o < HB; ++o) { bs2[o] = qsum(bs2[o]); bs1[o] = qsum(bs1[o]); bt1[o] = qsum(bt1[o]); }
+    for (int w = 0; w < nwave; ++w) {
+        if (wave == w) {
+            const bool first = (w == 0);
+#pragma unroll
+            for (int o = 0; o < DB; ++o)
+#pragma unroll
+                for (int i = 0; i < HB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* p = img3 + ((o * HB + i) * 4 + r) * 64 + lane;
+                        *p = first ? acc3[o][i][r] : (*p + acc3[o][i][r]);
+                    }
+#pragma unroll
+            for (int o = 0; o < HB; ++o)
+#pragma unroll
+                for (int i = 0; i < HB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* p = img2 + ((o * HB + i) * 4 + r) * 64 + lane;
+                        *p = first ? acc2[o][i][r] : (*p + acc2[o][i][r]);
+                    }
+#pragma unroll
+            for (int o = 0; o < HB; ++o)
+#pragma unroll
+                for (int i = 0; i < DB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* p = img1 + ((o * DB + i) * 4 + r) * 64 + lane;
+                        *p = first ? acc1[o][i][r] : (*p + acc1[o][i][r]);
+                    }
+            if (q == 0) {
+#pragma unroll
+                for (int o = 0; o < DB; ++o) {
+                    float* p = imgb + o * 16 + j; *p = first ? bs3[o] : (*p + bs3[o]);
+                }
+#pragma unroll
+                for (int o = 0; o < HB; ++o) {
+                    float* p2 = imgb + DB * 16 + o * 16 + j; *p2 = first ? bs2[o] : (*p2 + bs2[o]);
+                    float* p1 = imgb + (DB + HB) * 16 + o * 16 + j; *p1 = first ? bs1[o] : (*p1 + bs1[o]);
+                    float* pt = imgb + (DB + 2 * HB) * 16 + o * 16 + j; *pt = first ? bt1[o] : (*pt + bt1[o]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D tile (ob, ib): lane (col = l&15, qq = l>>4), reg rr  <->  dW[16 ob + 4 qq + rr][16 ib + col]
+    float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
+    for (int idx = tid; idx < G::NT3 * 256; idx += nthr) {
+        const int l = idx & 63, rr = (idx >> 6) & 3, t = idx >> 8, ib = t % HB, ob = t / HB;
+        const int o = 16 * ob + 4 * (l >> 4) + rr, i = 16 * ib + (l & 15);
+        if (o < D && i < H) gp[G::oW3 + o * H + i] = img3[idx];
+    }
+    for (int idx = tid; idx < G::NT2 * 256; idx += nthr) {
+        const int l = idx & 63, rr = (idx >> 6) & 3, t = idx >> 8, ib = t % HB, ob = t / HB;
+        const int o = 16 * ob + 4 * (l >> 4) + rr, i = 16 * ib + (l & 15);
+        if (o < H && i < H) gp[G::oW2 + o * H + i] = img2[idx];
+    }
+    for (int idx = tid; idx < G::NT1 * 256; idx += nthr) {
+        const int l = idx & 63, rr = (idx >> 6) & 3, t = idx >> 8, ib = t % DB, ob = t / DB;
+        const int o = 16 * ob + 4 * (l >> 4) + rr, i = 16 * ib + (l & 15);
+        if (o < H && i < D) gp[G::oW1 + o * (D + 1) + 1 + i] = img1[idx];
+    }
+    for (int f = tid; f < D; f += nthr) gp[G::ob3 + f] = imgb[f];
+    for (int f = tid; f < H; f += nthr) {
+        gp[G::ob2 + f] = imgb[DB * 16 + f];
+        gp[G::ob1 + f] = imgb[(DB + HB) * 16 + f];
+        gp[G::oW1 + f * (D + 1)] = imgb[(DB + 2 * HB) * 16 + f];
+    }
+}
+
+// host-side launch table entry
+struct HjbInstance {
+    int d, H, n_params;
+    int (*fwd_lds_bytes)(int drift_kind, int sigma_kind);
+    int (*bwd_lds_bytes)(int adaptive);
+    hipError_t (*launch_fwd)(const HjbArgs&, int grid, int block, hipStream_t);
+    hipError_t (*launch_bwd)(const HjbArgs&, int grid, int block, hipStream_t);
+    int path_floats_per_tile_step;   // KSD * 64
+};
+
+template <int D, int H>
+struct HjbLaunch {
+    using G = Geo<D, H>;
+    static int fwd_lds(int dk, int sk) { return G::fwd_lds_floats(dk, sk) * 4; }
+    static int bwd_lds(int ad) { return G::bwd_lds_floats(ad) * 4; }
+    static hipError_t fwd(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        const int bytes = fwd_lds(a.drift_kind, a.sigma_kind);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_fwd_kernel<D, H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjb_fwd_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
+        return hipGetLastError();
+    }
+    static hipError_t bwd(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        const int bytes = bwd_lds(a.adaptive);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_bwd_kernel<D, H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjb_bwd_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
+        return hipGetLastError();
+    }
+    static HjbInstance instance() {
+        return HjbInstance{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::KSD * 64};
+    }
+};
+
+}  // namespace psp
+
+#define PSP_DEFINE_INSTANCE(D_, H_) \
+    extern "C" psp::HjbInstance psp_instance_##D_##_##H_() { return psp::HjbLaunch<D_, H_>::instance(); }
+#define PSP_DECLARE_INSTANCE(D_, H_) extern "C" psp::HjbInstance psp_instance_##D_##_##H_();

@@ -1,0 +1,323 @@
+// psp_api.hip -- C ABI of libpsp_hip.so (see include/psp.h) + the small streaming kernels.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/psp.h"
+#include "hjb_kernels.h"
+
+#define X(D_, H_) PSP_DECLARE_INSTANCE(D_, H_)
+#include "instances.def"
+#undef X
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+int fail_hip(hipError_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return -10;
+}
+
+typedef psp::HjbInstance (*InstanceFn)();
+struct Entry { int d, H; InstanceFn fn; };
+const Entry kTable[] = {
+#define X(D_, H_) {D_, H_, &psp_instance_##D_##_##H_},
+#include "instances.def"
+#undef X
+};
+
+bool find_instance(int d, int H, psp::HjbInstance* out) {
+    for (const Entry& e : kTable)
+        if (e.d == d && e.H == H) { *out = e.fn(); return true; }
+    return false;
+}
+
+constexpr int kMaxLds = 160 * 1024;
+
+struct Plan {
+    psp::HjbInstance inst;
+    int ntile16, fwd_waves, fwd_grid, bwd_waves, bwd_grid;
+};
+
+int n_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;     // MI355X; also used when no device is visible (size queries on CPU)
+    }
+    return cus;
+}
+
+int make_plan(const psp_hjb_config* c, Plan* p) {
+    if (!c) return fail(-1, "null config");
+    if (c->d <= 0 || c->H <= 0 || c->K_local <= 0 || c->N <= 0) return fail(-1, "non-positive d/H/K/N");
+    if (!find_instance(c->d, c->H, &p->inst)) {
+        snprintf(g_err, sizeof(g_err), "no compiled HJB kernel instance for d=%d H=%d", c->d, c->H);
+        return -2;
+    }
+    if (c->drift_kind < 0 || c->drift_kind > 3 || c->sigma_kind < 0 || c->sigma_kind > 2 ||
+        c->runcost_kind < 0 || c->runcost_kind > 1 || c->term_kind < 0 || c->term_kind > 2 ||
+        c->loss_kind < 0 || c->loss_kind > 1 || c->noise_mode < 0 || c->noise_mode > 1)
+        return fail(-1, "config enum out of range");
+    if (p->inst.fwd_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
+        return fail(-3, "forward kernel weights do not fit the 160 KiB LDS for this (d,H,drift,sigma)");
+    if (p->inst.bwd_lds_bytes(c->adaptive) > kMaxLds)
+        return fail(-3, "backward kernel staging does not fit the 160 KiB LDS for this (d,H)");
+    p->ntile16 = (c->K_local + 15) / 16;
+    const int cus = n_cus();
+    // forward: one 16-trajectory tile per wave; 1..8 waves per workgroup so that small K still spreads over CUs
+    int fw = (p->ntile16 + cus - 1) / cus;
+    if (fw < 1) fw = 1;
+    if (fw > 8) fw = 8;
+    p->fwd_waves = fw;
+    p->fwd_grid = (p->ntile16 + fw - 1) / fw;
+    // backward: persistent, one 4-wave workgroup per CU (LDS-limited), fewer when there is little work
+    const long long nblk = (long long)c->N * p->ntile16;
+    p->bwd_waves = 4;
+    long long g = (nblk + p->bwd_waves - 1) / p->bwd_waves;
+    if (g > cus) g = cus;
+    if (g < 1) g = 1;
+    p->bwd_grid = (int)g;
+    return 0;
+}
+
+void fill_args(const psp_hjb_config* c, const Plan& p, psp::HjbArgs* a) {
+    memset(a, 0, sizeof(*a));
+    a->drift = c->drift; a->sigma = c->sigma; a->runcost = c->runcost; a->term = c->term;
+    a->k_offset = c->k_offset; a->K_global = c->K_global; a->K_local = c->K_local; a->N = c->N;
+    a->ntile16 = p.ntile16; a->dt = c->dt; a->sqdt = c->sqrt_dt; a->sigma_scale = c->sigma_scale;
+    a->drift_kind = c->drift_kind; a->sigma_kind = c->sigma_kind; a->runcost_kind = c->runcost_kind;
+    a->term_kind = c->term_kind; a->adaptive = c->adaptive; a->loss_kind = c->loss_kind;
+    a->noise_mode = c->noise_mode; a->store_path = c->store_path;
+}
+
+int check_ptrs(const psp_hjb_config* c) {
+    if ((c->drift_kind != PSP_DRIFT_ZERO) && !c->drift) return fail(-1, "drift parameters missing");
+    if (c->sigma_kind == PSP_SIGMA_DENSE && !c->sigma) return fail(-1, "sigma matrix missing");
+    if (c->runcost_kind == PSP_RUNCOST_DIAG_QUAD && !c->runcost) return fail(-1, "running-cost vector missing");
+    if (!c->term) return fail(-1, "terminal-cost vector missing");
+    return 0;
+}
+
+// ---- small kernels -------------------------------------------------------------------
+__global__ void reduce_partials_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+    // single workgroup, fixed summation order: thread t sums entries t, t+256, ... then a tree
+    __shared__ double s0[256], s1[256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { s0[threadIdx.x] += s0[threadIdx.x + w]; s1[threadIdx.x] += s1[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = s0[0]; out[1] = s1[0]; }
+}
+
+__global__ void reduce_grad_kernel(const float* __restrict__ part, int nwg, int P, float* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += part[(size_t)w * P + p];     // fixed order -> reproducible
+    out[p] = s;
+}
+
+// torch.optim.Adam single-tensor semantics (torch/optim/adam.py, _single_tensor_adam)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                            float step_size, float bc2_sqrt) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);              // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;             // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);                         // param.addcdiv_(exp_avg, denom, -step_size)
+}
+
+__global__ void philox_fill_kernel(float* __restrict__ out, int N, int K, int d, long long k_offset,
+                                   uint32_t seed_lo, uint32_t seed_hi, uint32_t iter) {
+    // one thread per Philox call: (step n, trajectory k, call idx = 4b+q) -> features 16b+4r+q
+    const int ncall = ((d + 15) / 16) * 4;
+    const long long total = (long long)N * K * ncall;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int idx = (int)(t % ncall);
+    const long long r0 = t / ncall;
+    const int k = (int)(r0 % K), n = (int)(r0 / K);
+    const psp::f32x4 z = psp::philox_block((uint32_t)(k_offset + k), (uint32_t)n, (uint32_t)idx, iter, seed_lo, seed_hi);
+    const int b = idx >> 2, q = idx & 3;
+    for (int r = 0; r < 4; ++r) {
+        const int f = 16 * b + 4 * r + q;
+        if (f < d) out[((size_t)(n + 1) * K + k) * d + f] = z[r];
+    }
+}
+
+__global__ void zero_kernel(float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 0.f;
+}
+
+// u = -Z(t, x): plain per-output kernel (evaluation only, not on the training hot path)
+__global__ void control_eval_kernel(int d, int H, const float* __restrict__ P, const float* __restrict__ X,
+                                    int K, float t, float* __restrict__ out) {
+    extern __shared__ float sm[];                 // h1[H], h2[H] for one trajectory per workgroup
+    float* h1 = sm; float* h2 = sm + H;
+    const int k = blockIdx.x;
+    const int oW1 = 0, ob1 = H * (d + 1), oW2 = ob1 + H, ob2 = oW2 + H * H, oW3 = ob2 + H, ob3 = oW3 + d * H;
+    for (int o = threadIdx.x; o < H; o += blockDim.x) {
+        float s = P[ob1 + o];
+        s = fmaf(P[oW1 + o * (d + 1)], t, s);
+        for (int i = 0; i < d; ++i) s = fmaf(P[oW1 + o * (d + 1) + 1 + i], X[(size_t)k * d + i], s);
+        h1[o] = tanhf(s);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < H; o += blockDim.x) {
+        float s = P[ob2 + o];
+        for (int i = 0; i < H; ++i) s = fmaf(P[oW2 + o * H + i], h1[i], s);
+        h2[o] = tanhf(s);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < d; o += blockDim.x) {
+        float s = P[ob3 + o];
+        for (int i = 0; i < H; ++i) s = fmaf(P[oW3 + o * H + i], h2[i], s);
+        out[(size_t)k * d + o] = -s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int psp_version(void) { return PSP_VERSION; }
+const char* psp_last_error(void) { return g_err; }
+
+int psp_hjb_supported(int32_t d, int32_t H) {
+    psp::HjbInstance inst;
+    return find_instance(d, H, &inst) ? 1 : 0;
+}
+
+int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out) {
+    Plan p;
+    int rc = make_plan(cfg, &p);
+    if (rc) return rc;
+    if (!out) return fail(-1, "null output");
+    memset(out, 0, sizeof(*out));
+    out->n_params = p.inst.n_params;
+    out->fwd_workgroups = p.fwd_grid;
+    out->bwd_workgroups = p.bwd_grid;
+    out->path_bytes = cfg->store_path
+        ? (int64_t)cfg->N * p.ntile16 * (int64_t)p.inst.path_floats_per_tile_step * 4 : 0;
+    out->fwd_partial_bytes = (int64_t)p.fwd_grid * 2 * 8;
+    out->grad_partial_bytes = (int64_t)p.bwd_grid * p.inst.n_params * 4;
+    return 0;
+}
+
+int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const float* x0, int32_t x0_stride,
+                        const float* y0, const float* xi, uint64_t seed, uint32_t iter, float* path,
+                        float* D_out, float* XN_out, double* fwd_partial, void* stream) {
+    Plan p;
+    int rc = make_plan(cfg, &p);
+    if (rc) return rc;
+    if ((rc = check_ptrs(cfg))) return rc;
+    if (!params || !x0 || !D_out || !fwd_partial) return fail(-1, "null buffer passed to psp_hjb_rollout_fwd");
+    if (x0_stride != 0 && x0_stride != cfg->d) return fail(-1, "x0_stride must be 0 or d");
+    if (cfg->noise_mode == PSP_NOISE_SUPPLIED && !xi) return fail(-1, "supplied-noise mode needs xi");
+    if (cfg->store_path && !path) return fail(-1, "store_path set but path buffer is null");
+    psp::HjbArgs a;
+    fill_args(cfg, p, &a);
+    a.params = params; a.x0 = x0; a.x0_stride = x0_stride; a.y0 = y0; a.xi = xi; a.path = path;
+    a.D = D_out; a.XN = XN_out; a.fwd_partial = fwd_partial;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
+    hipError_t e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel launch");
+    return 0;
+}
+
+int psp_hjb_terminal_reduce(const psp_hjb_config* cfg, const double* fwd_partial, double* sums_out, void* stream) {
+    Plan p;
+    int rc = make_plan(cfg, &p);
+    if (rc) return rc;
+    if (!fwd_partial || !sums_out) return fail(-1, "null buffer passed to psp_hjb_terminal_reduce");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fwd_partial,
+                       p.fwd_grid, sums_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "reduce_partials_kernel launch");
+    return 0;
+}
+
+int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const float* xi, uint64_t seed,
+                        uint32_t iter, const float* path, const float* D, const double* sums,
+                        float* grad_partial, float* grad_out, void* stream) {
+    Plan p;
+    int rc = make_plan(cfg, &p);
+    if (rc) return rc;
+    if (!params || !path || !D || !sums || !grad_partial || !grad_out)
+        return fail(-1, "null buffer passed to psp_hjb_rollout_bwd");
+    if (cfg->noise_mode == PSP_NOISE_SUPPLIED && !xi) return fail(-1, "supplied-noise mode needs xi");
+    psp::HjbArgs a;
+    fill_args(cfg, p, &a);
+    a.params = params; a.xi = xi; a.path = const_cast<float*>(path); a.D = const_cast<float*>(D);
+    a.sums = sums; a.grad_partial = grad_partial;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
+    hipError_t e = p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");
+    const int P = p.inst.n_params;
+    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       grad_partial, p.bwd_grid, P, grad_out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
+    return 0;
+}
+
+int psp_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  int32_t step, float lr, float beta1, float beta2, float eps, void* stream) {
+    if (!params || !grad || !exp_avg || !exp_avg_sq) return fail(-1, "null buffer passed to psp_adam_step");
+    if (n <= 0 || step <= 0) return fail(-1, "psp_adam_step needs n > 0 and a 1-based step");
+    // bias corrections in double on the host, as torch does for python-float steps
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params,
+                       grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, step_size, bc2_sqrt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "adam_kernel launch");
+    return 0;
+}
+
+int psp_philox_normal_fill(float* out, int32_t N, int32_t K_local, int32_t d, int64_t k_offset,
+                           uint64_t seed, uint32_t iter, void* stream) {
+    if (!out || N <= 0 || K_local <= 0 || d <= 0) return fail(-1, "bad arguments to psp_philox_normal_fill");
+    const long long n0 = (long long)K_local * d;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n0);
+    const long long total = (long long)N * K_local * (((d + 15) / 16) * 4);
+    hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       out, N, K_local, d, (long long)k_offset, (uint32_t)seed, (uint32_t)(seed >> 32), iter);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "philox_fill_kernel launch");
+    return 0;
+}
+
+int psp_hjb_control_eval(int32_t d, int32_t H, const float* params, const float* X, int32_t K, float t,
+                         float* minus_Z_out, void* stream) {
+    if (!params || !X || !minus_Z_out || d <= 0 || H <= 0 || K <= 0)
+        return fail(-1, "bad arguments to psp_hjb_control_eval");
+    hipLaunchKernelGGL(control_eval_kernel, dim3(K), dim3(64), 2 * H * sizeof(float), (hipStream_t)stream, d, H,
+                       params, X, K, t, minus_Z_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "control_eval_kernel launch");
+    return 0;
+}
+
+}  // extern "C"

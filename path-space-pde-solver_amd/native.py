@@ -1,0 +1,130 @@
+"""ctypes binding of libpsp_hip.so (C ABI in include/psp.h).
+
+The library is the product path for the HJB rollout; there is no CPU fallback behind it.
+``load()`` raises ``NativeLibraryError`` if the shared object is missing or does not export
+every symbol the header declares.  torch is imported first on purpose: libpsp_hip.so needs
+``libamdhip64.so.7`` and must bind to the HIP runtime torch already loaded, because stream
+handles and device pointers are shared between the two.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libpsp_hip.so")
+
+# enums (include/psp.h)
+DRIFT_ZERO, DRIFT_DENSE, DRIFT_DIAG, DRIFT_DOUBLE_WELL = 0, 1, 2, 3
+SIGMA_IDENTITY, SIGMA_DENSE, SIGMA_SCALED_IDENTITY = 0, 1, 2
+RUNCOST_ZERO, RUNCOST_DIAG_QUAD = 0, 1
+TERM_LINEAR, TERM_DIAG_QUAD, TERM_SHIFTED_QUAD = 0, 1, 2
+LOSS_LOG_VARIANCE, LOSS_MOMENT = 0, 1
+NOISE_SUPPLIED, NOISE_PHILOX = 0, 1
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class NativeCallError(RuntimeError):
+    pass
+
+
+class HjbConfig(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32), ("H", C.c_int32), ("K_local", C.c_int32), ("N", C.c_int32),
+        ("K_global", C.c_int64), ("k_offset", C.c_int64),
+        ("dt", C.c_float), ("sqrt_dt", C.c_float),
+        ("drift_kind", C.c_int32), ("sigma_kind", C.c_int32), ("runcost_kind", C.c_int32),
+        ("term_kind", C.c_int32), ("adaptive", C.c_int32), ("loss_kind", C.c_int32),
+        ("noise_mode", C.c_int32), ("store_path", C.c_int32),
+        ("sigma_scale", C.c_float), ("reserved", C.c_int32),
+        ("drift", C.c_void_p), ("sigma", C.c_void_p), ("runcost", C.c_void_p), ("term", C.c_void_p),
+    ]
+
+
+class HjbSizes(C.Structure):
+    _fields_ = [
+        ("path_bytes", C.c_int64), ("fwd_partial_bytes", C.c_int64), ("grad_partial_bytes", C.c_int64),
+        ("n_params", C.c_int32), ("fwd_workgroups", C.c_int32), ("bwd_workgroups", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+SIGNATURES = {
+    "psp_version": (C.c_int, []),
+    "psp_last_error": (C.c_char_p, []),
+    "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "psp_hjb_query": (C.c_int, [C.POINTER(HjbConfig), C.POINTER(HjbSizes)]),
+    "psp_hjb_rollout_fwd": (C.c_int, [C.POINTER(HjbConfig), _P, _P, C.c_int32, _P, _P, C.c_uint64, C.c_uint32,
+                                      _P, _P, _P, _P, _P]),
+    "psp_hjb_terminal_reduce": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P]),
+    "psp_hjb_rollout_bwd": (C.c_int, [C.POINTER(HjbConfig), _P, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    "psp_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "psp_philox_normal_fill": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32, _P]),
+    "psp_hjb_control_eval": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libpsp_hip.so (once) and bind every symbol of include/psp.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "%s not found: build it with `python path-space-pde-solver_amd/build.py` "
+            "(or __graft_entry__.build()). The HJB rollout has no non-HIP fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise NativeLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def is_built():
+    return os.path.exists(LIB_PATH)
+
+
+def last_error():
+    return load().psp_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NativeCallError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+def ptr(t):
+    """Raw device/host pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    if device.type != "cuda":
+        return None
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def supported(d, H):
+    return bool(load().psp_hjb_supported(int(d), int(H)))
+
+
+def query(cfg):
+    sizes = HjbSizes()
+    check(load().psp_hjb_query(C.byref(cfg), C.byref(sizes)), "psp_hjb_query")
+    return sizes

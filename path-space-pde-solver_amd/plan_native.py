@@ -1,0 +1,246 @@
+"""Native (HIP) execution plan for Solver.train on MI355X.
+
+Replaces the body of the reference's training iteration (solver.py:430-514) by five
+asynchronous launches through the C ABI of libpsp_hip.so (include/psp.h):
+
+    psp_hjb_rollout_fwd  ->  psp_hjb_terminal_reduce  -> [all-reduce (sum D, sum D^2)]
+    psp_hjb_rollout_bwd  -> [all-reduce flat gradient] -> psp_adam_step
+
+torch supplies device memory, the stream and (for world_size > 1) the RCCL all-reduces;
+no arithmetic of the hot path runs in torch.  Trajectories are sharded across ranks by
+contiguous blocks; noise is indexed by GLOBAL trajectory id so the result does not depend
+on the number of ranks.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+try:
+    from . import native as nat
+except ImportError:
+    import native as nat
+
+
+class PlanUnsupported(Exception):
+    """The (problem, net, loss, flags) combination is outside the native catalogue."""
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def native_eligibility(solver):
+    """Returns None if the solver can run natively, else a human-readable reason."""
+    if solver.device.type != 'cuda':
+        return 'device is %s (the HIP rollout needs a GPU)' % solver.device
+    if solver.approx_method != 'control' or solver.time_approx != 'inner':
+        return "only approx_method='control' with time_approx='inner' is native"
+    if solver.loss_method not in ('log-variance', 'moment'):
+        return "loss_method %r is not native (log-variance, moment)" % solver.loss_method
+    if solver.adaptive_forward_process and not solver.detach_forward:
+        return 'detach_forward=False back-propagates through the state path (not native)'
+    if solver.burgers_drift:
+        return 'burgers_drift is not native'
+    if solver.u_l2_error_flag:
+        return ('u_l2_error_flag=True evaluates problem.u_true on the host every step '
+                '(reference solver.py:491-494); pass u_l2_error_flag=False for the native plan')
+    if solver.IS_variance_K > 0 or solver.compute_gradient_variance > 0 or solver.log_gradient:
+        return 'per-iteration diagnostics (IS variance / gradient variance / gradient log) are not native'
+    if solver.metastability_logs is not None:
+        return 'metastability_logs needs X_N on the host every iteration'
+    net = solver.z_n
+    shape = getattr(net, 'native_shape', lambda: None)()
+    if shape is None or shape[0] != solver.d + 1 or shape[2] != solver.d:
+        return 'control net is not a two-hidden-layer tanh MLP (MySequential)'
+    spec_fn = getattr(solver.problem, 'native_spec', None)
+    spec = spec_fn() if spec_fn is not None else None
+    if spec is None:
+        return 'problem has no native_spec() (coefficients outside the native catalogue)'
+    if not nat.is_built():
+        raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
+    if not nat.supported(solver.d, shape[1]):
+        return 'no compiled kernel instance for d=%d, H=%d (see csrc/instances.def)' % (solver.d, shape[1])
+    return None
+
+
+class HjbNativePlan:
+    def __init__(self, solver, noise='reference'):
+        reason = native_eligibility(solver)
+        if reason is not None:
+            raise PlanUnsupported(reason)
+        self.s = solver
+        self.lib = nat.load()
+        self.noise = noise
+        dev = solver.device
+        self.dev = dev
+        self.dist, self.rank, self.world = _dist()
+        K = solver.K
+        if K % self.world != 0:
+            raise PlanUnsupported('K=%d is not divisible by world_size=%d' % (K, self.world))
+        self.K_local = K // self.world
+        self.k_offset = self.rank * self.K_local
+        net = solver.z_n
+        self.net = net
+        self.H = net.native_shape()[1]
+        self._flatten(net)
+        spec = solver.problem.native_spec()
+        self._keep = []   # device tensors referenced by raw pointer from the config
+
+        def dev_f32(t):
+            if t is None:
+                return None
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t
+
+        cfg = nat.HjbConfig()
+        cfg.d, cfg.H, cfg.K_local, cfg.N = solver.d, self.H, self.K_local, solver.N
+        cfg.K_global, cfg.k_offset = K, self.k_offset
+        cfg.dt = float(solver.delta_t.item())
+        cfg.sqrt_dt = float(solver.sq_delta_t.item())
+        cfg.drift_kind = spec['drift'][0]
+        cfg.drift = nat.ptr(dev_f32(spec['drift'][1])) if spec['drift'][1] is not None else None
+        cfg.sigma_kind = spec['sigma'][0]
+        cfg.sigma = nat.ptr(dev_f32(spec['sigma'][1])) if spec['sigma'][1] is not None else None
+        cfg.sigma_scale = float(spec['sigma'][2])
+        cfg.runcost_kind = spec['runcost'][0]
+        cfg.runcost = nat.ptr(dev_f32(spec['runcost'][1])) if spec['runcost'][1] is not None else None
+        cfg.term_kind = spec['term'][0]
+        cfg.term = nat.ptr(dev_f32(spec['term'][1]))
+        cfg.adaptive = 1 if solver.adaptive_forward_process else 0
+        cfg.loss_kind = nat.LOSS_LOG_VARIANCE if solver.loss_method == 'log-variance' else nat.LOSS_MOMENT
+        cfg.noise_mode = nat.NOISE_PHILOX if noise == 'philox' else nat.NOISE_SUPPLIED
+        cfg.store_path = 1
+        self.cfg = cfg
+        sizes = nat.query(cfg)
+        assert sizes.n_params == self.P, (sizes.n_params, self.P)
+        self.sizes = sizes
+        self.path = torch.empty(sizes.path_bytes // 4, dtype=torch.float32, device=dev)
+        self.fwd_partial = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)
+        self.grad_partial = torch.empty(sizes.grad_partial_bytes // 4, dtype=torch.float32, device=dev)
+        self.D = torch.empty(self.K_local, dtype=torch.float32, device=dev)
+        self.sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.grad = torch.empty(self.P, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(self.P, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.P, dtype=torch.float32, device=dev)
+        self.x0_vec = dev_f32(solver.X_0)
+        self.step = 0
+        self.events = None   # bench.py: list collecting HIP-event pairs around the two rollout kernels
+        # learnable Y_0 (solver.py:372-374): tiny Adam in torch on a 1-element tensor
+        self.learn_y0 = bool(solver.learn_Y_0)
+        if self.learn_y0:
+            self.y0_param = solver.y_0.Y_0
+            self.y0_m = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.y0_v = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.y0_grad = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------------------------
+    def _flatten(self, net):
+        """Re-home the net's parameters as views of one flat fp32 buffer (psp.h layout) so
+        that state_dict / save_networks / Z_n keep working on live values."""
+        params = net.flat_layout()
+        self.P = sum(p.numel() for p in params)
+        flat = torch.empty(self.P, dtype=torch.float32, device=self.dev)
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self.flat = flat
+
+    def _stream(self):
+        return nat.stream_ptr(self.dev)
+
+    def _reference_noise(self):
+        """The reference's per-iteration draws from the CPU generator (solver.py:367,381),
+        re-laid-out as (N+1, K_local, d) for coalesced per-step reads."""
+        s = self.s
+        x0 = None
+        if s.random_X_0:
+            x0 = torch.randn(s.K, s.d)
+        xi = torch.randn(s.K, s.d, s.N + 1)
+        lo, hi = self.k_offset, self.k_offset + self.K_local
+        xi_dev = xi[lo:hi].permute(2, 0, 1).contiguous().to(self.dev)
+        x0_dev = x0[lo:hi].contiguous().to(self.dev) if x0 is not None else None
+        return xi_dev, x0_dev
+
+    def iteration(self, l, loss_out):
+        """One training iteration; writes the fp32 loss into loss_out[l] (device, no sync)."""
+        s, lib, cfg = self.s, self.lib, self.cfg
+        st = self._stream()
+        seed = int(s.seed) & 0xFFFFFFFFFFFFFFFF
+        xi = x0 = None
+        if self.noise == 'reference':
+            xi, x0 = self._reference_noise()
+        elif s.random_X_0:
+            g = torch.Generator(device=self.dev)
+            g.manual_seed(int(s.seed) * 1000003 + l)
+            x0 = torch.randn(s.K, s.d, generator=g, device=self.dev)[self.k_offset:self.k_offset + self.K_local].contiguous()
+        x0_t = x0 if x0 is not None else self.x0_vec
+        x0_stride = s.d if x0 is not None else 0
+        y0_ptr = nat.ptr(self.y0_param) if self.learn_y0 else None
+        ev = None
+        if self.events is not None:      # events go on torch's current stream = the launch stream
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0_t), x0_stride, y0_ptr,
+                                          nat.ptr(xi), seed, l, nat.ptr(self.path), nat.ptr(self.D), None,
+                                          nat.ptr(self.fwd_partial), st), 'psp_hjb_rollout_fwd')
+        if ev is not None:
+            ev[1].record()
+        nat.check(lib.psp_hjb_terminal_reduce(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums), st),
+                  'psp_hjb_terminal_reduce')
+        if self.world > 1:
+            self.dist.all_reduce(self.sums)
+        K = float(s.K)
+        if s.loss_method == 'log-variance':
+            loss = self.sums[1] / K - (self.sums[0] / K) ** 2
+        else:
+            loss = self.sums[1] / K
+        loss_out[l] = loss.to(torch.float32)
+        if ev is not None:
+            ev[2].record()
+        nat.check(lib.psp_hjb_rollout_bwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(xi), seed, l, nat.ptr(self.path),
+                                          nat.ptr(self.D), nat.ptr(self.sums), nat.ptr(self.grad_partial),
+                                          nat.ptr(self.grad), st), 'psp_hjb_rollout_bwd')
+        if ev is not None:
+            ev[3].record()
+            self.events.append(ev)
+        if self.world > 1:
+            self.dist.all_reduce(self.grad)
+        self.step += 1
+        nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
+                                    self.P, self.step, float(s.lr), 0.9, 0.999, 1e-8, st), 'psp_adam_step')
+        if self.learn_y0:
+            # dL/dY_0 = sum_k w_k ; log-variance: exactly 0 ; moment: (2/K) sum D (global sums)
+            if s.loss_method == 'moment':
+                self.y0_grad[0] = (2.0 / K) * self.sums[0]
+            else:
+                self.y0_grad.zero_()
+            nat.check(lib.psp_adam_step(nat.ptr(self.y0_param), nat.ptr(self.y0_grad), nat.ptr(self.y0_m),
+                                        nat.ptr(self.y0_v), 1, self.step, float(s.lr), 0.9, 0.999, 1e-8, st),
+                      'psp_adam_step(Y_0)')
+        # keep xi alive until the kernels that read it are enqueued on this stream (they are);
+        # torch's caching allocator is stream-ordered, so freeing here is safe.
+        return loss
+
+    def forward_only(self, l, want_XN=False):
+        """Forward rollout without the path store; returns (D, X_N or None)."""
+        s, lib = self.s, self.lib
+        cfg = nat.HjbConfig.from_buffer_copy(self.cfg)
+        cfg.store_path = 0
+        xi = x0 = None
+        if self.noise == 'reference':
+            xi, x0 = self._reference_noise()
+        x0_t = x0 if x0 is not None else self.x0_vec
+        XN = torch.empty(self.K_local, s.d, dtype=torch.float32, device=self.dev) if want_XN else None
+        nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0_t), s.d if x0 is not None else 0,
+                                          nat.ptr(self.y0_param) if self.learn_y0 else None, nat.ptr(xi),
+                                          int(s.seed), l, None, nat.ptr(self.D), nat.ptr(XN),
+                                          nat.ptr(self.fwd_partial), self._stream()), 'psp_hjb_rollout_fwd')
+        return self.D, XN

@@ -1,0 +1,305 @@
+"""PDE / control problem definitions (API mirror of the hot-path part of the reference's
+problems.py).  A problem is a duck-typed object with attributes ``d, T, X_0, B, name`` and
+methods ``b(x), sigma(x), h(t, x, y, z), f(...), g(x)`` -- exactly what the reference's
+solvers call.  Differences from the reference:
+
+* the device is a constructor argument (``device=None`` -> CUDA/HIP if present, else CPU)
+  instead of the module global ``device = pt.device('cuda')`` (reference problems.py:11);
+* ``native_spec()`` describes the coefficient functions as a closed catalogue entry
+  (dense / diagonal / double-well drift, dense / identity sigma, diagonal quadratic costs)
+  so that Solver can run the hand-written HIP rollout.  Objects without ``native_spec``
+  (any user-supplied problem) run through the composite torch plan.
+
+Random matrices are drawn from the torch CPU generator in the reference's order, so equal
+seeds give identical A, B.
+"""
+import numpy as np
+import torch
+from scipy.linalg import expm
+
+try:
+    from . import native as _nat
+except ImportError:  # flat import (sys.path points at this directory)
+    import native as _nat
+
+
+def default_device():
+    return torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+
+def _resolve(device):
+    return default_device() if device is None else torch.device(device)
+
+
+def _classify_matrix(M):
+    """'identity' | ('scaled', s) | ('diag', vec) | 'dense' for a square matrix."""
+    Mc = M.detach().cpu()
+    d = Mc.shape[0]
+    off = Mc - torch.diag(torch.diagonal(Mc))
+    if torch.count_nonzero(off) != 0:
+        return 'dense', None
+    diag = torch.diagonal(Mc).clone()
+    if torch.equal(diag, torch.ones(d)):
+        return 'identity', None
+    if torch.all(diag == diag[0]):
+        return 'scaled', float(diag[0])
+    return 'diag', diag
+
+
+class _LinearDriftMixin:
+    """Shared pieces of the Ornstein-Uhlenbeck families (dense A, dense B)."""
+
+    def b(self, x):
+        return torch.mm(self.A, x.t()).t()
+
+    def sigma(self, x):
+        return self.B
+
+    def _linear_spec(self):
+        spec = {}
+        kind, val = _classify_matrix(self.A)
+        if kind == 'dense':
+            spec['drift'] = (_nat.DRIFT_DENSE, self.A.contiguous())
+        else:
+            diag = torch.diagonal(self.A).contiguous()
+            spec['drift'] = (_nat.DRIFT_DIAG, diag)
+        kind, val = _classify_matrix(self.B)
+        if kind == 'identity':
+            spec['sigma'] = (_nat.SIGMA_IDENTITY, None, 1.0)
+        elif kind == 'scaled':
+            spec['sigma'] = (_nat.SIGMA_SCALED_IDENTITY, None, val)
+        else:
+            spec['sigma'] = (_nat.SIGMA_DENSE, self.B.contiguous(), 1.0)
+        return spec
+
+
+class LLGC(_LinearDriftMixin):
+    """Ornstein-Uhlenbeck dynamics with linear terminal cost g(x) = alpha . x
+    (reference problems.py:14-65)."""
+
+    def __init__(self, name='LLGC', d=1, off_diag=0, T=5, seed=42, device=None):
+        self.device = _resolve(device)
+        torch.manual_seed(seed)
+        self.name, self.d, self.T = name, d, T
+        self.A = (-torch.eye(d) + off_diag * torch.randn(d, d)).to(self.device)
+        self.B = (torch.eye(d) + off_diag * torch.randn(d, d)).to(self.device)
+        self.alpha = torch.ones(d, 1).to(self.device)
+        self.X_0 = torch.zeros(d).to(self.device)
+        self.boundary, self.one_boundary, self.X_l, self.X_r = 'square', False, -2.0, 2.0
+        if not np.all(np.linalg.eigvals(self.A.cpu().numpy()).real < 0):
+            print('not all EV of A are negative')
+
+    def f(self, x, t):
+        return torch.zeros(x.shape[0]).to(x.device)
+
+    def h(self, t, x, y, z):
+        return -0.5 * torch.sum(z ** 2, dim=1)
+
+    def g(self, x):
+        return torch.mm(x, self.alpha)[:, 0]
+
+    def u_true(self, x, t):
+        # u*(x,t) = -B^T exp(A^T (T-t)) alpha, independent of x (reference problems.py:51-53)
+        A, B = self.A.cpu().numpy(), self.B.cpu().numpy()
+        col = B.T.dot(expm(A.T * (self.T - t)).dot(self.alpha.cpu().numpy()))
+        return -(col * np.ones(x.shape).T)
+
+    def native_spec(self):
+        spec = self._linear_spec()
+        spec['runcost'] = (_nat.RUNCOST_ZERO, None)
+        spec['term'] = (_nat.TERM_LINEAR, self.alpha[:, 0].contiguous())
+        return spec
+
+
+class LQGC(_LinearDriftMixin):
+    """Linear-quadratic Gaussian control: running cost x'Px, terminal cost x'Rx
+    (reference problems.py:118-175)."""
+
+    def __init__(self, name='LQGC', delta_t=0.05, d=1, off_diag=0, T=5, seed=42, device=None):
+        self.device = _resolve(device)
+        torch.manual_seed(seed)
+        self.name, self.d, self.T = name, d, T
+        self.A = (-torch.eye(d) + off_diag * torch.randn(d, d)).to(self.device)
+        self.B = (torch.eye(d) + off_diag * torch.randn(d, d)).to(self.device)
+        self.delta_t = delta_t
+        self.N = int(np.floor(self.T / self.delta_t))
+        self.X_0 = torch.zeros(d).to(self.device)
+        if not np.all(np.linalg.eigvals(self.A.cpu().numpy()).real < 0):
+            print('not all EV of A are negative')
+        self.P = 0.5 * torch.eye(d).to(self.device)
+        self.Q = 0.5 * torch.eye(d).to(self.device)
+        self.R = torch.eye(d).to(self.device)
+        self._riccati()
+
+    def _riccati(self):
+        """Backward Euler recursion for the value-function matrices F_n and offsets G_n
+        (reference problems.py:140-152); host-side diagnostics only."""
+        A, B, Q, P = (m.cpu() for m in (self.A, self.B, self.Q, self.P))
+        F = torch.zeros(self.N + 1, self.d, self.d)
+        F[self.N] = self.R.cpu()
+        Qinv = Q.inverse()
+        for n in range(self.N, 0, -1):
+            Fn = F[n]
+            F[n - 1] = Fn + (A.t() @ Fn + Fn @ A - Fn @ B @ Qinv @ B.t() @ Fn + P) * self.delta_t
+        G = torch.zeros(self.N + 1)
+        for n in range(self.N, 0, -1):
+            G[n - 1] = G[n] - torch.trace(B @ F[n] @ B) * self.delta_t
+        self.F, self.G = F, G
+
+    def f(self, x, t):
+        return torch.sum(x.t() * torch.mm(self.P, x.t()), 0)
+
+    def g(self, x):
+        return torch.sum(x.t() * torch.mm(self.R, x.t()), 0)
+
+    def h(self, t, x, y, z):
+        return -0.5 * torch.sum(z ** 2, dim=1) - self.f(x, t)
+
+    def u_true(self, x, t):
+        n = int(np.ceil(t / self.delta_t))
+        gain = self.Q.cpu().inverse() @ self.B.cpu().t() @ self.F[n]
+        return -(gain @ x.t()).detach().numpy()
+
+    def v_true(self, x, t):
+        n = int(np.ceil(t / self.delta_t))
+        return -torch.mm(x, torch.mm(self.F[n], x.t())).t() + self.G[n]
+
+    def native_spec(self):
+        kp, _ = _classify_matrix(self.P)
+        kr, _ = _classify_matrix(self.R)
+        if kp == 'dense' or kr == 'dense':
+            return None
+        spec = self._linear_spec()
+        spec['runcost'] = (_nat.RUNCOST_DIAG_QUAD, torch.diagonal(self.P).contiguous())
+        spec['term'] = (_nat.TERM_DIAG_QUAD, torch.diagonal(self.R).contiguous())
+        return spec
+
+
+class _DoubleWellBase:
+    def _setup(self, d, d_1, d_2, eta, kappa):
+        self.d, self.d_1, self.d_2 = d, d_1, d_2
+        self.eta, self.kappa = eta, kappa
+        self.eta_ = torch.tensor([eta] * d_1 + [1.0] * d_2).to(self.device)
+        self.kappa_ = torch.tensor([kappa] * d_1 + [1.0] * d_2).to(self.device)
+        self.B = torch.eye(d).to(self.device)
+        self.X_0 = -torch.ones(d).to(self.device)
+        self.ref_sol_is_defined = False
+
+    def V(self, x):
+        return self.kappa * (x ** 2 - 1) ** 2
+
+    def grad_V(self, x):
+        return 4.0 * self.kappa_ * (x * (x ** 2 - torch.ones(self.d).to(x.device)))
+
+    def b(self, x):
+        return -self.grad_V(x)
+
+    def sigma(self, x):
+        return self.B
+
+    def _well_cost(self, x):
+        return (torch.sum(self.eta_ * (x - torch.ones(self.d).to(x.device)) ** 2, 1)).squeeze()
+
+
+class DoubleWell_multidim(_DoubleWellBase):
+    """Independent double-well potential in every coordinate, identity diffusion
+    (reference problems.py:285-334)."""
+
+    def __init__(self, name='Double well', d=1, d_1=1, d_2=0, T=1, eta=1, kappa=1, device=None):
+        self.device = _resolve(device)
+        self.name, self.T = name, T
+        self._setup(d, d_1, d_2, eta, kappa)
+        self.boundary, self.boundary_distance = 'unbounded', 2.0
+
+    def h(self, t, x, y, z):
+        return -0.5 * torch.sum(z ** 2, dim=1)
+
+    def f(self, x, t):
+        return torch.zeros(x.shape[0]).to(x.device)
+
+    def g(self, x):
+        return self._well_cost(x)
+
+    def native_spec(self):
+        return {
+            'drift': (_nat.DRIFT_DOUBLE_WELL, self.kappa_.float().contiguous()),
+            'sigma': (_nat.SIGMA_IDENTITY, None, 1.0),
+            'runcost': (_nat.RUNCOST_ZERO, None),
+            'term': (_nat.TERM_SHIFTED_QUAD, self.eta_.float().contiguous()),
+        }
+
+
+class DoubleWell_multidim_for_general_solver(_DoubleWellBase):
+    """Same dynamics posed as a parabolic terminal-value problem for GeneralSolver
+    (reference problems.py:479-534): ``f(x)`` is the terminal condition."""
+
+    def __init__(self, name='Double well', d=1, d_1=1, d_2=0, T=1, eta=1, kappa=1, modus='HJB', device=None):
+        self.device = _resolve(device)
+        self.name, self.T, self.modus = name, T, modus
+        self._setup(d, d_1, d_2, eta, kappa)
+        self.boundary, self.X_l, self.X_r = 'unbounded_square', -2.5, 2.5
+
+    def h(self, t, x, y, z):
+        if self.modus == 'linear':
+            return torch.zeros(x.shape[0]).to(x.device)
+        return -0.5 * torch.sum(z ** 2, dim=1)
+
+    def f(self, x):
+        if self.modus == 'linear':
+            return torch.exp(-self._well_cost(x))
+        return self._well_cost(x)
+
+
+class AllenCahn:
+    """Allen-Cahn reaction term h = y - y^3, sigma = sqrt(2) I (reference problems.py:1175-1217,
+    torch branch ``modus='pt'``)."""
+
+    def __init__(self, name='Allen-Cahn', d=1, T=0.3, seed=42, modus='pt', device=None):
+        self.device = _resolve(device)
+        np.random.seed(seed)
+        self.name, self.d, self.T, self.modus = name, d, T, modus
+        self.B = np.eye(d) * np.sqrt(2)
+        self.B_pt = torch.tensor(self.B).float().to(self.device)
+        self.X_0 = np.zeros(d)
+        self.sigma_modus, self.boundary, self.boundary_distance = 'constant', 'unbounded', 2.0
+
+    def b(self, x):
+        return torch.zeros(x.shape).to(x.device)
+
+    def sigma(self, x):
+        return self.B_pt
+
+    def h(self, t, x, y, z):
+        return y - y ** 3
+
+    def f(self, x):
+        return 1 / (2 + 2 / 5 * torch.sum(x ** 2, 1))
+
+
+class HeatEquation:
+    """Heat equation with terminal condition |x|^2 (reference problems.py:1733-1764)."""
+
+    def __init__(self, name='Heat equation', d=1, T=1, seed=42, device=None):
+        self.device = _resolve(device)
+        torch.manual_seed(seed)
+        self.name, self.d, self.T = name, d, T
+        self.B = torch.sqrt(torch.tensor(2.0)) * torch.eye(d).to(self.device)
+        self.boundary, self.boundary_type, self.boundary_distance = 'unbounded', 'Dirichlet', 1.0
+
+    def b(self, x):
+        return torch.zeros(x.shape).to(x.device)
+
+    def sigma(self, x):
+        return self.B
+
+    def g(self, x, t):
+        return torch.zeros(x.shape[0]).to(x.device)
+
+    def h(self, t, x, y, z):
+        return torch.zeros(x.shape[0]).to(x.device)
+
+    def f(self, x):
+        return torch.sum(x ** 2, 1)
+
+    def v_true(self, x, t):
+        return torch.sum(x ** 2, 1) + 2 * (self.T - t) * self.d

@@ -1,0 +1,404 @@
+"""Solver: path-space training loop for HJB / semilinear PDE problems -- API mirror of the
+reference's ``solver.Solver`` (reference solver.py:18-557), MI355X-native underneath.
+
+Same constructor keywords, attributes (``loss_log, u_L2_loss, Y_0_log, times, z_n, y_0, Phis,
+p, N, K, L, lr, delta_t, delta_t_np, sq_delta_t, device, ...``) and methods (``train, Z_n, Z_n_,
+update_Phis, b, sigma, h, f, g, zero_grad, optimization_step, save_networks, load_networks,
+save_logs``) as the reference, so notebooks written against it run unchanged, including
+``model.z_n = OtherNet(...); model.update_Phis()``.
+
+``train()`` resolves every string switch ONCE into an execution plan:
+
+* native plan (plan_native.HjbNativePlan): hand-written HIP kernels behind the C ABI of
+  include/psp.h; used whenever (problem, net, loss, flags) is in the native catalogue.
+* composite plan (this file): the reference's op sequence restated with torch ops on
+  ``self.device`` for combinations outside the catalogue (other nets, ``time_approx='outer'``,
+  other losses, ``detach_forward=False``, per-step ``u_true`` logging).
+
+Extra keywords (all optional, appended after the reference's): ``device``, ``backend``
+('auto' | 'native' | 'torch'), ``noise`` ('reference' = the reference's CPU-generator stream,
+bit-compatible with its fixed-seed runs; 'philox' = on-device counter-based stream),
+``widths`` (hidden widths of the default control net; the reference hard-codes [30, 30]).
+"""
+import json
+import os
+import time
+import warnings
+from copy import deepcopy
+from datetime import date
+
+import numpy as np
+import torch
+
+try:
+    from .function_space import DenseNet, MySequential, SingleParam
+    from .plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
+    from . import native as _nat
+except ImportError:  # flat import: this directory itself is on sys.path, as with the reference
+    from function_space import DenseNet, MySequential, SingleParam
+    from plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
+    import native as _nat
+
+
+def _default_device():
+    return torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+
+class Solver:
+
+    def __init__(self, name, problem, lr=0.001, L=10000, K=50, delta_t=0.05,
+                 approx_method='control', loss_method='log-variance', time_approx='outer',
+                 learn_Y_0=False, adaptive_forward_process=True, detach_forward=False,
+                 early_stopping_time=10000, random_X_0=False, compute_gradient_variance=0,
+                 IS_variance_K=0, IS_variance_iter=1, metastability_logs=None, print_every=100,
+                 plot_trajectories=None, seed=42, save_results=False, u_l2_error_flag=True,
+                 log_gradient=False, burgers_drift=False, verbose=True,
+                 device=None, backend='auto', noise='reference', widths=(30, 30)):
+        self.problem, self.name = problem, name
+        self.date = date.today().strftime('%Y-%m-%d')
+        self.d, self.T = problem.d, problem.T
+        self.device = torch.device(device) if device is not None else getattr(problem, 'device', _default_device())
+        self.X_0 = torch.as_tensor(problem.X_0, dtype=torch.float32).to(self.device)
+        self.Y_0 = torch.tensor([0.0])
+        self.X_u_opt = None
+        if backend not in ('auto', 'native', 'torch'):
+            raise ValueError("backend must be 'auto', 'native' or 'torch'")
+        if noise not in ('reference', 'philox'):
+            raise ValueError("noise must be 'reference' or 'philox'")
+        self.backend, self.noise = backend, noise
+
+        # hyper-parameters (reference solver.py:36-45): fp32 step, float64 step count
+        self.seed = seed
+        self.delta_t_np = delta_t
+        self.delta_t = torch.tensor(self.delta_t_np).to(self.device)
+        self.sq_delta_t = torch.sqrt(self.delta_t).to(self.device)
+        self.N = int(np.floor(self.T / self.delta_t_np))
+        self.lr, self.L, self.K = lr, L, K
+        self.random_X_0 = random_X_0
+
+        self.loss_method = loss_method
+        self.approx_method = approx_method
+        self.learn_Y_0 = learn_Y_0
+        self.adaptive_forward_process = adaptive_forward_process
+        self.detach_forward = detach_forward
+        self.early_stopping_time = early_stopping_time
+        self.burgers_drift = burgers_drift
+
+        self.has_ref_solution = hasattr(problem, 'u_true')
+        self.u_l2_error_flag = u_l2_error_flag and self.has_ref_solution
+        if self.loss_method == 'relative_entropy':       # the two silent overrides of solver.py:61-64
+            self.adaptive_forward_process = True
+        if self.loss_method == 'cross_entropy':
+            self.learn_Y_0 = False
+
+        self.print_every, self.verbose, self.verbose_NN = print_every, verbose, False
+        self.save_results = save_results
+        self.compute_gradient_variance = compute_gradient_variance
+        self.IS_variance_K, self.IS_variance_iter = IS_variance_K, IS_variance_iter
+        self.metastability_logs = metastability_logs
+        self.plot_trajectories = plot_trajectories
+        self.log_gradient = log_gradient
+        self.print_gradient_norm = False
+
+        # ansatz spaces (solver.py:80-99); seeds as in the reference so initial weights agree
+        self.Phis = []
+        self.time_approx = time_approx
+        torch.manual_seed(seed)
+        if self.approx_method == 'control':
+            self.y_0 = SingleParam(lr=self.lr).to(self.device)
+            if self.time_approx == 'outer':
+                self.z_n = [DenseNet(d_in=self.d, d_out=self.d, lr=self.lr, seed=seed) for _ in range(self.N)]
+            elif self.time_approx == 'inner':
+                self.z_n = MySequential(d_in=self.d + 1, d_out=self.d, lr=self.lr, seed=123, widths=widths)
+        elif self.approx_method == 'value_function':
+            if self.time_approx == 'outer':
+                self.y_n = [DenseNet(d_in=self.d, d_out=1, lr=self.lr, seed=seed) for _ in range(self.N)]
+            elif self.time_approx == 'inner':
+                self.y_n = [DenseNet(d_in=self.d + 1, d_out=1, lr=self.lr, seed=seed)]
+        self.update_Phis()
+        for phi in self.Phis:
+            phi.train()
+
+        self.Y_0_log, self.loss_log, self.u_L2_loss = [], [], []
+        self.IS_rel_log, self.times = [], []
+        self.grads_rel_error_log, self.particles_close_to_target = [], []
+        self.plan_name = None        # 'native' | 'torch', set by train()
+        self.plan_reason = None      # why the composite plan was chosen (if it was)
+
+    # ---- problem pass-throughs (solver.py:121-140) ------------------------------------------
+    def b(self, x):
+        return self.problem.b(x)
+
+    def sigma(self, x):
+        return self.problem.sigma(x)
+
+    def h(self, t, x, y, z):
+        return self.problem.h(t, x, y, z)
+
+    def f(self, x, t):
+        return self.problem.f(x, t)
+
+    def g(self, x):
+        return self.problem.g(x)
+
+    def u_true(self, x, t):
+        return self.problem.u_true(x, t)
+
+    def v_true(self, x, t):
+        return self.problem.v_true(x, t)
+
+    # ---- ansatz bookkeeping -------------------------------------------------------------------
+    def update_Phis(self):
+        """Collect the trainable modules (solver.py:142-162); call after swapping ``z_n``."""
+        if self.approx_method == 'control':
+            nets = list(self.z_n) if self.time_approx == 'outer' else [self.z_n]
+            self.Phis = nets + ([self.y_0] if self.learn_Y_0 else [])
+        elif self.approx_method == 'value_function':
+            self.Phis = self.y_n
+        for phi in self.Phis:
+            phi.to(self.device)
+        self.p = sum(int(np.prod(q.size())) for q in self.Phis[0].parameters() if q.requires_grad)
+        if self.log_gradient:
+            self.gradient_log = torch.zeros(self.L, self.p)
+
+    def zero_grad(self):
+        for phi in self.Phis:
+            phi.optim.zero_grad()
+
+    def optimization_step(self):
+        for phi in self.Phis:
+            phi.optim.step()
+
+    # ---- control evaluation (solver.py:334-362) -----------------------------------------------
+    def Y_n(self, X, t):
+        n = int(np.ceil(t / self.delta_t))
+        if self.time_approx == 'outer':
+            return self.y_n[n](X)
+        t_X = torch.cat([torch.ones([X.shape[0], 1]).to(X.device) * t, X], 1)
+        return self.y_n[0](t_X)
+
+    def compute_grad_Y(self, X, n):
+        total = self.Y_n(X, n).squeeze(1).sum()
+        grad, = torch.autograd.grad(total, X, create_graph=True)
+        return torch.mm(self.sigma(X), grad.t()).t()
+
+    def Z_n_(self, X, n):
+        if self.approx_method == 'value_function':
+            return self.compute_grad_Y(X, n)
+        if self.time_approx == 'outer':
+            return self.z_n[max(0, min(n, self.N - 1))](X)
+        t_col = torch.ones([X.shape[0], 1]).to(self.device) * n * self.delta_t   # time is input column 0
+        return self.z_n(torch.cat([t_col, X], 1))
+
+    def Z_n(self, X, t):
+        t = torch.as_tensor(t, dtype=torch.float32, device=self.delta_t.device)
+        n = int(torch.ceil(t / self.delta_t))
+        return self.Z_n_(X, n)
+
+    # ---- losses (solver.py:164-192) -----------------------------------------------------------
+    def loss_function(self, X, Y, Z_sum, l):
+        m = self.loss_method
+        if m in ('moment', 'log-variance', 'log-variance-repa') or (m == 'relative_entropy_log-variance' and l >= 1000):
+            D = Y - self.g(X)
+            if m == 'moment':
+                return D.pow(2).mean()
+            var = D.pow(2).mean() - D.mean().pow(2)
+            return (l % 2 * 2 - 1) * var if m == 'log-variance-repa' else var
+        if m == 'variance':
+            return torch.var(torch.exp(-self.g(X) + Y))
+        if m in ('relative_entropy', 'relative_entropy_BSDE', 'reparametrization', 'relative_entropy_log-variance'):
+            return (Z_sum + self.g(X)).mean()
+        if m == 'cross_entropy':
+            w = torch.exp(-self.g(X) + Y.detach()) if self.adaptive_forward_process else torch.exp(-self.g(X))
+            return (Y * w).mean()
+        raise NotImplementedError('loss_method %r' % m)
+
+    def gradient_descent(self, X, Y, Z_sum, l, additional_loss):
+        self.zero_grad()
+        loss = self.loss_function(X, Y, Z_sum, l) + additional_loss
+        loss.backward()
+        self.optimization_step()
+        return loss
+
+    def initialize_training_data(self):
+        """Initial state, accumulators and the iteration's Brownian increments drawn on the CPU
+        generator and moved to the device (solver.py:364-382)."""
+        K, dev = self.K, self.device
+        X = self.X_0.repeat(K, 1).to(dev)
+        if self.random_X_0:
+            X = torch.randn(K, self.d).to(dev)
+        Y = self.Y_0.repeat(K).to(dev)
+        if self.approx_method == 'value_function':
+            X = X.clone().requires_grad_(True)
+            Y = self.Y_n(X, 0)[:, 0]
+        elif self.learn_Y_0:
+            Y = self.y_0(X)
+            self.Y_0_log.append(Y[0].item())
+        zeros = [torch.zeros(K).to(dev) for _ in range(5)]
+        xi = torch.randn(K, self.d, self.N + 1).to(dev)
+        return (X, Y, *zeros, xi)
+
+    # ---- training -----------------------------------------------------------------------------
+    def _choose_plan(self):
+        if self.backend == 'torch':
+            self.plan_name, self.plan_reason = 'torch', "backend='torch' requested"
+            return None
+        reason = native_eligibility(self)      # raises NativeLibraryError if the .so is missing on a GPU run
+        if reason is None:
+            self.plan_name, self.plan_reason = 'native', None
+            plan = getattr(self, '_native_plan', None)
+            if plan is None or plan.net is not self.z_n or plan.noise != self.noise:
+                plan = HjbNativePlan(self, noise=self.noise)     # owns the flat parameters and Adam moments
+                self._native_plan = plan
+            return plan
+        if self.backend == 'native':
+            raise PlanUnsupported('native plan unavailable: ' + reason)
+        if self.device.type == 'cuda':
+            warnings.warn('path-space solver: running the composite torch plan (%s)' % reason)
+        self.plan_name, self.plan_reason = 'torch', reason
+        return None
+
+    def train(self):
+        torch.manual_seed(self.seed)
+        if self.verbose:
+            print('d = %d, L = %d, K = %d, delta_t = %.2e, lr = %.2e, %s, %s, %s, %s'
+                  % (self.d, self.L, self.K, self.delta_t_np, self.lr, self.approx_method,
+                     self.time_approx, self.loss_method, 'adaptive' if self.adaptive_forward_process else ''))
+        plan = self._choose_plan()
+        if plan is not None:
+            self._train_native(plan)
+        else:
+            self._train_composite()
+        if self.save_results:
+            self.save_logs()
+
+    def _train_native(self, plan):
+        """L iterations on the HIP plan.  Nothing synchronises with the host inside the loop
+        (the reference syncs every iteration through loss.item(), solver.py:514); losses are
+        gathered on the device and read back once per print_every block."""
+        losses = torch.zeros(self.L, dtype=torch.float32, device=self.device)
+        y0_hist = torch.zeros(self.L, dtype=torch.float32, device=self.device) if self.learn_Y_0 else None
+        done = 0
+        t_block = time.time()
+        for l in range(self.L):
+            if self.learn_Y_0:
+                y0_hist[l:l + 1].copy_(self.y_0.Y_0.detach())       # Y_0 before the update (solver.py:374)
+            plan.iteration(l, losses)
+            if (self.verbose and l % self.print_every == 0) or l == self.L - 1:
+                vals = losses[done:l + 1].cpu().tolist()          # one sync per block
+                now = time.time()
+                per = (now - t_block) / max(1, l + 1 - done)
+                self.loss_log += vals
+                self.u_L2_loss += [0.0] * len(vals)
+                self.times += [per] * len(vals)
+                if self.learn_Y_0:
+                    self.Y_0_log += y0_hist[done:l + 1].cpu().tolist()
+                done, t_block = l + 1, now
+                if self.verbose and l % self.print_every == 0:
+                    msg = '%d - loss: %.4e - u L2: %.4e - time/iter: %.4fs' % (l, self.loss_log[-1], 0.0, per)
+                    if self.learn_Y_0:
+                        msg += ' - Y_0: %.4e' % self.Y_0_log[-1]
+                    print(msg)
+
+    def _train_composite(self):
+        """The reference iteration restated with torch ops on self.device (solver.py:430-554)."""
+        if self.approx_method != 'control':
+            raise NotImplementedError("composite plan covers approx_method='control' only")
+        if self.IS_variance_K > 0 or self.compute_gradient_variance > 0:
+            raise NotImplementedError('IS-variance / gradient-variance diagnostics are not implemented '
+                                      '(SURVEY.md 8f, next rows)')
+        dev, dt, sq = self.device, self.delta_t, self.sq_delta_t
+        repa = self.loss_method == 'reparametrization'
+        rel_ent = 'relative_entropy' in self.loss_method
+        for l in range(self.L):
+            t_0 = time.time()
+            X, Y, Z_sum, u_L2, _, _, _, xi = self.initialize_training_data()
+            frozen = deepcopy(self.z_n) if repa else None
+            for n in range(self.N):
+                Z = self.Z_n_(X, n)
+                c = torch.zeros(self.d, self.K).to(dev)
+                if self.adaptive_forward_process:
+                    if self.burgers_drift:
+                        c = torch.ones(self.d, self.K).to(dev) * (Y.unsqueeze(0) - (2 + self.d) / (2 * self.d))
+                    else:
+                        c = -self.Z_n_(X, n).t()           # second evaluation, as the reference does (:456)
+                if repa:
+                    if self.time_approx == 'outer':
+                        v = -deepcopy(self.z_n[max(0, min(n, self.N - 1))])(X)
+                    else:
+                        v = -frozen(torch.cat([torch.ones([X.shape[0], 1]).to(dev) * n * dt, X], 1))
+                if self.detach_forward:
+                    c = c.detach()
+                dW = xi[:, :, n + 1]
+                sig = self.sigma(X)
+                X = (X + (self.b(X) + torch.mm(sig, c).t()) * dt + torch.mm(sig, dW.t()).t() * sq)
+                # h is evaluated at the UPDATED state with the old Y and time n*dt (:477)
+                Y = (Y + (-self.h(dt * n, X, Y, Z) + torch.sum(Z * c.t(), 1)) * dt + torch.sum(Z * dW, 1) * sq)
+                if repa:
+                    Z_sum = Z_sum + (-0.5 * torch.sum(v ** 2, 1) * dt + torch.sum(v * c.t(), 1) * dt
+                                     + torch.sum(v * dW, 1) * sq)
+                if rel_ent:
+                    Z_sum = Z_sum + (0.5 * torch.sum(Z ** 2, dim=1) + self.f(X, n * dt)) * dt
+                    if self.loss_method == 'relative_entropy_BSDE':
+                        Z_sum = Z_sum + torch.sum(-Z * dW, 1) * sq
+                if self.u_l2_error_flag:
+                    ref = torch.tensor(self.u_true(X.cpu().detach(), n * self.delta_t_np)).t().float().to(dev)
+                    u_L2 = u_L2 + torch.sum((-Z - ref) ** 2 * dt, 1)
+            loss = self.gradient_descent(X, Y, Z_sum, l, torch.zeros(self.K).mean())
+            if self.log_gradient:
+                flat = torch.cat([q.grad.reshape(-1) for q in self.z_n.parameters() if q.grad is not None])
+                self.gradient_log[l, :] = flat.cpu().detach()
+            self.loss_log.append(loss.item())
+            self.u_L2_loss.append(torch.mean(u_L2).item())
+            if self.metastability_logs is not None:
+                target, epsilon = self.metastability_logs
+                self.particles_close_to_target.append(
+                    torch.mean((torch.sqrt(torch.sum((X - target) ** 2, 1)) < epsilon).float()))
+            self.times.append(time.time() - t_0)
+            if self.verbose and l % self.print_every == 0:
+                msg = ('%d - loss: %.4e - u L2: %.4e - time/iter: %.2fs'
+                       % (l, self.loss_log[-1], self.u_L2_loss[-1], np.mean(self.times[-self.print_every:])))
+                if self.learn_Y_0:
+                    msg += ' - Y_0: %.4e' % self.Y_0_log[-1]
+                print(msg)
+            if self.early_stopping_time is not None and l > self.early_stopping_time:
+                recent = self.u_L2_loss[-self.early_stopping_time:]
+                if np.std(recent) / self.u_L2_loss[-1] < 0.02:
+                    break
+
+    # ---- persistence (solver.py:283-332) ------------------------------------------------------
+    @staticmethod
+    def state_dict_to_list(sd):
+        return {k: (v.detach().cpu().numpy().tolist() if isinstance(v, torch.Tensor) else v) for k, v in sd.items()}
+
+    @staticmethod
+    def list_to_state_dict(l):
+        return {k: (torch.tensor(v) if isinstance(v, list) else v) for k, v in l.items()}
+
+    def save_logs(self, model_name='model'):
+        logs = {'name': self.name, 'date': self.date, 'd': self.d, 'T': self.T, 'seed': self.seed,
+                'delta_t': self.delta_t_np, 'N': self.N, 'lr': self.lr, 'K': self.K,
+                'loss_method': self.loss_method, 'learn_Y_0': self.learn_Y_0,
+                'adaptive_forward_process': self.adaptive_forward_process,
+                'Y_0_log': self.Y_0_log, 'loss_log': self.loss_log, 'u_L2_loss': self.u_L2_loss,
+                'Phis_state_dict': [self.state_dict_to_list(z.state_dict()) for z in self.Phis]}
+        os.makedirs('logs', exist_ok=True)
+        path, i = 'logs/%s_%s_%s.json' % (model_name, self.name, self.date), 1
+        while os.path.isfile(path):
+            i += 1
+            path = 'logs/%s_%s_%s_%d.json' % (model_name, self.name, self.date, i)
+        with open(path, 'w') as fh:
+            json.dump(logs, fh, indent=2)
+
+    def save_networks(self):
+        os.makedirs('output', exist_ok=True)
+        path = 'output/%s_%s.pt' % (self.name, self.date)
+        torch.save({'nn%d' % i: z.state_dict() for i, z in enumerate(self.Phis)}, path)
+        print('\nnetworks data has been stored to file: %s' % path)
+
+    def load_networks(self, cp_name):
+        print('\nload network data from file: %s' % cp_name)
+        checkpoint = torch.load(cp_name, map_location=self.device)
+        for i, z in enumerate(self.Phis):
+            z.load_state_dict(checkpoint['nn%d' % i])
+            z.eval()

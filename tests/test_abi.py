@@ -1,0 +1,74 @@
+"""The C-ABI shared library loads and exports every symbol include/psp.h declares.
+No compute calls here (no GPU needed): only size queries and argument validation."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from util_cases import psp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+nat = psp.native
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "psp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(psp_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not nat.is_built():
+        import __graft_entry__
+        __graft_entry__.build()
+    return nat.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    syms = declared_symbols()
+    assert "psp_hjb_rollout_fwd" in syms and "psp_adam_step" in syms
+    raw = C.CDLL(nat.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), s
+    assert set(syms) == set(nat.SIGNATURES), (set(syms) ^ set(nat.SIGNATURES))
+
+
+def test_version_and_support_table(lib):
+    assert lib.psp_version() == 100
+    assert nat.supported(100, 64) and nat.supported(2, 30)
+    assert not nat.supported(3, 7)
+
+
+def _cfg(d=100, H=64, K=1024, N=50):
+    c = nat.HjbConfig()
+    c.d, c.H, c.K_local, c.N, c.K_global = d, H, K, N, K
+    c.dt, c.sqrt_dt = 0.01, 0.1
+    c.drift_kind, c.sigma_kind = nat.DRIFT_DENSE, nat.SIGMA_DENSE
+    c.adaptive, c.store_path = 1, 1
+    return c
+
+
+def test_query_sizes_without_gpu(lib):
+    s = nat.query(_cfg())
+    p = (100 + 1) * 64 + 64 + 64 * 64 + 64 + 64 * 100 + 100
+    assert s.n_params == p == 17188
+    # X_n store: N steps x K/16 tiles x ceil(d/4) k-steps x 64 lanes x 4 B
+    assert s.path_bytes == 50 * 64 * 25 * 64 * 4
+    assert s.fwd_workgroups >= 1 and s.bwd_workgroups >= 1
+    assert s.grad_partial_bytes == s.bwd_workgroups * p * 4
+
+
+def test_unsupported_shape_reports_error(lib):
+    with pytest.raises(nat.NativeCallError) as e:
+        nat.query(_cfg(d=3, H=7))
+    assert "no compiled HJB kernel instance" in str(e.value)
+
+
+def test_null_buffers_are_rejected_before_any_launch(lib):
+    c = _cfg()
+    rc = lib.psp_hjb_rollout_fwd(C.byref(c), None, None, 0, None, None, 1, 0, None, None, None, None, None)
+    assert rc != 0 and "missing" in nat.last_error() or "null" in nat.last_error()
+    rc = lib.psp_adam_step(None, None, None, None, 10, 1, 1e-3, 0.9, 0.999, 1e-8, None)
+    assert rc != 0

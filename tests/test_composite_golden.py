@@ -1,0 +1,67 @@
+"""The package's composite torch plan (the fallback for combinations outside the native
+catalogue) must reproduce the reference's fixed-seed runs on CPU: bit-for-bit on the torch
+build the fixtures were made with, 1e-5 otherwise."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from util_cases import make_pkg_solver
+
+CASES = ["lqgc_d2_logvar", "lqgc_d2_logvar_noul2", "llgc_d100_h64_logvar", "llgc_d100_densenet64_logvar",
+         "dw_d10_logvar", "llgc_d20_diag_logvar", "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive",
+         "lqgc_d2_outer"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_composite_plan_matches_reference(name):
+    rec = load_golden(name)
+    exact = rec["torch"] == torch.__version__
+    torch.set_num_threads(1)
+    model = make_pkg_solver(rec["case"], "cpu")
+    model.train()
+    assert model.plan_name == "torch"
+    exp = rec["expected"]
+    assert model.N == exp["N"] and int(model.p) == exp["p"]
+    for got, want in zip(model.loss_log, exp["loss_log"]):
+        assert (got == want) if exact else math.isclose(got, want, rel_tol=1e-5)
+    assert len(model.loss_log) == len(exp["loss_log"])
+    if exp["u_L2_loss"] and any(v != 0 for v in exp["u_L2_loss"]):
+        for got, want in zip(model.u_L2_loss, exp["u_L2_loss"]):
+            assert math.isclose(got, want, rel_tol=1e-5)
+    for got, want in zip(model.Y_0_log, exp["Y_0_log"]):
+        assert math.isclose(got, want, rel_tol=1e-6, abs_tol=1e-9)
+    if exp["probes"]:
+        xp = torch.tensor(exp["probe_x"]).reshape(-1, model.d)
+        for pr in exp["probes"]:
+            with torch.no_grad():
+                u = -model.Z_n(xp, pr["t"])
+            want = torch.tensor(pr["minus_Z"]).reshape(u.shape)
+            assert torch.allclose(u, want, rtol=1e-5, atol=1e-7)
+
+
+def test_backend_native_refuses_cpu():
+    from path_space_pde_solver_amd import PlanUnsupported
+    rec = load_golden("lqgc_d2_logvar_noul2")
+    model = make_pkg_solver(rec["case"], "cpu", backend="native", L=1)
+    with pytest.raises(PlanUnsupported):
+        model.train()
+
+
+def test_flat_import_like_the_reference(tmp_path):
+    """Notebooks written against the reference do `from solver import Solver` with the source
+    directory on sys.path; the package directory supports the same flat import."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); "
+            "from solver import Solver; from problems import LQGC; from function_space import MySequential; "
+            "p = LQGC(d=2, off_diag=0.1, T=0.2, seed=1, delta_t=0.05, device='cpu'); "
+            "m = Solver('x', p, L=1, K=8, delta_t=0.05, time_approx='inner', detach_forward=True, "
+            "verbose=False, u_l2_error_flag=False, device='cpu'); m.train(); print(len(m.loss_log))"
+            % os.path.join(root, "path-space-pde-solver_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().endswith("1")
