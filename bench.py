@@ -55,7 +55,9 @@ def cpu_baseline(w, seconds_budget=20.0):
     from oracle import pathspace_oracle as orc
     Kc = min(4096, w["K"])
     prob = orc.make_problem("LLGC", d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42)
-    threads = torch.get_num_threads()
+    # a 1-GPU box exposes a 16-core CPU share; more torch threads than that only adds contention
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     cfg = orc.HJBConfig(K=Kc, delta_t=w["dt"], lr=1e-3, L=1, seed=42, adaptive_forward_process=True,
                         detach_forward=True)
     z = orc.TanhMLP(w["d"] + 1, w["d"], 1e-3, seed=123, widths=(w["H"], w["H"]))

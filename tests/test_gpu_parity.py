@@ -123,7 +123,7 @@ def test_adam_kernel_matches_torch_adam():
         nat.check(lib.psp_adam_step(nat.ptr(p), nat.ptr(gd), nat.ptr(m), nat.ptr(v), n, step, 1e-3, 0.9, 0.999,
                                     1e-8, None), "adam")
         torch.cuda.synchronize()
-        assert float((p.cpu() - ref.detach()).abs().max()) <= 2e-7
+        assert float((p.cpu() - ref.detach()).abs().max()) <= 5e-7      # <= 2 ulp at |p| ~ 2..4
 
 
 def test_control_eval_matches_torch():
