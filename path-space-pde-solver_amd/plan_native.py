@@ -18,19 +18,14 @@ import torch
 
 try:
     from . import native as nat
+    from . import sharding
 except ImportError:
     import native as nat
+    import sharding
 
 
 class PlanUnsupported(Exception):
     """The (problem, net, loss, flags) combination is outside the native catalogue."""
-
-
-def _dist():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return dist, dist.get_rank(), dist.get_world_size()
-    return None, 0, 1
 
 
 def native_eligibility(solver):
@@ -77,12 +72,13 @@ class HjbNativePlan:
         self.noise = noise
         dev = solver.device
         self.dev = dev
-        self.dist, self.rank, self.world = _dist()
+        self.dist, self.rank, self.world = sharding.dist_info()
         K = solver.K
-        if K % self.world != 0:
-            raise PlanUnsupported('K=%d is not divisible by world_size=%d' % (K, self.world))
-        self.K_local = K // self.world
-        self.k_offset = self.rank * self.K_local
+        try:
+            lo, hi = sharding.shard_bounds(K, self.rank, self.world)
+        except ValueError as e:
+            raise PlanUnsupported(str(e))
+        self.K_local, self.k_offset = hi - lo, lo
         net = solver.z_n
         self.net = net
         self.H = net.native_shape()[1]
@@ -195,13 +191,8 @@ class HjbNativePlan:
             ev[1].record()
         nat.check(lib.psp_hjb_terminal_reduce(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums), st),
                   'psp_hjb_terminal_reduce')
-        if self.world > 1:
-            self.dist.all_reduce(self.sums)
-        K = float(s.K)
-        if s.loss_method == 'log-variance':
-            loss = self.sums[1] / K - (self.sums[0] / K) ** 2
-        else:
-            loss = self.sums[1] / K
+        sharding.allreduce_sum_(self.sums)              # collective 1: 16 bytes
+        loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
         loss_out[l] = loss.to(torch.float32)
         if ev is not None:
             ev[2].record()
@@ -211,17 +202,13 @@ class HjbNativePlan:
         if ev is not None:
             ev[3].record()
             self.events.append(ev)
-        if self.world > 1:
-            self.dist.all_reduce(self.grad)
+        sharding.allreduce_sum_(self.grad)              # collective 2: p floats
         self.step += 1
         nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
                                     self.P, self.step, float(s.lr), 0.9, 0.999, 1e-8, st), 'psp_adam_step')
         if self.learn_y0:
             # dL/dY_0 = sum_k w_k ; log-variance: exactly 0 ; moment: (2/K) sum D (global sums)
-            if s.loss_method == 'moment':
-                self.y0_grad[0] = (2.0 / K) * self.sums[0]
-            else:
-                self.y0_grad.zero_()
+            self.y0_grad[0] = sharding.y0_gradient(self.sums, s.K, s.loss_method)
             nat.check(lib.psp_adam_step(nat.ptr(self.y0_param), nat.ptr(self.y0_grad), nat.ptr(self.y0_m),
                                         nat.ptr(self.y0_v), 1, self.step, float(s.lr), 0.9, 0.999, 1e-8, st),
                       'psp_adam_step(Y_0)')

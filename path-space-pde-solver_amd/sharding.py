@@ -1,0 +1,67 @@
+"""Trajectory sharding across ranks.
+
+Trajectories are independent inside an iteration until the terminal reduction, so the batch
+is split into contiguous blocks, one per rank.  Two collectives per iteration:
+
+  1. SUM all-reduce of (sum_k D_k, sum_k D_k^2): the log-variance loss
+     mean(D^2) - mean(D)^2 (reference solver.py:167-168) needs the GLOBAL mean -- averaging
+     per-shard variances would drop the between-shard variance of the means;
+  2. SUM all-reduce of the flat parameter gradient, after which every rank applies the
+     identical Adam step.
+
+The helpers below are the only place that arithmetic lives; plan_native.py uses them on the
+device (RCCL) and tests/test_sharding_gloo.py exercises them on CPU with gloo, world_size 2.
+"""
+import torch
+
+
+def dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def shard_bounds(K, rank, world):
+    """Contiguous block [lo, hi) of global trajectory indices owned by `rank`."""
+    if K % world != 0:
+        raise ValueError('K=%d is not divisible by world_size=%d' % (K, world))
+    per = K // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_sum_(t):
+    """In-place SUM all-reduce when a process group is initialised; no-op otherwise."""
+    dist, _, world = dist_info()
+    if world > 1:
+        dist.all_reduce(t)
+    return t
+
+
+def loss_from_sums(sums, K_global, loss_method):
+    """Loss value from GLOBAL (sum D, sum D^2) (fp64 tensor of 2)."""
+    K = float(K_global)
+    if loss_method == 'log-variance':
+        return sums[1] / K - (sums[0] / K) ** 2
+    if loss_method == 'moment':
+        return sums[1] / K
+    raise ValueError(loss_method)
+
+
+def loss_weights(D_local, sums, K_global, loss_method):
+    """w_k = dLoss/dD_k for this rank's trajectories, from GLOBAL sums:
+    log-variance (2/K)(D_k - mean D), moment (2/K) D_k.  The HIP backward kernel applies the
+    same formula (csrc/hjb_kernels.h, hjb_bwd_kernel)."""
+    K = float(K_global)
+    if loss_method == 'log-variance':
+        return (2.0 / K) * (D_local - (sums[0] / K).to(D_local.dtype))
+    if loss_method == 'moment':
+        return (2.0 / K) * D_local
+    raise ValueError(loss_method)
+
+
+def y0_gradient(sums, K_global, loss_method):
+    """d loss / d Y_0 = sum_k w_k over ALL ranks: (2/K) sum D for moment, exactly 0 for log-variance."""
+    if loss_method == 'moment':
+        return (2.0 / float(K_global)) * sums[0]
+    return torch.zeros((), dtype=sums.dtype, device=sums.device)
