@@ -237,21 +237,20 @@ struct Geo {
     static int fwd_lds_floats(int drift_kind, int sigma_kind) {
         return fA + (drift_kind == DRIFT_DENSE ? fB_dense_off : 0) + (sigma_kind == SIGMA_DENSE ? fB_dense_off : 0);
     }
-    // backward LDS carve (floats)
-    static constexpr int gW1 = 0, gW2 = gW1 + HB * KSD * 64, gW2T = gW2 + HB * KSH * 64,
-                         gW3T = gW2T + HB * KSH * 64, gVec = gW3T + HB * KSD * 64;
-    static constexpr int gb1 = gVec, gw1t = gb1 + HB * 16, gb2 = gw1t + HB * 16, gb3 = gb2 + HB * 16,
-                         gScr = gb3 + DB * 16;
-    static constexpr int SCR_HALF = (DB > HB ? DB : HB);    // tiles per operand side
-    static constexpr int SCR_TILES = 2 * SCR_HALF;          // per-wave transposition scratch (1 KiB tiles)
-    static constexpr int gW3 = gScr + 4 * SCR_TILES * 256;  // only when !adaptive
-    // register-native accumulator image used for the cross-wave reduction
-    static constexpr int NT3 = DB * HB, NT2 = HB * HB, NT1 = HB * DB;
-    static constexpr int ACC_FLOATS = (NT3 + NT2 + NT1) * 256 + (DB + 3 * HB) * 16;
-    static int bwd_lds_floats(int adaptive) {
-        int a = gW3 + (adaptive ? 0 : DB * KSH * 64);
-        return a > ACC_FLOATS ? a : ACC_FLOATS;
-    }
+    // path store: one block per (step n, 16-trajectory tile): register images of X_n, h1, h2
+    static constexpr int pX = 0, pH1 = KSD * 64, pH2 = pH1 + KSH * 64, PB = pH2 + KSH * 64;
+    // backward: 4 waves per workgroup arranged WH x WD over the (H-blocks x other-blocks) tile grids
+    static constexpr int WH = (HB >= 4) ? 4 : (HB >= 2 ? 2 : 1);
+    static constexpr int WD = 4 / WH;
+    static constexpr int NIB = cdiv(HB, WH);     // H-blocks per wave along the WH axis
+    static constexpr int NOBD = cdiv(DB, WD);    // d-blocks per wave along the WD axis
+    static constexpr int NOBH = cdiv(HB, WD);    // H-blocks per wave along the WD axis (dW2 rows)
+    // backward LDS carve (floats): transposed weight tables, b3, [W3], per-wave exchange tiles
+    static constexpr int gW2T = 0, gW3T = gW2T + HB * KSH * 64, gVec = gW3T + HB * KSD * 64;
+    static constexpr int gb3 = gVec, gEx = gb3 + DB * 16;
+    static constexpr int EXT = (DB > 2 * HB ? DB : 2 * HB);   // exchange tiles (1 KiB) per wave
+    static constexpr int gW3 = gEx + 4 * EXT * 256;           // only when !adaptive
+    static int bwd_lds_floats(int adaptive) { return gW3 + (adaptive ? 0 : DB * KSH * 64); }
 };
 
 // =======================================================================================
@@ -334,10 +333,10 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             const f32x4* vb3 = vecs + (G::vb3 - G::fVec) / 4;
             const f32x4* vdr = vecs + (G::vdr - G::fVec) / 4;
             const f32x4* vrun = vecs + (G::vrun - G::fVec) / 4;
+            float* pblk = a.path + ((size_t)n * a.ntile16 + t16) * (size_t)G::PB + lane;
             if (a.store_path) {
-                float* dst = a.path + ((size_t)n * a.ntile16 + t16) * (size_t)(KSD * 64) + lane;
 #pragma unroll
-                for (int ks = 0; ks < KSD; ++ks) dst[ks * 64] = X[ks >> 2][ks & 3];
+                for (int ks = 0; ks < KSD; ++ks) pblk[(G::pX / 64 + ks) * 64] = X[ks >> 2][ks & 3];
             }
             // ---- control net: Z = W3 tanh(W2 tanh(W1 [t,x] + b1) + b2) + b3 (function_space.py:190-195)
             f32x4 h1[HB];
@@ -352,6 +351,13 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             gemm_T<HB, KSH, HB>(h2, lds + G::fW2, h1, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
+            if (a.store_path) {                        // hidden activations for the backward pass (no recompute)
+#pragma unroll
+                for (int ks = 0; ks < KSH; ++ks) {
+                    pblk[(G::pH1 / 64 + ks) * 64] = h1[ks >> 2][ks & 3];
+                    pblk[(G::pH2 / 64 + ks) * 64] = h2[ks >> 2][ks & 3];
+                }
+            }
             f32x4 Z[DB];
 #pragma unroll
             for (int m = 0; m < DB; ++m) Z[m] = vb3[m * 4];
@@ -474,11 +480,21 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 // Backward kernel: analytic gradient of the loss w.r.t. the control-net parameters.
 // With detach_forward=True the state path carries no gradient (solver.py:468-472), so
 //   dL/dZ_n[k,:] = w_k ((Z_n + c) dt + xi_{n+1} sqrt(dt)),  (Z + c = 0 when adaptive)
-// and the parameter gradient is one batched MLP backward over all (n, k) samples.
-// Hidden activations are recomputed from the stored X_n (no activation store).
-// Weight gradients: each wave transposes its 16-sample panels through a private LDS tile
-// into "feature-on-lane" form and contracts over samples with MFMA into persistent
-// register accumulators; waves are summed through LDS, workgroups through grad_partial.
+// and the parameter gradient is one batched MLP backward over all (n, k) samples, using the
+// X_n, h1, h2 panels the forward kernel stored (register-image layout).
+//
+// Workgroup = 4 waves, 2 workgroups per CU (<= 256 VGPRs, <= 80 KiB LDS), persistent over
+// "rounds" of 4 sample blocks (16 samples each):
+//   P1  each wave, own block: G = w xi sqrt(dt) (same Philox counters as the forward),
+//       dz2 = (W3^T G)(1-h2^2), dz1 = (W2^T dz2)(1-h1^2)      [T layout, register-chained MFMA]
+//       -> G panel to this wave's LDS exchange tiles
+//   P2  weight gradient of layer 3 over all 4 blocks: every wave owns a fixed subset of the
+//       dW3 tiles; A operand = G in feature-on-lane form (ds_read_b128 of the exchange tile),
+//       B operand = h2 read DIRECTLY in feature-on-lane form from the path store (16 B/lane)
+//   P3  same for layers 2 and 1 (A = dz2 / dz1 from the exchange tiles, B = h1 / X_n from HBM/L2)
+// Weight-gradient tiles are disjoint between waves (72 accumulator registers per wave instead
+// of 288 for a per-wave copy), so there is no cross-wave reduction; workgroups are summed by
+// reduce_grad_kernel in a fixed order.
 // =======================================================================================
 __device__ __forceinline__ void tile_put(float* tile, f32x4 v, int lane) {
     tile[lane] = v[0]; tile[64 + lane] = v[1]; tile[128 + lane] = v[2]; tile[192 + lane] = v[3];
@@ -486,40 +502,31 @@ __device__ __forceinline__ void tile_put(float* tile, f32x4 v, int lane) {
 __device__ __forceinline__ f32x4 tile_get(const float* tile, int lane) {
     return *reinterpret_cast<const f32x4*>(tile + (lane & 15) * 16 + 4 * (lane >> 4));
 }
-
-// acc[ob][ib] += sum_samples A_F[ob] (feature o, sample) * B_F[ib] (feature i, sample);  bsum[ob] += sum_s A
-template <int OB, int IB>
-__device__ __forceinline__ void wgrad(f32x4 (&acc)[OB][IB], float (&bsum)[OB], const float* tilesA,
-                                      const float* tilesB, int lane) {
-    f32x4 av[OB], bv[IB];
-#pragma unroll
-    for (int o = 0; o < OB; ++o) av[o] = tile_get(tilesA + o * 256, lane);
-#pragma unroll
-    for (int i = 0; i < IB; ++i) bv[i] = tile_get(tilesB + i * 256, lane);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int o = 0; o < OB; ++o)
-#pragma unroll
-            for (int i = 0; i < IB; ++i) acc[o][i] = mfma16(av[o][r], bv[i][r], acc[o][i]);
-#pragma unroll
-    for (int o = 0; o < OB; ++o) bsum[o] += (av[o][0] + av[o][1]) + (av[o][2] + av[o][3]);
+// Feature-on-lane read of block b of a stored register image (KS k-steps): lane (i, q') gets
+// feature 16b+i of samples 4q'..4q'+3.  Image element (ks, j + 16 q) = feature 4ks+q, sample j.
+template <int KS>
+__device__ __forceinline__ f32x4 image_get_F(const float* img, int b, int lane) {
+    const int i = lane & 15, qq = lane >> 4;
+    const int ks = 4 * b + (i >> 2);
+    const int ksc = ks < KS ? ks : KS - 1;            // clamped address, select below (no branch)
+    const f32x4 v = *reinterpret_cast<const f32x4*>(img + ksc * 64 + 16 * (i & 3) + 4 * qq);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return ks < KS ? v : z;
 }
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 template <int D, int H>
-__global__ __launch_bounds__(256) void hjb_bwd_kernel(const HjbArgs a) {
+__global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
+    constexpr int WH = G::WH, WD = G::WD, NIB = G::NIB, NOBD = G::NOBD, NOBH = G::NOBH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
+    const int wh = wave % WH, wd = wave / WH;
     const float* __restrict__ P = a.params;
 
-    stage_aop(lds + G::gW1, HB, KSD, tid, nthr, [&](int row, int col) {
-        return (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f; });
-    stage_aop(lds + G::gW2, HB, KSH, tid, nthr, [&](int row, int col) {
-        return (row < H && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
     // transposed tables for the data-gradient GEMMs: da1 = W2^T dz2, da2 = W3^T G
     stage_aop(lds + G::gW2T, HB, KSH, tid, nthr, [&](int row, int col) {
         return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
@@ -528,30 +535,27 @@ __global__ __launch_bounds__(256) void hjb_bwd_kernel(const HjbArgs a) {
     if (!a.adaptive)
         stage_aop(lds + G::gW3, DB, KSH, tid, nthr, [&](int row, int col) {
             return (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f; });
-    stage_vec(lds + G::gb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
-    stage_vec(lds + G::gw1t, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW1 + f * (D + 1)] : 0.f; });
-    stage_vec(lds + G::gb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
     stage_vec(lds + G::gb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
     __syncthreads();
 
-    const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::gVec) + q;
-    float* scr = lds + G::gScr + wave * (G::SCR_TILES * 256);   // two sides of SCR_HALF tiles each
-    float* scrA = scr;
-    float* scrB = scr + G::SCR_HALF * 256;
+    const f32x4* vb3_0 = reinterpret_cast<const f32x4*>(lds + G::gb3) + q;
+    float* exch = lds + G::gEx;                       // [4 waves][EXT tiles][256]
+    float* my_ex = exch + wave * (G::EXT * 256);
 
-    // persistent accumulators (register-resident for the whole kernel)
-    f32x4 acc3[DB][HB], acc2[HB][HB], acc1[HB][DB];
-    float bs3[DB], bs2[HB], bs1[HB], bt1[HB];
+    // accumulators: this wave's tiles only
+    f32x4 acc3[NOBD][NIB], acc2[NOBH][NIB], acc1[NIB][NOBD];
+    float bs3[NOBD], bs2[NOBH], bs1[NIB], bt1[NIB];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < DB; ++o) { bs3[o] = 0.f;
+    for (int s = 0; s < NOBD; ++s) { bs3[s] = 0.f;
 #pragma unroll
-        for (int i = 0; i < HB; ++i) acc3[o][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int t = 0; t < NIB; ++t) { acc3[s][t] = zero4; acc1[t][s] = zero4; } }
 #pragma unroll
-    for (int o = 0; o < HB; ++o) { bs2[o] = 0.f; bs1[o] = 0.f; bt1[o] = 0.f;
+    for (int s = 0; s < NOBH; ++s) { bs2[s] = 0.f;
 #pragma unroll
-        for (int i = 0; i < HB; ++i) acc2[o][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NIB; ++t) acc2[s][t] = zero4; }
 #pragma unroll
-        for (int i = 0; i < DB; ++i) acc1[o][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < NIB; ++t) { bs1[t] = 0.f; bt1[t] = 0.f; }
 
     const double invK = 1.0 / (double)a.K_global;
     const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
@@ -559,204 +563,210 @@ __global__ __launch_bounds__(256) void hjb_bwd_kernel(const HjbArgs a) {
     const float dt = a.dt, sqdt = a.sqdt;
 
     const long long nblk = (long long)a.N * a.ntile16;
-    const long long wstride = (long long)gridDim.x * nwave;
-    for (long long blk = (long long)blockIdx.x * nwave + wave; blk < nblk; blk += wstride) {
-        const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
-        const int k = t16 * 16 + j;
-        const bool kvalid = k < a.K_local;
-        const uint32_t kglob = (uint32_t)(a.k_offset + k);
-        const float tn = (float)n * dt;
-        const f32x4* vecs = opaque(vecs0);
-        const f32x4* vb1 = vecs + (G::gb1 - G::gVec) / 4;
-        const f32x4* vw1t = vecs + (G::gw1t - G::gVec) / 4;
-        const f32x4* vb2 = vecs + (G::gb2 - G::gVec) / 4;
-        const f32x4* vb3 = vecs + (G::gb3 - G::gVec) / 4;
-
-        // ---- reload X_n (T layout, lane-linear) and recompute hidden activations
-        f32x4 X[DB];
+    const long long nround = (nblk + 3) / 4;
+    for (long long round = blockIdx.x; round < nround; round += gridDim.x) {
+        // ------------------------------------------------------------------ P1: own block
         {
-            const float* src = a.path + (size_t)blk * (size_t)(KSD * 64) + lane;
+            const long long blk0 = round * 4 + wave;
+            const bool bvalid = blk0 < nblk;
+            const long long blk = bvalid ? blk0 : nblk - 1;
+            const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
+            const int k = t16 * 16 + j;
+            const bool kvalid = bvalid && k < a.K_local;
+            const uint32_t kglob = (uint32_t)(a.k_offset + k);
+            const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+            f32x4 h1[HB], h2[HB];
 #pragma unroll
-            for (int b = 0; b < DB; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[b][r] = (4 * b + r < KSD) ? src[(4 * b + r) * 64] : 0.f;
-        }
-        f32x4 h1[HB], h2[HB];
-#pragma unroll
-        for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
-        gemm_T<HB, KSD, DB>(h1, lds + G::gW1, X, lane);
-#pragma unroll
-        for (int m = 0; m < HB; ++m) h1[m] = tanh4(h1[m]);
-#pragma unroll
-        for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
-        gemm_T<HB, KSH, HB>(h2, lds + G::gW2, h1, lane);
-#pragma unroll
-        for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
-
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- upstream gradient G = w_k ((Z + c) dt + xi sqrt(dt))   (T layout)
-        const float wk = kvalid ? coef * (a.D[k] - meanD) : 0.f;
-        f32x4 Gt[DB];
-#pragma unroll
-        for (int m = 0; m < DB; ++m) Gt[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!a.adaptive) {                                       // c = 0: the Z dt term survives
-#pragma unroll
-            for (int m = 0; m < DB; ++m) Gt[m] = vb3[m * 4];
-            gemm_T<DB, KSH, HB>(Gt, lds + G::gW3, h2, lane);     // Z
-        }
-#pragma unroll
-        for (int b = 0; b < DB; ++b) {
-            f32x4 xi;
-            if (a.noise_mode == NOISE_PHILOX) {
-                xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
-            } else {
-                const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
+            for (int m = 0; m < HB; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int f = 16 * b + 4 * r + q;
-                    const float v = xrow[f < D ? f : D - 1];
-                    xi[r] = (f < D && kvalid) ? v : 0.f;
+                    const int ks = 4 * m + r;
+                    h1[m][r] = ks < KSH ? pb[G::pH1 + ks * 64] : 0.f;
+                    h2[m][r] = ks < KSH ? pb[G::pH2 + ks * 64] : 0.f;
+                }
+            const float wk = kvalid ? coef * (a.D[kvalid ? k : 0] - meanD) : 0.f;
+            f32x4 Gt[DB];
+#pragma unroll
+            for (int m = 0; m < DB; ++m) Gt[m] = zero4;
+            if (!a.adaptive) {                                   // c = 0: the Z dt term survives
+                const f32x4* vb3 = opaque(vb3_0);
+#pragma unroll
+                for (int m = 0; m < DB; ++m) Gt[m] = vb3[m * 4];
+                gemm_T<DB, KSH, HB>(Gt, lds + G::gW3, h2, lane);   // Z = W3 h2 + b3
+            }
+#pragma unroll
+            for (int b = 0; b < DB; ++b) {
+                f32x4 xi;
+                if (a.noise_mode == NOISE_PHILOX) {
+                    xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
+                } else {
+                    const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 16 * b + 4 * r + q;
+                        const float v = xrow[f < D ? f : D - 1];
+                        xi[r] = (f < D && kvalid) ? v : 0.f;
+                    }
+                }
+                if (16 * b + 16 > D) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
+                }
+                Gt[b] = wk * (dt * Gt[b] + sqdt * xi);
+            }
+            f32x4 dz2[HB], dz1[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz2[m] = zero4;
+            gemm_T<HB, KSD, DB>(dz2, lds + G::gW3T, Gt, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz1[m] = zero4;
+            gemm_T<HB, KSH, HB>(dz1, lds + G::gW2T, dz2, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
+
+            // G panel -> exchange tiles [0, DB)
+#pragma unroll
+            for (int b = 0; b < DB; ++b) tile_put(my_ex + b * 256, Gt[b], lane);
+            __syncthreads();
+            // -------------------------------------------------------------- P2: dW3, db3
+#pragma unroll 1
+            for (int sb = 0; sb < 4; ++sb) {
+                const long long sblk0 = round * 4 + sb;
+                const long long sblk = sblk0 < nblk ? sblk0 : nblk - 1;
+                const float* sp = a.path + (size_t)sblk * (size_t)G::PB;
+                const float* ex = exch + sb * (G::EXT * 256);
+                f32x4 bv[NIB];
+#pragma unroll
+                for (int t = 0; t < NIB; ++t) {
+                    const int ib = wh + WH * t;
+                    bv[t] = image_get_F<KSH>(sp + G::pH2, ib < HB ? ib : 0, lane);
+                }
+#pragma unroll
+                for (int s = 0; s < NOBD; ++s) {
+                    const int ob = wd + WD * s;
+                    if (ob < DB) {
+                        const f32x4 av = tile_get(ex + ob * 256, lane);
+                        bs3[s] += hsum4(av);
+#pragma unroll
+                        for (int t = 0; t < NIB; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc3[s][t] = mfma16(av[r], bv[t][r], acc3[s][t]);
+                    }
                 }
             }
-            if (16 * b + 16 > D) {
+            __syncthreads();                             // everyone is done with the G tiles
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
+            for (int m = 0; m < HB; ++m) {
+                tile_put(my_ex + m * 256, dz2[m], lane);
+                tile_put(my_ex + (HB + m) * 256, dz1[m], lane);
             }
-            Gt[b] = wk * (dt * Gt[b] + sqdt * xi);
+            __syncthreads();
         }
-
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- layer 3: da2 = W3^T G ; dW3 += G^T h2 ; db3 += sum G
-        f32x4 dz2[HB];
+        // ------------------------------------------------------------------ P3: dW2, db2, dW1, db1, dW1[:,0]
+#pragma unroll 1
+        for (int sb = 0; sb < 4; ++sb) {
+            const long long sblk0 = round * 4 + sb;
+            const long long sblk = sblk0 < nblk ? sblk0 : nblk - 1;
+            const float tn = (float)((int)(sblk / a.ntile16)) * dt;
+            const float* sp = a.path + (size_t)sblk * (size_t)G::PB;
+            const float* ex = exch + sb * (G::EXT * 256);
+            {   // layer 2: rows = dz2 blocks (WD axis), cols = h1 blocks (WH axis)
+                f32x4 bv[NIB];
 #pragma unroll
-        for (int m = 0; m < HB; ++m) dz2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        gemm_T<HB, KSD, DB>(dz2, lds + G::gW3T, Gt, lane);
+                for (int t = 0; t < NIB; ++t) {
+                    const int ib = wh + WH * t;
+                    bv[t] = image_get_F<KSH>(sp + G::pH1, ib < HB ? ib : 0, lane);
+                }
 #pragma unroll
-        for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+                for (int s = 0; s < NOBH; ++s) {
+                    const int ob = wd + WD * s;
+                    if (ob < HB) {
+                        const f32x4 av = tile_get(ex + ob * 256, lane);
+                        bs2[s] += hsum4(av);
 #pragma unroll
-        for (int b = 0; b < DB; ++b) tile_put(scrA + b * 256, Gt[b], lane);
+                        for (int t = 0; t < NIB; ++t)
 #pragma unroll
-        for (int m = 0; m < HB; ++m) tile_put(scrB + m * 256, h2[m], lane);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        wgrad<DB, HB>(acc3, bs3, scrA, scrB, lane);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- layer 2: da1 = W2^T dz2 ; dW2 += dz2^T h1 ; db2 += sum dz2
-        f32x4 dz1[HB];
+                            for (int r = 0; r < 4; ++r) acc2[s][t] = mfma16(av[r], bv[t][r], acc2[s][t]);
+                    }
+                }
+            }
+            {   // layer 1: rows = dz1 blocks (WH axis), cols = X_n blocks (WD axis)
+                f32x4 av[NIB];
 #pragma unroll
-        for (int m = 0; m < HB; ++m) dz1[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        gemm_T<HB, KSH, HB>(dz1, lds + G::gW2T, dz2, lane);
+                for (int t = 0; t < NIB; ++t) {
+                    const int ob = wh + WH * t;
+                    av[t] = tile_get(ex + (HB + (ob < HB ? ob : 0)) * 256, lane);
+                    const float sv = hsum4(av[t]);
+                    bs1[t] += sv;
+                    bt1[t] = fmaf(tn, sv, bt1[t]);
+                }
 #pragma unroll
-        for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
+                for (int s = 0; s < NOBD; ++s) {
+                    const int ib = wd + WD * s;
+                    if (ib < DB) {
+                        const f32x4 bx = image_get_F<KSD>(sp + G::pX, ib, lane);
 #pragma unroll
-        for (int m = 0; m < HB; ++m) tile_put(scrA + m * 256, dz2[m], lane);
+                        for (int t = 0; t < NIB; ++t)
 #pragma unroll
-        for (int m = 0; m < HB; ++m) tile_put(scrB + m * 256, h1[m], lane);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        wgrad<HB, HB>(acc2, bs2, scrA, scrB, lane);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- layer 1: dW1[:,1:] += dz1^T X ; db1 += sum dz1 ; dW1[:,0] += t_n sum dz1
-        {   // X_n is re-read (L2-hot) rather than held in 4*DB registers across the whole block
-            const float* src = opaque(a.path + (size_t)blk * (size_t)(KSD * 64) + lane);
-#pragma unroll
-            for (int ks = 0; ks < 4 * DB; ++ks)
-                scrA[ks * 64 + lane] = (ks < KSD) ? src[ks * 64] : 0.f;
+                            for (int r = 0; r < 4; ++r) acc1[t][s] = mfma16(av[t][r], bx[r], acc1[t][s]);
+                    }
+                }
+            }
         }
-#pragma unroll
-        for (int m = 0; m < HB; ++m) tile_put(scrB + m * 256, dz1[m], lane);
-        __builtin_amdgcn_wave_barrier();
-        float bsl[HB];
-#pragma unroll
-        for (int m = 0; m < HB; ++m) bsl[m] = 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-        wgrad<HB, DB>(acc1, bsl, scrB, scrA, lane);
-#pragma unroll
-        for (int m = 0; m < HB; ++m) { bs1[m] += bsl[m]; bt1[m] = fmaf(tn, bsl[m], bt1[m]); }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();                                 // exchange tiles are rewritten next round
     }
 
-    // ---- cross-wave reduction through LDS in register-native order (deterministic), then
-    //      scatter into the torch flat layout of this workgroup's partial gradient
-    __syncthreads();                                   // weights / scratch no longer needed
-    float* img = lds;                                  // ACC_FLOATS
-    float* img3 = img, *img2 = img3 + G::NT3 * 256, *img1 = img2 + G::NT2 * 256;
-    float* imgb = img1 + G::NT1 * 256;                 // bs3 (DB*16) bs2 bs1 bt1 (HB*16 each)
-#pragma unroll
-    for (int o = 0; o < DB; ++o) bs3[o] = qsum(bs3[o]);
-#pragma unroll
-    for (int o = 0; o < HB; ++o) { bs2[o] = qsum(bs2[o]); bs1[o] = qsum(bs1[o]); bt1[o] = qsum(bt1[o]); }
-    for (int w = 0; w < nwave; ++w) {
-        if (wave == w) {
-            const bool first = (w == 0);
-#pragma unroll
-            for (int o = 0; o < DB; ++o)
-#pragma unroll
-                for (int i = 0; i < HB; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float* p = img3 + ((o * HB + i) * 4 + r) * 64 + lane;
-                        *p = first ? acc3[o][i][r] : (*p + acc3[o][i][r]);
-                    }
-#pragma unroll
-            for (int o = 0; o < HB; ++o)
-#pragma unroll
-                for (int i = 0; i < HB; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float* p = img2 + ((o * HB + i) * 4 + r) * 64 + lane;
-                        *p = first ? acc2[o][i][r] : (*p + acc2[o][i][r]);
-                    }
-#pragma unroll
-            for (int o = 0; o < HB; ++o)
-#pragma unroll
-                for (int i = 0; i < DB; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float* p = img1 + ((o * DB + i) * 4 + r) * 64 + lane;
-                        *p = first ? acc1[o][i][r] : (*p + acc1[o][i][r]);
-                    }
-            if (q == 0) {
-#pragma unroll
-                for (int o = 0; o < DB; ++o) {
-                    float* p = imgb + o * 16 + j; *p = first ? bs3[o] : (*p + bs3[o]);
-                }
-#pragma unroll
-                for (int o = 0; o < HB; ++o) {
-                    float* p2 = imgb + DB * 16 + o * 16 + j; *p2 = first ? bs2[o] : (*p2 + bs2[o]);
-                    float* p1 = imgb + (DB + HB) * 16 + o * 16 + j; *p1 = first ? bs1[o] : (*p1 + bs1[o]);
-                    float* pt = imgb + (DB + 2 * HB) * 16 + o * 16 + j; *pt = first ? bt1[o] : (*pt + bt1[o]);
-                }
-            }
-        }
-        __syncthreads();
-    }
+    // ---- write this wave's tiles into the workgroup's partial gradient (torch flat layout).
     // D tile (ob, ib): lane (col = l&15, qq = l>>4), reg rr  <->  dW[16 ob + 4 qq + rr][16 ib + col]
     float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
-    for (int idx = tid; idx < G::NT3 * 256; idx += nthr) {
-        const int l = idx & 63, rr = (idx >> 6) & 3, t = idx >> 8, ib = t % HB, ob = t / HB;
-        const int o = 16 * ob + 4 * (l >> 4) + rr, i = 16 * ib + (l & 15);
-        if (o < D && i < H) gp[G::oW3 + o * H + i] = img3[idx];
+    const int col = lane & 15, qq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NOBD; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int ob = wd + WD * s, ib = wh + WH * t;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int o3 = 16 * ob + 4 * qq + rr, i3 = 16 * ib + col;       // dW3[o in d][i in H]
+                if (ob < DB && ib < HB && o3 < D && i3 < H) gp[G::oW3 + o3 * H + i3] = acc3[s][t][rr];
+                const int o1 = 16 * ib + 4 * qq + rr, i1 = 16 * ob + col;       // dW1[o in H][i in d] (acc1[t][s])
+                if (ob < DB && ib < HB && o1 < H && i1 < D) gp[G::oW1 + o1 * (D + 1) + 1 + i1] = acc1[t][s][rr];
+            }
+        }
+#pragma unroll
+    for (int s = 0; s < NOBH; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int ob = wd + WD * s, ib = wh + WH * t;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int o2 = 16 * ob + 4 * qq + rr, i2 = 16 * ib + col;
+                if (ob < HB && ib < HB && o2 < H && i2 < H) gp[G::oW2 + o2 * H + i2] = acc2[s][t][rr];
+            }
+        }
+    // bias sums live on lane i = feature (q' partial sums): reduce over q', lanes q' == 0 write
+#pragma unroll
+    for (int s = 0; s < NOBD; ++s) {
+        const float v = qsum(bs3[s]);
+        const int f = 16 * (wd + WD * s) + col;
+        if (wh == 0 && qq == 0 && (wd + WD * s) < DB && f < D) gp[G::ob3 + f] = v;
     }
-    for (int idx = tid; idx < G::NT2 * 256; idx += nthr) {
-        const int l = idx & 63, rr = (idx >> 6) & 3, t = idx >> 8, ib = t % HB, ob = t / HB;
-        const int o = 16 * ob + 4 * (l >> 4) + rr, i = 16 * ib + (l & 15);
-        if (o < H && i < H) gp[G::oW2 + o * H + i] = img2[idx];
+#pragma unroll
+    for (int s = 0; s < NOBH; ++s) {
+        const float v = qsum(bs2[s]);
+        const int f = 16 * (wd + WD * s) + col;
+        if (wh == 0 && qq == 0 && (wd + WD * s) < HB && f < H) gp[G::ob2 + f] = v;
     }
-    for (int idx = tid; idx < G::NT1 * 256; idx += nthr) {
-        const int l = idx & 63, rr = (idx >> 6) & 3, t = idx >> 8, ib = t % DB, ob = t / DB;
-        const int o = 16 * ob + 4 * (l >> 4) + rr, i = 16 * ib + (l & 15);
-        if (o < H && i < D) gp[G::oW1 + o * (D + 1) + 1 + i] = img1[idx];
-    }
-    for (int f = tid; f < D; f += nthr) gp[G::ob3 + f] = imgb[f];
-    for (int f = tid; f < H; f += nthr) {
-        gp[G::ob2 + f] = imgb[DB * 16 + f];
-        gp[G::ob1 + f] = imgb[(DB + HB) * 16 + f];
-        gp[G::oW1 + f * (D + 1)] = imgb[(DB + 2 * HB) * 16 + f];
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) {
+        const float v1 = qsum(bs1[t]), vt = qsum(bt1[t]);
+        const int f = 16 * (wh + WH * t) + col;
+        if (wd == 0 && qq == 0 && (wh + WH * t) < HB && f < H) {
+            gp[G::ob1 + f] = v1;
+            gp[G::oW1 + f * (D + 1)] = vt;
+        }
     }
 }
 
@@ -767,7 +777,7 @@ struct HjbInstance {
     int (*bwd_lds_bytes)(int adaptive);
     hipError_t (*launch_fwd)(const HjbArgs&, int grid, int block, hipStream_t);
     hipError_t (*launch_bwd)(const HjbArgs&, int grid, int block, hipStream_t);
-    int path_floats_per_tile_step;   // KSD * 64
+    int path_floats_per_tile_step;   // Geo::PB
 };
 
 template <int D, int H>
@@ -792,7 +802,7 @@ struct HjbLaunch {
         return hipGetLastError();
     }
     static HjbInstance instance() {
-        return HjbInstance{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::KSD * 64};
+        return HjbInstance{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::PB};
     }
 };
 

@@ -80,11 +80,13 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     if (fw > 8) fw = 8;
     p->fwd_waves = fw;
     p->fwd_grid = (p->ntile16 + fw - 1) / fw;
-    // backward: persistent, one 4-wave workgroup per CU (LDS-limited), fewer when there is little work
+    // backward: persistent over rounds of 4 sample blocks; 4-wave workgroups, two per CU
+    // (<= 256 VGPRs and <= 80 KiB LDS each), fewer when there is little work
     const long long nblk = (long long)c->N * p->ntile16;
+    const long long nround = (nblk + 3) / 4;
     p->bwd_waves = 4;
-    long long g = (nblk + p->bwd_waves - 1) / p->bwd_waves;
-    if (g > cus) g = cus;
+    long long g = nround;
+    if (g > 2LL * cus) g = 2LL * cus;
     if (g < 1) g = 1;
     p->bwd_grid = (int)g;
     return 0;
