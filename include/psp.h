@@ -140,6 +140,11 @@ int psp_philox_normal_fill(float* out, int32_t N, int32_t K_local, int32_t d, in
 int psp_hjb_control_eval(int32_t d, int32_t H, const float* params, const float* X, int32_t K, float t,
                          float* minus_Z_out, void* stream);
 
+/* Diagnostics: device buffer that receives per-wave phase cycle sums (8 u64 per wave of the
+ * backward kernel).  Returns 1 if the library was built with -DPSP_STAMPS (diagnostic build,
+ * never the shipped one), 0 otherwise (the pointer is then ignored). NULL clears it. */
+int psp_debug_set_stamp_buffer(unsigned long long* buf, int64_t n_entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,7 +55,21 @@ def _compile(src, obj, defs, deps, force):
     return obj, True
 
 
-def build(force=False, jobs=None, verbose=True):
+def build(force=False, jobs=None, verbose=True, extra_flags=(), lib_path=None, obj_dir=None, only=None):
+    """extra_flags / lib_path / obj_dir / only=[(d,H)..] are for diagnostic variants (e.g.
+    -DPSP_STAMPS into csrc/libpsp_hip_stamps.so); the default call builds the shipped library."""
+    global FLAGS, OBJ, LIB
+    saved = (FLAGS, OBJ, LIB)
+    FLAGS = FLAGS + list(extra_flags)
+    OBJ = obj_dir or OBJ
+    LIB = lib_path or LIB
+    try:
+        return _build(force, jobs, verbose, only)
+    finally:
+        FLAGS, OBJ, LIB = saved
+
+
+def _build(force, jobs, verbose, only):
     os.makedirs(OBJ, exist_ok=True)
     hdr = os.path.join(CSRC, "hjb_kernels.h")
     inc = os.path.join(HERE, "..", "include", "psp.h")

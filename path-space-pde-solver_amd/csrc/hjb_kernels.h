@@ -37,6 +37,7 @@ struct HjbArgs {
     const float* term;
     const double* sums;
     float* grad_partial;
+    unsigned long long* dbg;   // diagnostic builds (-DPSP_STAMPS): per-wave phase cycle sums
     long long k_offset;
     long long K_global;
     int x0_stride;
@@ -61,6 +62,22 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// In-kernel phase stamps (diagnostic build only; the shipped kernels execute none of this).
+#ifdef PSP_STAMPS
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PSP_STAMP(var) const unsigned long long var = stamp_now()
+#define PSP_ACC(slot, t1, t0) stamps[slot] += (t1) - (t0)
+#else
+#define PSP_STAMP(var)
+#define PSP_ACC(slot, t1, t0)
+#endif
 
 // Makes a pointer value opaque to the optimiser at this program point.  Used inside the time /
 // sample loops so that loop-invariant LDS reads (bias vectors, cost vectors) are re-issued per
@@ -145,6 +162,8 @@ __device__ __forceinline__ void stage_vec(float* dst, int NBLK, int tid, int nth
 // mask lets VALU / SALU / VMEM cross (tanh, Philox, address math fill the MFMA shadows) but not
 // DS reads or MFMAs.  Prefetch distance = CH*MB MFMAs x 32 cycles >= one LDS round trip.
 constexpr int kFenceMask = 0x1 | 0x2 | 0x4 | 0x10 | 0x20 | 0x40;
+// fence for sample-block boundaries: only VALU / SALU may cross (pins VMEM, DS and MFMA order)
+constexpr int kFenceAluOnly = 0x2 | 0x4;
 template <int MB, int KS, int INB>
 __device__ __forceinline__ void gemm_T(f32x4 (&acc)[MB], const float* __restrict__ wlds,
                                        const f32x4 (&in)[INB], int lane) {
@@ -237,8 +256,10 @@ struct Geo {
     static int fwd_lds_floats(int drift_kind, int sigma_kind) {
         return fA + (drift_kind == DRIFT_DENSE ? fB_dense_off : 0) + (sigma_kind == SIGMA_DENSE ? fB_dense_off : 0);
     }
-    // path store: one block per (step n, 16-trajectory tile): register images of X_n, h1, h2
-    static constexpr int pX = 0, pH1 = KSD * 64, pH2 = pH1 + KSH * 64, PB = pH2 + KSH * 64;
+    // path store: one block per (step n, 16-trajectory tile): register images of X_n, h1, h2,
+    // each padded to whole 16-feature blocks (padded k-steps hold zeros) so that the backward
+    // kernel's feature-on-lane reads need neither clamping nor masking
+    static constexpr int pX = 0, pH1 = 4 * DB * 64, pH2 = pH1 + 4 * HB * 64, PB = pH2 + 4 * HB * 64;
     // backward: 4 waves per workgroup arranged WH x WD over the (H-blocks x other-blocks) tile grids
     static constexpr int WH = (HB >= 4) ? 4 : (HB >= 2 ? 2 : 1);
     static constexpr int WD = 4 / WH;
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             float* pblk = a.path + ((size_t)n * a.ntile16 + t16) * (size_t)G::PB + lane;
             if (a.store_path) {
 #pragma unroll
-                for (int ks = 0; ks < KSD; ++ks) pblk[(G::pX / 64 + ks) * 64] = X[ks >> 2][ks & 3];
+                for (int ks = 0; ks < 4 * DB; ++ks) pblk[(G::pX / 64 + ks) * 64] = X[ks >> 2][ks & 3];
             }
             // ---- control net: Z = W3 tanh(W2 tanh(W1 [t,x] + b1) + b2) + b3 (function_space.py:190-195)
             f32x4 h1[HB];
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
             if (a.store_path) {                        // hidden activations for the backward pass (no recompute)
 #pragma unroll
-                for (int ks = 0; ks < KSH; ++ks) {
+                for (int ks = 0; ks < 4 * HB; ++ks) {
                     pblk[(G::pH1 / 64 + ks) * 64] = h1[ks >> 2][ks & 3];
                     pblk[(G::pH2 / 64 + ks) * 64] = h2[ks >> 2][ks & 3];
                 }
@@ -502,16 +523,15 @@ __device__ __forceinline__ void tile_put(float* tile, f32x4 v, int lane) {
 __device__ __forceinline__ f32x4 tile_get(const float* tile, int lane) {
     return *reinterpret_cast<const f32x4*>(tile + (lane & 15) * 16 + 4 * (lane >> 4));
 }
-// Feature-on-lane read of block b of a stored register image (KS k-steps): lane (i, q') gets
-// feature 16b+i of samples 4q'..4q'+3.  Image element (ks, j + 16 q) = feature 4ks+q, sample j.
-template <int KS>
-__device__ __forceinline__ f32x4 image_get_F(const float* img, int b, int lane) {
+// Feature-on-lane read of one 16-feature block (1 KiB, wave-uniform pointer) of a stored register
+// image: lane (i, q') gets feature i of samples 4q'..4q'+3.  Image element (ks, j + 16 q) = feature
+// 4ks+q, sample j, so the lane offset is 64 (i>>2) + 16 (i&3) + 4 q' floats -- the same for every block.
+__device__ __forceinline__ int image_lane_offset_F(int lane) {
     const int i = lane & 15, qq = lane >> 4;
-    const int ks = 4 * b + (i >> 2);
-    const int ksc = ks < KS ? ks : KS - 1;            // clamped address, select below (no branch)
-    const f32x4 v = *reinterpret_cast<const f32x4*>(img + ksc * 64 + 16 * (i & 3) + 4 * qq);
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    return ks < KS ? v : z;
+    return 64 * (i >> 2) + 16 * (i & 3) + 4 * qq;
+}
+__device__ __forceinline__ f32x4 image_get_F(const float* block, int lofs) {
+    return *reinterpret_cast<const f32x4*>(block + lofs);
 }
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
@@ -524,7 +544,9 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int wh = wave % WH, wd = wave / WH;
+    // wave grid coordinates; compile-time zero along a 1-wide axis so tile validity folds statically
+    const int wh = (WH == 1) ? 0 : wave % WH, wd = (WD == 1) ? 0 : wave / WH;
+    const int lofsF = image_lane_offset_F(lane);
     const float* __restrict__ P = a.params;
 
     // transposed tables for the data-gradient GEMMs: da1 = W2^T dz2, da2 = W3^T G
@@ -564,7 +586,23 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
 
     const long long nblk = (long long)a.N * a.ntile16;
     const long long nround = (nblk + 3) / 4;
+#ifdef PSP_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (long long round = blockIdx.x; round < nround; round += gridDim.x) {
+        PSP_STAMP(ts0);
+        // L2 touch-prefetch (one dword per 128-B line, value unused): this round's X_n panels are
+        // first read in P3 and the NEXT round's h1/h2 panels in its P1 -- both would otherwise be
+        // ~2 us HBM first-touch misses that a one-block register prefetch cannot cover.
+        float touch0, touch1;
+        {
+            const long long xb0 = round * 4 + wave;                         // wave w touches block w's X_n
+            const float* xt = a.path + (size_t)(xb0 < nblk ? xb0 : nblk - 1) * (size_t)G::PB + G::pX;
+            touch0 = xt[(lane * 32 < 4 * DB * 64) ? lane * 32 : 0];
+            const long long nb0 = (round + gridDim.x) * 4 + wave;           // own block of the next round
+            const float* ht = a.path + (size_t)(nb0 < nblk ? nb0 : nblk - 1) * (size_t)G::PB + G::pH1;
+            touch1 = ht[(lane * 32 < 8 * HB * 64) ? lane * 32 : 0];
+        }
         // ------------------------------------------------------------------ P1: own block
         {
             const long long blk0 = round * 4 + wave;
@@ -575,24 +613,20 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
             const bool kvalid = bvalid && k < a.K_local;
             const uint32_t kglob = (uint32_t)(a.k_offset + k);
             const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
-            f32x4 h1[HB], h2[HB];
-#pragma unroll
-            for (int m = 0; m < HB; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ks = 4 * m + r;
-                    h1[m][r] = ks < KSH ? pb[G::pH1 + ks * 64] : 0.f;
-                    h2[m][r] = ks < KSH ? pb[G::pH2 + ks * 64] : 0.f;
-                }
             const float wk = kvalid ? coef * (a.D[kvalid ? k : 0] - meanD) : 0.f;
             f32x4 Gt[DB];
 #pragma unroll
             for (int m = 0; m < DB; ++m) Gt[m] = zero4;
             if (!a.adaptive) {                                   // c = 0: the Z dt term survives
                 const f32x4* vb3 = opaque(vb3_0);
+                f32x4 h2z[HB];
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h2z[m][r] = pb[G::pH2 + (4 * m + r) * 64];
 #pragma unroll
                 for (int m = 0; m < DB; ++m) Gt[m] = vb3[m * 4];
-                gemm_T<DB, KSH, HB>(Gt, lds + G::gW3, h2, lane);   // Z = W3 h2 + b3
+                gemm_T<DB, KSH, HB>(Gt, lds + G::gW3, h2z, lane);  // Z = W3 h2 + b3
             }
 #pragma unroll
             for (int b = 0; b < DB; ++b) {
@@ -614,48 +648,86 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
                 }
                 Gt[b] = wk * (dt * Gt[b] + sqdt * xi);
             }
+            // h2 / h1 are fetched right before the GEMM whose epilogue consumes them: the GEMM
+            // (100 / 64 MFMAs) covers the load latency and the panels are not live during Philox
             f32x4 dz2[HB], dz1[HB];
+            {
+                f32x4 h2[HB];
 #pragma unroll
-            for (int m = 0; m < HB; ++m) dz2[m] = zero4;
-            gemm_T<HB, KSD, DB>(dz2, lds + G::gW3T, Gt, lane);
+                for (int m = 0; m < HB; ++m)
 #pragma unroll
-            for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+                    for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
 #pragma unroll
-            for (int m = 0; m < HB; ++m) dz1[m] = zero4;
-            gemm_T<HB, KSH, HB>(dz1, lds + G::gW2T, dz2, lane);
+                for (int m = 0; m < HB; ++m) dz2[m] = zero4;
+                gemm_T<HB, KSD, DB>(dz2, lds + G::gW3T, Gt, lane);
 #pragma unroll
-            for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
-
-            // G panel -> exchange tiles [0, DB)
+                for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+            }
+            // G panel -> exchange tiles [0, DB) (done here so Gt dies before the next GEMM)
 #pragma unroll
             for (int b = 0; b < DB; ++b) tile_put(my_ex + b * 256, Gt[b], lane);
+            {
+                f32x4 h1[HB];
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h1[m][r] = pb[G::pH1 + (4 * m + r) * 64];
+#pragma unroll
+                for (int m = 0; m < HB; ++m) dz1[m] = zero4;
+                gemm_T<HB, KSH, HB>(dz1, lds + G::gW2T, dz2, lane);
+#pragma unroll
+                for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
+            }
+
+            PSP_STAMP(ts1);
             __syncthreads();
+            PSP_STAMP(ts2);
+            PSP_ACC(0, ts1, ts0);   // P1 compute
+            PSP_ACC(1, ts2, ts1);   // barrier A
             // -------------------------------------------------------------- P2: dW3, db3
-#pragma unroll 1
-            for (int sb = 0; sb < 4; ++sb) {
-                const long long sblk0 = round * 4 + sb;
-                const long long sblk = sblk0 < nblk ? sblk0 : nblk - 1;
-                const float* sp = a.path + (size_t)sblk * (size_t)G::PB;
-                const float* ex = exch + sb * (G::EXT * 256);
-                f32x4 bv[NIB];
+            // (tile indices are clamped, never branched on: out-of-range tiles accumulate into
+            //  registers that are not written back).  Rolled loop, operands of block sb+1 are
+            //  requested before the MFMAs of block sb.
+            {
+                int ibc[NIB], obc[NOBD];
 #pragma unroll
-                for (int t = 0; t < NIB; ++t) {
-                    const int ib = wh + WH * t;
-                    bv[t] = image_get_F<KSH>(sp + G::pH2, ib < HB ? ib : 0, lane);
+                for (int t = 0; t < NIB; ++t) ibc[t] = ((wh + WH * t) < HB ? (wh + WH * t) : HB - 1) * 256;
+#pragma unroll
+                for (int s2 = 0; s2 < NOBD; ++s2) obc[s2] = ((wd + WD * s2) < DB ? (wd + WD * s2) : DB - 1) * 256;
+                const long long rb = round * 4;
+                f32x4 bnext[NIB];
+                {
+                    const float* sp = a.path + (size_t)(rb < nblk ? rb : nblk - 1) * (size_t)G::PB + G::pH2;
+#pragma unroll
+                    for (int t = 0; t < NIB; ++t) bnext[t] = image_get_F(sp + ibc[t], lofsF);
                 }
+#pragma unroll 1
+                for (int sb = 0; sb < 4; ++sb) {
+                    const float* ex = exch + sb * (G::EXT * 256);
+                    f32x4 bv[NIB], av[NOBD];
 #pragma unroll
-                for (int s = 0; s < NOBD; ++s) {
-                    const int ob = wd + WD * s;
-                    if (ob < DB) {
-                        const f32x4 av = tile_get(ex + ob * 256, lane);
-                        bs3[s] += hsum4(av);
+                    for (int t = 0; t < NIB; ++t) bv[t] = bnext[t];
+                    {
+                        const long long nb = rb + (sb < 3 ? sb + 1 : sb);
+                        const float* sp = a.path + (size_t)(nb < nblk ? nb : nblk - 1) * (size_t)G::PB + G::pH2;
 #pragma unroll
-                        for (int t = 0; t < NIB; ++t)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc3[s][t] = mfma16(av[r], bv[t][r], acc3[s][t]);
+                        for (int t = 0; t < NIB; ++t) bnext[t] = image_get_F(sp + ibc[t], lofsF);
                     }
+                    __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued before the work below
+#pragma unroll
+                    for (int s2 = 0; s2 < NOBD; ++s2) {
+                        av[s2] = tile_get(ex + obc[s2], lane);
+                        bs3[s2] += hsum4(av[s2]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int s2 = 0; s2 < NOBD; ++s2)
+#pragma unroll
+                            for (int t = 0; t < NIB; ++t) acc3[s2][t] = mfma16(av[s2][r], bv[t][r], acc3[s2][t]);
                 }
             }
+            PSP_STAMP(ts3);
             __syncthreads();                             // everyone is done with the G tiles
 #pragma unroll
             for (int m = 0; m < HB; ++m) {
@@ -663,60 +735,93 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
                 tile_put(my_ex + (HB + m) * 256, dz1[m], lane);
             }
             __syncthreads();
+            PSP_STAMP(ts4);
+            PSP_ACC(2, ts3, ts2);   // P2 compute
+            PSP_ACC(3, ts4, ts3);   // barriers B + C + dz exchange
         }
+        PSP_STAMP(ts5);
         // ------------------------------------------------------------------ P3: dW2, db2, dW1, db1, dW1[:,0]
-#pragma unroll 1
-        for (int sb = 0; sb < 4; ++sb) {
-            const long long sblk0 = round * 4 + sb;
-            const long long sblk = sblk0 < nblk ? sblk0 : nblk - 1;
-            const float tn = (float)((int)(sblk / a.ntile16)) * dt;
-            const float* sp = a.path + (size_t)sblk * (size_t)G::PB;
-            const float* ex = exch + sb * (G::EXT * 256);
-            {   // layer 2: rows = dz2 blocks (WD axis), cols = h1 blocks (WH axis)
-                f32x4 bv[NIB];
+        {
+            int ibc[NIB], xbc[NOBD], o2c[NOBH], o1c[NIB];
 #pragma unroll
-                for (int t = 0; t < NIB; ++t) {
-                    const int ib = wh + WH * t;
-                    bv[t] = image_get_F<KSH>(sp + G::pH1, ib < HB ? ib : 0, lane);
-                }
-#pragma unroll
-                for (int s = 0; s < NOBH; ++s) {
-                    const int ob = wd + WD * s;
-                    if (ob < HB) {
-                        const f32x4 av = tile_get(ex + ob * 256, lane);
-                        bs2[s] += hsum4(av);
-#pragma unroll
-                        for (int t = 0; t < NIB; ++t)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc2[s][t] = mfma16(av[r], bv[t][r], acc2[s][t]);
-                    }
-                }
+            for (int t = 0; t < NIB; ++t) {
+                const int hb = (wh + WH * t) < HB ? (wh + WH * t) : HB - 1;
+                ibc[t] = hb * 256;
+                o1c[t] = (HB + hb) * 256;
             }
-            {   // layer 1: rows = dz1 blocks (WH axis), cols = X_n blocks (WD axis)
-                f32x4 av[NIB];
+#pragma unroll
+            for (int s2 = 0; s2 < NOBD; ++s2) xbc[s2] = ((wd + WD * s2) < DB ? (wd + WD * s2) : DB - 1) * 256;
+#pragma unroll
+            for (int s2 = 0; s2 < NOBH; ++s2) o2c[s2] = ((wd + WD * s2) < HB ? (wd + WD * s2) : HB - 1) * 256;
+            const long long rb = round * 4;
+            f32x4 hnext[NIB], xnext[NOBD];
+            {
+                const float* sp = a.path + (size_t)(rb < nblk ? rb : nblk - 1) * (size_t)G::PB;
+#pragma unroll
+                for (int t = 0; t < NIB; ++t) hnext[t] = image_get_F(sp + G::pH1 + ibc[t], lofsF);
+#pragma unroll
+                for (int s2 = 0; s2 < NOBD; ++s2) xnext[s2] = image_get_F(sp + G::pX + xbc[s2], lofsF);
+            }
+#pragma unroll 1
+            for (int sb = 0; sb < 4; ++sb) {
+                const long long cb = (rb + sb) < nblk ? (rb + sb) : nblk - 1;
+                const float tn = (float)((int)(cb / a.ntile16)) * dt;
+                const float* ex = exch + sb * (G::EXT * 256);
+                f32x4 hv[NIB], xv[NOBD], a2[NOBH], a1[NIB];
+#pragma unroll
+                for (int t = 0; t < NIB; ++t) hv[t] = hnext[t];
+#pragma unroll
+                for (int s2 = 0; s2 < NOBD; ++s2) xv[s2] = xnext[s2];
+                {   // next block's h1 / X_n panels (L2 after the touch-prefetch)
+                    const long long nb = rb + (sb < 3 ? sb + 1 : sb);
+                    const float* sp = a.path + (size_t)(nb < nblk ? nb : nblk - 1) * (size_t)G::PB;
+#pragma unroll
+                    for (int t = 0; t < NIB; ++t) hnext[t] = image_get_F(sp + G::pH1 + ibc[t], lofsF);
+#pragma unroll
+                    for (int s2 = 0; s2 < NOBD; ++s2) xnext[s2] = image_get_F(sp + G::pX + xbc[s2], lofsF);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // the prefetch is issued before the work below
+                // layer 2: rows = dz2 blocks (WD axis), cols = h1 blocks (WH axis)
+#pragma unroll
+                for (int s2 = 0; s2 < NOBH; ++s2) {
+                    a2[s2] = tile_get(ex + o2c[s2], lane);
+                    bs2[s2] += hsum4(a2[s2]);
+                }
+                // layer 1: rows = dz1 blocks (WH axis), cols = X_n blocks (WD axis)
 #pragma unroll
                 for (int t = 0; t < NIB; ++t) {
-                    const int ob = wh + WH * t;
-                    av[t] = tile_get(ex + (HB + (ob < HB ? ob : 0)) * 256, lane);
-                    const float sv = hsum4(av[t]);
+                    a1[t] = tile_get(ex + o1c[t], lane);
+                    const float sv = hsum4(a1[t]);
                     bs1[t] += sv;
                     bt1[t] = fmaf(tn, sv, bt1[t]);
                 }
 #pragma unroll
-                for (int s = 0; s < NOBD; ++s) {
-                    const int ib = wd + WD * s;
-                    if (ib < DB) {
-                        const f32x4 bx = image_get_F<KSD>(sp + G::pX, ib, lane);
+                for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                        for (int t = 0; t < NIB; ++t)
+                    for (int s2 = 0; s2 < NOBH; ++s2)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) acc1[t][s] = mfma16(av[t][r], bx[r], acc1[t][s]);
-                    }
+                        for (int t = 0; t < NIB; ++t) acc2[s2][t] = mfma16(a2[s2][r], hv[t][r], acc2[s2][t]);
+#pragma unroll
+                    for (int s2 = 0; s2 < NOBD; ++s2)
+#pragma unroll
+                        for (int t = 0; t < NIB; ++t) acc1[t][s2] = mfma16(a1[t][r], xv[s2][r], acc1[t][s2]);
                 }
             }
         }
+        asm volatile("" :: "v"(touch0), "v"(touch1));    // keep the touch loads alive until here
+        PSP_STAMP(ts6);
         __syncthreads();                                 // exchange tiles are rewritten next round
+        PSP_STAMP(ts7);
+        PSP_ACC(4, ts6, ts5);       // P3 compute
+        PSP_ACC(5, ts7, ts6);       // barrier D
+        PSP_ACC(6, ts7, ts0);       // whole round
     }
+#ifdef PSP_STAMPS
+    if (a.dbg && lane == 0) {
+        stamps[7] = (unsigned long long)((nround - blockIdx.x + gridDim.x - 1) / gridDim.x);
+        for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = stamps[i];
+    }
+#endif
 
     // ---- write this wave's tiles into the workgroup's partial gradient (torch flat layout).
     // D tile (ob, ib): lane (col = l&15, qq = l>>4), reg rr  <->  dW[16 ob + 4 qq + rr][16 ib + col]

@@ -14,6 +14,8 @@
 namespace {
 
 thread_local char g_err[512] = "";
+unsigned long long* g_dbg = nullptr;   // psp_debug_set_stamp_buffer
+long long g_dbg_n = 0;
 
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof(g_err), fmt, detail);
@@ -100,6 +102,7 @@ void fill_args(const psp_hjb_config* c, const Plan& p, psp::HjbArgs* a) {
     a->drift_kind = c->drift_kind; a->sigma_kind = c->sigma_kind; a->runcost_kind = c->runcost_kind;
     a->term_kind = c->term_kind; a->adaptive = c->adaptive; a->loss_kind = c->loss_kind;
     a->noise_mode = c->noise_mode; a->store_path = c->store_path;
+    a->dbg = (g_dbg && g_dbg_n >= (long long)p.bwd_grid * 4 * 8) ? g_dbg : nullptr;
 }
 
 int check_ptrs(const psp_hjb_config* c) {
@@ -203,6 +206,16 @@ extern "C" {
 
 int psp_version(void) { return PSP_VERSION; }
 const char* psp_last_error(void) { return g_err; }
+
+int psp_debug_set_stamp_buffer(unsigned long long* buf, int64_t n_entries) {
+    g_dbg = buf;
+    g_dbg_n = buf ? n_entries : 0;
+#ifdef PSP_STAMPS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int psp_hjb_supported(int32_t d, int32_t H) {
     psp::HjbInstance inst;

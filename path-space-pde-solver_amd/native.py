@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libpsp_hip.so")
+LIB_PATH = os.environ.get("PSP_LIB_PATH", os.path.join(HERE, "csrc", "libpsp_hip.so"))   # override: diagnostic builds
 
 # enums (include/psp.h)
 DRIFT_ZERO, DRIFT_DENSE, DRIFT_DIAG, DRIFT_DOUBLE_WELL = 0, 1, 2, 3
@@ -65,6 +65,7 @@ SIGNATURES = {
     "psp_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "psp_philox_normal_fill": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32, _P]),
     "psp_hjb_control_eval": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
+    "psp_debug_set_stamp_buffer": (C.c_int, [_P, C.c_int64]),
 }
 
 _lib = None
