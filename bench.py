@@ -147,6 +147,10 @@ def main():
     dom_ms = max(bwd_ms, fwd_ms)
     dom_flops = (fl["bwd_kernel"] if dom == "hjb_bwd_kernel" else fl["fwd_kernel"]) * units_local
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+    traffic = None                                   # HBM bytes per launch, from the committed PMC passes
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
     value = K_global * N_t * args.steps / elapsed
     out = {
         "metric": "trajectory-timesteps/sec (K*N/s), d=100 HJB log-variance training iteration",
@@ -158,7 +162,7 @@ def main():
                    "loss": "log-variance", "noise": "on-device Philox4x32-10",
                    "parallelism": "trajectory-sharded x%d" % world},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                      "alg_flops_per_traj_step": fl, "units_per_launch": units_local,
                      "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
                      "whole_step_tflops": fl["total"] * units_local / (1e-3 * (1e3 * elapsed / args.steps)) / 1e12},

@@ -1,0 +1,65 @@
+"""Multi-rank native plan on real hardware: two processes share cuda:0 (gloo carries the two
+collectives through the host), trajectories sharded by contiguous blocks with global Philox /
+reference-noise indexing.  The sharded run must reproduce the single-process run: SURVEY.md 8e
+parity criterion (<= 1e-6 relative; differences come only from fp32/fp64 summation order).
+RCCL itself cannot be rehearsed with one GPU; the code path differs only in the backend name."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG = dict(lr=1e-3, L=3, K=512, delta_t=0.01, loss_method="log-variance", time_approx="inner",
+           adaptive_forward_process=True, detach_forward=True, u_l2_error_flag=False, verbose=False,
+           seed=42, backend="native", widths=(64, 64))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _train(noise, out=None, rank=0):
+    sys.path.insert(0, ROOT)
+    import path_space_pde_solver_amd as psp
+    dev = torch.device("cuda:0")
+    prob = psp.LLGC(d=100, off_diag=0.01, T=0.2, seed=42, device=dev)
+    model = psp.Solver("two-rank", prob, device=dev, noise=noise, **CFG)
+    model.train()
+    assert model.plan_name == "native"
+    res = dict(loss=model.loss_log, params=torch.cat([p.detach().reshape(-1).cpu() for p in model.z_n.parameters()]),
+               K_local=model._native_plan.K_local, k_offset=model._native_plan.k_offset)
+    if out is not None and rank == 0:
+        torch.save(res, out)
+    return res
+
+
+def _worker(rank, world, port, noise, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = _train(noise, out, rank)
+    assert res["K_local"] == CFG["K"] // world and res["k_offset"] == rank * res["K_local"]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("noise", ["philox", "reference"])
+def test_two_ranks_match_one_rank(tmp_path, noise):
+    out = os.path.join(str(tmp_path), "two.pt")
+    mp.spawn(_worker, args=(2, _free_port(), noise, out), nprocs=2, join=True)
+    two = torch.load(out)
+    one = _train(noise)
+    for a, b in zip(two["loss"], one["loss"]):
+        assert abs(a - b) <= 1e-6 * abs(b), (two["loss"], one["loss"])
+    err = float((two["params"] - one["params"]).abs().max())
+    assert err <= 2e-6, err
