@@ -13,9 +13,10 @@ from .function_space import (Affine, Constant, DenseNet, DenseNet_tanh, Linear, 
 from .problems import (LLGC, LQGC, AllenCahn, DoubleWell_multidim,  # noqa: F401
                        DoubleWell_multidim_for_general_solver, HeatEquation)
 from .solver import Solver  # noqa: F401
+from .general_solver import GeneralSolver  # noqa: F401
 from .plan_native import PlanUnsupported  # noqa: F401
 from . import native  # noqa: F401
 
-__all__ = ['Solver', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
+__all__ = ['Solver', 'GeneralSolver', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
            'AllenCahn', 'HeatEquation', 'MySequential', 'DenseNet', 'DenseNet_tanh', 'SingleParam',
            'Constant', 'Linear', 'Affine', 'PlanUnsupported', 'native']

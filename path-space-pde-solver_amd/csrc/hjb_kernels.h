@@ -95,8 +95,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 multiply per (hi, lo) pair: v_mad_u64_u32 instead of v_mul_hi_u32 + v_mul_lo_u32
+        // (32-bit integer multiplies are quarter-rate VALU ops on CDNA)
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * (unsigned long long)c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -344,8 +348,12 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             }
         }
         float Y = a.y0 ? a.y0[0] : 0.f;               // solver.py:368 / :373
+#ifdef PSP_STAMPS
+        unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
         for (int n = 0; n < a.N; ++n) {
+            PSP_STAMP(fs0);
             const float tn = (float)n * dt;            // solver.py:355: ones * n * delta_t
             const f32x4* vecs = opaque(vecs0);         // re-read the small vectors each step (no hoisting)
             const f32x4* vb1 = vecs + (G::vb1 - G::fVec) / 4;
@@ -364,8 +372,10 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
             gemm_T<HB, KSD, DB>(h1, lds + G::fW1, X, lane);
+            PSP_STAMP(fs1);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = tanh4(h1[m]);
+            PSP_STAMP(fs2);
             f32x4 h2[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
@@ -383,6 +393,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
             for (int m = 0; m < DB; ++m) Z[m] = vb3[m * 4];
             gemm_T<DB, KSH, HB>(Z, lds + G::fW3, h2, lane);
+            PSP_STAMP(fs3);
 
             // ---- Brownian increment xi_{n+1} and the two row sums |Z|^2, Z.xi (solver.py:477-478)
             float S = 0.f, Pz = 0.f;
@@ -415,6 +426,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             }
             S = qsum(S);
             Pz = qsum(Pz);
+            PSP_STAMP(fs4);
 
             // ---- X_{n+1} = X + b(X) dt + sigma v      (solver.py:471-472)
             f32x4 Tn[DB];
@@ -440,6 +452,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             }
 #pragma unroll
             for (int b = 0; b < DB; ++b) X[b] = Tn[b];
+            PSP_STAMP(fs5);
 
             // ---- running cost f(X_{n+1}) (h sees the UPDATED state, solver.py:477) and Y update
             float fX = 0.f;
@@ -455,7 +468,21 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             // Y += (-h + Z.c) dt + Z.xi sqrt(dt);  -h = 0.5|Z|^2 + f ; Z.c = -|Z|^2 (adaptive) or 0
             const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
             Y = Y + drift_y * dt + Pz * sqdt;
+            PSP_STAMP(fs6);
+            PSP_ACC(0, fs1, fs0);   // path store of X + L1 GEMM
+            PSP_ACC(1, fs2, fs1);   // tanh 1
+            PSP_ACC(2, fs3, fs2);   // L2 + tanh 2 + h store + L3
+            PSP_ACC(3, fs4, fs3);   // noise + row sums
+            PSP_ACC(4, fs5, fs4);   // SDE GEMMs
+            PSP_ACC(5, fs6, fs5);   // running cost + Y
+            PSP_ACC(6, fs6, fs0);   // whole step
         }
+#ifdef PSP_STAMPS
+        if (a.dbg && lane == 0) {
+            stamps[7] = (unsigned long long)a.N;
+            for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+        }
+#endif
 
         // ---- terminal cost g(X_N) and D = Y - g  (problems.py:49,164,334; solver.py:167-168)
         float g = 0.f;
@@ -695,30 +722,34 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
 #pragma unroll
                 for (int s2 = 0; s2 < NOBD; ++s2) obc[s2] = ((wd + WD * s2) < DB ? (wd + WD * s2) : DB - 1) * 256;
                 const long long rb = round * 4;
-                f32x4 bnext[NIB];
+                f32x4 bnext[NIB], anext[NOBD];
                 {
                     const float* sp = a.path + (size_t)(rb < nblk ? rb : nblk - 1) * (size_t)G::PB + G::pH2;
 #pragma unroll
                     for (int t = 0; t < NIB; ++t) bnext[t] = image_get_F(sp + ibc[t], lofsF);
+#pragma unroll
+                    for (int s2 = 0; s2 < NOBD; ++s2) anext[s2] = tile_get(exch + obc[s2], lane);
                 }
 #pragma unroll 1
                 for (int sb = 0; sb < 4; ++sb) {
-                    const float* ex = exch + sb * (G::EXT * 256);
                     f32x4 bv[NIB], av[NOBD];
 #pragma unroll
                     for (int t = 0; t < NIB; ++t) bv[t] = bnext[t];
-                    {
-                        const long long nb = rb + (sb < 3 ? sb + 1 : sb);
+#pragma unroll
+                    for (int s2 = 0; s2 < NOBD; ++s2) av[s2] = anext[s2];
+                    {   // operands of block sb+1: h2 panel from L2/HBM, G tiles from LDS
+                        const int sn = sb < 3 ? sb + 1 : sb;
+                        const long long nb = rb + sn;
                         const float* sp = a.path + (size_t)(nb < nblk ? nb : nblk - 1) * (size_t)G::PB + G::pH2;
+                        const float* exn = exch + sn * (G::EXT * 256);
 #pragma unroll
                         for (int t = 0; t < NIB; ++t) bnext[t] = image_get_F(sp + ibc[t], lofsF);
+#pragma unroll
+                        for (int s2 = 0; s2 < NOBD; ++s2) anext[s2] = tile_get(exn + obc[s2], lane);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued before the work below
 #pragma unroll
-                    for (int s2 = 0; s2 < NOBD; ++s2) {
-                        av[s2] = tile_get(ex + obc[s2], lane);
-                        bs3[s2] += hsum4(av[s2]);
-                    }
+                    for (int s2 = 0; s2 < NOBD; ++s2) bs3[s2] += hsum4(av[s2]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -754,43 +785,50 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
 #pragma unroll
             for (int s2 = 0; s2 < NOBH; ++s2) o2c[s2] = ((wd + WD * s2) < HB ? (wd + WD * s2) : HB - 1) * 256;
             const long long rb = round * 4;
-            f32x4 hnext[NIB], xnext[NOBD];
+            f32x4 hnext[NIB], xnext[NOBD], a2next[NOBH], a1next[NIB];
             {
                 const float* sp = a.path + (size_t)(rb < nblk ? rb : nblk - 1) * (size_t)G::PB;
 #pragma unroll
                 for (int t = 0; t < NIB; ++t) hnext[t] = image_get_F(sp + G::pH1 + ibc[t], lofsF);
 #pragma unroll
                 for (int s2 = 0; s2 < NOBD; ++s2) xnext[s2] = image_get_F(sp + G::pX + xbc[s2], lofsF);
+#pragma unroll
+                for (int s2 = 0; s2 < NOBH; ++s2) a2next[s2] = tile_get(exch + o2c[s2], lane);
+#pragma unroll
+                for (int t = 0; t < NIB; ++t) a1next[t] = tile_get(exch + o1c[t], lane);
             }
 #pragma unroll 1
             for (int sb = 0; sb < 4; ++sb) {
                 const long long cb = (rb + sb) < nblk ? (rb + sb) : nblk - 1;
                 const float tn = (float)((int)(cb / a.ntile16)) * dt;
-                const float* ex = exch + sb * (G::EXT * 256);
                 f32x4 hv[NIB], xv[NOBD], a2[NOBH], a1[NIB];
 #pragma unroll
-                for (int t = 0; t < NIB; ++t) hv[t] = hnext[t];
+                for (int t = 0; t < NIB; ++t) { hv[t] = hnext[t]; a1[t] = a1next[t]; }
 #pragma unroll
                 for (int s2 = 0; s2 < NOBD; ++s2) xv[s2] = xnext[s2];
-                {   // next block's h1 / X_n panels (L2 after the touch-prefetch)
-                    const long long nb = rb + (sb < 3 ? sb + 1 : sb);
+#pragma unroll
+                for (int s2 = 0; s2 < NOBH; ++s2) a2[s2] = a2next[s2];
+                {   // operands of block sb+1: h1 / X_n panels (L2 after the touch-prefetch), dz tiles from LDS
+                    const int sn = sb < 3 ? sb + 1 : sb;
+                    const long long nb = rb + sn;
                     const float* sp = a.path + (size_t)(nb < nblk ? nb : nblk - 1) * (size_t)G::PB;
+                    const float* exn = exch + sn * (G::EXT * 256);
 #pragma unroll
                     for (int t = 0; t < NIB; ++t) hnext[t] = image_get_F(sp + G::pH1 + ibc[t], lofsF);
 #pragma unroll
                     for (int s2 = 0; s2 < NOBD; ++s2) xnext[s2] = image_get_F(sp + G::pX + xbc[s2], lofsF);
+#pragma unroll
+                    for (int s2 = 0; s2 < NOBH; ++s2) a2next[s2] = tile_get(exn + o2c[s2], lane);
+#pragma unroll
+                    for (int t = 0; t < NIB; ++t) a1next[t] = tile_get(exn + o1c[t], lane);
                 }
                 __builtin_amdgcn_sched_barrier(0);       // the prefetch is issued before the work below
                 // layer 2: rows = dz2 blocks (WD axis), cols = h1 blocks (WH axis)
 #pragma unroll
-                for (int s2 = 0; s2 < NOBH; ++s2) {
-                    a2[s2] = tile_get(ex + o2c[s2], lane);
-                    bs2[s2] += hsum4(a2[s2]);
-                }
+                for (int s2 = 0; s2 < NOBH; ++s2) bs2[s2] += hsum4(a2[s2]);
                 // layer 1: rows = dz1 blocks (WH axis), cols = X_n blocks (WD axis)
 #pragma unroll
                 for (int t = 0; t < NIB; ++t) {
-                    a1[t] = tile_get(ex + o1c[t], lane);
                     const float sv = hsum4(a1[t]);
                     bs1[t] += sv;
                     bt1[t] = fmaf(tn, sv, bt1[t]);

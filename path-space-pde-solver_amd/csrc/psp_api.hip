@@ -102,7 +102,8 @@ void fill_args(const psp_hjb_config* c, const Plan& p, psp::HjbArgs* a) {
     a->drift_kind = c->drift_kind; a->sigma_kind = c->sigma_kind; a->runcost_kind = c->runcost_kind;
     a->term_kind = c->term_kind; a->adaptive = c->adaptive; a->loss_kind = c->loss_kind;
     a->noise_mode = c->noise_mode; a->store_path = c->store_path;
-    a->dbg = (g_dbg && g_dbg_n >= (long long)p.bwd_grid * 4 * 8) ? g_dbg : nullptr;
+    // diagnostic stamp buffer: [forward: fwd_grid x 8 waves x 8][backward: bwd_grid x 4 waves x 8]
+    a->dbg = (g_dbg && g_dbg_n >= ((long long)p.fwd_grid * 8 + (long long)p.bwd_grid * 4) * 8) ? g_dbg : nullptr;
 }
 
 int check_ptrs(const psp_hjb_config* c) {
@@ -284,6 +285,7 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
     fill_args(cfg, p, &a);
     a.params = params; a.xi = xi; a.path = const_cast<float*>(path); a.D = const_cast<float*>(D);
     a.sums = sums; a.grad_partial = grad_partial;
+    if (a.dbg) a.dbg += (size_t)p.fwd_grid * 8 * 8;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
     hipError_t e = p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");

@@ -1,0 +1,201 @@
+"""GeneralSolver: diffusion / BSDE loss for parabolic terminal-value problems -- API mirror of the
+reference's ``solver.GeneralSolver`` (reference solver.py:934-1206) for the hot-path part:
+``loss_method in {'diffusion', 'BSDE'}`` on ``boundary in {'unbounded', 'unbounded_square'}``.
+
+One iteration (reference solver.py:1009-1201):
+  sample X uniformly in the domain and t ~ U(0, T); Y = V(X, t);
+  N Euler-Maruyama steps of the (optionally controlled) forward SDE, during which
+      Z = sigma^T grad_x V(X, t),   Y += ((-h(n dt, X, V(X,t), Z) + Z.c) dt + Z.xi sqrt(dt)) * active
+  (h sees the state BEFORE the move and V(X,t), not the running Y), trajectories freeze when
+  t + dt > T;  loss = alpha0 mean((V(X_N, t_N) - Y)^2) + alpha1 mean((V(X[:Kb], T) - f(X[:Kb]))^2)
+  ('diffusion')  or  mean((Y - f(X_N))^2) ('BSDE');  Adam on V.
+
+Execution plans, resolved once in ``train()``:
+  * native (plan_general_native, hand-written HIP): V is a DenseNet(d+1 -> 1) with two hidden
+    layers, problem in the native catalogue, device is a GPU;
+  * composite (this file): the reference op sequence with torch autograd on ``self.device``.
+Bounded domains, PINN and the BSDE-2/3/4 variants are outside the scope of this build
+ and raise NotImplementedError.
+"""
+import time
+import warnings
+
+import numpy as np
+import torch
+
+try:
+    from .function_space import DenseNet, SingleParam
+except ImportError:
+    from function_space import DenseNet, SingleParam
+
+
+def _default_device():
+    return torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+
+class GeneralSolver:
+
+    def __init__(self, problem, name, seed=42, delta_t=0.01, N=50, lr=0.001, L=100000, K=200, K_boundary=50,
+                 alpha=[1.0, 1.0, 1.0], adaptive_forward_process=False, detach_forward=True, print_every=100,
+                 verbose=True, approx_method='Y', sample_center=False, loss_method='diffusion',
+                 loss_with_stopped=False, K_test_log=None, PINN_log_variance=False, log_loss_parts=False,
+                 boundary_loss=True, full_hessian=False, uniform_square=False, solve_linear_L2_projection=False,
+                 device=None, backend='auto', noise='reference'):
+        self.problem, self.name = problem, name
+        self.d = problem.d
+        self.device = torch.device(device) if device is not None else getattr(problem, 'device', _default_device())
+        self.seed = seed
+        self.delta_t_np = delta_t
+        self.delta_t = torch.tensor(self.delta_t_np).to(self.device)
+        self.sq_delta_t = torch.sqrt(self.delta_t).to(self.device)
+        self.N, self.lr, self.L = N, lr, L
+        self.K, self.K_original, self.K_boundary = K, K, K_boundary
+        self.alpha = alpha
+        self.adaptive_forward_process = adaptive_forward_process
+        self.detach_forward = detach_forward
+        self.approx_method = approx_method
+        self.sample_center = sample_center
+        self.loss_method = loss_method
+        self.loss_with_stopped = loss_with_stopped
+        self.boundary_loss = boundary_loss
+        self.PINN_log_variance = PINN_log_variance
+        self.full_hessian = full_hessian
+        self.uniform_square = uniform_square
+        self.solve_linear_L2_projection = solve_linear_L2_projection
+        self.print_every, self.verbose = print_every, verbose
+        if backend not in ('auto', 'native', 'torch'):
+            raise ValueError("backend must be 'auto', 'native' or 'torch'")
+        self.backend, self.noise = backend, noise
+
+        torch.manual_seed(seed)                                   # reference solver.py:978-983
+        if approx_method == 'Y':
+            self.V = DenseNet(d_in=self.d + 1, d_out=1, lr=lr, seed=seed).to(self.device)
+        elif approx_method == 'Z':
+            self.y_0 = SingleParam(lr=lr).to(self.device)
+            self.Z = DenseNet(d_in=self.d + 1, d_out=self.d, lr=lr, seed=seed).to(self.device)
+
+        self.K_test_log = K_test_log
+        self.Y_0_log, self.loss_log, self.loss_log_domain, self.loss_log_boundary = [], [], [], []
+        self.u_L2_log, self.V_L2_log = [], []
+        self.V_test_L2, self.V_test_abs, self.V_test_rel_abs = [], [], []
+        self.times, self.lambda_log, self.K_log = [], [], []
+        self.log_loss_parts = log_loss_parts
+        self.plan_name, self.plan_reason = None, None
+
+    # -----------------------------------------------------------------------------------------
+    def _check_scope(self):
+        if self.approx_method != 'Y':
+            raise NotImplementedError("approx_method='Z' is outside this build's scope")
+        if self.loss_method not in ('diffusion', 'BSDE'):
+            raise NotImplementedError("loss_method %r: only 'diffusion' and 'BSDE' are built" % self.loss_method)
+        if 'unbounded' not in self.problem.boundary:
+            raise NotImplementedError("boundary %r: bounded domains are SURVEY.md 8f rank 3" % self.problem.boundary)
+        if self.sample_center or self.loss_with_stopped or self.solve_linear_L2_projection or self.K_test_log:
+            raise NotImplementedError('sample_center / loss_with_stopped / L2 projection / test logging are not built')
+
+    def sample_domain(self):
+        """Initial points, drawn from the CPU generator in the reference's order (solver.py:1040-1056)."""
+        K, d, dev, pb = self.K, self.d, self.device, self.problem
+        if pb.boundary == 'unbounded':
+            if self.uniform_square:
+                X = torch.rand(K, d).to(dev) * 2 - 1
+                radial = torch.rand(K).unsqueeze(1).to(dev)
+            else:
+                X = torch.randn(K, d).to(dev)
+                radial = (torch.rand(K).unsqueeze(1) ** (1 / d)).to(dev)
+            return pb.boundary_distance * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * radial
+        return (pb.X_r - pb.X_l) * torch.rand(K, d).to(dev) + pb.X_l
+
+    def train(self):
+        torch.manual_seed(self.seed)
+        self._check_scope()
+        plan = self._choose_plan()
+        if plan is not None:
+            return plan.train()
+        self._train_composite()
+
+    def _choose_plan(self):
+        if self.backend == 'torch':
+            self.plan_name, self.plan_reason = 'torch', "backend='torch' requested"
+            return None
+        try:
+            try:
+                from . import plan_general_native as pgn
+            except ImportError:
+                import plan_general_native as pgn
+        except ImportError:
+            pgn = None
+        reason = 'the native diffusion-loss plan is not built yet' if pgn is None else pgn.native_eligibility(self)
+        if reason is None:
+            self.plan_name = 'native'
+            return pgn.GeneralNativePlan(self)
+        if self.backend == 'native':
+            raise NotImplementedError('native plan unavailable: ' + reason)
+        if self.device.type == 'cuda':
+            warnings.warn('path-space GeneralSolver: running the composite torch plan (%s)' % reason)
+        self.plan_name, self.plan_reason = 'torch', reason
+        return None
+
+    def _train_composite(self):
+        pb, dev, dt, sq = self.problem, self.device, self.delta_t, self.sq_delta_t
+        K, d, T = self.K, self.d, pb.T
+        a0, a1 = self.alpha[0], self.alpha[1]
+        for l in range(self.L):
+            t_0 = time.time()
+            loss = 0
+            X = self.sample_domain()
+            if self.loss_method != 'BSDE' and self.boundary_loss:
+                Kb = self.K_boundary
+                X_T = torch.cat([X[:Kb, :], T * torch.ones(Kb).to(dev).unsqueeze(1)], 1)
+                loss = loss + a1 * torch.mean((self.V(X_T).squeeze() - pb.f(X[:Kb, :])) ** 2)
+            X = X.clone().requires_grad_(True)
+            t_n = torch.rand(K, 1).to(dev) * T
+            X_t_n = torch.cat([X, t_n], 1)                       # time is the LAST input column here
+            Y = self.V(X_t_n).squeeze()
+            stopped = torch.zeros(K).bool().to(dev)
+            K_count = 0
+            n_done = 0
+            for n in range(self.N):
+                n_done = n
+                if int(torch.sum(~stopped)) == 0:
+                    break
+                V_now = self.V(X_t_n)
+                grad_V, = torch.autograd.grad(V_now.squeeze().sum(), X, create_graph=True)
+                sig = pb.sigma(X)
+                Z = torch.mm(sig.t(), grad_V.t()).t()
+                xi = torch.randn(K, d).to(dev)
+                c = torch.zeros(d, K).to(dev)
+                if self.adaptive_forward_process:
+                    c = -Z.t()
+                if self.detach_forward:
+                    c = c.detach()
+                alive = (~stopped).float().unsqueeze(1).repeat(1, d)
+                X_prop = X + ((pb.b(X) + torch.mm(sig, c).t()) * dt + torch.mm(sig, xi.t()).t() * sq) * alive
+                in_time = (t_n.squeeze() + dt) <= T
+                act = in_time & ~stopped
+                actf = act.float()
+                Y = Y + ((-pb.h(n * dt, X, V_now.squeeze(), Z) + torch.sum(Z * c.t(), 1)) * dt
+                         + torch.sum(Z * xi, 1) * sq) * actf
+                X = (X * (~in_time | stopped).float().unsqueeze(1).repeat(1, d)
+                     + X_prop * actf.unsqueeze(1).repeat(1, d))
+                t_n = t_n + dt * actf.unsqueeze(1)
+                X_t_n = torch.cat([X, t_n], 1)
+                K_count = K_count + torch.sum(act)
+                stopped = stopped | (~in_time & ~stopped)
+            if self.loss_method == 'diffusion':
+                loss = loss + a0 * torch.mean((self.V(X_t_n).squeeze() - Y) ** 2)
+            self.V.zero_grad()
+            self.K_log.append(int(K_count))
+            if self.loss_method == 'BSDE':
+                if int(torch.sum(stopped)) != K:
+                    print('Not all trajectories stopped.')
+                loss = loss + torch.mean((Y - pb.f(X)) ** 2)
+            loss.backward()
+            self.V.optim.step()
+            self.loss_log.append(loss.item())
+            self.V_L2_log.append(0.0)
+            self.times.append(time.time() - t_0)
+            if self.verbose and l % self.print_every == 0:
+                print('%d - loss = %.4e, v L2 error = %.4e, n = %d, active: %d/%d, %.2f'
+                      % (l, self.loss_log[-1], self.V_L2_log[-1], n_done, int(torch.sum(~stopped)), K,
+                         np.mean(self.times[-self.print_every:])))

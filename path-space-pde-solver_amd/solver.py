@@ -34,10 +34,12 @@ try:
     from .function_space import DenseNet, MySequential, SingleParam
     from .plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
     from . import native as _nat
+    from .general_solver import GeneralSolver  # noqa: F401  (reference: `from solver import GeneralSolver`)
 except ImportError:  # flat import: this directory itself is on sys.path, as with the reference
     from function_space import DenseNet, MySequential, SingleParam
     from plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
     import native as _nat
+    from general_solver import GeneralSolver  # noqa: F401
 
 
 def _default_device():

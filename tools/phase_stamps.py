@@ -32,13 +32,25 @@ model = psp.Solver("diag", prob, lr=1e-3, L=4, K=65536, delta_t=0.01, loss_metho
 plan = model._choose_plan()
 nat = psp.native
 nwg = plan.sizes.bwd_workgroups
-buf = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
+fwg = plan.sizes.fwd_workgroups
+buf = torch.zeros((fwg * 8 + nwg * 4) * 8, dtype=torch.int64, device=dev)
 assert nat.load().psp_debug_set_stamp_buffer(nat.ptr(buf), buf.numel()) == 1, "library lacks -DPSP_STAMPS"
 losses = torch.zeros(4, device=dev)
 for l in range(3):
     plan.iteration(l, losses)
 torch.cuda.synchronize()
-s = buf.cpu().reshape(nwg, 4, 8).double()
+allb = buf.cpu().double()
+f = allb[:fwg * 64].reshape(fwg, 8, 8)
+steps = f[:, :, 7].clamp(min=1)
+fn = ["X store + L1 GEMM (100 MFMA)", "tanh 1", "L2 + tanh 2 + h store + L3 (176 MFMA)", "Philox + row sums",
+      "SDE GEMMs (350 MFMA)", "running cost + Y", "whole step"]
+ftot = (f[:, :, 6] / steps).mean()
+print("forward: workgroups %d, cycles per time step (mean over waves): %.0f; MFMA floor 626 x 32 = %d (x2 waves/SIMD: %d)"
+      % (fwg, ftot, 626 * 32, 626 * 64))
+for i, n in enumerate(fn):
+    v = f[:, :, i] / steps
+    print("  %-40s mean %8.0f  (%5.1f%%)" % (n, v.mean(), 100 * v.mean() / ftot))
+s = allb[fwg * 64:].reshape(nwg, 4, 8)
 rounds = s[:, :, 7]
 names = ["P1 compute", "barrier A", "P2 compute", "barriers B+C + dz exchange", "P3 compute", "barrier D", "whole round"]
 tot = (s[:, :, 6] / rounds).mean()
