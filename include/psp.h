@@ -140,6 +140,54 @@ int psp_philox_normal_fill(float* out, int32_t N, int32_t K_local, int32_t d, in
 int psp_hjb_control_eval(int32_t d, int32_t H, const float* params, const float* X, int32_t K, float t,
                          float* minus_Z_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * GeneralSolver.train hot path (reference solver.py:1001-1206): diffusion / BSDE loss on unbounded
+ * domains, V = DenseNet(d+1 -> 1, two hidden layers of width H, relu^2; function_space.py:116-140).
+ * Flat parameter layout = the DenseNet's registration order, weights stored (in, out), input [x, t]:
+ *     [W1 ((d+1) x H), b1 (H), W2 ((d+1+H) x H), b2 (H), W3 (d+1+2H), b3 (1)]
+ * ------------------------------------------------------------------------------------------------ */
+/* nonlinearity h(t,x,y,z): problems.py:1755 (0), :519 (-|z|^2/2), :1204 (y - y^3) */
+enum { PSP_GH_ZERO = 0, PSP_GH_QUAD = 1, PSP_GH_ALLEN_CAHN = 2 };
+
+typedef struct psp_gen_config {
+    int32_t d, H, K_local, N;
+    int64_t k_offset;     /* global index of local trajectory 0 (Philox counter)            */
+    float dt, sqrt_dt;    /* fp32 step and its fp32 square root (solver.py:950-951)          */
+    float T;              /* terminal time: a trajectory freezes once t + dt > T (:1131)     */
+    float sigma_scale;    /* sigma = s I (problems.py:493 s = 1; :1183,1740 s = sqrt 2)      */
+    int32_t drift_kind;   /* PSP_DRIFT_ZERO or PSP_DRIFT_DOUBLE_WELL                          */
+    int32_t h_kind;
+    int32_t adaptive;     /* 1: c = -Z detached (solver.py:1111-1114), 0: c = 0              */
+    int32_t noise_mode;   /* PSP_NOISE_SUPPLIED: xi is (N, K_local, d); PSP_NOISE_PHILOX      */
+    int32_t store_path;   /* 1: keep what the backward pass needs                            */
+    int32_t reserved;
+    const float* drift;   /* DOUBLE_WELL: kappa (d); else NULL                               */
+} psp_gen_config;
+
+typedef struct psp_gen_sizes {
+    int64_t path_bytes;        /* (N+1) sample slots x K/16 blocks of register images               */
+    int64_t ahat_bytes;        /* (N+1) x 16*ceil(K/16) floats                                       */
+    int64_t grad_partial_bytes;
+    int32_t n_params, fwd_workgroups, bwd_workgroups, reserved;
+} psp_gen_sizes;
+
+int psp_gen_supported(int32_t d, int32_t H);
+int psp_gen_query(const psp_gen_config* cfg, psp_gen_sizes* out);
+
+/* Forward rollout (solver.py:1076-1160 and V(X_N,t_N) of :1163): x0 (K_local,d), t0 (K_local) initial
+ * points/times; outputs per trajectory V(X_N,t_N), Y_N, X_N (K_local,d), t_N and the active-step count
+ * (K_log, :1152,1168) accumulated into *kcount (device u64, zeroed by the caller). */
+int psp_gen_rollout_fwd(const psp_gen_config* cfg, const float* params, const float* x0, const float* t0,
+                        const float* xi, uint64_t seed, uint32_t iter, float* path, float* ahat, float* VN,
+                        float* YN, float* XN, float* tN, unsigned long long* kcount, void* stream);
+
+/* Backward pass (replaces loss.backward() of solver.py:1187 for the domain part of the loss):
+ *   grad_out = sum_k [ wV_k dV(X_N,t_N)/dtheta + wY_k dY_N/dtheta ]   over this rank's trajectories,
+ * wY = dLoss/dY_N, wV = dLoss/dV(X_N,t_N) per trajectory (K_local each), formed by the caller from
+ * VN, YN (diffusion: wV = 2 a0 (VN - YN)/K = -wY ; BSDE: wV = 0, wY = 2 (YN - f(XN))/K). */
+int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const float* path, const float* ahat,
+                        const float* wY, const float* wV, float* grad_partial, float* grad_out, void* stream);
+
 /* Diagnostics: device buffer that receives per-wave phase cycle sums (8 u64 per wave of the
  * backward kernel).  Returns 1 if the library was built with -DPSP_STAMPS (diagnostic build,
  * never the shipped one), 0 otherwise (the pointer is then ignored). NULL clears it. */

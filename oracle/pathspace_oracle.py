@@ -444,6 +444,9 @@ def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=Fals
         if cfg.loss_method == "BSDE":
             loss = loss + torch.mean((Y - problem.f(X)) ** 2)        # :1174
         loss.backward()                                              # :1187
+        if trace:
+            tr["grads"] = [p.grad.detach().clone() for p in V.parameters()]
+            tr["VN_minus_Y"] = None
         V.optim.step()                                               # :1188
         out["loss_log"].append(loss.item())                          # :1192
         if trace:

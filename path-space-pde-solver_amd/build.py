@@ -23,9 +23,9 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
-def instances():
+def instances(fname="instances.def"):
     out = []
-    with open(os.path.join(CSRC, "instances.def")) as fh:
+    with open(os.path.join(CSRC, fname)) as fh:
         for line in fh:
             m = re.match(r"\s*X\(\s*(\d+)\s*,\s*(\d+)\s*\)", line)
             if m:
@@ -76,10 +76,16 @@ def _build(force, jobs, verbose, only):
     idef = os.path.join(CSRC, "instances.def")
     inst_src = os.path.join(CSRC, "hjb_instance.hip")
     api_src = os.path.join(CSRC, "psp_api.hip")
-    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, inc, idef])]
+    ghdr = os.path.join(CSRC, "gen_kernels.h")
+    gdef = os.path.join(CSRC, "gen_instances.def")
+    ginst_src = os.path.join(CSRC, "gen_instance.hip")
+    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, ghdr, inc, idef, gdef])]
     for d, H in instances():
         tasks.append((inst_src, os.path.join(OBJ, "inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [inst_src, hdr]))
+    for d, H in instances("gen_instances.def"):
+        tasks.append((ginst_src, os.path.join(OBJ, "gen_inst_%d_%d.o" % (d, H)),
+                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [ginst_src, ghdr, hdr]))
     jobs = jobs or min(6, os.cpu_count() or 2)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         results = list(ex.map(lambda t: _compile(t[0], t[1], t[2], t[3], force), tasks))

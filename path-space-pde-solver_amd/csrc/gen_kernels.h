@@ -1,0 +1,656 @@
+// gen_kernels.h -- CDNA4 kernels for GeneralSolver.train (diffusion / BSDE loss, unbounded domains).
+// Reference: solver.py:1001-1206 (step :1091-1160); V network: function_space.py:116-140 (DenseNet,
+// two hidden layers, relu(.)^2, weights stored (in, out), input = [x, t] with time LAST).
+//
+// Same register-chained "T layout" as hjb_kernels.h (16 trajectories per wave, weights as
+// pre-permuted MFMA A-operand tables in LDS).  Per time step the forward kernel evaluates
+//   z1 = W1^T x0 + b1, h1 = relu(z1)^2 ; z2 = W2^T [x0,h1] + b2, h2 = relu(z2)^2 ; V = W3^T [x0,h1,h2] + b3
+//   grad_x0 V by the reverse sweep (g_z2 = w3h2 * 2relu(z2), g_h1 = w3h1 + W2h g_z2, ...), Z = s grad_x V,
+//   the masked Euler / Y update, and -- for the backward pass -- the loss-weight-independent part of
+//   the tangent pass in direction u^ = act ((-h_z + c) dt + xi sqrt(dt)):  z1^ = W1^T (s u^), z2^ = ...
+// The backward kernel then needs, per sample, only  grad_theta [ a V + w (s u^) . grad_x V ]
+// (reverse-over-forward), with a = w_Y a^ (a^ stored) or w_V at the final point.
+#pragma once
+#include "hjb_kernels.h"
+
+namespace psp {
+
+enum { GH_ZERO = 0, GH_QUAD = 1, GH_ALLEN_CAHN = 2 };
+
+struct GenArgs {
+    const float* params;
+    const float* x0;      // (K_local, d) initial points
+    const float* t0;      // (K_local) initial times
+    const float* xi;      // supplied noise (N, K_local, d) or null
+    float* path;          // N+1 slots x ntile16 blocks of GGeo::PB floats
+    float* ahat;          // (N+1, 16*ntile16) per-sample value-gradient coefficient (without the loss weight)
+    float* VN;            // (K_local) V(X_N, t_N)
+    float* YN;            // (K_local)
+    float* XN;            // (K_local, d)
+    float* tN;            // (K_local)
+    unsigned long long* kcount;   // active-step counter (K_log, solver.py:1152)
+    const float* drift;   // kappa (d) for the double well
+    const float* wY;      // (K_local) dLoss/dY_N      (backward)
+    const float* wV;      // (K_local) dLoss/dV(X_N)   (backward)
+    float* grad_partial;
+    long long k_offset;
+    int K_local, N, ntile16;
+    float dt, sqdt, T, sigma_scale;
+    int drift_kind, h_kind, adaptive, noise_mode, store_path;
+    uint32_t seed_lo, seed_hi, iter;
+};
+
+template <int D, int H>
+struct GGeo {
+    static constexpr int DI = D + 1;                       // network input: [x (D), t]
+    static constexpr int DBI = cdiv(DI, 16), KSI = cdiv(DI, 4), HB = cdiv(H, 16), KSH = cdiv(H, 4);
+    // DenseNet flat parameter offsets (registration order W1,b1,W2,b2,W3,b3; weights are (in, out))
+    static constexpr int oW1 = 0, ob1 = DI * H, oW2 = ob1 + H, ob2 = oW2 + (DI + H) * H, oW3 = ob2 + H,
+                         ob3 = oW3 + DI + 2 * H, P = ob3 + 1;
+    // time feature position in the T layout (feature index D)
+    static constexpr int TB = D / 16, TR = (D % 16) / 4, TQ = D % 4;
+    // path block (16 samples): register images padded to whole blocks
+    static constexpr int pX = 0, pU = pX + 4 * DBI * 64, pD1 = pU + 4 * DBI * 64, pD2 = pD1 + 4 * HB * 64,
+                         pZ1 = pD2 + 4 * HB * 64, pZ2 = pZ1 + 4 * HB * 64, PB = pZ2 + 4 * HB * 64;
+    // forward LDS carve (floats): six A-operand tables + per-feature vectors
+    static constexpr int fW1f = 0, fW2xf = fW1f + HB * KSI * 64, fW2hf = fW2xf + HB * KSI * 64,
+                         fW2hr = fW2hf + HB * KSH * 64, fW2xr = fW2hr + HB * KSH * 64,
+                         fW1r = fW2xr + DBI * KSH * 64, fVec = fW1r + DBI * KSH * 64;
+    static constexpr int vb1 = fVec, vb2 = vb1 + HB * 16, vw3h1 = vb2 + HB * 16, vw3h2 = vw3h1 + HB * 16,
+                         vw3x = vw3h2 + HB * 16, vdr = vw3x + DBI * 16, fRed = vdr + DBI * 16, fEnd = fRed + 64;
+    static int fwd_lds_floats() { return fEnd; }
+    // backward: 4 waves arranged WH (column blocks of H) x WD (row blocks)
+    static constexpr int WH = (HB >= 4) ? 4 : (HB >= 2 ? 2 : 1), WD = 4 / WH;
+    static constexpr int NIB = cdiv(HB, WH);               // column blocks per wave
+    static constexpr int NRX = cdiv(DBI, WD), NRH = cdiv(HB, WD);   // x-row / h-row blocks per wave
+    static constexpr int gW2hr = 0, gVec = gW2hr + HB * KSH * 64, gw3h1 = gVec, gw3h2 = gw3h1 + HB * 16,
+                         gEx = gw3h2 + HB * 16;
+    static constexpr int EXT = 2 * HB;                     // exchange tiles (1 KiB) per wave: adjoint + tangent adjoint
+    static constexpr int gEnd = gEx + 4 * EXT * 256;
+    static int bwd_lds_floats() { return gEnd; }
+};
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    f32x4 o;
+    o[0] = fmaxf(v[0], 0.f); o[1] = fmaxf(v[1], 0.f); o[2] = fmaxf(v[2], 0.f); o[3] = fmaxf(v[3], 0.f);
+    return o;
+}
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
+    acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc);
+    acc = fmaf(a[2], b[2], acc); acc = fmaf(a[3], b[3], acc);
+    return acc;
+}
+// 2 * [v > 0] per component  (phi''(z) for phi = relu^2, evaluated on d = 2 relu(z))
+__device__ __forceinline__ f32x4 step2(f32x4 d) {
+    f32x4 o;
+    o[0] = d[0] > 0.f ? 2.f : 0.f; o[1] = d[1] > 0.f ? 2.f : 0.f;
+    o[2] = d[2] > 0.f ? 2.f : 0.f; o[3] = d[3] > 0.f ? 2.f : 0.f;
+    return o;
+}
+
+// =======================================================================================
+// Forward kernel
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
+    using G = GGeo<D, H>;
+    constexpr int DI = G::DI, DBI = G::DBI, KSI = G::KSI, HB = G::HB, KSH = G::KSH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const float* __restrict__ P = a.params;
+
+    // forward tables: out^T = W^T in^T  ->  A[row = out][k = in] = W[in][out]
+    stage_aop(lds + G::fW1f, HB, KSI, tid, nthr, [&](int row, int col) {
+        return (row < H && col < DI) ? P[G::oW1 + col * H + row] : 0.f; });
+    stage_aop(lds + G::fW2xf, HB, KSI, tid, nthr, [&](int row, int col) {
+        return (row < H && col < DI) ? P[G::oW2 + col * H + row] : 0.f; });
+    stage_aop(lds + G::fW2hf, HB, KSH, tid, nthr, [&](int row, int col) {
+        return (row < H && col < H) ? P[G::oW2 + (DI + col) * H + row] : 0.f; });
+    // reverse tables: g_in = W g_out  ->  A[row = in][k = out] = W[in][out]
+    stage_aop(lds + G::fW2hr, HB, KSH, tid, nthr, [&](int row, int col) {
+        return (row < H && col < H) ? P[G::oW2 + (DI + row) * H + col] : 0.f; });
+    stage_aop(lds + G::fW2xr, DBI, KSH, tid, nthr, [&](int row, int col) {
+        return (row < DI && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
+    stage_aop(lds + G::fW1r, DBI, KSH, tid, nthr, [&](int row, int col) {
+        return (row < DI && col < H) ? P[G::oW1 + row * H + col] : 0.f; });
+    stage_vec(lds + G::vb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
+    stage_vec(lds + G::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
+    stage_vec(lds + G::vw3h1, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + f] : 0.f; });
+    stage_vec(lds + G::vw3h2, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + H + f] : 0.f; });
+    stage_vec(lds + G::vw3x, DBI, tid, nthr, [&](int f) { return f < DI ? P[G::oW3 + f] : 0.f; });
+    stage_vec(lds + G::vdr, DBI, tid, nthr, [&](int f) { return (f < D && a.drift_kind == DRIFT_DWELL) ? a.drift[f] : 0.f; });
+    __syncthreads();
+    const float b3 = P[G::ob3];
+
+    const int t16 = blockIdx.x * nwave + wave;
+    const bool wave_valid = t16 < a.ntile16;
+    const int k = t16 * 16 + j;
+    const bool kvalid = wave_valid && k < a.K_local;
+    const uint32_t kglob = (uint32_t)(a.k_offset + k);
+    const float dt = a.dt, sqdt = a.sqdt, sig = a.sigma_scale, Tend = a.T;
+    unsigned long long nact = 0;
+
+    if (wave_valid) {
+        const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::fVec) + q;
+        // feature masks of this lane: f < D (state features) ; f == D is the time input
+        f32x4 X[DBI];
+#pragma unroll
+        for (int b = 0; b < DBI; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * b + 4 * r + q;
+                const float v = a.x0[(size_t)(kvalid ? k : 0) * D + (f < D ? f : D - 1)];
+                X[b][r] = (f < D && kvalid) ? v : 0.f;
+            }
+        float t = kvalid ? a.t0[k] : 0.f;
+        bool stopped = !kvalid;
+        float Y = 0.f;
+
+        // one network evaluation at the current (X, t): fills r1, r2 (relu(z)), returns V
+        auto net_value = [&](const f32x4* vecs, f32x4 (&r1)[HB], f32x4 (&r2)[HB]) {
+            const f32x4* vb1 = vecs + (G::vb1 - G::fVec) / 4;
+            const f32x4* vb2 = vecs + (G::vb2 - G::fVec) / 4;
+            const f32x4* vw3h1 = vecs + (G::vw3h1 - G::fVec) / 4;
+            const f32x4* vw3h2 = vecs + (G::vw3h2 - G::fVec) / 4;
+            const f32x4* vw3x = vecs + (G::vw3x - G::fVec) / 4;
+#pragma unroll
+            for (int m = 0; m < HB; ++m) r1[m] = vb1[m * 4];
+            gemm_T<HB, KSI, DBI>(r1, lds + G::fW1f, X, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) r1[m] = relu4(r1[m]);
+            f32x4 h1[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h1[m] = r1[m] * r1[m];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) r2[m] = vb2[m * 4];
+            gemm_T<HB, KSI, DBI>(r2, lds + G::fW2xf, X, lane);
+            gemm_T<HB, KSH, HB>(r2, lds + G::fW2hf, h1, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) r2[m] = relu4(r2[m]);
+            float v = 0.f;
+#pragma unroll
+            for (int b = 0; b < DBI; ++b) v = dot4(vw3x[b * 4], X[b], v);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) { v = dot4(vw3h1[m * 4], h1[m], v); v = dot4(vw3h2[m * 4], r2[m] * r2[m], v); }
+            return qsum(v) + b3;
+        };
+        auto put_time = [&](float tv) {
+            if (q == G::TQ) X[G::TB][G::TR] = tv;
+        };
+        put_time(t);
+
+        for (int n = 0; n < a.N; ++n) {
+            const f32x4* vecs = opaque(vecs0);
+            const f32x4* vw3h1 = vecs + (G::vw3h1 - G::fVec) / 4;
+            const f32x4* vw3h2 = vecs + (G::vw3h2 - G::fVec) / 4;
+            const f32x4* vw3x = vecs + (G::vw3x - G::fVec) / 4;
+            const f32x4* vdr = vecs + (G::vdr - G::fVec) / 4;
+            float* pblk = a.path + ((size_t)n * a.ntile16 + t16) * (size_t)G::PB + lane;
+            // ---- V(X,t) and the activations (solver.py:1100)
+            f32x4 r1[HB], r2[HB];
+            const float Vnow = net_value(vecs, r1, r2);
+            if (n == 0) Y = Vnow;                                   // solver.py:1081
+            // ---- grad_x V by the reverse sweep (replaces autograd.grad of solver.py:1103)
+            f32x4 gz2[HB], gz1[HB], gx[DBI];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) gz2[m] = vw3h2[m * 4] * (2.0f * r2[m]);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) gz1[m] = vw3h1[m * 4];
+            gemm_T<HB, KSH, HB>(gz1, lds + G::fW2hr, gz2, lane);     // g_h1 = w3h1 + W2h g_z2
+#pragma unroll
+            for (int m = 0; m < HB; ++m) gz1[m] = gz1[m] * (2.0f * r1[m]);
+#pragma unroll
+            for (int b = 0; b < DBI; ++b) gx[b] = vw3x[b * 4];
+            gemm_T<DBI, KSH, HB>(gx, lds + G::fW2xr, gz2, lane);
+            gemm_T<DBI, KSH, HB>(gx, lds + G::fW1r, gz1, lane);
+            // Z = sigma^T grad_x V (sigma = s I), state features only (solver.py:1104)
+            const bool in_time = (t + dt) <= Tend;                   // solver.py:1131 (fp32)
+            const bool act = in_time && !stopped;
+            const float actf = act ? 1.f : 0.f, alivef = stopped ? 0.f : 1.f;
+            float S = 0.f, Pz = 0.f;
+            f32x4 U[DBI];                                            // s * u^ : tangent direction in x-space
+#pragma unroll
+            for (int b = 0; b < DBI; ++b) {
+                f32x4 xi;
+                if (a.noise_mode == NOISE_PHILOX) {
+                    xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
+                } else {
+                    const float* xrow = a.xi + ((size_t)n * a.K_local + (kvalid ? k : 0)) * D;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 16 * b + 4 * r + q;
+                        xi[r] = xrow[f < D ? f : D - 1];
+                    }
+                }
+                f32x4 Z;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool fx = (16 * b + 4 * r + q) < D;
+                    xi[r] = (fx && kvalid) ? xi[r] : 0.f;
+                    Z[r] = fx ? sig * gx[b][r] : 0.f;
+                    S = fmaf(Z[r], Z[r], S);
+                    Pz = fmaf(Z[r], xi[r], Pz);
+                }
+                // c = -Z (adaptive) or 0, detached (solver.py:1110-1114)
+                const f32x4 cdt = a.adaptive ? (-dt) * Z : 0.f * Z;
+                // tangent direction u^ = act ((-h_z + c) dt + xi sqrt(dt)),  -h_z = Z for h = -|z|^2/2
+                f32x4 u = sqdt * xi + cdt;
+                if (a.h_kind == GH_QUAD) u += dt * Z;
+                U[b] = (actf * sig) * u;
+                // X_proposal = X + ((b(X) + sigma c) dt + sigma xi sqrt(dt)) * alive  (solver.py:1116-1117)
+                f32x4 drift = 0.f * Z;
+                if (a.drift_kind == DRIFT_DWELL) drift = -(4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
+                f32x4 step = (drift * dt + sig * cdt + (sig * sqdt) * xi) * alivef;
+                f32x4 Xn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool fx = (16 * b + 4 * r + q) < D;
+                    Xn[r] = (fx && act) ? X[b][r] + step[r] : X[b][r];
+                }
+                // keep the OLD X in the path store (the sample point), move afterwards
+                if (a.store_path) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pblk[G::pX + (4 * b + r) * 64] = X[b][r];
+                        pblk[G::pU + (4 * b + r) * 64] = U[b][r];
+                    }
+                }
+                X[b] = Xn;
+            }
+            S = qsum(S); Pz = qsum(Pz);
+            // ---- Y update (solver.py:1141-1142): h sees V(X,t) (not the running Y)
+            float minus_h = 0.f, hy = 0.f;
+            if (a.h_kind == GH_QUAD) minus_h = 0.5f * S;
+            else if (a.h_kind == GH_ALLEN_CAHN) { minus_h = -(Vnow - Vnow * Vnow * Vnow); hy = 1.0f - 3.0f * Vnow * Vnow; }
+            const float zc = a.adaptive ? -S : 0.f;
+            Y = Y + ((minus_h + zc) * dt + Pz * sqdt) * actf;
+            if (a.store_path) {
+                // loss-weight-independent part of the tangent pass: z1^ = W1^T U, z2^ = W2x^T U + W2h^T (d1 z1^)
+                f32x4 z1h[HB], z2h[HB];
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < HB; ++m) { z1h[m] = zero4; z2h[m] = zero4; }
+                gemm_T<HB, KSI, DBI>(z1h, lds + G::fW1f, U, lane);
+                f32x4 h1d[HB];
+#pragma unroll
+                for (int m = 0; m < HB; ++m) h1d[m] = (2.0f * r1[m]) * z1h[m];
+                gemm_T<HB, KSI, DBI>(z2h, lds + G::fW2xf, U, lane);
+                gemm_T<HB, KSH, HB>(z2h, lds + G::fW2hf, h1d, lane);
+#pragma unroll
+                for (int ks = 0; ks < 4 * HB; ++ks) {
+                    pblk[G::pD1 + ks * 64] = 2.0f * r1[ks >> 2][ks & 3];
+                    pblk[G::pD2 + ks * 64] = 2.0f * r2[ks >> 2][ks & 3];
+                    pblk[G::pZ1 + ks * 64] = z1h[ks >> 2][ks & 3];
+                    pblk[G::pZ2 + ks * 64] = z2h[ks >> 2][ks & 3];
+                }
+                // coefficient of grad_theta V at this sample: -h_y dt act, plus 1 for V(X_0,t_0) at n = 0
+                if (q == 0) a.ahat[(size_t)n * (a.ntile16 * 16) + k] = (n == 0 ? 1.f : 0.f) - hy * dt * actf;
+            }
+            // ---- time / stop bookkeeping (solver.py:1148-1155)
+            t = t + dt * actf;
+            put_time(t);
+            if (act && q == 0) ++nact;
+            stopped = stopped || !in_time;
+        }
+        // ---- final point: V(X_N, t_N) (solver.py:1163) as an extra value-only sample
+        {
+            const f32x4* vecs = opaque(vecs0);
+            f32x4 r1[HB], r2[HB];
+            const float VN = net_value(vecs, r1, r2);
+            if (a.store_path) {
+                float* pblk = a.path + ((size_t)a.N * a.ntile16 + t16) * (size_t)G::PB + lane;
+#pragma unroll
+                for (int ks = 0; ks < 4 * DBI; ++ks) { pblk[G::pX + ks * 64] = X[ks >> 2][ks & 3]; pblk[G::pU + ks * 64] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4 * HB; ++ks) {
+                    pblk[G::pD1 + ks * 64] = 2.0f * r1[ks >> 2][ks & 3];
+                    pblk[G::pD2 + ks * 64] = 2.0f * r2[ks >> 2][ks & 3];
+                    pblk[G::pZ1 + ks * 64] = 0.f;
+                    pblk[G::pZ2 + ks * 64] = 0.f;
+                }
+                if (q == 0) a.ahat[(size_t)a.N * (a.ntile16 * 16) + k] = 1.f;
+            }
+            if (kvalid && q == 0) { a.VN[k] = VN; a.YN[k] = Y; a.tN[k] = t; }
+            if (kvalid) {
+#pragma unroll
+                for (int b = 0; b < DBI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 16 * b + 4 * r + q;
+                        if (f < D) a.XN[(size_t)k * D + f] = X[b][r];
+                    }
+            }
+        }
+    }
+    // active-step count (integer, order independent)
+    for (int off = 1; off < 64; off <<= 1) nact += __shfl_xor(nact, off);
+    if (lane == 0 && nact) atomicAdd(a.kcount, nact);
+}
+
+// =======================================================================================
+// Backward kernel: grad_theta sum_samples [ a V + w (s u^) . grad_x V ]
+//   forward tangent (stored, times w):  z1' = w z1^,  h1' = d1 z1',  z2' = w z2^,  h2' = d2 z2'
+//   adjoints:  gz2' = w3h2 d2                      (adjoint of the tangent pre-activation z2')
+//              gz2  = a gz2' + w3h2 phi''(z2) z2'
+//              gh1' = w3h1 + W2h gz2' ; gh1 = a w3h1 + W2h gz2
+//              gz1' = gh1' d1 ;  gz1 = gh1 d1 + gh1' phi''(z1) z1'
+//   gradients: dW2 = [x0,h1]^T gz2 + [x0',h1']^T gz2' ; dW1 = x0^T gz1 + x0'^T gz1' ;
+//              dW3 = a [x0,h1,h2] + [x0',h1',h2'] ; db2 = gz2 ; db1 = gz1 ; db3 = a
+// Workgroup = 4 waves, rounds of 4 sample blocks, weight-gradient tiles split over the waves as in
+// hjb_bwd_kernel; the A operands (x0, x0', h1, h1') come straight from the stored images in
+// feature-on-lane form, the B operands (adjoints) through per-wave LDS exchange tiles.
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
+    using G = GGeo<D, H>;
+    constexpr int DI = G::DI, DBI = G::DBI, HB = G::HB, KSH = G::KSH;
+    constexpr int WH = G::WH, WD = G::WD, NIB = G::NIB, NRX = G::NRX, NRH = G::NRH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int wh = (WH == 1) ? 0 : wave % WH, wd = (WD == 1) ? 0 : wave / WH;
+    const int lofsF = image_lane_offset_F(lane);
+    const int qq = lane >> 4, col = lane & 15;
+    const float* __restrict__ P = a.params;
+
+    stage_aop(lds + G::gW2hr, HB, KSH, tid, nthr, [&](int row, int c2) {
+        return (row < H && c2 < H) ? P[G::oW2 + (DI + row) * H + c2] : 0.f; });
+    stage_vec(lds + G::gw3h1, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + f] : 0.f; });
+    stage_vec(lds + G::gw3h2, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + H + f] : 0.f; });
+    __syncthreads();
+    const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::gVec) + q;
+    float* exch = lds + G::gEx;
+    float* my_ex = exch + wave * (G::EXT * 256);
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // weight-gradient accumulators of this wave (rows x columns): dW2 x-rows, dW2 h-rows, dW1
+    f32x4 acc2x[NRX][NIB], acc2h[NRH][NIB], acc1[NRX][NIB];
+    float bs2[NIB], bs1[NIB], g3x[NRX], g3h1[NRH];
+    f32x4 g3h2T[HB];                                    // dW3 (h2 part) in T layout, reduced over lanes at the end
+    float g3b = 0.f;
+#pragma unroll
+    for (int s = 0; s < NRX; ++s) { g3x[s] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) { acc2x[s][t] = zero4; acc1[s][t] = zero4; } }
+#pragma unroll
+    for (int s = 0; s < NRH; ++s) { g3h1[s] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) acc2h[s][t] = zero4; }
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) { bs2[t] = 0.f; bs1[t] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < HB; ++m) g3h2T[m] = zero4;
+
+    int cbc[NIB], rxc[NRX], rhc[NRH];
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) cbc[t] = ((wh + WH * t) < HB ? (wh + WH * t) : HB - 1) * 256;
+#pragma unroll
+    for (int s = 0; s < NRX; ++s) rxc[s] = ((wd + WD * s) < DBI ? (wd + WD * s) : DBI - 1) * 256;
+#pragma unroll
+    for (int s = 0; s < NRH; ++s) rhc[s] = ((wd + WD * s) < HB ? (wd + WD * s) : HB - 1) * 256;
+
+    const int Kpad = a.ntile16 * 16;
+    const long long nblk = (long long)(a.N + 1) * a.ntile16;
+    const long long nround = (nblk + 3) / 4;
+    for (long long round = blockIdx.x; round < nround; round += gridDim.x) {
+        const long long rb = round * 4;
+        // ------------------------------------------------------------------ P1: adjoints of the own block
+        f32x4 gz1[HB], gz1t[HB];
+        {
+            const long long blk0 = rb + wave;
+            const bool bvalid = blk0 < nblk;
+            const long long blk = bvalid ? blk0 : nblk - 1;
+            const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
+            const int k = t16 * 16 + j;
+            const bool kvalid = bvalid && k < a.K_local;
+            const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+            const int kc = kvalid ? k : 0;
+            const bool fin = (n == a.N);
+            const float wsv = (kvalid && !fin) ? a.wY[kc] : 0.f;                       // weight of the tangent part
+            const float av = kvalid ? (fin ? a.wV[kc] : a.wY[kc] * a.ahat[(size_t)n * Kpad + kc]) : 0.f;
+            const f32x4* vecs = opaque(vecs0);
+            const f32x4* vw3h1 = vecs + (G::gw3h1 - G::gVec) / 4;
+            const f32x4* vw3h2 = vecs + (G::gw3h2 - G::gVec) / 4;
+            f32x4 d1[HB], d2[HB], z1t[HB], z2t[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d1[m][r] = pb[G::pD1 + (4 * m + r) * 64];
+                    d2[m][r] = pb[G::pD2 + (4 * m + r) * 64];
+                    z1t[m][r] = wsv * pb[G::pZ1 + (4 * m + r) * 64];
+                    z2t[m][r] = wsv * pb[G::pZ2 + (4 * m + r) * 64];
+                }
+            f32x4 gz2[HB], gz2t[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) {
+                gz2t[m] = vw3h2[m * 4] * d2[m];
+                gz2[m] = av * gz2t[m] + vw3h2[m * 4] * step2(d2[m]) * z2t[m];
+                // dW3 (h2 part): a h2 + h2'   with h2 = (d2/2)^2, h2' = d2 z2'
+                g3h2T[m] += av * (0.25f * d2[m] * d2[m]) + d2[m] * z2t[m];
+            }
+            g3b += (q == 0) ? av : 0.f;
+#pragma unroll
+            for (int m = 0; m < HB; ++m) { gz1t[m] = vw3h1[m * 4]; gz1[m] = av * vw3h1[m * 4]; }
+            gemm_T<HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
+            gemm_T<HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
+#pragma unroll
+            for (int m = 0; m < HB; ++m) {
+                gz1[m] = gz1[m] * d1[m] + gz1t[m] * step2(d1[m]) * z1t[m];
+                gz1t[m] = gz1t[m] * d1[m];
+            }
+            if (!kvalid) {
+#pragma unroll
+                for (int m = 0; m < HB; ++m) { gz2[m] = zero4; gz2t[m] = zero4; gz1[m] = zero4; gz1t[m] = zero4; }
+            }
+#pragma unroll
+            for (int m = 0; m < HB; ++m) { tile_put(my_ex + m * 256, gz2[m], lane); tile_put(my_ex + (HB + m) * 256, gz2t[m], lane); }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------------ P2: dW2, db2, dW3 (x, h1 parts)
+#pragma unroll 1
+        for (int sb = 0; sb < 4; ++sb) {
+            const long long cb0 = rb + sb;
+            const bool sval = cb0 < nblk;
+            const long long cb = sval ? cb0 : nblk - 1;
+            const int n = (int)(cb / a.ntile16), t16 = (int)(cb % a.ntile16);
+            const float* sp = a.path + (size_t)cb * (size_t)G::PB;
+            const float* ex = exch + sb * (G::EXT * 256);
+            // per-sample weights of the 4 samples this lane sees in F layout (samples 4q'..4q'+3)
+            f32x4 w4, a4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ks = t16 * 16 + 4 * qq + r;
+                const bool kv = sval && ks < a.K_local;
+                const int kc = kv ? ks : 0;
+                const bool fin = (n == a.N);
+                w4[r] = (kv && !fin) ? a.wY[kc] : 0.f;
+                a4[r] = kv ? (fin ? a.wV[kc] : a.wY[kc] * a.ahat[(size_t)n * Kpad + kc]) : 0.f;
+            }
+            f32x4 bz[NIB], bzt[NIB];
+#pragma unroll
+            for (int t = 0; t < NIB; ++t) {
+                bz[t] = tile_get(ex + cbc[t], lane);
+                bzt[t] = tile_get(ex + HB * 256 + cbc[t], lane);
+                bs2[t] += hsum4(bz[t]);
+            }
+#pragma unroll
+            for (int s = 0; s < NRX; ++s) {                             // x-rows: A = x0, x0' = w U
+                const f32x4 x0 = image_get_F(sp + G::pX + rxc[s], lofsF);
+                const f32x4 xt = w4 * image_get_F(sp + G::pU + rxc[s], lofsF);
+                g3x[s] += hsum4(a4 * x0 + xt);
+#pragma unroll
+                for (int t = 0; t < NIB; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc2x[s][t] = mfma16(x0[r], bz[t][r], acc2x[s][t]);
+                        acc2x[s][t] = mfma16(xt[r], bzt[t][r], acc2x[s][t]);
+                    }
+            }
+#pragma unroll
+            for (int s = 0; s < NRH; ++s) {                             // h-rows: A = h1 = (d1/2)^2, h1' = d1 w z1^
+                const f32x4 d1 = image_get_F(sp + G::pD1 + rhc[s], lofsF);
+                const f32x4 h1 = 0.25f * d1 * d1;
+                const f32x4 ht = d1 * (w4 * image_get_F(sp + G::pZ1 + rhc[s], lofsF));
+                g3h1[s] += hsum4(a4 * h1 + ht);
+#pragma unroll
+                for (int t = 0; t < NIB; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc2h[s][t] = mfma16(h1[r], bz[t][r], acc2h[s][t]);
+                        acc2h[s][t] = mfma16(ht[r], bzt[t][r], acc2h[s][t]);
+                    }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < HB; ++m) { tile_put(my_ex + m * 256, gz1[m], lane); tile_put(my_ex + (HB + m) * 256, gz1t[m], lane); }
+        __syncthreads();
+        // ------------------------------------------------------------------ P3: dW1, db1
+#pragma unroll 1
+        for (int sb = 0; sb < 4; ++sb) {
+            const long long cb0 = rb + sb;
+            const bool sval = cb0 < nblk;
+            const long long cb = sval ? cb0 : nblk - 1;
+            const int n = (int)(cb / a.ntile16), t16 = (int)(cb % a.ntile16);
+            const float* sp = a.path + (size_t)cb * (size_t)G::PB;
+            const float* ex = exch + sb * (G::EXT * 256);
+            f32x4 w4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ks = t16 * 16 + 4 * qq + r;
+                const bool kv = sval && ks < a.K_local && n != a.N;
+                w4[r] = kv ? a.wY[kv ? ks : 0] : 0.f;
+            }
+            f32x4 bz[NIB], bzt[NIB];
+#pragma unroll
+            for (int t = 0; t < NIB; ++t) {
+                bz[t] = tile_get(ex + cbc[t], lane);
+                bzt[t] = tile_get(ex + HB * 256 + cbc[t], lane);
+                bs1[t] += hsum4(bz[t]);
+            }
+#pragma unroll
+            for (int s = 0; s < NRX; ++s) {
+                const f32x4 x0 = image_get_F(sp + G::pX + rxc[s], lofsF);
+                const f32x4 xt = w4 * image_get_F(sp + G::pU + rxc[s], lofsF);
+#pragma unroll
+                for (int t = 0; t < NIB; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc1[s][t] = mfma16(x0[r], bz[t][r], acc1[s][t]);
+                        acc1[s][t] = mfma16(xt[r], bzt[t][r], acc1[s][t]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write-out: tile (rb, cb): lane (col, qq), reg rr <-> dW[16 rb + 4 qq + rr][16 cb + col]   (weights are (in, out))
+    float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
+#pragma unroll
+    for (int s = 0; s < NRX; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int rbk = wd + WD * s, cbk = wh + WH * t;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 16 * rbk + 4 * qq + rr, jo = 16 * cbk + col;
+                if (rbk < DBI && cbk < HB && i < DI && jo < H) {
+                    gp[G::oW2 + i * H + jo] = acc2x[s][t][rr];
+                    gp[G::oW1 + i * H + jo] = acc1[s][t][rr];
+                }
+            }
+        }
+#pragma unroll
+    for (int s = 0; s < NRH; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int rbk = wd + WD * s, cbk = wh + WH * t;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 16 * rbk + 4 * qq + rr, jo = 16 * cbk + col;
+                if (rbk < HB && cbk < HB && i < H && jo < H) gp[G::oW2 + (DI + i) * H + jo] = acc2h[s][t][rr];
+            }
+        }
+    // biases: lane = output feature in F layout; sum over q', lanes q' == 0 of the wd == 0 waves write
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) {
+        const float v2 = qsum(bs2[t]), v1 = qsum(bs1[t]);
+        const int f = 16 * (wh + WH * t) + col;
+        if (wd == 0 && qq == 0 && (wh + WH * t) < HB && f < H) { gp[G::ob2 + f] = v2; gp[G::ob1 + f] = v1; }
+    }
+    // dW3: x and h1 parts live on lane = feature (F layout) in the wh == 0 waves; h2 part and b3 in T layout
+#pragma unroll
+    for (int s = 0; s < NRX; ++s) {
+        const float v = qsum(g3x[s]);
+        const int f = 16 * (wd + WD * s) + col;
+        if (wh == 0 && qq == 0 && (wd + WD * s) < DBI && f < DI) gp[G::oW3 + f] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < NRH; ++s) {
+        const float v = qsum(g3h1[s]);
+        const int f = 16 * (wd + WD * s) + col;
+        if (wh == 0 && qq == 0 && (wd + WD * s) < HB && f < H) gp[G::oW3 + DI + f] = v;
+    }
+    // T-layout partial sums: reduce over the 16 trajectory lanes, then over the 4 waves through LDS
+    __syncthreads();
+    float* red = lds;                                   // [4 waves][HB*16 + 1]
+#pragma unroll
+    for (int m = 0; m < HB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = g3h2T[m][r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (j == 0) red[wave * (HB * 16 + 1) + 16 * m + 4 * r + q] = v;
+        }
+    {
+        float v = g3b;
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        if (lane == 0) red[wave * (HB * 16 + 1) + HB * 16] = v;
+    }
+    __syncthreads();
+    for (int f = tid; f < HB * 16 + 1; f += nthr) {
+        const float v = (red[f] + red[(HB * 16 + 1) + f]) + (red[2 * (HB * 16 + 1) + f] + red[3 * (HB * 16 + 1) + f]);
+        if (f < H) gp[G::oW3 + DI + H + f] = v;
+        else if (f == HB * 16) gp[G::ob3] = v;
+    }
+}
+
+struct GenInstance {
+    int d, H, n_params, path_floats_per_block;
+    int (*fwd_lds_bytes)();
+    int (*bwd_lds_bytes)();
+    hipError_t (*launch_fwd)(const GenArgs&, int grid, int block, hipStream_t);
+    hipError_t (*launch_bwd)(const GenArgs&, int grid, int block, hipStream_t);
+};
+
+template <int D, int H>
+struct GenLaunch {
+    using G = GGeo<D, H>;
+    static int fwd_lds() { return G::fwd_lds_floats() * 4; }
+    static int bwd_lds() { return G::bwd_lds_floats() * 4; }
+    static hipError_t fwd(const GenArgs& a, int grid, int block, hipStream_t s) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_fwd_kernel<D, H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds());
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gen_fwd_kernel<D, H>), dim3(grid), dim3(block), fwd_lds(), s, a);
+        return hipGetLastError();
+    }
+    static hipError_t bwd(const GenArgs& a, int grid, int block, hipStream_t s) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_bwd_kernel<D, H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds());
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gen_bwd_kernel<D, H>), dim3(grid), dim3(block), bwd_lds(), s, a);
+        return hipGetLastError();
+    }
+    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, &fwd_lds, &bwd_lds, &fwd, &bwd}; }
+};
+
+}  // namespace psp
+
+#define PSP_DEFINE_GEN_INSTANCE(D_, H_) \
+    extern "C" psp::GenInstance psp_gen_instance_##D_##_##H_() { return psp::GenLaunch<D_, H_>::instance(); }
+#define PSP_DECLARE_GEN_INSTANCE(D_, H_) extern "C" psp::GenInstance psp_gen_instance_##D_##_##H_();

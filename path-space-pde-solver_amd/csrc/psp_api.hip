@@ -6,9 +6,13 @@
 
 #include "../../include/psp.h"
 #include "hjb_kernels.h"
+#include "gen_kernels.h"
 
 #define X(D_, H_) PSP_DECLARE_INSTANCE(D_, H_)
 #include "instances.def"
+#undef X
+#define X(D_, H_) PSP_DECLARE_GEN_INSTANCE(D_, H_)
+#include "gen_instances.def"
 #undef X
 
 namespace {
@@ -36,6 +40,19 @@ const Entry kTable[] = {
 
 bool find_instance(int d, int H, psp::HjbInstance* out) {
     for (const Entry& e : kTable)
+        if (e.d == d && e.H == H) { *out = e.fn(); return true; }
+    return false;
+}
+
+typedef psp::GenInstance (*GenInstanceFn)();
+struct GenEntry { int d, H; GenInstanceFn fn; };
+const GenEntry kGenTable[] = {
+#define X(D_, H_) {D_, H_, &psp_gen_instance_##D_##_##H_},
+#include "gen_instances.def"
+#undef X
+};
+bool find_gen_instance(int d, int H, psp::GenInstance* out) {
+    for (const GenEntry& e : kGenTable)
         if (e.d == d && e.H == H) { *out = e.fn(); return true; }
     return false;
 }
@@ -112,6 +129,49 @@ int check_ptrs(const psp_hjb_config* c) {
     if (c->runcost_kind == PSP_RUNCOST_DIAG_QUAD && !c->runcost) return fail(-1, "running-cost vector missing");
     if (!c->term) return fail(-1, "terminal-cost vector missing");
     return 0;
+}
+
+struct GenPlan {
+    psp::GenInstance inst;
+    int ntile16, fwd_waves, fwd_grid, bwd_grid;
+};
+
+int n_cus();
+
+int make_gen_plan(const psp_gen_config* c, GenPlan* p) {
+    if (!c) return fail(-1, "null config");
+    if (c->d <= 0 || c->H <= 0 || c->K_local <= 0 || c->N <= 0) return fail(-1, "non-positive d/H/K/N");
+    if (!find_gen_instance(c->d, c->H, &p->inst)) {
+        snprintf(g_err, sizeof(g_err), "no compiled GeneralSolver kernel instance for d=%d H=%d", c->d, c->H);
+        return -2;
+    }
+    if ((c->drift_kind != PSP_DRIFT_ZERO && c->drift_kind != PSP_DRIFT_DOUBLE_WELL) || c->h_kind < 0 ||
+        c->h_kind > 2 || c->noise_mode < 0 || c->noise_mode > 1)
+        return fail(-1, "config enum out of range");
+    if (c->drift_kind == PSP_DRIFT_DOUBLE_WELL && !c->drift) return fail(-1, "double-well kappa vector missing");
+    if (p->inst.fwd_lds_bytes() > kMaxLds || p->inst.bwd_lds_bytes() > kMaxLds)
+        return fail(-3, "GeneralSolver kernel tables do not fit the 160 KiB LDS for this (d,H)");
+    p->ntile16 = (c->K_local + 15) / 16;
+    const int cus = n_cus();
+    int fw = (p->ntile16 + cus - 1) / cus;
+    if (fw < 1) fw = 1;
+    if (fw > 8) fw = 8;
+    p->fwd_waves = fw;
+    p->fwd_grid = (p->ntile16 + fw - 1) / fw;
+    const long long nround = ((long long)(c->N + 1) * p->ntile16 + 3) / 4;
+    long long g = nround;
+    if (g > 2LL * cus) g = 2LL * cus;
+    if (g < 1) g = 1;
+    p->bwd_grid = (int)g;
+    return 0;
+}
+
+void fill_gen_args(const psp_gen_config* c, const GenPlan& p, psp::GenArgs* a) {
+    memset(a, 0, sizeof(*a));
+    a->drift = c->drift; a->k_offset = c->k_offset; a->K_local = c->K_local; a->N = c->N; a->ntile16 = p.ntile16;
+    a->dt = c->dt; a->sqdt = c->sqrt_dt; a->T = c->T; a->sigma_scale = c->sigma_scale;
+    a->drift_kind = c->drift_kind; a->h_kind = c->h_kind; a->adaptive = c->adaptive;
+    a->noise_mode = c->noise_mode; a->store_path = c->store_path;
 }
 
 // ---- small kernels -------------------------------------------------------------------
@@ -289,6 +349,67 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
     hipError_t e = p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");
+    const int P = p.inst.n_params;
+    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       grad_partial, p.bwd_grid, P, grad_out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
+    return 0;
+}
+
+int psp_gen_supported(int32_t d, int32_t H) {
+    psp::GenInstance inst;
+    return find_gen_instance(d, H, &inst) ? 1 : 0;
+}
+
+int psp_gen_query(const psp_gen_config* cfg, psp_gen_sizes* out) {
+    GenPlan p;
+    int rc = make_gen_plan(cfg, &p);
+    if (rc) return rc;
+    if (!out) return fail(-1, "null output");
+    memset(out, 0, sizeof(*out));
+    out->n_params = p.inst.n_params;
+    out->fwd_workgroups = p.fwd_grid;
+    out->bwd_workgroups = p.bwd_grid;
+    out->path_bytes = cfg->store_path ? (int64_t)(cfg->N + 1) * p.ntile16 * (int64_t)p.inst.path_floats_per_block * 4 : 0;
+    out->ahat_bytes = (int64_t)(cfg->N + 1) * p.ntile16 * 16 * 4;
+    out->grad_partial_bytes = (int64_t)p.bwd_grid * p.inst.n_params * 4;
+    return 0;
+}
+
+int psp_gen_rollout_fwd(const psp_gen_config* cfg, const float* params, const float* x0, const float* t0,
+                        const float* xi, uint64_t seed, uint32_t iter, float* path, float* ahat, float* VN,
+                        float* YN, float* XN, float* tN, unsigned long long* kcount, void* stream) {
+    GenPlan p;
+    int rc = make_gen_plan(cfg, &p);
+    if (rc) return rc;
+    if (!params || !x0 || !t0 || !VN || !YN || !XN || !tN || !kcount)
+        return fail(-1, "null buffer passed to psp_gen_rollout_fwd");
+    if (cfg->noise_mode == PSP_NOISE_SUPPLIED && !xi) return fail(-1, "supplied-noise mode needs xi");
+    if (cfg->store_path && (!path || !ahat)) return fail(-1, "store_path set but path / ahat buffer is null");
+    psp::GenArgs a;
+    fill_gen_args(cfg, p, &a);
+    a.params = params; a.x0 = x0; a.t0 = t0; a.xi = xi; a.path = path; a.ahat = ahat;
+    a.VN = VN; a.YN = YN; a.XN = XN; a.tN = tN; a.kcount = kcount;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
+    hipError_t e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "gen_fwd_kernel launch");
+    return 0;
+}
+
+int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const float* path, const float* ahat,
+                        const float* wY, const float* wV, float* grad_partial, float* grad_out, void* stream) {
+    GenPlan p;
+    int rc = make_gen_plan(cfg, &p);
+    if (rc) return rc;
+    if (!params || !path || !ahat || !wY || !wV || !grad_partial || !grad_out)
+        return fail(-1, "null buffer passed to psp_gen_rollout_bwd");
+    psp::GenArgs a;
+    fill_gen_args(cfg, p, &a);
+    a.params = params; a.path = const_cast<float*>(path); a.ahat = const_cast<float*>(ahat);
+    a.wY = wY; a.wV = wV; a.grad_partial = grad_partial;
+    hipError_t e = p.inst.launch_bwd(a, p.bwd_grid, 256, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "gen_bwd_kernel launch");
     const int P = p.inst.n_params;
     hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        grad_partial, p.bwd_grid, P, grad_out);

@@ -128,7 +128,11 @@ class GeneralSolver:
         reason = 'the native diffusion-loss plan is not built yet' if pgn is None else pgn.native_eligibility(self)
         if reason is None:
             self.plan_name = 'native'
-            return pgn.GeneralNativePlan(self)
+            plan = getattr(self, '_gen_plan', None)
+            if plan is None or plan.s.V is not self.V:
+                plan = pgn.GeneralNativePlan(self)              # owns the flat parameters and Adam moments
+                self._gen_plan = plan
+            return plan
         if self.backend == 'native':
             raise NotImplementedError('native plan unavailable: ' + reason)
         if self.device.type == 'cuda':

@@ -21,6 +21,7 @@ RUNCOST_ZERO, RUNCOST_DIAG_QUAD = 0, 1
 TERM_LINEAR, TERM_DIAG_QUAD, TERM_SHIFTED_QUAD = 0, 1, 2
 LOSS_LOG_VARIANCE, LOSS_MOMENT = 0, 1
 NOISE_SUPPLIED, NOISE_PHILOX = 0, 1
+GH_ZERO, GH_QUAD, GH_ALLEN_CAHN = 0, 1, 2
 
 
 class NativeLibraryError(RuntimeError):
@@ -52,6 +53,25 @@ class HjbSizes(C.Structure):
     ]
 
 
+class GenConfig(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32), ("H", C.c_int32), ("K_local", C.c_int32), ("N", C.c_int32),
+        ("k_offset", C.c_int64),
+        ("dt", C.c_float), ("sqrt_dt", C.c_float), ("T", C.c_float), ("sigma_scale", C.c_float),
+        ("drift_kind", C.c_int32), ("h_kind", C.c_int32), ("adaptive", C.c_int32), ("noise_mode", C.c_int32),
+        ("store_path", C.c_int32), ("reserved", C.c_int32),
+        ("drift", C.c_void_p),
+    ]
+
+
+class GenSizes(C.Structure):
+    _fields_ = [
+        ("path_bytes", C.c_int64), ("ahat_bytes", C.c_int64), ("grad_partial_bytes", C.c_int64),
+        ("n_params", C.c_int32), ("fwd_workgroups", C.c_int32), ("bwd_workgroups", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 _P = C.c_void_p
 SIGNATURES = {
     "psp_version": (C.c_int, []),
@@ -66,6 +86,11 @@ SIGNATURES = {
     "psp_philox_normal_fill": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32, _P]),
     "psp_hjb_control_eval": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
     "psp_debug_set_stamp_buffer": (C.c_int, [_P, C.c_int64]),
+    "psp_gen_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "psp_gen_query": (C.c_int, [C.POINTER(GenConfig), C.POINTER(GenSizes)]),
+    "psp_gen_rollout_fwd": (C.c_int, [C.POINTER(GenConfig), _P, _P, _P, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P,
+                                      _P, _P, _P, _P]),
+    "psp_gen_rollout_bwd": (C.c_int, [C.POINTER(GenConfig), _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None
@@ -123,6 +148,16 @@ def stream_ptr(device):
 
 def supported(d, H):
     return bool(load().psp_hjb_supported(int(d), int(H)))
+
+
+def gen_supported(d, H):
+    return bool(load().psp_gen_supported(int(d), int(H)))
+
+
+def gen_query(cfg):
+    sizes = GenSizes()
+    check(load().psp_gen_query(C.byref(cfg), C.byref(sizes)), "psp_gen_query")
+    return sizes
 
 
 def query(cfg):

@@ -1,0 +1,202 @@
+"""Native (HIP) execution plan for GeneralSolver.train (diffusion / BSDE loss, unbounded domains).
+
+Per iteration (reference solver.py:1009-1201):
+    host RNG in the reference's order (domain sample, t ~ U(0,T), per-step xi)      [noise='reference']
+    psp_gen_rollout_fwd   -> V(X_N,t_N), Y_N, X_N, t_N, active-step count, path store
+    per-trajectory loss weights (K-vectors) and the small terminal-condition term in torch
+    psp_gen_rollout_bwd   -> flat gradient of the domain part of the loss
+    [all-reduce gradient] -> psp_adam_step
+The terminal term a1 mean((V(X[:Kb],T) - f(X[:Kb]))^2) involves K_boundary (~50) points and is
+differentiated by torch autograd on the same parameters (views of the flat buffer); it is
+O(K_boundary) work against O(K N) in the kernels.
+"""
+import ctypes as C
+
+import torch
+
+try:
+    from . import native as nat
+    from . import sharding
+    from .function_space import DenseNet
+except ImportError:
+    import native as nat
+    import sharding
+    from function_space import DenseNet
+
+
+def native_eligibility(solver):
+    if solver.device.type != 'cuda':
+        return 'device is %s (the HIP rollout needs a GPU)' % solver.device
+    if solver.approx_method != 'Y' or solver.loss_method not in ('diffusion', 'BSDE'):
+        return "only approx_method='Y' with loss_method 'diffusion' / 'BSDE' is native"
+    if solver.adaptive_forward_process and not solver.detach_forward:
+        return 'detach_forward=False back-propagates through the state path (not native)'
+    if not solver.boundary_loss and solver.loss_method == 'diffusion':
+        return 'boundary_loss=False is not native'
+    V = solver.V
+    dims = getattr(V, 'nn_dims', None)
+    if not isinstance(V, DenseNet) or dims is None or len(dims) != 4 or dims[1] != dims[2] or dims[3] != 1 \
+            or dims[0] != solver.d + 1:
+        return 'V is not a DenseNet(d+1 -> 1) with two equal hidden widths'
+    spec_fn = getattr(solver.problem, 'general_native_spec', None)
+    if spec_fn is None:
+        return 'problem has no general_native_spec() (coefficients outside the native catalogue)'
+    if not nat.is_built():
+        raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
+    if not nat.gen_supported(solver.d, dims[1]):
+        return 'no compiled kernel instance for d=%d, H=%d (see csrc/gen_instances.def)' % (solver.d, dims[1])
+    return None
+
+
+class GeneralNativePlan:
+    def __init__(self, solver):
+        s = solver
+        self.s = s
+        self.lib = nat.load()
+        self.dev = s.device
+        self.dist, self.rank, self.world = sharding.dist_info()
+        lo, hi = sharding.shard_bounds(s.K, self.rank, self.world)
+        self.lo, self.hi, self.K_local = lo, hi, hi - lo
+        self.H = s.V.nn_dims[1]
+        self._flatten(s.V)
+        spec = s.problem.general_native_spec()
+        self._keep = []
+        cfg = nat.GenConfig()
+        cfg.d, cfg.H, cfg.K_local, cfg.N = s.d, self.H, self.K_local, s.N
+        cfg.k_offset = lo
+        cfg.dt, cfg.sqrt_dt = float(s.delta_t.item()), float(s.sq_delta_t.item())
+        cfg.T = float(torch.tensor(s.problem.T, dtype=torch.float32).item())
+        cfg.sigma_scale = float(spec['sigma_scale'])
+        cfg.drift_kind = spec['drift'][0]
+        if spec['drift'][1] is not None:
+            t = spec['drift'][1].detach().to(device=self.dev, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            cfg.drift = nat.ptr(t)
+        cfg.h_kind = spec['h']
+        cfg.adaptive = 1 if s.adaptive_forward_process else 0
+        cfg.noise_mode = nat.NOISE_PHILOX if s.noise == 'philox' else nat.NOISE_SUPPLIED
+        cfg.store_path = 1
+        self.cfg = cfg
+        sz = nat.gen_query(cfg)
+        assert sz.n_params == self.P, (sz.n_params, self.P)
+        self.sizes = sz
+        dev, f32 = self.dev, torch.float32
+        self.path = torch.empty(sz.path_bytes // 4, dtype=f32, device=dev)
+        self.ahat = torch.zeros(sz.ahat_bytes // 4, dtype=f32, device=dev)
+        self.grad_partial = torch.empty(sz.grad_partial_bytes // 4, dtype=f32, device=dev)
+        self.VN = torch.empty(self.K_local, dtype=f32, device=dev)
+        self.YN = torch.empty(self.K_local, dtype=f32, device=dev)
+        self.tN = torch.empty(self.K_local, dtype=f32, device=dev)
+        self.XN = torch.empty(self.K_local, s.d, dtype=f32, device=dev)
+        self.kcount = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.grad = torch.empty(self.P, dtype=f32, device=dev)
+        self.m = torch.zeros(self.P, dtype=f32, device=dev)
+        self.v = torch.zeros(self.P, dtype=f32, device=dev)
+        self.step = 0
+
+    def _flatten(self, V):
+        params = list(V.W)                      # registration order W1,b1,W2,b2,W3,b3 (include/psp.h)
+        self.params = params
+        self.P = sum(p.numel() for p in params)
+        flat = torch.empty(self.P, dtype=torch.float32, device=self.dev)
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self.flat = flat
+
+    def _executed_steps(self, t0_cpu):
+        """Steps the reference executes before its early break (solver.py:1093-1097): it stops drawing
+        xi once every trajectory is frozen.  Emulated on the host in fp32 from t0."""
+        s = self.s
+        dt = torch.tensor(s.delta_t_np)
+        t = t0_cpu.clone().squeeze()
+        stopped = torch.zeros_like(t, dtype=torch.bool)
+        for n in range(s.N):
+            if int((~stopped).sum()) == 0:
+                return n
+            in_time = (t + dt) <= s.problem.T
+            act = in_time & ~stopped
+            t = t + dt * act.float()
+            stopped = stopped | ~in_time
+        return s.N
+
+    def iteration(self, l):
+        s, lib, cfg, dev = self.s, self.lib, self.cfg, self.dev
+        st = nat.stream_ptr(dev)
+        K, d, T = s.K, s.d, s.problem.T
+        lo, hi = self.lo, self.hi
+        diffusion = s.loss_method == 'diffusion'
+        # ---- host RNG in the reference's order (solver.py:1040-1056, :1078, :1106)
+        X = s.sample_domain()                                    # (K, d) on the device
+        for p in self.params:
+            p.grad = None
+        loss_T = None
+        if diffusion and s.boundary_loss:
+            Kb = s.K_boundary
+            X_T = torch.cat([X[:Kb, :], T * torch.ones(Kb, device=dev).unsqueeze(1)], 1)
+            loss_T = s.alpha[1] * torch.mean((s.V(X_T).squeeze() - s.problem.f(X[:Kb, :])) ** 2)
+            loss_T.backward()                                   # K_boundary points only
+        t0_cpu = torch.rand(K, 1) * T
+        xi = None
+        if s.noise == 'reference':
+            n_exec = self._executed_steps(t0_cpu)
+            xi_cpu = torch.zeros(s.N, hi - lo, d)
+            for n in range(n_exec):
+                xi_cpu[n] = torch.randn(K, d)[lo:hi]
+            xi = xi_cpu.to(dev)
+        x0 = X[lo:hi].contiguous()
+        t0 = t0_cpu[lo:hi, 0].contiguous().to(dev)
+        self.kcount.zero_()
+        nat.check(lib.psp_gen_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0), nat.ptr(t0), nat.ptr(xi),
+                                          int(s.seed) & 0xFFFFFFFFFFFFFFFF, l, nat.ptr(self.path),
+                                          nat.ptr(self.ahat), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN),
+                                          nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_gen_rollout_fwd')
+        # ---- per-trajectory loss weights (K-vectors)
+        if diffusion:
+            r = self.VN - self.YN
+            sq = torch.sum(r.double() ** 2).reshape(1)
+            sharding.allreduce_sum_(sq)
+            loss = s.alpha[0] * (sq[0] / K).float()
+            wV = (2.0 * s.alpha[0] / K) * r
+            wY = -wV
+            if loss_T is not None:
+                loss = loss + loss_T.detach()
+        else:
+            r = self.YN - s.problem.f(self.XN)
+            sq = torch.sum(r.double() ** 2).reshape(1)
+            sharding.allreduce_sum_(sq)
+            loss = (sq[0] / K).float()
+            wY = (2.0 / K) * r
+            wV = torch.zeros_like(r)
+        wY, wV = wY.contiguous(), wV.contiguous()
+        nat.check(lib.psp_gen_rollout_bwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(self.path), nat.ptr(self.ahat),
+                                          nat.ptr(wY), nat.ptr(wV), nat.ptr(self.grad_partial), nat.ptr(self.grad),
+                                          st), 'psp_gen_rollout_bwd')
+        sharding.allreduce_sum_(self.grad)
+        if loss_T is not None:                                   # identical on every rank: add after the reduce
+            self.grad += torch.cat([p.grad.reshape(-1) for p in self.params])
+        self.step += 1
+        nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
+                                    self.P, self.step, float(s.lr), 0.9, 0.999, 1e-8, st), 'psp_adam_step')
+        kc = self.kcount.clone()
+        sharding.allreduce_sum_(kc)
+        return loss, kc
+
+    def train(self):
+        s = self.s
+        losses, counts = [], []
+        for l in range(s.L):
+            loss, kc = self.iteration(l)
+            losses.append(loss)
+            counts.append(kc)
+            if (s.verbose and l % s.print_every == 0) or l == s.L - 1:
+                vals = torch.stack(losses).cpu().tolist()
+                s.loss_log += vals
+                s.K_log += [int(c.item()) for c in counts]
+                s.V_L2_log += [0.0] * len(vals)
+                if s.verbose and l % s.print_every == 0:
+                    print('%d - loss = %.4e' % (l, s.loss_log[-1]))
+                losses, counts = [], []

@@ -249,6 +249,10 @@ class DoubleWell_multidim_for_general_solver(_DoubleWellBase):
             return torch.exp(-self._well_cost(x))
         return self._well_cost(x)
 
+    def general_native_spec(self):
+        return {'drift': (_nat.DRIFT_DOUBLE_WELL, self.kappa_.float().contiguous()), 'sigma_scale': 1.0,
+                'h': _nat.GH_ZERO if self.modus == 'linear' else _nat.GH_QUAD}
+
 
 class AllenCahn:
     """Allen-Cahn reaction term h = y - y^3, sigma = sqrt(2) I (reference problems.py:1175-1217,
@@ -275,6 +279,9 @@ class AllenCahn:
     def f(self, x):
         return 1 / (2 + 2 / 5 * torch.sum(x ** 2, 1))
 
+    def general_native_spec(self):
+        return {'drift': (_nat.DRIFT_ZERO, None), 'sigma_scale': float(self.B_pt[0, 0]), 'h': _nat.GH_ALLEN_CAHN}
+
 
 class HeatEquation:
     """Heat equation with terminal condition |x|^2 (reference problems.py:1733-1764)."""
@@ -300,6 +307,9 @@ class HeatEquation:
 
     def f(self, x):
         return torch.sum(x ** 2, 1)
+
+    def general_native_spec(self):
+        return {'drift': (_nat.DRIFT_ZERO, None), 'sigma_scale': float(self.B[0, 0]), 'h': _nat.GH_ZERO}
 
     def v_true(self, x, t):
         return torch.sum(x ** 2, 1) + 2 * (self.T - t) * self.d
