@@ -37,6 +37,11 @@ WORKLOADS = {
     # structured variant A=-I, B=I (reported separately)
     "hjb_llgc_d100_K65536_N100_h64_diag": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.0),
 }
+GENERAL_WORKLOADS = {
+    # BASELINE.json configs[2] shape in fp32: d=100 diffusion loss, K=65536, N=100, V = DenseNet(101 -> 1, [64, 64])
+    "diffusion_dw_d100_K65536_N100_h64": dict(d=100, H=64, K=65536, N=100, T=0.3, dt=0.001, loss="diffusion"),
+    "bsde_dw_d100_K65536_N100_h64": dict(d=100, H=64, K=65536, N=100, T=0.1, dt=0.001, loss="BSDE"),
+}
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
 
@@ -81,11 +86,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="hjb_llgc_d100_K65536_N100_h64", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="hjb_llgc_d100_K65536_N100_h64",
+                    choices=sorted(WORKLOADS) + sorted(GENERAL_WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import path_space_pde_solver_amd as psp
+    if args.workload in GENERAL_WORKLOADS:
+        return main_general(args, psp)
     w = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,6 +180,62 @@ def main():
         out["cpu_baseline"] = cpu_baseline(w)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main_general(args, psp):
+    """GeneralSolver (diffusion / BSDE loss) workloads: metric counts ACTIVE trajectory-timesteps
+    (K_log, reference solver.py:1152), as SURVEY.md 8d prescribes."""
+    w = GENERAL_WORKLOADS[args.workload]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    prob = psp.DoubleWell_multidim_for_general_solver(d=w["d"], d_1=w["d"] // 2, d_2=w["d"] - w["d"] // 2, T=w["T"],
+                                                      eta=1, kappa=1, modus="HJB", device=dev)
+    total = args.warmup + args.steps
+    model = psp.GeneralSolver(problem=prob, name="bench", seed=42, delta_t=w["dt"], N=w["N"], lr=1e-3, L=total,
+                              K=w["K"] * world, K_boundary=50, alpha=[1.0, 1.0, 1.0], loss_method=w["loss"],
+                              verbose=False, device=dev, backend="native", noise="philox")
+    model.V = psp.DenseNet(d_in=w["d"] + 1, d_out=1, lr=1e-3, arch=[w["H"], w["H"]], seed=42).to(dev)
+    plan = model._choose_plan()
+    assert model.plan_name == "native"
+    for l in range(args.warmup):
+        plan.iteration(l)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    counts, losses = [], []
+    for l in range(args.warmup, total):
+        loss, kc = plan.iteration(l)
+        counts.append(kc)
+        losses.append(loss)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    active = float(torch.stack(counts).sum().item())
+    if rank == 0:
+        out = {"metric": "active trajectory-timesteps/sec, d=100 %s loss training iteration" % w["loss"],
+               "value": active / elapsed, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": args.workload, "problem": "DoubleWell_multidim_for_general_solver",
+                          "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%d-%d-1" % (w["d"] + 1, w["H"], w["H"]),
+                          "loss": w["loss"], "active_fraction": active / (w["K"] * world * w["N"] * args.steps)},
+               "launched_units_per_s": w["K"] * world * w["N"] * args.steps / elapsed,
+               "loss_first_last": [float(losses[0]), float(losses[-1])]}
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -82,10 +82,15 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 // Makes a pointer value opaque to the optimiser at this program point.  Used inside the time /
 // sample loops so that loop-invariant LDS reads (bias vectors, cost vectors) are re-issued per
 // iteration instead of being hoisted out of the loop and kept live (which spills ~160 VGPRs).
+// NOTE: launder an integer OFFSET, never the pointer: an asm-laundered pointer loses its LDS
+// address space and every read through it becomes a flat_load instead of a ds_read.
+__device__ __forceinline__ int opaque_i(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 template <class T>
-__device__ __forceinline__ const T* opaque(const T* p) {
-    asm volatile("" : "+v"(p));
-    return p;
+__device__ __forceinline__ const T* opaque(const T* p) {   // same pointer + opaque zero offset
+    return p + opaque_i(0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -169,11 +174,16 @@ constexpr int kFenceMask = 0x1 | 0x2 | 0x4 | 0x10 | 0x20 | 0x40;
 // fence for sample-block boundaries: only VALU / SALU may cross (pins VMEM, DS and MFMA order)
 constexpr int kFenceAluOnly = 0x2 | 0x4;
 template <int MB, int KS, int INB>
-__device__ __forceinline__ void gemm_T(f32x4 (&acc)[MB], const float* __restrict__ wlds,
+__device__ __forceinline__ void gemm_T(f32x4 (&acc)[MB], const float* wlds,
                                        const f32x4 (&in)[INB], int lane) {
     static_assert(INB * 4 >= KS, "input panel too small");
+    static_assert(MB * KS * 256 <= 65536, "table exceeds the 16-bit ds_read immediate offset");
     constexpr int CH = (MB >= 4) ? 2 : 4;
     constexpr int NCH = cdiv(KS, CH);
+    // one per-lane base address per GEMM call, every operand = base + immediate offset.  Without the
+    // laundering hipcc hoists a separate precomputed address VGPR per 4-KiB stride of every table out
+    // of the time loop (hundreds of registers, all spilled).
+    lane = opaque_i(lane);
     float buf[2][CH * MB];
 #pragma unroll
     for (int kk = 0; kk < CH; ++kk)

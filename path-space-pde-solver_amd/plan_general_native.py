@@ -107,6 +107,19 @@ class GeneralNativePlan:
             off += n
         self.flat = flat
 
+    def _sample_domain_device(self, l):
+        """Domain sample of solver.py:1040-1056 drawn with a device generator (noise='philox')."""
+        s, dev, pb = self.s, self.dev, self.s.problem
+        if not hasattr(self, '_gen'):
+            self._gen = torch.Generator(device=dev)
+        self._gen.manual_seed(int(s.seed) * 1000003 + l)
+        K, d = s.K, s.d
+        if pb.boundary == 'unbounded':
+            X = torch.randn(K, d, generator=self._gen, device=dev)
+            radial = torch.rand(K, generator=self._gen, device=dev).unsqueeze(1) ** (1 / d)
+            return pb.boundary_distance * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * radial
+        return (pb.X_r - pb.X_l) * torch.rand(K, d, generator=self._gen, device=dev) + pb.X_l
+
     def _executed_steps(self, t0_cpu):
         """Steps the reference executes before its early break (solver.py:1093-1097): it stops drawing
         xi once every trajectory is frozen.  Emulated on the host in fp32 from t0."""
@@ -129,8 +142,11 @@ class GeneralNativePlan:
         K, d, T = s.K, s.d, s.problem.T
         lo, hi = self.lo, self.hi
         diffusion = s.loss_method == 'diffusion'
-        # ---- host RNG in the reference's order (solver.py:1040-1056, :1078, :1106)
-        X = s.sample_domain()                                    # (K, d) on the device
+        if s.noise == 'reference':
+            # ---- host RNG in the reference's order (solver.py:1040-1056, :1078, :1106)
+            X = s.sample_domain()                                # (K, d) on the device
+        else:
+            X = self._sample_domain_device(l)                    # on-device generator, keyed by (seed, iteration)
         for p in self.params:
             p.grad = None
         loss_T = None
@@ -139,16 +155,18 @@ class GeneralNativePlan:
             X_T = torch.cat([X[:Kb, :], T * torch.ones(Kb, device=dev).unsqueeze(1)], 1)
             loss_T = s.alpha[1] * torch.mean((s.V(X_T).squeeze() - s.problem.f(X[:Kb, :])) ** 2)
             loss_T.backward()                                   # K_boundary points only
-        t0_cpu = torch.rand(K, 1) * T
         xi = None
         if s.noise == 'reference':
+            t0_cpu = torch.rand(K, 1) * T
             n_exec = self._executed_steps(t0_cpu)
             xi_cpu = torch.zeros(s.N, hi - lo, d)
             for n in range(n_exec):
                 xi_cpu[n] = torch.randn(K, d)[lo:hi]
             xi = xi_cpu.to(dev)
+            t0 = t0_cpu[lo:hi, 0].contiguous().to(dev)
+        else:
+            t0 = (torch.rand(K, generator=self._gen, device=dev) * T)[lo:hi].contiguous()
         x0 = X[lo:hi].contiguous()
-        t0 = t0_cpu[lo:hi, 0].contiguous().to(dev)
         self.kcount.zero_()
         nat.check(lib.psp_gen_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0), nat.ptr(t0), nat.ptr(xi),
                                           int(s.seed) & 0xFFFFFFFFFFFFFFFF, l, nat.ptr(self.path),
