@@ -183,7 +183,8 @@ int psp_gen_rollout_fwd(const psp_gen_config* cfg, const float* params, const fl
 
 /* Backward pass (replaces loss.backward() of solver.py:1187 for the domain part of the loss):
  *   grad_out = sum_k [ wV_k dV(X_N,t_N)/dtheta + wY_k dY_N/dtheta ]   over this rank's trajectories,
- * wY = dLoss/dY_N, wV = dLoss/dV(X_N,t_N) per trajectory (K_local each), formed by the caller from
+ * wY = dLoss/dY_N, wV = dLoss/dV(X_N,t_N) per trajectory, each ZERO-PADDED to 16*ceil(K_local/16)
+ * floats (the kernel reads them with unconditional 16-byte loads), formed by the caller from
  * VN, YN (diffusion: wV = 2 a0 (VN - YN)/K = -wY ; BSDE: wV = 0, wY = 2 (YN - f(XN))/K). */
 int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const float* path, const float* ahat,
                         const float* wY, const float* wV, float* grad_partial, float* grad_out, void* stream);

@@ -59,13 +59,16 @@ struct GGeo {
     static constexpr int vb1 = fVec, vb2 = vb1 + HB * 16, vw3h1 = vb2 + HB * 16, vw3h2 = vw3h1 + HB * 16,
                          vw3x = vw3h2 + HB * 16, vdr = vw3x + DBI * 16, fRed = vdr + DBI * 16, fEnd = fRed + 64;
     static int fwd_lds_floats() { return fEnd; }
-    // backward: 4 waves arranged WH (column blocks of H) x WD (row blocks)
-    static constexpr int WH = (HB >= 4) ? 4 : (HB >= 2 ? 2 : 1), WD = 4 / WH;
+    // backward: 4 waves arranged WH (column blocks of H) x WD (row blocks).  Rows are split first: the
+    // A operands (X, U, d1, z1^ images) then go to exactly one wave each, while the B operands (adjoint
+    // panels) are shared through the LDS exchange tiles.
+    static constexpr int WD = (DBI >= 4) ? 4 : (DBI >= 2 ? 2 : 1), WH = 4 / WD;
     static constexpr int NIB = cdiv(HB, WH);               // column blocks per wave
     static constexpr int NRX = cdiv(DBI, WD), NRH = cdiv(HB, WD);   // x-row / h-row blocks per wave
-    static constexpr int gW2hr = 0, gVec = gW2hr + HB * KSH * 64, gw3h1 = gVec, gw3h2 = gw3h1 + HB * 16,
-                         gEx = gw3h2 + HB * 16;
-    static constexpr int EXT = 2 * HB;                     // exchange tiles (1 KiB) per wave: adjoint + tangent adjoint
+    static constexpr int gW2hr = 0, gEx = gW2hr + HB * KSH * 64;
+    // exchange tiles (1 KiB) per wave: [gz2 | gz2' | gz1 | gz1'].  d=100, H=64: 16 KiB table + 64 KiB
+    // exchange = exactly 80 KiB -> two workgroups per CU (the w3 vectors are read from global instead)
+    static constexpr int EXT = 4 * HB;
     static constexpr int gEnd = gEx + 4 * EXT * 256;
     static int bwd_lds_floats() { return gEnd; }
 };
@@ -358,10 +361,14 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
 
     stage_aop(lds + G::gW2hr, HB, KSH, tid, nthr, [&](int row, int c2) {
         return (row < H && c2 < H) ? P[G::oW2 + (DI + row) * H + c2] : 0.f; });
-    stage_vec(lds + G::gw3h1, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + f] : 0.f; });
-    stage_vec(lds + G::gw3h2, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + H + f] : 0.f; });
     __syncthreads();
-    const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::gVec) + q;
+    // w3 (h1 / h2 parts) in T layout, straight from the parameter vector (32 L1-resident loads per round)
+    auto w3_T = [&](int base, int m) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int f = 16 * m + 4 * r + q; v[r] = f < H ? P[base + (f < H ? f : 0)] : 0.f; }
+        return v;
+    };
     float* exch = lds + G::gEx;
     float* my_ex = exch + wave * (G::EXT * 256);
 
@@ -397,9 +404,23 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
     const long long nround = (nblk + 3) / 4;
     for (long long round = blockIdx.x; round < nround; round += gridDim.x) {
         const long long rb = round * 4;
-        // ------------------------------------------------------------------ P1: adjoints of the own block
-        f32x4 gz1[HB], gz1t[HB];
+        // L2 touch-prefetch (one dword per 128-B line): wave w pulls block w's X / U / d1 / z1^ images
+        // (read in P2/P3 by every wave) and its own block of the NEXT round (d1, d2, z1^, z2^ for P1).
+        float touch[6];
         {
+            const long long xb0 = rb + wave;
+            const float* xt = a.path + (size_t)(xb0 < nblk ? xb0 : nblk - 1) * (size_t)G::PB;
+            constexpr int NA = G::pD2;                       // X, U, d1 images are contiguous: [0, pD2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int o = lane * 32 + i * 2048; touch[i] = xt[o < NA ? o : 0]; }
+            touch[4] = xt[G::pZ1 + ((lane * 32 < 4 * HB * 64) ? lane * 32 : 0)];
+            const long long nb0 = (round + gridDim.x) * 4 + wave;
+            const float* nt = a.path + (size_t)(nb0 < nblk ? nb0 : nblk - 1) * (size_t)G::PB + G::pD1;
+            touch[5] = nt[(lane * 32 < 16 * HB * 64) ? lane * 32 : 0];
+        }
+        // ------------------------------------------------------------------ P1: adjoints of the own block
+        {
+            f32x4 gz1[HB], gz1t[HB];
             const long long blk0 = rb + wave;
             const bool bvalid = blk0 < nblk;
             const long long blk = bvalid ? blk0 : nblk - 1;
@@ -407,13 +428,11 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
             const int k = t16 * 16 + j;
             const bool kvalid = bvalid && k < a.K_local;
             const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
-            const int kc = kvalid ? k : 0;
             const bool fin = (n == a.N);
-            const float wsv = (kvalid && !fin) ? a.wY[kc] : 0.f;                       // weight of the tangent part
-            const float av = kvalid ? (fin ? a.wV[kc] : a.wY[kc] * a.ahat[(size_t)n * Kpad + kc]) : 0.f;
-            const f32x4* vecs = opaque(vecs0);
-            const f32x4* vw3h1 = vecs + (G::gw3h1 - G::gVec) / 4;
-            const f32x4* vw3h2 = vecs + (G::gw3h2 - G::gVec) / 4;
+            // wY / wV / ahat are zero-padded to 16*ntile16 entries: plain loads, no branch around them
+            const float wy = a.wY[k], wv = a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
+            const float wsv = (bvalid && !fin) ? wy : 0.f;                             // weight of the tangent part
+            const float av = bvalid ? (fin ? wv : wy * ah) : 0.f;
             f32x4 d1[HB], d2[HB], z1t[HB], z2t[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m)
@@ -427,14 +446,15 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
             f32x4 gz2[HB], gz2t[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) {
-                gz2t[m] = vw3h2[m * 4] * d2[m];
-                gz2[m] = av * gz2t[m] + vw3h2[m * 4] * step2(d2[m]) * z2t[m];
+                const f32x4 w3h2 = w3_T(G::oW3 + DI + H, m);
+                gz2t[m] = w3h2 * d2[m];
+                gz2[m] = av * gz2t[m] + w3h2 * step2(d2[m]) * z2t[m];
                 // dW3 (h2 part): a h2 + h2'   with h2 = (d2/2)^2, h2' = d2 z2'
                 g3h2T[m] += av * (0.25f * d2[m] * d2[m]) + d2[m] * z2t[m];
             }
             g3b += (q == 0) ? av : 0.f;
 #pragma unroll
-            for (int m = 0; m < HB; ++m) { gz1t[m] = vw3h1[m * 4]; gz1[m] = av * vw3h1[m * 4]; }
+            for (int m = 0; m < HB; ++m) { gz1t[m] = w3_T(G::oW3 + DI, m); gz1[m] = av * gz1t[m]; }
             gemm_T<HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
             gemm_T<HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
 #pragma unroll
@@ -447,104 +467,107 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
                 for (int m = 0; m < HB; ++m) { gz2[m] = zero4; gz2t[m] = zero4; gz1[m] = zero4; gz1t[m] = zero4; }
             }
 #pragma unroll
-            for (int m = 0; m < HB; ++m) { tile_put(my_ex + m * 256, gz2[m], lane); tile_put(my_ex + (HB + m) * 256, gz2t[m], lane); }
+            for (int m = 0; m < HB; ++m) {
+                tile_put(my_ex + m * 256, gz2[m], lane);
+                tile_put(my_ex + (HB + m) * 256, gz2t[m], lane);
+                tile_put(my_ex + (2 * HB + m) * 256, gz1[m], lane);
+                tile_put(my_ex + (3 * HB + m) * 256, gz1t[m], lane);
+            }
         }
         __syncthreads();
-        // ------------------------------------------------------------------ P2: dW2, db2, dW3 (x, h1 parts)
-#pragma unroll 1
-        for (int sb = 0; sb < 4; ++sb) {
-            const long long cb0 = rb + sb;
-            const bool sval = cb0 < nblk;
-            const long long cb = sval ? cb0 : nblk - 1;
-            const int n = (int)(cb / a.ntile16), t16 = (int)(cb % a.ntile16);
-            const float* sp = a.path + (size_t)cb * (size_t)G::PB;
-            const float* ex = exch + sb * (G::EXT * 256);
-            // per-sample weights of the 4 samples this lane sees in F layout (samples 4q'..4q'+3)
-            f32x4 w4, a4;
+        // ------------------------------------------------------------------ P2: all weight gradients
+        // One loop over the 4 sample blocks feeds dW2 (x- and h-rows) and dW1 from a single load of the
+        // X / U images per block.  Two-stage operand pipeline: while the x-row MFMAs of block sb issue,
+        // its h-row images (d1, z1^) are in flight; while the h-row MFMAs issue, X / U of block sb+1 are.
+        {
+            auto blk_of = [&](int sb) {                            // provably wave-uniform 32-bit block index
+                const long long c0 = rb + sb;
+                return (size_t)__builtin_amdgcn_readfirstlane((int)(c0 < nblk ? c0 : nblk - 1));
+            };
+            f32x4 xbuf[NRX], ubuf[NRX], dbuf[NRH], zbuf[NRH];
+            {
+                const float* sp = a.path + (size_t)blk_of(0) * (size_t)G::PB;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ks = t16 * 16 + 4 * qq + r;
-                const bool kv = sval && ks < a.K_local;
-                const int kc = kv ? ks : 0;
+                for (int s2 = 0; s2 < NRX; ++s2) {
+                    xbuf[s2] = image_get_F(sp + G::pX + rxc[s2], lofsF);
+                    ubuf[s2] = image_get_F(sp + G::pU + rxc[s2], lofsF);
+                }
+            }
+#pragma unroll 1
+            for (int sb = 0; sb < 4; ++sb) {
+                const bool sval = (rb + sb) < nblk;
+                const int cb = (int)blk_of(sb);
+                const int n = cb / a.ntile16, t16 = cb % a.ntile16;
+                const float* sp = a.path + (size_t)cb * (size_t)G::PB;
+                const float* ex = exch + sb * (G::EXT * 256);
+                // stage A loads: h-row images of this block
+#pragma unroll
+                for (int s2 = 0; s2 < NRH; ++s2) {
+                    dbuf[s2] = image_get_F(sp + G::pD1 + rhc[s2], lofsF);
+                    zbuf[s2] = image_get_F(sp + G::pZ1 + rhc[s2], lofsF);
+                }
+                // per-sample weights of the 4 samples this lane sees in F layout (samples 4q'..4q'+3)
                 const bool fin = (n == a.N);
-                w4[r] = (kv && !fin) ? a.wY[kc] : 0.f;
-                a4[r] = kv ? (fin ? a.wV[kc] : a.wY[kc] * a.ahat[(size_t)n * Kpad + kc]) : 0.f;
-            }
-            f32x4 bz[NIB], bzt[NIB];
+                const int k4 = t16 * 16 + 4 * qq;
+                const f32x4 wy4 = *reinterpret_cast<const f32x4*>(a.wY + k4);
+                const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wV + k4);
+                const f32x4 ah4 = *reinterpret_cast<const f32x4*>(a.ahat + (size_t)n * Kpad + k4);
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 w4 = (sval && !fin) ? wy4 : z4;
+                const f32x4 a4 = sval ? (fin ? wv4 : wy4 * ah4) : z4;
+                f32x4 bz2[NIB], bz2t[NIB], bz1[NIB], bz1t[NIB];
 #pragma unroll
-            for (int t = 0; t < NIB; ++t) {
-                bz[t] = tile_get(ex + cbc[t], lane);
-                bzt[t] = tile_get(ex + HB * 256 + cbc[t], lane);
-                bs2[t] += hsum4(bz[t]);
-            }
+                for (int t = 0; t < NIB; ++t) {
+                    bz2[t] = tile_get(ex + cbc[t], lane);
+                    bz2t[t] = tile_get(ex + HB * 256 + cbc[t], lane);
+                    bz1[t] = tile_get(ex + 2 * HB * 256 + cbc[t], lane);
+                    bz1t[t] = tile_get(ex + 3 * HB * 256 + cbc[t], lane);
+                    bs2[t] += hsum4(bz2[t]);
+                    bs1[t] += hsum4(bz1[t]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < NRX; ++s) {                             // x-rows: A = x0, x0' = w U
-                const f32x4 x0 = image_get_F(sp + G::pX + rxc[s], lofsF);
-                const f32x4 xt = w4 * image_get_F(sp + G::pU + rxc[s], lofsF);
-                g3x[s] += hsum4(a4 * x0 + xt);
+                for (int s2 = 0; s2 < NRX; ++s2) {                          // x-rows: A = x0, x0' = w U
+                    const f32x4 x0 = xbuf[s2];
+                    const f32x4 xt = w4 * ubuf[s2];
+                    g3x[s2] += hsum4(a4 * x0 + xt);
 #pragma unroll
-                for (int t = 0; t < NIB; ++t)
+                    for (int t = 0; t < NIB; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc2x[s][t] = mfma16(x0[r], bz[t][r], acc2x[s][t]);
-                        acc2x[s][t] = mfma16(xt[r], bzt[t][r], acc2x[s][t]);
+                        for (int r = 0; r < 4; ++r) {
+                            acc2x[s2][t] = mfma16(x0[r], bz2[t][r], acc2x[s2][t]);
+                            acc1[s2][t] = mfma16(x0[r], bz1[t][r], acc1[s2][t]);
+                            acc2x[s2][t] = mfma16(xt[r], bz2t[t][r], acc2x[s2][t]);
+                            acc1[s2][t] = mfma16(xt[r], bz1t[t][r], acc1[s2][t]);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {   // stage B loads: x-row images of the next block (xbuf / ubuf are free now)
+                    const float* spn = a.path + (size_t)blk_of(sb < 3 ? sb + 1 : sb) * (size_t)G::PB;
+#pragma unroll
+                    for (int s2 = 0; s2 < NRX; ++s2) {
+                        xbuf[s2] = image_get_F(spn + G::pX + rxc[s2], lofsF);
+                        ubuf[s2] = image_get_F(spn + G::pU + rxc[s2], lofsF);
                     }
-            }
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < NRH; ++s) {                             // h-rows: A = h1 = (d1/2)^2, h1' = d1 w z1^
-                const f32x4 d1 = image_get_F(sp + G::pD1 + rhc[s], lofsF);
-                const f32x4 h1 = 0.25f * d1 * d1;
-                const f32x4 ht = d1 * (w4 * image_get_F(sp + G::pZ1 + rhc[s], lofsF));
-                g3h1[s] += hsum4(a4 * h1 + ht);
+                for (int s2 = 0; s2 < NRH; ++s2) {                          // h-rows: A = h1 = (d1/2)^2, h1' = d1 w z1^
+                    const f32x4 d1 = dbuf[s2];
+                    const f32x4 h1 = 0.25f * d1 * d1;
+                    const f32x4 ht = d1 * (w4 * zbuf[s2]);
+                    g3h1[s2] += hsum4(a4 * h1 + ht);
 #pragma unroll
-                for (int t = 0; t < NIB; ++t)
+                    for (int t = 0; t < NIB; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc2h[s][t] = mfma16(h1[r], bz[t][r], acc2h[s][t]);
-                        acc2h[s][t] = mfma16(ht[r], bzt[t][r], acc2h[s][t]);
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            acc2h[s2][t] = mfma16(h1[r], bz2[t][r], acc2h[s2][t]);
+                            acc2h[s2][t] = mfma16(ht[r], bz2t[t][r], acc2h[s2][t]);
+                        }
+                }
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < HB; ++m) { tile_put(my_ex + m * 256, gz1[m], lane); tile_put(my_ex + (HB + m) * 256, gz1t[m], lane); }
-        __syncthreads();
-        // ------------------------------------------------------------------ P3: dW1, db1
-#pragma unroll 1
-        for (int sb = 0; sb < 4; ++sb) {
-            const long long cb0 = rb + sb;
-            const bool sval = cb0 < nblk;
-            const long long cb = sval ? cb0 : nblk - 1;
-            const int n = (int)(cb / a.ntile16), t16 = (int)(cb % a.ntile16);
-            const float* sp = a.path + (size_t)cb * (size_t)G::PB;
-            const float* ex = exch + sb * (G::EXT * 256);
-            f32x4 w4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ks = t16 * 16 + 4 * qq + r;
-                const bool kv = sval && ks < a.K_local && n != a.N;
-                w4[r] = kv ? a.wY[kv ? ks : 0] : 0.f;
-            }
-            f32x4 bz[NIB], bzt[NIB];
-#pragma unroll
-            for (int t = 0; t < NIB; ++t) {
-                bz[t] = tile_get(ex + cbc[t], lane);
-                bzt[t] = tile_get(ex + HB * 256 + cbc[t], lane);
-                bs1[t] += hsum4(bz[t]);
-            }
-#pragma unroll
-            for (int s = 0; s < NRX; ++s) {
-                const f32x4 x0 = image_get_F(sp + G::pX + rxc[s], lofsF);
-                const f32x4 xt = w4 * image_get_F(sp + G::pU + rxc[s], lofsF);
-#pragma unroll
-                for (int t = 0; t < NIB; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc1[s][t] = mfma16(x0[r], bz[t][r], acc1[s][t]);
-                        acc1[s][t] = mfma16(xt[r], bzt[t][r], acc1[s][t]);
-                    }
-            }
-        }
+        asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]), "v"(touch[4]), "v"(touch[5]));
         __syncthreads();
     }
 

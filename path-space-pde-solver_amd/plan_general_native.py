@@ -92,6 +92,9 @@ class GeneralNativePlan:
         self.grad = torch.empty(self.P, dtype=f32, device=dev)
         self.m = torch.zeros(self.P, dtype=f32, device=dev)
         self.v = torch.zeros(self.P, dtype=f32, device=dev)
+        self.Kpad = 16 * ((self.K_local + 15) // 16)
+        self.wY = torch.zeros(self.Kpad, dtype=f32, device=dev)     # zero-padded (include/psp.h)
+        self.wV = torch.zeros(self.Kpad, dtype=f32, device=dev)
         self.step = 0
 
     def _flatten(self, V):
@@ -189,9 +192,10 @@ class GeneralNativePlan:
             loss = (sq[0] / K).float()
             wY = (2.0 / K) * r
             wV = torch.zeros_like(r)
-        wY, wV = wY.contiguous(), wV.contiguous()
+        self.wY[:self.K_local].copy_(wY)
+        self.wV[:self.K_local].copy_(wV)
         nat.check(lib.psp_gen_rollout_bwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(self.path), nat.ptr(self.ahat),
-                                          nat.ptr(wY), nat.ptr(wV), nat.ptr(self.grad_partial), nat.ptr(self.grad),
+                                          nat.ptr(self.wY), nat.ptr(self.wV), nat.ptr(self.grad_partial), nat.ptr(self.grad),
                                           st), 'psp_gen_rollout_bwd')
         sharding.allreduce_sum_(self.grad)
         if loss_T is not None:                                   # identical on every rank: add after the reduce
