@@ -207,6 +207,7 @@ def main_general(args, psp):
     assert model.plan_name == "native"
     for l in range(args.warmup):
         plan.iteration(l)
+    plan.events = []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -225,6 +226,15 @@ def main_general(args, psp):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     active = float(torch.stack(counts).sum().item())
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in plan.events) / max(1, len(plan.events))
+    bwd_ms = sum(e[2].elapsed_time(e[3]) for e in plan.events) / max(1, len(plan.events))
+    # algorithmic flops per LAUNCHED trajectory-timestep: value net F = 2[(d+1)H + (d+1+H)H + (d+1+2H)],
+    # its input gradient ~ F (reverse sweep), and the double-backward of both ~ 2 x that: forward kernel
+    # 2F (+ F for the tangent part it pre-computes), backward kernel 3F  -> 6F per unit in total
+    F = 2 * ((w["d"] + 1) * w["H"] + (w["d"] + 1 + w["H"]) * w["H"] + (w["d"] + 1 + 2 * w["H"]))
+    units = w["K"] * w["N"]
+    dom, dom_ms, dom_fl = ("gen_bwd_kernel", bwd_ms, 3 * F) if bwd_ms >= fwd_ms else ("gen_fwd_kernel", fwd_ms, 3 * F)
+    achieved = dom_fl * units / (dom_ms * 1e-3) / 1e12
     if rank == 0:
         out = {"metric": "active trajectory-timesteps/sec, d=100 %s loss training iteration" % w["loss"],
                "value": active / elapsed, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
@@ -233,6 +243,10 @@ def main_general(args, psp):
                "config": {"workload": args.workload, "problem": "DoubleWell_multidim_for_general_solver",
                           "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%d-%d-1" % (w["d"] + 1, w["H"], w["H"]),
                           "loss": w["loss"], "active_fraction": active / (w["K"] * world * w["N"] * args.steps)},
+               "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                            "alg_flops_per_launched_unit": {"value_net_F": F, "fwd_kernel": 3 * F, "bwd_kernel": 3 * F},
+                            "units_per_launch": units, "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms},
                "launched_units_per_s": w["K"] * world * w["N"] * args.steps / elapsed,
                "loss_first_last": [float(losses[0]), float(losses[-1])]}
         print(json.dumps(out))

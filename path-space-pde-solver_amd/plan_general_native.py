@@ -96,6 +96,7 @@ class GeneralNativePlan:
         self.wY = torch.zeros(self.Kpad, dtype=f32, device=dev)     # zero-padded (include/psp.h)
         self.wV = torch.zeros(self.Kpad, dtype=f32, device=dev)
         self.step = 0
+        self.events = None   # bench.py: HIP-event pairs around the two rollout kernels
 
     def _flatten(self, V):
         params = list(V.W)                      # registration order W1,b1,W2,b2,W3,b3 (include/psp.h)
@@ -171,10 +172,16 @@ class GeneralNativePlan:
             t0 = (torch.rand(K, generator=self._gen, device=dev) * T)[lo:hi].contiguous()
         x0 = X[lo:hi].contiguous()
         self.kcount.zero_()
+        ev = None
+        if self.events is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         nat.check(lib.psp_gen_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0), nat.ptr(t0), nat.ptr(xi),
                                           int(s.seed) & 0xFFFFFFFFFFFFFFFF, l, nat.ptr(self.path),
                                           nat.ptr(self.ahat), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN),
                                           nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_gen_rollout_fwd')
+        if ev is not None:
+            ev[1].record()
         # ---- per-trajectory loss weights (K-vectors)
         if diffusion:
             r = self.VN - self.YN
@@ -194,9 +201,14 @@ class GeneralNativePlan:
             wV = torch.zeros_like(r)
         self.wY[:self.K_local].copy_(wY)
         self.wV[:self.K_local].copy_(wV)
+        if ev is not None:
+            ev[2].record()
         nat.check(lib.psp_gen_rollout_bwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(self.path), nat.ptr(self.ahat),
                                           nat.ptr(self.wY), nat.ptr(self.wV), nat.ptr(self.grad_partial), nat.ptr(self.grad),
                                           st), 'psp_gen_rollout_bwd')
+        if ev is not None:
+            ev[3].record()
+            self.events.append(ev)
         sharding.allreduce_sum_(self.grad)
         if loss_T is not None:                                   # identical on every rank: add after the reduce
             self.grad += torch.cat([p.grad.reshape(-1) for p in self.params])
