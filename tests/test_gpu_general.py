@@ -71,3 +71,50 @@ def test_loss_log_matches_reference_golden(name):
         v = model.V(torch.cat([xp, tp], 1)).squeeze().cpu()
     want = torch.tensor(exp["probe_V"])
     assert float((v - want).abs().max()) <= 2e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_full_size_properties_diffusion():
+    """BASELINE.json configs[2] shape in fp32 (d=100, K=65536, N=100, DenseNet 101-64-64-1), Philox noise:
+    (a) determinism: two runs give bitwise identical loss, gradient and K_log;
+    (b) shard independence: the upper half of the trajectories run alone (k_offset = K/2, same x0 / t0)
+        reproduces the full run's V_N and Y_N bit for bit;
+    (c) the active-step count is the fraction implied by t0 ~ U(0, T): 1 - (N dt / T)/2 = 5/6."""
+    d, K, N = 100, 65536, 100
+    prob = psp.DoubleWell_multidim_for_general_solver(d=d, d_1=50, d_2=50, T=0.3, eta=1, kappa=1, modus="HJB",
+                                                      device=dev())
+
+    def make(Kx):
+        m = psp.GeneralSolver(problem=prob, name="full", seed=42, delta_t=0.001, N=N, lr=1e-3, L=1, K=Kx,
+                              K_boundary=50, alpha=[1.0, 1.0, 1.0], loss_method="diffusion", verbose=False,
+                              device=dev(), backend="native", noise="philox")
+        m.V = psp.DenseNet(d_in=d + 1, d_out=1, lr=1e-3, arch=[64, 64], seed=42).to(dev())
+        return m
+
+    a, b = make(K), make(K)
+    a.train()
+    b.train()
+    assert a.loss_log == b.loss_log and math.isfinite(a.loss_log[0]) and a.K_log == b.K_log
+    pa, pb = a._gen_plan, b._gen_plan
+    assert torch.equal(pa.grad, pb.grad) and torch.equal(pa.YN, pb.YN) and torch.equal(pa.VN, pb.VN)
+    assert bool(torch.isfinite(pa.grad).all())
+    # (c) active-step count: t0 ~ U(0, 0.3), N dt = 0.1 -> a trajectory is active for min(N, floor((T - t0)/dt)) steps
+    assert 0.80 * K * N < a.K_log[0] < 0.86 * K * N
+    # (b) rerun the upper half through the C ABI with the same initial points
+    import ctypes as C
+    nat = psp.native
+    half = make(K // 2)
+    plan = psp.plan_general_native.GeneralNativePlan(half)
+    plan.flat.copy_(torch.cat([p.detach().reshape(-1) for p in make(K).V.W]).to(dev()))   # initial weights
+    Xfull = pa._sample_domain_device(0)
+    t0full = torch.rand(K, generator=pa._gen, device=dev()) * prob.T
+    x0 = Xfull[K // 2:].contiguous()
+    t0 = t0full[K // 2:].contiguous()
+    plan.cfg.k_offset = K // 2
+    plan.kcount.zero_()
+    nat.check(nat.load().psp_gen_rollout_fwd(C.byref(plan.cfg), nat.ptr(plan.flat), nat.ptr(x0), nat.ptr(t0), None,
+                                             42, 0, nat.ptr(plan.path), nat.ptr(plan.ahat), nat.ptr(plan.VN),
+                                             nat.ptr(plan.YN), nat.ptr(plan.XN), nat.ptr(plan.tN),
+                                             nat.ptr(plan.kcount), None), "fwd")
+    torch.cuda.synchronize()
+    # the full run's outputs were produced with the ORIGINAL weights too (L=1: outputs precede the Adam step)
+    assert torch.equal(plan.YN, pa.YN[K // 2:]) and torch.equal(plan.VN, pa.VN[K // 2:])
