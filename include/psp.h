@@ -108,6 +108,20 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
                         const float* y0, const float* xi, uint64_t seed, uint32_t iter, float* path,
                         float* D_out, float* XN_out, double* fwd_partial, void* stream);
 
+/*
+ * Forward-only controlled rollout for importance-sampling evaluation: replaces the n-loop of
+ * utilities.do_importance_sampling_me (reference utilities.py:309-328) with u = -Z_n (control='approx').
+ * Same kernel as psp_hjb_rollout_fwd with store_path = 0 and
+ *   tfeat    : (N) fp32 network time input per step -- the reference maps t = n*delta_t to
+ *              ceil(t / model.delta_t) * model.delta_t (solver.py:360-362); NULL -> n*dt
+ *   D_out    : Y_N - g(X_N) with Y accumulated as in Solver.train; the Girsanov log-weight of
+ *              utilities.py:330-336 is  D_out - 2*Fint_out  (-int f - g - int u.dW - 0.5 int |u|^2)
+ *   Fint_out : optional (K_local) sum_n f(X_{n+1}) dt
+ */
+int psp_hjb_rollout_eval(const psp_hjb_config* cfg, const float* params, const float* x0, int32_t x0_stride,
+                         const float* xi, uint64_t seed, uint32_t iter, const float* tfeat, float* D_out,
+                         float* Fint_out, float* XN_out, double* fwd_partial, void* stream);
+
 /* Sums the per-workgroup partials in a fixed order: sums_out[0] = sum_k D_k, sums_out[1] = sum_k D_k^2
  * over this rank's trajectories (fp64, device).  The caller all-reduces sums_out across ranks. */
 int psp_hjb_terminal_reduce(const psp_hjb_config* cfg, const double* fwd_partial, double* sums_out, void* stream);

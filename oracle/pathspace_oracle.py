@@ -244,6 +244,8 @@ class HJBConfig:
     adaptive_forward_process: bool = True
     detach_forward: bool = False
     random_X_0: bool = False
+    IS_variance_K: int = 0
+    IS_variance_iter: int = 1
 
 
 def hjb_build(problem: OracleProblem, cfg: HJBConfig, net: Optional[torch.nn.Module] = None):
@@ -294,7 +296,7 @@ def hjb_train(problem: OracleProblem, cfg: HJBConfig, net=None, noise: Optional[
     dt32 = torch.tensor(cfg.delta_t)                                 # :39
     sq_dt32 = torch.sqrt(dt32)                                       # :40
     K, d = cfg.K, problem.d
-    out = dict(loss_log=[], Y_0_log=[], traces=[], N=N)
+    out = dict(loss_log=[], Y_0_log=[], traces=[], N=N, IS_rel_log=[])
     torch.manual_seed(cfg.seed)                                      # :422
     for l in range(cfg.L):
         X = problem.X_0.repeat(K, 1)                                 # :365
@@ -334,8 +336,41 @@ def hjb_train(problem: OracleProblem, cfg: HJBConfig, net=None, noise: Optional[
         for p_ in phis:
             p_.optim.step()                                          # :198-200
         out["loss_log"].append(loss.item())                          # :514
+        if cfg.IS_variance_K > 0 and l % cfg.IS_variance_iter == 0:  # :521-528 (draws from the same generator)
+            out["IS_rel_log"].append(is_eval(problem, z, cfg.delta_t, N, cfg.IS_variance_K,
+                                             time_approx=cfg.time_approx)[2])
     out["z"], out["y0"] = z, y0
     return out
+
+
+def is_eval(problem: OracleProblem, z, model_delta_t, N_model, K, delta_t=0.01, time_approx="inner"):
+    """Restates utilities.do_importance_sampling_me (utilities.py:287-359), control='approx',
+    simulate_naive=False: forward-only controlled rollout with its own step delta_t, Girsanov weight
+    exp(-int u.dW - 0.5 int |u|^2 dt), statistics of exp(-int f - g(X_T)) * weight."""
+    sq_dt = np.sqrt(delta_t)                                          # :298 (float64 numpy scalars)
+    N = int(np.ceil(problem.T / delta_t))                            # :299
+    dt32 = torch.tensor(model_delta_t)
+    X_u = problem.X_0.repeat(K, 1)                                   # :303
+    ito = torch.zeros(K)
+    riemann = torch.zeros(K)
+    f_int_u = torch.zeros(K)
+    for n in range(N):
+        xi = torch.randn(K, problem.d)                               # :310
+        t = n * delta_t
+        n_idx = int(torch.ceil(t / dt32))                            # solver.py:361 (Z_n)
+        with torch.no_grad():
+            ut = -control_eval(z, X_u, n_idx, dt32, N_model, time_approx)     # :321
+        sig = problem.sigma(X_u)
+        X_u = (X_u + (problem.b(X_u) + torch.mm(sig, ut.t()).t()) * delta_t
+               + torch.mm(sig, xi.t()).t() * sq_dt)                  # :324-325
+        ito = ito + torch.sum(ut * xi, 1) * sq_dt                    # :326
+        riemann = riemann + torch.sum(ut ** 2, 1) * delta_t          # :327
+        f_int_u = f_int_u + problem.f(X_u, n * delta_t) * delta_t    # :328
+    girsanov = torch.exp(-ito - 0.5 * riemann)                       # :330
+    w = torch.exp(-f_int_u - problem.g(X_u)) * girsanov
+    mean_IS = torch.mean(w).item()                                   # :336
+    var_IS = torch.var(w).item()                                     # :337
+    return mean_IS, var_IS, float(np.sqrt(var_IS) / mean_IS)         # :338
 
 
 def control_on_grid(z, X, t, delta_t, N, time_approx="inner"):

@@ -37,6 +37,8 @@ struct HjbArgs {
     const float* term;
     const double* sums;
     float* grad_partial;
+    const float* tfeat;        // optional (N) per-step network time input (evaluation rollouts); null -> n * dt
+    float* Fint;               // optional (K_local) running-cost integral sum_n f(X_{n+1}) dt
     unsigned long long* dbg;   // diagnostic builds (-DPSP_STAMPS): per-wave phase cycle sums
     long long k_offset;
     long long K_global;
@@ -358,13 +360,15 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             }
         }
         float Y = a.y0 ? a.y0[0] : 0.f;               // solver.py:368 / :373
+        float Fsum = 0.f;
 #ifdef PSP_STAMPS
         unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
         for (int n = 0; n < a.N; ++n) {
             PSP_STAMP(fs0);
-            const float tn = (float)n * dt;            // solver.py:355: ones * n * delta_t
+            // solver.py:355: ones * n * delta_t ; evaluation rollouts pass the table of solver.py:360-362
+            const float tn = a.tfeat ? a.tfeat[n] : (float)n * dt;
             const f32x4* vecs = opaque(vecs0);         // re-read the small vectors each step (no hoisting)
             const f32x4* vb1 = vecs + (G::vb1 - G::fVec) / 4;
             const f32x4* vw1t = vecs + (G::vw1t - G::fVec) / 4;
@@ -478,6 +482,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             // Y += (-h + Z.c) dt + Z.xi sqrt(dt);  -h = 0.5|Z|^2 + f ; Z.c = -|Z|^2 (adaptive) or 0
             const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
             Y = Y + drift_y * dt + Pz * sqdt;
+            Fsum = fmaf(fX, dt, Fsum);
             PSP_STAMP(fs6);
             PSP_ACC(0, fs1, fs0);   // path store of X + L1 GEMM
             PSP_ACC(1, fs2, fs1);   // tanh 1
@@ -510,6 +515,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
         g = qsum(g);
         const float Dk = Y - g;
         if (kvalid && q == 0) a.D[k] = Dk;
+        if (a.Fint && kvalid && q == 0) a.Fint[k] = Fsum;
         if (a.XN && kvalid) {
 #pragma unroll
             for (int b = 0; b < DB; ++b)

@@ -320,6 +320,27 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
     return 0;
 }
 
+int psp_hjb_rollout_eval(const psp_hjb_config* cfg, const float* params, const float* x0, int32_t x0_stride,
+                         const float* xi, uint64_t seed, uint32_t iter, const float* tfeat, float* D_out,
+                         float* Fint_out, float* XN_out, double* fwd_partial, void* stream) {
+    Plan p;
+    int rc = make_plan(cfg, &p);
+    if (rc) return rc;
+    if ((rc = check_ptrs(cfg))) return rc;
+    if (!params || !x0 || !D_out || !fwd_partial) return fail(-1, "null buffer passed to psp_hjb_rollout_eval");
+    if (x0_stride != 0 && x0_stride != cfg->d) return fail(-1, "x0_stride must be 0 or d");
+    if (cfg->noise_mode == PSP_NOISE_SUPPLIED && !xi) return fail(-1, "supplied-noise mode needs xi");
+    psp::HjbArgs a;
+    fill_args(cfg, p, &a);
+    a.store_path = 0;
+    a.params = params; a.x0 = x0; a.x0_stride = x0_stride; a.xi = xi; a.tfeat = tfeat;
+    a.D = D_out; a.Fint = Fint_out; a.XN = XN_out; a.fwd_partial = fwd_partial;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
+    hipError_t e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel (eval) launch");
+    return 0;
+}
+
 int psp_hjb_terminal_reduce(const psp_hjb_config* cfg, const double* fwd_partial, double* sums_out, void* stream) {
     Plan p;
     int rc = make_plan(cfg, &p);

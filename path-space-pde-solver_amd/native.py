@@ -80,6 +80,8 @@ SIGNATURES = {
     "psp_hjb_query": (C.c_int, [C.POINTER(HjbConfig), C.POINTER(HjbSizes)]),
     "psp_hjb_rollout_fwd": (C.c_int, [C.POINTER(HjbConfig), _P, _P, C.c_int32, _P, _P, C.c_uint64, C.c_uint32,
                                       _P, _P, _P, _P, _P]),
+    "psp_hjb_rollout_eval": (C.c_int, [C.POINTER(HjbConfig), _P, _P, C.c_int32, _P, C.c_uint64, C.c_uint32, _P, _P, _P,
+                                       _P, _P, _P]),
     "psp_hjb_terminal_reduce": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P]),
     "psp_hjb_rollout_bwd": (C.c_int, [C.POINTER(HjbConfig), _P, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "psp_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),

@@ -43,8 +43,8 @@ def native_eligibility(solver):
     if solver.u_l2_error_flag:
         return ('u_l2_error_flag=True evaluates problem.u_true on the host every step '
                 '(reference solver.py:491-494); pass u_l2_error_flag=False for the native plan')
-    if solver.IS_variance_K > 0 or solver.compute_gradient_variance > 0 or solver.log_gradient:
-        return 'per-iteration diagnostics (IS variance / gradient variance / gradient log) are not native'
+    if solver.compute_gradient_variance > 0 or solver.log_gradient:
+        return 'per-iteration diagnostics (gradient variance / gradient log) are not native'
     if solver.metastability_logs is not None:
         return 'metastability_logs needs X_N on the host every iteration'
     net = solver.z_n

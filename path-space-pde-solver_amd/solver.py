@@ -35,11 +35,13 @@ try:
     from .plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
     from . import native as _nat
     from .general_solver import GeneralSolver  # noqa: F401  (reference: `from solver import GeneralSolver`)
+    from .utilities import do_importance_sampling_me
 except ImportError:  # flat import: this directory itself is on sys.path, as with the reference
     from function_space import DenseNet, MySequential, SingleParam
     from plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
     import native as _nat
     from general_solver import GeneralSolver  # noqa: F401
+    from utilities import do_importance_sampling_me
 
 
 def _default_device():
@@ -286,6 +288,8 @@ class Solver:
             if self.learn_Y_0:
                 y0_hist[l:l + 1].copy_(self.y_0.Y_0.detach())       # Y_0 before the update (solver.py:374)
             plan.iteration(l, losses)
+            if self.IS_variance_K > 0 and l % self.IS_variance_iter == 0:        # solver.py:521-528
+                self.IS_rel_log.append(do_importance_sampling_me(self.problem, self, self.IS_variance_K)[2])
             if (self.verbose and l % self.print_every == 0) or l == self.L - 1:
                 vals = losses[done:l + 1].cpu().tolist()          # one sync per block
                 now = time.time()
@@ -306,9 +310,8 @@ class Solver:
         """The reference iteration restated with torch ops on self.device (solver.py:430-554)."""
         if self.approx_method != 'control':
             raise NotImplementedError("composite plan covers approx_method='control' only")
-        if self.IS_variance_K > 0 or self.compute_gradient_variance > 0:
-            raise NotImplementedError('IS-variance / gradient-variance diagnostics are not implemented '
-                                      '(SURVEY.md 8f, next rows)')
+        if self.compute_gradient_variance > 0:
+            raise NotImplementedError('per-sample gradient-variance diagnostics are not implemented')
         dev, dt, sq = self.device, self.delta_t, self.sq_delta_t
         repa = self.loss_method == 'reparametrization'
         rel_ent = 'relative_entropy' in self.loss_method
@@ -356,6 +359,8 @@ class Solver:
                 target, epsilon = self.metastability_logs
                 self.particles_close_to_target.append(
                     torch.mean((torch.sqrt(torch.sum((X - target) ** 2, 1)) < epsilon).float()))
+            if self.IS_variance_K > 0 and l % self.IS_variance_iter == 0:        # solver.py:521-528
+                self.IS_rel_log.append(do_importance_sampling_me(self.problem, self, self.IS_variance_K)[2])
             self.times.append(time.time() - t_0)
             if self.verbose and l % self.print_every == 0:
                 msg = ('%d - loss: %.4e - u L2: %.4e - time/iter: %.2fs'

@@ -1,0 +1,147 @@
+"""Evaluation utilities -- API mirror of the hot-path-adjacent part of the reference's utilities.py.
+
+``do_importance_sampling_me`` (reference utilities.py:287-359) estimates E[exp(-int f - g(X_T))] under the
+learned control with the Girsanov weight and reports mean, variance and relative error.  It is the
+same controlled Euler-Maruyama rollout as the training step, forward only, at ``K`` up to 1e7
+(SURVEY.md 8f rank 1), and is called from Solver.train every ``IS_variance_iter`` iterations when
+``IS_variance_K > 0`` (solver.py:521-528).
+
+Native plan: psp_hjb_rollout_eval (include/psp.h) on the solver's control net whenever the solver is
+native-eligible; composite torch plan otherwise.  Plotting helpers of the reference are out of scope.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+try:
+    from . import native as nat
+except ImportError:
+    import native as nat
+
+
+def _time_feature_table(model, N, delta_t):
+    """Network time input the reference uses at IS step n: Z_n(X, n*delta_t) -> index ceil(t/model.delta_t)
+    in fp32 (solver.py:360-362), then ones * index * model.delta_t (solver.py:355)."""
+    dt32 = model.delta_t.detach().cpu()
+    vals = []
+    for n in range(N):
+        t = torch.as_tensor(n * delta_t, dtype=torch.float32)
+        idx = int(torch.ceil(t / dt32))
+        vals.append(float((torch.ones(1) * idx * dt32).item()))
+    return torch.tensor(vals, dtype=torch.float32)
+
+
+def _native_reason(problem, model, control, simulate_naive):
+    try:
+        from .plan_native import native_eligibility
+    except ImportError:
+        from plan_native import native_eligibility
+    if control != 'approx' and model.u_l2_error_flag:
+        return "control='true' evaluates problem.u_true on the host"
+    if simulate_naive:
+        return 'simulate_naive needs the uncontrolled process too'
+    if getattr(model, 'backend', 'auto') == 'torch':
+        return "backend='torch' requested"
+    saved = (model.IS_variance_K, model.u_l2_error_flag)
+    model.IS_variance_K, model.u_l2_error_flag = 0, False          # these two do not matter for the evaluation itself
+    try:
+        return native_eligibility(model)
+    finally:
+        model.IS_variance_K, model.u_l2_error_flag = saved
+
+
+def _stats(logw):
+    w = torch.exp(logw)
+    mean_IS = torch.mean(w).item()
+    variance_IS = torch.var(w).item()
+    return mean_IS, variance_IS, float(np.sqrt(variance_IS) / mean_IS)
+
+
+def _is_native(problem, model, K, delta_t):
+    dev = model.device
+    lib = nat.load()
+    N = int(np.ceil(problem.T / delta_t))
+    spec = problem.native_spec()
+    keep = []
+
+    def dev_f32(t):
+        t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep.append(t)
+        return t
+
+    cfg = nat.HjbConfig()
+    cfg.d, cfg.H, cfg.K_local, cfg.N = model.d, model.z_n.native_shape()[1], K, N
+    cfg.K_global, cfg.k_offset = K, 0
+    cfg.dt = float(torch.tensor(delta_t, dtype=torch.float32).item())
+    cfg.sqrt_dt = float(torch.tensor(np.sqrt(delta_t), dtype=torch.float32).item())
+    cfg.drift_kind = spec['drift'][0]
+    cfg.drift = nat.ptr(dev_f32(spec['drift'][1])) if spec['drift'][1] is not None else None
+    cfg.sigma_kind = spec['sigma'][0]
+    cfg.sigma = nat.ptr(dev_f32(spec['sigma'][1])) if spec['sigma'][1] is not None else None
+    cfg.sigma_scale = float(spec['sigma'][2])
+    cfg.runcost_kind = spec['runcost'][0]
+    cfg.runcost = nat.ptr(dev_f32(spec['runcost'][1])) if spec['runcost'][1] is not None else None
+    cfg.term_kind = spec['term'][0]
+    cfg.term = nat.ptr(dev_f32(spec['term'][1]))
+    cfg.adaptive, cfg.loss_kind, cfg.store_path = 1, nat.LOSS_LOG_VARIANCE, 0
+    philox = getattr(model, 'noise', 'reference') == 'philox'
+    cfg.noise_mode = nat.NOISE_PHILOX if philox else nat.NOISE_SUPPLIED
+    sizes = nat.query(cfg)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.z_n.flat_layout()]).to(dev).contiguous()
+    xi = None
+    if not philox:                                   # the reference's draws: N x randn(K, d) (utilities.py:310)
+        xi_cpu = torch.zeros(N + 1, K, model.d)
+        for n in range(N):
+            xi_cpu[n + 1] = torch.randn(K, model.d)
+        xi = xi_cpu.to(dev)
+    tfeat = _time_feature_table(model, N, delta_t).to(dev)
+    x0 = dev_f32(torch.as_tensor(problem.X_0, dtype=torch.float32))
+    D = torch.empty(K, dtype=torch.float32, device=dev)
+    Fint = torch.empty(K, dtype=torch.float32, device=dev)
+    part = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)
+    model._is_calls = getattr(model, '_is_calls', 0) + 1
+    nat.check(lib.psp_hjb_rollout_eval(C.byref(cfg), nat.ptr(flat), nat.ptr(x0), 0, nat.ptr(xi),
+                                       (int(model.seed) + 7919) & 0xFFFFFFFFFFFFFFFF, model._is_calls,
+                                       nat.ptr(tfeat), nat.ptr(D), nat.ptr(Fint), None, nat.ptr(part),
+                                       nat.stream_ptr(dev)), 'psp_hjb_rollout_eval')
+    return _stats(D - 2.0 * Fint)
+
+
+def _is_composite(problem, model, K, delta_t):
+    dev = model.device
+    sq_dt = np.sqrt(delta_t)
+    N = int(np.ceil(problem.T / delta_t))
+    X_u = torch.as_tensor(problem.X_0, dtype=torch.float32).repeat(K, 1).to(dev)
+    ito = torch.zeros(K).to(dev)
+    riemann = torch.zeros(K).to(dev)
+    f_int_u = torch.zeros(K).to(dev)
+    for n in range(N):
+        xi = torch.randn(K, problem.d).to(dev)
+        with torch.no_grad():
+            ut = -model.Z_n(X_u, n * delta_t)
+        sig = problem.sigma(X_u)
+        X_u = (X_u + (problem.b(X_u) + torch.mm(sig, ut.t()).t()) * delta_t + torch.mm(sig, xi.t()).t() * sq_dt)
+        ito = ito + torch.sum(ut * xi, 1) * sq_dt
+        riemann = riemann + torch.sum(ut ** 2, 1) * delta_t
+        f_int_u = f_int_u + model.f(X_u, n * delta_t) * delta_t
+    return _stats(-f_int_u - problem.g(X_u) - ito - 0.5 * riemann)
+
+
+def do_importance_sampling_me(problem, model, K, control='approx', simulate_naive=False, verbose=False,
+                              delta_t=0.01, on_cpu=False, cross_statistics=None):
+    """Returns (mean_IS, variance_IS, rel_error_IS) -- reference utilities.py:287-359 for control='approx'.
+    ``simulate_naive``, ``control='true'`` with a reference solution, ``on_cpu`` and ``cross_statistics``
+    are not built."""
+    if simulate_naive or on_cpu or cross_statistics is not None or (control != 'approx' and model.u_l2_error_flag):
+        raise NotImplementedError('only the controlled estimator with the learned control is built')
+    reason = _native_reason(problem, model, control, simulate_naive)
+    if reason is None:
+        out = _is_native(problem, model, K, delta_t)
+    else:
+        if getattr(model, 'backend', 'auto') == 'native':
+            raise NotImplementedError('native IS evaluation unavailable: ' + reason)
+        out = _is_composite(problem, model, K, delta_t)
+    if verbose:
+        print('IS mean: %.4e, IS variance: %.4e, IS RE %.4e' % out)
+    return out

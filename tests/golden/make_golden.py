@@ -133,6 +133,22 @@ def run_solver_case(case):
     return res
 
 
+def run_is_case(case):
+    """Train a few iterations, then run the reference's importance-sampling evaluation
+    (utilities.py:287-359) on a fresh seed; also the in-loop variant (solver.py:521-528)."""
+    problem = make_problem(case["problem"])
+    skw = dict(case["solver"])
+    model = ref_sv.Solver(name=case["name"], problem=problem, verbose=False, **skw)
+    model.train()
+    torch.manual_seed(case["is_seed"])
+    mean_IS, var_IS, rel_IS = ref_ut.do_importance_sampling_me(problem, model, case["is_K"],
+                                                              delta_t=case["is_delta_t"])
+    return {"N": model.N, "loss_log": [float(v) for v in model.loss_log],
+            "IS_rel_log": [float(v) for v in model.IS_rel_log],
+            "mean_IS": float(mean_IS), "variance_IS": float(var_IS), "rel_error_IS": float(rel_IS),
+            "final_params": param_fingerprint(model.z_n)}
+
+
 def run_general_case(case):
     problem = make_problem(case["problem"])
     skw = dict(case["solver"])
@@ -210,6 +226,20 @@ CASES = [
          solver=dict(loss_method="log-variance", time_approx="outer", adaptive_forward_process=True,
                      detach_forward=True, early_stopping_time=None, L=3, lr=0.01, seed=42,
                      delta_t=0.05, K=64, u_l2_error_flag=False)),
+    # importance-sampling evaluation of the learned control, standalone and in the loop
+    dict(name="llgc_d20_is_eval", family="is",
+         problem=dict(kind="LLGC", kwargs=dict(d=20, off_diag=0.0, T=0.3, seed=42)),
+         solver=dict(HJB, L=3, lr=0.002, seed=42, delta_t=0.01, K=200, u_l2_error_flag=False),
+         is_seed=7, is_K=512, is_delta_t=0.01),
+    dict(name="lqgc_d4_is_eval", family="is",
+         problem=dict(kind="LQGC", kwargs=dict(d=4, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
+         solver=dict(HJB, L=3, lr=0.01, seed=3, delta_t=0.05, K=96, u_l2_error_flag=False),
+         is_seed=11, is_K=300, is_delta_t=0.01),
+    dict(name="dw_d10_is_in_loop", family="is",
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=10, d_1=5, d_2=5, T=0.5, eta=0.5, kappa=2.0)),
+         solver=dict(HJB, L=4, lr=0.005, seed=42, delta_t=0.01, K=256, u_l2_error_flag=False,
+                     IS_variance_K=128, IS_variance_iter=2),
+         is_seed=5, is_K=256, is_delta_t=0.01),
     # GeneralSolver, diffusion loss, unbounded square
     dict(name="dwgen_d10_diffusion", family="general",
          problem=dict(kind="DoubleWell_multidim_for_general_solver",
@@ -246,7 +276,7 @@ def main():
         if only and case["name"] not in only:
             continue
         print("running", case["name"], flush=True)
-        res = run_solver_case(case) if case["family"] == "solver" else run_general_case(case)
+        res = {"solver": run_solver_case, "general": run_general_case, "is": run_is_case}[case["family"]](case)
         rec = {"case": case, "expected": res, "torch": torch.__version__}
         with open(os.path.join(OUT, case["name"] + ".json"), "w") as fh:
             json.dump(rec, fh, indent=1)

@@ -65,3 +65,30 @@ def test_flat_import_like_the_reference(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip().endswith("1")
+
+
+IS_CASES = ["llgc_d20_is_eval", "lqgc_d4_is_eval", "dw_d10_is_in_loop"]
+
+
+@pytest.mark.parametrize("name", IS_CASES)
+def test_importance_sampling_composite_matches_reference(name):
+    """utilities.do_importance_sampling_me (reference utilities.py:287-359), standalone after training and
+    called from inside Solver.train (IS_variance_K > 0, solver.py:521-528)."""
+    from util_cases import psp
+    rec = load_golden(name)
+    exact = rec["torch"] == torch.__version__
+    case = rec["case"]
+    torch.set_num_threads(1)
+    model = make_pkg_solver(case, "cpu")
+    model.train()
+    exp = rec["expected"]
+    for got, want in zip(model.loss_log, exp["loss_log"]):
+        assert (got == want) if exact else math.isclose(got, want, rel_tol=1e-5)
+    assert len(model.IS_rel_log) == len(exp["IS_rel_log"])
+    for got, want in zip(model.IS_rel_log, exp["IS_rel_log"]):
+        assert math.isclose(got, want, rel_tol=1e-5)
+    torch.manual_seed(case["is_seed"])
+    m, v, r = psp.do_importance_sampling_me(model.problem, model, case["is_K"], delta_t=case["is_delta_t"])
+    assert math.isclose(m, exp["mean_IS"], rel_tol=1e-5)
+    assert math.isclose(v, exp["variance_IS"], rel_tol=1e-4)
+    assert math.isclose(r, exp["rel_error_IS"], rel_tol=1e-4)

@@ -186,3 +186,40 @@ def test_full_size_properties_philox():
     assert torch.equal(plan.D, pa.D[K // 2:])
     full_sum = pa.D.double().sum()
     assert abs(float(pa.sums[0] - full_sum)) <= 1e-6 * abs(float(full_sum)) + 1e-6
+
+
+@pytest.mark.parametrize("name", ["llgc_d20_is_eval", "lqgc_d4_is_eval", "dw_d10_is_in_loop"])
+def test_importance_sampling_native_matches_reference(name):
+    """Forward-only IS rollout through psp_hjb_rollout_eval (reference utilities.py:287-359), standalone after
+    native training and called from inside the native training loop (solver.py:521-528), on the reference's
+    CPU-generator noise.  The estimator is exp() of path sums, so tolerances are 2e-4 (mean) / 2e-3 (variance)."""
+    rec = load_golden(name)
+    case = rec["case"]
+    model = make_pkg_solver(case, dev(), backend="native")
+    model.train()
+    assert model.plan_name == "native"
+    exp = rec["expected"]
+    for got, want in zip(model.loss_log, exp["loss_log"]):
+        assert math.isclose(got, want, rel_tol=1e-4), (model.loss_log, exp["loss_log"])
+    assert len(model.IS_rel_log) == len(exp["IS_rel_log"])
+    for got, want in zip(model.IS_rel_log, exp["IS_rel_log"]):
+        assert math.isclose(got, want, rel_tol=2e-3), (model.IS_rel_log, exp["IS_rel_log"])
+    torch.manual_seed(case["is_seed"])
+    m, v, r = psp.do_importance_sampling_me(model.problem, model, case["is_K"], delta_t=case["is_delta_t"])
+    assert math.isclose(m, exp["mean_IS"], rel_tol=2e-4), (m, exp["mean_IS"])
+    assert math.isclose(v, exp["variance_IS"], rel_tol=2e-3), (v, exp["variance_IS"])
+    assert math.isclose(r, exp["rel_error_IS"], rel_tol=2e-3), (r, exp["rel_error_IS"])
+
+
+def test_importance_sampling_large_K_philox():
+    """K = 2^20 evaluation rollout with on-device noise: finite statistics, deterministic for a fixed call index."""
+    prob = psp.LLGC(d=20, off_diag=0.0, T=0.3, seed=42, device=dev())
+    model = psp.Solver("is", prob, lr=2e-3, L=2, K=256, delta_t=0.01, loss_method="log-variance",
+                       time_approx="inner", adaptive_forward_process=True, detach_forward=True,
+                       u_l2_error_flag=False, verbose=False, seed=42, device=dev(), backend="native", noise="philox")
+    model.train()
+    m, v, r = psp.do_importance_sampling_me(prob, model, 1 << 20)
+    assert math.isfinite(m) and math.isfinite(v) and m > 0 and r > 0
+    model._is_calls -= 1
+    m2, v2, r2 = psp.do_importance_sampling_me(prob, model, 1 << 20)
+    assert (m, v, r) == (m2, v2, r2)

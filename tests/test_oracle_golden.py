@@ -108,6 +108,31 @@ def test_general_oracle_matches_reference(name):
     _check_fp(orc.fingerprint(out["V"]), exp["final_params"], exact)
 
 
+IS_CASES = ["llgc_d20_is_eval", "lqgc_d4_is_eval", "dw_d10_is_in_loop"]
+
+
+@pytest.mark.parametrize("name", IS_CASES)
+def test_is_evaluation_oracle_matches_reference(name):
+    """utilities.do_importance_sampling_me, standalone after training and inside the loop."""
+    rec = load_golden(name)
+    exact = _same_build(rec)
+    case = rec["case"]
+    torch.set_num_threads(1)
+    prob = orc.make_problem(case["problem"]["kind"], **case["problem"]["kwargs"])
+    s = dict(case["solver"])
+    cfg = orc.HJBConfig(K=s["K"], delta_t=s["delta_t"], lr=s["lr"], L=s["L"], seed=s["seed"],
+                        loss_method=s["loss_method"], time_approx=s["time_approx"],
+                        adaptive_forward_process=s["adaptive_forward_process"], detach_forward=s["detach_forward"],
+                        IS_variance_K=s.get("IS_variance_K", 0), IS_variance_iter=s.get("IS_variance_iter", 1))
+    out = orc.hjb_train(prob, cfg)
+    exp = rec["expected"]
+    _check_series(out["loss_log"], exp["loss_log"], exact)
+    _check_series(out["IS_rel_log"], exp["IS_rel_log"], exact)
+    torch.manual_seed(case["is_seed"])
+    m, v, r = orc.is_eval(prob, out["z"], cfg.delta_t, out["N"], case["is_K"], delta_t=case["is_delta_t"])
+    _check_series([m, v, r], [exp["mean_IS"], exp["variance_IS"], exp["rel_error_IS"]], exact)
+
+
 def test_noise_fingerprint():
     """The CPU generator stream the reference's fixed-seed runs rely on."""
     idx = load_golden("index")
