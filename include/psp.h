@@ -39,7 +39,9 @@ enum { PSP_RUNCOST_ZERO = 0, PSP_RUNCOST_DIAG_QUAD = 1 };
 /* terminal cost g(x): problems.py:49 (alpha.x), :164 (x'Rx, diagonal R), :334 (sum eta_j (x_j-1)^2) */
 enum { PSP_TERM_LINEAR = 0, PSP_TERM_DIAG_QUAD = 1, PSP_TERM_SHIFTED_QUAD = 2 };
 /* loss: solver.py:167-168 (log-variance), :165-166 (moment) */
-enum { PSP_LOSS_LOG_VARIANCE = 0, PSP_LOSS_MOMENT = 1 };
+/* PSP_LOSS_WEIGHTS: psp_hjb_rollout_bwd takes w_k = dLoss/dY_k itself in its D argument (losses whose
+ * weights are not affine in D: variance :171-172, cross_entropy :183-186) */
+enum { PSP_LOSS_LOG_VARIANCE = 0, PSP_LOSS_MOMENT = 1, PSP_LOSS_WEIGHTS = 2 };
 /* Brownian increments: supplied = the reference's host-generated xi (solver.py:381), philox = on device */
 enum { PSP_NOISE_SUPPLIED = 0, PSP_NOISE_PHILOX = 1 };
 
@@ -102,11 +104,12 @@ int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out);
  *   path     : X_n store (path_bytes) or NULL
  *   D_out    : (K_local) fp32, D_k = Y_k - g(X_N,k)
  *   XN_out   : optional (K_local, d) final states or NULL
+ *   Y_out    : optional (K_local) Y_N (losses that need Y and g separately) or NULL
  *   fwd_partial: fwd_partial_bytes scratch
  */
 int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const float* x0, int32_t x0_stride,
                         const float* y0, const float* xi, uint64_t seed, uint32_t iter, float* path,
-                        float* D_out, float* XN_out, double* fwd_partial, void* stream);
+                        float* D_out, float* XN_out, float* Y_out, double* fwd_partial, void* stream);
 
 /*
  * Forward-only controlled rollout for importance-sampling evaluation: replaces the n-loop of

@@ -270,7 +270,7 @@ def control_eval(z, X, n, dt32, N, time_approx="inner"):
     return z(t_X)                                                    # :356
 
 
-def hjb_loss(kind, D, Y, gX, Z_sum=None):
+def hjb_loss(kind, D, Y, gX, Z_sum=None, adaptive=True):
     """solver.py:164-192 for the losses in scope."""
     if kind == "moment":
         return D.pow(2).mean()                                       # :166
@@ -278,6 +278,10 @@ def hjb_loss(kind, D, Y, gX, Z_sum=None):
         return D.pow(2).mean() - D.mean().pow(2)                     # :168
     if kind == "variance":
         return torch.var(torch.exp(-gX + Y))                         # :172
+    if kind == "cross_entropy":
+        if adaptive:
+            return (Y * torch.exp(-gX + Y.detach())).mean()          # :185
+        return (Y * torch.exp(-gX)).mean()                           # :186
     raise NotImplementedError(kind)
 
 
@@ -327,7 +331,7 @@ def hjb_train(problem: OracleProblem, cfg: HJBConfig, net=None, noise: Optional[
             p_.optim.zero_grad()                                     # :194-196
         gX = problem.g(X)
         D = Y - gX
-        loss = hjb_loss(cfg.loss_method, D, Y, gX) + torch.zeros(K).mean()   # :220, :434, :499
+        loss = hjb_loss(cfg.loss_method, D, Y, gX, adaptive=cfg.adaptive_forward_process) + torch.zeros(K).mean()   # :220, :434, :499
         loss.backward()                                              # :221
         if trace:
             tr["D"] = D.detach().clone()

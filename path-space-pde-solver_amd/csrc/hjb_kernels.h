@@ -39,6 +39,7 @@ struct HjbArgs {
     float* grad_partial;
     const float* tfeat;        // optional (N) per-step network time input (evaluation rollouts); null -> n * dt
     float* Fint;               // optional (K_local) running-cost integral sum_n f(X_{n+1}) dt
+    float* Yout;               // optional (K_local) Y_N
     unsigned long long* dbg;   // diagnostic builds (-DPSP_STAMPS): per-wave phase cycle sums
     long long k_offset;
     long long K_global;
@@ -56,7 +57,7 @@ enum { DRIFT_ZERO = 0, DRIFT_DENSE = 1, DRIFT_DIAG = 2, DRIFT_DWELL = 3 };
 enum { SIGMA_IDENT = 0, SIGMA_DENSE = 1, SIGMA_SCALE = 2 };
 enum { RUN_ZERO = 0, RUN_DIAGQ = 1 };
 enum { TERM_LINEAR = 0, TERM_DIAGQ = 1, TERM_SHIFTQ = 2 };
-enum { LOSS_LOGVAR = 0, LOSS_MOMENT = 1 };
+enum { LOSS_LOGVAR = 0, LOSS_MOMENT = 1, LOSS_WEIGHTS = 2 };
 enum { NOISE_SUPPLIED = 0, NOISE_PHILOX = 1 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
         const float Dk = Y - g;
         if (kvalid && q == 0) a.D[k] = Dk;
         if (a.Fint && kvalid && q == 0) a.Fint[k] = Fsum;
+        if (a.Yout && kvalid && q == 0) a.Yout[k] = Y;
         if (a.XN && kvalid) {
 #pragma unroll
             for (int b = 0; b < DB; ++b)
@@ -656,7 +658,9 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
             const bool kvalid = bvalid && k < a.K_local;
             const uint32_t kglob = (uint32_t)(a.k_offset + k);
             const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
-            const float wk = kvalid ? coef * (a.D[kvalid ? k : 0] - meanD) : 0.f;
+            // LOSS_WEIGHTS: the caller supplies w_k = dLoss/dY_k directly in the D argument
+            const float dk = a.D[kvalid ? k : 0];
+            const float wk = kvalid ? (a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)) : 0.f;
             f32x4 Gt[DB];
 #pragma unroll
             for (int m = 0; m < DB; ++m) Gt[m] = zero4;

@@ -85,7 +85,7 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     }
     if (c->drift_kind < 0 || c->drift_kind > 3 || c->sigma_kind < 0 || c->sigma_kind > 2 ||
         c->runcost_kind < 0 || c->runcost_kind > 1 || c->term_kind < 0 || c->term_kind > 2 ||
-        c->loss_kind < 0 || c->loss_kind > 1 || c->noise_mode < 0 || c->noise_mode > 1)
+        c->loss_kind < 0 || c->loss_kind > 2 || c->noise_mode < 0 || c->noise_mode > 1)
         return fail(-1, "config enum out of range");
     if (p->inst.fwd_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
         return fail(-3, "forward kernel weights do not fit the 160 KiB LDS for this (d,H,drift,sigma)");
@@ -301,7 +301,7 @@ int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out) {
 
 int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const float* x0, int32_t x0_stride,
                         const float* y0, const float* xi, uint64_t seed, uint32_t iter, float* path,
-                        float* D_out, float* XN_out, double* fwd_partial, void* stream) {
+                        float* D_out, float* XN_out, float* Y_out, double* fwd_partial, void* stream) {
     Plan p;
     int rc = make_plan(cfg, &p);
     if (rc) return rc;
@@ -313,7 +313,7 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
     psp::HjbArgs a;
     fill_args(cfg, p, &a);
     a.params = params; a.x0 = x0; a.x0_stride = x0_stride; a.y0 = y0; a.xi = xi; a.path = path;
-    a.D = D_out; a.XN = XN_out; a.fwd_partial = fwd_partial;
+    a.D = D_out; a.XN = XN_out; a.Yout = Y_out; a.fwd_partial = fwd_partial;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
     hipError_t e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel launch");

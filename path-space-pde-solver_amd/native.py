@@ -19,7 +19,7 @@ DRIFT_ZERO, DRIFT_DENSE, DRIFT_DIAG, DRIFT_DOUBLE_WELL = 0, 1, 2, 3
 SIGMA_IDENTITY, SIGMA_DENSE, SIGMA_SCALED_IDENTITY = 0, 1, 2
 RUNCOST_ZERO, RUNCOST_DIAG_QUAD = 0, 1
 TERM_LINEAR, TERM_DIAG_QUAD, TERM_SHIFTED_QUAD = 0, 1, 2
-LOSS_LOG_VARIANCE, LOSS_MOMENT = 0, 1
+LOSS_LOG_VARIANCE, LOSS_MOMENT, LOSS_WEIGHTS = 0, 1, 2
 NOISE_SUPPLIED, NOISE_PHILOX = 0, 1
 GH_ZERO, GH_QUAD, GH_ALLEN_CAHN = 0, 1, 2
 
@@ -79,7 +79,7 @@ SIGNATURES = {
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_query": (C.c_int, [C.POINTER(HjbConfig), C.POINTER(HjbSizes)]),
     "psp_hjb_rollout_fwd": (C.c_int, [C.POINTER(HjbConfig), _P, _P, C.c_int32, _P, _P, C.c_uint64, C.c_uint32,
-                                      _P, _P, _P, _P, _P]),
+                                      _P, _P, _P, _P, _P, _P]),
     "psp_hjb_rollout_eval": (C.c_int, [C.POINTER(HjbConfig), _P, _P, C.c_int32, _P, C.c_uint64, C.c_uint32, _P, _P, _P,
                                        _P, _P, _P]),
     "psp_hjb_terminal_reduce": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P]),

@@ -34,8 +34,8 @@ def native_eligibility(solver):
         return 'device is %s (the HIP rollout needs a GPU)' % solver.device
     if solver.approx_method != 'control' or solver.time_approx != 'inner':
         return "only approx_method='control' with time_approx='inner' is native"
-    if solver.loss_method not in ('log-variance', 'moment'):
-        return "loss_method %r is not native (log-variance, moment)" % solver.loss_method
+    if solver.loss_method not in ('log-variance', 'moment', 'variance', 'cross_entropy'):
+        return "loss_method %r is not native (log-variance, moment, variance, cross_entropy)" % solver.loss_method
     if solver.adaptive_forward_process and not solver.detach_forward:
         return 'detach_forward=False back-propagates through the state path (not native)'
     if solver.burgers_drift:
@@ -108,7 +108,9 @@ class HjbNativePlan:
         cfg.term_kind = spec['term'][0]
         cfg.term = nat.ptr(dev_f32(spec['term'][1]))
         cfg.adaptive = 1 if solver.adaptive_forward_process else 0
-        cfg.loss_kind = nat.LOSS_LOG_VARIANCE if solver.loss_method == 'log-variance' else nat.LOSS_MOMENT
+        cfg.loss_kind = {'log-variance': nat.LOSS_LOG_VARIANCE, 'moment': nat.LOSS_MOMENT}.get(
+            solver.loss_method, nat.LOSS_WEIGHTS)
+        self.generic_loss = cfg.loss_kind == nat.LOSS_WEIGHTS
         cfg.noise_mode = nat.NOISE_PHILOX if noise == 'philox' else nat.NOISE_SUPPLIED
         cfg.store_path = 1
         self.cfg = cfg
@@ -119,6 +121,8 @@ class HjbNativePlan:
         self.fwd_partial = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)
         self.grad_partial = torch.empty(sizes.grad_partial_bytes // 4, dtype=torch.float32, device=dev)
         self.D = torch.empty(self.K_local, dtype=torch.float32, device=dev)
+        self.Yn = torch.empty(self.K_local, dtype=torch.float32, device=dev) if self.generic_loss else None
+        self.w = torch.empty(self.K_local, dtype=torch.float32, device=dev) if self.generic_loss else None
         self.sums = torch.zeros(2, dtype=torch.float64, device=dev)
         self.grad = torch.empty(self.P, dtype=torch.float32, device=dev)
         self.m = torch.zeros(self.P, dtype=torch.float32, device=dev)
@@ -186,18 +190,22 @@ class HjbNativePlan:
             ev[0].record()
         nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0_t), x0_stride, y0_ptr,
                                           nat.ptr(xi), seed, l, nat.ptr(self.path), nat.ptr(self.D), None,
-                                          nat.ptr(self.fwd_partial), st), 'psp_hjb_rollout_fwd')
+                                          nat.ptr(self.Yn), nat.ptr(self.fwd_partial), st), 'psp_hjb_rollout_fwd')
         if ev is not None:
             ev[1].record()
         nat.check(lib.psp_hjb_terminal_reduce(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums), st),
                   'psp_hjb_terminal_reduce')
         sharding.allreduce_sum_(self.sums)              # collective 1: 16 bytes
-        loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
+        d_or_w = self.D
+        if self.generic_loss:
+            loss, d_or_w = self._generic_loss_weights()
+        else:
+            loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
         loss_out[l] = loss.to(torch.float32)
         if ev is not None:
             ev[2].record()
         nat.check(lib.psp_hjb_rollout_bwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(xi), seed, l, nat.ptr(self.path),
-                                          nat.ptr(self.D), nat.ptr(self.sums), nat.ptr(self.grad_partial),
+                                          nat.ptr(d_or_w), nat.ptr(self.sums), nat.ptr(self.grad_partial),
                                           nat.ptr(self.grad), st), 'psp_hjb_rollout_bwd')
         if ev is not None:
             ev[3].record()
@@ -216,6 +224,31 @@ class HjbNativePlan:
         # torch's caching allocator is stream-ordered, so freeing here is safe.
         return loss
 
+    def _generic_loss_weights(self):
+        """Losses whose weights w_k = dLoss/dY_k are not affine in D (K-vector arithmetic in torch, the
+        rollout and the gradient stay in the kernels):
+          variance       var(exp(-g + Y))            (solver.py:171-172, unbiased)  w = 2 (E - mean E) E / (K - 1)
+          cross_entropy  mean(Y exp(-g + Y.detach()))  (adaptive, :185)             w = exp(D) / K
+                         mean(Y exp(-g))               (else, :186)                 w = exp(-g) / K"""
+        s, K = self.s, float(self.s.K)
+        D = self.D
+        if s.loss_method == 'variance':
+            E = torch.exp(D)
+            st = torch.stack([E.double().sum(), (E.double() ** 2).sum()])
+            sharding.allreduce_sum_(st)
+            mean = st[0] / K
+            loss = (st[1] - K * mean * mean) / (K - 1.0)
+            w = (2.0 / (K - 1.0)) * (E - mean.float()) * E
+        else:
+            Y = self.Yn
+            E = torch.exp(D) if s.adaptive_forward_process else torch.exp(D - Y)     # exp(-g) = exp(D - Y)
+            st = (Y.double() * E.double()).sum().reshape(1)
+            sharding.allreduce_sum_(st)
+            loss = st[0] / K
+            w = E / K
+        self.w.copy_(w)
+        return loss, self.w
+
     def forward_only(self, l, want_XN=False):
         """Forward rollout without the path store; returns (D, X_N or None)."""
         s, lib = self.s, self.lib
@@ -228,6 +261,6 @@ class HjbNativePlan:
         XN = torch.empty(self.K_local, s.d, dtype=torch.float32, device=self.dev) if want_XN else None
         nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0_t), s.d if x0 is not None else 0,
                                           nat.ptr(self.y0_param) if self.learn_y0 else None, nat.ptr(xi),
-                                          int(s.seed), l, None, nat.ptr(self.D), nat.ptr(XN),
+                                          int(s.seed), l, None, nat.ptr(self.D), nat.ptr(XN), None,
                                           nat.ptr(self.fwd_partial), self._stream()), 'psp_hjb_rollout_fwd')
         return self.D, XN

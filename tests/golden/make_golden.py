@@ -210,6 +210,19 @@ CASES = [
          problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
          solver=dict(HJB, loss_method="moment", learn_Y_0=True, L=5, lr=0.01, seed=42, delta_t=0.05,
                      K=128, u_l2_error_flag=False)),
+    # losses that only change the per-trajectory weights
+    dict(name="lqgc_d2_variance", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
+         solver=dict(HJB, loss_method="variance", L=5, lr=0.01, seed=42, delta_t=0.05, K=128,
+                     u_l2_error_flag=False)),
+    dict(name="lqgc_d2_cross_entropy", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
+         solver=dict(HJB, loss_method="cross_entropy", L=5, lr=0.01, seed=42, delta_t=0.05, K=128,
+                     u_l2_error_flag=False)),
+    dict(name="llgc_d8_cross_entropy_nonadaptive", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=8, off_diag=0.05, T=0.4, seed=42)),
+         solver=dict(HJB, loss_method="cross_entropy", adaptive_forward_process=False, L=4, lr=0.003, seed=42,
+                     delta_t=0.02, K=160, u_l2_error_flag=False)),
     # random initial points
     dict(name="lqgc_d4_randx0", family="solver",
          problem=dict(kind="LQGC", kwargs=dict(d=4, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),

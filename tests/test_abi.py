@@ -69,7 +69,7 @@ def test_unsupported_shape_reports_error(lib):
 
 def test_null_buffers_are_rejected_before_any_launch(lib):
     c = _cfg()
-    rc = lib.psp_hjb_rollout_fwd(C.byref(c), None, None, 0, None, None, 1, 0, None, None, None, None, None)
+    rc = lib.psp_hjb_rollout_fwd(C.byref(c), None, None, 0, None, None, 1, 0, None, None, None, None, None, None)
     assert rc != 0 and "missing" in nat.last_error() or "null" in nat.last_error()
     rc = lib.psp_adam_step(None, None, None, None, 10, 1, 1e-3, 0.9, 0.999, 1e-8, None)
     assert rc != 0
