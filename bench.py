@@ -244,7 +244,10 @@ def main_general(args, psp):
                           "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%d-%d-1" % (w["d"] + 1, w["H"], w["H"]),
                           "loss": w["loss"], "active_fraction": active / (w["K"] * world * w["N"] * args.steps)},
                "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                            "traffic": (json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                                        .get(args.workload, {}).get(dom)
+                                        if os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")) else None),
                             "alg_flops_per_launched_unit": {"value_net_F": F, "fwd_kernel": 3 * F, "bwd_kernel": 3 * F},
                             "units_per_launch": units, "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms},
                "launched_units_per_s": w["K"] * world * w["N"] * args.steps / elapsed,
