@@ -363,10 +363,10 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
         return (row < H && c2 < H) ? P[G::oW2 + (DI + row) * H + c2] : 0.f; });
     __syncthreads();
     // w3 (h1 / h2 parts) in T layout, straight from the parameter vector (32 L1-resident loads per round)
-    auto w3_T = [&](int base, int m) {
+    auto w3_T = [&](int base, int m, int o0) {          // o0 = opaque zero: keeps the loads inside the round loop
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int f = 16 * m + 4 * r + q; v[r] = f < H ? P[base + (f < H ? f : 0)] : 0.f; }
+        for (int r = 0; r < 4; ++r) { const int f = 16 * m + 4 * r + q; v[r] = f < H ? P[base + o0 + (f < H ? f : 0)] : 0.f; }
         return v;
     };
     float* exch = lds + G::gEx;
@@ -433,34 +433,45 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
             const float wy = a.wY[k], wv = a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
             const float wsv = (bvalid && !fin) ? wy : 0.f;                             // weight of the tangent part
             const float av = bvalid ? (fin ? wv : wy * ah) : 0.f;
-            f32x4 d1[HB], d2[HB], z1t[HB], z2t[HB];
-#pragma unroll
-            for (int m = 0; m < HB; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    d1[m][r] = pb[G::pD1 + (4 * m + r) * 64];
-                    d2[m][r] = pb[G::pD2 + (4 * m + r) * 64];
-                    z1t[m][r] = wsv * pb[G::pZ1 + (4 * m + r) * 64];
-                    z2t[m][r] = wsv * pb[G::pZ2 + (4 * m + r) * 64];
-                }
+            const int o0 = opaque_i(0);
             f32x4 gz2[HB], gz2t[HB];
+            {
+                f32x4 d2[HB], z2t[HB];
 #pragma unroll
-            for (int m = 0; m < HB; ++m) {
-                const f32x4 w3h2 = w3_T(G::oW3 + DI + H, m);
-                gz2t[m] = w3h2 * d2[m];
-                gz2[m] = av * gz2t[m] + w3h2 * step2(d2[m]) * z2t[m];
-                // dW3 (h2 part): a h2 + h2'   with h2 = (d2/2)^2, h2' = d2 z2'
-                g3h2T[m] += av * (0.25f * d2[m] * d2[m]) + d2[m] * z2t[m];
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        d2[m][r] = pb[G::pD2 + (4 * m + r) * 64];
+                        z2t[m][r] = wsv * pb[G::pZ2 + (4 * m + r) * 64];
+                    }
+#pragma unroll
+                for (int m = 0; m < HB; ++m) {
+                    const f32x4 w3h2 = w3_T(G::oW3 + DI + H, m, o0);
+                    gz2t[m] = w3h2 * d2[m];
+                    gz2[m] = av * gz2t[m] + w3h2 * step2(d2[m]) * z2t[m];
+                    // dW3 (h2 part): a h2 + h2'   with h2 = (d2/2)^2, h2' = d2 z2'
+                    g3h2T[m] += av * (0.25f * d2[m] * d2[m]) + d2[m] * z2t[m];
+                }
             }
             g3b += (q == 0) ? av : 0.f;
 #pragma unroll
-            for (int m = 0; m < HB; ++m) { gz1t[m] = w3_T(G::oW3 + DI, m); gz1[m] = av * gz1t[m]; }
+            for (int m = 0; m < HB; ++m) { gz1t[m] = w3_T(G::oW3 + DI, m, o0); gz1[m] = av * gz1t[m]; }
             gemm_T<HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
             gemm_T<HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
+            {   // d1 / z1^ are L2-resident (touch-prefetched one round ahead): fetch them only now
+                f32x4 d1[HB], z1t[HB];
 #pragma unroll
-            for (int m = 0; m < HB; ++m) {
-                gz1[m] = gz1[m] * d1[m] + gz1t[m] * step2(d1[m]) * z1t[m];
-                gz1t[m] = gz1t[m] * d1[m];
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        d1[m][r] = pb[G::pD1 + (4 * m + r) * 64];
+                        z1t[m][r] = wsv * pb[G::pZ1 + (4 * m + r) * 64];
+                    }
+#pragma unroll
+                for (int m = 0; m < HB; ++m) {
+                    gz1[m] = gz1[m] * d1[m] + gz1t[m] * step2(d1[m]) * z1t[m];
+                    gz1t[m] = gz1t[m] * d1[m];
+                }
             }
             if (!kvalid) {
 #pragma unroll
