@@ -81,6 +81,26 @@ def cpu_baseline(w, seconds_budget=20.0):
                        % (Kc, w["K"], N, iters, el, torch.__version__))
 
 
+def secondary(psp, dev, w, steps=100, warmup=10):
+    prob = psp.LLGC(d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42, device=dev)
+    model = psp.Solver("bench-cfg1", prob, lr=1e-3, L=steps + warmup, K=w["K"], delta_t=w["dt"],
+                       loss_method="log-variance", time_approx="inner", adaptive_forward_process=True,
+                       detach_forward=True, u_l2_error_flag=False, verbose=False, seed=42, device=dev,
+                       backend="native", noise="philox", widths=(w["H"], w["H"]))
+    plan = model._choose_plan()
+    losses = torch.zeros(steps + warmup, dtype=torch.float32, device=dev)
+    for l in range(warmup):
+        plan.iteration(l, losses)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for l in range(warmup, warmup + steps):
+        plan.iteration(l, losses)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": w["K"] * model.N * steps / el, "unit": "trajectory-timesteps/s", "ms_per_step": 1e3 * el / steps,
+            "steps": steps, "K": w["K"], "N": model.N}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +109,7 @@ def main():
     ap.add_argument("--workload", default="hjb_llgc_d100_K65536_N100_h64",
                     choices=sorted(WORKLOADS) + sorted(GENERAL_WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] side measurement")
     args = ap.parse_args()
 
     import path_space_pde_solver_amd as psp
@@ -176,6 +197,10 @@ def main():
                      "whole_step_tflops": fl["total"] * units_local / (1e-3 * (1e3 * elapsed / args.steps)) / 1e12},
         "loss_first_last": [loss_vals[0], loss_vals[-1]],
     }
+    if world == 1 and args.workload == "hjb_llgc_d100_K65536_N100_h64" and not args.no_secondary:
+        # BASELINE.json configs[1] (d=100, K=1024, N=50) measured in the same process, for readers who take
+        # that as the quoted configuration: 64 16-trajectory tiles on 256 CUs, i.e. latency-bound
+        out["also_configs1_K1024_N50"] = secondary(psp, dev, WORKLOADS["hjb_llgc_d100_K1024_N50_h64"])
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
