@@ -289,6 +289,10 @@ struct Geo {
     static constexpr int EXT = (DB > 2 * HB ? DB : 2 * HB);   // exchange tiles (1 KiB) per wave
     static constexpr int gW3 = gEx + 4 * EXT * 256;           // only when !adaptive
     static int bwd_lds_floats(int adaptive) { return gW3 + (adaptive ? 0 : DB * KSH * 64); }
+    // role-specialised backward (hjb_bwd2_kernel): per sample block the exchange area holds the G panel as
+    // an exact k-step image (KSD x 64 floats) followed by the dz2 and dz1 panels; two buffers of 4 blocks
+    static constexpr int EXB = KSD * 64 + 8 * HB * 64;
+    static int bwd2_lds_floats() { return gEx + 2 * 4 * EXB; }
 };
 
 // =======================================================================================
@@ -577,6 +581,20 @@ __device__ __forceinline__ int image_lane_offset_F(int lane) {
 }
 __device__ __forceinline__ f32x4 image_get_F(const float* block, int lofs) {
     return *reinterpret_cast<const f32x4*>(block + lofs);
+}
+#ifndef PSP_ABLATE
+#define PSP_ABLATE 0      // diagnostic builds: 1 no Philox, 2 idle consumers, 4 idle producers, 8 consumers skip HBM, 16 producers skip HBM
+#endif
+#if defined(PSP_NO_SGB) && PSP_NO_SGB
+#define PSP_SGB(mask, n)
+#else
+#define PSP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#endif
+// accumulate-in-place MFMA (vDst tied to SrcC): keeps a persistent accumulator in ONE register quad across a
+// long unrolled stream (the builtin lets the allocator rename it, which costs copies and spills there).
+// Only for accumulators that no VALU / store reads until well after the stream (no hazard tracking in asm).
+__device__ __forceinline__ void mfma16_inplace(f32x4& c, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
@@ -933,6 +951,324 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
     }
 }
 
+// =======================================================================================
+// Backward kernel, role-specialised variant (adaptive forward process only).
+// One 8-wave workgroup per CU.  Waves 0-3 are PRODUCERS: each forms G, dz2, dz1 of one sample block
+// (Philox + two data-gradient GEMMs: VALU-heavy, no persistent accumulators) and writes the three
+// panels to the LDS exchange buffer of the NEXT round.  Waves 4-7 are CONSUMERS: each owns a fixed
+// subset of the weight-gradient tiles and contracts the CURRENT round's four blocks (MFMA-heavy).
+// A producer and a consumer share every SIMD, so the VALU work of one fills the MFMA shadows of the
+// other by construction instead of by the accident of two workgroups being out of phase; the two
+// exchange buffers are swapped at the single barrier per round.
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH, EXB = G::EXB;
+    constexpr int WH = G::WH, WD = G::WD, NIB = G::NIB, NOBD = G::NOBD, NOBH = G::NOBH;
+    constexpr int oDZ2 = KSD * 64, oDZ1 = KSD * 64 + 4 * HB * 64;      // offsets inside one block's exchange area
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const bool producer = wave < 4;
+    const int sub = wave & 3;                         // producer: block within the round; consumer: tile subset
+    const int wh = (WH == 1) ? 0 : sub % WH, wd = (WD == 1) ? 0 : sub / WH;
+    const int lofsF = image_lane_offset_F(lane);
+    const float* __restrict__ P = a.params;
+
+    stage_aop(lds + G::gW2T, HB, KSH, tid, nthr, [&](int row, int col) {
+        return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
+    stage_aop(lds + G::gW3T, HB, KSD, tid, nthr, [&](int row, int col) {
+        return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+    __syncthreads();
+    float* bufs = lds + G::gEx;                       // [2 buffers][4 blocks][EXB]
+
+    f32x4 acc3[NOBD][NIB], acc2[NOBH][NIB], acc1[NIB][NOBD];
+    f32x4 bs3[NOBD], bs2[NOBH], bs1[NIB], bt1[NIB];   // element-wise partial bias sums (horizontal sum at the end)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NOBD; ++s) { bs3[s] = zero4;
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) { acc3[s][t] = zero4; acc1[t][s] = zero4; } }
+#pragma unroll
+    for (int s = 0; s < NOBH; ++s) { bs2[s] = zero4;
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) acc2[s][t] = zero4; }
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) { bs1[t] = zero4; bt1[t] = zero4; }
+
+    const double invK = 1.0 / (double)a.K_global;
+    const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
+    const float coef = (float)(2.0 * invK);
+    const float sqdt = a.sqdt, dt = a.dt;
+    const long long nblk = (long long)a.N * a.ntile16;
+    const long long nround = (nblk + 3) / 4;
+    const int R = (int)((nround - blockIdx.x + gridDim.x - 1) / gridDim.x);   // rounds of this workgroup (>= 1)
+
+    if (producer) {
+        for (int it = 0; it <= R; ++it) {
+            if (it < R && !(PSP_ABLATE & 4)) {
+                // ---------------------------------------------------------- produce round r into bufs[it & 1]
+                const long long round = blockIdx.x + (long long)it * gridDim.x;
+                const long long blk0 = round * 4 + sub;
+                const bool bvalid = blk0 < nblk;
+                const long long blk = bvalid ? blk0 : nblk - 1;
+                const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
+                const int k = t16 * 16 + j;
+                const bool kvalid = bvalid && k < a.K_local;
+                const uint32_t kglob = (uint32_t)(a.k_offset + k);
+                const float* pb = a.path + (size_t)((PSP_ABLATE & 16) ? 0 : blk) * (size_t)G::PB + lane;
+                float* ex = bufs + ((it & 1) * 4 + sub) * EXB + lane;
+                // L2 touch-prefetch: this block's X_n image (consumers read it next iteration) and the
+                // h1 / h2 images of this wave's block of the NEXT round
+                float touch0, touch1;
+                {
+                    const float* xt = a.path + (size_t)blk * (size_t)G::PB + G::pX;
+                    touch0 = xt[(lane * 32 < 4 * DB * 64) ? lane * 32 : 0];
+                    const long long nb0 = (round + gridDim.x) * 4 + sub;
+                    const float* ht = a.path + (size_t)(nb0 < nblk ? nb0 : nblk - 1) * (size_t)G::PB + G::pH1;
+                    touch1 = ht[(lane * 32 < 8 * HB * 64) ? lane * 32 : 0];
+                }
+                const float dk = a.D[kvalid ? k : 0];
+                const float wk = kvalid ? (a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)) : 0.f;
+                f32x4 Gt[DB];
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    f32x4 xi;
+                    if (PSP_ABLATE & 1) {
+                        xi = f32x4{1.f, -1.f, 0.5f, -0.5f} * (float)(kglob & 3);
+                    } else if (a.noise_mode == NOISE_PHILOX) {
+                        xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
+                    } else {
+                        const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = 16 * b + 4 * r + q;
+                            const float v = xrow[f < D ? f : D - 1];
+                            xi[r] = (f < D && kvalid) ? v : 0.f;
+                        }
+                    }
+                    if (16 * b + 16 > D) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
+                    }
+                    Gt[b] = (wk * sqdt) * xi;                       // adaptive: the (Z + c) dt term cancels
+                }
+                f32x4 dz2[HB], dz1[HB];
+                {
+                    f32x4 h2[HB];
+#pragma unroll
+                    for (int m = 0; m < HB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) dz2[m] = zero4;
+                    gemm_T<HB, KSD, DB>(dz2, lds + G::gW3T, Gt, lane);
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KSD; ++ks) ex[ks * 64] = Gt[ks >> 2][ks & 3];     // exact k-step image of G
+                {
+                    f32x4 h1[HB];
+#pragma unroll
+                    for (int m = 0; m < HB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h1[m][r] = pb[G::pH1 + (4 * m + r) * 64];
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) dz1[m] = zero4;
+                    gemm_T<HB, KSH, HB>(dz1, lds + G::gW2T, dz2, lane);
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4 * HB; ++ks) {
+                    ex[oDZ2 + ks * 64] = dz2[ks >> 2][ks & 3];
+                    ex[oDZ1 + ks * 64] = dz1[ks >> 2][ks & 3];
+                }
+                asm volatile("" :: "v"(touch0), "v"(touch1));
+            }
+            __syncthreads();                              // swap the exchange buffers (pairs with the consumer loop)
+        }
+        return;
+    }
+    // ---- consumer-side persistent state: tile subset of this wave, operand sets, phase bodies ----------
+    // HBM operands (h2, h1, X_n images of one sample block, feature-on-lane) live in two ping-pong sets
+    // loaded one block ahead (across the round barrier too); LDS tiles are loaded one PHASE ahead
+    // (G tiles during the previous layer-2/1 phase, dz2/dz1 tiles during the layer-3 phase), and inside a
+    // phase the loads and the bias-sum VALU work are interleaved into the MFMA stream with
+    // sched_group_barrier, because a wave issues in order: anything left before or after the MFMA run
+    // is time the matrix pipe idles.
+    f32x4 oh2[NIB], oh1[NIB], ox[NOBD];               // HBM operands (feature-on-lane images)
+    f32x4 g3[NOBD], a2[NOBH], a1[NIB];                // LDS operands (exchange tiles)
+    int ibc[NIB], obc[NOBD], o2c[NOBH], o1c[NIB];
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) {
+        const int hb = (wh + WH * t) < HB ? (wh + WH * t) : HB - 1;
+        ibc[t] = hb * 256;
+        o1c[t] = oDZ1 + hb * 256;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NOBD; ++s2) obc[s2] = ((wd + WD * s2) < DB ? (wd + WD * s2) : DB - 1) * 256;
+#pragma unroll
+    for (int s2 = 0; s2 < NOBH; ++s2) o2c[s2] = oDZ2 + ((wd + WD * s2) < HB ? (wd + WD * s2) : HB - 1) * 256;
+    const int nblk_i = (int)nblk;                     // N * ntile16 < 2^31 is checked by the host
+    auto blk_at = [&](long long c0) __attribute__((always_inline)) {
+        const int c = (c0 < (long long)nblk_i) ? (int)c0 : nblk_i - 1;
+        return __builtin_amdgcn_readfirstlane((PSP_ABLATE & 8) ? 0 : c);
+    };
+    // wave-uniform tile base pointers are forced into SGPRs so every load is "SGPR base + lane offset"
+    typedef const __attribute__((address_space(1))) float* gptr_t;
+    auto sbase = [&](int blk, int ofs) __attribute__((always_inline)) {
+        unsigned long long addr = (unsigned long long)a.path + 4ull * ((unsigned long long)blk * (unsigned)G::PB + (unsigned)ofs);
+        asm volatile("" : "+s"(addr));                               // byte address of the tile, SGPR pair
+        return (gptr_t)addr;
+    };
+    const unsigned lofsU = (unsigned)lofsF;
+    auto get_F = [&](gptr_t base) __attribute__((always_inline)) {
+        return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + lofsU);
+    };
+    auto load_h2 = [&](int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) oh2[t] = get_F(sbase(blk, G::pH2 + ibc[t]));
+    };
+    auto load_g3 = [&](const float* ex) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s2 = 0; s2 < NOBD; ++s2) g3[s2] = tile_get(ex + obc[s2], lane);
+    };
+    // A wave issues in order, so everything that is not an MFMA is placed, one item per slot, BETWEEN the
+    // MFMAs of a phase (slot = one MFMA + at most kPer auxiliary items, closed by a scheduling fence).
+    // ---- layer 3 of block b: dW3 += G^T h2, db3 += sum G;
+    //      auxiliary items: fetch h1(b), X(b) from HBM/L2, dz2(b), dz1(b) from LDS, bias sums of G
+    auto phase_l3 = [&](int cb, const float* ex) __attribute__((always_inline)) {
+        constexpr int nM = 4 * NOBD * NIB, nAux = NIB + NOBD + NOBH + NIB + NOBD, kPer = (nAux + nM - 1) / nM;
+        auto aux = [&](int u) __attribute__((always_inline)) {
+            if (u < NIB) { oh1[u] = get_F(sbase(cb, G::pH1 + ibc[u])); return; }
+            u -= NIB;
+            if (u < NOBD) { ox[u] = get_F(sbase(cb, G::pX + obc[u])); return; }
+            u -= NOBD;
+            if (u < NOBH) { a2[u] = tile_get(ex + o2c[u], lane); return; }
+            u -= NOBH;
+            if (u < NIB) { a1[u] = tile_get(ex + o1c[u], lane); return; }
+            u -= NIB;
+            if (u < NOBD) bs3[u] += g3[u];
+        };
+#pragma unroll
+        for (int m = 0; m < nM; ++m) {
+            const int r = m / (NOBD * NIB), s2 = (m % (NOBD * NIB)) / NIB, t = m % NIB;
+            mfma16_inplace(acc3[s2][t], g3[s2][r], oh2[t][r]);
+#pragma unroll
+            for (int c = 0; c < kPer; ++c) aux(m * kPer + c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // ---- layers 2 and 1 of block b: dW2 += dz2^T h1, dW1 += dz1^T X_n, biases, time column;
+    //      auxiliary items: fetch h2(b+1) from HBM/L2 and, inside a round, G(b+1) from LDS; bias sums
+    auto phase_l21 = [&](int cb, int nb, const float* exn) __attribute__((always_inline)) {
+        constexpr int nT = (NOBH + NOBD) * NIB, nM = 4 * nT, nAux = NIB + NOBD + NOBH + NIB, kPer = (nAux + nM - 1) / nM;
+        const float tn = (float)(cb / a.ntile16) * dt;
+        auto aux = [&](int u) __attribute__((always_inline)) {
+            if (u < NIB) { oh2[u] = get_F(sbase(nb, G::pH2 + ibc[u])); return; }
+            u -= NIB;
+            if (u < NOBD) { if (exn) g3[u] = tile_get(exn + obc[u], lane); return; }
+            u -= NOBD;
+            if (u < NOBH) { bs2[u] += a2[u]; return; }
+            u -= NOBH;
+            if (u < NIB) {
+                bs1[u] += a1[u];
+                bt1[u] += tn * a1[u];
+            }
+        };
+#pragma unroll
+        for (int m = 0; m < nM; ++m) {
+            const int r = m / nT, e = m % nT;
+            if (e < NOBH * NIB) {
+                const int s2 = e / NIB, t = e % NIB;
+                mfma16_inplace(acc2[s2][t], a2[s2][r], oh1[t][r]);
+            } else {
+                const int s2 = (e - NOBH * NIB) / NIB, t = (e - NOBH * NIB) % NIB;
+                mfma16_inplace(acc1[t][s2], a1[t][r], ox[s2][r]);
+            }
+#pragma unroll
+            for (int c = 0; c < kPer; ++c) aux(m * kPer + c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (!(PSP_ABLATE & 2)) load_h2(blk_at((long long)blockIdx.x * 4));   // first block's h2, while the producers start
+    __syncthreads();                                      // pairs with producer iteration 0
+    for (int it = 1; it <= R; ++it) {
+        if (!(PSP_ABLATE & 2)) {
+            // -------------------------------------------------------------- consume round r from bufs[(it-1) & 1]
+            const int rb = (blockIdx.x + (it - 1) * gridDim.x) * 4;
+            const float* exch = bufs + ((it - 1) & 1) * 4 * EXB;
+            const int b0 = blk_at(rb), b1 = blk_at(rb + 1), b2 = blk_at(rb + 2), b3 = blk_at(rb + 3);
+            load_g3(exch);
+            __builtin_amdgcn_sched_barrier(0);
+            phase_l3(b0, exch);
+            phase_l21(b0, b1, exch + EXB);
+            phase_l3(b1, exch + EXB);
+            phase_l21(b1, b2, exch + 2 * EXB);
+            phase_l3(b2, exch + 2 * EXB);
+            phase_l21(b2, b3, exch + 3 * EXB);
+            phase_l3(b3, exch + 3 * EXB);
+            phase_l21(b3, blk_at((long long)rb + 4LL * gridDim.x), nullptr);   // h2 of the next round's first block
+        }
+        __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
+    }
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // matrix-pipe results settle before VALU / stores read them
+    // ---- consumers write their tiles into the workgroup's partial gradient (same mapping as hjb_bwd_kernel)
+    float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
+    const int col = lane & 15, qq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NOBD; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int ob = wd + WD * s, ib = wh + WH * t;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int o3 = 16 * ob + 4 * qq + rr, i3 = 16 * ib + col;
+                if (ob < DB && ib < HB && o3 < D && i3 < H) gp[G::oW3 + o3 * H + i3] = acc3[s][t][rr];
+                const int o1 = 16 * ib + 4 * qq + rr, i1 = 16 * ob + col;
+                if (ob < DB && ib < HB && o1 < H && i1 < D) gp[G::oW1 + o1 * (D + 1) + 1 + i1] = acc1[t][s][rr];
+            }
+        }
+#pragma unroll
+    for (int s = 0; s < NOBH; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int ob = wd + WD * s, ib = wh + WH * t;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int o2 = 16 * ob + 4 * qq + rr, i2 = 16 * ib + col;
+                if (ob < HB && ib < HB && o2 < H && i2 < H) gp[G::oW2 + o2 * H + i2] = acc2[s][t][rr];
+            }
+        }
+#pragma unroll
+    for (int s = 0; s < NOBD; ++s) {
+        const float v = qsum(hsum4(bs3[s]));
+        const int f = 16 * (wd + WD * s) + col;
+        if (wh == 0 && qq == 0 && (wd + WD * s) < DB && f < D) gp[G::ob3 + f] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < NOBH; ++s) {
+        const float v = qsum(hsum4(bs2[s]));
+        const int f = 16 * (wd + WD * s) + col;
+        if (wh == 0 && qq == 0 && (wd + WD * s) < HB && f < H) gp[G::ob2 + f] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) {
+        const float v1 = qsum(hsum4(bs1[t])), vt = qsum(hsum4(bt1[t]));
+        const int f = 16 * (wh + WH * t) + col;
+        if (wd == 0 && qq == 0 && (wh + WH * t) < HB && f < H) {
+            gp[G::ob1 + f] = v1;
+            gp[G::oW1 + f * (D + 1)] = vt;
+        }
+    }
+}
+
 // host-side launch table entry
 struct HjbInstance {
     int d, H, n_params;
@@ -941,6 +1277,8 @@ struct HjbInstance {
     hipError_t (*launch_fwd)(const HjbArgs&, int grid, int block, hipStream_t);
     hipError_t (*launch_bwd)(const HjbArgs&, int grid, int block, hipStream_t);
     int path_floats_per_tile_step;   // Geo::PB
+    int (*bwd2_lds_bytes)();
+    hipError_t (*launch_bwd2)(const HjbArgs&, int grid, hipStream_t);   // role-specialised variant, 512 threads
 };
 
 template <int D, int H>
@@ -964,8 +1302,17 @@ struct HjbLaunch {
         hipLaunchKernelGGL((hjb_bwd_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
+    static int bwd2_lds() { return G::bwd2_lds_floats() * 4; }
+    static hipError_t bwd2(const HjbArgs& a, int grid, hipStream_t s) {
+        const int bytes = bwd2_lds();
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_bwd2_kernel<D, H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjb_bwd2_kernel<D, H>), dim3(grid), dim3(512), bytes, s, a);
+        return hipGetLastError();
+    }
     static HjbInstance instance() {
-        return HjbInstance{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::PB};
+        return HjbInstance{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::PB, &bwd2_lds, &bwd2};
     }
 };
 

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/psp.h"
@@ -62,6 +63,7 @@ constexpr int kMaxLds = 160 * 1024;
 struct Plan {
     psp::HjbInstance inst;
     int ntile16, fwd_waves, fwd_grid, bwd_waves, bwd_grid;
+    bool bwd_specialised;       // hjb_bwd2_kernel (producer / consumer waves) instead of hjb_bwd_kernel
 };
 
 int n_cus() {
@@ -103,9 +105,14 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     // (<= 256 VGPRs and <= 80 KiB LDS each), fewer when there is little work
     const long long nblk = (long long)c->N * p->ntile16;
     const long long nround = (nblk + 3) / 4;
-    p->bwd_waves = 4;
+    // adaptive runs use the role-specialised kernel (one 8-wave workgroup per CU) when its double-buffered
+    // exchange area fits the LDS; PSP_BWD_VARIANT=1 forces the two-workgroups-per-CU kernel (A/B timing)
+    static const char* force = getenv("PSP_BWD_VARIANT");
+    p->bwd_specialised = c->adaptive && p->inst.bwd2_lds_bytes() <= kMaxLds && !(force && force[0] == '1');
+    p->bwd_waves = p->bwd_specialised ? 8 : 4;
     long long g = nround;
-    if (g > 2LL * cus) g = 2LL * cus;
+    const long long gmax = p->bwd_specialised ? cus : 2LL * cus;
+    if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     p->bwd_grid = (int)g;
     return 0;
@@ -368,7 +375,8 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
     a.sums = sums; a.grad_partial = grad_partial;
     if (a.dbg) a.dbg += (size_t)p.fwd_grid * 8 * 8;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    hipError_t e = p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
+    hipError_t e = p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
+                                     : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");
     const int P = p.inst.n_params;
     hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream,
