@@ -222,6 +222,13 @@ __device__ __forceinline__ float qsum(float v) {  // sum over the 4 q-lanes of a
     v += __shfl_xor(v, 32);
     return v;
 }
+__device__ __forceinline__ float jsumf(float v) {  // fp32 sum over the 16 trajectories of a wave (q fixed)
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
 __device__ __forceinline__ double jsum(double v) {  // sum over the 16 trajectories of a wave (q fixed)
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
@@ -276,7 +283,10 @@ struct Geo {
     // path store: one block per (step n, 16-trajectory tile): register images of X_n, h1, h2,
     // each padded to whole 16-feature blocks (padded k-steps hold zeros) so that the backward
     // kernel's feature-on-lane reads need neither clamping nor masking
-    static constexpr int pX = 0, pH1 = 4 * DB * 64, pH2 = pH1 + 4 * HB * 64, PB = pH2 + 4 * HB * 64;
+    // path block of one (time step, 16-trajectory tile): register images of X_n, h1, h2 and of the Brownian increment
+    // xi_{n+1} -- the backward kernels LOAD xi instead of regenerating it: next to an fp32 MFMA stream a VALU cycle is
+    // expensive (a dense MFMA wave leaves other VALU work ~1/5 of the issue time) while HBM has 6x headroom
+    static constexpr int pX = 0, pH1 = 4 * DB * 64, pH2 = pH1 + 4 * HB * 64, pXi = pH2 + 4 * HB * 64, PB = pXi + 4 * DB * 64;
     // backward: 4 waves per workgroup arranged WH x WD over the (H-blocks x other-blocks) tile grids
     static constexpr int WH = (HB >= 4) ? 4 : (HB >= 2 ? 2 : 1);
     static constexpr int WD = 4 / WH;
@@ -435,6 +445,10 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
                 }
+                if (a.store_path) {                    // the backward pass reads xi back (any noise mode)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pblk[(G::pXi / 64 + 4 * b + r) * 64] = xi[r];
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     S = fmaf(Z[b][r], Z[b][r], S);
@@ -585,6 +599,9 @@ __device__ __forceinline__ f32x4 image_get_F(const float* block, int lofs) {
 #ifndef PSP_ABLATE
 #define PSP_ABLATE 0      // diagnostic builds: 1 no Philox, 2 idle consumers, 4 idle producers, 8 consumers skip HBM, 16 producers skip HBM
 #endif
+#ifndef PSP_PRODUCER_PRIO
+#define PSP_PRODUCER_PRIO 3
+#endif
 #if defined(PSP_NO_SGB) && PSP_NO_SGB
 #define PSP_SGB(mask, n)
 #else
@@ -674,7 +691,6 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
             const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
             const int k = t16 * 16 + j;
             const bool kvalid = bvalid && k < a.K_local;
-            const uint32_t kglob = (uint32_t)(a.k_offset + k);
             const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
             // LOSS_WEIGHTS: the caller supplies w_k = dLoss/dY_k directly in the D argument
             const float dk = a.D[kvalid ? k : 0];
@@ -695,22 +711,9 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
             }
 #pragma unroll
             for (int b = 0; b < DB; ++b) {
-                f32x4 xi;
-                if (a.noise_mode == NOISE_PHILOX) {
-                    xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
-                } else {
-                    const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
+                f32x4 xi;                                        // xi_{n+1} image stored by the forward kernel
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = 16 * b + 4 * r + q;
-                        const float v = xrow[f < D ? f : D - 1];
-                        xi[r] = (f < D && kvalid) ? v : 0.f;
-                    }
-                }
-                if (16 * b + 16 > D) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
-                }
+                for (int r = 0; r < 4; ++r) xi[r] = pb[G::pXi + (4 * b + r) * 64];
                 Gt[b] = wk * (dt * Gt[b] + sqdt * xi);
             }
             // h2 / h1 are fetched right before the GEMM whose epilogue consumes them: the GEMM
@@ -967,6 +970,7 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH, EXB = G::EXB;
     constexpr int WH = G::WH, WD = G::WD, NIB = G::NIB, NOBD = G::NOBD, NOBH = G::NOBH;
     constexpr int oDZ2 = KSD * 64, oDZ1 = KSD * 64 + 4 * HB * 64;      // offsets inside one block's exchange area
+    constexpr int RS = 16 * DB + 48 * HB;                              // per-producer bias-sum slots (G | dz2 | dz1 | t dz1)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -985,18 +989,15 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     float* bufs = lds + G::gEx;                       // [2 buffers][4 blocks][EXB]
 
     f32x4 acc3[NOBD][NIB], acc2[NOBH][NIB], acc1[NIB][NOBD];
-    f32x4 bs3[NOBD], bs2[NOBH], bs1[NIB], bt1[NIB];   // element-wise partial bias sums (horizontal sum at the end)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < NOBD; ++s) { bs3[s] = zero4;
+    for (int s = 0; s < NOBD; ++s)
 #pragma unroll
-        for (int t = 0; t < NIB; ++t) { acc3[s][t] = zero4; acc1[t][s] = zero4; } }
+        for (int t = 0; t < NIB; ++t) { acc3[s][t] = zero4; acc1[t][s] = zero4; }
 #pragma unroll
-    for (int s = 0; s < NOBH; ++s) { bs2[s] = zero4;
+    for (int s = 0; s < NOBH; ++s)
 #pragma unroll
-        for (int t = 0; t < NIB; ++t) acc2[s][t] = zero4; }
-#pragma unroll
-    for (int t = 0; t < NIB; ++t) { bs1[t] = zero4; bt1[t] = zero4; }
+        for (int t = 0; t < NIB; ++t) acc2[s][t] = zero4;
 
     const double invK = 1.0 / (double)a.K_global;
     const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
@@ -1007,90 +1008,153 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     const int R = (int)((nround - blockIdx.x + gridDim.x - 1) / gridDim.x);   // rounds of this workgroup (>= 1)
 
     if (producer) {
+        // bias gradients (and the time column of dW1) are sums over samples of G, dz2, dz1: the producers hold
+        // those panels anyway and have slack every round, so they keep element-wise running sums in registers
+        // (reduced over the wave's 16 trajectories once, after the loop) and the consumers do no VALU work at all
+        __builtin_amdgcn_s_setprio(PSP_PRODUCER_PRIO);
+        f32x4 sG[DB], sZ2[HB], sZ1[HB], sT1[HB];
+#pragma unroll
+        for (int b = 0; b < DB; ++b) sG[b] = zero4;
+#pragma unroll
+        for (int m = 0; m < HB; ++m) { sZ2[m] = zero4; sZ1[m] = zero4; sT1[m] = zero4; }
+#ifdef PSP_STAMPS
+        unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        // software pipeline over this wave's blocks: xi and the trajectory weight of the NEXT round are requested at
+        // the top of an iteration (a whole iteration of lead), h2 / h1 of the current block right after G is formed
+        // (they are consumed after the first / second GEMM); with the X_n touch that is <= 63 loads in flight
+        auto own_block = [&](int it2) __attribute__((always_inline)) {
+            const long long b0 = ((long long)blockIdx.x + (long long)it2 * gridDim.x) * 4 + sub;
+            return b0 < nblk ? b0 : -1LL;
+        };
+        f32x4 xin[DB];
+        float dkn;
+        {
+            const long long b0 = own_block(0);
+            const long long blk = b0 >= 0 ? b0 : nblk - 1;
+            const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+            const int k0 = (int)(blk % a.ntile16) * 16 + j;
+            dkn = a.D[k0 < a.K_local ? k0 : 0];
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xin[b][r] = pb[G::pXi + (4 * b + r) * 64];
+        }
         for (int it = 0; it <= R; ++it) {
+            PSP_STAMP(tp0);
             if (it < R && !(PSP_ABLATE & 4)) {
                 // ---------------------------------------------------------- produce round r into bufs[it & 1]
-                const long long round = blockIdx.x + (long long)it * gridDim.x;
-                const long long blk0 = round * 4 + sub;
-                const bool bvalid = blk0 < nblk;
+                const long long blk0 = own_block(it);
+                const bool bvalid = blk0 >= 0;
                 const long long blk = bvalid ? blk0 : nblk - 1;
                 const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
                 const int k = t16 * 16 + j;
                 const bool kvalid = bvalid && k < a.K_local;
-                const uint32_t kglob = (uint32_t)(a.k_offset + k);
                 const float* pb = a.path + (size_t)((PSP_ABLATE & 16) ? 0 : blk) * (size_t)G::PB + lane;
                 float* ex = bufs + ((it & 1) * 4 + sub) * EXB + lane;
-                // L2 touch-prefetch: this block's X_n image (consumers read it next iteration) and the
-                // h1 / h2 images of this wave's block of the NEXT round
-                float touch0, touch1;
-                {
-                    const float* xt = a.path + (size_t)blk * (size_t)G::PB + G::pX;
-                    touch0 = xt[(lane * 32 < 4 * DB * 64) ? lane * 32 : 0];
-                    const long long nb0 = (round + gridDim.x) * 4 + sub;
-                    const float* ht = a.path + (size_t)(nb0 < nblk ? nb0 : nblk - 1) * (size_t)G::PB + G::pH1;
-                    touch1 = ht[(lane * 32 < 8 * HB * 64) ? lane * 32 : 0];
-                }
-                const float dk = a.D[kvalid ? k : 0];
+                const float dk = dkn;
                 const float wk = kvalid ? (a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)) : 0.f;
                 f32x4 Gt[DB];
 #pragma unroll
                 for (int b = 0; b < DB; ++b) {
-                    f32x4 xi;
-                    if (PSP_ABLATE & 1) {
-                        xi = f32x4{1.f, -1.f, 0.5f, -0.5f} * (float)(kglob & 3);
-                    } else if (a.noise_mode == NOISE_PHILOX) {
-                        xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
-                    } else {
-                        const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int f = 16 * b + 4 * r + q;
-                            const float v = xrow[f < D ? f : D - 1];
-                            xi[r] = (f < D && kvalid) ? v : 0.f;
-                        }
-                    }
-                    if (16 * b + 16 > D) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
-                    }
-                    Gt[b] = (wk * sqdt) * xi;                       // adaptive: the (Z + c) dt term cancels
+                    Gt[b] = (wk * sqdt) * xin[b];                   // adaptive: the (Z + c) dt term cancels
+                    sG[b] += Gt[b];
                 }
+                f32x4 h2[HB], h1[HB];
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h1[m][r] = pb[G::pH1 + (4 * m + r) * 64];
+                float touch0;
+                {
+                    // L2 touch (one dword per 128-B line) of the X_n image the consumers read next iteration
+                    const float* xt = a.path + (size_t)blk * (size_t)G::PB + G::pX;
+                    touch0 = xt[(lane * 32 < 4 * DB * 64) ? lane * 32 : 0];
+                    const long long n0 = own_block(it + 1);
+                    const long long nblk1 = n0 >= 0 ? n0 : nblk - 1;
+                    const float* pn = a.path + (size_t)nblk1 * (size_t)G::PB + lane;
+                    const int k1 = (int)(nblk1 % a.ntile16) * 16 + j;
+                    dkn = a.D[k1 < a.K_local ? k1 : 0];
+#pragma unroll
+                    for (int b = 0; b < DB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xin[b][r] = pn[G::pXi + (4 * b + r) * 64];
+                }
+                PSP_STAMP(tp1);
+                PSP_ACC(0, tp1, tp0);                 // weights -> G, issue of this block's h loads and next round's xi
                 f32x4 dz2[HB], dz1[HB];
                 {
-                    f32x4 h2[HB];
-#pragma unroll
-                    for (int m = 0; m < HB; ++m)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
 #pragma unroll
                     for (int m = 0; m < HB; ++m) dz2[m] = zero4;
                     gemm_T<HB, KSD, DB>(dz2, lds + G::gW3T, Gt, lane);
 #pragma unroll
-                    for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+                    for (int m = 0; m < HB; ++m) { dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]); sZ2[m] += dz2[m]; }
                 }
+                PSP_STAMP(tp2);
+                PSP_ACC(1, tp2, tp1);                 // h2 load + GEMM W3^T G + tanh'
 #pragma unroll
                 for (int ks = 0; ks < KSD; ++ks) ex[ks * 64] = Gt[ks >> 2][ks & 3];     // exact k-step image of G
                 {
-                    f32x4 h1[HB];
-#pragma unroll
-                    for (int m = 0; m < HB; ++m)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) h1[m][r] = pb[G::pH1 + (4 * m + r) * 64];
 #pragma unroll
                     for (int m = 0; m < HB; ++m) dz1[m] = zero4;
                     gemm_T<HB, KSH, HB>(dz1, lds + G::gW2T, dz2, lane);
+                    const float tn = (float)n * dt;
 #pragma unroll
-                    for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
+                    for (int m = 0; m < HB; ++m) {
+                        dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
+                        sZ1[m] += dz1[m];
+                        sT1[m] += tn * dz1[m];
+                    }
                 }
+                PSP_STAMP(tp3);
+                PSP_ACC(2, tp3, tp2);                 // G store + h1 load + GEMM W2^T dz2 + tanh'
 #pragma unroll
                 for (int ks = 0; ks < 4 * HB; ++ks) {
                     ex[oDZ2 + ks * 64] = dz2[ks >> 2][ks & 3];
                     ex[oDZ1 + ks * 64] = dz1[ks >> 2][ks & 3];
                 }
-                asm volatile("" :: "v"(touch0), "v"(touch1));
+                asm volatile("" :: "v"(touch0));
+                PSP_STAMP(tp4);
+                PSP_ACC(3, tp4, tp3);                 // dz stores
             }
+            PSP_STAMP(tp5);
             __syncthreads();                              // swap the exchange buffers (pairs with the consumer loop)
+            PSP_STAMP(tp6);
+            PSP_ACC(4, tp6, tp5);                     // barrier wait
+            PSP_ACC(6, tp6, tp0);
         }
+#ifdef PSP_STAMPS
+        if (a.dbg && lane == 0) {
+            stamps[7] = (unsigned long long)R;
+            for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+        }
+#endif
+        // per-wave bias sums -> LDS (the exchange area is free after the last barrier); lane (j = 0, q), component r
+        // of block b holds feature 16 b + 4 r + q
+        float* red = bufs + sub * RS;
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = jsumf(sG[b][r]);
+                if (j == 0) red[16 * b + 4 * r + q] = v;
+            }
+#pragma unroll
+        for (int m = 0; m < HB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v2 = jsumf(sZ2[m][r]), v1 = jsumf(sZ1[m][r]), vt = jsumf(sT1[m][r]);
+                if (j == 0) {
+                    red[16 * DB + 16 * m + 4 * r + q] = v2;
+                    red[16 * DB + 16 * HB + 16 * m + 4 * r + q] = v1;
+                    red[16 * DB + 32 * HB + 16 * m + 4 * r + q] = vt;
+                }
+            }
+        __syncthreads();                                  // pairs with the consumers' barrier before the bias write-out
         return;
     }
     // ---- consumer-side persistent state: tile subset of this wave, operand sets, phase bodies ----------
@@ -1100,7 +1164,7 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     // phase the loads and the bias-sum VALU work are interleaved into the MFMA stream with
     // sched_group_barrier, because a wave issues in order: anything left before or after the MFMA run
     // is time the matrix pipe idles.
-    f32x4 oh2[NIB], oh1[NIB], ox[NOBD];               // HBM operands (feature-on-lane images)
+    f32x4 oh2[NIB], oh1[2][NIB], ox[2][NOBD];         // HBM operands (feature-on-lane images); h1 / X double-buffered
     f32x4 g3[NOBD], a2[NOBH], a1[NIB];                // LDS operands (exchange tiles)
     int ibc[NIB], obc[NOBD], o2c[NOBH], o1c[NIB];
 #pragma unroll
@@ -1129,9 +1193,13 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     auto get_F = [&](gptr_t base) __attribute__((always_inline)) {
         return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + lofsU);
     };
-    auto load_h2 = [&](int blk) __attribute__((always_inline)) {
+    auto load_first = [&](int blk) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NIB; ++t) oh2[t] = get_F(sbase(blk, G::pH2 + ibc[t]));
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) oh1[0][t] = get_F(sbase(blk, G::pH1 + ibc[t]));
+#pragma unroll
+        for (int s2 = 0; s2 < NOBD; ++s2) ox[0][s2] = get_F(sbase(blk, G::pX + obc[s2]));
     };
     auto load_g3 = [&](const float* ex) __attribute__((always_inline)) {
 #pragma unroll
@@ -1139,20 +1207,19 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     };
     // A wave issues in order, so everything that is not an MFMA is placed, one item per slot, BETWEEN the
     // MFMAs of a phase (slot = one MFMA + at most kPer auxiliary items, closed by a scheduling fence).
-    // ---- layer 3 of block b: dW3 += G^T h2, db3 += sum G;
-    //      auxiliary items: fetch h1(b), X(b) from HBM/L2, dz2(b), dz1(b) from LDS, bias sums of G
-    auto phase_l3 = [&](int cb, const float* ex) __attribute__((always_inline)) {
-        constexpr int nM = 4 * NOBD * NIB, nAux = NIB + NOBD + NOBH + NIB + NOBD, kPer = (nAux + nM - 1) / nM;
+    // HBM operands are requested a whole block ahead: h1(b+1), X(b+1) during layer 3 of block b (into the other
+    // buffer), h2(b+1) during layers 2/1 of block b; LDS tiles one phase ahead.
+    // ---- layer 3 of block b (buffer pb): dW3 += G^T h2;  fetch h1(nb), X(nb) from HBM/L2 and dz2(b), dz1(b) from LDS
+    auto phase_l3 = [&](int pb, int nb, const float* ex) __attribute__((always_inline)) {
+        constexpr int nM = 4 * NOBD * NIB, nAux = NIB + NOBD + NOBH + NIB, kPer = (nAux + nM - 1) / nM;
         auto aux = [&](int u) __attribute__((always_inline)) {
-            if (u < NIB) { oh1[u] = get_F(sbase(cb, G::pH1 + ibc[u])); return; }
+            if (u < NIB) { oh1[pb ^ 1][u] = get_F(sbase(nb, G::pH1 + ibc[u])); return; }
             u -= NIB;
-            if (u < NOBD) { ox[u] = get_F(sbase(cb, G::pX + obc[u])); return; }
+            if (u < NOBD) { ox[pb ^ 1][u] = get_F(sbase(nb, G::pX + obc[u])); return; }
             u -= NOBD;
             if (u < NOBH) { a2[u] = tile_get(ex + o2c[u], lane); return; }
             u -= NOBH;
-            if (u < NIB) { a1[u] = tile_get(ex + o1c[u], lane); return; }
-            u -= NIB;
-            if (u < NOBD) bs3[u] += g3[u];
+            if (u < NIB) a1[u] = tile_get(ex + o1c[u], lane);
         };
 #pragma unroll
         for (int m = 0; m < nM; ++m) {
@@ -1163,32 +1230,24 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // ---- layers 2 and 1 of block b: dW2 += dz2^T h1, dW1 += dz1^T X_n, biases, time column;
-    //      auxiliary items: fetch h2(b+1) from HBM/L2 and, inside a round, G(b+1) from LDS; bias sums
-    auto phase_l21 = [&](int cb, int nb, const float* exn) __attribute__((always_inline)) {
-        constexpr int nT = (NOBH + NOBD) * NIB, nM = 4 * nT, nAux = NIB + NOBD + NOBH + NIB, kPer = (nAux + nM - 1) / nM;
-        const float tn = (float)(cb / a.ntile16) * dt;
+    // ---- layers 2 and 1 of block b (buffer pb): dW2 += dz2^T h1, dW1 += dz1^T X_n;
+    //      fetch h2(nb) from HBM/L2 and, inside a round, G(b+1) from LDS
+    auto phase_l21 = [&](int pb, int nb, const float* exn) __attribute__((always_inline)) {
+        constexpr int nT = (NOBH + NOBD) * NIB, nM = 4 * nT, nAux = NIB + NOBD, kPer = (nAux + nM - 1) / nM;
         auto aux = [&](int u) __attribute__((always_inline)) {
             if (u < NIB) { oh2[u] = get_F(sbase(nb, G::pH2 + ibc[u])); return; }
             u -= NIB;
-            if (u < NOBD) { if (exn) g3[u] = tile_get(exn + obc[u], lane); return; }
-            u -= NOBD;
-            if (u < NOBH) { bs2[u] += a2[u]; return; }
-            u -= NOBH;
-            if (u < NIB) {
-                bs1[u] += a1[u];
-                bt1[u] += tn * a1[u];
-            }
+            if (u < NOBD) { if (exn) g3[u] = tile_get(exn + obc[u], lane); }
         };
 #pragma unroll
         for (int m = 0; m < nM; ++m) {
             const int r = m / nT, e = m % nT;
             if (e < NOBH * NIB) {
                 const int s2 = e / NIB, t = e % NIB;
-                mfma16_inplace(acc2[s2][t], a2[s2][r], oh1[t][r]);
+                mfma16_inplace(acc2[s2][t], a2[s2][r], oh1[pb][t][r]);
             } else {
                 const int s2 = (e - NOBH * NIB) / NIB, t = (e - NOBH * NIB) % NIB;
-                mfma16_inplace(acc1[t][s2], a1[t][r], ox[s2][r]);
+                mfma16_inplace(acc1[t][s2], a1[t][r], ox[pb][s2][r]);
             }
 #pragma unroll
             for (int c = 0; c < kPer; ++c) aux(m * kPer + c);
@@ -1196,27 +1255,43 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
         }
     };
 
-    if (!(PSP_ABLATE & 2)) load_h2(blk_at((long long)blockIdx.x * 4));   // first block's h2, while the producers start
+    if (!(PSP_ABLATE & 2)) load_first(blk_at((long long)blockIdx.x * 4));   // first block's operands, while the producers start
     __syncthreads();                                      // pairs with producer iteration 0
+#ifdef PSP_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int it = 1; it <= R; ++it) {
+        PSP_STAMP(tc0);
         if (!(PSP_ABLATE & 2)) {
             // -------------------------------------------------------------- consume round r from bufs[(it-1) & 1]
             const int rb = (blockIdx.x + (it - 1) * gridDim.x) * 4;
             const float* exch = bufs + ((it - 1) & 1) * 4 * EXB;
-            const int b0 = blk_at(rb), b1 = blk_at(rb + 1), b2 = blk_at(rb + 2), b3 = blk_at(rb + 3);
+            const int b1 = blk_at(rb + 1), b2 = blk_at(rb + 2), b3 = blk_at(rb + 3);
             load_g3(exch);
             __builtin_amdgcn_sched_barrier(0);
-            phase_l3(b0, exch);
-            phase_l21(b0, b1, exch + EXB);
-            phase_l3(b1, exch + EXB);
-            phase_l21(b1, b2, exch + 2 * EXB);
-            phase_l3(b2, exch + 2 * EXB);
-            phase_l21(b2, b3, exch + 3 * EXB);
-            phase_l3(b3, exch + 3 * EXB);
-            phase_l21(b3, blk_at((long long)rb + 4LL * gridDim.x), nullptr);   // h2 of the next round's first block
+            const int bn = blk_at((long long)rb + 4LL * gridDim.x);       // first block of this workgroup's next round
+            phase_l3(0, b1, exch);
+            phase_l21(0, b1, exch + EXB);
+            phase_l3(1, b2, exch + EXB);
+            phase_l21(1, b2, exch + 2 * EXB);
+            phase_l3(0, b3, exch + 2 * EXB);
+            phase_l21(0, b3, exch + 3 * EXB);
+            phase_l3(1, bn, exch + 3 * EXB);
+            phase_l21(1, bn, nullptr);
         }
+        PSP_STAMP(tc1);
         __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
+        PSP_STAMP(tc2);
+        PSP_ACC(0, tc1, tc0);                             // eight phases of one round
+        PSP_ACC(4, tc2, tc1);                             // barrier wait
+        PSP_ACC(6, tc2, tc0);
     }
+#ifdef PSP_STAMPS
+    if (a.dbg && lane == 0) {
+        stamps[7] = (unsigned long long)R;
+        for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+    }
+#endif
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // matrix-pipe results settle before VALU / stores read them
     // ---- consumers write their tiles into the workgroup's partial gradient (same mapping as hjb_bwd_kernel)
@@ -1246,25 +1321,20 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
                 if (ob < HB && ib < HB && o2 < H && i2 < H) gp[G::oW2 + o2 * H + i2] = acc2[s][t][rr];
             }
         }
-#pragma unroll
-    for (int s = 0; s < NOBD; ++s) {
-        const float v = qsum(hsum4(bs3[s]));
-        const int f = 16 * (wd + WD * s) + col;
-        if (wh == 0 && qq == 0 && (wd + WD * s) < DB && f < D) gp[G::ob3 + f] = v;
-    }
-#pragma unroll
-    for (int s = 0; s < NOBH; ++s) {
-        const float v = qsum(hsum4(bs2[s]));
-        const int f = 16 * (wd + WD * s) + col;
-        if (wh == 0 && qq == 0 && (wd + WD * s) < HB && f < H) gp[G::ob2 + f] = v;
-    }
-#pragma unroll
-    for (int t = 0; t < NIB; ++t) {
-        const float v1 = qsum(hsum4(bs1[t])), vt = qsum(hsum4(bt1[t]));
-        const int f = 16 * (wh + WH * t) + col;
-        if (wd == 0 && qq == 0 && (wh + WH * t) < HB && f < H) {
-            gp[G::ob1 + f] = v1;
-            gp[G::oW1 + f * (D + 1)] = vt;
+    // biases and the time column of dW1: fixed-order sum of the four producers' partial sums (LDS)
+    __syncthreads();                                      // pairs with the producers' barrier after their LDS write
+    {
+        const float* red = bufs;
+        const int ct = tid - 256;
+        for (int f = ct; f < D; f += 256)
+            gp[G::ob3 + f] = (red[f] + red[RS + f]) + (red[2 * RS + f] + red[3 * RS + f]);
+        for (int f = ct; f < H; f += 256) {
+            const float* r2 = red + 16 * DB + f;
+            gp[G::ob2 + f] = (r2[0] + r2[RS]) + (r2[2 * RS] + r2[3 * RS]);
+            const float* r1 = r2 + 16 * HB;
+            gp[G::ob1 + f] = (r1[0] + r1[RS]) + (r1[2 * RS] + r1[3 * RS]);
+            const float* rt = r1 + 16 * HB;
+            gp[G::oW1 + f * (D + 1)] = (rt[0] + rt[RS]) + (rt[2 * RS] + rt[3 * RS]);
         }
     }
 }

@@ -127,7 +127,7 @@ void fill_args(const psp_hjb_config* c, const Plan& p, psp::HjbArgs* a) {
     a->term_kind = c->term_kind; a->adaptive = c->adaptive; a->loss_kind = c->loss_kind;
     a->noise_mode = c->noise_mode; a->store_path = c->store_path;
     // diagnostic stamp buffer: [forward: fwd_grid x 8 waves x 8][backward: bwd_grid x 4 waves x 8]
-    a->dbg = (g_dbg && g_dbg_n >= ((long long)p.fwd_grid * 8 + (long long)p.bwd_grid * 4) * 8) ? g_dbg : nullptr;
+    a->dbg = (g_dbg && g_dbg_n >= ((long long)p.fwd_grid * 8 + (long long)p.bwd_grid * 8) * 8) ? g_dbg : nullptr;
 }
 
 int check_ptrs(const psp_hjb_config* c) {

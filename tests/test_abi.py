@@ -54,9 +54,9 @@ def test_query_sizes_without_gpu(lib):
     s = nat.query(_cfg())
     p = (100 + 1) * 64 + 64 + 64 * 64 + 64 + 64 * 100 + 100
     assert s.n_params == p == 17188
-    # path store: N steps x K/16 tiles x (X, h1, h2 register images padded to 16-feature blocks:
-    # 4*ceil(d/16) + 2*4*ceil(H/16) k-steps) x 64 lanes x 4 B
-    assert s.path_bytes == 50 * 64 * (28 + 2 * 16) * 64 * 4
+    # path store: N steps x K/16 tiles x (X, xi, h1, h2 register images padded to 16-feature blocks:
+    # 2*4*ceil(d/16) + 2*4*ceil(H/16) k-steps) x 64 lanes x 4 B
+    assert s.path_bytes == 50 * 64 * (2 * 28 + 2 * 16) * 64 * 4
     assert s.fwd_workgroups >= 1 and s.bwd_workgroups >= 1
     assert s.grad_partial_bytes == s.bwd_workgroups * p * 4
 

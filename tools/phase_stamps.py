@@ -33,7 +33,7 @@ plan = model._choose_plan()
 nat = psp.native
 nwg = plan.sizes.bwd_workgroups
 fwg = plan.sizes.fwd_workgroups
-buf = torch.zeros((fwg * 8 + nwg * 4) * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros((fwg * 8 + nwg * 8) * 8, dtype=torch.int64, device=dev)
 assert nat.load().psp_debug_set_stamp_buffer(nat.ptr(buf), buf.numel()) == 1, "library lacks -DPSP_STAMPS"
 losses = torch.zeros(4, device=dev)
 for l in range(3):
@@ -50,6 +50,21 @@ print("forward: workgroups %d, cycles per time step (mean over waves): %.0f; MFM
 for i, n in enumerate(fn):
     v = f[:, :, i] / steps
     print("  %-40s mean %8.0f  (%5.1f%%)" % (n, v.mean(), 100 * v.mean() / ftot))
+if os.environ.get("PSP_BWD_VARIANT", "") != "1":
+    # role-specialised backward: 8 waves per workgroup, waves 0-3 producers, 4-7 consumers
+    s = allb[fwg * 64:fwg * 64 + nwg * 64].reshape(nwg, 8, 8)
+    pr, co = s[:, :4, :], s[:, 4:, :]
+    R = pr[:, :, 7].clamp(min=1)
+    print("backward (role-specialised): workgroups %d, rounds per workgroup %.1f" % (nwg, R.mean()))
+    for nm, i in [("  (of which: touch + D load -> weight)", 5), ("Philox + weights -> G", 0), ("h2 load, GEMM W3^T G, tanh'", 1), ("G store, h1 load, GEMM W2^T dz2, tanh'", 2),
+                  ("dz stores", 3), ("barrier wait", 4), ("whole round", 6)]:
+        v = pr[:, :, i] / R
+        print("  producer  %-40s mean %8.0f   min %8.0f  max %8.0f" % (nm, v.mean(), v.min(), v.max()))
+    Rc = co[:, :, 7].clamp(min=1)
+    for nm, i in [("eight phases (288 MFMA)", 0), ("barrier wait", 4), ("whole round", 6)]:
+        v = co[:, :, i] / Rc
+        print("  consumer  %-40s mean %8.0f   min %8.0f  max %8.0f" % (nm, v.mean(), v.min(), v.max()))
+    sys.exit(0)
 s = allb[fwg * 64:].reshape(nwg, 4, 8)
 rounds = s[:, :, 7]
 names = ["P1 compute", "barrier A", "P2 compute", "barriers B+C + dz exchange", "P3 compute", "barrier D", "whole round"]
