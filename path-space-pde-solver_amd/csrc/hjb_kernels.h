@@ -301,8 +301,8 @@ struct Geo {
     static int bwd_lds_floats(int adaptive) { return gW3 + (adaptive ? 0 : DB * KSH * 64); }
     // role-specialised backward (hjb_bwd2_kernel): per sample block the exchange area holds the G panel as
     // an exact k-step image (KSD x 64 floats) followed by the dz2 and dz1 panels; two buffers of 4 blocks
-    static constexpr int EXB = KSD * 64 + 8 * HB * 64;
-    static int bwd2_lds_floats() { return gEx + 2 * 4 * EXB; }
+    static constexpr int EXB = KSD * 64 + 4 * HB * 64;
+    static int bwd2_lds_floats() { return HB * KSD * 64 + 2 * 4 * EXB; }
 };
 
 // =======================================================================================
@@ -969,8 +969,8 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH, EXB = G::EXB;
     constexpr int WH = G::WH, WD = G::WD, NIB = G::NIB, NOBD = G::NOBD, NOBH = G::NOBH;
-    constexpr int oDZ2 = KSD * 64, oDZ1 = KSD * 64 + 4 * HB * 64;      // offsets inside one block's exchange area
-    constexpr int RS = 16 * DB + 48 * HB;                              // per-producer bias-sum slots (G | dz2 | dz1 | t dz1)
+    constexpr int oDZ2 = KSD * 64;                                     // dz2 panel inside one block's exchange area
+    constexpr int RS = 16 * DB + 16 * HB;                              // per-producer bias-sum slots (G | dz2)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -981,23 +981,11 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     const int lofsF = image_lane_offset_F(lane);
     const float* __restrict__ P = a.params;
 
-    stage_aop(lds + G::gW2T, HB, KSH, tid, nthr, [&](int row, int col) {
-        return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
-    stage_aop(lds + G::gW3T, HB, KSD, tid, nthr, [&](int row, int col) {
+    stage_aop(lds, HB, KSD, tid, nthr, [&](int row, int col) {          // W3^T as A-operand table (producers)
         return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
     __syncthreads();
-    float* bufs = lds + G::gEx;                       // [2 buffers][4 blocks][EXB]
-
-    f32x4 acc3[NOBD][NIB], acc2[NOBH][NIB], acc1[NIB][NOBD];
+    float* bufs = lds + HB * KSD * 64;                // [2 buffers][4 blocks][EXB]
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NOBD; ++s)
-#pragma unroll
-        for (int t = 0; t < NIB; ++t) { acc3[s][t] = zero4; acc1[t][s] = zero4; }
-#pragma unroll
-    for (int s = 0; s < NOBH; ++s)
-#pragma unroll
-        for (int t = 0; t < NIB; ++t) acc2[s][t] = zero4;
 
     const double invK = 1.0 / (double)a.K_global;
     const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
@@ -1008,21 +996,21 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     const int R = (int)((nround - blockIdx.x + gridDim.x - 1) / gridDim.x);   // rounds of this workgroup (>= 1)
 
     if (producer) {
-        // bias gradients (and the time column of dW1) are sums over samples of G, dz2, dz1: the producers hold
-        // those panels anyway and have slack every round, so they keep element-wise running sums in registers
-        // (reduced over the wave's 16 trajectories once, after the loop) and the consumers do no VALU work at all
-        __builtin_amdgcn_s_setprio(PSP_PRODUCER_PRIO);
-        f32x4 sG[DB], sZ2[HB], sZ1[HB], sT1[HB];
+        // ================================================================================ producers
+        // Per block: G = w sqrt(dt) xi (xi loaded from the path store), dz2 = (W3^T G)(1 - h2^2); both panels go to
+        // the exchange buffer of the next round.  db3 = sum G and db2 = sum dz2 are kept as element-wise running
+        // sums in registers (reduced over the wave's 16 trajectories once, after the loop).
+        f32x4 sG[DB], sZ2[HB];
 #pragma unroll
         for (int b = 0; b < DB; ++b) sG[b] = zero4;
 #pragma unroll
-        for (int m = 0; m < HB; ++m) { sZ2[m] = zero4; sZ1[m] = zero4; sT1[m] = zero4; }
+        for (int m = 0; m < HB; ++m) sZ2[m] = zero4;
 #ifdef PSP_STAMPS
         unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         // software pipeline over this wave's blocks: xi and the trajectory weight of the NEXT round are requested at
-        // the top of an iteration (a whole iteration of lead), h2 / h1 of the current block right after G is formed
-        // (they are consumed after the first / second GEMM); with the X_n touch that is <= 63 loads in flight
+        // the top of an iteration (a whole iteration of lead), h2 of the current block right after G is formed
+        // (consumed after the GEMM)
         auto own_block = [&](int it2) __attribute__((always_inline)) {
             const long long b0 = ((long long)blockIdx.x + (long long)it2 * gridDim.x) * 4 + sub;
             return b0 < nblk ? b0 : -1LL;
@@ -1047,11 +1035,12 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
                 const long long blk0 = own_block(it);
                 const bool bvalid = blk0 >= 0;
                 const long long blk = bvalid ? blk0 : nblk - 1;
-                const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
+                const int t16 = (int)(blk % a.ntile16);
                 const int k = t16 * 16 + j;
                 const bool kvalid = bvalid && k < a.K_local;
                 const float* pb = a.path + (size_t)((PSP_ABLATE & 16) ? 0 : blk) * (size_t)G::PB + lane;
                 float* ex = bufs + ((it & 1) * 4 + sub) * EXB + lane;
+                // LOSS_WEIGHTS: the caller supplies w_k = dLoss/dY_k directly in the D argument
                 const float dk = dkn;
                 const float wk = kvalid ? (a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)) : 0.f;
                 f32x4 Gt[DB];
@@ -1060,20 +1049,12 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
                     Gt[b] = (wk * sqdt) * xin[b];                   // adaptive: the (Z + c) dt term cancels
                     sG[b] += Gt[b];
                 }
-                f32x4 h2[HB], h1[HB];
+                f32x4 h2[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
-#pragma unroll
-                for (int m = 0; m < HB; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h1[m][r] = pb[G::pH1 + (4 * m + r) * 64];
-                float touch0;
                 {
-                    // L2 touch (one dword per 128-B line) of the X_n image the consumers read next iteration
-                    const float* xt = a.path + (size_t)blk * (size_t)G::PB + G::pX;
-                    touch0 = xt[(lane * 32 < 4 * DB * 64) ? lane * 32 : 0];
                     const long long n0 = own_block(it + 1);
                     const long long nblk1 = n0 >= 0 ? n0 : nblk - 1;
                     const float* pn = a.path + (size_t)nblk1 * (size_t)G::PB + lane;
@@ -1085,41 +1066,21 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
                         for (int r = 0; r < 4; ++r) xin[b][r] = pn[G::pXi + (4 * b + r) * 64];
                 }
                 PSP_STAMP(tp1);
-                PSP_ACC(0, tp1, tp0);                 // weights -> G, issue of this block's h loads and next round's xi
-                f32x4 dz2[HB], dz1[HB];
-                {
-#pragma unroll
-                    for (int m = 0; m < HB; ++m) dz2[m] = zero4;
-                    gemm_T<HB, KSD, DB>(dz2, lds + G::gW3T, Gt, lane);
-#pragma unroll
-                    for (int m = 0; m < HB; ++m) { dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]); sZ2[m] += dz2[m]; }
-                }
-                PSP_STAMP(tp2);
-                PSP_ACC(1, tp2, tp1);                 // h2 load + GEMM W3^T G + tanh'
+                PSP_ACC(0, tp1, tp0);                 // weights -> G, issue of this block's h2 loads and next round's xi
 #pragma unroll
                 for (int ks = 0; ks < KSD; ++ks) ex[ks * 64] = Gt[ks >> 2][ks & 3];     // exact k-step image of G
-                {
+                f32x4 dz2[HB];
 #pragma unroll
-                    for (int m = 0; m < HB; ++m) dz1[m] = zero4;
-                    gemm_T<HB, KSH, HB>(dz1, lds + G::gW2T, dz2, lane);
-                    const float tn = (float)n * dt;
+                for (int m = 0; m < HB; ++m) dz2[m] = zero4;
+                gemm_T<HB, KSD, DB>(dz2, lds, Gt, lane);
 #pragma unroll
-                    for (int m = 0; m < HB; ++m) {
-                        dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
-                        sZ1[m] += dz1[m];
-                        sT1[m] += tn * dz1[m];
-                    }
-                }
-                PSP_STAMP(tp3);
-                PSP_ACC(2, tp3, tp2);                 // G store + h1 load + GEMM W2^T dz2 + tanh'
+                for (int m = 0; m < HB; ++m) { dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]); sZ2[m] += dz2[m]; }
+                PSP_STAMP(tp2);
+                PSP_ACC(1, tp2, tp1);                 // G store + GEMM W3^T G + tanh'
 #pragma unroll
-                for (int ks = 0; ks < 4 * HB; ++ks) {
-                    ex[oDZ2 + ks * 64] = dz2[ks >> 2][ks & 3];
-                    ex[oDZ1 + ks * 64] = dz1[ks >> 2][ks & 3];
-                }
-                asm volatile("" :: "v"(touch0));
+                for (int ks = 0; ks < 4 * HB; ++ks) ex[oDZ2 + ks * 64] = dz2[ks >> 2][ks & 3];
                 PSP_STAMP(tp4);
-                PSP_ACC(3, tp4, tp3);                 // dz stores
+                PSP_ACC(3, tp4, tp2);                 // dz2 store
             }
             PSP_STAMP(tp5);
             __syncthreads();                              // swap the exchange buffers (pairs with the consumer loop)
@@ -1147,31 +1108,48 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
         for (int m = 0; m < HB; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v2 = jsumf(sZ2[m][r]), v1 = jsumf(sZ1[m][r]), vt = jsumf(sT1[m][r]);
-                if (j == 0) {
-                    red[16 * DB + 16 * m + 4 * r + q] = v2;
-                    red[16 * DB + 16 * HB + 16 * m + 4 * r + q] = v1;
-                    red[16 * DB + 32 * HB + 16 * m + 4 * r + q] = vt;
-                }
+                const float v2 = jsumf(sZ2[m][r]);
+                if (j == 0) red[16 * DB + 16 * m + 4 * r + q] = v2;
             }
         __syncthreads();                                  // pairs with the consumers' barrier before the bias write-out
         return;
     }
-    // ---- consumer-side persistent state: tile subset of this wave, operand sets, phase bodies ----------
-    // HBM operands (h2, h1, X_n images of one sample block, feature-on-lane) live in two ping-pong sets
-    // loaded one block ahead (across the round barrier too); LDS tiles are loaded one PHASE ahead
-    // (G tiles during the previous layer-2/1 phase, dz2/dz1 tiles during the layer-3 phase), and inside a
-    // phase the loads and the bias-sum VALU work are interleaved into the MFMA stream with
-    // sched_group_barrier, because a wave issues in order: anything left before or after the MFMA run
-    // is time the matrix pipe idles.
-    f32x4 oh2[NIB], oh1[2][NIB], ox[2][NOBD];         // HBM operands (feature-on-lane images); h1 / X double-buffered
-    f32x4 g3[NOBD], a2[NOBH], a1[NIB];                // LDS operands (exchange tiles)
-    int ibc[NIB], obc[NOBD], o2c[NOBH], o1c[NIB];
+    // ==================================================================================== consumers
+    // Wave `sub` owns hidden block(s) ib = wh + WH t of every weight-gradient tile row and, per sample block b:
+    //   dz1 tile   = (dz2^T W2[:, ib])  (1 - h1^2)   computed HERE as the transposed product: the MFMA output layout
+    //                (lane = feature, registers = samples) is exactly the A-operand layout the dW1 tiles need, W2's
+    //                block stays in KSH registers, h1 is already loaded for dW2 -- no LDS round trip, no redundancy
+    //   dW3 += G^T h2,  dW2 += dz2^T h1,  dW1 += dz1^T X_n,  db1 / time column += sums of the dz1 tile
+    // HBM operands (feature-on-lane images) are requested a whole block ahead: h1(b+1), X(b+1) during layer 3 of
+    // block b (into the other buffer), h2(b+1) during layers 2/1 of block b; LDS operands one phase ahead.
+    // A wave issues in order, so everything that is not a weight-gradient MFMA is placed BETWEEN those MFMAs
+    // (slot = one MFMA + a few auxiliary items, closed by a scheduling fence).
+    f32x4 acc3[NOBD][NIB], acc2[NOBH][NIB], acc1[NIB][NOBD];
+#pragma unroll
+    for (int s = 0; s < NOBD; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) { acc3[s][t] = zero4; acc1[t][s] = zero4; }
+#pragma unroll
+    for (int s = 0; s < NOBH; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) acc2[s][t] = zero4;
+    f32x4 bs1[NIB], bt1[NIB];                         // element-wise partial sums of the dz1 tiles (db1, time column)
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) { bs1[t] = zero4; bt1[t] = zero4; }
+    f32x4 oh2[NIB], oh1[2][NIB], ox[2][NOBD];         // HBM operands; h1 / X double-buffered
+    f32x4 g3[NOBD], a2[NOBH], a1[NIB];                // G and dz2 tiles from LDS; dz1 tiles computed in registers
+    float azk[4];                                     // rotating A operands (dz2 k-steps) of the dz1 product
+    float w2b[NIB][KSH];                              // B operands of the dz1 product: W2[4 ks + q][16 ib + n]
+    int ibc[NIB], obc[NOBD], o2c[NOBH];
 #pragma unroll
     for (int t = 0; t < NIB; ++t) {
         const int hb = (wh + WH * t) < HB ? (wh + WH * t) : HB - 1;
         ibc[t] = hb * 256;
-        o1c[t] = oDZ1 + hb * 256;
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) {
+            const int o = 4 * ks + q, i = 16 * hb + j;
+            w2b[t][ks] = (o < H && i < H) ? P[G::oW2 + o * H + i] : 0.f;
+        }
     }
 #pragma unroll
     for (int s2 = 0; s2 < NOBD; ++s2) obc[s2] = ((wd + WD * s2) < DB ? (wd + WD * s2) : DB - 1) * 256;
@@ -1201,43 +1179,61 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
 #pragma unroll
         for (int s2 = 0; s2 < NOBD; ++s2) ox[0][s2] = get_F(sbase(blk, G::pX + obc[s2]));
     };
-    auto load_g3 = [&](const float* ex) __attribute__((always_inline)) {
+    auto load_lds_first = [&](const float* ex) __attribute__((always_inline)) {     // round start: G tiles, first dz2 k-steps
 #pragma unroll
         for (int s2 = 0; s2 < NOBD; ++s2) g3[s2] = tile_get(ex + obc[s2], lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) azk[i] = ex[oDZ2 + i * 64 + lane];
     };
-    // A wave issues in order, so everything that is not an MFMA is placed, one item per slot, BETWEEN the
-    // MFMAs of a phase (slot = one MFMA + at most kPer auxiliary items, closed by a scheduling fence).
-    // HBM operands are requested a whole block ahead: h1(b+1), X(b+1) during layer 3 of block b (into the other
-    // buffer), h2(b+1) during layers 2/1 of block b; LDS tiles one phase ahead.
-    // ---- layer 3 of block b (buffer pb): dW3 += G^T h2;  fetch h1(nb), X(nb) from HBM/L2 and dz2(b), dz1(b) from LDS
-    auto phase_l3 = [&](int pb, int nb, const float* ex) __attribute__((always_inline)) {
-        constexpr int nM = 4 * NOBD * NIB, nAux = NIB + NOBD + NOBH + NIB, kPer = (nAux + nM - 1) / nM;
+    // ---- layer 3 of block cb (buffer pb): dW3 += G^T h2, and the dz1 tile;
+    //      fetch h1(nb), X(nb) from HBM/L2, the dz2 tiles and the remaining dz2 k-steps of this block from LDS
+    auto phase_l3 = [&](int pb, int cb, int nb, const float* ex) __attribute__((always_inline)) {
+        constexpr int nM = 4 * NOBD * NIB, nC = KSH * NIB, nAux = NIB + NOBD + NOBH, kPer = (nAux + nM - 1) / nM;
+        f32x4 dzt[NIB];
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) dzt[t] = zero4;
         auto aux = [&](int u) __attribute__((always_inline)) {
             if (u < NIB) { oh1[pb ^ 1][u] = get_F(sbase(nb, G::pH1 + ibc[u])); return; }
             u -= NIB;
             if (u < NOBD) { ox[pb ^ 1][u] = get_F(sbase(nb, G::pX + obc[u])); return; }
             u -= NOBD;
-            if (u < NOBH) { a2[u] = tile_get(ex + o2c[u], lane); return; }
-            u -= NOBH;
-            if (u < NIB) a1[u] = tile_get(ex + o1c[u], lane);
+            if (u < NOBH) a2[u] = tile_get(ex + o2c[u], lane);
         };
 #pragma unroll
         for (int m = 0; m < nM; ++m) {
             const int r = m / (NOBD * NIB), s2 = (m % (NOBD * NIB)) / NIB, t = m % NIB;
             mfma16_inplace(acc3[s2][t], g3[s2][r], oh2[t][r]);
 #pragma unroll
+            for (int c = 0; c < nC; ++c) {                       // dz1 product, spread evenly over the slots
+                if (c * nM / nC == m) {
+                    const int ks = c / NIB, tt = c % NIB;
+                    dzt[tt] = mfma16(azk[ks & 3], w2b[tt][ks], dzt[tt]);
+                    if (tt == NIB - 1 && ks + 4 < KSH) azk[ks & 3] = ex[oDZ2 + (ks + 4) * 64 + lane];
+                }
+            }
+#pragma unroll
             for (int c = 0; c < kPer; ++c) aux(m * kPer + c);
             __builtin_amdgcn_sched_barrier(0);
         }
+        const float tn = (float)(cb / a.ntile16) * dt;
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            a1[t] = dzt[t] * (1.0f - oh1[pb][t] * oh1[pb][t]);
+            bs1[t] += a1[t];
+            bt1[t] += tn * a1[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
     // ---- layers 2 and 1 of block b (buffer pb): dW2 += dz2^T h1, dW1 += dz1^T X_n;
-    //      fetch h2(nb) from HBM/L2 and, inside a round, G(b+1) from LDS
+    //      fetch h2(nb) from HBM/L2 and, inside a round, the next block's G tiles and first dz2 k-steps from LDS
     auto phase_l21 = [&](int pb, int nb, const float* exn) __attribute__((always_inline)) {
-        constexpr int nT = (NOBH + NOBD) * NIB, nM = 4 * nT, nAux = NIB + NOBD, kPer = (nAux + nM - 1) / nM;
+        constexpr int nT = (NOBH + NOBD) * NIB, nM = 4 * nT, nAux = NIB + NOBD + 4, kPer = (nAux + nM - 1) / nM;
         auto aux = [&](int u) __attribute__((always_inline)) {
             if (u < NIB) { oh2[u] = get_F(sbase(nb, G::pH2 + ibc[u])); return; }
             u -= NIB;
-            if (u < NOBD) { if (exn) g3[u] = tile_get(exn + obc[u], lane); }
+            if (u < NOBD) { if (exn) g3[u] = tile_get(exn + obc[u], lane); return; }
+            u -= NOBD;
+            if (u < 4) { if (exn) azk[u] = exn[oDZ2 + u * 64 + lane]; }
         };
 #pragma unroll
         for (int m = 0; m < nM; ++m) {
@@ -1266,17 +1262,17 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
             // -------------------------------------------------------------- consume round r from bufs[(it-1) & 1]
             const int rb = (blockIdx.x + (it - 1) * gridDim.x) * 4;
             const float* exch = bufs + ((it - 1) & 1) * 4 * EXB;
-            const int b1 = blk_at(rb + 1), b2 = blk_at(rb + 2), b3 = blk_at(rb + 3);
-            load_g3(exch);
-            __builtin_amdgcn_sched_barrier(0);
+            const int b0 = blk_at(rb), b1 = blk_at(rb + 1), b2 = blk_at(rb + 2), b3 = blk_at(rb + 3);
             const int bn = blk_at((long long)rb + 4LL * gridDim.x);       // first block of this workgroup's next round
-            phase_l3(0, b1, exch);
+            load_lds_first(exch);
+            __builtin_amdgcn_sched_barrier(0);
+            phase_l3(0, b0, b1, exch);
             phase_l21(0, b1, exch + EXB);
-            phase_l3(1, b2, exch + EXB);
+            phase_l3(1, b1, b2, exch + EXB);
             phase_l21(1, b2, exch + 2 * EXB);
-            phase_l3(0, b3, exch + 2 * EXB);
+            phase_l3(0, b2, b3, exch + 2 * EXB);
             phase_l21(0, b3, exch + 3 * EXB);
-            phase_l3(1, bn, exch + 3 * EXB);
+            phase_l3(1, b3, bn, exch + 3 * EXB);
             phase_l21(1, bn, nullptr);
         }
         PSP_STAMP(tc1);
@@ -1321,7 +1317,17 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
                 if (ob < HB && ib < HB && o2 < H && i2 < H) gp[G::oW2 + o2 * H + i2] = acc2[s][t][rr];
             }
         }
-    // biases and the time column of dW1: fixed-order sum of the four producers' partial sums (LDS)
+    // db1 and the time column of dW1: sums of this wave's dz1 tiles (lane = feature, 16 samples over q' and registers)
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) {
+        const float v1 = qsum(hsum4(bs1[t])), vt = qsum(hsum4(bt1[t]));
+        const int f = 16 * (wh + WH * t) + col;
+        if (wd == 0 && qq == 0 && (wh + WH * t) < HB && f < H) {
+            gp[G::ob1 + f] = v1;
+            gp[G::oW1 + f * (D + 1)] = vt;
+        }
+    }
+    // db3, db2: fixed-order sum of the four producers' partial sums (LDS)
     __syncthreads();                                      // pairs with the producers' barrier after their LDS write
     {
         const float* red = bufs;
@@ -1331,10 +1337,6 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
         for (int f = ct; f < H; f += 256) {
             const float* r2 = red + 16 * DB + f;
             gp[G::ob2 + f] = (r2[0] + r2[RS]) + (r2[2 * RS] + r2[3 * RS]);
-            const float* r1 = r2 + 16 * HB;
-            gp[G::ob1 + f] = (r1[0] + r1[RS]) + (r1[2 * RS] + r1[3 * RS]);
-            const float* rt = r1 + 16 * HB;
-            gp[G::oW1 + f * (D + 1)] = (rt[0] + rt[RS]) + (rt[2 * RS] + rt[3 * RS]);
         }
     }
 }

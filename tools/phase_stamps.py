@@ -56,12 +56,12 @@ if os.environ.get("PSP_BWD_VARIANT", "") != "1":
     pr, co = s[:, :4, :], s[:, 4:, :]
     R = pr[:, :, 7].clamp(min=1)
     print("backward (role-specialised): workgroups %d, rounds per workgroup %.1f" % (nwg, R.mean()))
-    for nm, i in [("  (of which: touch + D load -> weight)", 5), ("Philox + weights -> G", 0), ("h2 load, GEMM W3^T G, tanh'", 1), ("G store, h1 load, GEMM W2^T dz2, tanh'", 2),
-                  ("dz stores", 3), ("barrier wait", 4), ("whole round", 6)]:
+    for nm, i in [("xi -> G, issue h2 / next-xi loads", 0), ("G store, GEMM W3^T G, tanh'", 1),
+                  ("dz2 store", 3), ("barrier wait", 4), ("whole round", 6)]:
         v = pr[:, :, i] / R
         print("  producer  %-40s mean %8.0f   min %8.0f  max %8.0f" % (nm, v.mean(), v.min(), v.max()))
     Rc = co[:, :, 7].clamp(min=1)
-    for nm, i in [("eight phases (288 MFMA)", 0), ("barrier wait", 4), ("whole round", 6)]:
+    for nm, i in [("eight phases (352 MFMA)", 0), ("barrier wait", 4), ("whole round", 6)]:
         v = co[:, :, i] / Rc
         print("  consumer  %-40s mean %8.0f   min %8.0f  max %8.0f" % (nm, v.mean(), v.min(), v.max()))
     sys.exit(0)
