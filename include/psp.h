@@ -87,6 +87,9 @@ const char* psp_last_error(void);
 
 /* 1 if a compiled kernel instantiation exists for (d, H), else 0. */
 int psp_hjb_supported(int32_t d, int32_t H);
+/* Kernel family that serves (d, H): 0 none, 1 narrow (state panel in registers, tables in LDS; any flag
+ * combination of psp_hjb_config), 2 wide (large d: tables in global memory; adaptive != 0 only). */
+int psp_hjb_family(int32_t d, int32_t H);
 
 /* Fills *out; returns <0 if the config is not supported. */
 int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out);

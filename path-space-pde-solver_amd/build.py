@@ -79,10 +79,16 @@ def _build(force, jobs, verbose, only):
     ghdr = os.path.join(CSRC, "gen_kernels.h")
     gdef = os.path.join(CSRC, "gen_instances.def")
     ginst_src = os.path.join(CSRC, "gen_instance.hip")
-    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, ghdr, inc, idef, gdef])]
+    whdr = os.path.join(CSRC, "hjbw_kernels.h")
+    wdef = os.path.join(CSRC, "wide_instances.def")
+    winst_src = os.path.join(CSRC, "hjbw_instance.hip")
+    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, ghdr, whdr, inc, idef, gdef, wdef])]
     for d, H in instances():
         tasks.append((inst_src, os.path.join(OBJ, "inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [inst_src, hdr]))
+    for d, H in instances("wide_instances.def"):
+        tasks.append((winst_src, os.path.join(OBJ, "wide_inst_%d_%d.o" % (d, H)),
+                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [winst_src, whdr, hdr]))
     for d, H in instances("gen_instances.def"):
         tasks.append((ginst_src, os.path.join(OBJ, "gen_inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [ginst_src, ghdr, hdr]))

@@ -41,6 +41,7 @@ struct HjbArgs {
     float* Fint;               // optional (K_local) running-cost integral sum_n f(X_{n+1}) dt
     float* Yout;               // optional (K_local) Y_N
     unsigned long long* dbg;   // diagnostic builds (-DPSP_STAMPS): per-wave phase cycle sums
+    float* tables;             // wide kernels: A-operand tables in global memory (carved from the caller's scratch)
     long long k_offset;
     long long K_global;
     int x0_stride;
@@ -1351,6 +1352,8 @@ struct HjbInstance {
     int path_floats_per_tile_step;   // Geo::PB
     int (*bwd2_lds_bytes)();
     hipError_t (*launch_bwd2)(const HjbArgs&, int grid, hipStream_t);   // role-specialised variant, 512 threads
+    int wide;                        // 1: hjbw_kernels.h family (tables in global memory, 256-thread workgroups)
+    int fwd_table_floats, bwd_table_floats;
 };
 
 template <int D, int H>

@@ -1,0 +1,676 @@
+// hjbw_kernels.h -- "wide" HJB rollout kernels: the same algorithm as hjb_kernels.h for state dimensions whose
+// 16-trajectory panels no longer fit one wave's 256 registers next to the weight tables in LDS (d = 200, 500, ...).
+//
+// What changes against the narrow family:
+//   * one wave per SIMD (256-thread workgroups) so a wave owns the whole 512-entry unified register file:
+//     the state panel X (4 ceil(d/16) registers), the control / increment panel and the accumulators of the
+//     d x d products stay in registers for any d <= 512;
+//   * A-operand tables (W1, W2, W3, dt A, B; W3^T for the backward) live in GLOBAL memory (L2-resident, built per
+//     call by hjbw_tables_kernel) in k-step-major order [ks][mb][64], so one k-step of all output blocks is one
+//     contiguous run and the k-loop can stay ROLLED (a d = 500 product has 4000 MFMAs);
+//   * the B operand of a rolled k-loop cannot be a register array (dynamic index), so the input panel of the big
+//     products is written once per step to a per-wave LDS image [ks][64] and read back one dword per k-step;
+//   * the backward is streaming: a wave forms dz2 of its own sample block with a rolled k-loop over the stored
+//     xi image, then owns hidden block ib for every weight-gradient tile row and walks the d/16 state blocks,
+//     building the G tile of each straight from the xi image in feature-on-lane form (no G exchange at all).
+// Layouts, Philox counters, loss weights, path-store format and the flat gradient layout are those of
+// hjb_kernels.h; parity tests compare the two families on the same configuration.
+#pragma once
+#include <type_traits>
+
+#include "hjb_kernels.h"
+
+namespace psp {
+
+template <int D, int H>
+struct GeoW {
+    using G = Geo<D, H>;
+    static constexpr int DB = G::DB, HB = G::HB, KSH = G::KSH;
+    static constexpr int KP = 4 * DB;                 // k-steps of a d-dimensional contraction, padded to whole blocks
+    static_assert(HB == 4, "wide kernels are built for 49..64 hidden units (4 hidden blocks)");
+    static_assert(KSH == 16 || KSH == 15 || KSH == 14 || KSH == 13, "hidden k-steps");
+    // k-step-major A-operand tables in global memory: element ((ks * MB + mb) * 64 + lane)
+    static constexpr int tW1 = 0, tW2 = tW1 + KP * HB * 64, tW3 = tW2 + 16 * HB * 64, tA = tW3 + 16 * DB * 64,
+                         tB = tA + KP * DB * 64, fwd_table_floats = tB + KP * DB * 64;
+    static constexpr int bwd_table_floats = KP * HB * 64;            // W3^T
+    // forward LDS (floats): per-feature vectors, reduction scratch, one input image per wave
+    static constexpr int vb1 = 0, vw1t = vb1 + HB * 16, vb2 = vw1t + HB * 16, vb3 = vb2 + HB * 16,
+                         vdr = vb3 + DB * 16, vrun = vdr + DB * 16, vterm = vrun + DB * 16, fRed = vterm + DB * 16,
+                         fImg = fRed + 64, IMG = KP * 64, fwd_lds_floats = fImg + 4 * IMG;
+    // backward LDS (floats): dz2 k-step images of the four blocks of a round, double-buffered; bias staging reuses it
+    static constexpr int EXB = 4 * HB * 64, bwd_lds_floats = 2 * 4 * EXB + 4 * 16 * DB;
+};
+
+// dst[((ks * MB + mb) * 64 + lane)], lane = i + 16 q  <-  src(row = 16 mb + rowmap(i), col = 4 ks + q)
+template <class F>
+__device__ __forceinline__ void table_fill(float* dst, int MB, int KS, long long gtid, long long gstride, F src) {
+    const long long total = (long long)MB * KS * 64;
+    for (long long idx = gtid; idx < total; idx += gstride) {
+        const int lane = (int)(idx & 63);
+        const int t = (int)(idx >> 6);
+        const int mb = t % MB, ks = t / MB;
+        const int i = lane & 15, q = lane >> 4;
+        dst[idx] = src(16 * mb + 4 * (i & 3) + (i >> 2), 4 * ks + q);
+    }
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(256) void hjbw_tables_kernel(const HjbArgs a, int backward) {
+    using G = Geo<D, H>;
+    using W = GeoW<D, H>;
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gs = (long long)gridDim.x * blockDim.x;
+    const float* __restrict__ P = a.params;
+    float* T = a.tables;
+    if (backward) {
+        table_fill(T, W::HB, W::KP, gtid, gs, [&](int row, int col) {
+            return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+        return;
+    }
+    table_fill(T + W::tW1, W::HB, W::KP, gtid, gs, [&](int row, int col) {
+        return (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f; });
+    table_fill(T + W::tW2, W::HB, 16, gtid, gs, [&](int row, int col) {
+        return (row < H && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
+    table_fill(T + W::tW3, W::DB, 16, gtid, gs, [&](int row, int col) {
+        return (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f; });
+    if (a.drift_kind == DRIFT_DENSE) {
+        const float dt = a.dt;
+        const float* __restrict__ A = a.drift;
+        table_fill(T + W::tA, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+            return (row < D && col < D) ? dt * A[row * D + col] : 0.f; });
+    }
+    if (a.sigma_kind == SIGMA_DENSE) {
+        const float* __restrict__ B = a.sigma;
+        table_fill(T + W::tB, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+            return (row < D && col < D) ? B[row * D + col] : 0.f; });
+    }
+}
+
+// wave-uniform table pointers are forced into an SGPR pair so that every operand load is
+// "SGPR base + lane offset + immediate" (no per-load 64-bit address registers for the compiler to hoist)
+typedef const __attribute__((address_space(1))) float* gptr_t;
+__device__ __forceinline__ gptr_t sgpr_ptr(const float* p) {
+    unsigned long long addr = (unsigned long long)p;
+    asm volatile("" : "+s"(addr));
+    return (gptr_t)addr;
+}
+
+// acc[MB] += T . in,  T: k-step-major global table with KS k-steps, in: register panel (static indices, unrolled)
+// LD = number of output blocks per k-step in the table (MB of them, starting at tbl, are used)
+template <int MB, int KS, int INB, int LD = MB>
+__device__ __forceinline__ void gemm_regs(f32x4 (&acc)[MB], const float* __restrict__ tbl, const f32x4 (&in)[INB], int lane) {
+    static_assert(INB * 4 >= KS, "input panel too small");
+    constexpr int CH = (MB >= 16) ? 1 : (MB >= 8 ? 2 : 4);
+    constexpr int NCH = cdiv(KS, CH);
+    const unsigned ul = (unsigned)lane;
+    float buf[2][CH * MB];
+    {
+        gptr_t cb = sgpr_ptr(tbl);
+#pragma unroll
+        for (int kk = 0; kk < CH; ++kk)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                if (kk < KS) buf[0][kk * MB + mb] = cb[(kk * LD + mb) * 64 + ul];
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+            gptr_t cb = sgpr_ptr(tbl + (c + 1) * CH * LD * 64);
+#pragma unroll
+            for (int kk = 0; kk < CH; ++kk)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int ks = (c + 1) * CH + kk;
+                    if (ks < KS) buf[(c + 1) & 1][kk * MB + mb] = cb[(kk * LD + mb) * 64 + ul];
+                }
+        }
+#pragma unroll
+        for (int kk = 0; kk < CH; ++kk) {
+            const int ks = c * CH + kk;
+            if (ks < KS) {
+                const float bop = in[ks >> 2][ks & 3];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma16(buf[c & 1][kk * MB + mb], bop, acc[mb]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(kFenceMask);
+    }
+}
+
+// acc[MB] += T . img,  T: k-step-major global table with KP k-steps (KP % 4 == 0), img: this wave's LDS image of the
+// input panel (one dword per lane and k-step).  Rolled over k with a two-stage register pipeline.
+template <int MB, int KP>
+__device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restrict__ tbl, const float* img, int lane) {
+    constexpr int U = (MB >= 16) ? 1 : 2;             // k-steps per stage (2 U divides KP)
+    static_assert(KP % (2 * U) == 0, "k padding");
+    float ab[2][U * MB], bb[2][U];
+    const unsigned ul = (unsigned)lane;
+    auto load = [&](int st, int ks0) __attribute__((always_inline)) {
+        gptr_t tp = sgpr_ptr(tbl + (size_t)ks0 * (MB * 64));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bb[st][u] = img[(ks0 + u) * 64 + lane];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) ab[st][u * MB + mb] = tp[(u * MB + mb) * 64 + ul];
+        }
+    };
+    auto fma_stage = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma16(ab[st][u * MB + mb], bb[st][u], acc[mb]);
+    };
+    load(0, 0);
+#pragma unroll 1
+    for (int ks = 0; ks < KP; ks += 2 * U) {
+        load(1, ks + U);
+        __builtin_amdgcn_sched_barrier(kFenceMask);
+        fma_stage(0);
+        __builtin_amdgcn_sched_barrier(kFenceMask);
+        // the last iteration re-reads the final k-step (valid memory, result unused) instead of branching
+        load(0, (ks + 2 * U < KP) ? ks + 2 * U : KP - U);
+        __builtin_amdgcn_sched_barrier(kFenceMask);
+        fma_stage(1);
+        __builtin_amdgcn_sched_barrier(kFenceMask);
+    }
+}
+
+// =======================================================================================
+// Wide forward kernel: one wave = one 16-trajectory tile for all N steps (same per-step algebra, same
+// reference lines as hjb_fwd_kernel)
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    using W = GeoW<D, H>;
+    constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const float* __restrict__ P = a.params;
+    const float* __restrict__ T = a.tables;
+
+    stage_vec(lds + W::vb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
+    stage_vec(lds + W::vw1t, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW1 + f * (D + 1)] : 0.f; });
+    stage_vec(lds + W::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
+    stage_vec(lds + W::vb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
+    stage_vec(lds + W::vdr, DB, tid, nthr, [&](int f) {
+        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+    stage_vec(lds + W::vrun, DB, tid, nthr, [&](int f) {
+        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+    stage_vec(lds + W::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
+    __syncthreads();
+
+    const int t16 = blockIdx.x * nwave + wave;        // 16-trajectory tile owned by this wave
+    const bool wave_valid = t16 < a.ntile16;
+    const int k = t16 * 16 + j;
+    const bool kvalid = wave_valid && k < a.K_local;
+    const uint32_t kglob = (uint32_t)(a.k_offset + k);
+    const float dt = a.dt, sqdt = a.sqdt;
+    float* img = lds + W::fImg + wave * W::IMG;       // this wave's input image [KP][64]
+
+    double sD = 0.0, sD2 = 0.0;
+    if (wave_valid) {
+        const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds) + q;         // index by block * 4
+        const f32x4* vterm = vecs0 + W::vterm / 4;
+
+        f32x4 X[DB];                                   // X_0 (solver.py:365-367) in T layout
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * b + 4 * r + q;
+                const float v = a.x0[(size_t)(kvalid ? k : 0) * a.x0_stride + (f < D ? f : D - 1)];
+                X[b][r] = (f < D && kvalid) ? v : 0.f;
+            }
+        float Y = a.y0 ? a.y0[0] : 0.f;
+        float Fsum = 0.f;
+
+#pragma unroll 1
+        for (int n = 0; n < a.N; ++n) {
+            const float tn = a.tfeat ? a.tfeat[n] : (float)n * dt;
+            const f32x4* vecs = opaque(vecs0);         // re-read the small vectors each step (no hoisting)
+            const f32x4* vb1 = vecs + W::vb1 / 4;
+            const f32x4* vw1t = vecs + W::vw1t / 4;
+            const f32x4* vb2 = vecs + W::vb2 / 4;
+            const f32x4* vb3 = vecs + W::vb3 / 4;
+            const f32x4* vdr = vecs + W::vdr / 4;
+            const f32x4* vrun = vecs + W::vrun / 4;
+            // path block of (n, tile): wave-uniform base in SGPRs, stores are "base + lane + immediate"
+            typedef __attribute__((address_space(1))) float* gwptr_t;
+            auto pbase = [&](int ofs) __attribute__((always_inline)) {
+                unsigned long long addr = (unsigned long long)a.path +
+                    4ull * (((unsigned long long)n * a.ntile16 + t16) * (unsigned)G::PB + (unsigned)ofs);
+                asm volatile("" : "+s"(addr));
+                return (gwptr_t)addr;
+            };
+            const unsigned ul = (unsigned)lane;
+            // X_n: LDS image (B operand of the W1 and drift products) and path store
+#pragma unroll
+            for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = X[ks >> 2][ks & 3];
+            if (a.store_path) {
+                gwptr_t px = pbase(G::pX);
+#pragma unroll
+                for (int ks = 0; ks < KP; ++ks) px[ks * 64 + ul] = X[ks >> 2][ks & 3];
+            }
+            // ---- control net (function_space.py:190-195)
+            f32x4 h1[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
+            gemm_img<HB, KP>(h1, T + W::tW1, img, lane);
+            // ---- X_{n+1} = X + b(X) dt + sigma v (solver.py:471-472): the drift part now, while the image still holds X_n
+            if (a.drift_kind == DRIFT_DENSE) {
+                gemm_img<DB, KP>(X, T + W::tA, img, lane);                       // X += (dt A) X_n
+            } else if (a.drift_kind == DRIFT_DIAG) {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) X[b] += dt * (vdr[b * 4] * X[b]);
+            } else if (a.drift_kind == DRIFT_DWELL) {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) X[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
+            }
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h1[m] = tanh4(h1[m]);
+            f32x4 h2[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
+            gemm_regs<HB, 16, HB>(h2, T + W::tW2, h1, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
+            if (a.store_path) {
+                gwptr_t ph = pbase(G::pH1);
+#pragma unroll
+                for (int ks = 0; ks < 4 * HB; ++ks) {
+                    ph[ks * 64 + ul] = h1[ks >> 2][ks & 3];
+                    ph[(G::pH2 - G::pH1) + ks * 64 + ul] = h2[ks >> 2][ks & 3];
+                }
+            }
+            // ---- control output, Brownian increment and increment panel v, four state blocks at a time, so that Z is
+            //      never live as a whole: Z_g = W3[g] h2 + b3 -> row sums |Z|^2, Z.xi (solver.py:477-478) ->
+            //      v = c dt + xi sqrt(dt) (c = -Z if adaptive, solver.py:451-456) -> LDS image (dense sigma) or X
+            float S = 0.f, Pz = 0.f;
+            auto z_group = [&](auto nbc, int g) __attribute__((always_inline)) {
+                constexpr int NB = decltype(nbc)::value;
+                f32x4 Zg[NB];
+#pragma unroll
+                for (int m = 0; m < NB; ++m) Zg[m] = vb3[(4 * g + m) * 4];
+                gemm_regs<NB, 16, HB, DB>(Zg, T + W::tW3 + 4 * g * 64, h2, lane);
+#pragma unroll
+                for (int m = 0; m < NB; ++m) {
+                    const int b = 4 * g + m;
+                    f32x4 xi;
+                    if (a.noise_mode == NOISE_PHILOX) {
+                        xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
+                    } else {
+                        const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = 16 * b + 4 * r + q;
+                            const float v = xrow[f < D ? f : D - 1];
+                            xi[r] = (f < D && kvalid) ? v : 0.f;
+                        }
+                    }
+                    if (16 * b + 16 > D) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
+                    }
+                    if (a.store_path) {
+                        gwptr_t pxi = pbase(G::pXi + b * 256);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pxi[r * 64 + ul] = xi[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        S = fmaf(Zg[m][r], Zg[m][r], S);
+                        Pz = fmaf(Zg[m][r], xi[r], Pz);
+                    }
+                    const f32x4 v = a.adaptive ? (sqdt * xi - dt * Zg[m]) : (sqdt * xi);
+                    if (a.sigma_kind == SIGMA_DENSE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) img[(4 * b + r) * 64 + lane] = v[r];
+                    } else if (a.sigma_kind == SIGMA_SCALE) {
+                        X[b] += a.sigma_scale * v;
+                    } else {
+                        X[b] += v;
+                    }
+                }
+            };
+#pragma unroll
+            for (int g = 0; g < DB / 4; ++g) z_group(std::integral_constant<int, 4>{}, g);
+            if constexpr (DB % 4 != 0) z_group(std::integral_constant<int, DB % 4>{}, DB / 4);
+            S = qsum(S);
+            Pz = qsum(Pz);
+            if (a.sigma_kind == SIGMA_DENSE) gemm_img<DB, KP>(X, T + W::tB, img, lane);     // X += B v
+
+            // ---- running cost f(X_{n+1}) and Y update (solver.py:477-478)
+            float fX = 0.f;
+            if (a.runcost_kind == RUN_DIAGQ) {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    const f32x4 pv = vrun[b * 4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fX = fmaf(pv[r] * X[b][r], X[b][r], fX);
+                }
+                fX = qsum(fX);
+            }
+            const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
+            Y = Y + drift_y * dt + Pz * sqdt;
+            Fsum = fmaf(fX, dt, Fsum);
+        }
+
+        // ---- terminal cost g(X_N) and D = Y - g  (problems.py:49,164,334; solver.py:167-168)
+        float g = 0.f;
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            const f32x4 tv = vterm[b * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = X[b][r];
+                if (a.term_kind == TERM_LINEAR) g = fmaf(tv[r], x, g);
+                else if (a.term_kind == TERM_DIAGQ) g = fmaf(tv[r] * x, x, g);
+                else g = fmaf(tv[r] * (x - 1.0f), (x - 1.0f), g);
+            }
+        }
+        g = qsum(g);
+        const float Dk = Y - g;
+        if (kvalid && q == 0) a.D[k] = Dk;
+        if (a.Fint && kvalid && q == 0) a.Fint[k] = Fsum;
+        if (a.Yout && kvalid && q == 0) a.Yout[k] = Y;
+        if (a.XN && kvalid) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * b + 4 * r + q;
+                    if (f < D) a.XN[(size_t)k * D + f] = X[b][r];
+                }
+        }
+        if (kvalid && q == 0) { sD = (double)Dk; sD2 = (double)Dk * (double)Dk; }
+    }
+    sD = jsum(sD); sD2 = jsum(sD2);
+    double* red = reinterpret_cast<double*>(lds + W::fRed);
+    if (lane == 0) { red[2 * wave] = sD; red[2 * wave + 1] = sD2; }
+    __syncthreads();
+    if (tid == 0) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int w = 0; w < nwave; ++w) { t0 += red[2 * w]; t1 += red[2 * w + 1]; }
+        a.fwd_partial[2 * blockIdx.x] = t0;
+        a.fwd_partial[2 * blockIdx.x + 1] = t1;
+    }
+}
+
+// =======================================================================================
+// Wide backward kernel (adaptive forward process): analytic parameter gradient, streaming over the state blocks.
+// Workgroup = 4 waves (one per SIMD), persistent over rounds of 4 sample blocks:
+//   phase A  wave w, block 4 round + w:  dz2 = (W3^T G)(1 - h2^2), G = w sqrt(dt) xi, as a rolled k-loop over the
+//            stored xi image (one coalesced dword per lane and k-step) and the W3^T table; dz2 image -> LDS
+//   phase B  wave w owns hidden block ib = w of every tile row; for each of the 4 blocks:
+//            dz1 tile = (dz2^T W2[:, ib])(1 - h1^2)   (transposed product: MFMA output = operand layout)
+//            dW2[:, ib] += dz2^T h1;  then for every state block ob:
+//            G tile = xi tile * (w sqrt(dt)) straight from the xi image in feature-on-lane form,
+//            dW3[ob, ib] += G^T h2,  dW1[ib, ob] += dz1^T X_n
+//   biases: db2 from the phase-A panels, db1 / time column from the dz1 tiles, db3 from the G tiles (the ob range is
+//   split over the four waves).  One barrier per round (the dz2 exchange is double-buffered).
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(256) void hjbw_bwd_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    using W = GeoW<D, H>;
+    constexpr int DB = W::DB, HB = W::HB, KP = W::KP, EXB = W::EXB;
+    constexpr int OBW = cdiv(DB, 4);                  // state blocks per wave for the db3 sums
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const float* __restrict__ P = a.params;
+    const float* __restrict__ T = a.tables;           // W3^T, k-step-major
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned lofsU = (unsigned)image_lane_offset_F(lane);
+
+    const double invK = 1.0 / (double)a.K_global;
+    const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
+    const float coef = (float)(2.0 * invK);
+    const float sqdt = a.sqdt, dt = a.dt;
+    const long long nblk = (long long)a.N * a.ntile16;
+    const long long nround = (nblk + 3) / 4;
+
+    // persistent accumulators of this wave's tile row(s)
+    f32x4 acc3[DB], acc1[DB], acc2[HB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b) { acc3[b] = zero4; acc1[b] = zero4; }
+#pragma unroll
+    for (int m = 0; m < HB; ++m) acc2[m] = zero4;
+    f32x4 sZ2[HB], bs1 = zero4, bt1 = zero4;
+    float bs3[OBW];
+#pragma unroll
+    for (int m = 0; m < HB; ++m) sZ2[m] = zero4;
+#pragma unroll
+    for (int i = 0; i < OBW; ++i) bs3[i] = 0.f;
+    float w2b[16];                                    // B operands of the dz1 product: W2[4 ks + q][16 ib + n]
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int o = 4 * ks + q, i = 16 * wave + j;
+        w2b[ks] = (o < H && i < H) ? P[G::oW2 + o * H + i] : 0.f;
+    }
+
+    int par = 0;
+#pragma unroll 1
+    for (long long round = blockIdx.x; round < nround; round += gridDim.x, par ^= 1) {
+        float* exch = lds + par * 4 * EXB;
+        // ------------------------------------------------------------------ phase A: own block
+        {
+            const long long blk0 = round * 4 + wave;
+            const bool bvalid = blk0 < nblk;
+            const long long blk = bvalid ? blk0 : nblk - 1;
+            const int t16 = (int)(blk % a.ntile16);
+            const int k = t16 * 16 + j;
+            const bool kvalid = bvalid && k < a.K_local;
+            const float dk = a.D[kvalid ? k : 0];
+            const float wk = kvalid ? (a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)) : 0.f;
+            const float wks = wk * sqdt;
+            const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+            f32x4 h2[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
+            f32x4 dz2[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz2[m] = zero4;
+            // rolled k-loop, 4 k-steps per iteration, operands of the next iteration in flight
+            const float* xip = pb + G::pXi;
+            const unsigned ul = (unsigned)lane;
+            float xb[2][4], ab[2][4 * HB];
+            auto load = [&](int st, int ks0) __attribute__((always_inline)) {
+                gptr_t tp = sgpr_ptr(T + (size_t)ks0 * (HB * 64));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xb[st][u] = xip[(size_t)(ks0 + u) * 64];
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) ab[st][u * HB + m] = tp[(u * HB + m) * 64 + ul];
+                }
+            };
+            auto fma_stage = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float g = wks * xb[st][u];
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) dz2[m] = mfma16(ab[st][u * HB + m], g, dz2[m]);
+                }
+            };
+            load(0, 0);
+#pragma unroll 1
+            for (int ks = 0; ks < KP; ks += 8) {
+                load(1, (ks + 4 < KP) ? ks + 4 : KP - 4);
+                __builtin_amdgcn_sched_barrier(kFenceMask);
+                fma_stage(0);
+                __builtin_amdgcn_sched_barrier(kFenceMask);
+                if (ks + 4 < KP) {
+                    load(0, (ks + 8 < KP) ? ks + 8 : KP - 4);
+                    __builtin_amdgcn_sched_barrier(kFenceMask);
+                    fma_stage(1);
+                    __builtin_amdgcn_sched_barrier(kFenceMask);
+                }
+            }
+            float* ex = exch + wave * EXB + lane;
+#pragma unroll
+            for (int m = 0; m < HB; ++m) {
+                dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+                sZ2[m] += dz2[m];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ex[(4 * m + r) * 64] = dz2[m][r];
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------------ phase B: hidden block ib = wave
+#pragma unroll 1
+        for (int sb = 0; sb < 4; ++sb) {
+            const long long c0 = round * 4 + sb;
+            if (c0 >= nblk) break;                                    // wave-uniform
+            const int cb = __builtin_amdgcn_readfirstlane((int)c0);
+            const int n = cb / a.ntile16, t16 = cb % a.ntile16;
+            const float* bp = a.path + (size_t)cb * (size_t)G::PB;   // wave-uniform block base
+            const float* ex = exch + sb * EXB;
+            // per-lane weights of samples 4 q .. 4 q + 3 (feature-on-lane tiles hold 4 samples per lane)
+            f32x4 w4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = t16 * 16 + 4 * q + r;
+                const float dk = a.D[kk < a.K_local ? kk : 0];
+                w4[r] = (kk < a.K_local) ? (a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)) * sqdt : 0.f;
+            }
+            const f32x4 h2t = *reinterpret_cast<const f32x4*>(bp + G::pH2 + wave * 256 + lofsU);
+            const f32x4 h1t = *reinterpret_cast<const f32x4*>(bp + G::pH1 + wave * 256 + lofsU);
+            // dz1 tile of hidden block ib: (dz2^T W2[:, ib]) (1 - h1^2)
+            f32x4 dzt = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) dzt = mfma16(ex[ks * 64 + lane], w2b[ks], dzt);
+            // dW2[:, ib] += dz2^T h1
+#pragma unroll
+            for (int m = 0; m < HB; ++m) {
+                const f32x4 a2 = tile_get(ex + m * 256, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[m] = mfma16(a2[r], h1t[r], acc2[m]);
+            }
+            const f32x4 a1 = dzt * (1.0f - h1t * h1t);
+            bs1 += a1;
+            bt1 += ((float)n * dt) * a1;
+            // stream over the state blocks: xi tile -> G tile -> dW3, X tile -> dW1 (tiles of block ob + 2 in flight)
+            const float* xib = bp + G::pXi + lofsU;
+            const float* xb = bp + G::pX + lofsU;
+            f32x4 xit[3], xt[3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i < DB) {
+                    xit[i] = *reinterpret_cast<const f32x4*>(xib + i * 256);
+                    xt[i] = *reinterpret_cast<const f32x4*>(xb + i * 256);
+                }
+            }
+#pragma unroll
+            for (int ob = 0; ob < DB; ++ob) {
+                if (ob + 2 < DB) {
+                    xit[(ob + 2) % 3] = *reinterpret_cast<const f32x4*>(xib + (ob + 2) * 256);
+                    xt[(ob + 2) % 3] = *reinterpret_cast<const f32x4*>(xb + (ob + 2) * 256);
+                }
+                const f32x4 g = xit[ob % 3] * w4;
+                if (ob / OBW == wave) bs3[ob % OBW] += hsum4(g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc3[ob] = mfma16(g[r], h2t[r], acc3[ob]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc1[ob] = mfma16(a1[r], xt[ob % 3][r], acc1[ob]);
+                __builtin_amdgcn_sched_barrier(kFenceMask);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- write-out: tiles are disjoint between waves; D tile (row block, col block): lane (col = l & 15, qq = l >> 4),
+    //      reg rr <-> [16 rowblk + 4 qq + rr][16 colblk + col]
+    float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
+    const int col = lane & 15, qq = lane >> 4, ib = wave;
+#pragma unroll
+    for (int ob = 0; ob < DB; ++ob)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int o3 = 16 * ob + 4 * qq + rr, i3 = 16 * ib + col;
+            if (o3 < D && i3 < H) gp[G::oW3 + o3 * H + i3] = acc3[ob][rr];
+            const int o1 = 16 * ib + 4 * qq + rr, i1 = 16 * ob + col;
+            if (o1 < H && i1 < D) gp[G::oW1 + o1 * (D + 1) + 1 + i1] = acc1[ob][rr];
+        }
+#pragma unroll
+    for (int m = 0; m < HB; ++m)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int o2 = 16 * m + 4 * qq + rr, i2 = 16 * ib + col;
+            if (o2 < H && i2 < H) gp[G::oW2 + o2 * H + i2] = acc2[m][rr];
+        }
+    {
+        const float v1 = qsum(hsum4(bs1)), vt = qsum(hsum4(bt1));
+        const int f = 16 * ib + col;
+        if (qq == 0 && f < H) { gp[G::ob1 + f] = v1; gp[G::oW1 + f * (D + 1)] = vt; }
+    }
+#pragma unroll
+    for (int i = 0; i < OBW; ++i) {
+        const int ob = wave * OBW + i;
+        const float v = qsum(bs3[i]);
+        const int f = 16 * ob + col;
+        if (qq == 0 && ob < DB && f < D) gp[G::ob3 + f] = v;
+    }
+    // db2: the four waves' phase-A sums (lane (j, q), component r of block m <-> feature 16 m + 4 r + q), fixed order
+    float* red = lds + wave * 64;
+#pragma unroll
+    for (int m = 0; m < HB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v2 = jsumf(sZ2[m][r]);
+            if (j == 0) red[16 * m + 4 * r + q] = v2;
+        }
+    __syncthreads();
+    if (tid < H) gp[G::ob2 + tid] = (lds[tid] + lds[64 + tid]) + (lds[128 + tid] + lds[192 + tid]);
+}
+
+template <int D, int H>
+struct HjbwLaunch {
+    using G = Geo<D, H>;
+    using W = GeoW<D, H>;
+    static int fwd_lds(int, int) { return W::fwd_lds_floats * 4; }
+    static int bwd_lds(int) { return W::bwd_lds_floats * 4; }
+    static int bwd2_lds() { return W::bwd_lds_floats * 4; }
+    static hipError_t tables(const HjbArgs& a, int backward, hipStream_t s) {
+        hipLaunchKernelGGL((hjbw_tables_kernel<D, H>), dim3(256), dim3(256), 0, s, a, backward);
+        return hipGetLastError();
+    }
+    static hipError_t fwd(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        hipError_t e = tables(a, 0, s);
+        if (e != hipSuccess) return e;
+        const int bytes = W::fwd_lds_floats * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbw_fwd_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
+        return hipGetLastError();
+    }
+    static hipError_t bwd(const HjbArgs&, int, int, hipStream_t) { return hipErrorNotSupported; }
+    static hipError_t bwd2(const HjbArgs& a, int grid, hipStream_t s) {
+        hipError_t e = tables(a, 1, s);
+        if (e != hipSuccess) return e;
+        const int bytes = W::bwd_lds_floats * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_bwd_kernel<D, H>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbw_bwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
+        return hipGetLastError();
+    }
+    static HjbInstance instance() {
+        HjbInstance r{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::PB, &bwd2_lds, &bwd2};
+        r.wide = 1;
+        r.fwd_table_floats = W::fwd_table_floats;
+        r.bwd_table_floats = W::bwd_table_floats;
+        return r;
+    }
+};
+
+}  // namespace psp
+
+#define PSP_DEFINE_WIDE_INSTANCE(D_, H_) \
+    extern "C" psp::HjbInstance psp_wide_instance_##D_##_##H_() { return psp::HjbwLaunch<D_, H_>::instance(); }
+#define PSP_DECLARE_WIDE_INSTANCE(D_, H_) extern "C" psp::HjbInstance psp_wide_instance_##D_##_##H_();

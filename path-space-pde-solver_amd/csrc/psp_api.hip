@@ -8,9 +8,13 @@
 #include "../../include/psp.h"
 #include "hjb_kernels.h"
 #include "gen_kernels.h"
+#include "hjbw_kernels.h"
 
 #define X(D_, H_) PSP_DECLARE_INSTANCE(D_, H_)
 #include "instances.def"
+#undef X
+#define X(D_, H_) PSP_DECLARE_WIDE_INSTANCE(D_, H_)
+#include "wide_instances.def"
 #undef X
 #define X(D_, H_) PSP_DECLARE_GEN_INSTANCE(D_, H_)
 #include "gen_instances.def"
@@ -39,9 +43,25 @@ const Entry kTable[] = {
 #undef X
 };
 
+const Entry kWideTable[] = {
+#define X(D_, H_) {D_, H_, &psp_wide_instance_##D_##_##H_},
+#include "wide_instances.def"
+#undef X
+};
+
+// narrow family first (state panel in 256 registers, tables in LDS); the wide family covers larger d.
+// PSP_FORCE_WIDE=1 prefers the wide instance where both exist (parity tests of one family against the other).
 bool find_instance(int d, int H, psp::HjbInstance* out) {
-    for (const Entry& e : kTable)
+    static const char* fw = getenv("PSP_FORCE_WIDE");
+    const bool force_wide = fw && fw[0] == '1';
+    if (!force_wide)
+        for (const Entry& e : kTable)
+            if (e.d == d && e.H == H) { *out = e.fn(); return true; }
+    for (const Entry& e : kWideTable)
         if (e.d == d && e.H == H) { *out = e.fn(); return true; }
+    if (force_wide)
+        for (const Entry& e : kTable)
+            if (e.d == d && e.H == H) { *out = e.fn(); return true; }
     return false;
 }
 
@@ -94,11 +114,15 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     if (p->inst.bwd_lds_bytes(c->adaptive) > kMaxLds)
         return fail(-3, "backward kernel staging does not fit the 160 KiB LDS for this (d,H)");
     p->ntile16 = (c->K_local + 15) / 16;
+    if ((long long)c->N * p->ntile16 >= (1LL << 31)) return fail(-1, "N * ceil(K/16) must stay below 2^31");
     const int cus = n_cus();
+    if (p->inst.wide && !c->adaptive)
+        return fail(-2, "the wide kernels (this d) are built for adaptive_forward_process=True only");
     // forward: one 16-trajectory tile per wave; 1..8 waves per workgroup so that small K still spreads over CUs
+    // (wide family: 1..4 waves, one per SIMD)
     int fw = (p->ntile16 + cus - 1) / cus;
     if (fw < 1) fw = 1;
-    if (fw > 8) fw = 8;
+    if (fw > (p->inst.wide ? 4 : 8)) fw = p->inst.wide ? 4 : 8;
     p->fwd_waves = fw;
     p->fwd_grid = (p->ntile16 + fw - 1) / fw;
     // backward: persistent over rounds of 4 sample blocks; 4-wave workgroups, two per CU
@@ -109,7 +133,8 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     // exchange area fits the LDS; PSP_BWD_VARIANT=1 forces the two-workgroups-per-CU kernel (A/B timing)
     static const char* force = getenv("PSP_BWD_VARIANT");
     p->bwd_specialised = c->adaptive && p->inst.bwd2_lds_bytes() <= kMaxLds && !(force && force[0] == '1');
-    p->bwd_waves = p->bwd_specialised ? 8 : 4;
+    if (p->inst.wide) p->bwd_specialised = true;          // launch_bwd2 = hjbw_bwd_kernel (4 waves)
+    p->bwd_waves = (p->bwd_specialised && !p->inst.wide) ? 8 : 4;
     long long g = nround;
     const long long gmax = p->bwd_specialised ? cus : 2LL * cus;
     if (g > gmax) g = gmax;
@@ -285,9 +310,20 @@ int psp_debug_set_stamp_buffer(unsigned long long* buf, int64_t n_entries) {
 #endif
 }
 
+static int64_t grad_rows_bytes(const Plan& p) {       // partial-gradient rows, padded to 256 B
+    const int64_t b = (int64_t)p.bwd_grid * p.inst.n_params * 4;
+    return (b + 255) / 256 * 256;
+}
+
 int psp_hjb_supported(int32_t d, int32_t H) {
     psp::HjbInstance inst;
     return find_instance(d, H, &inst) ? 1 : 0;
+}
+
+int psp_hjb_family(int32_t d, int32_t H) {
+    psp::HjbInstance inst;
+    if (!find_instance(d, H, &inst)) return 0;
+    return inst.wide ? 2 : 1;
 }
 
 int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out) {
@@ -301,8 +337,9 @@ int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out) {
     out->bwd_workgroups = p.bwd_grid;
     out->path_bytes = cfg->store_path
         ? (int64_t)cfg->N * p.ntile16 * (int64_t)p.inst.path_floats_per_tile_step * 4 : 0;
-    out->fwd_partial_bytes = (int64_t)p.fwd_grid * 2 * 8;
-    out->grad_partial_bytes = (int64_t)p.bwd_grid * p.inst.n_params * 4;
+    // the wide family keeps its A-operand tables behind the partial sums in the same caller-owned scratch
+    out->fwd_partial_bytes = (int64_t)p.fwd_grid * 2 * 8 + (int64_t)p.inst.fwd_table_floats * 4;
+    out->grad_partial_bytes = grad_rows_bytes(p) + (int64_t)p.inst.bwd_table_floats * 4;
     return 0;
 }
 
@@ -321,6 +358,7 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
     fill_args(cfg, p, &a);
     a.params = params; a.x0 = x0; a.x0_stride = x0_stride; a.y0 = y0; a.xi = xi; a.path = path;
     a.D = D_out; a.XN = XN_out; a.Yout = Y_out; a.fwd_partial = fwd_partial;
+    a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
     hipError_t e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel launch");
@@ -342,6 +380,7 @@ int psp_hjb_rollout_eval(const psp_hjb_config* cfg, const float* params, const f
     a.store_path = 0;
     a.params = params; a.x0 = x0; a.x0_stride = x0_stride; a.xi = xi; a.tfeat = tfeat;
     a.D = D_out; a.Fint = Fint_out; a.XN = XN_out; a.fwd_partial = fwd_partial;
+    a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
     hipError_t e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel (eval) launch");
@@ -373,6 +412,7 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
     fill_args(cfg, p, &a);
     a.params = params; a.xi = xi; a.path = const_cast<float*>(path); a.D = const_cast<float*>(D);
     a.sums = sums; a.grad_partial = grad_partial;
+    a.tables = reinterpret_cast<float*>(reinterpret_cast<char*>(grad_partial) + grad_rows_bytes(p));
     if (a.dbg) a.dbg += (size_t)p.fwd_grid * 8 * 8;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
     hipError_t e = p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)

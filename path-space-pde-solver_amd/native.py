@@ -77,6 +77,7 @@ SIGNATURES = {
     "psp_version": (C.c_int, []),
     "psp_last_error": (C.c_char_p, []),
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "psp_hjb_family": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_query": (C.c_int, [C.POINTER(HjbConfig), C.POINTER(HjbSizes)]),
     "psp_hjb_rollout_fwd": (C.c_int, [C.POINTER(HjbConfig), _P, _P, C.c_int32, _P, _P, C.c_uint64, C.c_uint32,
                                       _P, _P, _P, _P, _P, _P]),
@@ -150,6 +151,11 @@ def stream_ptr(device):
 
 def supported(d, H):
     return bool(load().psp_hjb_supported(int(d), int(H)))
+
+
+def family(d, H):
+    """0 none, 1 narrow kernels, 2 wide kernels (large d, adaptive forward process only)."""
+    return int(load().psp_hjb_family(int(d), int(H)))
 
 
 def gen_supported(d, H):

@@ -59,6 +59,8 @@ def native_eligibility(solver):
         raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
     if not nat.supported(solver.d, shape[1]):
         return 'no compiled kernel instance for d=%d, H=%d (see csrc/instances.def)' % (solver.d, shape[1])
+    if nat.family(solver.d, shape[1]) == 2 and not solver.adaptive_forward_process:
+        return 'the wide kernels (d=%d) are built for adaptive_forward_process=True only' % solver.d
     return None
 
 

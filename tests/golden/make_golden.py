@@ -192,6 +192,15 @@ CASES = [
          problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=0.5, seed=42)),
          solver=dict(HJB, L=4, lr=0.001, seed=42, delta_t=0.01, K=1024, u_l2_error_flag=False),
          net=dict(kind="tanh_mlp", widths=[64, 64], seed=123), probe_times=[0.0, 0.25]),
+    # BASELINE.json configs[3] / configs[4] shapes (d=200, d=500; 2x64 tanh MLP) at a K the reference runs in seconds
+    dict(name="llgc_d200_h64_logvar", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=200, off_diag=0.1 / 200 ** 0.5, T=0.2, seed=42)),
+         solver=dict(HJB, L=3, lr=0.001, seed=42, delta_t=0.01, K=200, u_l2_error_flag=False),
+         net=dict(kind="tanh_mlp", widths=[64, 64], seed=123), probe_times=[0.0, 0.1]),
+    dict(name="llgc_d500_h64_logvar", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=500, off_diag=0.1 / 500 ** 0.5, T=0.1, seed=42)),
+         solver=dict(HJB, L=3, lr=0.001, seed=42, delta_t=0.01, K=72, u_l2_error_flag=False),
+         net=dict(kind="tanh_mlp", widths=[64, 64], seed=123), probe_times=[0.0]),
     # DenseNet swapped in as the control net (notebook extension point)
     dict(name="llgc_d100_densenet64_logvar", family="solver",
          problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=0.5, seed=42)),

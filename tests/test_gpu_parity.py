@@ -19,7 +19,8 @@ from util_cases import flat_params, make_oracle, make_pkg_solver, orc, psp
 pytestmark = pytest.mark.gpu
 nat = psp.native
 
-NATIVE_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_logvar", "dw_d10_logvar",
+NATIVE_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_logvar", "llgc_d200_h64_logvar",
+                "llgc_d500_h64_logvar", "dw_d10_logvar",
                 "llgc_d20_diag_logvar", "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive",
                 "lqgc_d2_variance", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
 
