@@ -36,6 +36,11 @@ WORKLOADS = {
     "hjb_llgc_d100_K1024_N50_h64": dict(d=100, H=64, K=1024, T=0.5, dt=0.01, off_diag=0.01),
     # structured variant A=-I, B=I (reported separately)
     "hjb_llgc_d100_K65536_N100_h64_diag": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.0),
+    # BASELINE.json configs[3]: d=200, K=262144 over 8 GPUs = 32768 per GPU, N=100 (wide kernel family)
+    "hjb_llgc_d200_K32768_N100_h64": dict(d=200, H=64, K=32768, T=1.0, dt=0.01, off_diag=0.1 / 200 ** 0.5),
+    # BASELINE.json configs[4] shape: d=500, N=200; K per GPU reduced from 131072 to 16384 (path store 15 GB)
+    "hjb_llgc_d500_K16384_N200_h64": dict(d=500, H=64, K=16384, T=2.0, dt=0.01, off_diag=0.1 / 500 ** 0.5),
+    "hjb_llgc_d500_K16384_N200_h64_diag": dict(d=500, H=64, K=16384, T=2.0, dt=0.01, off_diag=0.0),
 }
 GENERAL_WORKLOADS = {
     # BASELINE.json configs[2] shape in fp32: d=100 diffusion loss, K=65536, N=100, V = DenseNet(101 -> 1, [64, 64])

@@ -8,6 +8,8 @@
 //   * A-operand tables (W1, W2, W3, dt A, B; W3^T for the backward) live in GLOBAL memory (L2-resident, built per
 //     call by hjbw_tables_kernel) in k-step-major order [ks][mb][64], so one k-step of all output blocks is one
 //     contiguous run and the k-loop can stay ROLLED (a d = 500 product has 4000 MFMAs);
+//     (each wave streams its own operands: a workgroup-shared LDS stage with one barrier per k-step was measured
+//     25-40 % slower -- the L2 -> L1 stream of 32 B/clk per CU is not the limit, the barriers are);
 //   * the B operand of a rolled k-loop cannot be a register array (dynamic index), so the input panel of the big
 //     products is written once per step to a per-wave LDS image [ks][64] and read back one dword per k-step;
 //   * the backward is streaming: a wave forms dz2 of its own sample block with a rolled k-loop over the stored
@@ -103,27 +105,27 @@ __device__ __forceinline__ void gemm_regs(f32x4 (&acc)[MB], const float* __restr
     constexpr int NCH = cdiv(KS, CH);
     const unsigned ul = (unsigned)lane;
     float buf[2][CH * MB];
-    {
-        gptr_t cb = sgpr_ptr(tbl);
+    // one SGPR base per (k-step, 16 output blocks): every load is base + lane * 4 + immediate < 4096
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kk = 0; kk < CH; ++kk)
+        for (int kk = 0; kk < CH; ++kk) {
+            const int ks = c * CH + kk;
+            if (ks < KS) {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-                if (kk < KS) buf[0][kk * MB + mb] = cb[(kk * LD + mb) * 64 + ul];
-    }
+                for (int m0 = 0; m0 < MB; m0 += 16) {
+                    gptr_t cb = sgpr_ptr(tbl + (ks * LD + m0) * 64);
+#pragma unroll
+                    for (int mb = m0; mb < m0 + 16 && mb < MB; ++mb) buf[c & 1][kk * MB + mb] = cb[(mb - m0) * 64 + ul];
+                }
+            }
+        }
+    };
+    load_chunk(0);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) {
-            gptr_t cb = sgpr_ptr(tbl + (c + 1) * CH * LD * 64);
-#pragma unroll
-            for (int kk = 0; kk < CH; ++kk)
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const int ks = (c + 1) * CH + kk;
-                    if (ks < KS) buf[(c + 1) & 1][kk * MB + mb] = cb[(kk * LD + mb) * 64 + ul];
-                }
-        }
-#pragma unroll
+        if (c + 1 < NCH) load_chunk(c + 1);
+        __builtin_amdgcn_sched_barrier(0);            // the prefetch stays ahead of this chunk's MFMAs (global operands:
+#pragma unroll                                        // a fence that lets VMEM cross would let the loads sink to their use)
         for (int kk = 0; kk < CH; ++kk) {
             const int ks = c * CH + kk;
             if (ks < KS) {
@@ -132,7 +134,7 @@ __device__ __forceinline__ void gemm_regs(f32x4 (&acc)[MB], const float* __restr
                 for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma16(buf[c & 1][kk * MB + mb], bop, acc[mb]);
             }
         }
-        __builtin_amdgcn_sched_barrier(kFenceMask);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -145,12 +147,15 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
     float ab[2][U * MB], bb[2][U];
     const unsigned ul = (unsigned)lane;
     auto load = [&](int st, int ks0) __attribute__((always_inline)) {
-        gptr_t tp = sgpr_ptr(tbl + (size_t)ks0 * (MB * 64));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             bb[st][u] = img[(ks0 + u) * 64 + lane];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) ab[st][u * MB + mb] = tp[(u * MB + mb) * 64 + ul];
+            for (int m0 = 0; m0 < MB; m0 += 16) {
+                gptr_t tp = sgpr_ptr(tbl + ((size_t)(ks0 + u) * MB + m0) * 64);
+#pragma unroll
+                for (int mb = m0; mb < m0 + 16 && mb < MB; ++mb) ab[st][u * MB + mb] = tp[(mb - m0) * 64 + ul];
+            }
         }
     };
     auto fma_stage = [&](int st) __attribute__((always_inline)) {
@@ -163,14 +168,14 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
 #pragma unroll 1
     for (int ks = 0; ks < KP; ks += 2 * U) {
         load(1, ks + U);
-        __builtin_amdgcn_sched_barrier(kFenceMask);
+        __builtin_amdgcn_sched_barrier(0);
         fma_stage(0);
-        __builtin_amdgcn_sched_barrier(kFenceMask);
+        __builtin_amdgcn_sched_barrier(0);
         // the last iteration re-reads the final k-step (valid memory, result unused) instead of branching
         load(0, (ks + 2 * U < KP) ? ks + 2 * U : KP - U);
-        __builtin_amdgcn_sched_barrier(kFenceMask);
+        __builtin_amdgcn_sched_barrier(0);
         fma_stage(1);
-        __builtin_amdgcn_sched_barrier(kFenceMask);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -201,16 +206,18 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
     stage_vec(lds + W::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
     __syncthreads();
 
-    const int t16 = blockIdx.x * nwave + wave;        // 16-trajectory tile owned by this wave
-    const bool wave_valid = t16 < a.ntile16;
+    const int t16raw = blockIdx.x * nwave + wave;     // 16-trajectory tile owned by this wave
+    const bool wave_valid = t16raw < a.ntile16;       // surplus waves of the last workgroup run along on the last tile
+    const int t16 = wave_valid ? t16raw : a.ntile16 - 1;   // (no divergent control flow around the rolled products) but store nothing
     const int k = t16 * 16 + j;
     const bool kvalid = wave_valid && k < a.K_local;
     const uint32_t kglob = (uint32_t)(a.k_offset + k);
     const float dt = a.dt, sqdt = a.sqdt;
     float* img = lds + W::fImg + wave * W::IMG;       // this wave's input image [KP][64]
+    const bool store_path = a.store_path && wave_valid;
 
     double sD = 0.0, sD2 = 0.0;
-    if (wave_valid) {
+    {
         const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds) + q;         // index by block * 4
         const f32x4* vterm = vecs0 + W::vterm / 4;
 
@@ -226,10 +233,16 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
         float Y = a.y0 ? a.y0[0] : 0.f;
         float Fsum = 0.f;
 
+#ifdef PSP_STAMPS
+        unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #pragma unroll 1
         for (int n = 0; n < a.N; ++n) {
+            PSP_STAMP(ws0);
             const float tn = a.tfeat ? a.tfeat[n] : (float)n * dt;
             const f32x4* vecs = opaque(vecs0);         // re-read the small vectors each step (no hoisting)
+            const int qn = opaque_i(q);                // ... and rebuild the per-block Philox counters (else 3 registers
+                                                       // per state block are hoisted out of the step loop)
             const f32x4* vb1 = vecs + W::vb1 / 4;
             const f32x4* vw1t = vecs + W::vw1t / 4;
             const f32x4* vb2 = vecs + W::vb2 / 4;
@@ -248,16 +261,22 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
             // X_n: LDS image (B operand of the W1 and drift products) and path store
 #pragma unroll
             for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = X[ks >> 2][ks & 3];
-            if (a.store_path) {
-                gwptr_t px = pbase(G::pX);
+            if (store_path) {
 #pragma unroll
-                for (int ks = 0; ks < KP; ++ks) px[ks * 64 + ul] = X[ks >> 2][ks & 3];
+                for (int g = 0; g < KP / 16 + 1; ++g) {               // fresh SGPR base every 4 KiB: immediates stay < 4096
+                    gwptr_t px = pbase(G::pX + g * 16 * 64);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (g * 16 + e < KP) px[e * 64 + ul] = X[(g * 16 + e) >> 2][(g * 16 + e) & 3];
+                }
             }
+            PSP_STAMP(ws1);
             // ---- control net (function_space.py:190-195)
             f32x4 h1[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
             gemm_img<HB, KP>(h1, T + W::tW1, img, lane);
+            PSP_STAMP(ws2);
             // ---- X_{n+1} = X + b(X) dt + sigma v (solver.py:471-472): the drift part now, while the image still holds X_n
             if (a.drift_kind == DRIFT_DENSE) {
                 gemm_img<DB, KP>(X, T + W::tA, img, lane);                       // X += (dt A) X_n
@@ -268,6 +287,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) X[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
             }
+            PSP_STAMP(ws3);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = tanh4(h1[m]);
             f32x4 h2[HB];
@@ -276,14 +296,15 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
             gemm_regs<HB, 16, HB>(h2, T + W::tW2, h1, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
-            if (a.store_path) {
-                gwptr_t ph = pbase(G::pH1);
+            if (store_path) {
+                gwptr_t ph1 = pbase(G::pH1), ph2 = pbase(G::pH2);
 #pragma unroll
                 for (int ks = 0; ks < 4 * HB; ++ks) {
-                    ph[ks * 64 + ul] = h1[ks >> 2][ks & 3];
-                    ph[(G::pH2 - G::pH1) + ks * 64 + ul] = h2[ks >> 2][ks & 3];
+                    ph1[ks * 64 + ul] = h1[ks >> 2][ks & 3];
+                    ph2[ks * 64 + ul] = h2[ks >> 2][ks & 3];
                 }
             }
+            PSP_STAMP(ws4);
             // ---- control output, Brownian increment and increment panel v, four state blocks at a time, so that Z is
             //      never live as a whole: Z_g = W3[g] h2 + b3 -> row sums |Z|^2, Z.xi (solver.py:477-478) ->
             //      v = c dt + xi sqrt(dt) (c = -Z if adaptive, solver.py:451-456) -> LDS image (dense sigma) or X
@@ -299,7 +320,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
                     const int b = 4 * g + m;
                     f32x4 xi;
                     if (a.noise_mode == NOISE_PHILOX) {
-                        xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
+                        xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + qn), a.iter, a.seed_lo, a.seed_hi);
                     } else {
                         const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
 #pragma unroll
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
                     }
-                    if (a.store_path) {
+                    if (store_path) {
                         gwptr_t pxi = pbase(G::pXi + b * 256);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pxi[r * 64 + ul] = xi[r];
@@ -339,6 +360,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
             if constexpr (DB % 4 != 0) z_group(std::integral_constant<int, DB % 4>{}, DB / 4);
             S = qsum(S);
             Pz = qsum(Pz);
+            PSP_STAMP(ws5);
             if (a.sigma_kind == SIGMA_DENSE) gemm_img<DB, KP>(X, T + W::tB, img, lane);     // X += B v
 
             // ---- running cost f(X_{n+1}) and Y update (solver.py:477-478)
@@ -355,7 +377,21 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
             const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
             Y = Y + drift_y * dt + Pz * sqdt;
             Fsum = fmaf(fX, dt, Fsum);
+            PSP_STAMP(ws6);
+            PSP_ACC(0, ws1, ws0);   // X image + path store
+            PSP_ACC(1, ws2, ws1);   // W1 product
+            PSP_ACC(2, ws3, ws2);   // drift product
+            PSP_ACC(3, ws4, ws3);   // tanh, W2, tanh, h stores
+            PSP_ACC(4, ws5, ws4);   // Z groups: W3 product, Philox, xi store, v
+            PSP_ACC(5, ws6, ws5);   // sigma product, running cost, Y
+            PSP_ACC(6, ws6, ws0);
         }
+#ifdef PSP_STAMPS
+        if (a.dbg && lane == 0 && wave_valid) {
+            stamps[7] = (unsigned long long)a.N;
+            for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+        }
+#endif
 
         // ---- terminal cost g(X_N) and D = Y - g  (problems.py:49,164,334; solver.py:167-168)
         float g = 0.f;
@@ -501,14 +537,14 @@ __global__ __launch_bounds__(256) void hjbw_bwd_kernel(const HjbArgs a) {
 #pragma unroll 1
             for (int ks = 0; ks < KP; ks += 8) {
                 load(1, (ks + 4 < KP) ? ks + 4 : KP - 4);
-                __builtin_amdgcn_sched_barrier(kFenceMask);
+                __builtin_amdgcn_sched_barrier(0);
                 fma_stage(0);
-                __builtin_amdgcn_sched_barrier(kFenceMask);
+                __builtin_amdgcn_sched_barrier(0);
                 if (ks + 4 < KP) {
                     load(0, (ks + 8 < KP) ? ks + 8 : KP - 4);
-                    __builtin_amdgcn_sched_barrier(kFenceMask);
+                    __builtin_amdgcn_sched_barrier(0);
                     fma_stage(1);
-                    __builtin_amdgcn_sched_barrier(kFenceMask);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             float* ex = exch + wave * EXB + lane;
@@ -577,7 +613,7 @@ __global__ __launch_bounds__(256) void hjbw_bwd_kernel(const HjbArgs a) {
                 for (int r = 0; r < 4; ++r) acc3[ob] = mfma16(g[r], h2t[r], acc3[ob]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc1[ob] = mfma16(a1[r], xt[ob % 3][r], acc1[ob]);
-                __builtin_amdgcn_sched_barrier(kFenceMask);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

@@ -122,7 +122,8 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     // (wide family: 1..4 waves, one per SIMD)
     int fw = (p->ntile16 + cus - 1) / cus;
     if (fw < 1) fw = 1;
-    if (fw > (p->inst.wide ? 4 : 8)) fw = p->inst.wide ? 4 : 8;
+    if (fw > 8) fw = 8;
+    if (p->inst.wide && fw > 4) fw = 4;   // wide family: one wave per SIMD
     p->fwd_waves = fw;
     p->fwd_grid = (p->ntile16 + fw - 1) / fw;
     // backward: persistent over rounds of 4 sample blocks; 4-wave workgroups, two per CU
