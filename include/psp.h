@@ -136,8 +136,14 @@ int psp_hjb_terminal_reduce(const psp_hjb_config* cfg, const double* fwd_partial
  * Backward pass: replaces loss.backward() of solver.py:221 with the analytic gradient
  * (detach_forward=True: dL/dZ_n[k] = w_k ((Z_n + c) dt + xi_{n+1} sqrt(dt)),
  *  w_k = (2/K)(D_k - mean D) for log-variance, (2/K) D_k for moment).
+ *   path     : the path store written by psp_hjb_rollout_fwd with store_path != 0 (register images of
+ *              X_n, h1, h2 and of the Brownian increment xi_{n+1} per step and 16-trajectory tile)
+ *   xi, seed, iter : accepted for symmetry with the forward call and ignored -- the increments are read
+ *              back from `path`, whatever the noise mode (a VALU cycle next to the fp32 MFMA stream
+ *              costs more than the extra 448 B per trajectory-step of path store)
  *   sums     : GLOBAL (sum D, sum D^2), fp64 on device (after the all-reduce)
- *   grad_partial : grad_partial_bytes scratch (per-workgroup partial gradients)
+ *   grad_partial : grad_partial_bytes scratch (per-workgroup partial gradients; the wide kernel family
+ *              also keeps an operand table there)
  *   grad_out : flat gradient (n_params fp32) for this rank's trajectories, summed in a fixed
  *              order (bitwise reproducible).  The gradient of the learnable Y_0 (moment loss)
  *              is (2/K) sum_k D_k and is formed by the caller from `sums`.
