@@ -90,6 +90,13 @@ int psp_hjb_supported(int32_t d, int32_t H);
 /* Kernel family that serves (d, H): 0 none, 1 narrow (state panel in registers, tables in LDS; any flag
  * combination of psp_hjb_config), 2 wide (large d: tables in global memory; adaptive != 0 only). */
 int psp_hjb_family(int32_t d, int32_t H);
+/* Enumeration of the compiled (d, H) instances (family as above).  A configuration whose (d, H) is not in the
+ * list runs EXACTLY on any instance with larger d and H after zero padding (padded state components never couple
+ * back: zero weight rows / columns, zero drift, sigma, running- and terminal-cost entries); the host mirror
+ * (native_shapes.py) picks the cheapest one and keeps the index map between the real and the padded flat
+ * parameter / gradient vectors. */
+int psp_hjb_instance_count(void);
+int psp_hjb_instance_get(int32_t i, int32_t* d, int32_t* H, int32_t* family);
 
 /* Fills *out; returns <0 if the config is not supported. */
 int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out);

@@ -16,6 +16,7 @@ from .solver import Solver  # noqa: F401
 from .general_solver import GeneralSolver  # noqa: F401
 from .plan_native import PlanUnsupported  # noqa: F401
 from . import native  # noqa: F401
+from . import native_shapes  # noqa: F401
 from .utilities import do_importance_sampling_me  # noqa: F401
 
 __all__ = ['Solver', 'GeneralSolver', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',

@@ -327,6 +327,18 @@ int psp_hjb_family(int32_t d, int32_t H) {
     return inst.wide ? 2 : 1;
 }
 
+int psp_hjb_instance_count(void) {
+    return (int)(sizeof(kTable) / sizeof(kTable[0]) + sizeof(kWideTable) / sizeof(kWideTable[0]));
+}
+
+int psp_hjb_instance_get(int32_t i, int32_t* d, int32_t* H, int32_t* family) {
+    const int nn = (int)(sizeof(kTable) / sizeof(kTable[0])), nw = (int)(sizeof(kWideTable) / sizeof(kWideTable[0]));
+    if (i < 0 || i >= nn + nw || !d || !H || !family) return fail(-1, "instance index out of range");
+    const Entry& e = i < nn ? kTable[i] : kWideTable[i - nn];
+    *d = e.d; *H = e.H; *family = i < nn ? 1 : 2;
+    return 0;
+}
+
 int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out) {
     Plan p;
     int rc = make_plan(cfg, &p);

@@ -78,6 +78,8 @@ SIGNATURES = {
     "psp_last_error": (C.c_char_p, []),
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_family": (C.c_int, [C.c_int32, C.c_int32]),
+    "psp_hjb_instance_count": (C.c_int, []),
+    "psp_hjb_instance_get": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "psp_hjb_query": (C.c_int, [C.POINTER(HjbConfig), C.POINTER(HjbSizes)]),
     "psp_hjb_rollout_fwd": (C.c_int, [C.POINTER(HjbConfig), _P, _P, C.c_int32, _P, _P, C.c_uint64, C.c_uint32,
                                       _P, _P, _P, _P, _P, _P]),
@@ -156,6 +158,25 @@ def supported(d, H):
 def family(d, H):
     """0 none, 1 narrow kernels, 2 wide kernels (large d, adaptive forward process only)."""
     return int(load().psp_hjb_family(int(d), int(H)))
+
+
+def instances():
+    """[(d, H, family)] of the compiled HJB kernel instances (family 1 narrow, 2 wide)."""
+    lib = load()
+    out = []
+    for i in range(lib.psp_hjb_instance_count()):
+        d, H, f = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib.psp_hjb_instance_get(i, C.byref(d), C.byref(H), C.byref(f)), 'psp_hjb_instance_get')
+        out.append((d.value, H.value, f.value))
+    return out
+
+
+def query_rc(cfg):
+    """psp_hjb_query without raising: (rc, sizes, message)."""
+    sizes = HjbSizes()
+    lib = load()
+    rc = lib.psp_hjb_query(C.byref(cfg), C.byref(sizes))
+    return rc, sizes, (lib.psp_last_error().decode() if rc else '')
 
 
 def gen_supported(d, H):

@@ -18,9 +18,11 @@ import torch
 
 try:
     from . import native as nat
+    from . import native_shapes as shapes
     from . import sharding
 except ImportError:
     import native as nat
+    import native_shapes as shapes
     import sharding
 
 
@@ -57,10 +59,15 @@ def native_eligibility(solver):
         return 'problem has no native_spec() (coefficients outside the native catalogue)'
     if not nat.is_built():
         raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
-    if not nat.supported(solver.d, shape[1]):
-        return 'no compiled kernel instance for d=%d, H=%d (see csrc/instances.def)' % (solver.d, shape[1])
-    if nat.family(solver.d, shape[1]) == 2 and not solver.adaptive_forward_process:
-        return 'the wide kernels (d=%d) are built for adaptive_forward_process=True only' % solver.d
+    probe = nat.HjbConfig()
+    probe.K_local, probe.N, probe.K_global = 16, 1, 16
+    probe.drift_kind, probe.sigma_kind = spec['drift'][0], spec['sigma'][0]
+    probe.runcost_kind, probe.term_kind = spec['runcost'][0], spec['term'][0]
+    probe.adaptive = 1 if solver.adaptive_forward_process else 0
+    probe.store_path = 1
+    chosen, why = shapes.choose(probe, solver.d, shape[1])
+    if chosen is None:
+        return why
     return None
 
 
@@ -96,29 +103,38 @@ class HjbNativePlan:
             return t
 
         cfg = nat.HjbConfig()
-        cfg.d, cfg.H, cfg.K_local, cfg.N = solver.d, self.H, self.K_local, solver.N
+        cfg.K_local, cfg.N = self.K_local, solver.N
         cfg.K_global, cfg.k_offset = K, self.k_offset
         cfg.dt = float(solver.delta_t.item())
         cfg.sqrt_dt = float(solver.sq_delta_t.item())
         cfg.drift_kind = spec['drift'][0]
-        cfg.drift = nat.ptr(dev_f32(spec['drift'][1])) if spec['drift'][1] is not None else None
         cfg.sigma_kind = spec['sigma'][0]
-        cfg.sigma = nat.ptr(dev_f32(spec['sigma'][1])) if spec['sigma'][1] is not None else None
         cfg.sigma_scale = float(spec['sigma'][2])
         cfg.runcost_kind = spec['runcost'][0]
-        cfg.runcost = nat.ptr(dev_f32(spec['runcost'][1])) if spec['runcost'][1] is not None else None
         cfg.term_kind = spec['term'][0]
-        cfg.term = nat.ptr(dev_f32(spec['term'][1]))
         cfg.adaptive = 1 if solver.adaptive_forward_process else 0
         cfg.loss_kind = {'log-variance': nat.LOSS_LOG_VARIANCE, 'moment': nat.LOSS_MOMENT}.get(
             solver.loss_method, nat.LOSS_WEIGHTS)
         self.generic_loss = cfg.loss_kind == nat.LOSS_WEIGHTS
         cfg.noise_mode = nat.NOISE_PHILOX if noise == 'philox' else nat.NOISE_SUPPLIED
         cfg.store_path = 1
+        # kernel instance: the exact (d, H) if compiled, else the cheapest larger one (zero padding, native_shapes.py)
+        chosen, why = shapes.choose(cfg, solver.d, self.H)
+        if chosen is None:
+            raise PlanUnsupported(why)
+        self.d_pad, self.H_pad, self.family, sizes = chosen
+        self.pad = shapes.ParamPad(solver.d, self.H, self.d_pad, self.H_pad, dev)
+        pad = self.pad
+        cfg.drift = nat.ptr(dev_f32(pad.drift_or_sigma(spec['drift'][1]))) if spec['drift'][1] is not None else None
+        cfg.sigma = nat.ptr(dev_f32(pad.drift_or_sigma(spec['sigma'][1]))) if spec['sigma'][1] is not None else None
+        cfg.runcost = nat.ptr(dev_f32(pad.vec(spec['runcost'][1]))) if spec['runcost'][1] is not None else None
+        cfg.term = nat.ptr(dev_f32(pad.vec(spec['term'][1])))
         self.cfg = cfg
-        sizes = nat.query(cfg)
-        assert sizes.n_params == self.P, (sizes.n_params, self.P)
+        assert sizes.n_params == pad.Pp, (sizes.n_params, pad.Pp)
         self.sizes = sizes
+        # kernel-side (padded) parameter and gradient vectors; identical to the real ones when nothing is padded
+        self.flat_k = self.flat if pad.identity else pad.new_padded_params()
+        self.grad_k = None
         self.path = torch.empty(sizes.path_bytes // 4, dtype=torch.float32, device=dev)
         self.fwd_partial = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)
         self.grad_partial = torch.empty(sizes.grad_partial_bytes // 4, dtype=torch.float32, device=dev)
@@ -127,9 +143,10 @@ class HjbNativePlan:
         self.w = torch.empty(self.K_local, dtype=torch.float32, device=dev) if self.generic_loss else None
         self.sums = torch.zeros(2, dtype=torch.float64, device=dev)
         self.grad = torch.empty(self.P, dtype=torch.float32, device=dev)
+        self.grad_k = self.grad if pad.identity else torch.empty(pad.Pp, dtype=torch.float32, device=dev)
         self.m = torch.zeros(self.P, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.P, dtype=torch.float32, device=dev)
-        self.x0_vec = dev_f32(solver.X_0)
+        self.x0_vec = dev_f32(pad.vec(solver.X_0.detach().to(dev)))
         self.step = 0
         self.events = None   # bench.py: list collecting HIP-event pairs around the two rollout kernels
         # learnable Y_0 (solver.py:372-374): tiny Adam in torch on a 1-element tensor
@@ -167,8 +184,8 @@ class HjbNativePlan:
             x0 = torch.randn(s.K, s.d)
         xi = torch.randn(s.K, s.d, s.N + 1)
         lo, hi = self.k_offset, self.k_offset + self.K_local
-        xi_dev = xi[lo:hi].permute(2, 0, 1).contiguous().to(self.dev)
-        x0_dev = x0[lo:hi].contiguous().to(self.dev) if x0 is not None else None
+        xi_dev = self.pad.last_dim(xi[lo:hi].permute(2, 0, 1).contiguous().to(self.dev))
+        x0_dev = self.pad.last_dim(x0[lo:hi].contiguous().to(self.dev)) if x0 is not None else None
         return xi_dev, x0_dev
 
     def iteration(self, l, loss_out):
@@ -182,15 +199,17 @@ class HjbNativePlan:
         elif s.random_X_0:
             g = torch.Generator(device=self.dev)
             g.manual_seed(int(s.seed) * 1000003 + l)
-            x0 = torch.randn(s.K, s.d, generator=g, device=self.dev)[self.k_offset:self.k_offset + self.K_local].contiguous()
+            x0 = self.pad.last_dim(torch.randn(s.K, s.d, generator=g, device=self.dev)[
+                self.k_offset:self.k_offset + self.K_local].contiguous())
         x0_t = x0 if x0 is not None else self.x0_vec
-        x0_stride = s.d if x0 is not None else 0
+        x0_stride = self.d_pad if x0 is not None else 0
+        flat_k = self.pad.scatter_params(self.flat, self.flat_k)
         y0_ptr = nat.ptr(self.y0_param) if self.learn_y0 else None
         ev = None
         if self.events is not None:      # events go on torch's current stream = the launch stream
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
-        nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0_t), x0_stride, y0_ptr,
+        nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(x0_t), x0_stride, y0_ptr,
                                           nat.ptr(xi), seed, l, nat.ptr(self.path), nat.ptr(self.D), None,
                                           nat.ptr(self.Yn), nat.ptr(self.fwd_partial), st), 'psp_hjb_rollout_fwd')
         if ev is not None:
@@ -206,12 +225,13 @@ class HjbNativePlan:
         loss_out[l] = loss.to(torch.float32)
         if ev is not None:
             ev[2].record()
-        nat.check(lib.psp_hjb_rollout_bwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(xi), seed, l, nat.ptr(self.path),
+        nat.check(lib.psp_hjb_rollout_bwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(xi), seed, l, nat.ptr(self.path),
                                           nat.ptr(d_or_w), nat.ptr(self.sums), nat.ptr(self.grad_partial),
-                                          nat.ptr(self.grad), st), 'psp_hjb_rollout_bwd')
+                                          nat.ptr(self.grad_k), st), 'psp_hjb_rollout_bwd')
         if ev is not None:
             ev[3].record()
             self.events.append(ev)
+        self.pad.gather_grad(self.grad_k, self.grad)    # real entries of the (possibly padded) gradient
         sharding.allreduce_sum_(self.grad)              # collective 2: p floats
         self.step += 1
         nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
@@ -260,9 +280,10 @@ class HjbNativePlan:
         if self.noise == 'reference':
             xi, x0 = self._reference_noise()
         x0_t = x0 if x0 is not None else self.x0_vec
-        XN = torch.empty(self.K_local, s.d, dtype=torch.float32, device=self.dev) if want_XN else None
-        nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0_t), s.d if x0 is not None else 0,
+        XN = torch.empty(self.K_local, self.d_pad, dtype=torch.float32, device=self.dev) if want_XN else None
+        flat_k = self.pad.scatter_params(self.flat, self.flat_k)
+        nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(x0_t), self.d_pad if x0 is not None else 0,
                                           nat.ptr(self.y0_param) if self.learn_y0 else None, nat.ptr(xi),
                                           int(s.seed), l, None, nat.ptr(self.D), nat.ptr(XN), None,
                                           nat.ptr(self.fwd_partial), self._stream()), 'psp_hjb_rollout_fwd')
-        return self.D, XN
+        return self.D, (XN[:, :s.d] if XN is not None else None)

@@ -16,8 +16,10 @@ import torch
 
 try:
     from . import native as nat
+    from . import native_shapes as shapes
 except ImportError:
     import native as nat
+    import native_shapes as shapes
 
 
 def _time_feature_table(model, N, delta_t):
@@ -70,33 +72,39 @@ def _is_native(problem, model, K, delta_t):
         keep.append(t)
         return t
 
+    H = model.z_n.native_shape()[1]
     cfg = nat.HjbConfig()
-    cfg.d, cfg.H, cfg.K_local, cfg.N = model.d, model.z_n.native_shape()[1], K, N
+    cfg.K_local, cfg.N = K, N
     cfg.K_global, cfg.k_offset = K, 0
     cfg.dt = float(torch.tensor(delta_t, dtype=torch.float32).item())
     cfg.sqrt_dt = float(torch.tensor(np.sqrt(delta_t), dtype=torch.float32).item())
     cfg.drift_kind = spec['drift'][0]
-    cfg.drift = nat.ptr(dev_f32(spec['drift'][1])) if spec['drift'][1] is not None else None
     cfg.sigma_kind = spec['sigma'][0]
-    cfg.sigma = nat.ptr(dev_f32(spec['sigma'][1])) if spec['sigma'][1] is not None else None
     cfg.sigma_scale = float(spec['sigma'][2])
     cfg.runcost_kind = spec['runcost'][0]
-    cfg.runcost = nat.ptr(dev_f32(spec['runcost'][1])) if spec['runcost'][1] is not None else None
     cfg.term_kind = spec['term'][0]
-    cfg.term = nat.ptr(dev_f32(spec['term'][1]))
     cfg.adaptive, cfg.loss_kind, cfg.store_path = 1, nat.LOSS_LOG_VARIANCE, 0
     philox = getattr(model, 'noise', 'reference') == 'philox'
     cfg.noise_mode = nat.NOISE_PHILOX if philox else nat.NOISE_SUPPLIED
-    sizes = nat.query(cfg)
+    chosen, why = shapes.choose(cfg, model.d, H)       # exact instance or the cheapest larger one (zero padding)
+    if chosen is None:
+        raise NotImplementedError('native IS evaluation unavailable: ' + why)
+    d_pad, H_pad, _, sizes = chosen
+    pad = shapes.ParamPad(model.d, H, d_pad, H_pad, dev)
+    cfg.drift = nat.ptr(dev_f32(pad.drift_or_sigma(spec['drift'][1]))) if spec['drift'][1] is not None else None
+    cfg.sigma = nat.ptr(dev_f32(pad.drift_or_sigma(spec['sigma'][1]))) if spec['sigma'][1] is not None else None
+    cfg.runcost = nat.ptr(dev_f32(pad.vec(spec['runcost'][1]))) if spec['runcost'][1] is not None else None
+    cfg.term = nat.ptr(dev_f32(pad.vec(spec['term'][1])))
     flat = torch.cat([p.detach().reshape(-1) for p in model.z_n.flat_layout()]).to(dev).contiguous()
+    flat = pad.scatter_params(flat, pad.new_padded_params() if not pad.identity else None)
     xi = None
     if not philox:                                   # the reference's draws: N x randn(K, d) (utilities.py:310)
         xi_cpu = torch.zeros(N + 1, K, model.d)
         for n in range(N):
             xi_cpu[n + 1] = torch.randn(K, model.d)
-        xi = xi_cpu.to(dev)
+        xi = pad.last_dim(xi_cpu.to(dev))
     tfeat = _time_feature_table(model, N, delta_t).to(dev)
-    x0 = dev_f32(torch.as_tensor(problem.X_0, dtype=torch.float32))
+    x0 = dev_f32(pad.vec(torch.as_tensor(problem.X_0, dtype=torch.float32).to(dev)))
     D = torch.empty(K, dtype=torch.float32, device=dev)
     Fint = torch.empty(K, dtype=torch.float32, device=dev)
     part = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)

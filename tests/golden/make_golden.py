@@ -201,6 +201,26 @@ CASES = [
          problem=dict(kind="LLGC", kwargs=dict(d=500, off_diag=0.1 / 500 ** 0.5, T=0.1, seed=42)),
          solver=dict(HJB, L=3, lr=0.001, seed=42, delta_t=0.01, K=72, u_l2_error_flag=False),
          net=dict(kind="tanh_mlp", widths=[64, 64], seed=123), probe_times=[0.0]),
+    # shapes without an exact kernel instance: run on the next instance up after zero padding (native_shapes.py)
+    dict(name="llgc_d7_default_logvar", family="solver",                       # (7, 30) -> (16, 32)
+         problem=dict(kind="LLGC", kwargs=dict(d=7, off_diag=0.1, T=0.3, seed=42)),
+         solver=dict(HJB, L=4, lr=0.002, seed=42, delta_t=0.01, K=100, u_l2_error_flag=False)),
+    dict(name="lqgc_d33_h50_logvar", family="solver",                          # (33, 50) -> (48, 64)
+         problem=dict(kind="LQGC", kwargs=dict(d=33, off_diag=0.05, T=0.5, seed=42, delta_t=0.05)),
+         solver=dict(HJB, L=3, lr=0.002, seed=42, delta_t=0.05, K=130, u_l2_error_flag=False),
+         net=dict(kind="tanh_mlp", widths=[50, 50], seed=123), probe_times=[0.0, 0.25]),
+    dict(name="dw_d70_h64_logvar", family="solver",                            # (70, 64) -> (80, 64)
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=70, d_1=35, d_2=35, T=0.2, eta=0.02, kappa=1.0)),  # small eta: keeps mean(D)^2 / var(D) moderate so the reference's fp32 loss is itself accurate to 1e-5
+         solver=dict(HJB, L=3, lr=0.002, seed=42, delta_t=0.01, K=96, u_l2_error_flag=False),
+         net=dict(kind="tanh_mlp", widths=[64, 64], seed=123)),
+    dict(name="llgc_d105_h64_logvar", family="solver",                         # dense (112, 64) exceeds the LDS -> wide (128, 64)
+         problem=dict(kind="LLGC", kwargs=dict(d=105, off_diag=0.01, T=0.2, seed=42)),
+         solver=dict(HJB, L=3, lr=0.001, seed=42, delta_t=0.01, K=80, u_l2_error_flag=False),
+         net=dict(kind="tanh_mlp", widths=[64, 64], seed=123)),
+    dict(name="llgc_d300_h40_logvar", family="solver",                         # (300, 40) -> wide (320, 64)
+         problem=dict(kind="LLGC", kwargs=dict(d=300, off_diag=0.1 / 300 ** 0.5, T=0.1, seed=42)),
+         solver=dict(HJB, L=3, lr=0.001, seed=42, delta_t=0.01, K=48, u_l2_error_flag=False),
+         net=dict(kind="tanh_mlp", widths=[40, 40], seed=123), probe_times=[0.0]),
     # DenseNet swapped in as the control net (notebook extension point)
     dict(name="llgc_d100_densenet64_logvar", family="solver",
          problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=0.5, seed=42)),

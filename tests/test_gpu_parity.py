@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 nat = psp.native
 
 NATIVE_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_logvar", "llgc_d200_h64_logvar",
-                "llgc_d500_h64_logvar", "dw_d10_logvar",
+                "llgc_d500_h64_logvar", "llgc_d7_default_logvar", "lqgc_d33_h50_logvar", "dw_d70_h64_logvar", "llgc_d105_h64_logvar",
+                "llgc_d300_h40_logvar", "dw_d10_logvar",
                 "llgc_d20_diag_logvar", "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive",
                 "lqgc_d2_variance", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
 
@@ -54,7 +55,11 @@ def test_first_iteration_D_and_gradient_match_oracle(name):
     g_ref = oracle_flat_grads(tr)
     assert g.shape == g_ref.shape
     assert float((g - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
-    assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=2e-5)
+    # the reference forms mean(D^2) - mean(D)^2 in fp32: its own rounding error is ~eps * mean(D^2) / var (the kernel
+    # sums in fp64), so the first-iteration bound follows the conditioning, capped by the contract's 1e-4
+    cond = float((tr["D"].double() ** 2).mean()) / max(abs(ref["loss_log"][0]), 1e-30)
+    tol = min(1e-4, max(2e-5, 4 * 6e-8 * cond))
+    assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=tol), (model.loss_log[0], ref["loss_log"][0], cond)
 
 
 @pytest.mark.parametrize("name", NATIVE_CASES)
