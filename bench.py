@@ -34,6 +34,9 @@ WORKLOADS = {
     "hjb_llgc_d100_K65536_N100_h64": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.01),
     # BASELINE.json configs[1]
     "hjb_llgc_d100_K1024_N50_h64": dict(d=100, H=64, K=1024, T=0.5, dt=0.01, off_diag=0.01),
+    "hjb_llgc_d100_K4096_N50_h64": dict(d=100, H=64, K=4096, T=0.5, dt=0.01, off_diag=0.01),
+    "hjb_llgc_d100_K8192_N50_h64": dict(d=100, H=64, K=8192, T=0.5, dt=0.01, off_diag=0.01),
+    "hjb_llgc_d100_K16384_N50_h64": dict(d=100, H=64, K=16384, T=0.5, dt=0.01, off_diag=0.01),
     # structured variant A=-I, B=I (reported separately)
     "hjb_llgc_d100_K65536_N100_h64_diag": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.0),
     # BASELINE.json configs[3]: d=200, K=262144 over 8 GPUs = 32768 per GPU, N=100 (wide kernel family)

@@ -1,8 +1,17 @@
 // One (d, H) instantiation of the rollout kernels; compiled once per line of instances.def.
 #include "hjb_kernels.h"
+#include "hjbs_kernels.h"
 #ifndef PSP_D
 #error "compile with -DPSP_D=<d> -DPSP_H=<H>"
 #endif
 #define PSP_CAT_(a, b) a##b
 #define PSP_DEFINE_(D_, H_) PSP_DEFINE_INSTANCE(D_, H_)
+#undef PSP_DEFINE_INSTANCE
+#define PSP_DEFINE_INSTANCE(D_, H_)                                                       \
+    extern "C" psp::HjbInstance psp_instance_##D_##_##H_() {                                \
+        psp::HjbInstance r = psp::HjbLaunch<D_, H_>::instance();                           \
+        r.split_lds_bytes = &psp::HjbsLaunch<D_, H_>::lds_bytes;                           \
+        r.launch_fwd_split = &psp::HjbsLaunch<D_, H_>::fwd;                                \
+        return r;                                                                           \
+    }
 PSP_DEFINE_(PSP_D, PSP_H)

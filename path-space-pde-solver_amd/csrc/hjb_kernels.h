@@ -1354,6 +1354,8 @@ struct HjbInstance {
     hipError_t (*launch_bwd2)(const HjbArgs&, int grid, hipStream_t);   // role-specialised variant, 512 threads
     int wide;                        // 1: hjbw_kernels.h family (tables in global memory, 256-thread workgroups)
     int fwd_table_floats, bwd_table_floats;
+    int (*split_lds_bytes)();        // hjbs_kernels.h: feature-split forward for small K (null: not built for this instance)
+    hipError_t (*launch_fwd_split)(const HjbArgs&, int grid, hipStream_t);
 };
 
 template <int D, int H>

@@ -84,6 +84,7 @@ struct Plan {
     psp::HjbInstance inst;
     int ntile16, fwd_waves, fwd_grid, bwd_waves, bwd_grid;
     bool bwd_specialised;       // hjb_bwd2_kernel (producer / consumer waves) instead of hjb_bwd_kernel
+    bool fwd_split;             // hjbs_fwd_kernel (four waves per tile) instead of hjb_fwd_kernel
 };
 
 int n_cus() {
@@ -126,6 +127,12 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     if (p->inst.wide && fw > 4) fw = 4;   // wide family: one wave per SIMD
     p->fwd_waves = fw;
     p->fwd_grid = (p->ntile16 + fw - 1) / fw;
+    // few tiles: the feature-split forward (four waves per tile, weights in registers) cuts the per-step latency ~3x.
+    // It wins while one-wave-per-tile would leave SIMDs idle: up to 2 tiles per CU (PSP_FWD_VARIANT=1 / 2 force either)
+    static const char* fv = getenv("PSP_FWD_VARIANT");
+    p->fwd_split = !p->inst.wide && p->inst.launch_fwd_split && p->inst.split_lds_bytes() <= kMaxLds &&
+                   ((fv && fv[0] == '2') || (!(fv && fv[0] == '1') && p->ntile16 <= 2 * cus));
+    if (p->fwd_split) { p->fwd_waves = 4; p->fwd_grid = p->ntile16; }
     // backward: persistent over rounds of 4 sample blocks; 4-wave workgroups, two per CU
     // (<= 256 VGPRs and <= 80 KiB LDS each), fewer when there is little work
     const long long nblk = (long long)c->N * p->ntile16;
@@ -225,9 +232,16 @@ __global__ void reduce_partials_kernel(const double* __restrict__ part, int n, d
 __global__ void reduce_grad_kernel(const float* __restrict__ part, int nwg, int P, float* __restrict__ out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += part[(size_t)w * P + p];     // fixed order -> reproducible
-    out[p] = s;
+    // eight independent partial sums (eight loads in flight instead of a 256-deep dependent chain), combined in a
+    // fixed order -> still bitwise reproducible
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int w = 0;
+    for (; w + 8 <= nwg; w += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(w + u) * P + p];
+    }
+    for (int u = 0; w < nwg; ++w, ++u) s[u] += part[(size_t)w * P + p];
+    out[p] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // torch.optim.Adam single-tensor semantics (torch/optim/adam.py, _single_tensor_adam)
@@ -373,7 +387,8 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
     a.D = D_out; a.XN = XN_out; a.Yout = Y_out; a.fwd_partial = fwd_partial;
     a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    hipError_t e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    hipError_t e = p.fwd_split ? p.inst.launch_fwd_split(a, p.fwd_grid, (hipStream_t)stream)
+                               : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel launch");
     return 0;
 }
@@ -395,7 +410,8 @@ int psp_hjb_rollout_eval(const psp_hjb_config* cfg, const float* params, const f
     a.D = D_out; a.Fint = Fint_out; a.XN = XN_out; a.fwd_partial = fwd_partial;
     a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    hipError_t e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    hipError_t e = p.fwd_split ? p.inst.launch_fwd_split(a, p.fwd_grid, (hipStream_t)stream)
+                               : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel (eval) launch");
     return 0;
 }
@@ -432,7 +448,7 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
                                      : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");
     const int P = p.inst.n_params;
-    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream,
                        grad_partial, p.bwd_grid, P, grad_out);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
@@ -493,7 +509,7 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
     hipError_t e = p.inst.launch_bwd(a, p.bwd_grid, 256, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "gen_bwd_kernel launch");
     const int P = p.inst.n_params;
-    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream,
                        grad_partial, p.bwd_grid, P, grad_out);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
