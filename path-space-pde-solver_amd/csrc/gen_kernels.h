@@ -653,12 +653,349 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
     }
 }
 
+
+// =======================================================================================
+// Backward kernel, role-specialised variant (same scheme as hjb_bwd2_kernel).
+// One 8-wave workgroup per CU, rounds of 4 sample blocks, one barrier per round, double-buffered LDS exchange.
+//   producers (waves 0-3): the adjoint panels gz2, gz2', gz1, gz1' of their own block (two register-chained
+//       64-MFMA products + the element-wise adjoint algebra) -> exchange buffer of the NEXT round; the T-layout parts
+//       of dW3 (h2 rows) and db3 as running register sums;
+//   consumers (waves 4-7): wave c owns column block(s) c of dW1 / dW2 for ALL row blocks, so its B operands are just
+//       four exchange tiles per block; the row operands (X, U and d1, z1^ image tiles, feature-on-lane, straight from
+//       the path store) run through a 3-deep register ring, one row tile per slot group:
+//           x rows:  dW2x += x^T gz2 + (w U)^T gz2',   dW1 += x^T gz1 + (w U)^T gz1'     (16 MFMAs per tile)
+//           h rows:  dW2h += h1^T gz2 + h1'^T gz2',     h1 = (d1/2)^2, h1' = d1 w z1^    ( 8 MFMAs per tile)
+//       biases from the exchange tiles, the feature-on-lane parts of dW3 from the row tiles (rows split over the waves).
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
+    using G = GGeo<D, H>;
+    constexpr int DI = G::DI, DBI = G::DBI, HB = G::HB, KSH = G::KSH, EXT = G::EXT;
+    constexpr int WHc = (HB >= 4) ? 4 : (HB >= 2 ? 2 : 1), WDc = 4 / WHc;      // consumers: columns first
+    constexpr int NIB = cdiv(HB, WHc), NRX = cdiv(DBI, WDc), NRH = cdiv(HB, WDc), NROW = NRX + NRH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const bool producer = wave < 4;
+    const int sub = wave & 3;
+    const unsigned lofsU = (unsigned)image_lane_offset_F(lane);
+    const int qq = lane >> 4, col = lane & 15;
+    const float* __restrict__ P = a.params;
+
+    stage_aop(lds + G::gW2hr, HB, KSH, tid, nthr, [&](int row, int c2) {
+        return (row < H && c2 < H) ? P[G::oW2 + (DI + row) * H + c2] : 0.f; });
+    __syncthreads();
+    float* bufs = lds + G::gEx;                       // [2 buffers][4 blocks][EXT tiles][256]
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int Kpad = a.ntile16 * 16;
+    const long long nblk = (long long)(a.N + 1) * a.ntile16;
+    const long long nround = (nblk + 3) / 4;
+    const int R = (int)((nround - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
+
+    if (producer) {
+        auto w3_T = [&](int base, int m, int o0) {          // o0 = opaque zero: keeps the loads inside the round loop
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int f = 16 * m + 4 * r + q; v[r] = f < H ? P[base + o0 + (f < H ? f : 0)] : 0.f; }
+            return v;
+        };
+        f32x4 g3h2T[HB];                                // dW3 (h2 part) in T layout, reduced over lanes at the end
+        float g3b = 0.f;
+#pragma unroll
+        for (int m = 0; m < HB; ++m) g3h2T[m] = zero4;
+        for (int it = 0; it <= R; ++it) {
+            if (it < R) {
+                const long long round = blockIdx.x + (long long)it * gridDim.x;
+                const long long rb = round * 4;
+                float* my_ex = bufs + ((it & 1) * 4 + sub) * (EXT * 256);
+                // L2 touch (one dword per 128-B line) of the row images the consumers read next iteration
+                float touch[5];
+                {
+                    const long long xb0 = rb + sub;
+                    const float* xt = a.path + (size_t)(xb0 < nblk ? xb0 : nblk - 1) * (size_t)G::PB;
+                    constexpr int NA = G::pD2;                   // X, U, d1 images are contiguous: [0, pD2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const int o = lane * 32 + i * 2048; touch[i] = xt[o < NA ? o : 0]; }
+                    touch[4] = xt[G::pZ1 + ((lane * 32 < 4 * HB * 64) ? lane * 32 : 0)];
+                }
+                        // ---------------------------------------------------------- adjoints of the own block
+                {
+                    f32x4 gz1[HB], gz1t[HB];
+                    const long long blk0 = rb + sub;
+                    const bool bvalid = blk0 < nblk;
+                    const long long blk = bvalid ? blk0 : nblk - 1;
+                    const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
+                    const int k = t16 * 16 + j;
+                    const bool kvalid = bvalid && k < a.K_local;
+                    const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+                    const bool fin = (n == a.N);
+                    // wY / wV / ahat are zero-padded to 16*ntile16 entries: plain loads, no branch around them
+                    const float wy = a.wY[k], wv = a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
+                    const float wsv = (bvalid && !fin) ? wy : 0.f;                             // weight of the tangent part
+                    const float av = bvalid ? (fin ? wv : wy * ah) : 0.f;
+                    const int o0 = opaque_i(0);
+                    f32x4 gz2[HB], gz2t[HB];
+                    {
+                        f32x4 d2[HB], z2t[HB];
+        #pragma unroll
+                        for (int m = 0; m < HB; ++m)
+        #pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                d2[m][r] = pb[G::pD2 + (4 * m + r) * 64];
+                                z2t[m][r] = wsv * pb[G::pZ2 + (4 * m + r) * 64];
+                            }
+        #pragma unroll
+                        for (int m = 0; m < HB; ++m) {
+                            const f32x4 w3h2 = w3_T(G::oW3 + DI + H, m, o0);
+                            gz2t[m] = w3h2 * d2[m];
+                            gz2[m] = av * gz2t[m] + w3h2 * step2(d2[m]) * z2t[m];
+                            // dW3 (h2 part): a h2 + h2'   with h2 = (d2/2)^2, h2' = d2 z2'
+                            g3h2T[m] += av * (0.25f * d2[m] * d2[m]) + d2[m] * z2t[m];
+                        }
+                    }
+                    g3b += (q == 0) ? av : 0.f;
+        #pragma unroll
+                    for (int m = 0; m < HB; ++m) { gz1t[m] = w3_T(G::oW3 + DI, m, o0); gz1[m] = av * gz1t[m]; }
+                    gemm_T<HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
+                    gemm_T<HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
+                    {   // d1 / z1^ are L2-resident (touch-prefetched one round ahead): fetch them only now
+                        f32x4 d1[HB], z1t[HB];
+        #pragma unroll
+                        for (int m = 0; m < HB; ++m)
+        #pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                d1[m][r] = pb[G::pD1 + (4 * m + r) * 64];
+                                z1t[m][r] = wsv * pb[G::pZ1 + (4 * m + r) * 64];
+                            }
+        #pragma unroll
+                        for (int m = 0; m < HB; ++m) {
+                            gz1[m] = gz1[m] * d1[m] + gz1t[m] * step2(d1[m]) * z1t[m];
+                            gz1t[m] = gz1t[m] * d1[m];
+                        }
+                    }
+                    if (!kvalid) {
+        #pragma unroll
+                        for (int m = 0; m < HB; ++m) { gz2[m] = zero4; gz2t[m] = zero4; gz1[m] = zero4; gz1t[m] = zero4; }
+                    }
+        #pragma unroll
+                    for (int m = 0; m < HB; ++m) {
+                        tile_put(my_ex + m * 256, gz2[m], lane);
+                        tile_put(my_ex + (HB + m) * 256, gz2t[m], lane);
+                        tile_put(my_ex + (2 * HB + m) * 256, gz1[m], lane);
+                        tile_put(my_ex + (3 * HB + m) * 256, gz1t[m], lane);
+                    }
+                }
+
+                asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]), "v"(touch[4]));
+            }
+            __syncthreads();                              // swap the exchange buffers (pairs with the consumer loop)
+        }
+        // T-layout partial sums of dW3 (h2 rows) and db3: reduce over the 16 trajectory lanes, then over the 4 producers
+        float* red = bufs;                                // [4][HB*16 + 1]; the exchange area is free after the last barrier
+#pragma unroll
+        for (int m = 0; m < HB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = g3h2T[m][r];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                if (j == 0) red[sub * (HB * 16 + 1) + 16 * m + 4 * r + q] = v;
+            }
+        {
+            float v = g3b;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (lane == 0) red[sub * (HB * 16 + 1) + HB * 16] = v;
+        }
+        __syncthreads();                                  // pairs with the consumers' barrier before the dW3 write-out
+        return;
+    }
+    // ==================================================================================== consumers
+    const int wh = (WHc == 1) ? 0 : sub % WHc, wd = (WDc == 1) ? 0 : sub / WHc;
+    f32x4 acc2x[NRX][NIB], acc2h[NRH][NIB], acc1[NRX][NIB];
+    float bs2[NIB], bs1[NIB], g3r[NROW];
+#pragma unroll
+    for (int s = 0; s < NRX; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) { acc2x[s][t] = zero4; acc1[s][t] = zero4; }
+#pragma unroll
+    for (int s = 0; s < NRH; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) acc2h[s][t] = zero4;
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) { bs2[t] = 0.f; bs1[t] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) g3r[i] = 0.f;
+    int cbc[NIB];
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) cbc[t] = ((wh + WHc * t) < HB ? (wh + WHc * t) : HB - 1) * 256;
+    // row item i of a block: i < NRX -> x rows (images X, U), else h rows (images d1, z1^); image offsets of the pair
+    auto row_ofs0 = [&](int i) { return i < NRX ? G::pX + ((wd + WDc * i) < DBI ? (wd + WDc * i) : DBI - 1) * 256
+                                               : G::pD1 + ((wd + WDc * (i - NRX)) < HB ? (wd + WDc * (i - NRX)) : HB - 1) * 256; };
+    auto row_ofs1 = [&](int i) { return i < NRX ? G::pU + ((wd + WDc * i) < DBI ? (wd + WDc * i) : DBI - 1) * 256
+                                               : G::pZ1 + ((wd + WDc * (i - NRX)) < HB ? (wd + WDc * (i - NRX)) : HB - 1) * 256; };
+    const int nblk_i = (int)nblk;
+    auto blk_at = [&](long long c0) __attribute__((always_inline)) {
+        const int c = (c0 < (long long)nblk_i) ? (int)c0 : nblk_i - 1;
+        return __builtin_amdgcn_readfirstlane(c);
+    };
+    typedef const __attribute__((address_space(1))) float* gptr_t;
+    auto get_F = [&](int blk, int ofs) __attribute__((always_inline)) {
+        unsigned long long addr = (unsigned long long)a.path + 4ull * ((unsigned long long)blk * (unsigned)G::PB + (unsigned)ofs);
+        asm volatile("" : "+s"(addr));
+        return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((gptr_t)addr + lofsU);
+    };
+    f32x4 ra[3], rb_[3];                               // 3-deep ring of row-operand pairs
+    f32x4 w4n = zero4, a4n = zero4;                    // per-sample weights of the NEXT block (4 samples per lane)
+    auto load_weights = [&](long long c0) __attribute__((always_inline)) {
+        const bool sval = c0 < nblk;
+        const int cb = blk_at(c0);
+        const int n = cb / a.ntile16, t16 = cb % a.ntile16;
+        const bool fin = (n == a.N);
+        const int k4 = t16 * 16 + 4 * qq;
+        const f32x4 wy4 = *reinterpret_cast<const f32x4*>(a.wY + k4);
+        const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wV + k4);
+        const f32x4 ah4 = *reinterpret_cast<const f32x4*>(a.ahat + (size_t)n * Kpad + k4);
+        w4n = (sval && !fin) ? wy4 : zero4;
+        a4n = sval ? (fin ? wv4 : wy4 * ah4) : zero4;
+    };
+    // prologue: first two row items and the weights of this workgroup's first block
+    {
+        const int b0 = blk_at((long long)blockIdx.x * 4);
+        ra[0] = get_F(b0, row_ofs0(0)); rb_[0] = get_F(b0, row_ofs1(0));
+        if (NROW > 1) { ra[1] = get_F(b0, row_ofs0(1)); rb_[1] = get_F(b0, row_ofs1(1)); }
+        load_weights((long long)blockIdx.x * 4);
+    }
+    __syncthreads();                                      // pairs with producer iteration 0
+    for (int it = 1; it <= R; ++it) {
+        const long long rb = ((long long)blockIdx.x + (long long)(it - 1) * gridDim.x) * 4;
+        const float* exch = bufs + ((it - 1) & 1) * 4 * (EXT * 256);
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const float* ex = exch + sb * (EXT * 256);
+            const int cb = blk_at(rb + sb);
+            // next block (within the round, or the first block of this workgroup's next round)
+            const long long cn0 = (sb < 3) ? rb + sb + 1 : rb + 4LL * gridDim.x;
+            const int cnx = blk_at(cn0);
+            const f32x4 w4 = w4n, a4 = a4n;
+            f32x4 bz2[NIB], bz2t[NIB], bz1[NIB], bz1t[NIB];
+#pragma unroll
+            for (int t = 0; t < NIB; ++t) {
+                bz2[t] = tile_get(ex + cbc[t], lane);
+                bz2t[t] = tile_get(ex + HB * 256 + cbc[t], lane);
+                bz1[t] = tile_get(ex + 2 * HB * 256 + cbc[t], lane);
+                bz1t[t] = tile_get(ex + 3 * HB * 256 + cbc[t], lane);
+            }
+            load_weights(cn0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NIB; ++t) { bs2[t] += hsum4(bz2[t]); bs1[t] += hsum4(bz1[t]); }
+#pragma unroll
+            for (int i = 0; i < NROW; ++i) {
+                const int slot = (sb * NROW + i) % 3;
+                // request the row item two ahead (same block, or the next block's first items)
+                {
+                    const int i2 = i + 2;
+                    const int nslot = (sb * NROW + i2) % 3;
+                    if (i2 < NROW) { ra[nslot] = get_F(cb, row_ofs0(i2)); rb_[nslot] = get_F(cb, row_ofs1(i2)); }
+                    else { ra[nslot] = get_F(cnx, row_ofs0(i2 - NROW)); rb_[nslot] = get_F(cnx, row_ofs1(i2 - NROW)); }
+                }
+                f32x4 A0, A1;
+                if (i < NRX) { A0 = ra[slot]; A1 = w4 * rb_[slot]; }                         // x0, x0' = w U
+                else { const f32x4 d1 = ra[slot]; A0 = 0.25f * d1 * d1; A1 = d1 * (w4 * rb_[slot]); }   // h1, h1'
+                if (i % WHc == wh) g3r[i] += hsum4(a4 * A0 + A1);                             // dW3 rows, split over waves
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NIB; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (i < NRX) {
+                            acc2x[i][t] = mfma16(A0[r], bz2[t][r], acc2x[i][t]);
+                            acc1[i][t] = mfma16(A0[r], bz1[t][r], acc1[i][t]);
+                            acc2x[i][t] = mfma16(A1[r], bz2t[t][r], acc2x[i][t]);
+                            acc1[i][t] = mfma16(A1[r], bz1t[t][r], acc1[i][t]);
+                        } else {
+                            acc2h[i - NRX][t] = mfma16(A0[r], bz2[t][r], acc2h[i - NRX][t]);
+                            acc2h[i - NRX][t] = mfma16(A1[r], bz2t[t][r], acc2h[i - NRX][t]);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the ring's slot phase is static: re-home the two pairs prefetched for the next round to slots 0 and 1
+        if ((4 * NROW) % 3 != 0) {
+            const f32x4 t0a = ra[(4 * NROW) % 3], t0b = rb_[(4 * NROW) % 3];
+            const f32x4 t1a = ra[(4 * NROW + 1) % 3], t1b = rb_[(4 * NROW + 1) % 3];
+            ra[0] = t0a; rb_[0] = t0b; ra[1] = t1a; rb_[1] = t1b;
+        }
+        __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
+    }
+
+    // ---- write-out: tile (rbk, cbk): lane (col, qq), reg rr <-> dW[16 rbk + 4 qq + rr][16 cbk + col]   (weights are (in, out))
+#pragma unroll
+    for (int s = 0; s < NRX; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int rbk = wd + WDc * s, cbk = wh + WHc * t;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 16 * rbk + 4 * qq + rr, jo = 16 * cbk + col;
+                if (rbk < DBI && cbk < HB && i < DI && jo < H) {
+                    gp[G::oW2 + i * H + jo] = acc2x[s][t][rr];
+                    gp[G::oW1 + i * H + jo] = acc1[s][t][rr];
+                }
+            }
+        }
+#pragma unroll
+    for (int s = 0; s < NRH; ++s)
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int rbk = wd + WDc * s, cbk = wh + WHc * t;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 16 * rbk + 4 * qq + rr, jo = 16 * cbk + col;
+                if (rbk < HB && cbk < HB && i < H && jo < H) gp[G::oW2 + (DI + i) * H + jo] = acc2h[s][t][rr];
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < NIB; ++t) {
+        const float v2 = qsum(bs2[t]), v1 = qsum(bs1[t]);
+        const int f = 16 * (wh + WHc * t) + col;
+        if (wd == 0 && qq == 0 && (wh + WHc * t) < HB && f < H) { gp[G::ob2 + f] = v2; gp[G::ob1 + f] = v1; }
+    }
+    // dW3, x and h1 rows: lane = feature; row item i belongs to the wave with i % WHc == wh
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+        const float v = qsum(g3r[i]);
+        if (i % WHc == wh && qq == 0) {
+            if (i < NRX) {
+                const int f = 16 * (wd + WDc * i) + col;
+                if ((wd + WDc * i) < DBI && f < DI) gp[G::oW3 + f] = v;
+            } else {
+                const int f = 16 * (wd + WDc * (i - NRX)) + col;
+                if ((wd + WDc * (i - NRX)) < HB && f < H) gp[G::oW3 + DI + f] = v;
+            }
+        }
+    }
+    __syncthreads();                                      // pairs with the producers' barrier after their LDS write
+    {
+        const float* red = bufs;
+        for (int f = tid - 256; f < HB * 16 + 1; f += 256) {
+            const float v = (red[f] + red[(HB * 16 + 1) + f]) + (red[2 * (HB * 16 + 1) + f] + red[3 * (HB * 16 + 1) + f]);
+            if (f < H) gp[G::oW3 + DI + H + f] = v;
+            else if (f == HB * 16) gp[G::ob3] = v;
+        }
+    }
+}
+
 struct GenInstance {
     int d, H, n_params, path_floats_per_block;
     int (*fwd_lds_bytes)();
     int (*bwd_lds_bytes)();
     hipError_t (*launch_fwd)(const GenArgs&, int grid, int block, hipStream_t);
     hipError_t (*launch_bwd)(const GenArgs&, int grid, int block, hipStream_t);
+    int (*bwd2_lds_bytes)();
+    hipError_t (*launch_bwd2)(const GenArgs&, int grid, hipStream_t);   // role-specialised variant, 512 threads
 };
 
 template <int D, int H>
@@ -666,6 +1003,14 @@ struct GenLaunch {
     using G = GGeo<D, H>;
     static int fwd_lds() { return G::fwd_lds_floats() * 4; }
     static int bwd_lds() { return G::bwd_lds_floats() * 4; }
+    static int bwd2_lds() { return (G::gEx + 2 * 4 * G::EXT * 256) * 4; }
+    static hipError_t bwd2(const GenArgs& a, int grid, hipStream_t s) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_bwd2_kernel<D, H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bwd2_lds());
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gen_bwd2_kernel<D, H>), dim3(grid), dim3(512), bwd2_lds(), s, a);
+        return hipGetLastError();
+    }
     static hipError_t fwd(const GenArgs& a, int grid, int block, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_fwd_kernel<D, H>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds());
@@ -680,7 +1025,7 @@ struct GenLaunch {
         hipLaunchKernelGGL((gen_bwd_kernel<D, H>), dim3(grid), dim3(block), bwd_lds(), s, a);
         return hipGetLastError();
     }
-    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, &fwd_lds, &bwd_lds, &fwd, &bwd}; }
+    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, &fwd_lds, &bwd_lds, &fwd, &bwd, &bwd2_lds, &bwd2}; }
 };
 
 }  // namespace psp

@@ -174,6 +174,7 @@ int check_ptrs(const psp_hjb_config* c) {
 struct GenPlan {
     psp::GenInstance inst;
     int ntile16, fwd_waves, fwd_grid, bwd_grid;
+    bool bwd_specialised;       // gen_bwd2_kernel (producer / consumer waves) instead of gen_bwd_kernel
 };
 
 int n_cus();
@@ -199,8 +200,11 @@ int make_gen_plan(const psp_gen_config* c, GenPlan* p) {
     p->fwd_waves = fw;
     p->fwd_grid = (p->ntile16 + fw - 1) / fw;
     const long long nround = ((long long)(c->N + 1) * p->ntile16 + 3) / 4;
+    static const char* force = getenv("PSP_BWD_VARIANT");
+    p->bwd_specialised = p->inst.bwd2_lds_bytes() <= kMaxLds && !(force && force[0] == '1');
     long long g = nround;
-    if (g > 2LL * cus) g = 2LL * cus;
+    const long long gmax = p->bwd_specialised ? cus : 2LL * cus;
+    if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     p->bwd_grid = (int)g;
     return 0;
@@ -506,7 +510,8 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
     fill_gen_args(cfg, p, &a);
     a.params = params; a.path = const_cast<float*>(path); a.ahat = const_cast<float*>(ahat);
     a.wY = wY; a.wV = wV; a.grad_partial = grad_partial;
-    hipError_t e = p.inst.launch_bwd(a, p.bwd_grid, 256, (hipStream_t)stream);
+    hipError_t e = p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
+                                     : p.inst.launch_bwd(a, p.bwd_grid, 256, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "gen_bwd_kernel launch");
     const int P = p.inst.n_params;
     hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream,
