@@ -705,6 +705,22 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
         float g3b = 0.f;
 #pragma unroll
         for (int m = 0; m < HB; ++m) g3h2T[m] = zero4;
+        // the four images of the own block (d2, z2^, d1, z1^; T layout) are requested one iteration ahead
+        f32x4 pd2[HB], pz2[HB], pd1[HB], pz1[HB];
+        auto prefetch_block = [&](int it2) __attribute__((always_inline)) {
+            const long long b0 = ((long long)blockIdx.x + (long long)it2 * gridDim.x) * 4 + sub;
+            const float* pb = a.path + (size_t)(b0 < nblk ? b0 : nblk - 1) * (size_t)G::PB + lane;
+#pragma unroll
+            for (int m = 0; m < HB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pd2[m][r] = pb[G::pD2 + (4 * m + r) * 64];
+                    pz2[m][r] = pb[G::pZ2 + (4 * m + r) * 64];
+                    pd1[m][r] = pb[G::pD1 + (4 * m + r) * 64];
+                    pz1[m][r] = pb[G::pZ1 + (4 * m + r) * 64];
+                }
+        };
+        prefetch_block(0);
         for (int it = 0; it <= R; ++it) {
             if (it < R) {
                 const long long round = blockIdx.x + (long long)it * gridDim.x;
@@ -775,8 +791,9 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                             gz1t[m] = gz1t[m] * d1[m];
                         }
                     }
+                    prefetch_block(it + 1);               // next round's images: a whole iteration of lead
                     if (!kvalid) {
-        #pragma unroll
+#pragma unroll
                         for (int m = 0; m < HB; ++m) { gz2[m] = zero4; gz2t[m] = zero4; gz1[m] = zero4; gz1t[m] = zero4; }
                     }
         #pragma unroll
