@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
     constexpr int DI = G::DI, DBI = G::DBI, KSI = G::KSI, HB = G::HB, KSH = G::KSH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
     const int j = lane & 15, q = lane >> 4;
     const float* __restrict__ P = a.params;
 
@@ -190,7 +190,17 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             const f32x4* vw3h2 = vecs + (G::vw3h2 - G::fVec) / 4;
             const f32x4* vw3x = vecs + (G::vw3x - G::fVec) / 4;
             const f32x4* vdr = vecs + (G::vdr - G::fVec) / 4;
-            float* pblk = a.path + ((size_t)n * a.ntile16 + t16) * (size_t)G::PB + lane;
+            // path block of (n, tile): wave-uniform base forced into SGPRs, stores are "base + lane * 4 + immediate < 4 KiB"
+            // (distinct large offsets otherwise become hoisted / spilled 64-bit address registers, and a spill reload
+            // waits with vmcnt(0) behind the store in front of it)
+            typedef __attribute__((address_space(1))) float* gwptr_t;
+            auto pbase = [&](int slot, int ofs) __attribute__((always_inline)) {
+                unsigned long long addr = (unsigned long long)a.path +
+                    4ull * (((unsigned long long)slot * a.ntile16 + t16) * (unsigned)G::PB + (unsigned)ofs);
+                asm volatile("" : "+s"(addr));
+                return (gwptr_t)addr;
+            };
+            const unsigned ul = (unsigned)lane;
             // ---- V(X,t) and the activations (solver.py:1100)
             f32x4 r1[HB], r2[HB];
             const float Vnow = net_value(vecs, r1, r2);
@@ -254,10 +264,11 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 }
                 // keep the OLD X in the path store (the sample point), move afterwards
                 if (a.store_path) {
+                    gwptr_t px = pbase(n, G::pX + b * 256), pu = pbase(n, G::pU + b * 256);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        pblk[G::pX + (4 * b + r) * 64] = X[b][r];
-                        pblk[G::pU + (4 * b + r) * 64] = U[b][r];
+                        px[r * 64 + ul] = X[b][r];
+                        pu[r * 64 + ul] = U[b][r];
                     }
                 }
                 X[b] = Xn;
@@ -281,12 +292,15 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 for (int m = 0; m < HB; ++m) h1d[m] = (2.0f * r1[m]) * z1h[m];
                 gemm_T<HB, KSI, DBI>(z2h, lds + G::fW2xf, U, lane);
                 gemm_T<HB, KSH, HB>(z2h, lds + G::fW2hf, h1d, lane);
+                {
+                    gwptr_t p1 = pbase(n, G::pD1), p2 = pbase(n, G::pD2), p3 = pbase(n, G::pZ1), p4 = pbase(n, G::pZ2);
 #pragma unroll
-                for (int ks = 0; ks < 4 * HB; ++ks) {
-                    pblk[G::pD1 + ks * 64] = 2.0f * r1[ks >> 2][ks & 3];
-                    pblk[G::pD2 + ks * 64] = 2.0f * r2[ks >> 2][ks & 3];
-                    pblk[G::pZ1 + ks * 64] = z1h[ks >> 2][ks & 3];
-                    pblk[G::pZ2 + ks * 64] = z2h[ks >> 2][ks & 3];
+                    for (int ks = 0; ks < 4 * HB; ++ks) {
+                        p1[ks * 64 + ul] = 2.0f * r1[ks >> 2][ks & 3];
+                        p2[ks * 64 + ul] = 2.0f * r2[ks >> 2][ks & 3];
+                        p3[ks * 64 + ul] = z1h[ks >> 2][ks & 3];
+                        p4[ks * 64 + ul] = z2h[ks >> 2][ks & 3];
+                    }
                 }
                 // coefficient of grad_theta V at this sample: -h_y dt act, plus 1 for V(X_0,t_0) at n = 0
                 if (q == 0) a.ahat[(size_t)n * (a.ntile16 * 16) + k] = (n == 0 ? 1.f : 0.f) - hy * dt * actf;
