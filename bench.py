@@ -180,9 +180,16 @@ def main():
     dense = w["off_diag"] != 0.0
     fl = alg_flops_per_traj_step(w["d"], w["H"], dense)
     units_local = w["K"] * N_t                           # trajectory-timesteps per launch on one GPU
-    dom = "hjb_bwd_kernel" if bwd_ms >= fwd_ms else "hjb_fwd_kernel"
+    # kernel names as they appear in rocprof: family 1 = hjb_kernels.h (hjbs_kernels.h forward when there are at most two
+    # tiles per CU), family 2 = hjbw_kernels.h
+    ntile = (plan.K_local + 15) // 16
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    fwd_name = "hjbw_fwd_kernel" if plan.family == 2 else ("hjbs_fwd_kernel" if ntile <= 2 * cus else "hjb_fwd_kernel")
+    bwd_name = "hjbw_bwd_kernel" if plan.family == 2 else "hjb_bwd2_kernel"
+    bwd_dominant = bwd_ms >= fwd_ms
+    dom = bwd_name if bwd_dominant else fwd_name
     dom_ms = max(bwd_ms, fwd_ms)
-    dom_flops = (fl["bwd_kernel"] if dom == "hjb_bwd_kernel" else fl["fwd_kernel"]) * units_local
+    dom_flops = (fl["bwd_kernel"] if bwd_dominant else fl["fwd_kernel"]) * units_local
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12
     traffic = None                                   # HBM bytes per launch, from the committed PMC passes
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -190,7 +197,7 @@ def main():
         traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
     value = K_global * N_t * args.steps / elapsed
     out = {
-        "metric": "trajectory-timesteps/sec (K*N/s), d=100 HJB log-variance training iteration",
+        "metric": "trajectory-timesteps/sec (K*N/s), d=%d HJB log-variance training iteration" % w["d"],
         "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -207,7 +214,7 @@ def main():
     }
     if world == 1 and args.workload == "hjb_llgc_d100_K65536_N100_h64" and not args.no_secondary:
         # BASELINE.json configs[1] (d=100, K=1024, N=50) measured in the same process, for readers who take
-        # that as the quoted configuration: 64 16-trajectory tiles on 256 CUs, i.e. latency-bound
+        # that as the quoted configuration (64 16-trajectory tiles: runs on the feature-split forward kernel)
         out["also_configs1_K1024_N50"] = secondary(psp, dev, WORKLOADS["hjb_llgc_d100_K1024_N50_h64"])
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
