@@ -205,6 +205,10 @@ typedef struct psp_gen_sizes {
 } psp_gen_sizes;
 
 int psp_gen_supported(int32_t d, int32_t H);
+/* enumeration of the compiled GeneralSolver instances; zero padding works as for the HJB kernels (the time input stays
+ * the LAST row of W1 / the x-t block of W2, W3: the host index map moves it from row d to row d_pad) */
+int psp_gen_instance_count(void);
+int psp_gen_instance_get(int32_t i, int32_t* d, int32_t* H);
 int psp_gen_query(const psp_gen_config* cfg, psp_gen_sizes* out);
 
 /* Forward rollout (solver.py:1076-1160 and V(X_N,t_N) of :1163): x0 (K_local,d), t0 (K_local) initial

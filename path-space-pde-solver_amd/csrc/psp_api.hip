@@ -464,6 +464,15 @@ int psp_gen_supported(int32_t d, int32_t H) {
     return find_gen_instance(d, H, &inst) ? 1 : 0;
 }
 
+int psp_gen_instance_count(void) { return (int)(sizeof(kGenTable) / sizeof(kGenTable[0])); }
+
+int psp_gen_instance_get(int32_t i, int32_t* d, int32_t* H) {
+    const int n = (int)(sizeof(kGenTable) / sizeof(kGenTable[0]));
+    if (i < 0 || i >= n || !d || !H) return fail(-1, "instance index out of range");
+    *d = kGenTable[i].d; *H = kGenTable[i].H;
+    return 0;
+}
+
 int psp_gen_query(const psp_gen_config* cfg, psp_gen_sizes* out) {
     GenPlan p;
     int rc = make_gen_plan(cfg, &p);

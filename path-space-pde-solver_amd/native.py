@@ -78,6 +78,8 @@ SIGNATURES = {
     "psp_last_error": (C.c_char_p, []),
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_family": (C.c_int, [C.c_int32, C.c_int32]),
+    "psp_gen_instance_count": (C.c_int, []),
+    "psp_gen_instance_get": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "psp_hjb_instance_count": (C.c_int, []),
     "psp_hjb_instance_get": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "psp_hjb_query": (C.c_int, [C.POINTER(HjbConfig), C.POINTER(HjbSizes)]),
@@ -169,6 +171,24 @@ def instances():
         check(lib.psp_hjb_instance_get(i, C.byref(d), C.byref(H), C.byref(f)), 'psp_hjb_instance_get')
         out.append((d.value, H.value, f.value))
     return out
+
+
+def gen_instances():
+    """[(d, H)] of the compiled GeneralSolver kernel instances."""
+    lib = load()
+    out = []
+    for i in range(lib.psp_gen_instance_count()):
+        d, H = C.c_int32(), C.c_int32()
+        check(lib.psp_gen_instance_get(i, C.byref(d), C.byref(H)), 'psp_gen_instance_get')
+        out.append((d.value, H.value))
+    return out
+
+
+def gen_query_rc(cfg):
+    sizes = GenSizes()
+    lib = load()
+    rc = lib.psp_gen_query(C.byref(cfg), C.byref(sizes))
+    return rc, sizes, (lib.psp_last_error().decode() if rc else '')
 
 
 def query_rc(cfg):

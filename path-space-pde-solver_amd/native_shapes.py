@@ -126,3 +126,57 @@ class ParamPad:
         if t is None:
             return None
         return self.mat(t) if t.dim() == 2 else self.vec(t)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GeneralSolver (value net V = DenseNet(d+1 -> 1, arch [H, H]), weights stored (in, out), time is the LAST input)
+# ------------------------------------------------------------------------------------------------------------------
+def gen_candidates(d, H):
+    c = [(D, Hh) for (D, Hh) in nat.gen_instances() if D >= d and Hh >= H]
+    c.sort(key=lambda t: (0 if (t[0] == d and t[1] == H) else 1, 3 * ((t[0] + 1) * t[1] + (t[0] + 1 + t[1]) * t[1])))
+    return c
+
+
+def gen_choose(cfg, d, H):
+    last = 'no compiled GeneralSolver kernel instance covers d=%d, H=%d (csrc/gen_instances.def)' % (d, H)
+    for D, Hh in gen_candidates(d, H):
+        cfg.d, cfg.H = D, Hh
+        rc, sizes, msg = nat.gen_query_rc(cfg)
+        if rc == 0:
+            return (D, Hh, sizes), None
+        last = msg
+    return None, last
+
+
+class GenParamPad(ParamPad):
+    """Index map for the DenseNet flat vector [W1 (DI x H), b1, W2 ((DI+H) x H), b2, W3 (DI+2H), b3], DI = d + 1.
+    Input rows are [x (d), t]: padding moves the t row from index d to index d_pad and shifts the h1 / h2 row blocks."""
+
+    def __init__(self, d, H, dp, Hp, dev):
+        self.d, self.H, self.dp, self.Hp, self.dev = d, H, dp, Hp, dev
+        self.identity = (d == dp and H == Hp)
+        DI, DIp = d + 1, dp + 1
+        self.P = DI * H + H + (DI + H) * H + H + (DI + 2 * H) + 1
+        self.Pp = DIp * Hp + Hp + (DIp + Hp) * Hp + Hp + (DIp + 2 * Hp) + 1
+        if self.identity:
+            self.idx = None
+            return
+        ar = torch.arange
+        rows_in = torch.cat([ar(d), torch.tensor([dp])])                           # x rows, then t
+        rows2 = torch.cat([rows_in, DIp + ar(H)])                                    # ... then h1
+        rows3 = torch.cat([rows2, DIp + Hp + ar(H)])                                 # ... then h2
+        oW1, ob1 = 0, DIp * Hp
+        oW2 = ob1 + Hp
+        ob2 = oW2 + (DIp + Hp) * Hp
+        oW3 = ob2 + Hp
+        ob3 = oW3 + DIp + 2 * Hp
+        parts = [
+            (oW1 + rows_in[:, None] * Hp + ar(H)[None, :]).reshape(-1),
+            ob1 + ar(H),
+            (oW2 + rows2[:, None] * Hp + ar(H)[None, :]).reshape(-1),
+            ob2 + ar(H),
+            oW3 + rows3,
+            torch.tensor([ob3]),
+        ]
+        self.idx = torch.cat(parts).to(dev)
+        assert self.idx.numel() == self.P

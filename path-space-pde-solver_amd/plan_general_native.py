@@ -16,10 +16,12 @@ import torch
 
 try:
     from . import native as nat
+    from . import native_shapes as shapes
     from . import sharding
     from .function_space import DenseNet
 except ImportError:
     import native as nat
+    import native_shapes as shapes
     import sharding
     from function_space import DenseNet
 
@@ -43,8 +45,8 @@ def native_eligibility(solver):
         return 'problem has no general_native_spec() (coefficients outside the native catalogue)'
     if not nat.is_built():
         raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
-    if not nat.gen_supported(solver.d, dims[1]):
-        return 'no compiled kernel instance for d=%d, H=%d (see csrc/gen_instances.def)' % (solver.d, dims[1])
+    if not shapes.gen_candidates(solver.d, dims[1]):
+        return 'no compiled kernel instance covers d=%d, H=%d (see csrc/gen_instances.def)' % (solver.d, dims[1])
     return None
 
 
@@ -62,24 +64,33 @@ class GeneralNativePlan:
         spec = s.problem.general_native_spec()
         self._keep = []
         cfg = nat.GenConfig()
-        cfg.d, cfg.H, cfg.K_local, cfg.N = s.d, self.H, self.K_local, s.N
+        cfg.K_local, cfg.N = self.K_local, s.N
         cfg.k_offset = lo
         cfg.dt, cfg.sqrt_dt = float(s.delta_t.item()), float(s.sq_delta_t.item())
         cfg.T = float(torch.tensor(s.problem.T, dtype=torch.float32).item())
         cfg.sigma_scale = float(spec['sigma_scale'])
         cfg.drift_kind = spec['drift'][0]
-        if spec['drift'][1] is not None:
-            t = spec['drift'][1].detach().to(device=self.dev, dtype=torch.float32).contiguous()
-            self._keep.append(t)
-            cfg.drift = nat.ptr(t)
         cfg.h_kind = spec['h']
         cfg.adaptive = 1 if s.adaptive_forward_process else 0
         cfg.noise_mode = nat.NOISE_PHILOX if s.noise == 'philox' else nat.NOISE_SUPPLIED
         cfg.store_path = 1
+        # kernel instance: the exact (d, H) if compiled, else the cheapest larger one (zero padding, native_shapes.py)
+        if spec['drift'][1] is not None:              # psp_gen_query validates the pointer: any device tensor will do for
+            t_probe = spec['drift'][1].detach().to(device=self.dev, dtype=torch.float32).contiguous()   # the size query
+            cfg.drift = nat.ptr(t_probe)
+        chosen, why = shapes.gen_choose(cfg, s.d, self.H)
+        if chosen is None:
+            raise NotImplementedError('native plan unavailable: ' + why)
+        self.d_pad, self.H_pad, sz = chosen
+        self.pad = shapes.GenParamPad(s.d, self.H, self.d_pad, self.H_pad, self.dev)
+        if spec['drift'][1] is not None:
+            t = self.pad.vec(spec['drift'][1].detach().to(device=self.dev, dtype=torch.float32)).contiguous()
+            self._keep.append(t)
+            cfg.drift = nat.ptr(t)
         self.cfg = cfg
-        sz = nat.gen_query(cfg)
-        assert sz.n_params == self.P, (sz.n_params, self.P)
+        assert sz.n_params == self.pad.Pp, (sz.n_params, self.pad.Pp)
         self.sizes = sz
+        self.flat_k = self.flat if self.pad.identity else self.pad.new_padded_params()
         dev, f32 = self.dev, torch.float32
         self.path = torch.empty(sz.path_bytes // 4, dtype=f32, device=dev)
         self.ahat = torch.zeros(sz.ahat_bytes // 4, dtype=f32, device=dev)
@@ -87,9 +98,11 @@ class GeneralNativePlan:
         self.VN = torch.empty(self.K_local, dtype=f32, device=dev)
         self.YN = torch.empty(self.K_local, dtype=f32, device=dev)
         self.tN = torch.empty(self.K_local, dtype=f32, device=dev)
-        self.XN = torch.empty(self.K_local, s.d, dtype=f32, device=dev)
+        self.XN_k = torch.empty(self.K_local, self.d_pad, dtype=f32, device=dev)
+        self.XN = self.XN_k[:, :s.d]
         self.kcount = torch.zeros(1, dtype=torch.int64, device=dev)
         self.grad = torch.empty(self.P, dtype=f32, device=dev)
+        self.grad_k = self.grad if self.pad.identity else torch.empty(self.pad.Pp, dtype=f32, device=dev)
         self.m = torch.zeros(self.P, dtype=f32, device=dev)
         self.v = torch.zeros(self.P, dtype=f32, device=dev)
         self.Kpad = 16 * ((self.K_local + 15) // 16)
@@ -166,19 +179,20 @@ class GeneralNativePlan:
             xi_cpu = torch.zeros(s.N, hi - lo, d)
             for n in range(n_exec):
                 xi_cpu[n] = torch.randn(K, d)[lo:hi]
-            xi = xi_cpu.to(dev)
+            xi = self.pad.last_dim(xi_cpu.to(dev))
             t0 = t0_cpu[lo:hi, 0].contiguous().to(dev)
         else:
             t0 = (torch.rand(K, generator=self._gen, device=dev) * T)[lo:hi].contiguous()
-        x0 = X[lo:hi].contiguous()
+        x0 = self.pad.last_dim(X[lo:hi].contiguous())
+        flat_k = self.pad.scatter_params(self.flat, self.flat_k)
         self.kcount.zero_()
         ev = None
         if self.events is not None:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
-        nat.check(lib.psp_gen_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0), nat.ptr(t0), nat.ptr(xi),
+        nat.check(lib.psp_gen_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(x0), nat.ptr(t0), nat.ptr(xi),
                                           int(s.seed) & 0xFFFFFFFFFFFFFFFF, l, nat.ptr(self.path),
-                                          nat.ptr(self.ahat), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN),
+                                          nat.ptr(self.ahat), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN_k),
                                           nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_gen_rollout_fwd')
         if ev is not None:
             ev[1].record()
@@ -203,9 +217,10 @@ class GeneralNativePlan:
         self.wV[:self.K_local].copy_(wV)
         if ev is not None:
             ev[2].record()
-        nat.check(lib.psp_gen_rollout_bwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(self.path), nat.ptr(self.ahat),
-                                          nat.ptr(self.wY), nat.ptr(self.wV), nat.ptr(self.grad_partial), nat.ptr(self.grad),
+        nat.check(lib.psp_gen_rollout_bwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.path), nat.ptr(self.ahat),
+                                          nat.ptr(self.wY), nat.ptr(self.wV), nat.ptr(self.grad_partial), nat.ptr(self.grad_k),
                                           st), 'psp_gen_rollout_bwd')
+        self.pad.gather_grad(self.grad_k, self.grad)
         if ev is not None:
             ev[3].record()
             self.events.append(ev)

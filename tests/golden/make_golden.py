@@ -300,6 +300,23 @@ CASES = [
          solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=80, K_boundary=16,
                      alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
          net=dict(arch=[24, 24], seed=42)),
+    # shapes without an exact GeneralSolver instance (zero padding, native_shapes.GenParamPad)
+    dict(name="dwgen_d7_h20_diffusion", family="general",                        # (7, 20) -> (10, 24)
+         problem=dict(kind="DoubleWell_multidim_for_general_solver",
+                      kwargs=dict(d=7, d_1=3, d_2=4, T=0.3, eta=1, kappa=1, modus="HJB")),
+         solver=dict(seed=42, delta_t=0.01, N=12, lr=0.001, L=3, K=90, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
+         net=dict(arch=[20, 20], seed=42)),
+    dict(name="allencahn_d20_default_diffusion", family="general",               # default arch [30, 30]: (20, 30) -> (32, 32)
+         problem=dict(kind="AllenCahn", kwargs=dict(d=20, T=0.3, seed=42, modus="pt")),
+         solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=80, K_boundary=16,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion")),
+    dict(name="dwgen_d40_h50_bsde", family="general",                            # (40, 50) -> (48, 64)
+         problem=dict(kind="DoubleWell_multidim_for_general_solver",
+                      kwargs=dict(d=40, d_1=20, d_2=20, T=0.1, eta=0.1, kappa=1, modus="HJB")),
+         solver=dict(seed=42, delta_t=0.01, N=12, lr=0.001, L=3, K=64, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="BSDE"),
+         net=dict(arch=[50, 50], seed=42)),
     dict(name="heat_d6_diffusion", family="general",
          problem=dict(kind="HeatEquation", kwargs=dict(d=6, T=0.5, seed=42)),
          solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=72, K_boundary=16,

@@ -8,7 +8,8 @@ import torch
 from conftest import load_golden
 from util_cases import psp
 
-CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion"]
+CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
+         "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde"]
 
 
 def build(case, device="cpu", backend="auto"):

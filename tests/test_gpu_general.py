@@ -10,7 +10,8 @@ from conftest import load_golden
 from util_cases import orc, psp
 
 pytestmark = pytest.mark.gpu
-CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion"]
+CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
+         "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde"]
 
 
 def dev():

@@ -60,3 +60,40 @@ def test_padded_network_equals_real_network():
     assert torch.equal(g, g_pad[pad.idx])
     ident = shapes.ParamPad(100, 64, 100, 64, torch.device('cpu'))
     assert ident.identity and ident.scatter_params(flat, None) is flat
+
+
+def densenet(flat, d, H, x_t):
+    """DenseNet(d+1 -> 1, arch [H, H]), relu^2, weights (in, out), input [x, t] (time last)."""
+    DI = d + 1
+    o = 0
+    W1 = flat[o:o + DI * H].view(DI, H); o += DI * H
+    b1 = flat[o:o + H]; o += H
+    W2 = flat[o:o + (DI + H) * H].view(DI + H, H); o += (DI + H) * H
+    b2 = flat[o:o + H]; o += H
+    W3 = flat[o:o + DI + 2 * H].view(DI + 2 * H, 1); o += DI + 2 * H
+    b3 = flat[o:o + 1]; o += 1
+    assert o == flat.numel()
+    act = lambda z: torch.relu(z) ** 2
+    h1 = act(x_t @ W1 + b1)
+    c1 = torch.cat([x_t, h1], 1)
+    h2 = act(c1 @ W2 + b2)
+    return torch.cat([c1, h2], 1) @ W3 + b3
+
+
+def test_padded_value_net_equals_real_value_net():
+    torch.manual_seed(1)
+    d, H, dp, Hp = 7, 20, 10, 24
+    pad = shapes.GenParamPad(d, H, dp, Hp, torch.device('cpu'))
+    flat = 0.3 * torch.randn(pad.P)
+    flat_pad = pad.scatter_params(flat, pad.new_padded_params())
+    assert flat_pad.numel() == pad.Pp and int((flat_pad != 0).sum()) == pad.P
+    x, t = torch.randn(6, d), torch.rand(6, 1)
+    v = densenet(flat, d, H, torch.cat([x, t], 1))
+    xp = pad.last_dim(x)
+    xp[:, d:] = torch.randn(6, dp - d)                  # noise in the padded state components must not matter
+    vp = densenet(flat_pad, dp, Hp, torch.cat([xp, t], 1))
+    assert torch.allclose(vp, v, atol=1e-5)
+    cands = shapes.gen_candidates(20, 30)
+    assert cands and cands[0] == (32, 32)
+    assert shapes.gen_candidates(100, 64)[0] == (100, 64)
+    assert shapes.gen_candidates(101, 64) == []

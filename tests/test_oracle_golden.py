@@ -18,7 +18,8 @@ SOLVER_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_l
                 "llgc_d100_densenet64_logvar", "dw_d10_logvar", "llgc_d20_diag_logvar",
                 "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive", "lqgc_d2_outer",
                 "lqgc_d2_variance", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
-GENERAL_CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion"]
+GENERAL_CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
+                 "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde"]
 
 
 def _same_build(rec):
