@@ -139,12 +139,14 @@ __device__ __forceinline__ void gemm_regs(f32x4 (&acc)[MB], const float* __restr
 }
 
 // acc[MB] += T . img,  T: k-step-major global table with KP k-steps (KP % 4 == 0), img: this wave's LDS image of the
-// input panel (one dword per lane and k-step).  Rolled over k with a two-stage register pipeline.
+// input panel (one dword per lane and k-step).  Rolled over k with a static ring of NST register stages of U k-steps
+// (KP % (NST * U) == 0): the operands of a stage are requested NST - 1 stages before its MFMAs issue.
 template <int MB, int KP>
 __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restrict__ tbl, const float* img, int lane) {
-    constexpr int U = (MB >= 16) ? 1 : 2;             // k-steps per stage (2 U divides KP)
-    static_assert(KP % (2 * U) == 0, "k padding");
-    float ab[2][U * MB], bb[2][U];
+    constexpr int NST = 2;                            // (a 4-stage ring of single k-steps was measured 10 % slower at d = 200)
+    constexpr int U = (MB >= 16) ? 1 : 2;
+    static_assert(KP % (NST * U) == 0, "k padding");
+    float ab[NST][U * MB], bb[NST][U];
     const unsigned ul = (unsigned)lane;
     auto load = [&](int st, int ks0) __attribute__((always_inline)) {
 #pragma unroll
@@ -164,18 +166,19 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma16(ab[st][u * MB + mb], bb[st][u], acc[mb]);
     };
-    load(0, 0);
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) load(st, st * U);
 #pragma unroll 1
-    for (int ks = 0; ks < KP; ks += 2 * U) {
-        load(1, ks + U);
-        __builtin_amdgcn_sched_barrier(0);
-        fma_stage(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // the last iteration re-reads the final k-step (valid memory, result unused) instead of branching
-        load(0, (ks + 2 * U < KP) ? ks + 2 * U : KP - U);
-        __builtin_amdgcn_sched_barrier(0);
-        fma_stage(1);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int ks = 0; ks < KP; ks += NST * U) {
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            // request the stage NST - 1 ahead (past the end: re-read the last k-steps, valid memory, result unused)
+            const int kn = ks + (st + NST - 1) * U;
+            load((st + NST - 1) % NST, kn < KP ? kn : KP - U);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_stage(st);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
