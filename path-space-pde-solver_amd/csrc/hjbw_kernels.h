@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void hjbw_bwd_kernel(const HjbArgs a) {
             // rolled k-loop, 4 k-steps per iteration, operands of the next iteration in flight
             const float* xip = pb + G::pXi;
             const unsigned ul = (unsigned)lane;
-            float xb[2][4], ab[2][4 * HB];
+            float xb[3][4], ab[3][4 * HB];
             auto load = [&](int st, int ks0) __attribute__((always_inline)) {
                 gptr_t tp = sgpr_ptr(T + (size_t)ks0 * (HB * 64));
 #pragma unroll
@@ -536,19 +536,17 @@ __global__ __launch_bounds__(256) void hjbw_bwd_kernel(const HjbArgs a) {
                     for (int m = 0; m < HB; ++m) dz2[m] = mfma16(ab[st][u * HB + m], g, dz2[m]);
                 }
             };
+            // fully unrolled, three register stages of 4 k-steps: the operands of stage g + 2 are requested before the
+            // MFMAs of stage g issue (two stages = 32 MFMAs = ~1 k cycles of lead for the L2-resident table / xi image)
+            constexpr int NG = KP / 4;
             load(0, 0);
-#pragma unroll 1
-            for (int ks = 0; ks < KP; ks += 8) {
-                load(1, (ks + 4 < KP) ? ks + 4 : KP - 4);
+            if (NG > 1) load(1, 4);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 2 < NG) load((g + 2) % 3, 4 * (g + 2));
                 __builtin_amdgcn_sched_barrier(0);
-                fma_stage(0);
+                fma_stage(g % 3);
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks + 4 < KP) {
-                    load(0, (ks + 8 < KP) ? ks + 8 : KP - 4);
-                    __builtin_amdgcn_sched_barrier(0);
-                    fma_stage(1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
             }
             float* ex = exch + wave * EXB + lane;
 #pragma unroll
@@ -596,9 +594,10 @@ __global__ __launch_bounds__(256) void hjbw_bwd_kernel(const HjbArgs a) {
             // stream over the state blocks: xi tile -> G tile -> dW3, X tile -> dW1 (tiles of block ob + 2 in flight)
             const float* xib = bp + G::pXi + lofsU;
             const float* xb = bp + G::pX + lofsU;
-            f32x4 xit[3], xt[3];
+            constexpr int RD = 6;                                     // ring depth: RD - 1 tiles (~1.3 k cycles) ahead
+            f32x4 xit[RD], xt[RD];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < RD - 1; ++i) {
                 if (i < DB) {
                     xit[i] = *reinterpret_cast<const f32x4*>(xib + i * 256);
                     xt[i] = *reinterpret_cast<const f32x4*>(xb + i * 256);
@@ -606,16 +605,16 @@ __global__ __launch_bounds__(256) void hjbw_bwd_kernel(const HjbArgs a) {
             }
 #pragma unroll
             for (int ob = 0; ob < DB; ++ob) {
-                if (ob + 2 < DB) {
-                    xit[(ob + 2) % 3] = *reinterpret_cast<const f32x4*>(xib + (ob + 2) * 256);
-                    xt[(ob + 2) % 3] = *reinterpret_cast<const f32x4*>(xb + (ob + 2) * 256);
+                if (ob + RD - 1 < DB) {
+                    xit[(ob + RD - 1) % RD] = *reinterpret_cast<const f32x4*>(xib + (ob + RD - 1) * 256);
+                    xt[(ob + RD - 1) % RD] = *reinterpret_cast<const f32x4*>(xb + (ob + RD - 1) * 256);
                 }
-                const f32x4 g = xit[ob % 3] * w4;
+                const f32x4 g = xit[ob % RD] * w4;
                 if (ob / OBW == wave) bs3[ob % OBW] += hsum4(g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc3[ob] = mfma16(g[r], h2t[r], acc3[ob]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc1[ob] = mfma16(a1[r], xt[ob % 3][r], acc1[ob]);
+                for (int r = 0; r < 4; ++r) acc1[ob] = mfma16(a1[r], xt[ob % RD][r], acc1[ob]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
