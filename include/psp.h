@@ -41,7 +41,9 @@ enum { PSP_TERM_LINEAR = 0, PSP_TERM_DIAG_QUAD = 1, PSP_TERM_SHIFTED_QUAD = 2 };
 /* loss: solver.py:167-168 (log-variance), :165-166 (moment) */
 /* PSP_LOSS_WEIGHTS: psp_hjb_rollout_bwd takes w_k = dLoss/dY_k itself in its D argument (losses whose
  * weights are not affine in D: variance :171-172, cross_entropy :183-186) */
-enum { PSP_LOSS_LOG_VARIANCE = 0, PSP_LOSS_MOMENT = 1, PSP_LOSS_WEIGHTS = 2 };
+/* PSP_LOSS_REL_ENTROPY (solver.py:179-180, 484-486): the forward kernel accumulates Y = -Zsum =
+ * -sum_n (|Z_n|^2 / 2 + f(X_{n+1})) dt, so D = Y - g(X_N) = -(Zsum + g) and the loss is -mean D = -sums[0] / K. */
+enum { PSP_LOSS_LOG_VARIANCE = 0, PSP_LOSS_MOMENT = 1, PSP_LOSS_WEIGHTS = 2, PSP_LOSS_REL_ENTROPY = 3 };
 /* Brownian increments: supplied = the reference's host-generated xi (solver.py:381), philox = on device */
 enum { PSP_NOISE_SUPPLIED = 0, PSP_NOISE_PHILOX = 1 };
 
@@ -62,7 +64,8 @@ typedef struct psp_hjb_config {
     int32_t adaptive;     /* 1: c = -Z (solver.py:456), 0: c = 0 (solver.py:451) */
     int32_t loss_kind;
     int32_t noise_mode;
-    int32_t store_path;   /* 1: keep X_n for the backward pass, 0: forward only  */
+    int32_t store_path;   /* 0: forward only; 1: keep X_n, h1, h2, xi for the backward pass;
+                           * 2 / 3: same with xi - sqrt(dt) Z / Z in the xi slot, for psp_hjb_adjoint_sweep */
     float sigma_scale;    /* PSP_SIGMA_SCALED_IDENTITY                            */
     int32_t reserved;
     const float* drift;   /* DENSE: A (d*d row-major); DIAG: a (d); DOUBLE_WELL: kappa (d) */
@@ -158,6 +161,21 @@ int psp_hjb_terminal_reduce(const psp_hjb_config* cfg, const double* fwd_partial
 int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const float* xi, uint64_t seed,
                         uint32_t iter, const float* path, const float* D, const double* sums,
                         float* grad_partial, float* grad_out, void* stream);
+
+/*
+ * Gradients THROUGH the state path: adaptive_forward_process=True with detach_forward=False, the reference's default
+ * flags (solver.py:451-469: c = -Z_n(X_n) is not detached, so loss.backward() of solver.py:221 also differentiates the
+ * Euler-Maruyama recursion :471-478).  Call sequence per iteration:
+ *     psp_hjb_rollout_fwd   with store_path = 2 (losses of Y_N - g(X_N)) or 3 (PSP_LOSS_REL_ENTROPY), XN_out given
+ *     [loss and per-trajectory weights  mu_k = dL/dY_N[k],  nu_k = dL/dZsum_N[k]  from D on the caller's side]
+ *     psp_hjb_adjoint_sweep  reverse-time adjoint recursion per trajectory (kernel: csrc/hjba_kernels.h); rewrites the
+ *                            xi slot of `path` with dL/dZ_n / sqrt(dt)
+ *     psp_hjb_rollout_bwd   with loss_kind = PSP_LOSS_WEIGHTS and D = 1 for every trajectory
+ *   XN : (K_local, d) terminal states from the forward call;  mu, nu : K_local floats each (nu may be NULL = 0).
+ * Narrow kernel family only (returns -2 for the large-d family).
+ */
+int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float* path, const float* XN,
+                          const float* mu, const float* nu, void* stream);
 
 /* torch.optim.Adam(lr, betas=(b1,b2), eps, weight_decay=0, amsgrad=False) on a flat buffer
  * (function_space.py:185, solver.py:198-200).  step is 1-based. */

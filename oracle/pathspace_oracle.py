@@ -282,6 +282,8 @@ def hjb_loss(kind, D, Y, gX, Z_sum=None, adaptive=True):
         if adaptive:
             return (Y * torch.exp(-gX + Y.detach())).mean()          # :185
         return (Y * torch.exp(-gX)).mean()                           # :186
+    if kind == "relative_entropy":
+        return (Z_sum + gX).mean()                                   # :179-180
     raise NotImplementedError(kind)
 
 
@@ -312,6 +314,7 @@ def hjb_train(problem: OracleProblem, cfg: HJBConfig, net=None, noise: Optional[
             out["Y_0_log"].append(Y[0].item())                       # :374
         xi = torch.randn(K, d, N + 1) if noise is None else noise[l]     # :381
         tr = dict(X=[X.clone()], Y=[]) if trace else None
+        Z_sum = torch.zeros(K)                                       # :376
         for n in range(N):
             Z = control_eval(z, X, n, dt32, N, cfg.time_approx)      # :449
             c = torch.zeros(d, K)                                    # :451
@@ -324,6 +327,8 @@ def hjb_train(problem: OracleProblem, cfg: HJBConfig, net=None, noise: Optional[
                  + torch.mm(sig, xi[:, :, n + 1].t()).t() * sq_dt32)     # :471-472
             Y = (Y + (-problem.h(dt32 * n, X, Y, Z) + torch.sum(Z * c.t(), 1)) * dt32
                  + torch.sum(Z * xi[:, :, n + 1], 1) * sq_dt32)      # :477-478 (h sees X_{n+1})
+            if "relative_entropy" in cfg.loss_method:                # :484-486 (f at the UPDATED state, time n dt)
+                Z_sum = Z_sum + (0.5 * torch.sum(Z ** 2, dim=1) + problem.f(X, n * dt32)) * dt32
             if trace:
                 tr["X"].append(X.detach().clone())
                 tr["Y"].append(Y.detach().clone())
@@ -331,10 +336,11 @@ def hjb_train(problem: OracleProblem, cfg: HJBConfig, net=None, noise: Optional[
             p_.optim.zero_grad()                                     # :194-196
         gX = problem.g(X)
         D = Y - gX
-        loss = hjb_loss(cfg.loss_method, D, Y, gX, adaptive=cfg.adaptive_forward_process) + torch.zeros(K).mean()   # :220, :434, :499
+        loss = hjb_loss(cfg.loss_method, D, Y, gX, Z_sum=Z_sum, adaptive=cfg.adaptive_forward_process) + torch.zeros(K).mean()   # :220, :434, :499
         loss.backward()                                              # :221
         if trace:
             tr["D"] = D.detach().clone()
+            tr["Zsum_g"] = (Z_sum + gX).detach().clone()
             tr["grads"] = [p.grad.detach().clone() for p in (z.parameters() if not isinstance(z, list) else z[0].parameters())]
             out["traces"].append(tr)
         for p_ in phis:

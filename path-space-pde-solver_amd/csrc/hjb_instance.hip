@@ -1,6 +1,7 @@
 // One (d, H) instantiation of the rollout kernels; compiled once per line of instances.def.
 #include "hjb_kernels.h"
 #include "hjbs_kernels.h"
+#include "hjba_kernels.h"
 #ifndef PSP_D
 #error "compile with -DPSP_D=<d> -DPSP_H=<H>"
 #endif
@@ -12,6 +13,7 @@
         psp::HjbInstance r = psp::HjbLaunch<D_, H_>::instance();                           \
         r.split_lds_bytes = &psp::HjbsLaunch<D_, H_>::lds_bytes;                           \
         r.launch_fwd_split = &psp::HjbsLaunch<D_, H_>::fwd;                                \
+        r.launch_adj = &psp::HjbaLaunch<D_, H_>::adj;                                      \
         return r;                                                                           \
     }
 PSP_DEFINE_(PSP_D, PSP_H)

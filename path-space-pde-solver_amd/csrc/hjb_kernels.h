@@ -42,6 +42,8 @@ struct HjbArgs {
     float* Yout;               // optional (K_local) Y_N
     unsigned long long* dbg;   // diagnostic builds (-DPSP_STAMPS): per-wave phase cycle sums
     float* tables;             // wide kernels: A-operand tables in global memory (carved from the caller's scratch)
+    const float* adj_mu;       // adjoint sweep (hjba_kernels.h): dL/dY_N per trajectory
+    const float* adj_nu;       //                                  dL/dZsum_N per trajectory (relative entropy), may be null
     long long k_offset;
     long long K_global;
     int x0_stride;
@@ -58,7 +60,7 @@ enum { DRIFT_ZERO = 0, DRIFT_DENSE = 1, DRIFT_DIAG = 2, DRIFT_DWELL = 3 };
 enum { SIGMA_IDENT = 0, SIGMA_DENSE = 1, SIGMA_SCALE = 2 };
 enum { RUN_ZERO = 0, RUN_DIAGQ = 1 };
 enum { TERM_LINEAR = 0, TERM_DIAGQ = 1, TERM_SHIFTQ = 2 };
-enum { LOSS_LOGVAR = 0, LOSS_MOMENT = 1, LOSS_WEIGHTS = 2 };
+enum { LOSS_LOGVAR = 0, LOSS_MOMENT = 1, LOSS_WEIGHTS = 2, LOSS_RELENT = 3 };
 enum { NOISE_SUPPLIED = 0, NOISE_PHILOX = 1 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -358,6 +360,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     const uint32_t kglob = (uint32_t)(a.k_offset + k);
     const float dt = a.dt, sqdt = a.sqdt;
 
+    const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
+    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : 0.f);
     double sD = 0.0, sD2 = 0.0;
     if (wave_valid) {
         // per-lane-q views of the staged vectors
@@ -446,9 +450,14 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
                 }
-                if (a.store_path) {                    // the backward pass reads xi back (any noise mode)
+                if (a.store_path) {
+                    // 1: xi (the backward pass reads it back, any noise mode); attached forward process (hjba_kernels.h):
+                    // 2: xi - sqrt(dt) Z, 3: Z  -- the adjoint sweep replaces it by dL/dZ_n / sqrt(dt)
+                    // (as an affine combination with wave-uniform coefficients: a nested vector select here was lowered to
+                    // a switch whose Z arm read a stale accumulator)
+                    const f32x4 wv = store_cxi * xi + store_cz * Z[b];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pblk[(G::pXi / 64 + 4 * b + r) * 64] = xi[r];
+                    for (int r = 0; r < 4; ++r) pblk[(G::pXi / 64 + 4 * b + r) * 64] = wv[r];
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -500,8 +509,14 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
                 fX = qsum(fX);
             }
             // Y += (-h + Z.c) dt + Z.xi sqrt(dt);  -h = 0.5|Z|^2 + f ; Z.c = -|Z|^2 (adaptive) or 0
-            const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
-            Y = Y + drift_y * dt + Pz * sqdt;
+            if (a.loss_kind == LOSS_RELENT) {
+                // relative entropy (solver.py:179-180, 484-486): Y carries -Zsum = -sum (|Z|^2 / 2 + f(X_{n+1})) dt,
+                // so D = Y - g = -(Zsum + g) and the loss is -mean D
+                Y = Y - (0.5f * S + fX) * dt;
+            } else {
+                const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
+                Y = Y + drift_y * dt + Pz * sqdt;
+            }
             Fsum = fmaf(fX, dt, Fsum);
             PSP_STAMP(fs6);
             PSP_ACC(0, fs1, fs0);   // path store of X + L1 GEMM
@@ -1356,6 +1371,7 @@ struct HjbInstance {
     int fwd_table_floats, bwd_table_floats;
     int (*split_lds_bytes)();        // hjbs_kernels.h: feature-split forward for small K (null: not built for this instance)
     hipError_t (*launch_fwd_split)(const HjbArgs&, int grid, hipStream_t);
+    hipError_t (*launch_adj)(const HjbArgs&, int grid, int block, hipStream_t);   // hjba_kernels.h adjoint sweep (null: not built)
 };
 
 template <int D, int H>

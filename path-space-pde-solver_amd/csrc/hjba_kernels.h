@@ -1,0 +1,197 @@
+// hjba_kernels.h -- reverse-time adjoint sweep for gradients THROUGH the state path.
+//
+// With adaptive_forward_process=True and detach_forward=False (the reference's default flags, solver.py:451-469) the
+// control c = -Z_n(X_n) stays attached, so the loss also depends on the parameters through X.  For a loss with
+// per-trajectory weights  mu_k = dL/dY_N[k],  nu_k = dL/dZsum_N[k]  (relative entropy: solver.py:179-180, 484-486)
+// the step  X_{n+1} = X_n + b(X_n) dt + B(-Z_n dt + xi sqrt(dt)),
+//           Y_{n+1} = Y_n + (f(X_{n+1}) - |Z_n|^2 / 2) dt + Z_n.xi sqrt(dt),   Zsum_{n+1} = Zsum_n + (|Z_n|^2 / 2 + f(X_{n+1})) dt
+// has the adjoint recursion (lambda_N = (nu - mu) grad g(X_N)):
+//     lambda'   = lambda_{n+1} + (mu + nu) dt grad f(X_{n+1})
+//     gZ_n      = mu (-Z_n dt + xi sqrt(dt)) + nu Z_n dt - dt B^T lambda'            (= dL/dZ_n, all paths)
+//     lambda_n  = lambda' + dt b'(X_n)^T lambda' + J_n^T gZ_n,      J_n = dZ_n/dX_n = W3 diag(1-h2^2) W2 diag(1-h1^2) W1x
+// and the parameter gradient is sum_n (dZ_n/dtheta)^T gZ_n -- exactly what hjb_bwd2_kernel computes from a panel G.
+// So this kernel only walks backwards in time (sequential per trajectory tile, one wave per tile like the forward,
+// 626 MFMAs per step at d = 100: B^T, W3^T, W2^T, W1x^T, (dt A)^T products chained in registers) and overwrites the
+// image the forward kernel left in the xi slot of the path store
+//     store_path = 2:  W = xi - sqrt(dt) Z   (mu-losses:  gZ = mu sqrt(dt) W - dt B^T lambda')
+//     store_path = 3:  W = Z                 (relative entropy: gZ = nu dt W - dt B^T lambda')
+// with gZ / sqrt(dt); the backward kernel then runs with unit trajectory weights.
+#pragma once
+#include "hjb_kernels.h"
+
+namespace psp {
+
+template <int D, int H>
+__global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const float* __restrict__ P = a.params;
+
+    // transposed A-operand tables in the forward kernel's LDS carve (same sizes, orientations swapped)
+    float* tW3T = lds + G::fW1;                        // HB x KSD : W3^T
+    float* tW2T = lds + G::fW2;                        // HB x KSH : W2^T
+    float* tW1T = lds + G::fW3;                        // DB x KSH : W1x^T
+    float* tAT = lds + G::fA;                          // DB x KSD : (dt A)^T
+    float* tBT = tAT + (a.drift_kind == DRIFT_DENSE ? G::fB_dense_off : 0);
+    stage_aop(tW3T, HB, KSD, tid, nthr, [&](int row, int col) {
+        return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+    stage_aop(tW2T, HB, KSH, tid, nthr, [&](int row, int col) {
+        return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
+    stage_aop(tW1T, DB, KSH, tid, nthr, [&](int row, int col) {
+        return (row < D && col < H) ? P[G::oW1 + col * (D + 1) + 1 + row] : 0.f; });
+    if (a.drift_kind == DRIFT_DENSE) {
+        const float dt = a.dt;
+        const float* __restrict__ A = a.drift;
+        stage_aop(tAT, DB, KSD, tid, nthr, [&](int row, int col) {
+            return (row < D && col < D) ? dt * A[col * D + row] : 0.f; });
+    }
+    if (a.sigma_kind == SIGMA_DENSE) {
+        const float* __restrict__ B = a.sigma;
+        stage_aop(tBT, DB, KSD, tid, nthr, [&](int row, int col) {
+            return (row < D && col < D) ? B[col * D + row] : 0.f; });
+    }
+    stage_vec(lds + G::vdr, DB, tid, nthr, [&](int f) {
+        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+    stage_vec(lds + G::vrun, DB, tid, nthr, [&](int f) {
+        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+    stage_vec(lds + G::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
+    __syncthreads();
+
+    const int t16 = blockIdx.x * nwave + wave;
+    if (t16 >= a.ntile16) return;
+    const int k = t16 * 16 + j;
+    const bool kvalid = k < a.K_local;
+    const float dt = a.dt, sqdt = a.sqdt, rsq = 1.0f / a.sqdt;
+    const float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
+    const float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    const float coefW = (a.store_path == 3) ? nu * dt : mu * sqdt;
+    const float wf = (mu + nu) * dt;                   // weight of grad f(X_{n+1})
+    const bool need_x = a.runcost_kind == RUN_DIAGQ || a.drift_kind == DRIFT_DWELL;
+    const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::fVec) + q;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // lambda_N = (nu - mu) grad g(X_N)   (problems.py:49,164,334) and X_N for grad f at the last step
+    f32x4 lam[DB], Xn1[DB];
+    {
+        const f32x4* vterm = vecs0 + (G::vterm - G::fVec) / 4;
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            const f32x4 tv = vterm[b * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * b + 4 * r + q;
+                const float x = (f < D && kvalid) ? a.XN[(size_t)k * D + f] : 0.f;
+                Xn1[b][r] = x;
+                float gg;
+                if (a.term_kind == TERM_LINEAR) gg = tv[r];
+                else if (a.term_kind == TERM_DIAGQ) gg = 2.0f * tv[r] * x;
+                else gg = 2.0f * tv[r] * (x - 1.0f);
+                lam[b][r] = (nu - mu) * gg;
+            }
+        }
+    }
+
+#pragma unroll 1
+    for (int n = a.N - 1; n >= 0; --n) {
+        const f32x4* vecs = opaque(vecs0);
+        const f32x4* vdr = vecs + (G::vdr - G::fVec) / 4;
+        const f32x4* vrun = vecs + (G::vrun - G::fVec) / 4;
+        float* pblk = a.path + ((size_t)n * a.ntile16 + t16) * (size_t)G::PB + lane;
+        // lambda' = lambda_{n+1} + (mu + nu) dt grad f(X_{n+1}),  f = x^T diag(p) x  (problems.py:161)
+        if (a.runcost_kind == RUN_DIAGQ) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) lam[b] += (2.0f * wf) * (vrun[b * 4] * Xn1[b]);
+        }
+        // q = B^T lambda'
+        f32x4 qv[DB];
+        if (a.sigma_kind == SIGMA_DENSE) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) qv[b] = zero4;
+            gemm_T<DB, KSD, DB>(qv, tBT, lam, lane);
+        } else if (a.sigma_kind == SIGMA_SCALE) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) qv[b] = a.sigma_scale * lam[b];
+        } else {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) qv[b] = lam[b];
+        }
+        // gZ_n from the image the forward left in the xi slot; gZ / sqrt(dt) goes back in its place
+        f32x4 gz[DB];
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            f32x4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = pblk[G::pXi + (4 * b + r) * 64];
+            gz[b] = coefW * w - dt * qv[b];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pblk[G::pXi + (4 * b + r) * 64] = rsq * gz[b][r];
+        }
+        // J_n^T gZ_n through the stored activations
+        f32x4 dz2[HB], dz1[HB];
+        {
+            f32x4 h2[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[m][r] = pblk[G::pH2 + (4 * m + r) * 64];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz2[m] = zero4;
+            gemm_T<HB, KSD, DB>(dz2, tW3T, gz, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+        }
+        {
+            f32x4 h1[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[m][r] = pblk[G::pH1 + (4 * m + r) * 64];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz1[m] = zero4;
+            gemm_T<HB, KSH, HB>(dz1, tW2T, dz2, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
+        }
+        // lambda_n = lambda' + dt b'(X_n)^T lambda' + W1x^T dz1
+        f32x4 ln[DB];
+#pragma unroll
+        for (int b = 0; b < DB; ++b) ln[b] = lam[b];
+        gemm_T<DB, KSH, HB>(ln, tW1T, dz1, lane);
+        if (need_x) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xn1[b][r] = pblk[G::pX + (4 * b + r) * 64];          // X_n
+        }
+        if (a.drift_kind == DRIFT_DENSE) {
+            gemm_T<DB, KSD, DB>(ln, tAT, lam, lane);
+        } else if (a.drift_kind == DRIFT_DIAG) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) ln[b] += dt * (vdr[b * 4] * lam[b]);
+        } else if (a.drift_kind == DRIFT_DWELL) {      // b = -4 kappa x (x^2 - 1)  ->  b' = -4 kappa (3 x^2 - 1)
+#pragma unroll
+            for (int b = 0; b < DB; ++b) ln[b] -= dt * (4.0f * vdr[b * 4] * ((3.0f * Xn1[b] * Xn1[b] - 1.0f) * lam[b]));
+        }
+#pragma unroll
+        for (int b = 0; b < DB; ++b) lam[b] = ln[b];
+    }
+}
+
+template <int D, int H>
+struct HjbaLaunch {
+    using G = Geo<D, H>;
+    static hipError_t adj(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        const int bytes = G::fwd_lds_floats(a.drift_kind, a.sigma_kind) * 4;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_adj_kernel<D, H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjb_adj_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
+        return hipGetLastError();
+    }
+};
+
+}  // namespace psp

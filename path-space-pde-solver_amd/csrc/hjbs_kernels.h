@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
             X[io][r] = (f < D && kvalid) ? v : 0.f;
         }
     float Yw = 0.f, Fw = 0.f;                          // this wave's partial of Y and of the running-cost integral
+    const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
+    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : 0.f);
 
 #pragma unroll 1
     for (int n = 0; n < a.N; ++n) {
@@ -249,9 +251,10 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (16 * sb + 4 * r + q >= D) xi[r] = 0.f;
-                if (a.store_path) {
+                if (a.store_path) {                    // 1: xi, 2: xi - sqrt(dt) Z, 3: Z (see hjb_fwd_kernel)
+                    const f32x4 wv = store_cxi * xi + store_cz * Z[io];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pblk[(G::pXi / 64 + 4 * sb + r) * 64] = xi[r];
+                    for (int r = 0; r < 4; ++r) pblk[(G::pXi / 64 + 4 * sb + r) * 64] = wv[r];
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -294,7 +297,8 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
                 }
             }
         }
-        const float term = (a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S)) * dt + Pz * sqdt;
+        const float term = (a.loss_kind == LOSS_RELENT) ? -(0.5f * S + fX) * dt        // Y carries -Zsum (hjb_fwd_kernel)
+                           : (a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S)) * dt + Pz * sqdt;
         Yw += term;
         Fw = fmaf(fX, dt, Fw);
     }

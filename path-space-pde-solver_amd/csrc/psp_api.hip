@@ -108,7 +108,8 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     }
     if (c->drift_kind < 0 || c->drift_kind > 3 || c->sigma_kind < 0 || c->sigma_kind > 2 ||
         c->runcost_kind < 0 || c->runcost_kind > 1 || c->term_kind < 0 || c->term_kind > 2 ||
-        c->loss_kind < 0 || c->loss_kind > 2 || c->noise_mode < 0 || c->noise_mode > 1)
+        c->loss_kind < 0 || c->loss_kind > 3 || c->noise_mode < 0 || c->noise_mode > 1 || c->store_path < 0 ||
+        c->store_path > 3)
         return fail(-1, "config enum out of range");
     if (p->inst.fwd_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
         return fail(-3, "forward kernel weights do not fit the 160 KiB LDS for this (d,H,drift,sigma)");
@@ -456,6 +457,30 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
                        grad_partial, p.bwd_grid, P, grad_out);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
+    return 0;
+}
+
+int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float* path, const float* XN,
+                          const float* mu, const float* nu, void* stream) {
+    Plan p;
+    int rc = make_plan(cfg, &p);
+    if (rc) return rc;
+    if ((rc = check_ptrs(cfg))) return rc;
+    if (!p.inst.launch_adj) return fail(-2, "the adjoint sweep is not built for this kernel family (wide kernels)");
+    if (!params || !path || !XN || !mu) return fail(-1, "null buffer passed to psp_hjb_adjoint_sweep");
+    if (cfg->store_path != 2 && cfg->store_path != 3)
+        return fail(-1, "psp_hjb_adjoint_sweep needs the path written with store_path = 2 or 3");
+    if (!cfg->adaptive) return fail(-1, "without the adaptive forward process the state path carries no gradient");
+    psp::HjbArgs a;
+    fill_args(cfg, p, &a);
+    a.params = params; a.path = path; a.XN = const_cast<float*>(XN); a.adj_mu = mu; a.adj_nu = nu;
+    // one wave per 16-trajectory tile, like hjb_fwd_kernel (the recursion is sequential in time)
+    int fw = (p.ntile16 + n_cus() - 1) / n_cus();
+    if (fw < 1) fw = 1;
+    if (fw > 8) fw = 8;
+    const int grid = (p.ntile16 + fw - 1) / fw;
+    hipError_t e = p.inst.launch_adj(a, grid, fw * 64, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hjb_adj_kernel launch");
     return 0;
 }
 

@@ -19,7 +19,7 @@ DRIFT_ZERO, DRIFT_DENSE, DRIFT_DIAG, DRIFT_DOUBLE_WELL = 0, 1, 2, 3
 SIGMA_IDENTITY, SIGMA_DENSE, SIGMA_SCALED_IDENTITY = 0, 1, 2
 RUNCOST_ZERO, RUNCOST_DIAG_QUAD = 0, 1
 TERM_LINEAR, TERM_DIAG_QUAD, TERM_SHIFTED_QUAD = 0, 1, 2
-LOSS_LOG_VARIANCE, LOSS_MOMENT, LOSS_WEIGHTS = 0, 1, 2
+LOSS_LOG_VARIANCE, LOSS_MOMENT, LOSS_WEIGHTS, LOSS_REL_ENTROPY = 0, 1, 2, 3
 NOISE_SUPPLIED, NOISE_PHILOX = 0, 1
 GH_ZERO, GH_QUAD, GH_ALLEN_CAHN = 0, 1, 2
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "psp_last_error": (C.c_char_p, []),
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_family": (C.c_int, [C.c_int32, C.c_int32]),
+    "psp_hjb_adjoint_sweep": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P, _P, _P, _P]),
     "psp_gen_instance_count": (C.c_int, []),
     "psp_gen_instance_get": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "psp_hjb_instance_count": (C.c_int, []),

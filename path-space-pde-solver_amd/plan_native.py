@@ -36,10 +36,9 @@ def native_eligibility(solver):
         return 'device is %s (the HIP rollout needs a GPU)' % solver.device
     if solver.approx_method != 'control' or solver.time_approx != 'inner':
         return "only approx_method='control' with time_approx='inner' is native"
-    if solver.loss_method not in ('log-variance', 'moment', 'variance', 'cross_entropy'):
-        return "loss_method %r is not native (log-variance, moment, variance, cross_entropy)" % solver.loss_method
-    if solver.adaptive_forward_process and not solver.detach_forward:
-        return 'detach_forward=False back-propagates through the state path (not native)'
+    if solver.loss_method not in ('log-variance', 'moment', 'variance', 'cross_entropy', 'relative_entropy'):
+        return ("loss_method %r is not native (log-variance, moment, variance, cross_entropy, relative_entropy)"
+                % solver.loss_method)
     if solver.burgers_drift:
         return 'burgers_drift is not native'
     if solver.u_l2_error_flag:
@@ -68,6 +67,12 @@ def native_eligibility(solver):
     chosen, why = shapes.choose(probe, solver.d, shape[1])
     if chosen is None:
         return why
+    if solver.adaptive_forward_process and not solver.detach_forward and solver.loss_method == 'cross_entropy':
+        return ('cross_entropy with detach_forward=False also differentiates exp(-g(X_N)) through the state path '
+                '(not a function of Y_N - g(X_N) alone): composite plan')
+    if solver.adaptive_forward_process and not solver.detach_forward and chosen[2] != 1:
+        return ('detach_forward=False back-propagates through the state path: the adjoint sweep is built for the '
+                'narrow kernel family only (this shape runs on the large-d family)')
     return None
 
 
@@ -113,11 +118,15 @@ class HjbNativePlan:
         cfg.runcost_kind = spec['runcost'][0]
         cfg.term_kind = spec['term'][0]
         cfg.adaptive = 1 if solver.adaptive_forward_process else 0
-        cfg.loss_kind = {'log-variance': nat.LOSS_LOG_VARIANCE, 'moment': nat.LOSS_MOMENT}.get(
-            solver.loss_method, nat.LOSS_WEIGHTS)
+        cfg.loss_kind = {'log-variance': nat.LOSS_LOG_VARIANCE, 'moment': nat.LOSS_MOMENT,
+                         'relative_entropy': nat.LOSS_REL_ENTROPY}.get(solver.loss_method, nat.LOSS_WEIGHTS)
         self.generic_loss = cfg.loss_kind == nat.LOSS_WEIGHTS
+        self.relent = solver.loss_method == 'relative_entropy'
+        # gradients through the state path (the reference's default flags): forward with the attached-mode image in
+        # the xi slot, reverse-time adjoint sweep, then the ordinary backward with unit weights (include/psp.h)
+        self.attached = bool(solver.adaptive_forward_process and not solver.detach_forward)
         cfg.noise_mode = nat.NOISE_PHILOX if noise == 'philox' else nat.NOISE_SUPPLIED
-        cfg.store_path = 1
+        cfg.store_path = 3 if self.relent else (2 if self.attached else 1)
         # kernel instance: the exact (d, H) if compiled, else the cheapest larger one (zero padding, native_shapes.py)
         chosen, why = shapes.choose(cfg, solver.d, self.H)
         if chosen is None:
@@ -147,6 +156,16 @@ class HjbNativePlan:
         self.m = torch.zeros(self.P, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.P, dtype=torch.float32, device=dev)
         self.x0_vec = dev_f32(pad.vec(solver.X_0.detach().to(dev)))
+        if self.attached and self.family != 1:
+            raise PlanUnsupported('the adjoint sweep (detach_forward=False) is built for the narrow kernel family only')
+        if self.attached or self.relent:
+            self.cfg_w = nat.HjbConfig.from_buffer_copy(cfg)          # backward with explicit trajectory weights
+            self.cfg_w.loss_kind = nat.LOSS_WEIGHTS
+            self.w_bwd = torch.empty(self.K_local, dtype=torch.float32, device=dev)
+            if self.attached:
+                self.XN_k = torch.empty(self.K_local, self.d_pad, dtype=torch.float32, device=dev)
+                self.mu = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
+                self.nu = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
         self.step = 0
         self.events = None   # bench.py: list collecting HIP-event pairs around the two rollout kernels
         # learnable Y_0 (solver.py:372-374): tiny Adam in torch on a 1-element tensor
@@ -210,14 +229,15 @@ class HjbNativePlan:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
         nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(x0_t), x0_stride, y0_ptr,
-                                          nat.ptr(xi), seed, l, nat.ptr(self.path), nat.ptr(self.D), None,
+                                          nat.ptr(xi), seed, l, nat.ptr(self.path), nat.ptr(self.D),
+                                          nat.ptr(self.XN_k) if self.attached else None,
                                           nat.ptr(self.Yn), nat.ptr(self.fwd_partial), st), 'psp_hjb_rollout_fwd')
         if ev is not None:
             ev[1].record()
         nat.check(lib.psp_hjb_terminal_reduce(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums), st),
                   'psp_hjb_terminal_reduce')
         sharding.allreduce_sum_(self.sums)              # collective 1: 16 bytes
-        d_or_w = self.D
+        d_or_w, bcfg = self.D, cfg
         if self.generic_loss:
             loss, d_or_w = self._generic_loss_weights()
         else:
@@ -225,7 +245,25 @@ class HjbNativePlan:
         loss_out[l] = loss.to(torch.float32)
         if ev is not None:
             ev[2].record()
-        nat.check(lib.psp_hjb_rollout_bwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(xi), seed, l, nat.ptr(self.path),
+        if self.attached:
+            # per-trajectory weights mu = dL/dY_N, nu = dL/dZsum_N (global K and global mean: rank-independent)
+            if self.relent:
+                self.mu.zero_()
+                self.nu.fill_(1.0 / float(s.K))
+            elif self.generic_loss:
+                self.mu.copy_(d_or_w)
+            else:
+                self.mu.copy_(sharding.loss_weights(self.D, self.sums, s.K, s.loss_method))
+            nat.check(lib.psp_hjb_adjoint_sweep(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.path), nat.ptr(self.XN_k),
+                                                nat.ptr(self.mu), nat.ptr(self.nu) if self.relent else None, st),
+                      'psp_hjb_adjoint_sweep')
+            self.w_bwd.fill_(1.0)                       # the sweep left dL/dZ_n / sqrt(dt) in the xi slot
+            d_or_w, bcfg = self.w_bwd, self.cfg_w
+        elif self.relent:
+            # detached relative entropy: dL/dZ_n = Z_n dt / K, and the xi slot holds Z_n  ->  weight sqrt(dt) / K
+            self.w_bwd.fill_(float(cfg.sqrt_dt) / float(s.K))
+            d_or_w, bcfg = self.w_bwd, self.cfg_w
+        nat.check(lib.psp_hjb_rollout_bwd(C.byref(bcfg), nat.ptr(flat_k), nat.ptr(xi), seed, l, nat.ptr(self.path),
                                           nat.ptr(d_or_w), nat.ptr(self.sums), nat.ptr(self.grad_partial),
                                           nat.ptr(self.grad_k), st), 'psp_hjb_rollout_bwd')
         if ev is not None:

@@ -45,6 +45,8 @@ def loss_from_sums(sums, K_global, loss_method):
         return sums[1] / K - (sums[0] / K) ** 2
     if loss_method == 'moment':
         return sums[1] / K
+    if loss_method == 'relative_entropy':      # the forward kernel accumulates D = -(Zsum + g(X_N)) (include/psp.h)
+        return -sums[0] / K
     raise ValueError(loss_method)
 
 

@@ -221,6 +221,27 @@ CASES = [
          problem=dict(kind="LLGC", kwargs=dict(d=300, off_diag=0.1 / 300 ** 0.5, T=0.1, seed=42)),
          solver=dict(HJB, L=3, lr=0.001, seed=42, delta_t=0.01, K=48, u_l2_error_flag=False),
          net=dict(kind="tanh_mlp", widths=[40, 40], seed=123), probe_times=[0.0]),
+    # gradients THROUGH the state path: adaptive_forward_process=True with detach_forward=False (the reference's default
+    # flags, solver.py:451-469), and the relative-entropy loss (solver.py:179-180, 484-486)
+    dict(name="lqgc_d2_attached_logvar", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
+         solver=dict(HJB, detach_forward=False, L=5, lr=0.01, seed=42, delta_t=0.05, K=128, u_l2_error_flag=False)),
+    dict(name="llgc_d100_h64_attached_logvar", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=0.3, seed=42)),
+         solver=dict(HJB, detach_forward=False, L=3, lr=0.001, seed=42, delta_t=0.01, K=256, u_l2_error_flag=False),
+         net=dict(kind="tanh_mlp", widths=[64, 64], seed=123)),
+    dict(name="dw_d10_attached_moment", family="solver",
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=10, d_1=5, d_2=5, T=0.3, eta=0.5, kappa=2.0)),
+         solver=dict(HJB, detach_forward=False, loss_method="moment", learn_Y_0=True, L=4, lr=0.005, seed=42,
+                     delta_t=0.01, K=160, u_l2_error_flag=False)),
+    dict(name="lqgc_d4_relative_entropy", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=4, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
+         solver=dict(HJB, detach_forward=False, loss_method="relative_entropy", L=5, lr=0.01, seed=42, delta_t=0.05,
+                     K=128, u_l2_error_flag=False)),
+    dict(name="llgc_d20_relative_entropy_detached", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=20, off_diag=0.05, T=0.3, seed=42)),
+         solver=dict(HJB, detach_forward=True, loss_method="relative_entropy", L=4, lr=0.002, seed=42, delta_t=0.01,
+                     K=200, u_l2_error_flag=False)),
     # DenseNet swapped in as the control net (notebook extension point)
     dict(name="llgc_d100_densenet64_logvar", family="solver",
          problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=0.5, seed=42)),

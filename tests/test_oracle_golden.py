@@ -15,6 +15,8 @@ SOLVER_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_l
                 "llgc_d500_h64_logvar",
                 "llgc_d7_default_logvar", "lqgc_d33_h50_logvar", "dw_d70_h64_logvar", "llgc_d105_h64_logvar",
                 "llgc_d300_h40_logvar",
+                "lqgc_d2_attached_logvar", "llgc_d100_h64_attached_logvar", "dw_d10_attached_moment",
+                "lqgc_d4_relative_entropy", "llgc_d20_relative_entropy_detached",
                 "llgc_d100_densenet64_logvar", "dw_d10_logvar", "llgc_d20_diag_logvar",
                 "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive", "lqgc_d2_outer",
                 "lqgc_d2_variance", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
@@ -77,6 +79,10 @@ def test_solver_oracle_matches_reference(name):
     _check_series(out["Y_0_log"], exp["Y_0_log"], exact)
     z = out["z"]
     if exp["final_params"] is not None:
+        # with gradients through the state path the backward graph sums contributions in an order that depends on
+        # how the graph was built: losses agree bit-for-bit, final parameters to ~1e-7 relative
+        sc = rec["case"]["solver"]
+        exact = exact and not (sc["adaptive_forward_process"] and not sc["detach_forward"])
         _check_fp(orc.fingerprint(z), exp["final_params"], exact)
         xp = torch.tensor(exp["probe_x"]).reshape(-1, prob.d)
         for pr in exp["probes"]:
