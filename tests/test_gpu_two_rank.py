@@ -27,12 +27,12 @@ def _free_port():
     return p
 
 
-def _train(noise, out=None, rank=0):
+def _train(noise, out=None, rank=0, detach=True):
     sys.path.insert(0, ROOT)
     import path_space_pde_solver_amd as psp
     dev = torch.device("cuda:0")
     prob = psp.LLGC(d=100, off_diag=0.01, T=0.2, seed=42, device=dev)
-    model = psp.Solver("two-rank", prob, device=dev, noise=noise, **CFG)
+    model = psp.Solver("two-rank", prob, device=dev, noise=noise, **dict(CFG, detach_forward=detach))
     model.train()
     assert model.plan_name == "native"
     res = dict(loss=model.loss_log, params=torch.cat([p.detach().reshape(-1).cpu() for p in model.z_n.parameters()]),
@@ -42,12 +42,12 @@ def _train(noise, out=None, rank=0):
     return res
 
 
-def _worker(rank, world, port, noise, out):
+def _worker(rank, world, port, noise, out, detach=True):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = _train(noise, out, rank)
+    res = _train(noise, out, rank, detach)
     assert res["K_local"] == CFG["K"] // world and res["k_offset"] == rank * res["K_local"]
     dist.barrier()
     dist.destroy_process_group()
@@ -59,6 +59,18 @@ def test_two_ranks_match_one_rank(tmp_path, noise):
     mp.spawn(_worker, args=(2, _free_port(), noise, out), nprocs=2, join=True)
     two = torch.load(out)
     one = _train(noise)
+    for a, b in zip(two["loss"], one["loss"]):
+        assert abs(a - b) <= 1e-6 * abs(b), (two["loss"], one["loss"])
+    err = float((two["params"] - one["params"]).abs().max())
+    assert err <= 2e-6, err
+
+
+def test_two_ranks_match_one_rank_attached(tmp_path):
+    """Gradients through the state path (adjoint sweep): the per-trajectory weights use the GLOBAL mean of D."""
+    out = os.path.join(str(tmp_path), "two_att.pt")
+    mp.spawn(_worker, args=(2, _free_port(), "philox", out, False), nprocs=2, join=True)
+    two = torch.load(out)
+    one = _train("philox", detach=False)
     for a, b in zip(two["loss"], one["loss"]):
         assert abs(a - b) <= 1e-6 * abs(b), (two["loss"], one["loss"])
     err = float((two["params"] - one["params"]).abs().max())
