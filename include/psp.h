@@ -171,11 +171,11 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
  *     psp_hjb_adjoint_sweep  reverse-time adjoint recursion per trajectory (kernel: csrc/hjba_kernels.h); rewrites the
  *                            xi slot of `path` with dL/dZ_n / sqrt(dt)
  *     psp_hjb_rollout_bwd   with loss_kind = PSP_LOSS_WEIGHTS and D = 1 for every trajectory
- *   XN : (K_local, d) terminal states from the forward call;  mu, nu : K_local floats each (nu may be NULL = 0).
- * Narrow kernel family only (returns -2 for the large-d family).
+ *   XN : (K_local, d) terminal states from the forward call;  mu, nu : K_local floats each (nu may be NULL = 0);
+ *   fwd_partial : the forward call's scratch (the large-d kernel family rebuilds its operand tables in it).
  */
 int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float* path, const float* XN,
-                          const float* mu, const float* nu, void* stream);
+                          const float* mu, const float* nu, double* fwd_partial, void* stream);
 
 /* torch.optim.Adam(lr, betas=(b1,b2), eps, weight_decay=0, amsgrad=False) on a flat buffer
  * (function_space.py:185, solver.py:198-200).  step is 1-based. */

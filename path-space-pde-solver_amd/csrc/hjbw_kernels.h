@@ -35,6 +35,10 @@ struct GeoW {
     static constexpr int tW1 = 0, tW2 = tW1 + KP * HB * 64, tW3 = tW2 + 16 * HB * 64, tA = tW3 + 16 * DB * 64,
                          tB = tA + KP * DB * 64, fwd_table_floats = tB + KP * DB * 64;
     static constexpr int bwd_table_floats = KP * HB * 64;            // W3^T
+    // adjoint sweep (transposed orientations), same total size as the forward set
+    static constexpr int aBT = 0, aAT = aBT + KP * DB * 64, aW3T = aAT + KP * DB * 64, aW2T = aW3T + KP * HB * 64,
+                         aW1T = aW2T + 16 * HB * 64, adj_table_floats = aW1T + 16 * DB * 64;
+    static_assert(adj_table_floats == fwd_table_floats, "the sweep reuses the forward kernel's table region");
     // forward LDS (floats): per-feature vectors, reduction scratch, one input image per wave
     static constexpr int vb1 = 0, vw1t = vb1 + HB * 16, vb2 = vw1t + HB * 16, vb3 = vb2 + HB * 16,
                          vdr = vb3 + DB * 16, vrun = vdr + DB * 16, vterm = vrun + DB * 16, fRed = vterm + DB * 16,
@@ -63,9 +67,29 @@ __global__ __launch_bounds__(256) void hjbw_tables_kernel(const HjbArgs a, int b
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gs = (long long)gridDim.x * blockDim.x;
     const float* __restrict__ P = a.params;
     float* T = a.tables;
-    if (backward) {
+    if (backward == 1) {
         table_fill(T, W::HB, W::KP, gtid, gs, [&](int row, int col) {
             return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+        return;
+    }
+    if (backward == 2) {                               // adjoint sweep: B^T, (dt A)^T, W3^T, W2^T, W1x^T
+        if (a.sigma_kind == SIGMA_DENSE) {
+            const float* __restrict__ B = a.sigma;
+            table_fill(T + W::aBT, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+                return (row < D && col < D) ? B[col * D + row] : 0.f; });
+        }
+        if (a.drift_kind == DRIFT_DENSE) {
+            const float dt = a.dt;
+            const float* __restrict__ A = a.drift;
+            table_fill(T + W::aAT, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+                return (row < D && col < D) ? dt * A[col * D + row] : 0.f; });
+        }
+        table_fill(T + W::aW3T, W::HB, W::KP, gtid, gs, [&](int row, int col) {
+            return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+        table_fill(T + W::aW2T, W::HB, 16, gtid, gs, [&](int row, int col) {
+            return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
+        table_fill(T + W::aW1T, W::DB, 16, gtid, gs, [&](int row, int col) {
+            return (row < D && col < H) ? P[G::oW1 + col * (D + 1) + 1 + row] : 0.f; });
         return;
     }
     table_fill(T + W::tW1, W::HB, W::KP, gtid, gs, [&](int row, int col) {
@@ -666,6 +690,168 @@ __global__ __launch_bounds__(256) void hjbw_bwd_kernel(const HjbArgs a) {
     if (tid < H) gp[G::ob2 + tid] = (lds[tid] + lds[64 + tid]) + (lds[128 + tid] + lds[192 + tid]);
 }
 
+// =======================================================================================
+// Wide adjoint sweep (gradients through the state path; recursion and path-store protocol of hjba_kernels.h).
+// One wave = one 16-trajectory tile, backwards in time: lambda' goes to the wave's LDS image, B^T lambda' and
+// (dt A)^T lambda' are rolled k-loops over it (the second accumulates into lambda in place), gZ replaces the image,
+// W3^T gZ is the third rolled product, W2^T and W1x^T are short unrolled ones.
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(256) void hjbw_adj_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    using W = GeoW<D, H>;
+    constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const float* __restrict__ T = a.tables;
+
+    stage_vec(lds + W::vdr, DB, tid, nthr, [&](int f) {
+        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+    stage_vec(lds + W::vrun, DB, tid, nthr, [&](int f) {
+        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+    stage_vec(lds + W::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
+    __syncthreads();
+
+    const int t16raw = blockIdx.x * nwave + wave;
+    if (t16raw >= a.ntile16) return;                   // no workgroup barriers below
+    const int t16 = t16raw;
+    const int k = t16 * 16 + j;
+    const bool kvalid = k < a.K_local;
+    const float dt = a.dt, sqdt = a.sqdt, rsq = 1.0f / a.sqdt;
+    const float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
+    const float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    const float coefW = (a.store_path == 3) ? nu * dt : mu * sqdt;
+    const float wf = (mu + nu) * dt;
+    float* img = lds + W::fImg + wave * W::IMG;
+    const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds) + q;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 lam[DB];                                     // lambda_N = (nu - mu) grad g(X_N)
+    {
+        const f32x4* vterm = vecs0 + W::vterm / 4;
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            const f32x4 tv = vterm[b * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * b + 4 * r + q;
+                const float x = (f < D && kvalid) ? a.XN[(size_t)k * D + f] : 0.f;
+                float gg;
+                if (a.term_kind == TERM_LINEAR) gg = tv[r];
+                else if (a.term_kind == TERM_DIAGQ) gg = 2.0f * tv[r] * x;
+                else gg = 2.0f * tv[r] * (x - 1.0f);
+                lam[b][r] = (nu - mu) * gg;
+            }
+        }
+    }
+
+#pragma unroll 1
+    for (int n = a.N - 1; n >= 0; --n) {
+        const f32x4* vecs = opaque(vecs0);
+        const f32x4* vdr = vecs + W::vdr / 4;
+        const f32x4* vrun = vecs + W::vrun / 4;
+        // path blocks through wave-uniform SGPR bases (loads / stores are "base + lane * 4 + immediate < 4 KiB")
+        typedef __attribute__((address_space(1))) float* gwptr_t;
+        auto pbase = [&](int nn, int ofs) __attribute__((always_inline)) {
+            unsigned long long addr = (unsigned long long)a.path +
+                4ull * (((unsigned long long)nn * a.ntile16 + t16) * (unsigned)G::PB + (unsigned)ofs);
+            asm volatile("" : "+s"(addr));
+            return (gwptr_t)addr;
+        };
+        const unsigned ul = (unsigned)lane;
+        // lambda' = lambda_{n+1} + (mu + nu) dt grad f(X_{n+1});  X_{n+1} from the next path block (or X_N)
+        if (a.runcost_kind == RUN_DIAGQ) {
+            const int nx = n + 1 < a.N ? n + 1 : n;
+#pragma unroll
+            for (int b = 0; b < DB; ++b) {
+                gwptr_t px = pbase(nx, G::pX + b * 256);
+                f32x4 x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * b + 4 * r + q;
+                    const float xp = px[r * 64 + ul];
+                    const float xn = (f < D && kvalid) ? a.XN[(size_t)k * D + (f < D ? f : 0)] : 0.f;
+                    x[r] = (n + 1 < a.N) ? xp : xn;
+                }
+                lam[b] += (2.0f * wf) * (vrun[b * 4] * x);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = lam[ks >> 2][ks & 3];
+        // q = B^T lambda'
+        f32x4 qv[DB];
+        if (a.sigma_kind == SIGMA_DENSE) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) qv[b] = zero4;
+            gemm_img<DB, KP>(qv, T + W::aBT, img, lane);
+        } else if (a.sigma_kind == SIGMA_SCALE) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) qv[b] = a.sigma_scale * lam[b];
+        } else {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) qv[b] = lam[b];
+        }
+        // lambda += dt b'(X_n)^T lambda'   (in place; the image still holds lambda')
+        if (a.drift_kind == DRIFT_DENSE) {
+            gemm_img<DB, KP>(lam, T + W::aAT, img, lane);
+        } else if (a.drift_kind == DRIFT_DIAG) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) lam[b] += dt * (vdr[b * 4] * lam[b]);
+        } else if (a.drift_kind == DRIFT_DWELL) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) {
+                gwptr_t px = pbase(n, G::pX + b * 256);
+                f32x4 x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = px[r * 64 + ul];
+                lam[b] -= dt * (4.0f * vdr[b * 4] * ((3.0f * x * x - 1.0f) * lam[b]));
+            }
+        }
+        // gZ_n: back into the xi slot (as gZ / sqrt(dt)) and into the image (B operand of the W3^T product)
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            gwptr_t pw = pbase(n, G::pXi + b * 256);
+            f32x4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = pw[r * 64 + ul];
+            const f32x4 gz = coefW * w - dt * qv[b];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pw[r * 64 + ul] = rsq * gz[r];
+                img[(4 * b + r) * 64 + lane] = gz[r];
+            }
+        }
+        f32x4 dz2[HB], dz1[HB];
+        {
+            f32x4 h2[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[m][r] = pbase(n, G::pH2)[(4 * m + r) * 64 + ul];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz2[m] = zero4;
+            gemm_img<HB, KP>(dz2, T + W::aW3T, img, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
+        }
+        {
+            f32x4 h1[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[m][r] = pbase(n, G::pH1)[(4 * m + r) * 64 + ul];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz1[m] = zero4;
+            gemm_regs<HB, 16, HB>(dz1, T + W::aW2T, dz2, lane);
+#pragma unroll
+            for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
+        }
+        gemm_regs<DB, 16, HB>(lam, T + W::aW1T, dz1, lane);               // lambda_n += W1x^T dz1
+    }
+}
+
 template <int D, int H>
 struct HjbwLaunch {
     using G = Geo<D, H>;
@@ -698,8 +884,19 @@ struct HjbwLaunch {
         hipLaunchKernelGGL((hjbw_bwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
         return hipGetLastError();
     }
+    static hipError_t adj(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        hipError_t e = tables(a, 2, s);
+        if (e != hipSuccess) return e;
+        const int bytes = W::fwd_lds_floats * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_adj_kernel<D, H>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbw_adj_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
+        return hipGetLastError();
+    }
     static HjbInstance instance() {
         HjbInstance r{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::PB, &bwd2_lds, &bwd2};
+        r.launch_adj = &adj;
         r.wide = 1;
         r.fwd_table_floats = W::fwd_table_floats;
         r.bwd_table_floats = W::bwd_table_floats;

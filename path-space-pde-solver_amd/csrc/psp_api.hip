@@ -461,23 +461,26 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
 }
 
 int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float* path, const float* XN,
-                          const float* mu, const float* nu, void* stream) {
+                          const float* mu, const float* nu, double* fwd_partial, void* stream) {
     Plan p;
     int rc = make_plan(cfg, &p);
     if (rc) return rc;
     if ((rc = check_ptrs(cfg))) return rc;
-    if (!p.inst.launch_adj) return fail(-2, "the adjoint sweep is not built for this kernel family (wide kernels)");
-    if (!params || !path || !XN || !mu) return fail(-1, "null buffer passed to psp_hjb_adjoint_sweep");
+    if (!p.inst.launch_adj) return fail(-2, "the adjoint sweep is not built for this kernel instance");
+    if (!params || !path || !XN || !mu || !fwd_partial) return fail(-1, "null buffer passed to psp_hjb_adjoint_sweep");
     if (cfg->store_path != 2 && cfg->store_path != 3)
         return fail(-1, "psp_hjb_adjoint_sweep needs the path written with store_path = 2 or 3");
     if (!cfg->adaptive) return fail(-1, "without the adaptive forward process the state path carries no gradient");
     psp::HjbArgs a;
     fill_args(cfg, p, &a);
     a.params = params; a.path = path; a.XN = const_cast<float*>(XN); a.adj_mu = mu; a.adj_nu = nu;
-    // one wave per 16-trajectory tile, like hjb_fwd_kernel (the recursion is sequential in time)
+    // the wide family keeps its (transposed) operand tables where the forward kernel kept its own: behind the partial
+    // sums of the forward scratch, whatever forward variant wrote them
+    a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);
+    // one wave per 16-trajectory tile, like the forward kernels (the recursion is sequential in time)
     int fw = (p.ntile16 + n_cus() - 1) / n_cus();
     if (fw < 1) fw = 1;
-    if (fw > 8) fw = 8;
+    if (fw > (p.inst.wide ? 4 : 8)) fw = p.inst.wide ? 4 : 8;
     const int grid = (p.ntile16 + fw - 1) / fw;
     hipError_t e = p.inst.launch_adj(a, grid, fw * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_adj_kernel launch");

@@ -70,9 +70,6 @@ def native_eligibility(solver):
     if solver.adaptive_forward_process and not solver.detach_forward and solver.loss_method == 'cross_entropy':
         return ('cross_entropy with detach_forward=False also differentiates exp(-g(X_N)) through the state path '
                 '(not a function of Y_N - g(X_N) alone): composite plan')
-    if solver.adaptive_forward_process and not solver.detach_forward and chosen[2] != 1:
-        return ('detach_forward=False back-propagates through the state path: the adjoint sweep is built for the '
-                'narrow kernel family only (this shape runs on the large-d family)')
     return None
 
 
@@ -156,8 +153,6 @@ class HjbNativePlan:
         self.m = torch.zeros(self.P, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.P, dtype=torch.float32, device=dev)
         self.x0_vec = dev_f32(pad.vec(solver.X_0.detach().to(dev)))
-        if self.attached and self.family != 1:
-            raise PlanUnsupported('the adjoint sweep (detach_forward=False) is built for the narrow kernel family only')
         if self.attached or self.relent:
             self.cfg_w = nat.HjbConfig.from_buffer_copy(cfg)          # backward with explicit trajectory weights
             self.cfg_w.loss_kind = nat.LOSS_WEIGHTS
@@ -255,8 +250,8 @@ class HjbNativePlan:
             else:
                 self.mu.copy_(sharding.loss_weights(self.D, self.sums, s.K, s.loss_method))
             nat.check(lib.psp_hjb_adjoint_sweep(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.path), nat.ptr(self.XN_k),
-                                                nat.ptr(self.mu), nat.ptr(self.nu) if self.relent else None, st),
-                      'psp_hjb_adjoint_sweep')
+                                                nat.ptr(self.mu), nat.ptr(self.nu) if self.relent else None,
+                                                nat.ptr(self.fwd_partial), st), 'psp_hjb_adjoint_sweep')
             self.w_bwd.fill_(1.0)                       # the sweep left dL/dZ_n / sqrt(dt) in the xi slot
             d_or_w, bcfg = self.w_bwd, self.cfg_w
         elif self.relent:

@@ -23,7 +23,10 @@ SHAPES = [
     ("DoubleWell_multidim", 30, [64, 64], 130, False),   # -> (32, 64), attached, elementwise drift
     ("LQGC", 20, [40, 40], 12000, True),    # many tiles: tile-per-wave forward, several backward rounds per workgroup
     ("LLGC", 40, [48, 48], 9000, False),    # same with the adjoint sweep
-    ("LLGC", 112, [20, 20], 48, True),      # (112, 32) does not fit the LDS with dense A and B -> wide family (128, 64)
+    ("LLGC", 112, [20, 20], 48, True),
+    ("LLGC", 200, [64, 64], 80, False),     # wide family with the adjoint sweep (hjbw_adj_kernel)
+    ("LQGC", 130, [40, 40], 40, False),     # -> wide (192, 64), running cost + quadratic terminal cost, attached
+    ("LLGC", 500, [64, 64], 36, False),      # (112, 32) does not fit the LDS with dense A and B -> wide family (128, 64)
 ]
 
 
