@@ -91,7 +91,7 @@ const char* psp_last_error(void);
 /* 1 if a compiled kernel instantiation exists for (d, H), else 0. */
 int psp_hjb_supported(int32_t d, int32_t H);
 /* Kernel family that serves (d, H): 0 none, 1 narrow (state panel in registers, tables in LDS; any flag
- * combination of psp_hjb_config), 2 wide (large d: tables in global memory; adaptive != 0 only). */
+ * combination of psp_hjb_config), 2 wide (large d: tables in global memory). */
 int psp_hjb_family(int32_t d, int32_t H);
 /* Enumeration of the compiled (d, H) instances (family as above).  A configuration whose (d, H) is not in the
  * list runs EXACTLY on any instance with larger d and H after zero padding (padded state components never couple
@@ -172,10 +172,12 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
  *                            xi slot of `path` with dL/dZ_n / sqrt(dt)
  *     psp_hjb_rollout_bwd   with loss_kind = PSP_LOSS_WEIGHTS and D = 1 for every trajectory
  *   XN : (K_local, d) terminal states from the forward call;  mu, nu : K_local floats each (nu may be NULL = 0);
+ *   wT : K_local weights of grad g(X_N) in lambda_N, or NULL for nu - mu (losses that depend on X_N only through
+ *        Y_N - g(X_N) resp. Zsum_N + g(X_N)); cross_entropy passes -Y_N exp(D) / K (solver.py:183-185);
  *   fwd_partial : the forward call's scratch (the large-d kernel family rebuilds its operand tables in it).
  */
 int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float* path, const float* XN,
-                          const float* mu, const float* nu, double* fwd_partial, void* stream);
+                          const float* mu, const float* nu, const float* wT, double* fwd_partial, void* stream);
 
 /* torch.optim.Adam(lr, betas=(b1,b2), eps, weight_decay=0, amsgrad=False) on a flat buffer
  * (function_space.py:185, solver.py:198-200).  step is 1-based. */

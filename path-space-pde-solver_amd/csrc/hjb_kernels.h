@@ -44,6 +44,7 @@ struct HjbArgs {
     float* tables;             // wide kernels: A-operand tables in global memory (carved from the caller's scratch)
     const float* adj_mu;       // adjoint sweep (hjba_kernels.h): dL/dY_N per trajectory
     const float* adj_nu;       //                                  dL/dZsum_N per trajectory (relative entropy), may be null
+    const float* adj_wT;       //   weight of grad g(X_N) in lambda_N per trajectory; null: nu - mu (losses of Y_N - g(X_N))
     long long k_offset;
     long long K_global;
     int x0_stride;
@@ -300,8 +301,7 @@ struct Geo {
     static constexpr int gW2T = 0, gW3T = gW2T + HB * KSH * 64, gVec = gW3T + HB * KSD * 64;
     static constexpr int gb3 = gVec, gEx = gb3 + DB * 16;
     static constexpr int EXT = (DB > 2 * HB ? DB : 2 * HB);   // exchange tiles (1 KiB) per wave
-    static constexpr int gW3 = gEx + 4 * EXT * 256;           // only when !adaptive
-    static int bwd_lds_floats(int adaptive) { return gW3 + (adaptive ? 0 : DB * KSH * 64); }
+    static int bwd_lds_floats(int) { return gEx + 4 * EXT * 256; }
     // role-specialised backward (hjb_bwd2_kernel): per sample block the exchange area holds the G panel as
     // an exact k-step image (KSD x 64 floats) followed by the dz2 and dz1 panels; two buffers of 4 blocks
     static constexpr int EXB = KSD * 64 + 4 * HB * 64;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     const float dt = a.dt, sqdt = a.sqdt;
 
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
-    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : 0.f);
+    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
     double sD = 0.0, sD2 = 0.0;
     if (wave_valid) {
         // per-lane-q views of the staged vectors
@@ -451,7 +451,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
                     for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
                 }
                 if (a.store_path) {
-                    // 1: xi (the backward pass reads it back, any noise mode); attached forward process (hjba_kernels.h):
+                    // 1: xi, or xi + sqrt(dt) Z when the forward process is NOT adaptive (then dL/dZ_n = w (Z dt + xi sqrt(dt))
+                    //    = w sqrt(dt) * image, the same expression the backward kernels evaluate); attached process (hjba_kernels.h):
                     // 2: xi - sqrt(dt) Z, 3: Z  -- the adjoint sweep replaces it by dL/dZ_n / sqrt(dt)
                     // (as an affine combination with wave-uniform coefficients: a nested vector select here was lowered to
                     // a switch whose Z arm read a stale accumulator)
@@ -650,9 +651,6 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
         return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
     stage_aop(lds + G::gW3T, HB, KSD, tid, nthr, [&](int row, int col) {
         return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
-    if (!a.adaptive)
-        stage_aop(lds + G::gW3, DB, KSH, tid, nthr, [&](int row, int col) {
-            return (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f; });
     stage_vec(lds + G::gb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
     __syncthreads();
 
@@ -714,23 +712,12 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
             f32x4 Gt[DB];
 #pragma unroll
             for (int m = 0; m < DB; ++m) Gt[m] = zero4;
-            if (!a.adaptive) {                                   // c = 0: the Z dt term survives
-                const f32x4* vb3 = opaque(vb3_0);
-                f32x4 h2z[HB];
-#pragma unroll
-                for (int m = 0; m < HB; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h2z[m][r] = pb[G::pH2 + (4 * m + r) * 64];
-#pragma unroll
-                for (int m = 0; m < DB; ++m) Gt[m] = vb3[m * 4];
-                gemm_T<DB, KSH, HB>(Gt, lds + G::gW3, h2z, lane);  // Z = W3 h2 + b3
-            }
 #pragma unroll
             for (int b = 0; b < DB; ++b) {
                 f32x4 xi;                                        // xi_{n+1} image stored by the forward kernel
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xi[r] = pb[G::pXi + (4 * b + r) * 64];
-                Gt[b] = wk * (dt * Gt[b] + sqdt * xi);
+                Gt[b] = (wk * sqdt) * xi;      // the image is xi (+ sqrt(dt) Z when the forward process is not adaptive)
             }
             // h2 / h1 are fetched right before the GEMM whose epilogue consumes them: the GEMM
             // (100 / 64 MFMAs) covers the load latency and the panels are not live during Philox

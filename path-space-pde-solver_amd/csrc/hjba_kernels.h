@@ -5,7 +5,7 @@
 // per-trajectory weights  mu_k = dL/dY_N[k],  nu_k = dL/dZsum_N[k]  (relative entropy: solver.py:179-180, 484-486)
 // the step  X_{n+1} = X_n + b(X_n) dt + B(-Z_n dt + xi sqrt(dt)),
 //           Y_{n+1} = Y_n + (f(X_{n+1}) - |Z_n|^2 / 2) dt + Z_n.xi sqrt(dt),   Zsum_{n+1} = Zsum_n + (|Z_n|^2 / 2 + f(X_{n+1})) dt
-// has the adjoint recursion (lambda_N = (nu - mu) grad g(X_N)):
+// has the adjoint recursion (lambda_N = (nu - mu) grad g(X_N), or wT grad g(X_N) with an explicit terminal weight):
 //     lambda'   = lambda_{n+1} + (mu + nu) dt grad f(X_{n+1})
 //     gZ_n      = mu (-Z_n dt + xi sqrt(dt)) + nu Z_n dt - dt B^T lambda'            (= dL/dZ_n, all paths)
 //     lambda_n  = lambda' + dt b'(X_n)^T lambda' + J_n^T gZ_n,      J_n = dZ_n/dX_n = W3 diag(1-h2^2) W2 diag(1-h1^2) W1x
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
     const float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
     const float coefW = (a.store_path == 3) ? nu * dt : mu * sqdt;
     const float wf = (mu + nu) * dt;                   // weight of grad f(X_{n+1})
+    const float wT = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);      // weight of grad g(X_N) in lambda_N
     const bool need_x = a.runcost_kind == RUN_DIAGQ || a.drift_kind == DRIFT_DWELL;
     const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::fVec) + q;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
                 if (a.term_kind == TERM_LINEAR) gg = tv[r];
                 else if (a.term_kind == TERM_DIAGQ) gg = 2.0f * tv[r] * x;
                 else gg = 2.0f * tv[r] * (x - 1.0f);
-                lam[b][r] = (nu - mu) * gg;
+                lam[b][r] = wT * gg;
             }
         }
     }

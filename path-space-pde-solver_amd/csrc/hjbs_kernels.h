@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         }
     float Yw = 0.f, Fw = 0.f;                          // this wave's partial of Y and of the running-cost integral
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
-    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : 0.f);
+    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
 
 #pragma unroll 1
     for (int n = 0; n < a.N; ++n) {

@@ -242,6 +242,8 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
     const float dt = a.dt, sqdt = a.sqdt;
     float* img = lds + W::fImg + wave * W::IMG;       // this wave's input image [KP][64]
     const bool store_path = a.store_path && wave_valid;
+    const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;
+    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
 
     double sD = 0.0, sD2 = 0.0;
     {
@@ -361,10 +363,11 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
                     }
-                    if (store_path) {
+                    if (store_path) {                  // image in the xi slot: c_xi xi + c_z Z (see hjb_fwd_kernel)
                         gwptr_t pxi = pbase(G::pXi + b * 256);
+                        const f32x4 wv = store_cxi * xi + store_cz * Zg[m];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pxi[r * 64 + ul] = xi[r];
+                        for (int r = 0; r < 4; ++r) pxi[r * 64 + ul] = wv[r];
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -401,8 +404,12 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
                 }
                 fX = qsum(fX);
             }
-            const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
-            Y = Y + drift_y * dt + Pz * sqdt;
+            if (a.loss_kind == LOSS_RELENT) {
+                Y = Y - (0.5f * S + fX) * dt;           // Y carries -Zsum (hjb_fwd_kernel)
+            } else {
+                const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
+                Y = Y + drift_y * dt + Pz * sqdt;
+            }
             Fsum = fmaf(fX, dt, Fsum);
             PSP_STAMP(ws6);
             PSP_ACC(0, ws1, ws0);   // X image + path store
@@ -724,6 +731,7 @@ __global__ __launch_bounds__(256) void hjbw_adj_kernel(const HjbArgs a) {
     const float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
     const float coefW = (a.store_path == 3) ? nu * dt : mu * sqdt;
     const float wf = (mu + nu) * dt;
+    const float wT = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);      // weight of grad g(X_N) in lambda_N
     float* img = lds + W::fImg + wave * W::IMG;
     const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds) + q;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -742,7 +750,7 @@ __global__ __launch_bounds__(256) void hjbw_adj_kernel(const HjbArgs a) {
                 if (a.term_kind == TERM_LINEAR) gg = tv[r];
                 else if (a.term_kind == TERM_DIAGQ) gg = 2.0f * tv[r] * x;
                 else gg = 2.0f * tv[r] * (x - 1.0f);
-                lam[b][r] = (nu - mu) * gg;
+                lam[b][r] = wT * gg;
             }
         }
     }

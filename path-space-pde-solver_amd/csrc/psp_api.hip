@@ -118,8 +118,6 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     p->ntile16 = (c->K_local + 15) / 16;
     if ((long long)c->N * p->ntile16 >= (1LL << 31)) return fail(-1, "N * ceil(K/16) must stay below 2^31");
     const int cus = n_cus();
-    if (p->inst.wide && !c->adaptive)
-        return fail(-2, "the wide kernels (this d) are built for adaptive_forward_process=True only");
     // forward: one 16-trajectory tile per wave; 1..8 waves per workgroup so that small K still spreads over CUs
     // (wide family: 1..4 waves, one per SIMD)
     int fw = (p->ntile16 + cus - 1) / cus;
@@ -141,7 +139,7 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     // adaptive runs use the role-specialised kernel (one 8-wave workgroup per CU) when its double-buffered
     // exchange area fits the LDS; PSP_BWD_VARIANT=1 forces the two-workgroups-per-CU kernel (A/B timing)
     static const char* force = getenv("PSP_BWD_VARIANT");
-    p->bwd_specialised = c->adaptive && p->inst.bwd2_lds_bytes() <= kMaxLds && !(force && force[0] == '1');
+    p->bwd_specialised = p->inst.bwd2_lds_bytes() <= kMaxLds && !(force && force[0] == '1');
     if (p->inst.wide) p->bwd_specialised = true;          // launch_bwd2 = hjbw_bwd_kernel (4 waves)
     p->bwd_waves = (p->bwd_specialised && !p->inst.wide) ? 8 : 4;
     long long g = nround;
@@ -461,7 +459,7 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
 }
 
 int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float* path, const float* XN,
-                          const float* mu, const float* nu, double* fwd_partial, void* stream) {
+                          const float* mu, const float* nu, const float* wT, double* fwd_partial, void* stream) {
     Plan p;
     int rc = make_plan(cfg, &p);
     if (rc) return rc;
@@ -473,7 +471,7 @@ int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float*
     if (!cfg->adaptive) return fail(-1, "without the adaptive forward process the state path carries no gradient");
     psp::HjbArgs a;
     fill_args(cfg, p, &a);
-    a.params = params; a.path = path; a.XN = const_cast<float*>(XN); a.adj_mu = mu; a.adj_nu = nu;
+    a.params = params; a.path = path; a.XN = const_cast<float*>(XN); a.adj_mu = mu; a.adj_nu = nu; a.adj_wT = wT;
     // the wide family keeps its (transposed) operand tables where the forward kernel kept its own: behind the partial
     // sums of the forward scratch, whatever forward variant wrote them
     a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);

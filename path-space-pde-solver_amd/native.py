@@ -78,7 +78,7 @@ SIGNATURES = {
     "psp_last_error": (C.c_char_p, []),
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_family": (C.c_int, [C.c_int32, C.c_int32]),
-    "psp_hjb_adjoint_sweep": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P, _P, _P, _P, _P]),
+    "psp_hjb_adjoint_sweep": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P, _P, _P, _P, _P, _P]),
     "psp_gen_instance_count": (C.c_int, []),
     "psp_gen_instance_get": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "psp_hjb_instance_count": (C.c_int, []),
@@ -159,7 +159,7 @@ def supported(d, H):
 
 
 def family(d, H):
-    """0 none, 1 narrow kernels, 2 wide kernels (large d, adaptive forward process only)."""
+    """0 none, 1 narrow kernels, 2 wide kernels (large d)."""
     return int(load().psp_hjb_family(int(d), int(H)))
 
 

@@ -67,9 +67,6 @@ def native_eligibility(solver):
     chosen, why = shapes.choose(probe, solver.d, shape[1])
     if chosen is None:
         return why
-    if solver.adaptive_forward_process and not solver.detach_forward and solver.loss_method == 'cross_entropy':
-        return ('cross_entropy with detach_forward=False also differentiates exp(-g(X_N)) through the state path '
-                '(not a function of Y_N - g(X_N) alone): composite plan')
     return None
 
 
@@ -161,6 +158,7 @@ class HjbNativePlan:
                 self.XN_k = torch.empty(self.K_local, self.d_pad, dtype=torch.float32, device=dev)
                 self.mu = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
                 self.nu = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
+                self.wT = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
         self.step = 0
         self.events = None   # bench.py: list collecting HIP-event pairs around the two rollout kernels
         # learnable Y_0 (solver.py:372-374): tiny Adam in torch on a 1-element tensor
@@ -242,15 +240,21 @@ class HjbNativePlan:
             ev[2].record()
         if self.attached:
             # per-trajectory weights mu = dL/dY_N, nu = dL/dZsum_N (global K and global mean: rank-independent)
+            wT = None
             if self.relent:
                 self.mu.zero_()
                 self.nu.fill_(1.0 / float(s.K))
             elif self.generic_loss:
                 self.mu.copy_(d_or_w)
+                if s.loss_method == 'cross_entropy':
+                    # mean(Y exp(-g(X_N) + Y.detach())) (solver.py:183-185) also depends on X_N through exp(-g):
+                    # lambda_N = -(Y_N exp(D) / K) grad g, while dL/dY_N = exp(D) / K
+                    wT = self.wT
+                    wT.copy_(-self.Yn * d_or_w)
             else:
                 self.mu.copy_(sharding.loss_weights(self.D, self.sums, s.K, s.loss_method))
             nat.check(lib.psp_hjb_adjoint_sweep(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.path), nat.ptr(self.XN_k),
-                                                nat.ptr(self.mu), nat.ptr(self.nu) if self.relent else None,
+                                                nat.ptr(self.mu), nat.ptr(self.nu) if self.relent else None, nat.ptr(wT),
                                                 nat.ptr(self.fwd_partial), st), 'psp_hjb_adjoint_sweep')
             self.w_bwd.fill_(1.0)                       # the sweep left dL/dZ_n / sqrt(dt) in the xi slot
             d_or_w, bcfg = self.w_bwd, self.cfg_w

@@ -234,6 +234,14 @@ CASES = [
          problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=10, d_1=5, d_2=5, T=0.3, eta=0.5, kappa=2.0)),
          solver=dict(HJB, detach_forward=False, loss_method="moment", learn_Y_0=True, L=4, lr=0.005, seed=42,
                      delta_t=0.01, K=160, u_l2_error_flag=False)),
+    dict(name="lqgc_d2_attached_cross_entropy", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
+         solver=dict(HJB, detach_forward=False, loss_method="cross_entropy", L=5, lr=0.01, seed=42, delta_t=0.05, K=128,
+                     u_l2_error_flag=False)),
+    dict(name="llgc_d200_nonadaptive_logvar", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=200, off_diag=0.1 / 200 ** 0.5, T=0.1, seed=42)),
+         solver=dict(HJB, adaptive_forward_process=False, L=3, lr=0.001, seed=42, delta_t=0.01, K=64, u_l2_error_flag=False),
+         net=dict(kind="tanh_mlp", widths=[64, 64], seed=123)),
     dict(name="lqgc_d4_relative_entropy", family="solver",
          problem=dict(kind="LQGC", kwargs=dict(d=4, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
          solver=dict(HJB, detach_forward=False, loss_method="relative_entropy", L=5, lr=0.01, seed=42, delta_t=0.05,

@@ -26,7 +26,8 @@ NATIVE_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_l
                 "lqgc_d2_variance", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive",
                 # gradients through the state path (adjoint sweep) and the relative-entropy loss
                 "lqgc_d2_attached_logvar", "llgc_d100_h64_attached_logvar", "dw_d10_attached_moment",
-                "lqgc_d4_relative_entropy", "llgc_d20_relative_entropy_detached"]
+                "lqgc_d4_relative_entropy", "llgc_d20_relative_entropy_detached",
+                "lqgc_d2_attached_cross_entropy", "llgc_d200_nonadaptive_logvar"]
 
 
 def dev():

@@ -17,6 +17,7 @@ SOLVER_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_l
                 "llgc_d300_h40_logvar",
                 "lqgc_d2_attached_logvar", "llgc_d100_h64_attached_logvar", "dw_d10_attached_moment",
                 "lqgc_d4_relative_entropy", "llgc_d20_relative_entropy_detached",
+                "lqgc_d2_attached_cross_entropy", "llgc_d200_nonadaptive_logvar",
                 "llgc_d100_densenet64_logvar", "dw_d10_logvar", "llgc_d20_diag_logvar",
                 "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive", "lqgc_d2_outer",
                 "lqgc_d2_variance", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
