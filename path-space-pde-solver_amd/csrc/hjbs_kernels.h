@@ -112,8 +112,12 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
     const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
 
+#ifdef PSP_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #pragma unroll 1
     for (int n = 0; n < a.N; ++n) {
+        PSP_STAMP(ss0);
         const float tn = a.tfeat ? a.tfeat[n] : (float)n * dt;
         const f32x4* vecs = opaque(vecs0);             // re-read the small vectors each step (no hoisting)
         const int qn = opaque_i(q);
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
             }
         }
         __syncthreads();
+        PSP_STAMP(ss1);
         // ---- P1: own hidden blocks of h1 = tanh(W1 [t, x] + b1) and the drift part of own state blocks, one k-loop
         f32x4 h1[NHo];
 #pragma unroll
@@ -149,14 +154,19 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
             float bx[KP];
 #pragma unroll
             for (int ks = 0; ks < KP; ++ks) bx[ks] = imgX[ks * 64 + lane];
+            if (denseA) {                              // (the wave-uniform test stays OUTSIDE the unrolled k-loop: inside, every
+#pragma unroll                                         // k-step became a branch with accumulator moves and hazard nops around it)
+                for (int ks = 0; ks < KP; ++ks) {
 #pragma unroll
-            for (int ks = 0; ks < KP; ++ks) {
-#pragma unroll
-                for (int io = 0; io < NHo; ++io) h1[io] = mfma16(w1r[io][ks], bx[ks], h1[io]);
-                if (denseA) {
+                    for (int io = 0; io < NHo; ++io) h1[io] = mfma16(w1r[io][ks], bx[ks], h1[io]);
 #pragma unroll
                     for (int io = 0; io < NBo; ++io) X[io] = mfma16(ar[io][ks], bx[ks], X[io]);
                 }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KP; ++ks)
+#pragma unroll
+                    for (int io = 0; io < NHo; ++io) h1[io] = mfma16(w1r[io][ks], bx[ks], h1[io]);
             }
         }
         if (a.drift_kind == DRIFT_DIAG) {
@@ -186,6 +196,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
             }
         }
         __syncthreads();
+        PSP_STAMP(ss2);
         // ---- P2: own hidden blocks of h2 = tanh(W2 h1 + b2)
         f32x4 h2[NHo];
 #pragma unroll
@@ -216,6 +227,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
             }
         }
         __syncthreads();
+        PSP_STAMP(ss3);
         // ---- P3: own state blocks of Z = W3 h2 + b3, Brownian increment, row-sum partials, increment panel v
         f32x4 Z[NBo];
 #pragma unroll
@@ -272,6 +284,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
                 }
             }
         }
+        PSP_STAMP(ss4);
         if (denseB) {
             __syncthreads();
             // ---- P4: X += B v for the own state blocks
@@ -301,7 +314,20 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
                            : (a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S)) * dt + Pz * sqdt;
         Yw += term;
         Fw = fmaf(fX, dt, Fw);
+        PSP_STAMP(ss5);
+        PSP_ACC(0, ss1, ss0);   // P0: X image + store + barrier
+        PSP_ACC(1, ss2, ss1);   // P1: W1 + drift product, tanh, h1 image + barrier
+        PSP_ACC(2, ss3, ss2);   // P2: W2 product, tanh, h2 image + barrier
+        PSP_ACC(3, ss4, ss3);   // P3: W3 product, Philox, v image
+        PSP_ACC(4, ss5, ss4);   // P4: barrier + sigma product + costs
+        PSP_ACC(6, ss5, ss0);
     }
+#ifdef PSP_STAMPS
+    if (a.dbg && lane == 0) {
+        stamps[7] = (unsigned long long)a.N;
+        for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+    }
+#endif
 
     // ---- terminal cost over the own blocks; the four partials of a trajectory meet in LDS
     float g = 0.f;
