@@ -194,13 +194,25 @@ int psp_hjb_control_eval(int32_t d, int32_t H, const float* params, const float*
                          float* minus_Z_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * GeneralSolver.train hot path (reference solver.py:1001-1206): diffusion / BSDE loss on unbounded
- * domains, V = DenseNet(d+1 -> 1, two hidden layers of width H, relu^2; function_space.py:116-140).
+ * GeneralSolver.train hot path (reference solver.py:1001-1206): diffusion / BSDE loss on unbounded and bounded
+ * (sphere / box) domains, V = DenseNet(d+1 -> 1, two hidden layers of width H, relu^2; function_space.py:116-140).
+ * EllipticSolver.train (solver.py:628-826, V = DenseNet(d -> 1)) runs through the same entry points with T = +inf
+ * and a zero time row in the parameter map (the padded-shape index map of the host adds it).
  * Flat parameter layout = the DenseNet's registration order, weights stored (in, out), input [x, t]:
  *     [W1 ((d+1) x H), b1 (H), W2 ((d+1+H) x H), b2 (H), W3 (d+1+2H), b3 (1)]
  * ------------------------------------------------------------------------------------------------ */
-/* nonlinearity h(t,x,y,z): problems.py:1755 (0), :519 (-|z|^2/2), :1204 (y - y^3) */
-enum { PSP_GH_ZERO = 0, PSP_GH_QUAD = 1, PSP_GH_ALLEN_CAHN = 2 };
+/* nonlinearity h(t,x,y,z): problems.py:1755 (0), :519 (-|z|^2/2), :1204 (y - y^3), and the exponential-on-the-ball
+ * family  h = -2 al y (2 al |x|^2 + d) - e y + nl,  nl = 0 (LIN: problems.py:985, :1130 with e = 1),
+ * E - y^2 (SQ: :1022), sin(E - y^2) (SIN: :1058, :1166 with e = 1 and the time term), E = exp(2 al |x|^2 + 2 tau t_n);
+ * h_par = {al, d, e, tau} */
+enum { PSP_GH_ZERO = 0, PSP_GH_QUAD = 1, PSP_GH_ALLEN_CAHN = 2, PSP_GH_EXPBALL_LIN = 3, PSP_GH_EXPBALL_SQ = 4,
+       PSP_GH_EXPBALL_SIN = 5 };
+/* exit test of a bounded domain: a trajectory stays active while (solver.py:1119-1129; EllipticSolver :758-767)
+ *   SPHERE        |X_n| < dom_a               (the state BEFORE the move, as the reference tests it)
+ *   BOX           dom_a <= X_proposal <= dom_b in every coordinate
+ *   BOX_UPPER_ALL X_proposal <= dom_b in every coordinate   (EllipticSolver, one_boundary)
+ *   BOX_UPPER_ANY X_proposal <= dom_b in some coordinate    (GeneralSolver, one_boundary) */
+enum { PSP_DOM_NONE = 0, PSP_DOM_SPHERE = 1, PSP_DOM_BOX = 2, PSP_DOM_BOX_UPPER_ALL = 3, PSP_DOM_BOX_UPPER_ANY = 4 };
 
 typedef struct psp_gen_config {
     int32_t d, H, K_local, N;
@@ -213,8 +225,10 @@ typedef struct psp_gen_config {
     int32_t adaptive;     /* 1: c = -Z detached (solver.py:1111-1114), 0: c = 0              */
     int32_t noise_mode;   /* PSP_NOISE_SUPPLIED: xi is (N, K_local, d); PSP_NOISE_PHILOX      */
     int32_t store_path;   /* 1: keep what the backward pass needs                            */
-    int32_t reserved;
+    int32_t domain_kind;  /* PSP_DOM_*                                                         */
     const float* drift;   /* DOUBLE_WELL: kappa (d); else NULL                               */
+    float dom_a, dom_b;   /* sphere radius (dom_a) or box bounds X_l, X_r                     */
+    float h_par[4];       /* PSP_GH_EXPBALL_*: al, d (the REAL dimension, not a padded one), e, tau */
 } psp_gen_config;
 
 typedef struct psp_gen_sizes {

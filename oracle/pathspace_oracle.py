@@ -143,7 +143,87 @@ def problem_heat(d=1, T=1, seed=42) -> OracleProblem:
         extra=dict(boundary="unbounded", boundary_distance=1.0))     # :1741-1743
 
 
+def _exp_ball(kind, d, alpha, T, parabolic, extra_y, nonlinear, boundary_type):
+    """The exponential-on-the-ball family (problems.py:962-993 ExponentialOnSphere, :995-1029 ExponentialOnBallNonlinear,
+    :1031-1065 ExponentialOnBallNonlinearSin, :1137-1172 ExponentialOnSphereNonlinearParabolic):
+    sigma = sqrt(2) I, b = 0, unit ball, v_true = exp(alpha |x|^2 [+ t])."""
+    B = torch.sqrt(torch.tensor(2.0)) * torch.eye(d)                 # :967, :1000, :1036, :1142
+    r2 = lambda x: torch.sum(x ** 2, 1)
+
+    def h_elliptic(x, y, z):
+        if nonlinear == "none":
+            return -alpha * y * (alpha * 4 * r2(x) + 2 * d)          # :985
+        lin = -2 * alpha * y * (alpha * 2 * r2(x) + d)
+        if nonlinear == "sq":
+            return lin + torch.exp(2 * alpha * r2(x)) - y ** 2       # :1022
+        return lin + torch.sin(torch.exp(2 * alpha * r2(x)) - y ** 2)    # :1058
+
+    def h_parabolic(t, x, y, z):                                     # :1166
+        return -2 * alpha * y * (alpha * 2 * r2(x) + d) - y + torch.sin(torch.exp(2 * alpha * r2(x) + 2 * t) - y ** 2)
+
+    if parabolic:
+        def g(x, t):                                                 # :1159-1163
+            if boundary_type == "Neumann":
+                return 2 * alpha * x * torch.exp(alpha * r2(x) + t).unsqueeze(1)
+            return torch.exp(alpha * r2(x) + t)
+        f = lambda x: torch.exp(alpha * r2(x) + T)                   # :1157
+        v_true = lambda x, t: torch.exp(alpha * r2(x) + t)
+    else:
+        def g(x):                                                    # :982, :1016-1019
+            if boundary_type == "Neumann":
+                return 2 * alpha * x * torch.exp(alpha * r2(x)).unsqueeze(1)
+            return torch.exp(alpha * r2(x))
+        f = lambda x, t=None: torch.zeros(x.shape[0])
+        v_true = lambda x: torch.exp(alpha * r2(x))
+    return OracleProblem(
+        kind=kind, d=d, T=T, X_0=torch.zeros(d), B=B, b=lambda x: torch.zeros(x.shape), sigma=lambda x: B,
+        h=h_parabolic if parabolic else h_elliptic, f=f, g=g,
+        extra=dict(boundary="sphere", boundary_distance=1.0, boundary_type=boundary_type, v_true=v_true))
+
+
+def problem_exp_sphere(d=2, alpha=1.0) -> OracleProblem:
+    return _exp_ball("ExponentialOnSphere", d, alpha, None, False, 0, "none", "Dirichlet")
+
+
+def problem_exp_ball_nonlinear(d=2, alpha=1.0, boundary_type="Dirichlet") -> OracleProblem:
+    return _exp_ball("ExponentialOnBallNonlinear", d, alpha, None, False, 0, "sq", boundary_type)
+
+
+def problem_exp_ball_nonlinear_sin(d=2, alpha=1.0, boundary_type="Dirichlet") -> OracleProblem:
+    return _exp_ball("ExponentialOnBallNonlinearSin", d, alpha, None, False, 0, "sin", boundary_type)
+
+
+def problem_exp_sphere_nonlinear_parabolic(d=2, T=1.0, alpha=1.0, boundary_type="Dirichlet") -> OracleProblem:
+    """boundary_type is an attribute the reference class fixes to 'Dirichlet' (:1148); callers set 'Neumann' on the
+    instance (the Neumann notebook), which is what the keyword stands for here."""
+    return _exp_ball("ExponentialOnSphereNonlinearParabolic", d, alpha, T, True, 1, "sin", boundary_type)
+
+
+def problem_quadratic_on_box(d=2, T=0.5, X_l=-1.0, X_r=1.0, one_boundary=False, scale=1.0, parabolic=True,
+                             quad_h=True) -> OracleProblem:
+    """NOT a reference class: a duck-typed problem on the box [X_l, X_r]^d that pins the 'square' exit
+    tests (solver.py:1125-1129, :762-767) with coefficients the kernels have: b = 0, sigma = scale I,
+    h = -|z|^2/2 (or 0), boundary/terminal data |x|^2.  The golden script hands the same object to the reference solvers."""
+    B = scale * torch.eye(d)
+    hq = (lambda z: -0.5 * torch.sum(z ** 2, dim=1)) if quad_h else (lambda z: torch.zeros(z.shape[0]))
+    q = lambda x: torch.sum(x ** 2, 1)
+    if parabolic:
+        h, f, g = (lambda t, x, y, z: hq(z)), (lambda x: q(x)), (lambda x, t: q(x) + (T - t))
+        v_true = lambda x, t: q(x)
+    else:
+        h, f, g = (lambda x, y, z: hq(z)), (lambda x, t=None: torch.zeros(x.shape[0])), (lambda x: q(x))
+        v_true = lambda x: q(x)
+    return OracleProblem(kind="QuadraticOnBox", d=d, T=T, X_0=torch.zeros(d), B=B, b=lambda x: torch.zeros(x.shape),
+                         sigma=lambda x: B, h=h, f=f, g=g,
+                         extra=dict(boundary="square", X_l=X_l, X_r=X_r, one_boundary=one_boundary,
+                                    boundary_type="Dirichlet", v_true=v_true))
+
+
 PROBLEMS = {
+    "ExponentialOnSphere": problem_exp_sphere, "ExponentialOnBallNonlinear": problem_exp_ball_nonlinear,
+    "ExponentialOnBallNonlinearSin": problem_exp_ball_nonlinear_sin,
+    "ExponentialOnSphereNonlinearParabolic": problem_exp_sphere_nonlinear_parabolic,
+    "QuadraticOnBox": problem_quadratic_on_box,
     "LLGC": problem_llgc, "LQGC": problem_lqgc, "DoubleWell_multidim": problem_double_well,
     "DoubleWell_multidim_for_general_solver": problem_double_well_general,
     "AllenCahn": problem_allen_cahn, "HeatEquation": problem_heat,
@@ -392,7 +472,7 @@ def control_on_grid(z, X, t, delta_t, N, time_approx="inner"):
 
 
 # --------------------------------------------------------------------------------------
-# GeneralSolver.train restatement (reference solver.py:1001-1206), unbounded domains
+# GeneralSolver.train restatement (reference solver.py:1001-1206), unbounded and bounded (sphere / square) domains
 # --------------------------------------------------------------------------------------
 @dataclass
 class GeneralConfig:
@@ -416,21 +496,69 @@ def general_build(problem: OracleProblem, cfg: GeneralConfig, arch=None):
     return DenseNetOracle(problem.d + 1, 1, cfg.lr, seed=cfg.seed, **kw)    # :980
 
 
+def sample_boundary(problem: OracleProblem, Kb: int):
+    """Uniform points on the boundary (solver.py:1020-1038 == :650-680).  The square variant shuffles with numpy's
+    GLOBAL generator (np.random.shuffle), as the reference does."""
+    d, ex = problem.d, problem.extra
+    if ex["boundary"] == "sphere":
+        Xb = torch.randn(Kb, d)                                      # :1021
+        return ex["boundary_distance"] * Xb / torch.sqrt(torch.sum(Xb ** 2, 1)).unsqueeze(1)    # :1022
+    assert ex["boundary"] == "square"
+    half = int(Kb / 2)
+    sel = np.concatenate([np.ones(half)[:, np.newaxis], np.zeros([half, d - 1])], 1)     # :1029
+    np.apply_along_axis(np.random.shuffle, 1, sel)                   # :1030
+    a = np.concatenate([sel, np.zeros([half, d])]).astype(bool)      # :1031
+    b = np.concatenate([np.zeros([half, d]), sel]).astype(bool)      # :1032
+    X_l, X_r = ex["X_l"], ex["X_r"]
+    Xb = (X_r - X_l) * torch.rand(Kb, d) + X_l                       # :1033
+    Xb[torch.tensor(a.astype(float)).bool()] = X_l                   # :1034
+    Xb[torch.tensor(b.astype(float)).bool()] = X_r                   # :1035
+    if ex["one_boundary"]:
+        Xb[torch.tensor(a.astype(float)).bool()] = X_r               # :1037
+        Xb[torch.tensor(b.astype(float)).bool()] = X_r               # :1038
+    return Xb
+
+
+def exit_test(problem: OracleProblem, X, X_prop, elliptic: bool):
+    """new_selection of solver.py:1119-1129 (GeneralSolver) / :758-767 (EllipticSolver)."""
+    ex = problem.extra
+    if ex["boundary"] == "sphere":
+        return torch.all(torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) < ex["boundary_distance"], 1)   # :1121 (X, not the proposal)
+    if ex["boundary"] == "square":
+        if ex["one_boundary"]:
+            le = X_prop <= ex["X_r"]
+            return torch.all(le, 1) if elliptic else torch.any(le, 1)            # :764 vs :1127
+        return torch.all((X_prop >= ex["X_l"]) & (X_prop <= ex["X_r"]), 1)       # :1129
+    return torch.ones(X.shape[0]).bool()
+
+
+def neumann_residual(V, Xb_in, g_val, d):
+    """mean((grad_x V . x - g . x)^2) on the boundary batch (solver.py:1069-1074, :688-693)."""
+    Xb_in = Xb_in.clone().requires_grad_(True)
+    Y_eval = V(Xb_in).squeeze().sum()
+    grad_V, = torch.autograd.grad(Y_eval, Xb_in, create_graph=True)
+    xb = Xb_in[:, :d]
+    return torch.mean((torch.sum(grad_V[:, :d] * xb, 1) - torch.sum(g_val * xb, 1)) ** 2)
+
+
 def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=False):
     """Restates GeneralSolver.train for loss_method in {'diffusion','BSDE'} on
-    boundary in {'unbounded','unbounded_square'} (solver.py:1001-1206)."""
+    boundary in {'unbounded','unbounded_square','sphere','square'} (solver.py:1001-1206)."""
     if V is None:
         V = general_build(problem, cfg)
     dt32 = torch.tensor(cfg.delta_t)                                 # :950
     sq_dt32 = torch.sqrt(dt32)                                       # :951
     K, d, T = cfg.K, problem.d, problem.T
     bnd = problem.extra["boundary"]
-    assert "unbounded" in bnd
+    bounded = "unbounded" not in bnd
+    btype = problem.extra.get("boundary_type")
     out = dict(loss_log=[], K_log=[], traces=[])
     torch.manual_seed(cfg.seed)                                      # :1003
     for l in range(cfg.L):
         loss = 0
-        if bnd == "unbounded":
+        if bounded:
+            X_boundary = sample_boundary(problem, cfg.K_boundary)    # :1020-1038
+        if bnd in ("unbounded", "sphere"):                           # :1040
             if cfg.uniform_square:
                 X = torch.rand(K, d) * 2 - 1                         # :1042
                 X = problem.extra["boundary_distance"] * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) \
@@ -442,10 +570,17 @@ def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=Fals
         else:
             X_l, X_r = problem.extra["X_l"], problem.extra["X_r"]
             X = (X_r - X_l) * torch.rand(K, d) + X_l                 # :1056
+        if bounded:
+            t_b = torch.rand(cfg.K_boundary, 1) * T                  # :1059
+            X_t_b = torch.cat([X_boundary, t_b], 1)                  # :1060
         if cfg.loss_method != "BSDE":                                # :1062 (boundary_loss=True)
             Kb = cfg.K_boundary
             X_T = torch.cat([X[:Kb, :], T * torch.ones(Kb).unsqueeze(1)], 1)    # :1063
             loss = loss + cfg.alpha[1] * torch.mean((V(X_T).squeeze() - problem.f(X[:Kb, :])) ** 2)   # :1064
+            if bounded and btype == "Dirichlet":                     # :1066-1067
+                loss = loss + cfg.alpha[2] * torch.mean((V(X_t_b).squeeze() - problem.g(X_boundary, t_b.squeeze())) ** 2)
+            elif bounded and btype == "Neumann":                     # :1068-1074
+                loss = loss + cfg.alpha[2] * neumann_residual(V, X_t_b, problem.g(X_boundary, t_b.squeeze()), d)
         X = X.clone().requires_grad_(True)                           # :1076
         t_n = torch.rand(K, 1) * T                                   # :1078
         X_t_n = torch.cat([X, t_n], 1)                               # :1079
@@ -471,7 +606,7 @@ def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=Fals
             sel = (~stopped).float().unsqueeze(1).repeat(1, d)
             X_prop = (X + ((problem.b(X) + torch.mm(problem.sigma(X), c).t()) * dt32
                            + torch.mm(problem.sigma(X), xi.t()).t() * sq_dt32) * sel)   # :1116-1117
-            new_sel = torch.ones(K).bool()                           # :1119
+            new_sel = exit_test(problem, X, X_prop, elliptic=False)  # :1119-1129
             new_sel = new_sel & ((t_n.squeeze() + dt32) <= T)        # :1131
             act = (new_sel & ~stopped)
             Y = (Y + ((-problem.h(n * dt32, X, Y_.squeeze(), Z) + torch.sum(Z * c.t(), 1)) * dt32
@@ -487,13 +622,125 @@ def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=Fals
         V.zero_grad()                                                # :1164
         out["K_log"].append(int(K_count))                            # :1168
         if cfg.loss_method == "BSDE":
-            loss = loss + torch.mean((Y - problem.f(X)) ** 2)        # :1174
+            if not bounded:
+                loss = loss + torch.mean((Y - problem.f(X)) ** 2)    # :1174
+            elif btype == "Dirichlet":
+                loss = loss + torch.mean((Y - problem.g(X, t_n.squeeze())) ** 2)     # :1176
+            else:
+                raise NotImplementedError("BSDE loss with a Neumann boundary (solver.py:1177-1183) is not restated")
         loss.backward()                                              # :1187
         if trace:
             tr["grads"] = [p.grad.detach().clone() for p in V.parameters()]
             tr["VN_minus_Y"] = None
         V.optim.step()                                               # :1188
         out["loss_log"].append(loss.item())                          # :1192
+        if trace:
+            out["traces"].append(tr)
+    out["V"] = V
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# EllipticSolver.train restatement (reference solver.py:628-826): diffusion / BSDE loss, exit-time problems
+# --------------------------------------------------------------------------------------
+@dataclass
+class EllipticConfig:
+    K: int
+    N: int
+    delta_t: float
+    lr: float = 0.001
+    L: int = 1
+    seed: int = 42
+    K_boundary: int = 50
+    alpha: tuple = (1.0, 1.0)
+    loss_method: str = "diffusion"
+    adaptive_forward_process: bool = False
+    detach_forward: bool = True
+    boundary_type: str = "Dirichlet"
+    uniform_square: bool = False
+
+
+def elliptic_build(problem: OracleProblem, cfg: EllipticConfig, arch=None):
+    torch.manual_seed(cfg.seed)                                      # :604
+    kw = {} if arch is None else dict(arch=arch)
+    return DenseNetOracle(problem.d, 1, cfg.lr, seed=cfg.seed, **kw)     # :606
+
+
+def elliptic_train(problem: OracleProblem, cfg: EllipticConfig, V=None, trace=False):
+    """Restates EllipticSolver.train for loss_method in {'diffusion','BSDE'} on boundary in {'sphere','square'}."""
+    if V is None:
+        V = elliptic_build(problem, cfg)
+    dt32 = torch.tensor(cfg.delta_t)                                 # :576
+    sq_dt32 = torch.sqrt(dt32)                                       # :577
+    K, d, ex = cfg.K, problem.d, problem.extra
+    out = dict(loss_log=[], K_log=[], V_L2_log=[], traces=[])
+    torch.manual_seed(cfg.seed)                                      # :630
+    np.random.seed(cfg.seed)                                         # :631
+    for l in range(cfg.L):
+        loss = 0
+        X_boundary = sample_boundary(problem, cfg.K_boundary)        # :650-680
+        if cfg.loss_method != "BSDE":                                # :683 (boundary_loss=True)
+            if cfg.boundary_type == "Dirichlet":
+                loss = loss + cfg.alpha[1] * torch.mean((V(X_boundary).squeeze() - problem.g(X_boundary)) ** 2)   # :685
+            else:
+                loss = loss + cfg.alpha[1] * neumann_residual(V, X_boundary, problem.g(X_boundary), d)           # :687-693
+        if ex["boundary"] == "sphere":
+            if cfg.uniform_square:
+                X = torch.rand(K, d) * 2 - 1                         # :697
+                X = ex["boundary_distance"] * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * (torch.rand(K).unsqueeze(1))
+            else:
+                X = torch.randn(K, d)                                # :700
+                X = ex["boundary_distance"] * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) \
+                    * (torch.rand(K).unsqueeze(1) ** (1 / d))        # :701
+        else:
+            X = (ex["X_r"] - ex["X_l"]) * torch.rand(K, d) + ex["X_l"]       # :713
+        X = X.clone().requires_grad_(True)                           # :718
+        Y = V(X).squeeze()                                           # :721
+        stopped = torch.zeros(K).bool()                              # :724
+        V_L2 = torch.zeros(K)
+        K_count = 0
+        tr = dict(X0=X.detach().clone(), xi=[]) if trace else None
+        for n in range(cfg.N):
+            Y_ = V(X)                                                # :733
+            Y_eval = Y_.squeeze().sum()
+            Z, = torch.autograd.grad(Y_eval, X, create_graph=True)   # :736
+            Z = torch.mm(problem.sigma(X).t(), Z.t()).t()            # :737
+            xi = torch.randn(K, d)                                   # :739  (drawn BEFORE the all-stopped test)
+            selection = ~stopped
+            if torch.sum(selection) == 0:                            # :742-744
+                break
+            if trace:
+                tr["xi"].append(xi.clone())
+            V_L2[selection] += ((V(X[selection]).squeeze() - ex["v_true"](X[selection].detach()).float().squeeze()) ** 2
+                                ).detach() * cfg.delta_t             # :746
+            c = torch.zeros(d, K)                                    # :748
+            if cfg.adaptive_forward_process:
+                c = -Z.t()
+            if cfg.detach_forward:
+                c = c.detach()
+            sel = selection.float().unsqueeze(1).repeat(1, d)
+            X_prop = (X + ((problem.b(X) + torch.mm(problem.sigma(X), c).t()) * dt32
+                           + torch.mm(problem.sigma(X), xi.t()).t() * sq_dt32) * sel)    # :754-755
+            new_sel = exit_test(problem, X, X_prop, elliptic=True)   # :758-767
+            act = new_sel & ~stopped
+            Y = (Y + ((-problem.h(X, Y_.squeeze(), Z) + torch.sum(Z * c.t(), 1)) * dt32
+                      + torch.sum(Z * xi, 1) * sq_dt32) * act.float())        # :776-777
+            X = (X * (~new_sel | stopped).float().unsqueeze(1).repeat(1, d)
+                 + X_prop * act.float().unsqueeze(1).repeat(1, d))   # :780-781
+            K_count = K_count + torch.sum(act)                       # :784
+            stopped = stopped | (~new_sel & ~stopped)                # :786-787
+        if cfg.loss_method == "diffusion":
+            loss = loss + cfg.alpha[0] * torch.mean((V(X).squeeze() - Y) ** 2)   # :799
+        out["K_log"].append(int(K_count))                            # :803
+        if cfg.loss_method == "BSDE":
+            loss = loss + torch.mean((problem.g(X) - Y) ** 2)        # :808
+        V.zero_grad()                                                # :813
+        loss.backward()                                              # :814
+        if trace:
+            tr["grads"] = [p.grad.detach().clone() for p in V.parameters()]
+        V.optim.step()                                               # :815
+        out["loss_log"].append(loss.item())                          # :819
+        out["V_L2_log"].append(torch.mean(V_L2).item())              # :820
         if trace:
             out["traces"].append(tr)
     out["V"] = V

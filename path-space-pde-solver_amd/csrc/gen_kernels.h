@@ -15,7 +15,9 @@
 
 namespace psp {
 
-enum { GH_ZERO = 0, GH_QUAD = 1, GH_ALLEN_CAHN = 2 };
+enum { GH_ZERO = 0, GH_QUAD = 1, GH_ALLEN_CAHN = 2, GH_EXPBALL_LIN = 3, GH_EXPBALL_SQ = 4, GH_EXPBALL_SIN = 5 };
+// exit test of a bounded domain (solver.py:1119-1129, :758-767): sphere |X_n| < a (the state BEFORE the move), boxes on the proposal
+enum { DOM_NONE = 0, DOM_SPHERE = 1, DOM_BOX = 2, DOM_BOX_UPPER_ALL = 3, DOM_BOX_UPPER_ANY = 4 };
 
 struct GenArgs {
     const float* params;
@@ -37,6 +39,9 @@ struct GenArgs {
     int K_local, N, ntile16;
     float dt, sqdt, T, sigma_scale;
     int drift_kind, h_kind, adaptive, noise_mode, store_path;
+    int domain_kind;      // DOM_*
+    float dom_a, dom_b;   // sphere radius / box bounds X_l, X_r
+    float h_par[4];       // GH_EXPBALL_*: alpha, d (real dimension), coefficient of the extra -y, 1 if the exponent carries 2 t
     uint32_t seed_lo, seed_hi, iter;
 };
 
@@ -219,13 +224,8 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             gemm_T<DBI, KSH, HB>(gx, lds + G::fW2xr, gz2, lane);
             gemm_T<DBI, KSH, HB>(gx, lds + G::fW1r, gz1, lane);
             // Z = sigma^T grad_x V (sigma = s I), state features only (solver.py:1104)
-            const bool in_time = (t + dt) <= Tend;                   // solver.py:1131 (fp32)
-            const bool act = in_time && !stopped;
-            const float actf = act ? 1.f : 0.f, alivef = stopped ? 0.f : 1.f;
-            float S = 0.f, Pz = 0.f;
-            f32x4 U[DBI];                                            // s * u^ : tangent direction in x-space
-#pragma unroll
-            for (int b = 0; b < DBI; ++b) {
+            const float alivef = stopped ? 0.f : 1.f;
+            auto noise_block = [&](int b) __attribute__((always_inline)) {
                 f32x4 xi;
                 if (a.noise_mode == NOISE_PHILOX) {
                     xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
@@ -237,12 +237,68 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                         xi[r] = xrow[f < D ? f : D - 1];
                     }
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xi[r] = ((16 * b + 4 * r + q) < D && kvalid) ? xi[r] : 0.f;
+                return xi;
+            };
+            auto z_block = [&](int b) __attribute__((always_inline)) {
                 f32x4 Z;
 #pragma unroll
+                for (int r = 0; r < 4; ++r) Z[r] = ((16 * b + 4 * r + q) < D) ? sig * gx[b][r] : 0.f;
+                return Z;
+            };
+            // (X_proposal - X) of solver.py:1116-1117: ((b(X) + sigma c) dt + sigma xi sqrt(dt)) * alive,  c = -Z (adaptive) or 0
+            auto move_block = [&](int b, const f32x4& Z, const f32x4& xi) __attribute__((always_inline)) {
+                const f32x4 cdt = a.adaptive ? (-dt) * Z : 0.f * Z;
+                f32x4 drift = 0.f * Z;
+                if (a.drift_kind == DRIFT_DWELL) drift = -(4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
+                const f32x4 step = (drift * dt + sig * cdt + (sig * sqdt) * xi) * alivef;
+                return step;
+            };
+            // ---- exit test of a bounded domain (solver.py:1119-1129; EllipticSolver :758-767) and |x|^2 for the x-dependent h
+            float rr = 0.f;
+            if (a.domain_kind == DOM_SPHERE || a.h_kind >= GH_EXPBALL_LIN) {
+#pragma unroll
+                for (int b = 0; b < DBI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((16 * b + 4 * r + q) < D) rr = fmaf(X[b][r], X[b][r], rr);
+                rr = qsum(rr);
+            }
+            bool inside = true;
+            if (a.domain_kind == DOM_SPHERE) {
+                inside = sqrtf(rr) < a.dom_a;                        // the state BEFORE the move (:1121)
+            } else if (a.domain_kind >= DOM_BOX) {
+                // the boxes test the PROPOSAL (:1126-1129): one extra pass over the blocks (noise regenerated: the
+                // move itself needs the verdict, and keeping both images would cost the unbounded case registers)
+                float n_out = 0.f, n_le = 0.f;
+#pragma unroll
+                for (int b = 0; b < DBI; ++b) {
+                    const f32x4 xi = noise_block(b);
+                    const f32x4 Xp = X[b] + move_block(b, z_block(b), xi);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if ((16 * b + 4 * r + q) < D) {
+                            const bool lo_ok = a.domain_kind != DOM_BOX || Xp[r] >= a.dom_a, hi_ok = Xp[r] <= a.dom_b;
+                            n_out += (lo_ok && hi_ok) ? 0.f : 1.f;
+                            n_le += hi_ok ? 1.f : 0.f;
+                        }
+                    }
+                }
+                n_out = qsum(n_out); n_le = qsum(n_le);
+                inside = a.domain_kind == DOM_BOX_UPPER_ANY ? n_le > 0.f : n_out == 0.f;
+            }
+            const bool in_time = inside && (t + dt) <= Tend;         // new_selection of solver.py:1119-1131 (fp32)
+            const bool act = in_time && !stopped;
+            const float actf = act ? 1.f : 0.f;
+            float S = 0.f, Pz = 0.f;
+            f32x4 U[DBI];                                            // s * u^ : tangent direction in x-space
+#pragma unroll
+            for (int b = 0; b < DBI; ++b) {
+                const f32x4 xi = noise_block(b);
+                const f32x4 Z = z_block(b);
+#pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool fx = (16 * b + 4 * r + q) < D;
-                    xi[r] = (fx && kvalid) ? xi[r] : 0.f;
-                    Z[r] = fx ? sig * gx[b][r] : 0.f;
                     S = fmaf(Z[r], Z[r], S);
                     Pz = fmaf(Z[r], xi[r], Pz);
                 }
@@ -252,10 +308,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 f32x4 u = sqdt * xi + cdt;
                 if (a.h_kind == GH_QUAD) u += dt * Z;
                 U[b] = (actf * sig) * u;
-                // X_proposal = X + ((b(X) + sigma c) dt + sigma xi sqrt(dt)) * alive  (solver.py:1116-1117)
-                f32x4 drift = 0.f * Z;
-                if (a.drift_kind == DRIFT_DWELL) drift = -(4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
-                f32x4 step = (drift * dt + sig * cdt + (sig * sqdt) * xi) * alivef;
+                const f32x4 step = move_block(b, Z, xi);
                 f32x4 Xn;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -278,6 +331,20 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             float minus_h = 0.f, hy = 0.f;
             if (a.h_kind == GH_QUAD) minus_h = 0.5f * S;
             else if (a.h_kind == GH_ALLEN_CAHN) { minus_h = -(Vnow - Vnow * Vnow * Vnow); hy = 1.0f - 3.0f * Vnow * Vnow; }
+            else if (a.h_kind >= GH_EXPBALL_LIN) {
+                // h = -2 al y (2 al |x|^2 + d) - e y + {0, E - y^2, sin(E - y^2)},  E = exp(2 al |x|^2 + 2 t), t = n dt
+                // (problems.py:985, :1022, :1058, :1130, :1166; h sees y = V(X,t), solver.py:1141)
+                const float al = a.h_par[0];
+                const float lin = 2.0f * al * (2.0f * al * rr + a.h_par[1]) + a.h_par[2];
+                float nl = 0.f, nly = 0.f;
+                if (a.h_kind != GH_EXPBALL_LIN) {
+                    const float arg = expf(2.0f * al * rr + 2.0f * a.h_par[3] * ((float)n * dt)) - Vnow * Vnow;
+                    if (a.h_kind == GH_EXPBALL_SQ) { nl = arg; nly = -2.0f * Vnow; }
+                    else { nl = sinf(arg); nly = -2.0f * Vnow * cosf(arg); }
+                }
+                minus_h = Vnow * lin - nl;
+                hy = nly - lin;
+            }
             const float zc = a.adaptive ? -S : 0.f;
             Y = Y + ((minus_h + zc) * dt + Pz * sqdt) * actf;
             if (a.store_path) {

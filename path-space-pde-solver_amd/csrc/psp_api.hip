@@ -186,8 +186,11 @@ int make_gen_plan(const psp_gen_config* c, GenPlan* p) {
         return -2;
     }
     if ((c->drift_kind != PSP_DRIFT_ZERO && c->drift_kind != PSP_DRIFT_DOUBLE_WELL) || c->h_kind < 0 ||
-        c->h_kind > 2 || c->noise_mode < 0 || c->noise_mode > 1)
+        c->h_kind > PSP_GH_EXPBALL_SIN || c->noise_mode < 0 || c->noise_mode > 1 || c->domain_kind < 0 ||
+        c->domain_kind > PSP_DOM_BOX_UPPER_ANY)
         return fail(-1, "config enum out of range");
+    if (c->domain_kind == PSP_DOM_SPHERE && !(c->dom_a > 0.f)) return fail(-1, "sphere radius must be positive");
+    if (c->domain_kind == PSP_DOM_BOX && !(c->dom_a < c->dom_b)) return fail(-1, "box bounds must satisfy X_l < X_r");
     if (c->drift_kind == PSP_DRIFT_DOUBLE_WELL && !c->drift) return fail(-1, "double-well kappa vector missing");
     if (p->inst.fwd_lds_bytes() > kMaxLds || p->inst.bwd_lds_bytes() > kMaxLds)
         return fail(-3, "GeneralSolver kernel tables do not fit the 160 KiB LDS for this (d,H)");
@@ -215,6 +218,8 @@ void fill_gen_args(const psp_gen_config* c, const GenPlan& p, psp::GenArgs* a) {
     a->dt = c->dt; a->sqdt = c->sqrt_dt; a->T = c->T; a->sigma_scale = c->sigma_scale;
     a->drift_kind = c->drift_kind; a->h_kind = c->h_kind; a->adaptive = c->adaptive;
     a->noise_mode = c->noise_mode; a->store_path = c->store_path;
+    a->domain_kind = c->domain_kind; a->dom_a = c->dom_a; a->dom_b = c->dom_b;
+    for (int i = 0; i < 4; ++i) a->h_par[i] = c->h_par[i];
 }
 
 // ---- small kernels -------------------------------------------------------------------

@@ -21,7 +21,8 @@ RUNCOST_ZERO, RUNCOST_DIAG_QUAD = 0, 1
 TERM_LINEAR, TERM_DIAG_QUAD, TERM_SHIFTED_QUAD = 0, 1, 2
 LOSS_LOG_VARIANCE, LOSS_MOMENT, LOSS_WEIGHTS, LOSS_REL_ENTROPY = 0, 1, 2, 3
 NOISE_SUPPLIED, NOISE_PHILOX = 0, 1
-GH_ZERO, GH_QUAD, GH_ALLEN_CAHN = 0, 1, 2
+GH_ZERO, GH_QUAD, GH_ALLEN_CAHN, GH_EXPBALL_LIN, GH_EXPBALL_SQ, GH_EXPBALL_SIN = 0, 1, 2, 3, 4, 5
+DOM_NONE, DOM_SPHERE, DOM_BOX, DOM_BOX_UPPER_ALL, DOM_BOX_UPPER_ANY = 0, 1, 2, 3, 4
 
 
 class NativeLibraryError(RuntimeError):
@@ -59,8 +60,9 @@ class GenConfig(C.Structure):
         ("k_offset", C.c_int64),
         ("dt", C.c_float), ("sqrt_dt", C.c_float), ("T", C.c_float), ("sigma_scale", C.c_float),
         ("drift_kind", C.c_int32), ("h_kind", C.c_int32), ("adaptive", C.c_int32), ("noise_mode", C.c_int32),
-        ("store_path", C.c_int32), ("reserved", C.c_int32),
+        ("store_path", C.c_int32), ("domain_kind", C.c_int32),
         ("drift", C.c_void_p),
+        ("dom_a", C.c_float), ("dom_b", C.c_float), ("h_par", C.c_float * 4),
     ]
 
 

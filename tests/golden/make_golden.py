@@ -89,10 +89,46 @@ def wide_tanh_mlp(d_in, d_out, widths, lr, seed):
     return net
 
 
+class QuadraticOnBox:
+    """NOT a reference class: a duck-typed user problem handed to the REFERENCE solvers to pin the
+    'square' exit tests (solver.py:1125-1129, :762-767): b = 0, sigma = scale I, h = -|z|^2/2 (or 0), data |x|^2."""
+
+    def __init__(self, d=2, T=0.5, X_l=-1.0, X_r=1.0, one_boundary=False, scale=1.0, parabolic=True, quad_h=True):
+        self.name, self.d, self.T = "Quadratic on box", d, T
+        self.B = scale * torch.eye(d)
+        self.boundary, self.boundary_type = "square", "Dirichlet"
+        self.X_l, self.X_r, self.one_boundary = X_l, X_r, one_boundary
+        self.parabolic, self.quad_h = parabolic, quad_h
+
+    def b(self, x):
+        return torch.zeros(x.shape)
+
+    def sigma(self, x):
+        return self.B
+
+    def _hq(self, z):
+        return -0.5 * torch.sum(z ** 2, dim=1) if self.quad_h else torch.zeros(z.shape[0])
+
+    def h(self, *args):            # (t, x, y, z) for GeneralSolver, (x, y, z) for EllipticSolver
+        return self._hq(args[-1])
+
+    def f(self, x, t=None):
+        return torch.sum(x ** 2, 1) if self.parabolic else torch.zeros(x.shape[0])
+
+    def g(self, x, t=None):
+        return torch.sum(x ** 2, 1) + (self.T - t) if self.parabolic else torch.sum(x ** 2, 1)
+
+    def v_true(self, x, t=None):
+        return torch.sum(x ** 2, 1)
+
+
 def make_problem(spec):
     kind = spec["kind"]
     kw = dict(spec["kwargs"])
-    return getattr(ref_pb, kind)(**kw)
+    pb = QuadraticOnBox(**kw) if kind == "QuadraticOnBox" else getattr(ref_pb, kind)(**kw)
+    for k, v in spec.get("attrs", {}).items():      # attributes callers set on the instance (e.g. boundary_type)
+        setattr(pb, k, v)
+    return pb
 
 
 def probe_points(d, n=5, seed=7):
@@ -168,6 +204,32 @@ def run_general_case(case):
         "K_log": [int(v_) for v_ in model.K_log],
         "init_params": init_fp, "final_params": param_fingerprint(model.V),
         "probe_x": f32list(xp), "probe_t": 0.5 * problem.T, "probe_V": f32list(v),
+    }
+
+
+def run_general_bounded_case(case):
+    np.random.seed(case.get("numpy_seed", 0))        # GeneralSolver.train does not seed numpy (the square boundary shuffle)
+    return run_general_case(case)
+
+
+def run_elliptic_case(case):
+    problem = make_problem(case["problem"])
+    skw = dict(case["solver"])
+    model = ref_sv.EllipticSolver(problem=problem, name=case["name"], verbose=False, **skw)
+    net = case.get("net")
+    if net is not None:
+        model.V = ref_fs.DenseNet(d_in=problem.d, d_out=1, lr=skw["lr"], arch=net["arch"], seed=net["seed"])
+    init_fp = param_fingerprint(model.V)
+    model.train()
+    xp = 0.4 * probe_points(problem.d)
+    with torch.no_grad():
+        v = model.V(xp).squeeze()
+    return {
+        "loss_log": [float(v_) for v_ in model.loss_log],
+        "K_log": [int(v_) for v_ in model.K_log],
+        "V_L2_log": [float(v_) for v_ in model.V_L2_log],
+        "init_params": init_fp, "final_params": param_fingerprint(model.V),
+        "probe_x": f32list(xp), "probe_V": f32list(v),
     }
 
 
@@ -346,6 +408,51 @@ CASES = [
          solver=dict(seed=42, delta_t=0.01, N=12, lr=0.001, L=3, K=64, K_boundary=20,
                      alpha=[1.0, 1.0, 1.0], loss_method="BSDE"),
          net=dict(arch=[50, 50], seed=42)),
+    # bounded domains: exit tests, Dirichlet / Neumann boundary terms, BSDE with boundary data
+    dict(name="expsphere_d4_diffusion_dirichlet", family="general_bounded",
+         problem=dict(kind="ExponentialOnSphereNonlinearParabolic", kwargs=dict(d=4, T=0.6, alpha=0.5)),
+         solver=dict(seed=42, delta_t=0.01, N=30, lr=0.001, L=3, K=96, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion")),
+    dict(name="expsphere_d12_h40_bsde_dirichlet", family="general_bounded",
+         problem=dict(kind="ExponentialOnSphereNonlinearParabolic", kwargs=dict(d=12, T=0.5, alpha=0.3)),
+         solver=dict(seed=42, delta_t=0.005, N=100, lr=0.001, L=3, K=80, K_boundary=16,
+                     alpha=[1.0, 1.0, 1.0], loss_method="BSDE"),
+         net=dict(arch=[40, 40], seed=42)),
+    dict(name="expsphere_d3_diffusion_neumann", family="general_bounded",
+         problem=dict(kind="ExponentialOnSphereNonlinearParabolic", kwargs=dict(d=3, T=0.5, alpha=0.7),
+                      attrs=dict(boundary_type="Neumann")),
+         solver=dict(seed=42, delta_t=0.01, N=25, lr=0.001, L=3, K=64, K_boundary=18,
+                     alpha=[1.0, 0.5, 2.0], loss_method="diffusion")),
+    dict(name="box_d5_diffusion", family="general_bounded", numpy_seed=3,
+         problem=dict(kind="QuadraticOnBox", kwargs=dict(d=5, T=0.4, X_l=-1.0, X_r=1.0, scale=1.2)),
+         solver=dict(seed=42, delta_t=0.01, N=30, lr=0.001, L=3, K=96, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion", adaptive_forward_process=True)),
+    dict(name="box_d3_upper_bsde", family="general_bounded", numpy_seed=4,
+         problem=dict(kind="QuadraticOnBox", kwargs=dict(d=3, T=0.3, X_l=-1.0, X_r=0.5, one_boundary=True, quad_h=False)),
+         solver=dict(seed=42, delta_t=0.01, N=40, lr=0.001, L=3, K=64, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="BSDE")),
+    # EllipticSolver (solver.py:560-826): same step without the time input
+    dict(name="expball_sin_d5_elliptic_diffusion", family="elliptic",
+         problem=dict(kind="ExponentialOnBallNonlinearSin", kwargs=dict(d=5, alpha=0.5)),
+         solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=96, K_boundary=20, loss_method="diffusion")),
+    dict(name="expball_sq_d3_elliptic_bsde", family="elliptic",
+         problem=dict(kind="ExponentialOnBallNonlinear", kwargs=dict(d=3, alpha=0.5)),
+         solver=dict(seed=42, delta_t=0.02, N=120, lr=0.001, L=3, K=64, K_boundary=20, loss_method="BSDE"),
+         net=dict(arch=[24, 24], seed=42)),
+    dict(name="expsphere_lin_d10_elliptic_diffusion", family="elliptic",
+         problem=dict(kind="ExponentialOnSphere", kwargs=dict(d=10, alpha=0.3)),
+         solver=dict(seed=42, delta_t=0.005, N=16, lr=0.001, L=3, K=80, K_boundary=20, loss_method="diffusion",
+                     adaptive_forward_process=True)),
+    dict(name="expball_sin_d4_elliptic_neumann", family="elliptic",
+         problem=dict(kind="ExponentialOnBallNonlinearSin", kwargs=dict(d=4, alpha=0.5, boundary_type="Neumann")),
+         solver=dict(seed=42, delta_t=0.01, N=15, lr=0.001, L=3, K=64, K_boundary=20, loss_method="diffusion",
+                     boundary_type="Neumann", alpha=[1.0, 0.5])),
+    dict(name="box_d4_elliptic_diffusion", family="elliptic",
+         problem=dict(kind="QuadraticOnBox", kwargs=dict(d=4, X_l=-1.0, X_r=1.0, parabolic=False)),
+         solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=96, K_boundary=20, loss_method="diffusion")),
+    dict(name="box_d2_upper_elliptic_diffusion", family="elliptic",
+         problem=dict(kind="QuadraticOnBox", kwargs=dict(d=2, X_l=-1.0, X_r=0.6, one_boundary=True, parabolic=False, quad_h=False)),
+         solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=64, K_boundary=20, loss_method="diffusion")),
     dict(name="heat_d6_diffusion", family="general",
          problem=dict(kind="HeatEquation", kwargs=dict(d=6, T=0.5, seed=42)),
          solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=72, K_boundary=16,
@@ -364,7 +471,8 @@ def main():
         if only and case["name"] not in only:
             continue
         print("running", case["name"], flush=True)
-        res = {"solver": run_solver_case, "general": run_general_case, "is": run_is_case}[case["family"]](case)
+        res = {"solver": run_solver_case, "general": run_general_case, "is": run_is_case,
+               "general_bounded": run_general_bounded_case, "elliptic": run_elliptic_case}[case["family"]](case)
         rec = {"case": case, "expected": res, "torch": torch.__version__}
         with open(os.path.join(OUT, case["name"] + ".json"), "w") as fh:
             json.dump(rec, fh, indent=1)

@@ -120,6 +120,62 @@ def test_general_oracle_matches_reference(name):
     _check_fp(orc.fingerprint(out["V"]), exp["final_params"], exact)
 
 
+BOUNDED_CASES = ["expsphere_d4_diffusion_dirichlet", "expsphere_d12_h40_bsde_dirichlet", "expsphere_d3_diffusion_neumann",
+                 "box_d5_diffusion", "box_d3_upper_bsde"]
+ELLIPTIC_CASES = ["expball_sin_d5_elliptic_diffusion", "expball_sq_d3_elliptic_bsde", "expsphere_lin_d10_elliptic_diffusion",
+                  "expball_sin_d4_elliptic_neumann", "box_d4_elliptic_diffusion", "box_d2_upper_elliptic_diffusion"]
+
+
+def _bounded_problem(case):
+    import numpy as np
+    kw = dict(case["problem"]["kwargs"])
+    kw.update(case["problem"].get("attrs", {}))          # boundary_type set on the instance -> oracle keyword
+    if "numpy_seed" in case:
+        np.random.seed(case["numpy_seed"])
+    return orc.make_problem(case["problem"]["kind"], **kw)
+
+
+@pytest.mark.parametrize("name", BOUNDED_CASES)
+def test_general_bounded_oracle_matches_reference(name):
+    """GeneralSolver on sphere / square domains: exit tests, Dirichlet / Neumann terms, BSDE with boundary data."""
+    rec = load_golden(name)
+    exact = _same_build(rec)
+    case = rec["case"]
+    torch.set_num_threads(1)
+    prob = _bounded_problem(case)
+    s = case["solver"]
+    cfg = orc.GeneralConfig(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=s["L"], seed=s["seed"],
+                            K_boundary=s["K_boundary"], alpha=tuple(s["alpha"]), loss_method=s["loss_method"],
+                            adaptive_forward_process=s.get("adaptive_forward_process", False))
+    V = orc.general_build(prob, cfg, arch=case["net"]["arch"] if "net" in case else None)
+    out = orc.general_train(prob, cfg, V=V)
+    exp = rec["expected"]
+    _check_series(out["loss_log"], exp["loss_log"], exact)
+    assert out["K_log"] == exp["K_log"]
+    _check_fp(orc.fingerprint(out["V"]), exp["final_params"], exact)
+
+
+@pytest.mark.parametrize("name", ELLIPTIC_CASES)
+def test_elliptic_oracle_matches_reference(name):
+    rec = load_golden(name)
+    exact = _same_build(rec)
+    case = rec["case"]
+    torch.set_num_threads(1)
+    prob = _bounded_problem(case)
+    s = case["solver"]
+    cfg = orc.EllipticConfig(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=s["L"], seed=s["seed"],
+                             K_boundary=s["K_boundary"], alpha=tuple(s.get("alpha", (1.0, 1.0))),
+                             loss_method=s["loss_method"], boundary_type=s.get("boundary_type", "Dirichlet"),
+                             adaptive_forward_process=s.get("adaptive_forward_process", False))
+    V = orc.elliptic_build(prob, cfg, arch=case["net"]["arch"] if "net" in case else None)
+    out = orc.elliptic_train(prob, cfg, V=V)
+    exp = rec["expected"]
+    _check_series(out["loss_log"], exp["loss_log"], exact)
+    assert out["K_log"] == exp["K_log"]
+    _check_series(out["V_L2_log"], exp["V_L2_log"], False)
+    _check_fp(orc.fingerprint(out["V"]), exp["final_params"], exact)
+
+
 IS_CASES = ["llgc_d20_is_eval", "lqgc_d4_is_eval", "dw_d10_is_in_loop"]
 
 
