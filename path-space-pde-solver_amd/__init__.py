@@ -11,14 +11,17 @@ The directory can be used in two ways:
 from .function_space import (Affine, Constant, DenseNet, DenseNet_tanh, Linear, MySequential,  # noqa: F401
                              SingleParam)
 from .problems import (LLGC, LQGC, AllenCahn, DoubleWell_multidim,  # noqa: F401
-                       DoubleWell_multidim_for_general_solver, HeatEquation)
+                       DoubleWell_multidim_for_general_solver, HeatEquation, ExponentialOnSphere,
+                       ExponentialOnBallNonlinear, ExponentialOnBallNonlinearSin,
+                       ExponentialOnSphereNonlinearParabolic, QuadraticOnBox)
 from .solver import Solver  # noqa: F401
-from .general_solver import GeneralSolver  # noqa: F401
+from .general_solver import GeneralSolver, EllipticSolver  # noqa: F401
 from .plan_native import PlanUnsupported  # noqa: F401
 from . import native  # noqa: F401
 from . import native_shapes  # noqa: F401
 from .utilities import do_importance_sampling_me  # noqa: F401
 
-__all__ = ['Solver', 'GeneralSolver', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
+__all__ = ['Solver', 'GeneralSolver', 'EllipticSolver', 'ExponentialOnSphere', 'ExponentialOnBallNonlinear',
+           'ExponentialOnBallNonlinearSin', 'ExponentialOnSphereNonlinearParabolic', 'QuadraticOnBox', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
            'AllenCahn', 'HeatEquation', 'MySequential', 'DenseNet', 'DenseNet_tanh', 'SingleParam',
            'Constant', 'Linear', 'Affine', 'PlanUnsupported', 'native']

@@ -1,21 +1,24 @@
-"""GeneralSolver: diffusion / BSDE loss for parabolic terminal-value problems -- API mirror of the
-reference's ``solver.GeneralSolver`` (reference solver.py:934-1206) for the hot-path part:
-``loss_method in {'diffusion', 'BSDE'}`` on ``boundary in {'unbounded', 'unbounded_square'}``.
+"""GeneralSolver / EllipticSolver: diffusion / BSDE loss for parabolic terminal-value problems and for elliptic
+exit-time problems -- API mirrors of the reference's ``solver.GeneralSolver`` (reference solver.py:934-1206) and
+``solver.EllipticSolver`` (:560-826) for the hot-path part: ``loss_method in {'diffusion', 'BSDE'}`` on
+``boundary in {'unbounded', 'unbounded_square', 'sphere', 'square'}``.
 
 One iteration (reference solver.py:1009-1201):
   sample X uniformly in the domain and t ~ U(0, T); Y = V(X, t);
   N Euler-Maruyama steps of the (optionally controlled) forward SDE, during which
       Z = sigma^T grad_x V(X, t),   Y += ((-h(n dt, X, V(X,t), Z) + Z.c) dt + Z.xi sqrt(dt)) * active
   (h sees the state BEFORE the move and V(X,t), not the running Y), trajectories freeze when
-  t + dt > T;  loss = alpha0 mean((V(X_N, t_N) - Y)^2) + alpha1 mean((V(X[:Kb], T) - f(X[:Kb]))^2)
-  ('diffusion')  or  mean((Y - f(X_N))^2) ('BSDE');  Adam on V.
+  t + dt > T or when they fail the exit test of a bounded domain (sphere: |X_n| < R on the state before the move;
+  square: the proposal inside the box);  loss = alpha0 mean((V(X_N, t_N) - Y)^2) + alpha1 mean((V(X[:Kb], T) - f(X[:Kb]))^2)
+  [+ alpha2 * Dirichlet / Neumann residual on K_boundary boundary points] ('diffusion')  or  mean((Y - f(X_N))^2)
+  / mean((Y - g(X_N, t_N))^2) ('BSDE');  Adam on V.  EllipticSolver is the same step without the time input.
 
 Execution plans, resolved once in ``train()``:
   * native (plan_general_native, hand-written HIP): V is a DenseNet(d+1 -> 1) with two hidden
     layers, problem in the native catalogue, device is a GPU;
   * composite (this file): the reference op sequence with torch autograd on ``self.device``.
-Bounded domains, PINN and the BSDE-2/3/4 variants are outside the scope of this build
- and raise NotImplementedError.
+The 'two_spheres' / 'square-corner' domains, PINN and the BSDE-2/3/4 variants are outside the scope of this
+build and raise NotImplementedError.
 """
 import time
 import warnings
@@ -33,7 +36,48 @@ def _default_device():
     return torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
 
+def sample_boundary(pb, Kb, d, dev):
+    """Uniform points on the boundary, drawn in the reference's order (solver.py:1020-1038 == :650-668); the square
+    variant shuffles with numpy's global generator like the reference."""
+    if pb.boundary == 'sphere':
+        Xb = torch.randn(Kb, d).to(dev)
+        return pb.boundary_distance * Xb / torch.sqrt(torch.sum(Xb ** 2, 1)).unsqueeze(1)
+    half = int(Kb / 2)
+    pick = np.concatenate([np.ones(half)[:, np.newaxis], np.zeros([half, d - 1])], 1)
+    np.apply_along_axis(np.random.shuffle, 1, pick)
+    lower = torch.tensor(np.concatenate([pick, np.zeros([half, d])]).astype(float)).bool()
+    upper = torch.tensor(np.concatenate([np.zeros([half, d]), pick]).astype(float)).bool()
+    Xb = (pb.X_r - pb.X_l) * torch.rand(Kb, d).to(dev) + pb.X_l
+    Xb[lower] = pb.X_r if pb.one_boundary else pb.X_l
+    Xb[upper] = pb.X_r
+    return Xb
+
+
+def exit_test(pb, X, X_prop, elliptic):
+    """new_selection of solver.py:1119-1129 / :758-767: True while the trajectory stays in the domain."""
+    if pb.boundary == 'sphere':
+        return torch.sqrt(torch.sum(X ** 2, 1)) < pb.boundary_distance          # the state BEFORE the move
+    if pb.boundary == 'square':
+        if pb.one_boundary:
+            le = X_prop <= pb.X_r
+            return torch.all(le, 1) if elliptic else torch.any(le, 1)
+        return torch.all((X_prop >= pb.X_l) & (X_prop <= pb.X_r), 1)
+    return torch.ones(X.shape[0], dtype=torch.bool, device=X.device)
+
+
+def neumann_residual(V, Xb_in, g_val, d):
+    """mean((grad_x V . x - g . x)^2) over the boundary batch (solver.py:1069-1074, :688-693)."""
+    Xb_in = Xb_in.detach().clone().requires_grad_(True)
+    grad_V, = torch.autograd.grad(V(Xb_in).squeeze().sum(), Xb_in, create_graph=True)
+    xb = Xb_in[:, :d]
+    return torch.mean((torch.sum(grad_V[:, :d] * xb, 1) - torch.sum(g_val * xb, 1)) ** 2)
+
+
+_DOMAINS = ('unbounded', 'unbounded_square', 'sphere', 'square')
+
+
 class GeneralSolver:
+    elliptic = False
 
     def __init__(self, problem, name, seed=42, delta_t=0.01, N=50, lr=0.001, L=100000, K=200, K_boundary=50,
                  alpha=[1.0, 1.0, 1.0], adaptive_forward_process=False, detach_forward=True, print_every=100,
@@ -88,15 +132,22 @@ class GeneralSolver:
             raise NotImplementedError("approx_method='Z' is outside this build's scope")
         if self.loss_method not in ('diffusion', 'BSDE'):
             raise NotImplementedError("loss_method %r: only 'diffusion' and 'BSDE' are built" % self.loss_method)
-        if 'unbounded' not in self.problem.boundary:
-            raise NotImplementedError("boundary %r: bounded domains are SURVEY.md 8f rank 3" % self.problem.boundary)
+        if self.problem.boundary not in _DOMAINS:
+            raise NotImplementedError("boundary %r is not built (sphere / square / unbounded are)" % self.problem.boundary)
+        if self.bounded and self.loss_method == 'BSDE' and getattr(self.problem, 'boundary_type', None) != 'Dirichlet' \
+                and not self.elliptic:
+            raise NotImplementedError('BSDE loss with a Neumann boundary (solver.py:1177-1183) is not built')
         if self.sample_center or self.loss_with_stopped or self.solve_linear_L2_projection or self.K_test_log:
             raise NotImplementedError('sample_center / loss_with_stopped / L2 projection / test logging are not built')
+
+    @property
+    def bounded(self):
+        return 'unbounded' not in self.problem.boundary
 
     def sample_domain(self):
         """Initial points, drawn from the CPU generator in the reference's order (solver.py:1040-1056)."""
         K, d, dev, pb = self.K, self.d, self.device, self.problem
-        if pb.boundary == 'unbounded':
+        if pb.boundary in ('unbounded', 'sphere'):
             if self.uniform_square:
                 X = torch.rand(K, d).to(dev) * 2 - 1
                 radial = torch.rand(K).unsqueeze(1).to(dev)
@@ -105,6 +156,15 @@ class GeneralSolver:
                 radial = (torch.rand(K).unsqueeze(1) ** (1 / d)).to(dev)
             return pb.boundary_distance * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * radial
         return (pb.X_r - pb.X_l) * torch.rand(K, d).to(dev) + pb.X_l
+
+    def boundary_residual(self, X_in_b, X_b, t_b):
+        """Dirichlet / Neumann residual on the boundary batch (solver.py:1066-1074)."""
+        pb = self.problem
+        if pb.boundary_type == 'Dirichlet':
+            return torch.mean((self.V(X_in_b).squeeze() - pb.g(X_b, t_b.squeeze())) ** 2)
+        if pb.boundary_type == 'Neumann':
+            return neumann_residual(self.V, X_in_b, pb.g(X_b, t_b.squeeze()), self.d)
+        raise NotImplementedError('boundary_type %r' % pb.boundary_type)
 
     def train(self):
         torch.manual_seed(self.seed)
@@ -144,14 +204,22 @@ class GeneralSolver:
         pb, dev, dt, sq = self.problem, self.device, self.delta_t, self.sq_delta_t
         K, d, T = self.K, self.d, pb.T
         a0, a1 = self.alpha[0], self.alpha[1]
+        bounded = self.bounded
         for l in range(self.L):
             t_0 = time.time()
             loss = 0
+            if bounded:
+                X_b = sample_boundary(pb, self.K_boundary, d, dev)
             X = self.sample_domain()
+            if bounded:
+                t_b = torch.rand(self.K_boundary, 1).to(dev) * T
+                X_t_b = torch.cat([X_b, t_b], 1)
             if self.loss_method != 'BSDE' and self.boundary_loss:
                 Kb = self.K_boundary
                 X_T = torch.cat([X[:Kb, :], T * torch.ones(Kb).to(dev).unsqueeze(1)], 1)
                 loss = loss + a1 * torch.mean((self.V(X_T).squeeze() - pb.f(X[:Kb, :])) ** 2)
+                if bounded:
+                    loss = loss + self.alpha[2] * self.boundary_residual(X_t_b, X_b, t_b)
             X = X.clone().requires_grad_(True)
             t_n = torch.rand(K, 1).to(dev) * T
             X_t_n = torch.cat([X, t_n], 1)                       # time is the LAST input column here
@@ -175,7 +243,7 @@ class GeneralSolver:
                     c = c.detach()
                 alive = (~stopped).float().unsqueeze(1).repeat(1, d)
                 X_prop = X + ((pb.b(X) + torch.mm(sig, c).t()) * dt + torch.mm(sig, xi.t()).t() * sq) * alive
-                in_time = (t_n.squeeze() + dt) <= T
+                in_time = exit_test(pb, X, X_prop, False) & ((t_n.squeeze() + dt) <= T)
                 act = in_time & ~stopped
                 actf = act.float()
                 Y = Y + ((-pb.h(n * dt, X, V_now.squeeze(), Z) + torch.sum(Z * c.t(), 1)) * dt
@@ -193,11 +261,124 @@ class GeneralSolver:
             if self.loss_method == 'BSDE':
                 if int(torch.sum(stopped)) != K:
                     print('Not all trajectories stopped.')
-                loss = loss + torch.mean((Y - pb.f(X)) ** 2)
+                loss = loss + torch.mean((Y - (pb.g(X, t_n.squeeze()) if bounded else pb.f(X))) ** 2)
             loss.backward()
             self.V.optim.step()
             self.loss_log.append(loss.item())
             self.V_L2_log.append(0.0)
+            self.times.append(time.time() - t_0)
+            if self.verbose and l % self.print_every == 0:
+                print('%d - loss = %.4e, v L2 error = %.4e, n = %d, active: %d/%d, %.2f'
+                      % (l, self.loss_log[-1], self.V_L2_log[-1], n_done, int(torch.sum(~stopped)), K,
+                         np.mean(self.times[-self.print_every:])))
+
+
+class EllipticSolver(GeneralSolver):
+    """Exit-time (elliptic) problems: API mirror of the reference's ``solver.EllipticSolver`` (solver.py:560-826).
+    V = DenseNet(d -> 1) has no time input, ``problem.h(x, y, z)`` / ``problem.g(x)`` take no time, trajectories run
+    until they leave the domain (at most N steps) and ``alpha = [domain, boundary]``.  Same two execution plans."""
+    elliptic = True
+
+    def __init__(self, problem, name, seed=42, delta_t=0.01, N=50, lr=0.001, L=100000, K=200, K_boundary=50,
+                 alpha=[1.0, 1.0], adaptive_forward_process=False, detach_forward=True, print_every=100, verbose=True,
+                 approx_method='Y', sample_center=False, loss_method='diffusion', loss_with_stopped=False,
+                 K_test_log=None, PINN_log_variance=False, log_loss_parts=False, boundary_loss=True,
+                 boundary_type='Dirichlet', variance_moment_split=False, full_hessian=False, uniform_square=False,
+                 device=None, backend='auto', noise='reference'):
+        super().__init__(problem, name, seed=seed, delta_t=delta_t, N=N, lr=lr, L=L, K=K, K_boundary=K_boundary,
+                         alpha=alpha, adaptive_forward_process=adaptive_forward_process, detach_forward=detach_forward,
+                         print_every=print_every, verbose=verbose, approx_method='skip', sample_center=sample_center,
+                         loss_method=loss_method, loss_with_stopped=loss_with_stopped, K_test_log=K_test_log,
+                         PINN_log_variance=PINN_log_variance, log_loss_parts=log_loss_parts, boundary_loss=boundary_loss,
+                         full_hessian=full_hessian, uniform_square=uniform_square, device=device, backend=backend,
+                         noise=noise)
+        self.approx_method = approx_method
+        self.boundary_type = boundary_type
+        self.variance_moment_split = variance_moment_split
+        torch.manual_seed(seed)                                   # reference solver.py:604-609
+        if approx_method == 'Y':
+            self.V = DenseNet(d_in=self.d, d_out=1, lr=lr, seed=seed).to(self.device)
+        elif approx_method == 'Z':
+            self.y_0 = SingleParam(lr=lr).to(self.device)
+            self.Z = DenseNet(d_in=self.d, d_out=self.d, lr=lr, seed=seed).to(self.device)
+
+    def _check_scope(self):
+        if self.problem.boundary not in ('sphere', 'square'):
+            raise NotImplementedError("boundary %r is not built for EllipticSolver (sphere / square are)" % self.problem.boundary)
+        if self.variance_moment_split or self.full_hessian:
+            raise NotImplementedError('variance_moment_split / full_hessian are not built')
+        super()._check_scope()
+
+    def boundary_residual(self, X_b):
+        """Dirichlet / Neumann residual on the boundary batch (solver.py:683-693); the type is the SOLVER's argument."""
+        if self.boundary_type == 'Dirichlet':
+            return torch.mean((self.V(X_b).squeeze() - self.problem.g(X_b)) ** 2)
+        if self.boundary_type == 'Neumann':
+            return neumann_residual(self.V, X_b, self.problem.g(X_b), self.d)
+        raise NotImplementedError('boundary_type %r' % self.boundary_type)
+
+    def train(self):
+        torch.manual_seed(self.seed)
+        np.random.seed(self.seed)                                 # solver.py:631
+        self._check_scope()
+        plan = self._choose_plan()
+        if plan is not None:
+            return plan.train()
+        self._train_composite()
+
+    def _train_composite(self):
+        pb, dev, dt, sq = self.problem, self.device, self.delta_t, self.sq_delta_t
+        K, d = self.K, self.d
+        for l in range(self.L):
+            t_0 = time.time()
+            loss = 0
+            X_b = sample_boundary(pb, self.K_boundary, d, dev)
+            if self.loss_method != 'BSDE' and self.boundary_loss:
+                loss = loss + self.alpha[1] * self.boundary_residual(X_b)
+            X = self.sample_domain().clone().requires_grad_(True)
+            Y = self.V(X).squeeze()
+            stopped = torch.zeros(K).bool().to(dev)
+            V_L2 = torch.zeros(K)
+            K_count, n_done = 0, 0
+            for n in range(self.N):
+                n_done = n
+                V_now = self.V(X)
+                Z, = torch.autograd.grad(V_now.squeeze().sum(), X, create_graph=True)
+                sig = pb.sigma(X)
+                Z = torch.mm(sig.t(), Z.t()).t()
+                xi = torch.randn(K, d).to(dev)                   # drawn before the all-stopped test (solver.py:739-744)
+                alive_b = ~stopped
+                if int(torch.sum(alive_b)) == 0:
+                    break
+                if hasattr(pb, 'v_true'):
+                    V_L2[alive_b.cpu()] += ((self.V(X[alive_b]).squeeze() - pb.v_true(X[alive_b].detach()).float().squeeze()) ** 2
+                                            ).detach().cpu() * self.delta_t_np
+                c = torch.zeros(d, K).to(dev)
+                if self.adaptive_forward_process:
+                    c = -Z.t()
+                if self.detach_forward:
+                    c = c.detach()
+                alive = alive_b.float().unsqueeze(1).repeat(1, d)
+                X_prop = X + ((pb.b(X) + torch.mm(sig, c).t()) * dt + torch.mm(sig, xi.t()).t() * sq) * alive
+                inside = exit_test(pb, X, X_prop, True)
+                act = inside & ~stopped
+                actf = act.float()
+                Y = Y + ((-pb.h(X, V_now.squeeze(), Z) + torch.sum(Z * c.t(), 1)) * dt + torch.sum(Z * xi, 1) * sq) * actf
+                X = (X * (~inside | stopped).float().unsqueeze(1).repeat(1, d) + X_prop * actf.unsqueeze(1).repeat(1, d))
+                K_count = K_count + torch.sum(act)
+                stopped = stopped | (~inside & ~stopped)
+            if self.loss_method == 'diffusion':
+                loss = loss + self.alpha[0] * torch.mean((self.V(X).squeeze() - Y) ** 2)
+            self.K_log.append(int(K_count))
+            if self.loss_method == 'BSDE':
+                if int(torch.sum(stopped)) != K:
+                    print('Not all trajectories stopped.')
+                loss = loss + torch.mean((pb.g(X) - Y) ** 2)
+            self.V.zero_grad()
+            loss.backward()
+            self.V.optim.step()
+            self.loss_log.append(loss.item())
+            self.V_L2_log.append(torch.mean(V_L2).item())
             self.times.append(time.time() - t_0)
             if self.verbose and l % self.print_every == 0:
                 print('%d - loss = %.4e, v L2 error = %.4e, n = %d, active: %d/%d, %.2f'

@@ -152,17 +152,19 @@ class GenParamPad(ParamPad):
     """Index map for the DenseNet flat vector [W1 (DI x H), b1, W2 ((DI+H) x H), b2, W3 (DI+2H), b3], DI = d + 1.
     Input rows are [x (d), t]: padding moves the t row from index d to index d_pad and shifts the h1 / h2 row blocks."""
 
-    def __init__(self, d, H, dp, Hp, dev):
+    def __init__(self, d, H, dp, Hp, dev, time_input=True):
+        """time_input=False: the real net is DenseNet(d -> 1) (EllipticSolver, reference solver.py:606); the kernels'
+        time row then stays zero in the padded vector, so the (finite) time register never reaches the value."""
         self.d, self.H, self.dp, self.Hp, self.dev = d, H, dp, Hp, dev
-        self.identity = (d == dp and H == Hp)
-        DI, DIp = d + 1, dp + 1
+        self.identity = (d == dp and H == Hp and time_input)
+        DI, DIp = d + (1 if time_input else 0), dp + 1
         self.P = DI * H + H + (DI + H) * H + H + (DI + 2 * H) + 1
         self.Pp = DIp * Hp + Hp + (DIp + Hp) * Hp + Hp + (DIp + 2 * Hp) + 1
         if self.identity:
             self.idx = None
             return
         ar = torch.arange
-        rows_in = torch.cat([ar(d), torch.tensor([dp])])                           # x rows, then t
+        rows_in = torch.cat([ar(d), torch.tensor([dp])]) if time_input else ar(d)  # x rows, then t
         rows2 = torch.cat([rows_in, DIp + ar(H)])                                    # ... then h1
         rows3 = torch.cat([rows2, DIp + Hp + ar(H)])                                 # ... then h2
         oW1, ob1 = 0, DIp * Hp

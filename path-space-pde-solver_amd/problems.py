@@ -313,3 +313,152 @@ class HeatEquation:
 
     def v_true(self, x, t):
         return torch.sum(x ** 2, 1) + 2 * (self.T - t) * self.d
+
+
+# ---------------------------------------------------------------------------------------------
+# bounded domains: the exponential-on-the-ball family and a box problem
+# ---------------------------------------------------------------------------------------------
+class _ExpBall:
+    """v(x[,t]) = exp(alpha |x|^2 [+ t]) on the unit ball, b = 0, sigma = sqrt(2) I (reference problems.py:962-1172).
+    ``_nl`` selects the nonlinearity of h: 'none' | 'sq' | 'sin'; ``_parabolic`` adds the time argument, the extra -y
+    and the 2t in the exponent (ExponentialOnSphereNonlinearParabolic, :1166)."""
+    _nl, _parabolic = 'none', False
+
+    def _setup(self, name, d, alpha, boundary_type, device):
+        self.device = _resolve(device)
+        self.name, self.d, self.alpha = name, d, alpha
+        self.B = (torch.sqrt(torch.tensor(2.0)) * torch.eye(d)).to(self.device)
+        self.X_0 = torch.zeros(d).to(self.device)
+        self.Y_0 = torch.zeros(1).to(self.device)
+        self.boundary, self.boundary_distance = 'sphere', 1.0
+        self.boundary_type = boundary_type
+
+    def b(self, x):
+        return torch.zeros(x.shape).to(x.device)
+
+    def sigma(self, x):
+        return self.B
+
+    def _r2(self, x):
+        return torch.sum(x ** 2, 1)
+
+    def _h(self, x, y, t):
+        al, d = self.alpha, self.d
+        if self._nl == 'none':
+            return -al * y * (al * 4 * self._r2(x) + 2 * d)
+        lin = -2 * al * y * (al * 2 * self._r2(x) + d)
+        if self._parabolic:
+            return lin - y + torch.sin(torch.exp(2 * al * self._r2(x) + 2 * t) - y ** 2)
+        e = torch.exp(2 * al * self._r2(x))
+        return lin + e - y ** 2 if self._nl == 'sq' else lin + torch.sin(e - y ** 2)
+
+    def u_true(self, x):
+        return -2 * torch.sqrt(torch.tensor(2.0)) * self.alpha * x * torch.exp(self.alpha * self._r2(x).unsqueeze(1))
+
+    def general_native_spec(self):
+        kind = {'none': _nat.GH_EXPBALL_LIN, 'sq': _nat.GH_EXPBALL_SQ, 'sin': _nat.GH_EXPBALL_SIN}[self._nl]
+        par = 1.0 if self._parabolic else 0.0
+        return {'drift': (_nat.DRIFT_ZERO, None), 'sigma_scale': float(self.B[0, 0]), 'h': kind,
+                'h_par': (float(self.alpha), float(self.d), par, par)}
+
+
+class _ExpBallElliptic(_ExpBall):
+    def f(self, x, t=None):
+        return torch.zeros(x.shape[0]).to(x.device)
+
+    def g(self, x):
+        if self.boundary_type == 'Neumann':
+            return 2 * self.alpha * x * torch.exp(self.alpha * self._r2(x)).unsqueeze(1)
+        return torch.exp(self.alpha * self._r2(x))
+
+    def h(self, x, y, z):
+        return self._h(x, y, None)
+
+    def v_true(self, x):
+        return torch.exp(self.alpha * self._r2(x))
+
+
+class ExponentialOnSphere(_ExpBallElliptic):
+    """Linear elliptic problem (reference problems.py:962-993)."""
+
+    def __init__(self, name='Exponential on sphere', d=2, alpha=1.0, device=None):
+        self._setup(name, d, alpha, 'Dirichlet', device)
+
+
+class ExponentialOnBallNonlinear(_ExpBallElliptic):
+    """h carries exp(2 alpha |x|^2) - y^2 (reference problems.py:995-1029)."""
+    _nl = 'sq'
+
+    def __init__(self, name='Exponential on ball nonlinear', d=2, alpha=1.0, boundary_type='Dirichlet', device=None):
+        self._setup(name, d, alpha, boundary_type, device)
+
+
+class ExponentialOnBallNonlinearSin(_ExpBallElliptic):
+    """h carries sin(exp(2 alpha |x|^2) - y^2) (reference problems.py:1031-1065)."""
+    _nl = 'sin'
+
+    def __init__(self, name='Exponential on ball nonlinear', d=2, alpha=1.0, boundary_type='Dirichlet', device=None):
+        self._setup(name, d, alpha, boundary_type, device)
+
+
+class ExponentialOnSphereNonlinearParabolic(_ExpBall):
+    """Parabolic version for GeneralSolver (reference problems.py:1137-1172); ``boundary_type`` is 'Dirichlet' and the
+    Neumann notebook sets it to 'Neumann' on the instance."""
+    _nl, _parabolic = 'sin', True
+
+    def __init__(self, name='Exponential on ball', d=2, T=1.0, alpha=1.0, device=None):
+        self._setup(name, d, alpha, 'Dirichlet', device)
+        self.T = T
+
+    def f(self, x):
+        return torch.exp(self.alpha * self._r2(x) + self.T)
+
+    def g(self, x, t):
+        if self.boundary_type == 'Neumann':
+            return 2 * self.alpha * x * torch.exp(self.alpha * self._r2(x) + t).unsqueeze(1)
+        return torch.exp(self.alpha * self._r2(x) + t)
+
+    def h(self, t, x, y, z):
+        return self._h(x, y, t)
+
+    def v_true(self, x, t):
+        return torch.exp(self.alpha * self._r2(x) + t)
+
+
+class QuadraticOnBox:
+    """NOT a reference class: b = 0, sigma = scale I, h = -|z|^2/2 (or 0) with data |x|^2 on the box [X_l, X_r]^d.
+    It exercises the 'square' exit tests of the solvers (reference solver.py:1125-1129, :762-767) with coefficients
+    the kernels have; ``parabolic`` selects the GeneralSolver (h(t,x,y,z), f(x), g(x,t)) or the EllipticSolver
+    (h(x,y,z), g(x)) calling convention."""
+
+    def __init__(self, name='Quadratic on box', d=2, T=0.5, X_l=-1.0, X_r=1.0, one_boundary=False, scale=1.0,
+                 parabolic=True, quad_h=True, device=None):
+        self.device = _resolve(device)
+        self.name, self.d, self.T = name, d, T
+        self.B = (scale * torch.eye(d)).to(self.device)
+        self.boundary, self.boundary_type = 'square', 'Dirichlet'
+        self.X_l, self.X_r, self.one_boundary = X_l, X_r, one_boundary
+        self.parabolic, self.quad_h = parabolic, quad_h
+
+    def b(self, x):
+        return torch.zeros(x.shape).to(x.device)
+
+    def sigma(self, x):
+        return self.B
+
+    def h(self, *args):
+        z = args[-1]
+        return -0.5 * torch.sum(z ** 2, dim=1) if self.quad_h else torch.zeros(z.shape[0]).to(z.device)
+
+    def f(self, x, t=None):
+        return torch.sum(x ** 2, 1) if self.parabolic else torch.zeros(x.shape[0]).to(x.device)
+
+    def g(self, x, t=None):
+        return torch.sum(x ** 2, 1) + (self.T - t) if self.parabolic else torch.sum(x ** 2, 1)
+
+    def v_true(self, x, t=None):
+        return torch.sum(x ** 2, 1)
+
+    def general_native_spec(self):
+        return {'drift': (_nat.DRIFT_ZERO, None), 'sigma_scale': float(self.B[0, 0]),
+                'h': _nat.GH_QUAD if self.quad_h else _nat.GH_ZERO}

@@ -12,13 +12,28 @@ CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "he
          "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde"]
 
 
-def build(case, device="cpu", backend="auto"):
+BOUNDED = ["expsphere_d4_diffusion_dirichlet", "expsphere_d12_h40_bsde_dirichlet", "expsphere_d3_diffusion_neumann",
+           "box_d5_diffusion", "box_d3_upper_bsde"]
+ELLIPTIC = ["expball_sin_d5_elliptic_diffusion", "expball_sq_d3_elliptic_bsde", "expsphere_lin_d10_elliptic_diffusion",
+            "expball_sin_d4_elliptic_neumann", "box_d4_elliptic_diffusion", "box_d2_upper_elliptic_diffusion"]
+
+
+def build(case, device="cpu", backend="auto", **over):
+    """Package solver for a golden case (GeneralSolver, or EllipticSolver for family 'elliptic')."""
+    import numpy as np
     prob = getattr(psp, case["problem"]["kind"])(device=device, **case["problem"]["kwargs"])
-    model = psp.GeneralSolver(problem=prob, name=case["name"], verbose=False, device=device, backend=backend,
-                              **case["solver"])
+    for k, v in case["problem"].get("attrs", {}).items():
+        setattr(prob, k, v)
+    elliptic = case["family"] == "elliptic"
+    cls = psp.EllipticSolver if elliptic else psp.GeneralSolver
+    kw = dict(case["solver"])
+    kw.update(over)
+    model = cls(problem=prob, name=case["name"], verbose=False, device=device, backend=backend, **kw)
     if "net" in case:
-        model.V = psp.DenseNet(d_in=prob.d + 1, d_out=1, lr=case["solver"]["lr"], arch=case["net"]["arch"],
-                               seed=case["net"]["seed"]).to(device)
+        model.V = psp.DenseNet(d_in=prob.d + (0 if elliptic else 1), d_out=1, lr=case["solver"]["lr"],
+                               arch=case["net"]["arch"], seed=case["net"]["seed"]).to(device)
+    if "numpy_seed" in case:
+        np.random.seed(case["numpy_seed"])         # GeneralSolver.train leaves numpy unseeded (square boundary shuffle)
     return prob, model
 
 
@@ -40,6 +55,30 @@ def test_general_composite_matches_reference(name):
         v = model.V(torch.cat([xp, tp], 1)).squeeze()
     want = torch.tensor(exp["probe_V"])
     assert torch.allclose(v, want, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC)
+def test_bounded_and_elliptic_composite_matches_reference(name):
+    """Sphere / square domains (exit tests, Dirichlet / Neumann terms, BSDE with boundary data) and EllipticSolver."""
+    rec = load_golden(name)
+    exact = rec["torch"] == torch.__version__
+    torch.set_num_threads(1)
+    prob, model = build(rec["case"])
+    model.train()
+    assert model.plan_name == "torch"
+    exp = rec["expected"]
+    assert model.K_log == exp["K_log"]
+    for got, want in zip(model.loss_log, exp["loss_log"]):
+        assert (got == want) if exact else math.isclose(got, want, rel_tol=1e-5)
+    xp = torch.tensor(exp["probe_x"]).reshape(-1, prob.d)
+    if rec["case"]["family"] == "elliptic":
+        for got, want in zip(model.V_L2_log, exp["V_L2_log"]):
+            assert math.isclose(got, want, rel_tol=1e-5)
+    else:
+        xp = torch.cat([xp, torch.full((xp.shape[0], 1), exp["probe_t"])], 1)
+    with torch.no_grad():
+        v = model.V(xp).squeeze()
+    assert torch.allclose(v, torch.tensor(exp["probe_V"]), rtol=1e-5, atol=1e-7)
 
 
 def test_out_of_scope_variants_raise():
