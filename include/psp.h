@@ -229,6 +229,9 @@ typedef struct psp_gen_config {
     const float* drift;   /* DOUBLE_WELL: kappa (d); else NULL                               */
     float dom_a, dom_b;   /* sphere radius (dom_a) or box bounds X_l, X_r                     */
     float h_par[4];       /* PSP_GH_EXPBALL_*: al, d (the REAL dimension, not a padded one), e, tau */
+    int32_t d_real;       /* components the exit test and |x|^2 read when d is a zero-padded instance (0: all d);
+                           * the padding carries device noise, which nothing else ever reads                */
+    int32_t reserved;
 } psp_gen_config;
 
 typedef struct psp_gen_sizes {

@@ -40,6 +40,7 @@ struct GenArgs {
     float dt, sqdt, T, sigma_scale;
     int drift_kind, h_kind, adaptive, noise_mode, store_path;
     int domain_kind;      // DOM_*
+    int d_real;           // state components the exit test / |x|^2 see (a zero-padded instance carries noise in the padding)
     float dom_a, dom_b;   // sphere radius / box bounds X_l, X_r
     float h_par[4];       // GH_EXPBALL_*: alpha, d (real dimension), coefficient of the extra -y, 1 if the exponent carries 2 t
     uint32_t seed_lo, seed_hi, iter;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 for (int b = 0; b < DBI; ++b)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if ((16 * b + 4 * r + q) < D) rr = fmaf(X[b][r], X[b][r], rr);
+                        if ((16 * b + 4 * r + q) < a.d_real) rr = fmaf(X[b][r], X[b][r], rr);
                 rr = qsum(rr);
             }
             bool inside = true;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                     const f32x4 Xp = X[b] + move_block(b, z_block(b), xi);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if ((16 * b + 4 * r + q) < D) {
+                        if ((16 * b + 4 * r + q) < a.d_real) {
                             const bool lo_ok = a.domain_kind != DOM_BOX || Xp[r] >= a.dom_a, hi_ok = Xp[r] <= a.dom_b;
                             n_out += (lo_ok && hi_ok) ? 0.f : 1.f;
                             n_le += hi_ok ? 1.f : 0.f;

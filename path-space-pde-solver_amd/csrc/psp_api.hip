@@ -219,6 +219,7 @@ void fill_gen_args(const psp_gen_config* c, const GenPlan& p, psp::GenArgs* a) {
     a->drift_kind = c->drift_kind; a->h_kind = c->h_kind; a->adaptive = c->adaptive;
     a->noise_mode = c->noise_mode; a->store_path = c->store_path;
     a->domain_kind = c->domain_kind; a->dom_a = c->dom_a; a->dom_b = c->dom_b;
+    a->d_real = (c->d_real > 0 && c->d_real < c->d) ? c->d_real : c->d;
     for (int i = 0; i < 4; ++i) a->h_par[i] = c->h_par[i];
 }
 

@@ -63,6 +63,7 @@ class GenConfig(C.Structure):
         ("store_path", C.c_int32), ("domain_kind", C.c_int32),
         ("drift", C.c_void_p),
         ("dom_a", C.c_float), ("dom_b", C.c_float), ("h_par", C.c_float * 4),
+        ("d_real", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

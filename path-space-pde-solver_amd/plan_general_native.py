@@ -1,4 +1,5 @@
-"""Native (HIP) execution plan for GeneralSolver.train (diffusion / BSDE loss, unbounded domains).
+"""Native (HIP) execution plan for GeneralSolver.train and EllipticSolver.train (diffusion / BSDE loss on unbounded,
+sphere and box domains).
 
 Per iteration (reference solver.py:1009-1201):
     host RNG in the reference's order (domain sample, t ~ U(0,T), per-step xi)      [noise='reference']
@@ -6,9 +7,16 @@ Per iteration (reference solver.py:1009-1201):
     per-trajectory loss weights (K-vectors) and the small terminal-condition term in torch
     psp_gen_rollout_bwd   -> flat gradient of the domain part of the loss
     [all-reduce gradient] -> psp_adam_step
-The terminal term a1 mean((V(X[:Kb],T) - f(X[:Kb]))^2) involves K_boundary (~50) points and is
-differentiated by torch autograd on the same parameters (views of the flat buffer); it is
-O(K_boundary) work against O(K N) in the kernels.
+The terminal term a1 mean((V(X[:Kb],T) - f(X[:Kb]))^2) and the Dirichlet / Neumann residual on the boundary batch
+involve K_boundary (~50) points and are differentiated by torch autograd on the same parameters (views of the flat
+buffer); they are O(K_boundary) work against O(K N) in the kernels.
+
+Bounded domains (reference solver.py:1119-1129, :758-767): the exit test runs inside the forward kernel
+(psp_gen_config.domain_kind).  EllipticSolver (V = DenseNet(d -> 1), no time input) runs through the same kernels
+with T = +inf and a parameter index map that leaves the kernels' time row zero (native_shapes.GenParamPad).
+With noise='reference' the host must consume exactly as many randn(K,d) draws as the reference loop executes before
+its all-stopped break; on a bounded domain that count depends on the paths, so it is read back from t_N after the
+forward kernel and the CPU generator is rewound and advanced by that many draws.
 """
 import ctypes as C
 
@@ -19,11 +27,13 @@ try:
     from . import native_shapes as shapes
     from . import sharding
     from .function_space import DenseNet
+    from . import general_solver as gs
 except ImportError:
     import native as nat
     import native_shapes as shapes
     import sharding
     from function_space import DenseNet
+    import general_solver as gs
 
 
 def native_eligibility(solver):
@@ -37,9 +47,10 @@ def native_eligibility(solver):
         return 'boundary_loss=False is not native'
     V = solver.V
     dims = getattr(V, 'nn_dims', None)
+    d_in = solver.d + (0 if solver.elliptic else 1)
     if not isinstance(V, DenseNet) or dims is None or len(dims) != 4 or dims[1] != dims[2] or dims[3] != 1 \
-            or dims[0] != solver.d + 1:
-        return 'V is not a DenseNet(d+1 -> 1) with two equal hidden widths'
+            or dims[0] != d_in:
+        return 'V is not a DenseNet(%d -> 1) with two equal hidden widths' % d_in
     spec_fn = getattr(solver.problem, 'general_native_spec', None)
     if spec_fn is None:
         return 'problem has no general_native_spec() (coefficients outside the native catalogue)'
@@ -67,7 +78,18 @@ class GeneralNativePlan:
         cfg.K_local, cfg.N = self.K_local, s.N
         cfg.k_offset = lo
         cfg.dt, cfg.sqrt_dt = float(s.delta_t.item()), float(s.sq_delta_t.item())
-        cfg.T = float(torch.tensor(s.problem.T, dtype=torch.float32).item())
+        self.elliptic = bool(s.elliptic)
+        cfg.T = float('inf') if self.elliptic else float(torch.tensor(s.problem.T, dtype=torch.float32).item())
+        pb = s.problem
+        if pb.boundary == 'sphere':
+            cfg.domain_kind, cfg.dom_a = nat.DOM_SPHERE, float(pb.boundary_distance)
+        elif pb.boundary == 'square':
+            cfg.dom_a, cfg.dom_b = float(pb.X_l), float(pb.X_r)
+            cfg.domain_kind = nat.DOM_BOX if not pb.one_boundary else \
+                (nat.DOM_BOX_UPPER_ALL if self.elliptic else nat.DOM_BOX_UPPER_ANY)
+        cfg.d_real = s.d
+        for i, v in enumerate(spec.get('h_par', ())):
+            cfg.h_par[i] = float(v)
         cfg.sigma_scale = float(spec['sigma_scale'])
         cfg.drift_kind = spec['drift'][0]
         cfg.h_kind = spec['h']
@@ -82,7 +104,7 @@ class GeneralNativePlan:
         if chosen is None:
             raise NotImplementedError('native plan unavailable: ' + why)
         self.d_pad, self.H_pad, sz = chosen
-        self.pad = shapes.GenParamPad(s.d, self.H, self.d_pad, self.H_pad, self.dev)
+        self.pad = shapes.GenParamPad(s.d, self.H, self.d_pad, self.H_pad, self.dev, time_input=not self.elliptic)
         if spec['drift'][1] is not None:
             t = self.pad.vec(spec['drift'][1].detach().to(device=self.dev, dtype=torch.float32)).contiguous()
             self._keep.append(t)
@@ -131,7 +153,7 @@ class GeneralNativePlan:
             self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(int(s.seed) * 1000003 + l)
         K, d = s.K, s.d
-        if pb.boundary == 'unbounded':
+        if pb.boundary in ('unbounded', 'sphere'):
             X = torch.randn(K, d, generator=self._gen, device=dev)
             radial = torch.rand(K, generator=self._gen, device=dev).unsqueeze(1) ** (1 / d)
             return pb.boundary_distance * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * radial
@@ -153,36 +175,72 @@ class GeneralNativePlan:
             stopped = stopped | ~in_time
         return s.N
 
+    def _draws_executed(self, t0):
+        """randn(K,d) draws the reference loop makes on a bounded domain: it leaves at the first step that finds every
+        trajectory stopped (solver.py:1093-1097; EllipticSolver draws xi before that test, :739-744).  A trajectory is
+        active for round((t_N - t_0)/dt) steps and stopped by the step after."""
+        s = self.s
+        m = torch.round((self.tN - t0) / self.cfg.dt).max().reshape(1)
+        dist, _, world = sharding.dist_info()
+        if world > 1:
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        m = int(m.item())
+        return min(s.N, m + (2 if self.elliptic else 1))
+
+    def _boundary_terms(self, X, X_b, t_b):
+        """The K_boundary-sized loss terms, differentiated by autograd into p.grad (solver.py:1062-1074, :683-693)."""
+        s, dev = self.s, self.dev
+        if s.loss_method == 'BSDE' or not s.boundary_loss:
+            return None
+        if self.elliptic:
+            loss_b = s.alpha[1] * s.boundary_residual(X_b)
+        else:
+            Kb, T = s.K_boundary, s.problem.T
+            X_T = torch.cat([X[:Kb, :], T * torch.ones(Kb, device=dev).unsqueeze(1)], 1)
+            loss_b = s.alpha[1] * torch.mean((s.V(X_T).squeeze() - s.problem.f(X[:Kb, :])) ** 2)
+            if s.bounded:
+                loss_b = loss_b + s.alpha[2] * s.boundary_residual(torch.cat([X_b, t_b], 1), X_b, t_b)
+        loss_b.backward()                                       # K_boundary points only
+        return loss_b
+
     def iteration(self, l):
         s, lib, cfg, dev = self.s, self.lib, self.cfg, self.dev
         st = nat.stream_ptr(dev)
-        K, d, T = s.K, s.d, s.problem.T
+        K, d, pb = s.K, s.d, s.problem
         lo, hi = self.lo, self.hi
         diffusion = s.loss_method == 'diffusion'
-        if s.noise == 'reference':
-            # ---- host RNG in the reference's order (solver.py:1040-1056, :1078, :1106)
-            X = s.sample_domain()                                # (K, d) on the device
-        else:
-            X = self._sample_domain_device(l)                    # on-device generator, keyed by (seed, iteration)
+        bounded, ell = s.bounded, self.elliptic
+        reference_noise = s.noise == 'reference'
         for p in self.params:
             p.grad = None
-        loss_T = None
-        if diffusion and s.boundary_loss:
-            Kb = s.K_boundary
-            X_T = torch.cat([X[:Kb, :], T * torch.ones(Kb, device=dev).unsqueeze(1)], 1)
-            loss_T = s.alpha[1] * torch.mean((s.V(X_T).squeeze() - s.problem.f(X[:Kb, :])) ** 2)
-            loss_T.backward()                                   # K_boundary points only
-        xi = None
-        if s.noise == 'reference':
-            t0_cpu = torch.rand(K, 1) * T
-            n_exec = self._executed_steps(t0_cpu)
+        # ---- host RNG in the reference's order (solver.py:1020-1060, :1078, :1106; EllipticSolver :650-739)
+        X_b = gs.sample_boundary(pb, s.K_boundary, d, dev) if bounded else None
+        if ell:
+            loss_T = self._boundary_terms(None, X_b, None)      # no RNG inside: order as in the reference
+        X = s.sample_domain() if reference_noise else self._sample_domain_device(l)
+        t_b = None
+        if bounded and not ell:
+            t_b = torch.rand(s.K_boundary, 1).to(dev) * pb.T
+        if not ell:
+            loss_T = self._boundary_terms(X, X_b, t_b)
+        xi, rng_state, t0_all = None, None, None
+        if ell:
+            t0 = torch.zeros(hi - lo, device=dev)
+        elif reference_noise:
+            t0_all = torch.rand(K, 1) * pb.T
+            t0 = t0_all[lo:hi, 0].contiguous().to(dev)
+        else:
+            t0 = (torch.rand(K, generator=self._gen, device=dev) * pb.T)[lo:hi].contiguous()
+        if reference_noise:
+            if bounded:
+                rng_state = torch.get_rng_state()               # the number of draws is known after the rollout
+                n_draw = s.N
+            else:
+                n_draw = self._executed_steps(t0_all)
             xi_cpu = torch.zeros(s.N, hi - lo, d)
-            for n in range(n_exec):
+            for n in range(n_draw):
                 xi_cpu[n] = torch.randn(K, d)[lo:hi]
             xi = self.pad.last_dim(xi_cpu.to(dev))
-            t0 = t0_cpu[lo:hi, 0].contiguous().to(dev)
-        else:
-            t0 = (torch.rand(K, generator=self._gen, device=dev) * T)[lo:hi].contiguous()
         x0 = self.pad.last_dim(X[lo:hi].contiguous())
         flat_k = self.pad.scatter_params(self.flat, self.flat_k)
         self.kcount.zero_()
@@ -196,6 +254,11 @@ class GeneralNativePlan:
                                           nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_gen_rollout_fwd')
         if ev is not None:
             ev[1].record()
+        if rng_state is not None:                                # rewind, then consume what the reference consumes
+            draws = self._draws_executed(t0)
+            torch.set_rng_state(rng_state)
+            for _ in range(draws):
+                torch.randn(K, d)
         # ---- per-trajectory loss weights (K-vectors)
         if diffusion:
             r = self.VN - self.YN
@@ -207,7 +270,13 @@ class GeneralNativePlan:
             if loss_T is not None:
                 loss = loss + loss_T.detach()
         else:
-            r = self.YN - s.problem.f(self.XN)
+            if ell:
+                target = pb.g(self.XN)                            # solver.py:808
+            elif bounded:
+                target = pb.g(self.XN, self.tN)                   # :1176
+            else:
+                target = pb.f(self.XN)                            # :1174
+            r = self.YN - target
             sq = torch.sum(r.double() ** 2).reshape(1)
             sharding.allreduce_sum_(sq)
             loss = (sq[0] / K).float()
@@ -226,7 +295,8 @@ class GeneralNativePlan:
             self.events.append(ev)
         sharding.allreduce_sum_(self.grad)
         if loss_T is not None:                                   # identical on every rank: add after the reduce
-            self.grad += torch.cat([p.grad.reshape(-1) for p in self.params])
+            self.grad += torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                    for p in self.params])       # (a pure Neumann residual never touches b3)
         self.step += 1
         nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
                                     self.P, self.step, float(s.lr), 0.9, 0.999, 1e-8, st), 'psp_adam_step')

@@ -1,0 +1,116 @@
+"""GPU parity of the native plan on bounded domains (sphere / box exit tests inside the forward kernel, Dirichlet /
+Neumann terms, BSDE with boundary data) and of EllipticSolver (same kernels, no time input) against the oracle's
+autograd and the reference's golden runs.  Tolerances as in test_gpu_general.py: gradient <= 5e-4 * max|g|,
+loss per iteration <= 2e-4 relative, active-step counts exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_general_composite_golden import BOUNDED, ELLIPTIC, build as build_pkg
+from util_cases import orc, psp
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def oracle_run(case, L):
+    kw = dict(case["problem"]["kwargs"])
+    kw.update(case["problem"].get("attrs", {}))
+    prob = orc.make_problem(case["problem"]["kind"], **kw)
+    s = case["solver"]
+    if "numpy_seed" in case:
+        np.random.seed(case["numpy_seed"])
+    common = dict(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=L, seed=s["seed"], K_boundary=s["K_boundary"],
+                  loss_method=s["loss_method"], adaptive_forward_process=s.get("adaptive_forward_process", False))
+    arch = case["net"]["arch"] if "net" in case else None
+    if case["family"] == "elliptic":
+        cfg = orc.EllipticConfig(alpha=tuple(s.get("alpha", (1.0, 1.0))), boundary_type=s.get("boundary_type", "Dirichlet"),
+                                 **common)
+        return orc.elliptic_train(prob, cfg, V=orc.elliptic_build(prob, cfg, arch=arch), trace=True)
+    cfg = orc.GeneralConfig(alpha=tuple(s["alpha"]), **common)
+    return orc.general_train(prob, cfg, V=orc.general_build(prob, cfg, arch=arch), trace=True)
+
+
+@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC)
+def test_first_iteration_gradient_matches_oracle(name):
+    case = load_golden(name)["case"]
+    prob, model = build_pkg(case, device=dev(), backend="native", L=1)
+    model.train()
+    assert model.plan_name == "native"
+    ref = oracle_run(case, 1)
+    assert model.K_log == ref["K_log"]
+    assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=5e-5), (model.loss_log, ref["loss_log"])
+    g_ref = torch.cat([g.reshape(-1) for g in ref["traces"][0]["grads"]])
+    g = model._gen_plan.grad.cpu()
+    assert g.shape == g_ref.shape
+    err = float((g - g_ref).abs().max())
+    assert err <= 5e-4 * float(g_ref.abs().max()), (err, float(g_ref.abs().max()))
+
+
+@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC)
+def test_loss_log_matches_reference_golden(name):
+    """Several iterations: also checks that the host consumed exactly the reference's number of noise draws
+    (the all-stopped break of solver.py:1093-1097 / :742-744), otherwise iteration 2 would see other noise."""
+    rec = load_golden(name)
+    prob, model = build_pkg(rec["case"], device=dev(), backend="native")
+    model.train()
+    exp = rec["expected"]
+    assert model.K_log == exp["K_log"]
+    for l, (got, want) in enumerate(zip(model.loss_log, exp["loss_log"])):
+        assert math.isclose(got, want, rel_tol=2e-4), (l, model.loss_log, exp["loss_log"])
+    xp = torch.tensor(exp["probe_x"]).reshape(-1, prob.d).to(dev())
+    if rec["case"]["family"] != "elliptic":
+        xp = torch.cat([xp, torch.full((xp.shape[0], 1), exp["probe_t"], device=dev())], 1)
+    with torch.no_grad():
+        v = model.V(xp).squeeze().cpu()
+    want = torch.tensor(exp["probe_V"])
+    assert float((v - want).abs().max()) <= 2e-4 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["sphere", "box"])
+def test_exit_times_philox_large(kind):
+    """Size-independent properties at K = 2^17 with device noise: determinism (bitwise), every trajectory's frozen
+    point is consistent with its exit test, and the active-step count equals sum_k round((t_N - t_0)/dt)."""
+    K, N, d = 1 << 17, 60, 12
+    if kind == "sphere":
+        prob = psp.ExponentialOnSphereNonlinearParabolic(d=d, T=1.0, alpha=0.2, device=dev())
+    else:
+        prob = psp.QuadraticOnBox(d=d, T=1.0, X_l=-1.0, X_r=1.0, scale=1.0, device=dev())
+
+    def make():
+        m = psp.GeneralSolver(problem=prob, name="big", seed=42, delta_t=0.005, N=N, lr=1e-3, L=1, K=K, K_boundary=50,
+                              alpha=[1.0, 1.0, 1.0], loss_method="diffusion", verbose=False, device=dev(),
+                              backend="native", noise="philox")
+        m.V = psp.DenseNet(d_in=d + 1, d_out=1, lr=1e-3, arch=[32, 32], seed=42).to(dev())
+        return m
+
+    a, b = make(), make()
+    np.random.seed(1)          # GeneralSolver.train leaves numpy unseeded (the square boundary sample shuffles with it)
+    a.train()
+    np.random.seed(1)
+    b.train()
+    pa, pb = a._gen_plan, b._gen_plan
+    assert a.loss_log == b.loss_log and math.isfinite(a.loss_log[0]) and a.K_log == b.K_log
+    assert torch.equal(pa.grad, pb.grad) and torch.equal(pa.YN, pb.YN) and bool(torch.isfinite(pa.grad).all())
+    X0 = pa._sample_domain_device(0)
+    t0 = torch.rand(K, generator=pa._gen, device=dev()) * prob.T
+    steps = torch.round((pa.tN - t0) / pa.cfg.dt)
+    assert int(steps.sum().item()) == a.K_log[0]
+    assert 0 < a.K_log[0] < K * N
+    XN = pa.XN
+    if kind == "sphere":
+        # a trajectory that stopped early by leaving the ball sits outside it (the test reads the state before the move)
+        early = (steps < N) & ((pa.tN + pa.cfg.dt) <= prob.T)
+        assert int(early.sum()) > 0
+        assert bool((XN[early].norm(dim=1) >= prob.boundary_distance).all())
+        assert bool((XN[~early & (steps == N)].norm(dim=1) < 10.0).all())
+    else:
+        # the box test reads the proposal: nobody ever steps outside
+        assert bool(((XN >= prob.X_l) & (XN <= prob.X_r)).all())
+        assert int((steps < N).sum()) > 0
