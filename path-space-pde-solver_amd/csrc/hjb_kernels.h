@@ -39,6 +39,8 @@ struct HjbArgs {
     float* grad_partial;
     const float* tfeat;        // optional (N) per-step network time input (evaluation rollouts); null -> n * dt
     float* Fint;               // optional (K_local) running-cost integral sum_n f(X_{n+1}) dt
+    const float* uref;         // optional (N, D) reference control u*(t_n) of an x-independent solution (solver.py:491-494)
+    float* ul2;                // (K_local) sum_n |-Z_n - u*(t_n)|^2 dt, written when uref is set
     float* Yout;               // optional (K_local) Y_N
     unsigned long long* dbg;   // diagnostic builds (-DPSP_STAMPS): per-wave phase cycle sums
     float* tables;             // wide kernels: A-operand tables in global memory (carved from the caller's scratch)
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             }
         }
         float Y = a.y0 ? a.y0[0] : 0.f;               // solver.py:368 / :373
-        float Fsum = 0.f;
+        float Fsum = 0.f, ULsum = 0.f;
 #ifdef PSP_STAMPS
         unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             PSP_STAMP(fs3);
 
             // ---- Brownian increment xi_{n+1} and the two row sums |Z|^2, Z.xi (solver.py:477-478)
-            float S = 0.f, Pz = 0.f;
+            float S = 0.f, Pz = 0.f, UL = 0.f;
 #pragma unroll
             for (int b = 0; b < DB; ++b) {
                 f32x4 xi;
@@ -465,9 +467,19 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
                     S = fmaf(Z[b][r], Z[b][r], S);
                     Pz = fmaf(Z[b][r], xi[r], Pz);
                 }
+                if (a.uref) {                          // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494)
+                    const float* ur = a.uref + (size_t)n * D;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 16 * b + 4 * r + q;
+                        const float e = (f < D) ? Z[b][r] + ur[f < D ? f : D - 1] : 0.f;
+                        UL = fmaf(e, e, UL);
+                    }
+                }
                 // v = c dt + xi sqrt(dt), c = -Z (adaptive) or 0  (solver.py:451-456,471-472)
                 Z[b] = a.adaptive ? (sqdt * xi - dt * Z[b]) : (sqdt * xi);
             }
+            ULsum = fmaf(UL, dt, ULsum);
             S = qsum(S);
             Pz = qsum(Pz);
             PSP_STAMP(fs4);
@@ -552,6 +564,10 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
         const float Dk = Y - g;
         if (kvalid && q == 0) a.D[k] = Dk;
         if (a.Fint && kvalid && q == 0) a.Fint[k] = Fsum;
+        if (a.uref) {
+            const float ULt = qsum(ULsum);
+            if (kvalid && q == 0) a.ul2[k] = ULt;
+        }
         if (a.Yout && kvalid && q == 0) a.Yout[k] = Y;
         if (a.XN && kvalid) {
 #pragma unroll

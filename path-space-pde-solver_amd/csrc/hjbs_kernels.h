@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
             const float v = a.x0[(size_t)(kvalid ? k : 0) * a.x0_stride + (f < D ? f : D - 1)];
             X[io][r] = (f < D && kvalid) ? v : 0.f;
         }
-    float Yw = 0.f, Fw = 0.f;                          // this wave's partial of Y and of the running-cost integral
+    float Yw = 0.f, Fw = 0.f, ULw = 0.f;               // this wave's partial of Y, of the running-cost integral and of u_L2
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
     const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
 
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                 for (int io = 0; io < NBo; ++io) Z[io] = mfma16(w3r[io][ks], bh[ks], Z[io]);
         }
-        float S = 0.f, Pz = 0.f;
+        float S = 0.f, Pz = 0.f, UL = 0.f;
 #pragma unroll
         for (int io = 0; io < NBo; ++io) {
             const int sb = wave + 4 * io;
@@ -272,6 +272,15 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     S = fmaf(Z[io][r], Z[io][r], S);
                     Pz = fmaf(Z[io][r], xi[r], Pz);
+                }
+                if (a.uref) {                          // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494)
+                    const float* ur = a.uref + (size_t)n * D;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 16 * sb + 4 * r + q;
+                        const float e = (f < D) ? Z[io][r] + ur[f < D ? f : D - 1] : 0.f;
+                        UL = fmaf(e, e, UL);
+                    }
                 }
                 const f32x4 v = a.adaptive ? (sqdt * xi - dt * Z[io]) : (sqdt * xi);     // v = c dt + xi sqrt(dt)
                 if (denseB) {
@@ -314,6 +323,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
                            : (a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S)) * dt + Pz * sqdt;
         Yw += term;
         Fw = fmaf(fX, dt, Fw);
+        ULw = fmaf(UL, dt, ULw);
         PSP_STAMP(ss5);
         PSP_ACC(0, ss1, ss0);   // P0: X image + store + barrier
         PSP_ACC(1, ss2, ss1);   // P1: W1 + drift product, tanh, h1 image + barrier
@@ -352,12 +362,13 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
             }
         }
     }
-    const float Yp = qsum(Yw), Fp = qsum(Fw), gp = qsum(g);
+    const float Yp = qsum(Yw), Fp = qsum(Fw), gp = qsum(g), Up = qsum(ULw);
     float* red = lds + S_::fRed;                       // [wave][j]: Y, then F, then g partials
     __syncthreads();                                   // the images are dead; fRed is separate, but keep the phases apart
     if (q == 0) red[wave * 64 + j] = Yp;
     if (q == 1) red[wave * 64 + 16 + j] = Fp;
     if (q == 2) red[wave * 64 + 32 + j] = gp;
+    if (q == 3) red[wave * 64 + 48 + j] = Up;
     __syncthreads();
     if (wave == 0) {
         const float Y = (a.y0 ? a.y0[0] : 0.f) + ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j]));
@@ -367,6 +378,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         if (kvalid && q == 0) {
             a.D[k] = Dk;
             if (a.Fint) a.Fint[k] = F;
+            if (a.uref) a.ul2[k] = (red[48 + j] + red[64 + 48 + j]) + (red[128 + 48 + j] + red[192 + 48 + j]);
             if (a.Yout) a.Yout[k] = Y;
         }
         double sD = (kvalid && q == 0) ? (double)Dk : 0.0, sD2 = (kvalid && q == 0) ? (double)Dk * (double)Dk : 0.0;

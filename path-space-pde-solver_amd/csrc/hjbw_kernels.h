@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
                 X[b][r] = (f < D && kvalid) ? v : 0.f;
             }
         float Y = a.y0 ? a.y0[0] : 0.f;
-        float Fsum = 0.f;
+        float Fsum = 0.f, ULsum = 0.f;
 
 #ifdef PSP_STAMPS
         unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
             // ---- control output, Brownian increment and increment panel v, four state blocks at a time, so that Z is
             //      never live as a whole: Z_g = W3[g] h2 + b3 -> row sums |Z|^2, Z.xi (solver.py:477-478) ->
             //      v = c dt + xi sqrt(dt) (c = -Z if adaptive, solver.py:451-456) -> LDS image (dense sigma) or X
-            float S = 0.f, Pz = 0.f;
+            float S = 0.f, Pz = 0.f, UL = 0.f;
             auto z_group = [&](auto nbc, int g) __attribute__((always_inline)) {
                 constexpr int NB = decltype(nbc)::value;
                 f32x4 Zg[NB];
@@ -374,6 +374,15 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
                         S = fmaf(Zg[m][r], Zg[m][r], S);
                         Pz = fmaf(Zg[m][r], xi[r], Pz);
                     }
+                    if (a.uref) {                      // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494)
+                        const float* ur = a.uref + (size_t)n * D;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = 16 * b + 4 * r + q;
+                            const float e = (f < D) ? Zg[m][r] + ur[f < D ? f : D - 1] : 0.f;
+                            UL = fmaf(e, e, UL);
+                        }
+                    }
                     const f32x4 v = a.adaptive ? (sqdt * xi - dt * Zg[m]) : (sqdt * xi);
                     if (a.sigma_kind == SIGMA_DENSE) {
 #pragma unroll
@@ -390,6 +399,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
             if constexpr (DB % 4 != 0) z_group(std::integral_constant<int, DB % 4>{}, DB / 4);
             S = qsum(S);
             Pz = qsum(Pz);
+            ULsum = fmaf(UL, dt, ULsum);
             PSP_STAMP(ws5);
             if (a.sigma_kind == SIGMA_DENSE) gemm_img<DB, KP>(X, T + W::tB, img, lane);     // X += B v
 
@@ -444,6 +454,10 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
         const float Dk = Y - g;
         if (kvalid && q == 0) a.D[k] = Dk;
         if (a.Fint && kvalid && q == 0) a.Fint[k] = Fsum;
+        if (a.uref) {
+            const float ULt = qsum(ULsum);
+            if (kvalid && q == 0) a.ul2[k] = ULt;
+        }
         if (a.Yout && kvalid && q == 0) a.Yout[k] = Y;
         if (a.XN && kvalid) {
 #pragma unroll

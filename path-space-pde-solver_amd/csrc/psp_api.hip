@@ -158,6 +158,7 @@ void fill_args(const psp_hjb_config* c, const Plan& p, psp::HjbArgs* a) {
     a->drift_kind = c->drift_kind; a->sigma_kind = c->sigma_kind; a->runcost_kind = c->runcost_kind;
     a->term_kind = c->term_kind; a->adaptive = c->adaptive; a->loss_kind = c->loss_kind;
     a->noise_mode = c->noise_mode; a->store_path = c->store_path;
+    a->uref = c->u_ref; a->ul2 = c->u_l2_out;
     // diagnostic stamp buffer: [forward: fwd_grid x 8 waves x 8][backward: bwd_grid x 4 waves x 8]
     a->dbg = (g_dbg && g_dbg_n >= ((long long)p.fwd_grid * 8 + (long long)p.bwd_grid * 8) * 8) ? g_dbg : nullptr;
 }
@@ -167,6 +168,7 @@ int check_ptrs(const psp_hjb_config* c) {
     if (c->sigma_kind == PSP_SIGMA_DENSE && !c->sigma) return fail(-1, "sigma matrix missing");
     if (c->runcost_kind == PSP_RUNCOST_DIAG_QUAD && !c->runcost) return fail(-1, "running-cost vector missing");
     if (!c->term) return fail(-1, "terminal-cost vector missing");
+    if (c->u_ref && !c->u_l2_out) return fail(-1, "u_ref set but u_l2_out is null");
     return 0;
 }
 
@@ -415,6 +417,7 @@ int psp_hjb_rollout_eval(const psp_hjb_config* cfg, const float* params, const f
     psp::HjbArgs a;
     fill_args(cfg, p, &a);
     a.store_path = 0;
+    a.uref = nullptr; a.ul2 = nullptr;      // the evaluation grid is not the training grid (utilities.py:296-299)
     a.params = params; a.x0 = x0; a.x0_stride = x0_stride; a.xi = xi; a.tfeat = tfeat;
     a.D = D_out; a.Fint = Fint_out; a.XN = XN_out; a.fwd_partial = fwd_partial;
     a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);

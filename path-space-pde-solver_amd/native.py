@@ -43,6 +43,7 @@ class HjbConfig(C.Structure):
         ("noise_mode", C.c_int32), ("store_path", C.c_int32),
         ("sigma_scale", C.c_float), ("reserved", C.c_int32),
         ("drift", C.c_void_p), ("sigma", C.c_void_p), ("runcost", C.c_void_p), ("term", C.c_void_p),
+        ("u_ref", C.c_void_p), ("u_l2_out", C.c_void_p),
     ]
 
 

@@ -41,9 +41,10 @@ def native_eligibility(solver):
                 % solver.loss_method)
     if solver.burgers_drift:
         return 'burgers_drift is not native'
-    if solver.u_l2_error_flag:
-        return ('u_l2_error_flag=True evaluates problem.u_true on the host every step '
-                '(reference solver.py:491-494); pass u_l2_error_flag=False for the native plan')
+    if solver.u_l2_error_flag and getattr(solver.problem, 'u_true_x_independent', False) is not True:
+        return ('u_l2_error_flag=True evaluates problem.u_true(X_n, t_n) on the host every step '
+                '(reference solver.py:491-494); only a u_true that does not depend on x (LLGC) is logged inside '
+                'the kernels -- pass u_l2_error_flag=False for the native plan')
     if solver.compute_gradient_variance > 0 or solver.log_gradient:
         return 'per-iteration diagnostics (gradient variance / gradient log) are not native'
     if solver.metastability_logs is not None:
@@ -150,6 +151,17 @@ class HjbNativePlan:
         self.m = torch.zeros(self.P, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.P, dtype=torch.float32, device=dev)
         self.x0_vec = dev_f32(pad.vec(solver.X_0.detach().to(dev)))
+        self.ul2 = None
+        if solver.u_l2_error_flag:
+            # u_L2 log (solver.py:491-494) for an x-independent reference control: u*(t_n) once per plan instead of
+            # problem.u_true(X.cpu(), t_n) every step of every iteration; the kernels accumulate |-Z_n - u*(t_n)|^2 dt
+            import numpy as np
+            probe = torch.zeros(1, solver.d)
+            rows = [torch.tensor(np.asarray(solver.problem.u_true(probe, n * solver.delta_t_np))).reshape(solver.d, -1)[:, 0].float()
+                    for n in range(solver.N)]
+            self.uref = dev_f32(pad.last_dim(torch.stack(rows).to(dev)))
+            self.ul2 = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
+            cfg.u_ref, cfg.u_l2_out = nat.ptr(self.uref), nat.ptr(self.ul2)
         if self.attached or self.relent:
             self.cfg_w = nat.HjbConfig.from_buffer_copy(cfg)          # backward with explicit trajectory weights
             self.cfg_w.loss_kind = nat.LOSS_WEIGHTS
@@ -200,8 +212,9 @@ class HjbNativePlan:
         x0_dev = self.pad.last_dim(x0[lo:hi].contiguous().to(self.dev)) if x0 is not None else None
         return xi_dev, x0_dev
 
-    def iteration(self, l, loss_out):
-        """One training iteration; writes the fp32 loss into loss_out[l] (device, no sync)."""
+    def iteration(self, l, loss_out, ul2_out=None):
+        """One training iteration; writes the fp32 loss into loss_out[l] (and mean u_L2 into ul2_out[l]) on the
+        device, no sync."""
         s, lib, cfg = self.s, self.lib, self.cfg
         st = self._stream()
         seed = int(s.seed) & 0xFFFFFFFFFFFFFFFF
@@ -236,6 +249,10 @@ class HjbNativePlan:
         else:
             loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
         loss_out[l] = loss.to(torch.float32)
+        if self.ul2 is not None and ul2_out is not None:
+            m = (self.ul2.sum() / float(s.K)).reshape(1)
+            sharding.allreduce_sum_(m)
+            ul2_out[l:l + 1] = m
         if ev is not None:
             ev[2].record()
         if self.attached:

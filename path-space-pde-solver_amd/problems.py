@@ -98,6 +98,8 @@ class LLGC(_LinearDriftMixin):
     def g(self, x):
         return torch.mm(x, self.alpha)[:, 0]
 
+    u_true_x_independent = True    # lets the native plan tabulate u*(t_n) once (plan_native.py)
+
     def u_true(self, x, t):
         # u*(x,t) = -B^T exp(A^T (T-t)) alpha, independent of x (reference problems.py:51-53)
         A, B = self.A.cpu().numpy(), self.B.cpu().numpy()

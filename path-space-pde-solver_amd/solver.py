@@ -281,30 +281,37 @@ class Solver:
         (the reference syncs every iteration through loss.item(), solver.py:514); losses are
         gathered on the device and read back once per print_every block."""
         losses = torch.zeros(self.L, dtype=torch.float32, device=self.device)
+        ul2 = torch.zeros(self.L, dtype=torch.float32, device=self.device) if self.u_l2_error_flag else None
         y0_hist = torch.zeros(self.L, dtype=torch.float32, device=self.device) if self.learn_Y_0 else None
         done = 0
         t_block = time.time()
         for l in range(self.L):
             if self.learn_Y_0:
                 y0_hist[l:l + 1].copy_(self.y_0.Y_0.detach())       # Y_0 before the update (solver.py:374)
-            plan.iteration(l, losses)
+            plan.iteration(l, losses, ul2)
             if self.IS_variance_K > 0 and l % self.IS_variance_iter == 0:        # solver.py:521-528
                 self.IS_rel_log.append(do_importance_sampling_me(self.problem, self, self.IS_variance_K)[2])
-            if (self.verbose and l % self.print_every == 0) or l == self.L - 1:
+            # early stopping reads the u_L2 log every iteration once l > early_stopping_time (solver.py:550-554)
+            watch = ul2 is not None and self.early_stopping_time is not None and l > self.early_stopping_time
+            if (self.verbose and l % self.print_every == 0) or l == self.L - 1 or watch:
                 vals = losses[done:l + 1].cpu().tolist()          # one sync per block
                 now = time.time()
                 per = (now - t_block) / max(1, l + 1 - done)
                 self.loss_log += vals
-                self.u_L2_loss += [0.0] * len(vals)
+                self.u_L2_loss += ul2[done:l + 1].cpu().tolist() if ul2 is not None else [0.0] * len(vals)
                 self.times += [per] * len(vals)
                 if self.learn_Y_0:
                     self.Y_0_log += y0_hist[done:l + 1].cpu().tolist()
                 done, t_block = l + 1, now
                 if self.verbose and l % self.print_every == 0:
-                    msg = '%d - loss: %.4e - u L2: %.4e - time/iter: %.4fs' % (l, self.loss_log[-1], 0.0, per)
+                    msg = '%d - loss: %.4e - u L2: %.4e - time/iter: %.4fs' % (l, self.loss_log[-1], self.u_L2_loss[-1], per)
                     if self.learn_Y_0:
                         msg += ' - Y_0: %.4e' % self.Y_0_log[-1]
                     print(msg)
+                if watch:
+                    recent = self.u_L2_loss[-self.early_stopping_time:]
+                    if np.std(recent) / self.u_L2_loss[-1] < 0.02:
+                        break
 
     def _train_composite(self):
         """The reference iteration restated with torch ops on self.device (solver.py:430-554)."""

@@ -245,6 +245,13 @@ CASES = [
     dict(name="lqgc_d2_logvar_noul2", family="solver",
          problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
          solver=dict(HJB, L=6, lr=0.01, seed=42, delta_t=0.05, K=128, u_l2_error_flag=False)),
+    # u_L2 logging left ON (the reference's default, every HJB notebook runs with it): LLGC's u* does not depend on x
+    dict(name="llgc_d8_logvar_ul2", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=8, off_diag=0.05, T=0.4, seed=42)),
+         solver=dict(HJB, L=5, lr=0.003, seed=42, delta_t=0.02, K=96)),
+    dict(name="llgc_d40_moment_ul2", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=40, off_diag=0.02, T=0.2, seed=42)),
+         solver=dict(HJB, loss_method="moment", learn_Y_0=True, L=4, lr=0.002, seed=42, delta_t=0.01, K=80)),
     # BASELINE.json configs[1] shape with the reference's default 2x30 net
     dict(name="llgc_d100_h30_logvar", family="solver",
          problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=0.5, seed=42)),

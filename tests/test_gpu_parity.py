@@ -27,7 +27,9 @@ NATIVE_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_l
                 # gradients through the state path (adjoint sweep) and the relative-entropy loss
                 "lqgc_d2_attached_logvar", "llgc_d100_h64_attached_logvar", "dw_d10_attached_moment",
                 "lqgc_d4_relative_entropy", "llgc_d20_relative_entropy_detached",
-                "lqgc_d2_attached_cross_entropy", "llgc_d200_nonadaptive_logvar"]
+                "lqgc_d2_attached_cross_entropy", "llgc_d200_nonadaptive_logvar",
+                # u_L2 logging on (the reference default): accumulated inside the forward kernels
+                "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2"]
 
 
 def dev():
@@ -81,6 +83,10 @@ def test_loss_log_matches_reference_golden(name):
         assert math.isclose(got, want, rel_tol=1e-4), (l, model.loss_log, exp["loss_log"])
     for got, want in zip(model.Y_0_log, exp["Y_0_log"]):
         assert math.isclose(got, want, rel_tol=1e-4, abs_tol=1e-6)
+    if rec["case"]["solver"].get("u_l2_error_flag", True):     # logged natively only for an x-independent u_true
+        assert len(model.u_L2_loss) == len(exp["u_L2_loss"])
+        for got, want in zip(model.u_L2_loss, exp["u_L2_loss"]):
+            assert math.isclose(got, want, rel_tol=1e-4), (model.u_L2_loss, exp["u_L2_loss"])
     # learned control on the probe grid: u = -Z_n(x, t)
     if exp["probes"]:
         xp = torch.tensor(exp["probe_x"]).reshape(-1, model.d).to(dev())
