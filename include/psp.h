@@ -267,6 +267,48 @@ int psp_gen_rollout_fwd(const psp_gen_config* cfg, const float* params, const fl
 int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const float* path, const float* ahat,
                         const float* wY, const float* wV, float* grad_partial, float* grad_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Solver.train with a DenseNet control (function_space.py:116-140: dense-concat layers, relu^2, weights (in, out)):
+ *   time_approx='outer' (the constructor default, solver.py:88, 352-353): N nets DenseNet(d -> d), one per time step
+ *                                                              -> per_step = 1, time_input = 0
+ *   a DenseNet(d+1 -> d) swapped into z_n with time_approx='inner' (solver.py:142-162, 355: input [t, x])
+ *                                                              -> per_step = 0, time_input = 1
+ * Forward rollout only: the parameter gradient of this family is formed by library GEMMs on the flat batches the
+ * rollout stores (X_n and the xi image, row-major with the REAL widths), see plan_dense_native.py.
+ * base.d / base.H name the compiled instance (psp_dnet_instance_get; whole 16-blocks); d_real <= d, H_real <= H are
+ * the net's sizes.  params = per_step ? N : 1 consecutive parameter sets in the DenseNet's registration order
+ *     [W1 (di x H_real), b1, W2 ((di+H_real) x H_real), b2, W3 ((di+2 H_real) x d_real), b3],  di = d_real + time_input,
+ * read with their real strides (no padded copy).  Problem vectors / matrices, x0 and supplied noise are padded to
+ * base.d as for the other entry points.  relative_entropy and attached forward processes are not built here.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct psp_dnet_config {
+    psp_hjb_config base;
+    int32_t d_real, H_real;
+    int32_t time_input;   /* 1: the net's input is [t, x] (time = column 0) */
+    int32_t per_step;     /* 1: one parameter set per time step            */
+} psp_dnet_config;
+
+typedef struct psp_dnet_sizes {
+    int64_t table_bytes;       /* scratch for the A-operand tables the call writes (L2-resident)   */
+    int64_t fwd_partial_bytes;
+    int64_t n_params_per_set;
+    int32_t fwd_workgroups, reserved;
+} psp_dnet_sizes;
+
+int psp_dnet_instance_count(void);
+int psp_dnet_instance_get(int32_t i, int32_t* d, int32_t* H);
+int psp_dnet_query(const psp_dnet_config* cfg, psp_dnet_sizes* out);
+int psp_dnet_terminal_reduce(const psp_dnet_config* cfg, const double* fwd_partial, double* sums_out, void* stream);
+/* px, pxi: (N, K_local, d_real) stores of X_n and of the xi image (xi, or xi + sqrt(dt) Z when the forward process is
+ * not adaptive: dL/dZ_n = w_k sqrt(dt) * image either way); written when base.store_path = 1.  tfeat: optional (N)
+ * time feature per step (importance-sampling grids, utilities.py:296-299), NULL -> n * dt.  Outputs as for
+ * psp_hjb_rollout_fwd / psp_hjb_rollout_eval; psp_dnet_terminal_reduce reduces fwd_partial (this family's own
+ * workgroup count) to the global (sum D, sum D^2). */
+int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* params, const float* x0, int32_t x0_stride,
+                         const float* y0, const float* xi, uint64_t seed, uint32_t iter, const float* tfeat,
+                         float* px, float* pxi, float* D_out, float* Fint_out, float* XN_out, float* Y_out,
+                         double* fwd_partial, float* tables, void* stream);
+
 /* Diagnostics: device buffer that receives per-wave phase cycle sums (8 u64 per wave of the
  * backward kernel).  Returns 1 if the library was built with -DPSP_STAMPS (diagnostic build,
  * never the shipped one), 0 otherwise (the pointer is then ignored). NULL clears it. */

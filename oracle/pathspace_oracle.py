@@ -421,7 +421,9 @@ def hjb_train(problem: OracleProblem, cfg: HJBConfig, net=None, noise: Optional[
         if trace:
             tr["D"] = D.detach().clone()
             tr["Zsum_g"] = (Z_sum + gX).detach().clone()
-            tr["grads"] = [p.grad.detach().clone() for p in (z.parameters() if not isinstance(z, list) else z[0].parameters())]
+            nets_ = z if isinstance(z, list) else [z]                # 'outer': every step's net, in step order
+            tr["grads"] = [p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)
+                           for net_ in nets_ for p in net_.parameters()]
             out["traces"].append(tr)
         for p_ in phis:
             p_.optim.step()                                          # :198-200

@@ -82,7 +82,13 @@ def _build(force, jobs, verbose, only):
     whdr = os.path.join(CSRC, "hjbw_kernels.h")
     wdef = os.path.join(CSRC, "wide_instances.def")
     winst_src = os.path.join(CSRC, "hjbw_instance.hip")
-    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, ghdr, whdr, inc, idef, gdef, wdef])]
+    dhdr = os.path.join(CSRC, "hjbd_kernels.h")
+    ddef = os.path.join(CSRC, "dense_instances.def")
+    dinst_src = os.path.join(CSRC, "hjbd_instance.hip")
+    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, ghdr, whdr, dhdr, inc, idef, gdef, wdef, ddef])]
+    for d, H in instances("dense_instances.def"):
+        tasks.append((dinst_src, os.path.join(OBJ, "dnet_inst_%d_%d.o" % (d, H)),
+                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [dinst_src, dhdr, whdr, hdr]))
     for d, H in instances():
         tasks.append((inst_src, os.path.join(OBJ, "inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [inst_src, hdr, os.path.join(CSRC, "hjbs_kernels.h"), os.path.join(CSRC, "hjba_kernels.h")]))

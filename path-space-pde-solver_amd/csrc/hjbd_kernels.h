@@ -1,0 +1,367 @@
+// hjbd_kernels.h -- forward rollout with a DenseNet control (function_space.py:116-140: dense-concat layers,
+// relu(.)^2, weights stored (in, out)), for the two places the reference uses one as the control of Solver:
+//   * time_approx='outer' (solver.py:88, the constructor default): N nets DenseNet(d -> d), one per time step,
+//     Z_n = z_n[n](X_n) (solver.py:352-353)                                   -> per_step = 1, time_input = 0
+//   * a DenseNet swapped into z_n with time_approx='inner' (notebook extension point, solver.py:142-162):
+//     DenseNet(d+1 -> d) on [t, X] with time as input column 0 (solver.py:355) -> per_step = 0, time_input = 1
+// Per step:  z1 = W1^T u + b1, r1 = relu(z1), h1 = r1^2;  z2 = W2^T [u, h1] + b2, r2 = relu(z2), h2 = r2^2;
+//            Z = W3^T [u, h1, h2] + b3      (u = X_n or [t_n, X_n]),
+// then the same Euler-Maruyama / Y update as hjbw_fwd_kernel (solver.py:471-478).
+//
+// Built on the wide family's streaming products (hjbw_kernels.h): one wave per SIMD owns a 16-trajectory tile, all
+// A-operand tables live in global memory (L2-resident, written per call by hjbd_tables_kernel), so "one weight set
+// per time step" is nothing but a table pointer that advances with n.  The tables are filled from the REAL
+// parameter layout with zero padding up to the compiled (D, H) instance, and the time column of every layer is
+// folded into per-step bias vectors (b + t_n W[0, :]) by the tables kernel: the host keeps no index map.
+// What the backward pass needs -- X_n and the image of the Brownian increment -- is written ROW-MAJOR with the real
+// widths ((N, K, d) each): the parameter gradient of this family is formed by library GEMMs on those flat batches
+// (plan_dense_native.py), not by a hand-written kernel.
+#pragma once
+#include "hjbw_kernels.h"
+
+namespace psp {
+
+struct DnetArgs {
+    HjbArgs h;                 // problem, noise, outputs (params = the first parameter set; path / tables unused here)
+    float* tbl;                // table region (DGeo::table_floats(...) floats)
+    float* px;                 // (N, K_local, d_real) X_n          (store_path)
+    float* pxi;                // (N, K_local, d_real) image of xi_{n+1}: xi, or xi + sqrt(dt) Z for a non-adaptive process
+    int d_real, h_real;        // the net's real input / hidden widths (the instance is zero padded above them)
+    int time_input;            // 1: input is [t, x] (time = column 0); 0: input is x
+    int per_step;              // 1: N consecutive parameter sets, one per time step
+};
+
+__device__ __forceinline__ f32x4 relu4d(f32x4 v) {
+    f32x4 o;
+    o[0] = fmaxf(v[0], 0.f); o[1] = fmaxf(v[1], 0.f); o[2] = fmaxf(v[2], 0.f); o[3] = fmaxf(v[3], 0.f);
+    return o;
+}
+
+template <int D, int H>
+struct DGeo {
+    static constexpr int DB = cdiv(D, 16), HB = cdiv(H, 16), KP = 4 * DB;
+    static_assert(H % 16 == 0 && D % 16 == 0, "DenseNet-control instances are whole blocks (real sizes are runtime values)");
+    // one weight set, k-step-major [ks][blocks][64]:  [W1 | W2x] over x (2 HB blocks), W2h over h1, W3x over x, [W3h1 ; W3h2] over h
+    static constexpr int tW12 = 0, tW2h = tW12 + KP * 2 * HB * 64, tW3x = tW2h + 4 * HB * HB * 64,
+                         tW3h1 = tW3x + KP * DB * 64, tW3h2 = tW3h1 + 4 * HB * DB * 64, set_floats = tW3h2 + 4 * HB * DB * 64;
+    // per-step bias vectors (time column folded in), T-layout order [block][q][r]
+    static constexpr int v1 = 0, v2 = v1 + HB * 16, v3 = v2 + HB * 16, vec_floats = v3 + DB * 16;
+    // region: [dt A][B][sets ...][vectors of step 0 .. N-1]
+    static constexpr int oA = 0, oB = oA + KP * DB * 64, oSets = oB + KP * DB * 64;
+    static __host__ __device__ long long table_floats(int N, int per_step) {
+        return (long long)oSets + (long long)(per_step ? N : 1) * set_floats + (long long)N * vec_floats;
+    }
+    // LDS (floats): problem vectors, reduction scratch, two images per wave (X_n and the increment panel v)
+    static constexpr int vdr = 0, vrun = vdr + DB * 16, vterm = vrun + DB * 16, fRed = vterm + DB * 16,
+                         fImg = fRed + 64, IMG = KP * 64, lds_floats = fImg + 4 * 2 * IMG;
+    // real flat parameter layout of one net (registration order W1,b1,W2,b2,W3,b3; weights (in, out))
+    static __host__ __device__ long long n_params(int d, int h, int time_input) {
+        const long long di = d + (time_input ? 1 : 0);
+        return di * h + h + (di + h) * h + h + (di + 2 * h) * d + d;
+    }
+};
+
+template <int D, int H>
+__global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a) {
+    using W = DGeo<D, H>;
+    const HjbArgs& h = a.h;
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gs = (long long)gridDim.x * blockDim.x;
+    const int d = a.d_real, hh = a.h_real, to = a.time_input ? 1 : 0, di = d + to;
+    const long long P = W::n_params(d, hh, a.time_input);
+    const long long oW1 = 0, ob1 = (long long)di * hh, oW2 = ob1 + hh, ob2 = oW2 + (long long)(di + hh) * hh,
+                    oW3 = ob2 + hh, ob3 = oW3 + (long long)(di + 2 * hh) * d;
+    float* T = a.tbl;
+    if (h.drift_kind == DRIFT_DENSE) {
+        const float dt = h.dt;
+        const float* __restrict__ A = h.drift;
+        table_fill(T + W::oA, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+            return (row < D && col < D) ? dt * A[row * D + col] : 0.f; });
+    }
+    if (h.sigma_kind == SIGMA_DENSE) {
+        const float* __restrict__ B = h.sigma;
+        table_fill(T + W::oB, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+            return (row < D && col < D) ? B[row * D + col] : 0.f; });
+    }
+    const int nsets = a.per_step ? h.N : 1;
+    for (int s = 0; s < nsets; ++s) {
+        const float* __restrict__ Pp = h.params + (long long)s * P;
+        float* Ts = T + W::oSets + (long long)s * W::set_floats;
+        table_fill(Ts + W::tW12, 2 * W::HB, W::KP, gtid, gs, [&](int row, int col) {      // rows: [W1 outputs | W2 outputs]
+            const int o = row < 16 * W::HB ? row : row - 16 * W::HB;
+            if (o >= hh || col >= d) return 0.f;
+            return row < 16 * W::HB ? Pp[oW1 + (long long)(to + col) * hh + o] : Pp[oW2 + (long long)(to + col) * hh + o]; });
+        table_fill(Ts + W::tW2h, W::HB, 4 * W::HB, gtid, gs, [&](int row, int col) {
+            return (row < hh && col < hh) ? Pp[oW2 + (long long)(di + col) * hh + row] : 0.f; });
+        table_fill(Ts + W::tW3x, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+            return (row < d && col < d) ? Pp[oW3 + (long long)(to + col) * d + row] : 0.f; });
+        table_fill(Ts + W::tW3h1, W::DB, 4 * W::HB, gtid, gs, [&](int row, int col) {
+            return (row < d && col < hh) ? Pp[oW3 + (long long)(di + col) * d + row] : 0.f; });
+        table_fill(Ts + W::tW3h2, W::DB, 4 * W::HB, gtid, gs, [&](int row, int col) {
+            return (row < d && col < hh) ? Pp[oW3 + (long long)(di + hh + col) * d + row] : 0.f; });
+    }
+    // per-step bias vectors b + t_n W[0, :]  (time input = column 0 of every layer's input block; solver.py:355)
+    float* V = T + W::oSets + (long long)nsets * W::set_floats;
+    const long long nv = (long long)h.N * W::vec_floats;
+    for (long long idx = gtid; idx < nv; idx += gs) {
+        const int n = (int)(idx / W::vec_floats), e = (int)(idx % W::vec_floats);
+        const float* __restrict__ Pp = h.params + (long long)(a.per_step ? n : 0) * P;
+        const float tn = h.tfeat ? h.tfeat[n] : (float)n * h.dt;
+        const int which = e < W::v2 ? 0 : (e < W::v3 ? 1 : 2);
+        const int loc = e - (which == 0 ? W::v1 : (which == 1 ? W::v2 : W::v3));
+        const int f = 16 * (loc >> 4) + 4 * (loc & 3) + ((loc >> 2) & 3);       // [block][q][r] -> feature 16 b + 4 r + q
+        float v = 0.f;
+        if (which == 0 && f < hh) v = Pp[ob1 + f] + (to ? tn * Pp[oW1 + f] : 0.f);
+        if (which == 1 && f < hh) v = Pp[ob2 + f] + (to ? tn * Pp[oW2 + f] : 0.f);
+        if (which == 2 && f < d) v = Pp[ob3 + f] + (to ? tn * Pp[oW3 + f] : 0.f);
+        V[idx] = v;
+    }
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(256) void hjbd_fwd_kernel(const DnetArgs da) {
+    using W = DGeo<D, H>;
+    constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
+    const HjbArgs& a = da.h;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const float* __restrict__ T = da.tbl;
+    const int dr = da.d_real;
+
+    stage_vec(lds + W::vdr, DB, tid, nthr, [&](int f) {
+        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+    stage_vec(lds + W::vrun, DB, tid, nthr, [&](int f) {
+        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+    stage_vec(lds + W::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
+    __syncthreads();
+
+    const int t16raw = blockIdx.x * nwave + wave;
+    const bool wave_valid = t16raw < a.ntile16;       // surplus waves of the last workgroup run along on the last tile
+    const int t16 = wave_valid ? t16raw : a.ntile16 - 1;
+    const int k = t16 * 16 + j;
+    const bool kvalid = wave_valid && k < a.K_local;
+    const uint32_t kglob = (uint32_t)(a.k_offset + k);
+    const float dt = a.dt, sqdt = a.sqdt;
+    float* imgX = lds + W::fImg + wave * 2 * W::IMG;  // this wave's image of X_n   [KP][64]
+    float* imgV = imgX + W::IMG;                      // ... and of the increment panel v (dense sigma)
+    const bool store = a.store_path && kvalid;
+    const float store_cz = a.adaptive ? 0.f : a.sqdt; // image: xi, or xi + sqrt(dt) Z for a non-adaptive process (hjb_fwd_kernel)
+    const int nsets_m1 = da.per_step ? a.N - 1 : 0;
+    const float* Vbase = T + W::oSets + (long long)(nsets_m1 + 1) * W::set_floats;
+
+    double sD = 0.0, sD2 = 0.0;
+    {
+        const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds) + q;
+        const f32x4* vterm = vecs0 + W::vterm / 4;
+        f32x4 X[DB];                                   // X_0 (solver.py:365-367) in T layout
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * b + 4 * r + q;
+                const float v = a.x0[(size_t)(kvalid ? k : 0) * a.x0_stride + (f < D ? f : D - 1)];
+                X[b][r] = (f < D && kvalid) ? v : 0.f;
+            }
+        float Y = a.y0 ? a.y0[0] : 0.f;
+        float Fsum = 0.f;
+
+#pragma unroll 1
+        for (int n = 0; n < a.N; ++n) {
+            const f32x4* vecs = opaque(vecs0);
+            const int qn = opaque_i(q);
+            const f32x4* vdr = vecs + W::vdr / 4;
+            const f32x4* vrun = vecs + W::vrun / 4;
+            const float* Ts = T + W::oSets + (long long)(da.per_step ? n : 0) * W::set_floats;     // this step's weight set
+            const f32x4* Vn = reinterpret_cast<const f32x4*>(Vbase + (long long)n * W::vec_floats) + qn;
+            const size_t row = ((size_t)n * a.K_local + (kvalid ? k : 0));
+            // ---- X_n: LDS image (B operand of every product over x) and the row-major store for the backward pass
+#pragma unroll
+            for (int ks = 0; ks < KP; ++ks) imgX[ks * 64 + lane] = X[ks >> 2][ks & 3];
+            if (store) {
+                float* px = da.px + row * dr;
+#pragma unroll
+                for (int b = 0; b < DB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 16 * b + 4 * r + q;
+                        if (f < dr) px[f] = X[b][r];
+                    }
+            }
+            // ---- z1 and the x-part of z2 in one pass over the image (function_space.py:133-140)
+            f32x4 z12[2 * HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) { z12[m] = Vn[(W::v1 / 16 + m) * 4]; z12[HB + m] = Vn[(W::v2 / 16 + m) * 4]; }
+            gemm_img<2 * HB, KP>(z12, Ts + W::tW12, imgX, lane);
+            // ---- drift part of X_{n+1} while the image still holds X_n (solver.py:471)
+            f32x4 Xn[DB];
+#pragma unroll
+            for (int b = 0; b < DB; ++b) Xn[b] = X[b];
+            if (a.drift_kind == DRIFT_DENSE) {
+                gemm_img<DB, KP>(Xn, T + W::oA, imgX, lane);
+            } else if (a.drift_kind == DRIFT_DIAG) {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) Xn[b] += dt * (vdr[b * 4] * X[b]);
+            } else if (a.drift_kind == DRIFT_DWELL) {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) Xn[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
+            }
+            f32x4 h1[HB], h2[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) { const f32x4 r = relu4d(z12[m]); h1[m] = r * r; }
+            {
+                f32x4 z2[HB];
+#pragma unroll
+                for (int m = 0; m < HB; ++m) z2[m] = z12[HB + m];
+                gemm_regs<HB, 4 * HB, HB>(z2, Ts + W::tW2h, h1, lane);
+#pragma unroll
+                for (int m = 0; m < HB; ++m) { const f32x4 r = relu4d(z2[m]); h2[m] = r * r; }
+            }
+            // ---- control output four state blocks at a time: Z_g = W3x[g] x + W3h1[g] h1 + W3h2[g] h2 + b3
+            float S = 0.f, Pz = 0.f;
+            auto z_group = [&](auto nbc, int g) __attribute__((always_inline)) {
+                constexpr int NB = decltype(nbc)::value;
+                f32x4 Zg[NB];
+#pragma unroll
+                for (int m = 0; m < NB; ++m) Zg[m] = Vn[(W::v3 / 16 + 4 * g + m) * 4];
+                gemm_img<NB, KP, DB>(Zg, Ts + W::tW3x + 4 * g * 64, imgX, lane);
+                gemm_regs<NB, 4 * HB, HB, DB>(Zg, Ts + W::tW3h1 + 4 * g * 64, h1, lane);
+                gemm_regs<NB, 4 * HB, HB, DB>(Zg, Ts + W::tW3h2 + 4 * g * 64, h2, lane);
+#pragma unroll
+                for (int m = 0; m < NB; ++m) {
+                    const int b = 4 * g + m;
+                    f32x4 xi;
+                    if (a.noise_mode == NOISE_PHILOX) {
+                        xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + qn), a.iter, a.seed_lo, a.seed_hi);
+                    } else {
+                        const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = 16 * b + 4 * r + q;
+                            xi[r] = xrow[f < D ? f : D - 1];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= dr || !kvalid) xi[r] = 0.f;   // padding carries no noise
+                    if (store) {
+                        float* pxi = da.pxi + row * dr;
+                        const f32x4 wv = xi + store_cz * Zg[m];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = 16 * b + 4 * r + q;
+                            if (f < dr) pxi[f] = wv[r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        S = fmaf(Zg[m][r], Zg[m][r], S);
+                        Pz = fmaf(Zg[m][r], xi[r], Pz);
+                    }
+                    const f32x4 v = a.adaptive ? (sqdt * xi - dt * Zg[m]) : (sqdt * xi);
+                    if (a.sigma_kind == SIGMA_DENSE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) imgV[(4 * b + r) * 64 + lane] = v[r];
+                    } else if (a.sigma_kind == SIGMA_SCALE) {
+                        Xn[b] += a.sigma_scale * v;
+                    } else {
+                        Xn[b] += v;
+                    }
+                }
+            };
+#pragma unroll
+            for (int g = 0; g < DB / 4; ++g) z_group(std::integral_constant<int, 4>{}, g);
+            if constexpr (DB % 4 != 0) z_group(std::integral_constant<int, DB % 4>{}, DB / 4);
+            S = qsum(S);
+            Pz = qsum(Pz);
+            if (a.sigma_kind == SIGMA_DENSE) gemm_img<DB, KP>(Xn, T + W::oB, imgV, lane);    // X += B v
+#pragma unroll
+            for (int b = 0; b < DB; ++b) X[b] = Xn[b];
+            // ---- running cost f(X_{n+1}) and Y update (solver.py:477-478)
+            float fX = 0.f;
+            if (a.runcost_kind == RUN_DIAGQ) {
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    const f32x4 pv = vrun[b * 4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fX = fmaf(pv[r] * X[b][r], X[b][r], fX);
+                }
+                fX = qsum(fX);
+            }
+            const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
+            Y = Y + drift_y * dt + Pz * sqdt;
+            Fsum = fmaf(fX, dt, Fsum);
+        }
+
+        // ---- terminal cost g(X_N) and D = Y - g  (problems.py:49,164,334; solver.py:167-168)
+        float g = 0.f;
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            const f32x4 tv = vterm[b * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = X[b][r];
+                if (a.term_kind == TERM_LINEAR) g = fmaf(tv[r], x, g);
+                else if (a.term_kind == TERM_DIAGQ) g = fmaf(tv[r] * x, x, g);
+                else g = fmaf(tv[r] * (x - 1.0f), (x - 1.0f), g);
+            }
+        }
+        g = qsum(g);
+        const float Dk = Y - g;
+        if (kvalid && q == 0) a.D[k] = Dk;
+        if (a.Fint && kvalid && q == 0) a.Fint[k] = Fsum;
+        if (a.Yout && kvalid && q == 0) a.Yout[k] = Y;
+        if (a.XN && kvalid) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * b + 4 * r + q;
+                    if (f < D) a.XN[(size_t)k * D + f] = X[b][r];
+                }
+        }
+        if (kvalid && q == 0) { sD = (double)Dk; sD2 = (double)Dk * (double)Dk; }
+    }
+    sD = jsum(sD); sD2 = jsum(sD2);
+    double* red = reinterpret_cast<double*>(lds + W::fRed);
+    if (lane == 0) { red[2 * wave] = sD; red[2 * wave + 1] = sD2; }
+    __syncthreads();
+    if (tid == 0) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int w = 0; w < nwave; ++w) { t0 += red[2 * w]; t1 += red[2 * w + 1]; }
+        a.fwd_partial[2 * blockIdx.x] = t0;
+        a.fwd_partial[2 * blockIdx.x + 1] = t1;
+    }
+}
+
+// host-side launch table entry of this family
+struct DnetInstance {
+    int d, H;
+    int lds_bytes;
+    int set_floats, vec_floats, shared_floats;
+    hipError_t (*launch_fwd)(const DnetArgs&, int grid, hipStream_t);
+};
+
+template <int D, int H>
+struct DnetLaunch {
+    using W = DGeo<D, H>;
+    static hipError_t fwd(const DnetArgs& a, int grid, hipStream_t s) {
+        hipLaunchKernelGGL((hjbd_tables_kernel<D, H>), dim3(512), dim3(256), 0, s, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const int bytes = W::lds_floats * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_fwd_kernel<D, H>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbd_fwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
+        return hipGetLastError();
+    }
+    static DnetInstance instance() {
+        return DnetInstance{D, H, W::lds_floats * 4, W::set_floats, W::vec_floats, W::oSets, &fwd};
+    }
+};
+
+}  // namespace psp
+
+#define PSP_DEFINE_DNET_INSTANCE(D_, H_) \
+    extern "C" psp::DnetInstance psp_dnet_instance_##D_##_##H_() { return psp::DnetLaunch<D_, H_>::instance(); }
+#define PSP_DECLARE_DNET_INSTANCE(D_, H_) extern "C" psp::DnetInstance psp_dnet_instance_##D_##_##H_();

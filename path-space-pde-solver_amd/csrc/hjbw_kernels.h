@@ -165,7 +165,7 @@ __device__ __forceinline__ void gemm_regs(f32x4 (&acc)[MB], const float* __restr
 // acc[MB] += T . img,  T: k-step-major global table with KP k-steps (KP % 4 == 0), img: this wave's LDS image of the
 // input panel (one dword per lane and k-step).  Rolled over k with a static ring of NST register stages of U k-steps
 // (KP % (NST * U) == 0): the operands of a stage are requested NST - 1 stages before its MFMAs issue.
-template <int MB, int KP>
+template <int MB, int KP, int LD = MB>
 __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restrict__ tbl, const float* img, int lane) {
     constexpr int NST = 2;                            // (a 4-stage ring of single k-steps was measured 10 % slower at d = 200)
     constexpr int U = (MB >= 16) ? 1 : 2;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
             bb[st][u] = img[(ks0 + u) * 64 + lane];
 #pragma unroll
             for (int m0 = 0; m0 < MB; m0 += 16) {
-                gptr_t tp = sgpr_ptr(tbl + ((size_t)(ks0 + u) * MB + m0) * 64);
+                gptr_t tp = sgpr_ptr(tbl + ((size_t)(ks0 + u) * LD + m0) * 64);       // LD: output blocks per k-step in the table
 #pragma unroll
                 for (int mb = m0; mb < m0 + 16 && mb < MB; ++mb) ab[st][u * MB + mb] = tp[(mb - m0) * 64 + ul];
             }

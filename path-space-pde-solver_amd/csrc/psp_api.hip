@@ -9,7 +9,11 @@
 #include "hjb_kernels.h"
 #include "gen_kernels.h"
 #include "hjbw_kernels.h"
+#include "hjbd_kernels.h"
 
+#define X(D_, H_) PSP_DECLARE_DNET_INSTANCE(D_, H_)
+#include "dense_instances.def"
+#undef X
 #define X(D_, H_) PSP_DECLARE_INSTANCE(D_, H_)
 #include "instances.def"
 #undef X
@@ -74,6 +78,19 @@ const GenEntry kGenTable[] = {
 };
 bool find_gen_instance(int d, int H, psp::GenInstance* out) {
     for (const GenEntry& e : kGenTable)
+        if (e.d == d && e.H == H) { *out = e.fn(); return true; }
+    return false;
+}
+
+typedef psp::DnetInstance (*DnetInstanceFn)();
+struct DnetEntry { int d, H; DnetInstanceFn fn; };
+const DnetEntry kDnetTable[] = {
+#define X(D_, H_) {D_, H_, &psp_dnet_instance_##D_##_##H_},
+#include "dense_instances.def"
+#undef X
+};
+bool find_dnet_instance(int d, int H, psp::DnetInstance* out) {
+    for (const DnetEntry& e : kDnetTable)
         if (e.d == d && e.H == H) { *out = e.fn(); return true; }
     return false;
 }
@@ -325,6 +342,98 @@ extern "C" {
 
 int psp_version(void) { return PSP_VERSION; }
 const char* psp_last_error(void) { return g_err; }
+
+// ---- DenseNet control (hjbd_kernels.h): time_approx='outer' and DenseNet(d+1 -> d) controls ---------------------
+namespace {
+struct DnetPlan { psp::DnetInstance inst; int ntile16, grid; long long table_floats, n_params; };
+int make_dnet_plan(const psp_dnet_config* c, DnetPlan* p) {
+    if (!c) return fail(-1, "null config");
+    const psp_hjb_config& b = c->base;
+    if (b.d <= 0 || b.H <= 0 || b.K_local <= 0 || b.N <= 0) return fail(-1, "non-positive d/H/K/N");
+    if (!find_dnet_instance(b.d, b.H, &p->inst)) {
+        snprintf(g_err, sizeof(g_err), "no compiled DenseNet-control kernel instance for d=%d H=%d", b.d, b.H);
+        return -2;
+    }
+    if (c->d_real <= 0 || c->d_real > b.d || c->H_real <= 0 || c->H_real > b.H)
+        return fail(-1, "d_real / H_real must lie in [1, d] / [1, H] of the instance");
+    if (b.drift_kind < 0 || b.drift_kind > 3 || b.sigma_kind < 0 || b.sigma_kind > 2 || b.runcost_kind < 0 ||
+        b.runcost_kind > 1 || b.term_kind < 0 || b.term_kind > 2 || b.noise_mode < 0 || b.noise_mode > 1 ||
+        b.store_path < 0 || b.store_path > 1)
+        return fail(-1, "config enum out of range");
+    if (b.loss_kind == PSP_LOSS_REL_ENTROPY) return fail(-1, "relative entropy is not built for the DenseNet control");
+    if (p->inst.lds_bytes > kMaxLds) return fail(-3, "DenseNet-control kernel images do not fit the 160 KiB LDS");
+    p->ntile16 = (b.K_local + 15) / 16;
+    p->grid = (p->ntile16 + 3) / 4;
+    p->table_floats = (long long)p->inst.shared_floats + (long long)(c->per_step ? b.N : 1) * p->inst.set_floats +
+                      (long long)b.N * p->inst.vec_floats;
+    const long long di = c->d_real + (c->time_input ? 1 : 0), h = c->H_real, d = c->d_real;
+    p->n_params = di * h + h + (di + h) * h + h + (di + 2 * h) * d + d;
+    return 0;
+}
+}  // namespace
+
+extern "C" int psp_dnet_instance_count(void) { return (int)(sizeof(kDnetTable) / sizeof(kDnetTable[0])); }
+extern "C" int psp_dnet_instance_get(int32_t i, int32_t* d, int32_t* H) {
+    if (i < 0 || i >= psp_dnet_instance_count() || !d || !H) return fail(-1, "instance index out of range");
+    *d = kDnetTable[i].d; *H = kDnetTable[i].H;
+    return 0;
+}
+
+extern "C" int psp_dnet_query(const psp_dnet_config* cfg, psp_dnet_sizes* out) {
+    DnetPlan p;
+    int rc = make_dnet_plan(cfg, &p);
+    if (rc) return rc;
+    if (!out) return fail(-1, "null output");
+    out->table_bytes = p.table_floats * 4;
+    out->fwd_partial_bytes = (int64_t)p.grid * 2 * 8;
+    out->n_params_per_set = p.n_params;
+    out->fwd_workgroups = p.grid;
+    out->reserved = 0;
+    return 0;
+}
+
+extern "C" int psp_dnet_terminal_reduce(const psp_dnet_config* cfg, const double* fwd_partial, double* sums_out, void* stream) {
+    DnetPlan p;
+    int rc = make_dnet_plan(cfg, &p);
+    if (rc) return rc;
+    if (!fwd_partial || !sums_out) return fail(-1, "null buffer passed to psp_dnet_terminal_reduce");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fwd_partial, p.grid, sums_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "reduce_partials_kernel launch");
+    return 0;
+}
+
+extern "C" int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* params, const float* x0, int32_t x0_stride,
+                                    const float* y0, const float* xi, uint64_t seed, uint32_t iter, const float* tfeat,
+                                    float* px, float* pxi, float* D_out, float* Fint_out, float* XN_out, float* Y_out,
+                                    double* fwd_partial, float* tables, void* stream) {
+    DnetPlan p;
+    int rc = make_dnet_plan(cfg, &p);
+    if (rc) return rc;
+    const psp_hjb_config* b = &cfg->base;
+    if ((rc = check_ptrs(b))) return rc;
+    if (!params || !x0 || !D_out || !fwd_partial || !tables) return fail(-1, "null buffer passed to psp_dnet_rollout_fwd");
+    if (x0_stride != 0 && x0_stride != b->d) return fail(-1, "x0_stride must be 0 or d");
+    if (b->noise_mode == PSP_NOISE_SUPPLIED && !xi) return fail(-1, "supplied-noise mode needs xi");
+    if (b->store_path && (!px || !pxi)) return fail(-1, "store_path set but the X / xi stores are null");
+    psp::DnetArgs a;
+    memset(&a, 0, sizeof(a));
+    psp::HjbArgs& h = a.h;
+    h.drift = b->drift; h.sigma = b->sigma; h.runcost = b->runcost; h.term = b->term;
+    h.k_offset = b->k_offset; h.K_global = b->K_global; h.K_local = b->K_local; h.N = b->N;
+    h.ntile16 = p.ntile16; h.dt = b->dt; h.sqdt = b->sqrt_dt; h.sigma_scale = b->sigma_scale;
+    h.drift_kind = b->drift_kind; h.sigma_kind = b->sigma_kind; h.runcost_kind = b->runcost_kind;
+    h.term_kind = b->term_kind; h.adaptive = b->adaptive; h.loss_kind = b->loss_kind;
+    h.noise_mode = b->noise_mode; h.store_path = b->store_path;
+    h.params = params; h.x0 = x0; h.x0_stride = x0_stride; h.y0 = y0; h.xi = xi; h.tfeat = tfeat;
+    h.D = D_out; h.Fint = Fint_out; h.XN = XN_out; h.Yout = Y_out; h.fwd_partial = fwd_partial;
+    h.seed_lo = (uint32_t)seed; h.seed_hi = (uint32_t)(seed >> 32); h.iter = iter;
+    a.tbl = tables; a.px = px; a.pxi = pxi;
+    a.d_real = cfg->d_real; a.h_real = cfg->H_real; a.time_input = cfg->time_input ? 1 : 0; a.per_step = cfg->per_step ? 1 : 0;
+    hipError_t e = p.inst.launch_fwd(a, p.grid, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hjbd_fwd_kernel launch");
+    return 0;
+}
 
 int psp_debug_set_stamp_buffer(unsigned long long* buf, int64_t n_entries) {
     g_dbg = buf;

@@ -68,6 +68,16 @@ class GenConfig(C.Structure):
     ]
 
 
+class DnetConfig(C.Structure):
+    _fields_ = [("base", HjbConfig), ("d_real", C.c_int32), ("H_real", C.c_int32), ("time_input", C.c_int32),
+                ("per_step", C.c_int32)]
+
+
+class DnetSizes(C.Structure):
+    _fields_ = [("table_bytes", C.c_int64), ("fwd_partial_bytes", C.c_int64), ("n_params_per_set", C.c_int64),
+                ("fwd_workgroups", C.c_int32), ("reserved", C.c_int32)]
+
+
 class GenSizes(C.Structure):
     _fields_ = [
         ("path_bytes", C.c_int64), ("ahat_bytes", C.c_int64), ("grad_partial_bytes", C.c_int64),
@@ -83,6 +93,12 @@ SIGNATURES = {
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_family": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_adjoint_sweep": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "psp_dnet_instance_count": (C.c_int, []),
+    "psp_dnet_instance_get": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "psp_dnet_query": (C.c_int, [C.POINTER(DnetConfig), C.POINTER(DnetSizes)]),
+    "psp_dnet_terminal_reduce": (C.c_int, [C.POINTER(DnetConfig), _P, _P, _P]),
+    "psp_dnet_rollout_fwd": (C.c_int, [C.POINTER(DnetConfig), _P, _P, C.c_int32, _P, _P, C.c_uint64, C.c_uint32, _P,
+                                       _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "psp_gen_instance_count": (C.c_int, []),
     "psp_gen_instance_get": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "psp_hjb_instance_count": (C.c_int, []),
@@ -185,6 +201,17 @@ def gen_instances():
     for i in range(lib.psp_gen_instance_count()):
         d, H = C.c_int32(), C.c_int32()
         check(lib.psp_gen_instance_get(i, C.byref(d), C.byref(H)), 'psp_gen_instance_get')
+        out.append((d.value, H.value))
+    return out
+
+
+def dnet_instances():
+    """[(d, H)] of the compiled DenseNet-control forward kernels."""
+    lib = load()
+    out = []
+    for i in range(lib.psp_dnet_instance_count()):
+        d, H = C.c_int32(), C.c_int32()
+        check(lib.psp_dnet_instance_get(i, C.byref(d), C.byref(H)), 'psp_dnet_instance_get')
         out.append((d.value, H.value))
     return out
 

@@ -1,0 +1,285 @@
+"""Native execution plan for Solver.train with a DenseNet control (reference function_space.py:116-140):
+
+  * time_approx='outer' -- the reference's constructor default (solver.py:88): N nets DenseNet(d -> d), one per
+    time step, each with its own Adam (solver.py:142-162, 194-200);
+  * time_approx='inner' with a DenseNet(d+1 -> d) swapped into z_n (notebook extension point).
+
+Per iteration (reference solver.py:430-514):
+    psp_dnet_rollout_fwd     hand-written HIP rollout (csrc/hjbd_kernels.h): D_k, the terminal sums and the two flat
+                             batches the gradient needs, X_n and the xi image, each (N, K, d) row-major
+    psp_dnet_terminal_reduce (sum D, sum D^2)                      [all-reduce 1]
+    parameter gradient       detach_forward=True makes dL/dZ_n[k] = w_k sqrt(dt) image_n[k], so the gradient
+                             of every net is that of a plain feed-forward batch: recomputed activations and ~12 library
+                             GEMMs (torch.bmm: batch = time steps for 'outer', one flat batch for 'inner'), written
+                             analytically below -- no autograd graph                    [all-reduce 2]
+    psp_adam_step            one fused Adam over the concatenation of all parameter sets (identical to the reference's
+                             per-net Adams: same lr, betas and step count)
+The rollout is the sequential, launch-bound part of the reference (N steps x ~70 eager kernels) and is the hand-written
+kernel; the gradient is GEMM-shaped and is left to rocBLAS.  Relative entropy and gradients through the state path
+(detach_forward=False) are outside this plan and keep the composite one.
+"""
+import ctypes as C
+
+import torch
+
+try:
+    from . import native as nat
+    from . import native_shapes as shapes
+    from . import sharding
+    from .function_space import DenseNet
+    from .plan_native import HjbNativePlan, PlanUnsupported
+except ImportError:
+    import native as nat
+    import native_shapes as shapes
+    import sharding
+    from function_space import DenseNet
+    from plan_native import HjbNativePlan, PlanUnsupported
+
+_LOSSES = ('log-variance', 'moment', 'variance', 'cross_entropy')
+
+
+def _nets(solver):
+    return list(solver.z_n) if solver.time_approx == 'outer' else [solver.z_n]
+
+
+def _instance_for(d, H):
+    cands = [(D, Hh) for (D, Hh) in nat.dnet_instances() if D >= d and Hh >= H]
+    return min(cands, key=lambda t: (t[0] * t[0] + 3 * t[0] * t[1], t[1])) if cands else None
+
+
+def dense_eligibility(solver):
+    """None if the solver can run on this plan, else a human-readable reason."""
+    if solver.device.type != 'cuda':
+        return 'device is %s (the HIP rollout needs a GPU)' % solver.device
+    if solver.approx_method != 'control':
+        return "only approx_method='control' is native"
+    if solver.loss_method not in _LOSSES:
+        return 'loss_method %r is not native for a DenseNet control (%s are)' % (solver.loss_method, ', '.join(_LOSSES))
+    if solver.adaptive_forward_process and not solver.detach_forward:
+        return 'detach_forward=False back-propagates through the state path (composite plan for DenseNet controls)'
+    if solver.burgers_drift or solver.u_l2_error_flag or solver.compute_gradient_variance > 0 or solver.log_gradient \
+            or solver.metastability_logs is not None:
+        return 'per-step / per-iteration diagnostics (u_L2, gradient logs, metastability) are not native here'
+    nets = _nets(solver)
+    outer = solver.time_approx == 'outer'
+    if outer and len(nets) != solver.N:
+        return "time_approx='outer' needs one net per time step"
+    d_in = solver.d + (0 if outer else 1)
+    dims0 = getattr(nets[0], 'nn_dims', None)
+    for net in nets:
+        dims = getattr(net, 'nn_dims', None)
+        if not isinstance(net, DenseNet) or dims is None or len(dims) != 4 or dims[1] != dims[2] \
+                or dims[0] != d_in or dims[3] != solver.d or dims != dims0:
+            return 'control is not a DenseNet(%d -> %d) with two equal hidden widths' % (d_in, solver.d)
+    spec_fn = getattr(solver.problem, 'native_spec', None)
+    if spec_fn is None or spec_fn() is None:
+        return 'problem has no native_spec() (coefficients outside the native catalogue)'
+    if not nat.is_built():
+        raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
+    if _instance_for(solver.d, dims0[1]) is None:
+        return 'no compiled DenseNet-control instance covers d=%d, H=%d (csrc/dense_instances.def)' % (solver.d, dims0[1])
+    return None
+
+
+class DenseNativePlan:
+    def __init__(self, solver, noise='reference'):
+        reason = dense_eligibility(solver)
+        if reason is not None:
+            raise PlanUnsupported(reason)
+        s = solver
+        self.s, self.noise, self.lib, self.dev = s, noise, nat.load(), s.device
+        dev = self.dev
+        self.dist, self.rank, self.world = sharding.dist_info()
+        try:
+            lo, hi = sharding.shard_bounds(s.K, self.rank, self.world)
+        except ValueError as e:
+            raise PlanUnsupported(str(e))
+        self.K_local, self.k_offset = hi - lo, lo
+        self.outer = s.time_approx == 'outer'
+        self.nets = _nets(s)
+        self.net = s.z_n                              # identity check in Solver._choose_plan
+        self.B = len(self.nets)                       # parameter sets
+        self.H = self.nets[0].nn_dims[1]
+        self.di = s.d + (0 if self.outer else 1)
+        self._flatten()
+        self.d_pad, self.H_pad = _instance_for(s.d, self.H)
+        self.pad = shapes.ParamPad(s.d, self.H, self.d_pad, self.H_pad, dev)      # used for the problem data / x0 / noise only
+        spec = s.problem.native_spec()
+        self._keep = []
+
+        def dev_f32(t):
+            if t is None:
+                return None
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t
+
+        cfg = nat.DnetConfig()
+        b = cfg.base
+        b.d, b.H = self.d_pad, self.H_pad
+        b.K_local, b.N, b.K_global, b.k_offset = self.K_local, s.N, s.K, self.k_offset
+        b.dt, b.sqrt_dt = float(s.delta_t.item()), float(s.sq_delta_t.item())
+        b.drift_kind, b.sigma_kind, b.sigma_scale = spec['drift'][0], spec['sigma'][0], float(spec['sigma'][2])
+        b.runcost_kind, b.term_kind = spec['runcost'][0], spec['term'][0]
+        b.adaptive = 1 if s.adaptive_forward_process else 0
+        b.loss_kind = {'log-variance': nat.LOSS_LOG_VARIANCE, 'moment': nat.LOSS_MOMENT}.get(s.loss_method, nat.LOSS_WEIGHTS)
+        self.generic_loss = b.loss_kind == nat.LOSS_WEIGHTS
+        b.noise_mode = nat.NOISE_PHILOX if noise == 'philox' else nat.NOISE_SUPPLIED
+        b.store_path = 1
+        pad = self.pad
+        b.drift = nat.ptr(dev_f32(pad.drift_or_sigma(spec['drift'][1]))) if spec['drift'][1] is not None else None
+        b.sigma = nat.ptr(dev_f32(pad.drift_or_sigma(spec['sigma'][1]))) if spec['sigma'][1] is not None else None
+        b.runcost = nat.ptr(dev_f32(pad.vec(spec['runcost'][1]))) if spec['runcost'][1] is not None else None
+        b.term = nat.ptr(dev_f32(pad.vec(spec['term'][1])))
+        cfg.d_real, cfg.H_real = s.d, self.H
+        cfg.time_input, cfg.per_step = (0 if self.outer else 1), (1 if self.outer else 0)
+        self.cfg = cfg
+        sizes = nat.DnetSizes()
+        nat.check(self.lib.psp_dnet_query(C.byref(cfg), C.byref(sizes)), 'psp_dnet_query')
+        assert sizes.n_params_per_set == self.Pset, (sizes.n_params_per_set, self.Pset)
+        f32 = torch.float32
+        self.tables = torch.empty(sizes.table_bytes // 4, dtype=f32, device=dev)
+        self.fwd_partial = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)
+        self.PX = torch.empty(s.N, self.K_local, s.d, dtype=f32, device=dev)
+        self.PXI = torch.empty(s.N, self.K_local, s.d, dtype=f32, device=dev)
+        self.D = torch.empty(self.K_local, dtype=f32, device=dev)
+        self.Yn = torch.empty(self.K_local, dtype=f32, device=dev) if self.generic_loss else None
+        self.w = torch.empty(self.K_local, dtype=f32, device=dev) if self.generic_loss else None
+        self.sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.grad = torch.zeros(self.P, dtype=f32, device=dev)
+        self.m = torch.zeros(self.P, dtype=f32, device=dev)
+        self.v = torch.zeros(self.P, dtype=f32, device=dev)
+        self.x0_vec = dev_f32(pad.vec(s.X_0.detach().to(dev)))
+        self.tn = (torch.arange(s.N, device=dev, dtype=f32) * b.dt)        # fp32 n * dt, as the kernel forms it
+        self.step = 0
+        self.events = None
+        self.ul2 = None
+        self.learn_y0 = bool(s.learn_Y_0)
+        if self.learn_y0:
+            self.y0_param = s.y_0.Y_0
+            self.y0_m = torch.zeros(1, dtype=f32, device=dev)
+            self.y0_v = torch.zeros(1, dtype=f32, device=dev)
+            self.y0_grad = torch.zeros(1, dtype=f32, device=dev)
+        # sample chunk of the gradient GEMMs: bounds the recomputed activations ((di + 2H + d) floats per sample)
+        self.chunk = max(1, (1 << 21) // max(1, self.K_local)) if not self.outer else s.N
+
+    # ------------------------------------------------------------------------------------
+    def _flatten(self):
+        """All parameter sets as views of ONE flat fp32 buffer [set 0 | set 1 | ...] (include/psp.h layout per set):
+        state_dict / save_networks / Z_n keep working on live values, the fused Adam sees one vector."""
+        per = [list(net.W) for net in self.nets]                     # registration order W1,b1,W2,b2,W3,b3
+        self.Pset = sum(p.numel() for p in per[0])
+        self.P = self.Pset * len(per)
+        flat = torch.empty(self.P, dtype=torch.float32, device=self.dev)
+        off = 0
+        for params in per:
+            for p in params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+        self.flat = flat
+        di, H, d = self.di, self.H, self.nets[0].nn_dims[3]
+        o, self.off = 0, {}
+        for name, shape in (('W1', (di, H)), ('b1', (H,)), ('W2', (di + H, H)), ('b2', (H,)),
+                            ('W3', (di + 2 * H, d)), ('b3', (d,))):
+            n = 1
+            for v in shape:
+                n *= v
+            self.off[name] = (o, n, shape)
+            o += n
+
+    def _set_view(self, buf, name):
+        """(B, *shape) strided view of one tensor of every parameter set inside a flat (B * Pset) buffer."""
+        o, n, shape = self.off[name]
+        return buf.view(self.B, self.Pset)[:, o:o + n].reshape(self.B, *shape) if self.B == 1 else \
+            buf.view(self.B, self.Pset)[:, o:o + n].unflatten(1, shape)
+
+    _reference_noise = HjbNativePlan._reference_noise
+    _generic_loss_weights = HjbNativePlan._generic_loss_weights
+
+    # ------------------------------------------------------------------------------------
+    def _gradient(self, w):
+        """grad of sum_{n,k} G_n[k] . Z_n(X_n[k]) over all parameter sets, G = w_k sqrt(dt) image (row-major stores)."""
+        s, H, di, d = self.s, self.H, self.di, self.s.d
+        N, K = s.N, self.K_local
+        grad = self.grad
+        grad.zero_()
+        W1, b1, W2, b2, W3 = (self._set_view(self.flat, k) for k in ('W1', 'b1', 'W2', 'b2', 'W3'))
+        gW1, gb1, gW2, gb2, gW3, gb3 = (self._set_view(grad, k) for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'))
+        W3h = W3[:, di:, :].transpose(1, 2)                       # (B, d, 2H): d[h1, h2] = G W3h
+        W2h = W2[:, di:, :].transpose(1, 2)                       # (B, H, H)
+        scale = (w * float(self.cfg.base.sqrt_dt)).view(1, K, 1)
+        for n0 in range(0, N, self.chunk):
+            n1 = min(N, n0 + self.chunk)
+            X = self.PX[n0:n1]
+            G = self.PXI[n0:n1] * scale                           # (n, K, d)
+            if self.outer:
+                U, sl = X, slice(n0, n1)                          # batch = time steps, one net each
+            else:
+                t = self.tn[n0:n1].view(-1, 1, 1).expand(n1 - n0, K, 1)
+                U, G, sl = torch.cat([t, X], 2).reshape(1, -1, di), G.reshape(1, -1, d), slice(0, 1)
+            r1 = torch.relu(torch.baddbmm(b1[sl].unsqueeze(1), U, W1[sl]))
+            U2 = torch.cat([U, r1 * r1], 2)
+            r2 = torch.relu(torch.baddbmm(b2[sl].unsqueeze(1), U2, W2[sl]))
+            U3 = torch.cat([U2, r2 * r2], 2)
+            gW3[sl] += torch.bmm(U3.transpose(1, 2), G)
+            gb3[sl] += G.sum(1)
+            dh = torch.bmm(G, W3h[sl])                            # (B, S, 2H): [dh1 (skip path), dh2]
+            dz2 = dh[:, :, H:] * (2.0 * r2)
+            gW2[sl] += torch.bmm(U2.transpose(1, 2), dz2)
+            gb2[sl] += dz2.sum(1)
+            dz1 = (dh[:, :, :H] + torch.bmm(dz2, W2h[sl])) * (2.0 * r1)
+            gW1[sl] += torch.bmm(U.transpose(1, 2), dz1)
+            gb1[sl] += dz1.sum(1)
+        return grad
+
+    def iteration(self, l, loss_out, ul2_out=None):
+        s, lib, cfg = self.s, self.lib, self.cfg
+        st = nat.stream_ptr(self.dev)
+        seed = int(s.seed) & 0xFFFFFFFFFFFFFFFF
+        xi = x0 = None
+        if self.noise == 'reference':
+            xi, x0 = self._reference_noise()
+        elif s.random_X_0:
+            g = torch.Generator(device=self.dev)
+            g.manual_seed(int(s.seed) * 1000003 + l)
+            x0 = self.pad.last_dim(torch.randn(s.K, s.d, generator=g, device=self.dev)[
+                self.k_offset:self.k_offset + self.K_local].contiguous())
+        x0_t = x0 if x0 is not None else self.x0_vec
+        ev = None
+        if self.events is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        nat.check(lib.psp_dnet_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0_t), self.d_pad if x0 is not None else 0,
+                                           nat.ptr(self.y0_param) if self.learn_y0 else None, nat.ptr(xi), seed, l, None,
+                                           nat.ptr(self.PX), nat.ptr(self.PXI), nat.ptr(self.D), None, None,
+                                           nat.ptr(self.Yn), nat.ptr(self.fwd_partial), nat.ptr(self.tables), st),
+                  'psp_dnet_rollout_fwd')
+        if ev is not None:
+            ev[1].record()
+        nat.check(lib.psp_dnet_terminal_reduce(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums), st),
+                  'psp_dnet_terminal_reduce')
+        sharding.allreduce_sum_(self.sums)                        # collective 1: 16 bytes
+        if self.generic_loss:
+            loss, w = self._generic_loss_weights()
+        else:
+            loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
+            w = sharding.loss_weights(self.D, self.sums, s.K, s.loss_method)
+        loss_out[l] = loss.to(torch.float32)
+        if ev is not None:
+            ev[2].record()
+        self._gradient(w)
+        if ev is not None:
+            ev[3].record()
+            self.events.append(ev)
+        sharding.allreduce_sum_(self.grad)                        # collective 2
+        self.step += 1
+        nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
+                                    self.P, self.step, float(s.lr), 0.9, 0.999, 1e-8, st), 'psp_adam_step')
+        if self.learn_y0:
+            self.y0_grad[0] = sharding.y0_gradient(self.sums, s.K, s.loss_method)
+            nat.check(lib.psp_adam_step(nat.ptr(self.y0_param), nat.ptr(self.y0_grad), nat.ptr(self.y0_m),
+                                        nat.ptr(self.y0_v), 1, self.step, float(s.lr), 0.9, 0.999, 1e-8, st),
+                      'psp_adam_step(Y_0)')
+        return loss

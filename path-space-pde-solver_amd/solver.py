@@ -33,14 +33,16 @@ import torch
 try:
     from .function_space import DenseNet, MySequential, SingleParam
     from .plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
+    from .plan_dense_native import DenseNativePlan, dense_eligibility
     from . import native as _nat
-    from .general_solver import GeneralSolver  # noqa: F401  (reference: `from solver import GeneralSolver`)
+    from .general_solver import GeneralSolver, EllipticSolver  # noqa: F401  (reference: `from solver import GeneralSolver`)
     from .utilities import do_importance_sampling_me
 except ImportError:  # flat import: this directory itself is on sys.path, as with the reference
     from function_space import DenseNet, MySequential, SingleParam
     from plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
+    from plan_dense_native import DenseNativePlan, dense_eligibility
     import native as _nat
-    from general_solver import GeneralSolver  # noqa: F401
+    from general_solver import GeneralSolver, EllipticSolver  # noqa: F401
     from utilities import do_importance_sampling_me
 
 
@@ -255,6 +257,16 @@ class Solver:
                 plan = HjbNativePlan(self, noise=self.noise)     # owns the flat parameters and Adam moments
                 self._native_plan = plan
             return plan
+        dense_reason = dense_eligibility(self)  # DenseNet controls: time_approx='outer', DenseNet swapped into z_n
+        if dense_reason is None:
+            self.plan_name, self.plan_reason = 'native', None
+            plan = getattr(self, '_native_plan', None)
+            if plan is None or plan.net is not self.z_n or plan.noise != self.noise or not isinstance(plan, DenseNativePlan):
+                plan = DenseNativePlan(self, noise=self.noise)
+                self._native_plan = plan
+            return plan
+        if isinstance(self.z_n, list) or isinstance(self.z_n, DenseNet):
+            reason = dense_reason
         if self.backend == 'native':
             raise PlanUnsupported('native plan unavailable: ' + reason)
         if self.device.type == 'cuda':

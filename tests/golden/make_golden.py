@@ -366,6 +366,21 @@ CASES = [
          solver=dict(loss_method="log-variance", time_approx="outer", adaptive_forward_process=True,
                      detach_forward=True, early_stopping_time=None, L=3, lr=0.01, seed=42,
                      delta_t=0.05, K=64, u_l2_error_flag=False)),
+    # DenseNet controls on the native plan (csrc/hjbd_kernels.h): 'outer' with a padded shape and learn_Y_0, and a
+    # DenseNet(d+1 -> d) with a generic loss on the double well
+    dict(name="llgc_d12_outer_moment", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=12, off_diag=0.05, T=0.2, seed=42)),
+         solver=dict(loss_method="moment", learn_Y_0=True, time_approx="outer", adaptive_forward_process=True,
+                     detach_forward=True, early_stopping_time=None, L=4, lr=0.003, seed=42, delta_t=0.02, K=80,
+                     u_l2_error_flag=False)),
+    dict(name="dw_d20_densenet_nonadaptive", family="solver",
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=20, d_1=10, d_2=10, T=0.2, eta=0.3, kappa=1.0)),
+         solver=dict(HJB, adaptive_forward_process=False, L=4, lr=0.002, seed=42, delta_t=0.01, K=96, u_l2_error_flag=False),
+         net=dict(kind="densenet", arch=[40, 40], seed=7), probe_times=[0.0, 0.1]),
+    dict(name="lqgc_d6_densenet_variance", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=6, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
+         solver=dict(HJB, loss_method="variance", L=4, lr=0.005, seed=42, delta_t=0.05, K=128, u_l2_error_flag=False),
+         net=dict(kind="densenet", arch=[24, 24], seed=7), probe_times=[0.0]),
     # importance-sampling evaluation of the learned control, standalone and in the loop
     dict(name="llgc_d20_is_eval", family="is",
          problem=dict(kind="LLGC", kwargs=dict(d=20, off_diag=0.0, T=0.3, seed=42)),

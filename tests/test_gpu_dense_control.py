@@ -1,0 +1,85 @@
+"""GPU parity of the DenseNet-control plan (csrc/hjbd_kernels.h forward rollout + GEMM gradient, plan_dense_native.py):
+time_approx='outer' (the reference's constructor default: one DenseNet(d -> d) per time step) and a
+DenseNet(d+1 -> d) swapped into z_n.  Same bars as test_gpu_parity.py: D_k <= 2e-5 max|D|, gradient <= 2e-4 max|g|
+against the oracle's autograd, loss logs <= 1e-4 relative against the reference's own runs."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from util_cases import flat_params, make_oracle, make_pkg_solver, orc, psp
+
+pytestmark = pytest.mark.gpu
+CASES = ["lqgc_d2_outer", "llgc_d100_densenet64_logvar", "llgc_d12_outer_moment", "dw_d20_densenet_nonadaptive", "lqgc_d6_densenet_variance"]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_first_iteration_D_and_gradient_match_oracle(name):
+    case = load_golden(name)["case"]
+    model = make_pkg_solver(case, dev(), backend="native", L=1)
+    oprob, ocfg, omodels = make_oracle(case, L=1)
+    model.train()
+    assert model.plan_name == "native" and isinstance(model._native_plan, psp.plan_dense_native.DenseNativePlan)
+    plan = model._native_plan
+    ref = orc.hjb_train(oprob, ocfg, step_models=omodels, trace=True)
+    tr = ref["traces"][0]
+    D, D_ref = plan.D.cpu(), tr["D"]
+    assert float((D - D_ref).abs().max()) <= 2e-5 * max(1.0, float(D_ref.abs().max()))
+    g, g_ref = plan.grad.cpu(), torch.cat([x.reshape(-1) for x in tr["grads"]])
+    assert g.shape == g_ref.shape
+    assert float((g - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
+    cond = float((D_ref.double() ** 2).mean()) / max(abs(ref["loss_log"][0]), 1e-30)
+    tol = min(1e-4, max(2e-5, 4 * 6e-8 * cond))
+    assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=tol), (model.loss_log[0], ref["loss_log"][0])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_loss_log_matches_reference_golden(name):
+    rec = load_golden(name)
+    model = make_pkg_solver(rec["case"], dev(), backend="native")
+    model.train()
+    exp = rec["expected"]
+    assert len(model.loss_log) == len(exp["loss_log"])
+    for l, (got, want) in enumerate(zip(model.loss_log, exp["loss_log"])):
+        assert math.isclose(got, want, rel_tol=1e-4), (l, model.loss_log, exp["loss_log"])
+    for got, want in zip(model.Y_0_log, exp["Y_0_log"]):
+        assert math.isclose(got, want, rel_tol=1e-4, abs_tol=1e-6)
+    if exp["probes"]:
+        xp = torch.tensor(exp["probe_x"]).reshape(-1, model.d).to(dev())
+        for pr in exp["probes"]:
+            with torch.no_grad():
+                u = (-model.Z_n(xp, pr["t"])).cpu()
+            want = torch.tensor(pr["minus_Z"]).reshape(u.shape)
+            assert float((u - want).abs().max()) <= 1e-4 * max(1e-2, float(want.abs().max()))
+
+
+def test_outer_philox_large_is_deterministic_and_shard_independent():
+    """K = 2^15, d = 40, N = 30 with device noise: two runs agree bitwise in D; the upper half of the trajectories run
+    alone (k_offset = K/2) reproduces the full run's D."""
+    d, K = 40, 1 << 15
+    prob = psp.LLGC(d=d, off_diag=0.05, T=0.3, seed=42, device=dev())
+
+    def make(Kx):
+        return psp.Solver(name="big", problem=prob, loss_method="log-variance", time_approx="outer", L=1, lr=1e-3, seed=42,
+                          delta_t=0.01, K=Kx, adaptive_forward_process=True, detach_forward=True, u_l2_error_flag=False,
+                          verbose=False, device=dev(), backend="native", noise="philox")
+
+    a, b = make(K), make(K)
+    a.train()
+    b.train()
+    pa, pb = a._native_plan, b._native_plan
+    assert a.loss_log == b.loss_log and math.isfinite(a.loss_log[0])
+    assert torch.equal(pa.D, pb.D) and bool(torch.isfinite(pa.grad).all())
+    half = make(K // 2)
+    ph = psp.plan_dense_native.DenseNativePlan(half, noise="philox")
+    ph.flat.copy_(torch.cat([p.detach().reshape(-1) for net in make(K).z_n for p in net.W]).to(dev()))
+    ph.cfg.base.k_offset = K // 2
+    losses = torch.zeros(1, device=dev())
+    ph.iteration(0, losses)
+    torch.cuda.synchronize()
+    assert torch.equal(ph.D, pa.D[K // 2:])
