@@ -10,7 +10,7 @@ Per iteration (reference solver.py:430-514):
     psp_dnet_terminal_reduce (sum D, sum D^2)                      [all-reduce 1]
     parameter gradient       detach_forward=True makes dL/dZ_n[k] = w_k sqrt(dt) image_n[k], so the gradient
                              of every net is that of a plain feed-forward batch: recomputed activations and ~12 library
-                             GEMMs (torch.bmm: batch = time steps for 'outer', one flat batch for 'inner'), written
+                             GEMMs (batched over the time steps; 'inner' shares one net across the batch), written
                              analytically below -- no autograd graph                    [all-reduce 2]
     psp_adam_step            one fused Adam over the concatenation of all parameter sets (identical to the reference's
                              per-net Adams: same lr, betas and step count)
@@ -214,24 +214,27 @@ class DenseNativePlan:
             n1 = min(N, n0 + self.chunk)
             X = self.PX[n0:n1]
             G = self.PXI[n0:n1] * scale                           # (n, K, d)
+            # batch = time steps in both modes: 'outer' pairs step n with its own net, 'inner' broadcasts the one net over
+            # the steps and sums the per-step weight gradients (rocBLAS handles n reductions over K rows far better than
+            # one tall-skinny reduction over n K rows)
             if self.outer:
-                U, sl = X, slice(n0, n1)                          # batch = time steps, one net each
+                U, sl = X, slice(n0, n1)
             else:
-                t = self.tn[n0:n1].view(-1, 1, 1).expand(n1 - n0, K, 1)
-                U, G, sl = torch.cat([t, X], 2).reshape(1, -1, di), G.reshape(1, -1, d), slice(0, 1)
-            r1 = torch.relu(torch.baddbmm(b1[sl].unsqueeze(1), U, W1[sl]))
+                U, sl = torch.cat([self.tn[n0:n1].view(-1, 1, 1).expand(n1 - n0, K, 1), X], 2), slice(0, 1)
+            red = (lambda t: t) if self.outer else (lambda t: t.sum(0, keepdim=True))
+            r1 = torch.relu(torch.matmul(U, W1[sl]) + b1[sl].unsqueeze(1))
             U2 = torch.cat([U, r1 * r1], 2)
-            r2 = torch.relu(torch.baddbmm(b2[sl].unsqueeze(1), U2, W2[sl]))
+            r2 = torch.relu(torch.matmul(U2, W2[sl]) + b2[sl].unsqueeze(1))
             U3 = torch.cat([U2, r2 * r2], 2)
-            gW3[sl] += torch.bmm(U3.transpose(1, 2), G)
-            gb3[sl] += G.sum(1)
-            dh = torch.bmm(G, W3h[sl])                            # (B, S, 2H): [dh1 (skip path), dh2]
+            gW3[sl] += red(torch.matmul(U3.transpose(1, 2), G))
+            gb3[sl] += red(G.sum(1))
+            dh = torch.matmul(G, W3h[sl])                         # (n, K, 2H): [dh1 (skip path), dh2]
             dz2 = dh[:, :, H:] * (2.0 * r2)
-            gW2[sl] += torch.bmm(U2.transpose(1, 2), dz2)
-            gb2[sl] += dz2.sum(1)
-            dz1 = (dh[:, :, :H] + torch.bmm(dz2, W2h[sl])) * (2.0 * r1)
-            gW1[sl] += torch.bmm(U.transpose(1, 2), dz1)
-            gb1[sl] += dz1.sum(1)
+            gW2[sl] += red(torch.matmul(U2.transpose(1, 2), dz2))
+            gb2[sl] += red(dz2.sum(1))
+            dz1 = (dh[:, :, :H] + torch.matmul(dz2, W2h[sl])) * (2.0 * r1)
+            gW1[sl] += red(torch.matmul(U.transpose(1, 2), dz1))
+            gb1[sl] += red(dz1.sum(1))
         return grad
 
     def iteration(self, l, loss_out, ul2_out=None):
