@@ -116,6 +116,92 @@ def _is_native(problem, model, K, delta_t):
     return _stats(D - 2.0 * Fint)
 
 
+def _dense_reason(problem, model):
+    """None if the learned control is a DenseNet configuration the hjbd forward kernel covers (plan_dense_native.py)."""
+    try:
+        from .plan_dense_native import dense_eligibility
+    except ImportError:
+        from plan_dense_native import dense_eligibility
+    if getattr(model, 'backend', 'auto') == 'torch':
+        return "backend='torch' requested"
+    saved = (model.IS_variance_K, model.u_l2_error_flag, model.loss_method, model.detach_forward)
+    model.IS_variance_K, model.u_l2_error_flag, model.loss_method, model.detach_forward = 0, False, 'log-variance', True
+    try:                                              # (training-only restrictions do not matter for a forward sweep)
+        return dense_eligibility(model)
+    finally:
+        model.IS_variance_K, model.u_l2_error_flag, model.loss_method, model.detach_forward = saved
+
+
+def _is_dense_native(problem, model, K, delta_t):
+    """The controlled forward sweep of utilities.py:296-330 on the DenseNet-control rollout kernel.  The reference
+    evaluates Z_n(X, n delta_t) through solver.py:360-362: step index ceil(t / model.delta_t) -> the time feature
+    (inner) or the per-step net (outer); here that index selects the time-feature entry or the parameter set."""
+    try:
+        from .plan_dense_native import _instance_for, _nets
+    except ImportError:
+        from plan_dense_native import _instance_for, _nets
+    dev = model.device
+    lib = nat.load()
+    N = int(np.ceil(problem.T / delta_t))
+    spec = problem.native_spec()
+    keep = []
+
+    def dev_f32(t):
+        t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep.append(t)
+        return t
+
+    nets = _nets(model)
+    outer = model.time_approx == 'outer'
+    H = nets[0].nn_dims[1]
+    d_pad, H_pad = _instance_for(model.d, H)
+    pad = shapes.ParamPad(model.d, H, d_pad, H_pad, dev)
+    cfg = nat.DnetConfig()
+    b = cfg.base
+    b.d, b.H, b.K_local, b.N, b.K_global, b.k_offset = d_pad, H_pad, K, N, K, 0
+    b.dt = float(torch.tensor(delta_t, dtype=torch.float32).item())
+    b.sqrt_dt = float(torch.tensor(np.sqrt(delta_t), dtype=torch.float32).item())
+    b.drift_kind, b.sigma_kind, b.sigma_scale = spec['drift'][0], spec['sigma'][0], float(spec['sigma'][2])
+    b.runcost_kind, b.term_kind = spec['runcost'][0], spec['term'][0]
+    b.adaptive, b.loss_kind, b.store_path = 1, nat.LOSS_LOG_VARIANCE, 0
+    philox = getattr(model, 'noise', 'reference') == 'philox'
+    b.noise_mode = nat.NOISE_PHILOX if philox else nat.NOISE_SUPPLIED
+    b.drift = nat.ptr(dev_f32(pad.drift_or_sigma(spec['drift'][1]))) if spec['drift'][1] is not None else None
+    b.sigma = nat.ptr(dev_f32(pad.drift_or_sigma(spec['sigma'][1]))) if spec['sigma'][1] is not None else None
+    b.runcost = nat.ptr(dev_f32(pad.vec(spec['runcost'][1]))) if spec['runcost'][1] is not None else None
+    b.term = nat.ptr(dev_f32(pad.vec(spec['term'][1])))
+    cfg.d_real, cfg.H_real = model.d, H
+    cfg.time_input, cfg.per_step = (0 if outer else 1), (1 if outer else 0)
+    sets = [torch.cat([p.detach().reshape(-1) for p in net.W]).to(dev) for net in nets]
+    tfeat = _time_feature_table(model, N, delta_t)
+    if outer:                                        # one parameter set per EVALUATION step: the net solver.py:192-193 picks
+        dt32 = float(model.delta_t.detach().cpu())
+        idx = [max(0, min(int(round(float(t) / dt32)), model.N - 1)) for t in tfeat.tolist()]
+        flat = torch.cat([sets[i] for i in idx]).contiguous()
+    else:
+        flat = sets[0].contiguous()
+    sizes = nat.DnetSizes()
+    nat.check(lib.psp_dnet_query(C.byref(cfg), C.byref(sizes)), 'psp_dnet_query')
+    xi = None
+    if not philox:                                   # the reference's draws: N x randn(K, d) (utilities.py:310)
+        xi_cpu = torch.zeros(N + 1, K, model.d)
+        for n in range(N):
+            xi_cpu[n + 1] = torch.randn(K, model.d)
+        xi = pad.last_dim(xi_cpu.to(dev))
+    tfeat = tfeat.to(dev)
+    x0 = dev_f32(pad.vec(torch.as_tensor(problem.X_0, dtype=torch.float32).to(dev)))
+    D = torch.empty(K, dtype=torch.float32, device=dev)
+    Fint = torch.empty(K, dtype=torch.float32, device=dev)
+    part = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)
+    tables = torch.empty(sizes.table_bytes // 4, dtype=torch.float32, device=dev)
+    model._is_calls = getattr(model, '_is_calls', 0) + 1
+    nat.check(lib.psp_dnet_rollout_fwd(C.byref(cfg), nat.ptr(flat), nat.ptr(x0), 0, None, nat.ptr(xi),
+                                       (int(model.seed) + 7919) & 0xFFFFFFFFFFFFFFFF, model._is_calls, nat.ptr(tfeat),
+                                       None, None, nat.ptr(D), nat.ptr(Fint), None, None, nat.ptr(part),
+                                       nat.ptr(tables), nat.stream_ptr(dev)), 'psp_dnet_rollout_fwd')
+    return _stats(D - 2.0 * Fint)
+
+
 def _is_composite(problem, model, K, delta_t):
     dev = model.device
     sq_dt = np.sqrt(delta_t)
@@ -146,6 +232,8 @@ def do_importance_sampling_me(problem, model, K, control='approx', simulate_naiv
     reason = _native_reason(problem, model, control, simulate_naive)
     if reason is None:
         out = _is_native(problem, model, K, delta_t)
+    elif _dense_reason(problem, model) is None:
+        out = _is_dense_native(problem, model, K, delta_t)
     else:
         if getattr(model, 'backend', 'auto') == 'native':
             raise NotImplementedError('native IS evaluation unavailable: ' + reason)

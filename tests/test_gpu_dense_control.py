@@ -83,3 +83,22 @@ def test_outer_philox_large_is_deterministic_and_shard_independent():
     ph.iteration(0, losses)
     torch.cuda.synchronize()
     assert torch.equal(ph.D, pa.D[K // 2:])
+
+
+@pytest.mark.parametrize("name", ["llgc_d12_outer_moment", "lqgc_d6_densenet_variance"])
+def test_importance_sampling_evaluation_on_the_dense_kernel(name):
+    """utilities.do_importance_sampling_me (reference utilities.py:287-359) with a DenseNet control: the forward sweep on
+    hjbd_fwd_kernel against the same sweep in torch, same host noise; the evaluation grid (delta_t = 0.01) differs from
+    the training grid, so the step -> net / time-feature index map of solver.py:360-362 is exercised."""
+    case = load_golden(name)["case"]
+    model = make_pkg_solver(case, dev(), backend="native", L=2)
+    model.train()
+    ut = psp.utilities
+    assert ut._native_reason(model.problem, model, "approx", False) is not None      # not the tanh-MLP path
+    assert ut._dense_reason(model.problem, model) is None
+    torch.manual_seed(11)
+    got = ut.do_importance_sampling_me(model.problem, model, 400, delta_t=0.01)
+    torch.manual_seed(11)
+    want = ut._is_composite(model.problem, model, 400, 0.01)
+    for a, b in zip(got, want):
+        assert math.isclose(a, b, rel_tol=2e-4), (got, want)
