@@ -72,7 +72,7 @@ typedef struct psp_hjb_config {
     const float* sigma;   /* DENSE: B (d*d row-major); else NULL                  */
     const float* runcost; /* DIAG_QUAD: p (d); else NULL                          */
     const float* term;    /* alpha / r / eta (d)                                  */
-    const float* u_ref;   /* optional (N, d): reference control u*(t_n) of a solution that does not depend on x
+    const float* u_ref;   /* optional (N, d) + 16 floats of slack: reference control u*(t_n) of a solution that does not depend on x
                            * (LLGC, problems.py:51-53); enables the u_L2 log of solver.py:491-494 inside the
                            * forward kernels.  NULL: no logging                                             */
     float* u_l2_out;      /* (K_local): sum_n |-Z_n(X_n) - u*(t_n)|^2 dt per trajectory (mean = u_L2_loss)  */

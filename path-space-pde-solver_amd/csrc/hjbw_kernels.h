@@ -210,7 +210,9 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
 // Wide forward kernel: one wave = one 16-trajectory tile for all N steps (same per-step algebra, same
 // reference lines as hjb_fwd_kernel)
 // =======================================================================================
-template <int D, int H>
+// LOGU: the u_L2 log of solver.py:491-494 (psp_hjb_config.u_ref); a separate instantiation because at d = 500 the kernel
+// sits on the 512-register limit and two more live accumulators cost the ordinary path 8 % (measured)
+template <int D, int H, bool LOGU = false>
 __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
                 X[b][r] = (f < D && kvalid) ? v : 0.f;
             }
         float Y = a.y0 ? a.y0[0] : 0.f;
-        float Fsum = 0.f, ULsum = 0.f;
+        float Fsum = 0.f;
+        [[maybe_unused]] float ULsum = 0.f;
 
 #ifdef PSP_STAMPS
         unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -337,7 +340,8 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
             // ---- control output, Brownian increment and increment panel v, four state blocks at a time, so that Z is
             //      never live as a whole: Z_g = W3[g] h2 + b3 -> row sums |Z|^2, Z.xi (solver.py:477-478) ->
             //      v = c dt + xi sqrt(dt) (c = -Z if adaptive, solver.py:451-456) -> LDS image (dense sigma) or X
-            float S = 0.f, Pz = 0.f, UL = 0.f;
+            float S = 0.f, Pz = 0.f;
+            [[maybe_unused]] float UL = 0.f;
             auto z_group = [&](auto nbc, int g) __attribute__((always_inline)) {
                 constexpr int NB = decltype(nbc)::value;
                 f32x4 Zg[NB];
@@ -374,12 +378,12 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
                         S = fmaf(Zg[m][r], Zg[m][r], S);
                         Pz = fmaf(Zg[m][r], xi[r], Pz);
                     }
-                    if (a.uref) {                      // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494)
-                        const float* ur = a.uref + (size_t)n * D;
-#pragma unroll
+                    if constexpr (LOGU) {              // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494); the table row
+                        gptr_t ur = sgpr_ptr(a.uref + (size_t)n * D + 16 * b);      // base stays in SGPRs (the host pads the
+#pragma unroll                                                              // table by 16 floats: no clamped index)
                         for (int r = 0; r < 4; ++r) {
-                            const int f = 16 * b + 4 * r + q;
-                            const float e = (f < D) ? Zg[m][r] + ur[f < D ? f : D - 1] : 0.f;
+                            float e = Zg[m][r] + ur[4 * r + q];
+                            if (16 * b + 16 > D) e = (16 * b + 4 * r + q < D) ? e : 0.f;
                             UL = fmaf(e, e, UL);
                         }
                     }
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
             if constexpr (DB % 4 != 0) z_group(std::integral_constant<int, DB % 4>{}, DB / 4);
             S = qsum(S);
             Pz = qsum(Pz);
-            ULsum = fmaf(UL, dt, ULsum);
+            if constexpr (LOGU) ULsum = fmaf(UL, dt, ULsum);
             PSP_STAMP(ws5);
             if (a.sigma_kind == SIGMA_DENSE) gemm_img<DB, KP>(X, T + W::tB, img, lane);     // X += B v
 
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
         const float Dk = Y - g;
         if (kvalid && q == 0) a.D[k] = Dk;
         if (a.Fint && kvalid && q == 0) a.Fint[k] = Fsum;
-        if (a.uref) {
+        if constexpr (LOGU) {
             const float ULt = qsum(ULsum);
             if (kvalid && q == 0) a.ul2[k] = ULt;
         }
@@ -889,10 +893,17 @@ struct HjbwLaunch {
         hipError_t e = tables(a, 0, s);
         if (e != hipSuccess) return e;
         const int bytes = W::fwd_lds_floats * 4;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H>),
+        if (a.uref) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((hjbw_fwd_kernel<D, H, true>), dim3(grid), dim3(block), bytes, s, a);
+            return hipGetLastError();
+        }
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjbw_fwd_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
+        hipLaunchKernelGGL((hjbw_fwd_kernel<D, H, false>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
     static hipError_t bwd(const HjbArgs&, int, int, hipStream_t) { return hipErrorNotSupported; }

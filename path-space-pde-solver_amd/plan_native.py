@@ -159,7 +159,8 @@ class HjbNativePlan:
             probe = torch.zeros(1, solver.d)
             rows = [torch.tensor(np.asarray(solver.problem.u_true(probe, n * solver.delta_t_np))).reshape(solver.d, -1)[:, 0].float()
                     for n in range(solver.N)]
-            self.uref = dev_f32(pad.last_dim(torch.stack(rows).to(dev)))
+            table = pad.last_dim(torch.stack(rows).to(dev)).reshape(-1)
+            self.uref = dev_f32(torch.cat([table, torch.zeros(16, device=dev)]))   # 16 floats of slack: the kernels read whole blocks
             self.ul2 = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
             cfg.u_ref, cfg.u_l2_out = nat.ptr(self.uref), nat.ptr(self.ul2)
         if self.attached or self.relent:
