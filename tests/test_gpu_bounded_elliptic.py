@@ -114,3 +114,51 @@ def test_exit_times_philox_large(kind):
         # the box test reads the proposal: nobody ever steps outside
         assert bool(((XN >= prob.X_l) & (XN <= prob.X_r)).all())
         assert int((steps < N).sum()) > 0
+
+
+def _case(family, kind, kwargs, attrs=None, net=None, **solver):
+    c = dict(name="bsweep", family=family, problem=dict(kind=kind, kwargs=kwargs), solver=dict(seed=42, lr=0.001, L=1, **solver))
+    if attrs:
+        c["problem"]["attrs"] = attrs
+    if net:
+        c["net"] = dict(arch=net, seed=42)
+    if kind == "QuadraticOnBox":
+        c["numpy_seed"] = 5
+    return c
+
+
+EDGE_CASES = [
+    # ragged K, a single step, K < 16
+    _case("general_bounded", "ExponentialOnSphereNonlinearParabolic", dict(d=2, T=0.5, alpha=0.5), delta_t=0.02, N=1, K=37,
+          K_boundary=8, alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
+    _case("general_bounded", "QuadraticOnBox", dict(d=3, T=0.4, X_l=-0.7, X_r=0.9, scale=1.5), delta_t=0.02, N=7, K=9,
+          K_boundary=6, alpha=[1.0, 2.0, 0.5], loss_method="diffusion"),
+    # padded shapes with several state blocks and wide nets; every trajectory exits before N (BSDE needs all stopped)
+    _case("general_bounded", "ExponentialOnSphereNonlinearParabolic", dict(d=37, T=0.3, alpha=0.1), net=[50, 50], delta_t=0.01,
+          N=40, K=120, K_boundary=10, alpha=[1.0, 1.0, 1.0], loss_method="BSDE"),
+    _case("general_bounded", "QuadraticOnBox", dict(d=70, T=0.2, X_l=-1.0, X_r=1.0, scale=0.7), net=[64, 64], delta_t=0.01,
+          N=12, K=200, K_boundary=10, alpha=[1.0, 1.0, 1.0], loss_method="diffusion", adaptive_forward_process=True),
+    # elliptic: box whose lower bound is positive (the zero padding of the instance lies OUTSIDE the box), one-sided box
+    _case("elliptic", "QuadraticOnBox", dict(d=5, X_l=0.5, X_r=2.0, parabolic=False), delta_t=0.01, N=15, K=50, K_boundary=10,
+          loss_method="diffusion"),
+    _case("elliptic", "QuadraticOnBox", dict(d=18, X_l=-1.0, X_r=0.4, one_boundary=True, parabolic=False, quad_h=False),
+          net=[20, 20], delta_t=0.02, N=10, K=33, K_boundary=10, loss_method="diffusion"),
+    _case("elliptic", "ExponentialOnBallNonlinear", dict(d=33, alpha=0.1), net=[48, 48], delta_t=0.002, N=25, K=64,
+          K_boundary=12, loss_method="diffusion", adaptive_forward_process=True),
+]
+
+
+@pytest.mark.parametrize("case", EDGE_CASES, ids=lambda c: "%s-%s-d%d-K%d" % (c["family"], c["problem"]["kind"][:12],
+                                                                         c["problem"]["kwargs"]["d"], c["solver"]["K"]))
+def test_edge_shapes_match_oracle(case):
+    """Ragged K, single step, padded instances, boxes that exclude the origin: first iteration against the oracle."""
+    prob, model = build_pkg(case, device=dev(), backend="native", L=1)
+    model.train()
+    assert model.plan_name == "native"
+    ref = oracle_run(case, 1)
+    assert model.K_log == ref["K_log"]
+    assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=5e-5), (model.loss_log, ref["loss_log"])
+    g_ref = torch.cat([g.reshape(-1) for g in ref["traces"][0]["grads"]])
+    g = model._gen_plan.grad.cpu()
+    err = float((g - g_ref).abs().max())
+    assert err <= 5e-4 * float(g_ref.abs().max()), (err, float(g_ref.abs().max()))

@@ -102,3 +102,50 @@ def test_importance_sampling_evaluation_on_the_dense_kernel(name):
     want = ut._is_composite(model.problem, model, 400, 0.01)
     for a, b in zip(got, want):
         assert math.isclose(a, b, rel_tol=2e-4), (got, want)
+
+
+# (time_approx, problem kind, d, H, K, delta_t, T, adaptive): corners of the instance grid, ragged K, single step, tiny nets
+DENSE_SHAPES = [
+    ("outer", "LLGC", 3, 5, 37, 0.05, 0.2, True),          # (16, 32) instance, K not a multiple of 16
+    ("outer", "LQGC", 17, 33, 16, 0.05, 0.05, True),       # N = 1; (32, 64)
+    ("inner", "LLGC", 64, 64, 100, 0.05, 0.15, True),      # exact (64, 64)
+    ("inner", "DoubleWell_multidim", 65, 30, 50, 0.05, 0.1, False),   # -> (128, 32), elementwise drift, non-adaptive image
+    ("outer", "LLGC", 130, 40, 24, 0.05, 0.1, True),       # -> (256, 64): 16 state blocks, dense A and B
+    ("inner", "LQGC", 200, 16, 20, 0.05, 0.1, True),       # -> (256, 32), running + terminal quadratic costs
+    ("outer", "LLGC", 20, 30, 5000, 0.05, 0.15, True),     # many workgroups (313 tiles)
+]
+
+
+@pytest.mark.parametrize("mode,kind,d,H,K,dt,T,adaptive", DENSE_SHAPES)
+def test_dense_shape_sweep_matches_oracle(mode, kind, d, H, K, dt, T, adaptive):
+    if kind == "DoubleWell_multidim":
+        kwargs = dict(d=d, d_1=d // 2, d_2=d - d // 2, T=T, eta=0.05, kappa=1.0)
+    elif kind == "LQGC":
+        kwargs = dict(d=d, off_diag=0.05, T=T, seed=42, delta_t=dt)
+    else:
+        kwargs = dict(d=d, off_diag=0.3 / d ** 0.5, T=T, seed=42)
+    solver = dict(loss_method="log-variance", time_approx=mode, adaptive_forward_process=adaptive, detach_forward=True,
+                  early_stopping_time=None, L=1, lr=0.002, seed=42, delta_t=dt, K=K, u_l2_error_flag=False)
+    case = dict(name="dsweep", family="solver", problem=dict(kind=kind, kwargs=kwargs), solver=solver)
+    if mode == "inner":
+        case["net"] = dict(kind="densenet", arch=[H, H], seed=5)
+    model = make_pkg_solver(case, dev(), backend="native", L=1)
+    oprob, ocfg, omodels = make_oracle(case, L=1)
+    if mode == "outer":                                   # arch is not a Solver keyword: swap the per-step nets on both sides
+        model.z_n = [psp.DenseNet(d_in=d, d_out=d, lr=0.002, arch=[H, H], seed=5 + n).to(dev()) for n in range(model.N)]
+        model.update_Phis()
+        z = [orc.DenseNetOracle(d, d, 0.002, arch=[H, H], seed=5 + n) for n in range(model.N)]
+        omodels = (z, omodels[1], omodels[2])
+    model.train()
+    assert model.plan_name == "native" and isinstance(model._native_plan, psp.plan_dense_native.DenseNativePlan)
+    plan = model._native_plan
+    ref = orc.hjb_train(oprob, ocfg, step_models=omodels, trace=True)
+    tr = ref["traces"][0]
+    D = plan.D.cpu()
+    assert D.shape == tr["D"].shape
+    assert float((D - tr["D"]).abs().max()) <= 2e-5 * max(1.0, float(tr["D"].abs().max()))
+    g, g_ref = plan.grad.cpu(), torch.cat([x.reshape(-1) for x in tr["grads"]])
+    assert g.shape == g_ref.shape
+    assert float((g - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max()), (plan.d_pad, plan.H_pad)
+    cond = float((tr["D"].double() ** 2).mean()) / max(abs(ref["loss_log"][0]), 1e-30)
+    assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=min(1e-4, max(2e-5, 4 * 6e-8 * cond)))
