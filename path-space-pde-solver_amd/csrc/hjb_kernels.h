@@ -243,22 +243,15 @@ __device__ __forceinline__ double jsum(double v) {  // sum over the 16 trajector
     return v;
 }
 
-// Branch-free fp32 tanh (ocml tanhf is a two-way divergent branch per call).
-//   |x| <  0.35 : odd Taylor series to x^11 (truncation < 5e-9 relative)
-//   |x| >= 0.35 : 1 - 2 / (exp(2|x|) + 1), exp via v_exp_f32, 1/x via v_rcp_f32 (~1 ulp each)
-// Max error vs fp64 tanh ~3e-7 relative (tests/test_gpu_kernels.py checks it on the device).
+// Branch-free fp32 tanh (ocml tanhf is a two-way divergent branch per call):
+//   tanh(x) = sign(x) (1 - 2 / (exp(2|x|) + 1)),  exp via v_exp_f32, 1/x via v_rcp_f32 (~1 ulp each): six full-rate and
+//   two quarter-rate VALU ops.  Absolute error <= 2e-7 everywhere (the subtraction cancels for small |x|, so the RELATIVE
+//   error grows like 1e-7 / |x|; the forward kernels are VALU-limited next to fp32 MFMA -- DESIGN.md section 4 -- and the
+//   Taylor branch that kept 3e-7 relative accuracy below |x| = 0.35 cost 3.5 % of the forward kernel).
 __device__ __forceinline__ float tanh_f32(float x) {
-    const float ax = fabsf(x);
-    const float x2 = x * x;
-    float p = -1382.0f / 155925.0f;
-    p = fmaf(p, x2, 62.0f / 2835.0f);
-    p = fmaf(p, x2, -17.0f / 315.0f);
-    p = fmaf(p, x2, 2.0f / 15.0f);
-    p = fmaf(p, x2, -1.0f / 3.0f);
-    const float small = fmaf(x * x2, p, x);
-    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);        // exp(2|x|)
+    const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.8853900817779268f);  // exp(2|x|)
     const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);    // saturates to 1 for large |x|
-    return ax < 0.35f ? small : copysignf(big, x);
+    return copysignf(big, x);
 }
 __device__ __forceinline__ f32x4 tanh4(f32x4 v) {
     f32x4 o;
