@@ -16,7 +16,7 @@ for W in hjb_llgc_d100_K65536_N100_h64 hjb_llgc_d100_K1024_N50_h64 hjb_llgc_d200
     echo "bench $W done: $(python3 -c "import json,sys; j=json.load(open('$OUT/${W}_bench.json')); print(j['value'], j['ms_per_step'], j['roofline']['frac'])")"
     rm -rf /tmp/prof_$W
     (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$W -o run --output-format csv -- \
-        python3 "$ROOT/bench.py" --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/${W}_prof.err") || exit 1
+        python3 "$ROOT/bench.py" --workload $W --steps $STEPS --warmup 5 --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/${W}_prof.err") || exit 1
     F=$(find /tmp/prof_$W -name "*kernel_stats.csv" | head -1)
     [ -n "$F" ] && cp "$F" "$OUT/${W}_kernel_stats.csv" && echo "profile $W: $(head -3 "$OUT/${W}_kernel_stats.csv" | tail -2 | cut -c1-150)"
 done
