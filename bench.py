@@ -49,6 +49,8 @@ GENERAL_WORKLOADS = {
     # BASELINE.json configs[2] shape in fp32: d=100 diffusion loss, K=65536, N=100, V = DenseNet(101 -> 1, [64, 64])
     "diffusion_dw_d100_K65536_N100_h64": dict(d=100, H=64, K=65536, N=100, T=0.3, dt=0.001, loss="diffusion"),
     "bsde_dw_d100_K65536_N100_h64": dict(d=100, H=64, K=65536, N=100, T=0.1, dt=0.001, loss="BSDE"),
+    # BASELINE.json configs[2] as written: value-net products of the forward rollout on bf16 MFMA (fp32 state / accumulate)
+    "diffusion_dw_d100_K65536_N100_h64_bf16": dict(d=100, H=64, K=65536, N=100, T=0.3, dt=0.001, loss="diffusion", mlp="bf16"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
@@ -241,7 +243,7 @@ def main_general(args, psp):
     total = args.warmup + args.steps
     model = psp.GeneralSolver(problem=prob, name="bench", seed=42, delta_t=w["dt"], N=w["N"], lr=1e-3, L=total,
                               K=w["K"] * world, K_boundary=50, alpha=[1.0, 1.0, 1.0], loss_method=w["loss"],
-                              verbose=False, device=dev, backend="native", noise="philox")
+                              verbose=False, device=dev, backend="native", noise="philox", mlp_dtype=w.get("mlp", "fp32"))
     model.V = psp.DenseNet(d_in=w["d"] + 1, d_out=1, lr=1e-3, arch=[w["H"], w["H"]], seed=42).to(dev)
     plan = model._choose_plan()
     assert model.plan_name == "native"
@@ -279,7 +281,9 @@ def main_general(args, psp):
         out = {"metric": "active trajectory-timesteps/sec, d=100 %s loss training iteration" % w["loss"],
                "value": active / elapsed, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16 value-net products in the forward rollout, f32 state / accumulate / backward" if w.get("mlp") == "bf16" else "f32",
+               "data": "synthetic",
                "config": {"workload": args.workload, "problem": "DoubleWell_multidim_for_general_solver",
                           "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%d-%d-1" % (w["d"] + 1, w["H"], w["H"]),
                           "loss": w["loss"], "active_fraction": active / (w["K"] * world * w["N"] * args.steps)},

@@ -79,6 +79,57 @@ struct GGeo {
     static int bwd_lds_floats() { return gEnd; }
 };
 
+// ---- bf16 MFMA variant of the register-chained products (BASELINE.json configs[2]: "bf16 MFMA MLP path") -----------
+// v_mfma_f32_16x16x32_bf16: A (16 x 32) lane (i, g) holds k = 8g..8g+7, B (32 x 16) lane (n, g) likewise, fp32 accumulate.
+// One k-step spans TWO 16-feature blocks of the T layout; lane (j, q) already holds in[2S][0..3], in[2S+1][0..3], so the
+// B operand is a pack of eight local registers (no shuffle): k = 8q + e  <->  feature 32 S + (e < 4 ? 4e : 16 + 4(e-4)) + q.
+// The A tables are laid out for that map (stage_aop_bf16), rows keep the rowmap of the fp32 tables, so the fp32
+// accumulators chain from layer to layer exactly as in the fp32 kernels.  State, accumulators, Y and the path store stay fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <class F>
+__device__ __forceinline__ void stage_aop_bf16(float* dstf, int MB, int NS, int tid, int nthr, F src) {
+    bf16x8* dst = reinterpret_cast<bf16x8*>(dstf);
+    const int total = MB * NS * 64;
+    for (int idx = tid; idx < total; idx += nthr) {
+        const int lane = idx & 63, t = idx >> 6;
+        const int S = t % NS, mb = t / NS;
+        const int i = lane & 15, g = lane >> 4;
+        const int row = 16 * mb + 4 * (i & 3) + (i >> 2);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)src(row, 32 * S + (e < 4 ? 4 * e : 16 + 4 * (e - 4)) + g);
+        dst[idx] = v;
+    }
+}
+template <int MB, int INB>
+__device__ __forceinline__ void gemm_Tb(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane) {
+    constexpr int NS = (INB + 1) / 2;
+    const bf16x8* tbl = reinterpret_cast<const bf16x8*>(wlds) + opaque_i(lane);
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+        bf16x8 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b[e] = (__bf16)in[2 * S][e];
+            b[4 + e] = (2 * S + 1 < INB) ? (__bf16)in[(2 * S + 1 < INB) ? 2 * S + 1 : 0][e] : (__bf16)0.0f;
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tbl[(mb * NS + S) * 64], b, acc[mb], 0, 0, 0);
+    }
+}
+// dispatch of one product: fp32 16x16x4 chain (gemm_T) or the bf16 16x16x32 one
+template <bool BF16, int MB, int KS, int INB>
+__device__ __forceinline__ void gen_gemm(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane) {
+    if constexpr (BF16) gemm_Tb<MB, INB>(acc, wlds, in, lane);
+    else gemm_T<MB, KS, INB>(acc, wlds, in, lane);
+}
+template <bool BF16, class F>
+__device__ __forceinline__ void gen_stage(float* dst, int MB, int KS, int INB, int tid, int nthr, F src) {
+    if constexpr (BF16) stage_aop_bf16(dst, MB, (INB + 1) / 2, tid, nthr, src);
+    else stage_aop(dst, MB, KS, tid, nthr, src);
+}
+
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     f32x4 o;
     o[0] = fmaxf(v[0], 0.f); o[1] = fmaxf(v[1], 0.f); o[2] = fmaxf(v[2], 0.f); o[3] = fmaxf(v[3], 0.f);
@@ -100,7 +151,7 @@ __device__ __forceinline__ f32x4 step2(f32x4 d) {
 // =======================================================================================
 // Forward kernel
 // =======================================================================================
-template <int D, int H>
+template <int D, int H, bool BF16 = false>
 __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, KSI = G::KSI, HB = G::HB, KSH = G::KSH;
@@ -111,18 +162,18 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
     const float* __restrict__ P = a.params;
 
     // forward tables: out^T = W^T in^T  ->  A[row = out][k = in] = W[in][out]
-    stage_aop(lds + G::fW1f, HB, KSI, tid, nthr, [&](int row, int col) {
+    gen_stage<BF16>(lds + G::fW1f, HB, KSI, DBI, tid, nthr, [&](int row, int col) {
         return (row < H && col < DI) ? P[G::oW1 + col * H + row] : 0.f; });
-    stage_aop(lds + G::fW2xf, HB, KSI, tid, nthr, [&](int row, int col) {
+    gen_stage<BF16>(lds + G::fW2xf, HB, KSI, DBI, tid, nthr, [&](int row, int col) {
         return (row < H && col < DI) ? P[G::oW2 + col * H + row] : 0.f; });
-    stage_aop(lds + G::fW2hf, HB, KSH, tid, nthr, [&](int row, int col) {
+    gen_stage<BF16>(lds + G::fW2hf, HB, KSH, HB, tid, nthr, [&](int row, int col) {
         return (row < H && col < H) ? P[G::oW2 + (DI + col) * H + row] : 0.f; });
     // reverse tables: g_in = W g_out  ->  A[row = in][k = out] = W[in][out]
-    stage_aop(lds + G::fW2hr, HB, KSH, tid, nthr, [&](int row, int col) {
+    gen_stage<BF16>(lds + G::fW2hr, HB, KSH, HB, tid, nthr, [&](int row, int col) {
         return (row < H && col < H) ? P[G::oW2 + (DI + row) * H + col] : 0.f; });
-    stage_aop(lds + G::fW2xr, DBI, KSH, tid, nthr, [&](int row, int col) {
+    gen_stage<BF16>(lds + G::fW2xr, DBI, KSH, HB, tid, nthr, [&](int row, int col) {
         return (row < DI && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
-    stage_aop(lds + G::fW1r, DBI, KSH, tid, nthr, [&](int row, int col) {
+    gen_stage<BF16>(lds + G::fW1r, DBI, KSH, HB, tid, nthr, [&](int row, int col) {
         return (row < DI && col < H) ? P[G::oW1 + row * H + col] : 0.f; });
     stage_vec(lds + G::vb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
     stage_vec(lds + G::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
@@ -166,7 +217,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             const f32x4* vw3x = vecs + (G::vw3x - G::fVec) / 4;
 #pragma unroll
             for (int m = 0; m < HB; ++m) r1[m] = vb1[m * 4];
-            gemm_T<HB, KSI, DBI>(r1, lds + G::fW1f, X, lane);
+            gen_gemm<BF16, HB, KSI, DBI>(r1, lds + G::fW1f, X, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) r1[m] = relu4(r1[m]);
             f32x4 h1[HB];
@@ -174,8 +225,8 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             for (int m = 0; m < HB; ++m) h1[m] = r1[m] * r1[m];
 #pragma unroll
             for (int m = 0; m < HB; ++m) r2[m] = vb2[m * 4];
-            gemm_T<HB, KSI, DBI>(r2, lds + G::fW2xf, X, lane);
-            gemm_T<HB, KSH, HB>(r2, lds + G::fW2hf, h1, lane);
+            gen_gemm<BF16, HB, KSI, DBI>(r2, lds + G::fW2xf, X, lane);
+            gen_gemm<BF16, HB, KSH, HB>(r2, lds + G::fW2hf, h1, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) r2[m] = relu4(r2[m]);
             float v = 0.f;
@@ -217,13 +268,13 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             for (int m = 0; m < HB; ++m) gz2[m] = vw3h2[m * 4] * (2.0f * r2[m]);
 #pragma unroll
             for (int m = 0; m < HB; ++m) gz1[m] = vw3h1[m * 4];
-            gemm_T<HB, KSH, HB>(gz1, lds + G::fW2hr, gz2, lane);     // g_h1 = w3h1 + W2h g_z2
+            gen_gemm<BF16, HB, KSH, HB>(gz1, lds + G::fW2hr, gz2, lane);     // g_h1 = w3h1 + W2h g_z2
 #pragma unroll
             for (int m = 0; m < HB; ++m) gz1[m] = gz1[m] * (2.0f * r1[m]);
 #pragma unroll
             for (int b = 0; b < DBI; ++b) gx[b] = vw3x[b * 4];
-            gemm_T<DBI, KSH, HB>(gx, lds + G::fW2xr, gz2, lane);
-            gemm_T<DBI, KSH, HB>(gx, lds + G::fW1r, gz1, lane);
+            gen_gemm<BF16, DBI, KSH, HB>(gx, lds + G::fW2xr, gz2, lane);
+            gen_gemm<BF16, DBI, KSH, HB>(gx, lds + G::fW1r, gz1, lane);
             // Z = sigma^T grad_x V (sigma = s I), state features only (solver.py:1104)
             const float alivef = stopped ? 0.f : 1.f;
             auto noise_block = [&](int b) __attribute__((always_inline)) {
@@ -354,12 +405,12 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < HB; ++m) { z1h[m] = zero4; z2h[m] = zero4; }
-                gemm_T<HB, KSI, DBI>(z1h, lds + G::fW1f, U, lane);
+                gen_gemm<BF16, HB, KSI, DBI>(z1h, lds + G::fW1f, U, lane);
                 f32x4 h1d[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) h1d[m] = (2.0f * r1[m]) * z1h[m];
-                gemm_T<HB, KSI, DBI>(z2h, lds + G::fW2xf, U, lane);
-                gemm_T<HB, KSH, HB>(z2h, lds + G::fW2hf, h1d, lane);
+                gen_gemm<BF16, HB, KSI, DBI>(z2h, lds + G::fW2xf, U, lane);
+                gen_gemm<BF16, HB, KSH, HB>(z2h, lds + G::fW2hf, h1d, lane);
                 {
                     gwptr_t p1 = pbase(n, G::pD1), p2 = pbase(n, G::pD2), p3 = pbase(n, G::pZ1), p4 = pbase(n, G::pZ2);
 #pragma unroll
@@ -1095,6 +1146,7 @@ struct GenInstance {
     hipError_t (*launch_bwd)(const GenArgs&, int grid, int block, hipStream_t);
     int (*bwd2_lds_bytes)();
     hipError_t (*launch_bwd2)(const GenArgs&, int grid, hipStream_t);   // role-specialised variant, 512 threads
+    hipError_t (*launch_fwd_bf16)(const GenArgs&, int grid, int block, hipStream_t);   // value-net products on bf16 MFMA
 };
 
 template <int D, int H>
@@ -1117,6 +1169,13 @@ struct GenLaunch {
         hipLaunchKernelGGL((gen_fwd_kernel<D, H>), dim3(grid), dim3(block), fwd_lds(), s, a);
         return hipGetLastError();
     }
+    static hipError_t fwd_bf16(const GenArgs& a, int grid, int block, hipStream_t s) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_fwd_kernel<D, H, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds());
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gen_fwd_kernel<D, H, true>), dim3(grid), dim3(block), fwd_lds(), s, a);
+        return hipGetLastError();
+    }
     static hipError_t bwd(const GenArgs& a, int grid, int block, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_bwd_kernel<D, H>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds());
@@ -1124,7 +1183,7 @@ struct GenLaunch {
         hipLaunchKernelGGL((gen_bwd_kernel<D, H>), dim3(grid), dim3(block), bwd_lds(), s, a);
         return hipGetLastError();
     }
-    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, &fwd_lds, &bwd_lds, &fwd, &bwd, &bwd2_lds, &bwd2}; }
+    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, &fwd_lds, &bwd_lds, &fwd, &bwd, &bwd2_lds, &bwd2, &fwd_bf16}; }
 };
 
 }  // namespace psp

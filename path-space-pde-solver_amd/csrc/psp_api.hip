@@ -647,7 +647,9 @@ int psp_gen_rollout_fwd(const psp_gen_config* cfg, const float* params, const fl
     a.params = params; a.x0 = x0; a.t0 = t0; a.xi = xi; a.path = path; a.ahat = ahat;
     a.VN = VN; a.YN = YN; a.XN = XN; a.tN = tN; a.kcount = kcount;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    hipError_t e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    if (cfg->mlp_dtype != PSP_MLP_FP32 && cfg->mlp_dtype != PSP_MLP_BF16) return fail(-1, "mlp_dtype out of range");
+    hipError_t e = cfg->mlp_dtype == PSP_MLP_BF16 ? p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream)
+                                                  : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "gen_fwd_kernel launch");
     return 0;
 }

@@ -84,8 +84,11 @@ class GeneralSolver:
                  verbose=True, approx_method='Y', sample_center=False, loss_method='diffusion',
                  loss_with_stopped=False, K_test_log=None, PINN_log_variance=False, log_loss_parts=False,
                  boundary_loss=True, full_hessian=False, uniform_square=False, solve_linear_L2_projection=False,
-                 device=None, backend='auto', noise='reference'):
+                 device=None, backend='auto', noise='reference', mlp_dtype='fp32'):
         self.problem, self.name = problem, name
+        if mlp_dtype not in ('fp32', 'bf16'):
+            raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
+        self.mlp_dtype = mlp_dtype      # 'bf16': value-net products of the native forward rollout on bf16 MFMA (own tolerance)
         self.d = problem.d
         self.device = torch.device(device) if device is not None else getattr(problem, 'device', _default_device())
         self.seed = seed
@@ -284,14 +287,14 @@ class EllipticSolver(GeneralSolver):
                  approx_method='Y', sample_center=False, loss_method='diffusion', loss_with_stopped=False,
                  K_test_log=None, PINN_log_variance=False, log_loss_parts=False, boundary_loss=True,
                  boundary_type='Dirichlet', variance_moment_split=False, full_hessian=False, uniform_square=False,
-                 device=None, backend='auto', noise='reference'):
+                 device=None, backend='auto', noise='reference', mlp_dtype='fp32'):
         super().__init__(problem, name, seed=seed, delta_t=delta_t, N=N, lr=lr, L=L, K=K, K_boundary=K_boundary,
                          alpha=alpha, adaptive_forward_process=adaptive_forward_process, detach_forward=detach_forward,
                          print_every=print_every, verbose=verbose, approx_method='skip', sample_center=sample_center,
                          loss_method=loss_method, loss_with_stopped=loss_with_stopped, K_test_log=K_test_log,
                          PINN_log_variance=PINN_log_variance, log_loss_parts=log_loss_parts, boundary_loss=boundary_loss,
                          full_hessian=full_hessian, uniform_square=uniform_square, device=device, backend=backend,
-                         noise=noise)
+                         noise=noise, mlp_dtype=mlp_dtype)
         self.approx_method = approx_method
         self.boundary_type = boundary_type
         self.variance_moment_split = variance_moment_split

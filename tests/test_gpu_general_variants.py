@@ -44,3 +44,32 @@ def test_role_specialised_backward_matches_two_workgroup_backward(K, H, loss):
     for x, y in zip(a['loss'], b['loss']):
         assert abs(x - y) <= 2e-5 * max(1.0, abs(x)), (a['loss'], b['loss'])
     assert max(abs(x - y) for x, y in zip(a['g'], b['g'])) <= 2e-4 * a['gmax']
+
+
+def test_bf16_forward_products_track_the_fp32_kernels():
+    """BASELINE.json configs[2] names a bf16 MFMA MLP path: mlp_dtype='bf16' runs the value-net products of the forward
+    rollout (V, grad_x V, tangent pass) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; state, Y, the path store and the
+    backward stay fp32.  Its OWN tolerance (bf16 operands carry 8 mantissa bits): loss within 2 % of the fp32 kernels and
+    of the reference's golden run over the logged iterations, gradient direction cosine >= 0.999, active-step counts equal."""
+    import math
+
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden
+    from test_gpu_general import build
+    for name in ("dwgen_d10_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde", "heat_d6_diffusion"):
+        rec = load_golden(name)
+        res = {}
+        for dt in ("fp32", "bf16"):
+            prob, model = build(rec["case"], mlp_dtype=dt)
+            model.train()
+            assert model.plan_name == "native"
+            res[dt] = (model.loss_log, model.K_log, model._gen_plan.grad.double().cpu())
+        g32, g16 = res["fp32"][2], res["bf16"][2]
+        cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+        assert res["fp32"][1] == res["bf16"][1], name
+        assert cos >= 0.999, (name, cos)
+        for a, b, g in zip(res["bf16"][0], res["fp32"][0], rec["expected"]["loss_log"]):
+            assert math.isclose(a, b, rel_tol=2e-2) and math.isclose(a, g, rel_tol=2e-2), (name, res["bf16"][0], res["fp32"][0])
+        assert res["bf16"][0] != res["fp32"][0], name            # the bf16 path really ran

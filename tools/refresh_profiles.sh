@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/final
 mkdir -p "$OUT"
 for W in hjb_llgc_d100_K65536_N100_h64 hjb_llgc_d100_K1024_N50_h64 hjb_llgc_d200_K32768_N100_h64 \
-         hjb_llgc_d500_K16384_N200_h64 diffusion_dw_d100_K65536_N100_h64; do
+         hjb_llgc_d500_K16384_N200_h64 diffusion_dw_d100_K65536_N100_h64 diffusion_dw_d100_K65536_N100_h64_bf16; do
     STEPS=20; [ "$W" = hjb_llgc_d100_K1024_N50_h64 ] && STEPS=200
     EXTRA="--no-cpu-baseline --no-secondary"; [ "$W" = hjb_llgc_d100_K65536_N100_h64 ] && EXTRA="--no-secondary"
     python3 bench.py --workload $W --steps $STEPS --warmup 5 $EXTRA > "$OUT/${W}_bench.json" 2> "$OUT/${W}_bench.err" || exit 1
