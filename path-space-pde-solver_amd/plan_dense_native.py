@@ -207,8 +207,11 @@ class DenseNativePlan:
         grad.zero_()
         W1, b1, W2, b2, W3 = (self._set_view(self.flat, k) for k in ('W1', 'b1', 'W2', 'b2', 'W3'))
         gW1, gb1, gW2, gb2, gW3, gb3 = (self._set_view(grad, k) for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'))
-        W3h = W3[:, di:, :].transpose(1, 2)                       # (B, d, 2H): d[h1, h2] = G W3h
-        W2h = W2[:, di:, :].transpose(1, 2)                       # (B, H, H)
+        # row blocks of the dense-concat weights: [input | h1 | h2]; every product below works on one block, so the
+        # concatenated activations [u, h1, h2] are never materialised (the torch.cat copies were a quarter of this function)
+        W2u, W2h = W2[:, :di, :], W2[:, di:, :]
+        W3h1T, W3h2T = W3[:, di:di + H, :].transpose(1, 2), W3[:, di + H:, :].transpose(1, 2)     # (B, d, H)
+        W2hT = W2h.transpose(1, 2)
         scale = (w * float(self.cfg.base.sqrt_dt)).view(1, K, 1)
         for n0 in range(0, N, self.chunk):
             n1 = min(N, n0 + self.chunk)
@@ -222,18 +225,21 @@ class DenseNativePlan:
             else:
                 U, sl = torch.cat([self.tn[n0:n1].view(-1, 1, 1).expand(n1 - n0, K, 1), X], 2), slice(0, 1)
             red = (lambda t: t) if self.outer else (lambda t: t.sum(0, keepdim=True))
+            UT = U.transpose(1, 2)
             r1 = torch.relu(torch.matmul(U, W1[sl]) + b1[sl].unsqueeze(1))
-            U2 = torch.cat([U, r1 * r1], 2)
-            r2 = torch.relu(torch.matmul(U2, W2[sl]) + b2[sl].unsqueeze(1))
-            U3 = torch.cat([U2, r2 * r2], 2)
-            gW3[sl] += red(torch.matmul(U3.transpose(1, 2), G))
+            h1 = r1 * r1
+            r2 = torch.relu(torch.matmul(U, W2u[sl]) + torch.matmul(h1, W2h[sl]) + b2[sl].unsqueeze(1))
+            h2 = r2 * r2
+            gW3[sl][:, :di] += red(torch.matmul(UT, G))
+            gW3[sl][:, di:di + H] += red(torch.matmul(h1.transpose(1, 2), G))
+            gW3[sl][:, di + H:] += red(torch.matmul(h2.transpose(1, 2), G))
             gb3[sl] += red(G.sum(1))
-            dh = torch.matmul(G, W3h[sl])                         # (n, K, 2H): [dh1 (skip path), dh2]
-            dz2 = dh[:, :, H:] * (2.0 * r2)
-            gW2[sl] += red(torch.matmul(U2.transpose(1, 2), dz2))
+            dz2 = torch.matmul(G, W3h2T[sl]) * (2.0 * r2)
+            gW2[sl][:, :di] += red(torch.matmul(UT, dz2))
+            gW2[sl][:, di:] += red(torch.matmul(h1.transpose(1, 2), dz2))
             gb2[sl] += red(dz2.sum(1))
-            dz1 = (dh[:, :, :H] + torch.matmul(dz2, W2h[sl])) * (2.0 * r1)
-            gW1[sl] += red(torch.matmul(U.transpose(1, 2), dz1))
+            dz1 = (torch.matmul(G, W3h1T[sl]) + torch.matmul(dz2, W2hT[sl])) * (2.0 * r1)
+            gW1[sl] += red(torch.matmul(UT, dz1))
             gb1[sl] += red(dz1.sum(1))
         return grad
 
