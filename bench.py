@@ -51,6 +51,7 @@ GENERAL_WORKLOADS = {
     "bsde_dw_d100_K65536_N100_h64": dict(d=100, H=64, K=65536, N=100, T=0.1, dt=0.001, loss="BSDE"),
     # BASELINE.json configs[2] as written: value-net products of the forward rollout on bf16 MFMA (fp32 state / accumulate)
     "diffusion_dw_d100_K65536_N100_h64_bf16": dict(d=100, H=64, K=65536, N=100, T=0.3, dt=0.001, loss="diffusion", mlp="bf16"),
+    "diffusion_dw_d100_K65536_N100_h64_bf16fwd": dict(d=100, H=64, K=65536, N=100, T=0.3, dt=0.001, loss="diffusion", mlp="bf16_fwd"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
@@ -282,7 +283,8 @@ def main_general(args, psp):
                "value": active / elapsed, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16 value-net products in the forward rollout, f32 state / accumulate / backward" if w.get("mlp") == "bf16" else "f32",
+               "dtype": {"bf16": "bf16 MFMA operands in both rollout kernels, f32 state / accumulate / element-wise",
+                         "bf16_fwd": "bf16 MFMA operands in the forward rollout, f32 state / accumulate / backward"}.get(w.get("mlp"), "f32"),
                "data": "synthetic",
                "config": {"workload": args.workload, "problem": "DoubleWell_multidim_for_general_solver",
                           "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%d-%d-1" % (w["d"] + 1, w["H"], w["H"]),

@@ -216,7 +216,7 @@ enum { PSP_GH_ZERO = 0, PSP_GH_QUAD = 1, PSP_GH_ALLEN_CAHN = 2, PSP_GH_EXPBALL_L
  *   BOX           dom_a <= X_proposal <= dom_b in every coordinate
  *   BOX_UPPER_ALL X_proposal <= dom_b in every coordinate   (EllipticSolver, one_boundary)
  *   BOX_UPPER_ANY X_proposal <= dom_b in some coordinate    (GeneralSolver, one_boundary) */
-enum { PSP_MLP_FP32 = 0, PSP_MLP_BF16 = 1 };
+enum { PSP_MLP_FP32 = 0, PSP_MLP_BF16_FWD = 1, PSP_MLP_BF16 = 2 };
 enum { PSP_DOM_NONE = 0, PSP_DOM_SPHERE = 1, PSP_DOM_BOX = 2, PSP_DOM_BOX_UPPER_ALL = 3, PSP_DOM_BOX_UPPER_ANY = 4 };
 
 typedef struct psp_gen_config {
@@ -236,9 +236,10 @@ typedef struct psp_gen_config {
     float h_par[4];       /* PSP_GH_EXPBALL_*: al, d (the REAL dimension, not a padded one), e, tau */
     int32_t d_real;       /* components the exit test and |x|^2 read when d is a zero-padded instance (0: all d);
                            * the padding carries device noise, which nothing else ever reads                */
-    int32_t mlp_dtype;    /* PSP_MLP_FP32 (0) or PSP_MLP_BF16: the value-net products of the FORWARD rollout (V, grad_x V
-                           * and the tangent pass) on v_mfma_f32_16x16x32_bf16 -- bf16 operands, fp32 accumulate; state,
-                           * Y, the path store and the whole backward pass stay fp32 (BASELINE.json configs[2]) */
+    int32_t mlp_dtype;    /* PSP_MLP_FP32 (0); PSP_MLP_BF16_FWD: the value-net products of the forward rollout (V, grad_x V,
+                           * tangent pass) on v_mfma_f32_16x16x32_bf16 -- bf16 operands, fp32 accumulate; PSP_MLP_BF16: also the
+                           * adjoint products and the weight-gradient outer products of the backward kernel.  State, Y,
+                           * accumulators, the path store and every element-wise step stay fp32 (BASELINE.json configs[2]) */
 } psp_gen_config;
 
 typedef struct psp_gen_sizes {

@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
 //           h rows:  dW2h += h1^T gz2 + h1'^T gz2',     h1 = (d1/2)^2, h1' = d1 w z1^    ( 8 MFMAs per tile)
 //       biases from the exchange tiles, the feature-on-lane parts of dW3 from the row tiles (rows split over the waves).
 // =======================================================================================
-template <int D, int H>
+template <int D, int H, bool BF16 = false>
 __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, HB = G::HB, KSH = G::KSH, EXT = G::EXT;
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     const int qq = lane >> 4, col = lane & 15;
     const float* __restrict__ P = a.params;
 
-    stage_aop(lds + G::gW2hr, HB, KSH, tid, nthr, [&](int row, int c2) {
+    gen_stage<BF16>(lds + G::gW2hr, HB, KSH, HB, tid, nthr, [&](int row, int c2) {
         return (row < H && c2 < H) ? P[G::oW2 + (DI + row) * H + c2] : 0.f; });
     __syncthreads();
     float* bufs = lds + G::gEx;                       // [2 buffers][4 blocks][EXT tiles][256]
@@ -907,8 +907,8 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     g3b += (q == 0) ? av : 0.f;
         #pragma unroll
                     for (int m = 0; m < HB; ++m) { gz1t[m] = w3_T(G::oW3 + DI, m, o0); gz1[m] = av * gz1t[m]; }
-                    gemm_T<HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
-                    gemm_T<HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
+                    gen_gemm<BF16, HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
+                    gen_gemm<BF16, HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
                     {   // d1 / z1^ are L2-resident (touch-prefetched one round ahead): fetch them only now
                         f32x4 d1[HB], z1t[HB];
         #pragma unroll
@@ -1009,6 +1009,95 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
         w4n = (sval && !fin) ? wy4 : zero4;
         a4n = sval ? (fin ? wv4 : wy4 * ah4) : zero4;
     };
+    if constexpr (BF16) {
+        // bf16 outer products (v_mfma_f32_16x16x32_bf16): the 32-deep k-step is the sample index of TWO sample blocks --
+        // lane (row / col, qq) holds samples 4qq..4qq+3 of either block in both operands, so a k-step is a pack of the two
+        // blocks' registers on both sides (the sum over k does not care which slot a sample sits in).  One MFMA replaces
+        // eight fp32 ones; the consumers turn from MFMA-bound into a stream over the path store.
+        auto pack2 = [&](const f32x4& u0, const f32x4& u1) __attribute__((always_inline)) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (__bf16)u0[e]; v[4 + e] = (__bf16)u1[e]; }
+            return v;
+        };
+        auto weights_of = [&](long long c0, f32x4& w4, f32x4& a4) __attribute__((always_inline)) {
+            const bool sval = c0 < nblk;
+            const int cb = blk_at(c0);
+            const int n = cb / a.ntile16, t16 = cb % a.ntile16;
+            const bool fin = (n == a.N);
+            const int k4 = t16 * 16 + 4 * qq;
+            const f32x4 wy4 = *reinterpret_cast<const f32x4*>(a.wY + k4);
+            const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wV + k4);
+            const f32x4 ah4 = *reinterpret_cast<const f32x4*>(a.ahat + (size_t)n * Kpad + k4);
+            w4 = (sval && !fin) ? wy4 : zero4;
+            a4 = sval ? (fin ? wv4 : wy4 * ah4) : zero4;
+        };
+        __syncthreads();                                      // pairs with producer iteration 0
+        for (int it = 1; it <= R; ++it) {
+            const long long rb = ((long long)blockIdx.x + (long long)(it - 1) * gridDim.x) * 4;
+            const float* exch = bufs + ((it - 1) & 1) * 4 * (EXT * 256);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float* ex0 = exch + (2 * p) * (EXT * 256);
+                const float* ex1 = ex0 + EXT * 256;
+                const int cb0 = blk_at(rb + 2 * p), cb1 = blk_at(rb + 2 * p + 1);
+                f32x4 ra0[3], rb0[3], ra1[3], rb1[3];          // 3-deep ring over the row items of the pair
+#pragma unroll
+                for (int i = 0; i < 2 && i < NROW; ++i) {
+                    ra0[i] = get_F(cb0, row_ofs0(i)); rb0[i] = get_F(cb0, row_ofs1(i));
+                    ra1[i] = get_F(cb1, row_ofs0(i)); rb1[i] = get_F(cb1, row_ofs1(i));
+                }
+                f32x4 w40, a40, w41, a41;
+                weights_of(rb + 2 * p, w40, a40);
+                weights_of(rb + 2 * p + 1, w41, a41);
+                bf16x8 pz2[NIB], pz2t[NIB], pz1[NIB], pz1t[NIB];
+#pragma unroll
+                for (int t = 0; t < NIB; ++t) {
+                    const f32x4 u0 = tile_get(ex0 + cbc[t], lane), u1 = tile_get(ex1 + cbc[t], lane);
+                    const f32x4 v0 = tile_get(ex0 + 2 * HB * 256 + cbc[t], lane), v1 = tile_get(ex1 + 2 * HB * 256 + cbc[t], lane);
+                    bs2[t] += hsum4(u0) + hsum4(u1);
+                    bs1[t] += hsum4(v0) + hsum4(v1);
+                    pz2[t] = pack2(u0, u1);
+                    pz1[t] = pack2(v0, v1);
+                    pz2t[t] = pack2(tile_get(ex0 + HB * 256 + cbc[t], lane), tile_get(ex1 + HB * 256 + cbc[t], lane));
+                    pz1t[t] = pack2(tile_get(ex0 + 3 * HB * 256 + cbc[t], lane), tile_get(ex1 + 3 * HB * 256 + cbc[t], lane));
+                }
+#pragma unroll
+                for (int i = 0; i < NROW; ++i) {
+                    const int slot = i % 3;
+                    if (i + 2 < NROW) {
+                        const int ns = (i + 2) % 3;
+                        ra0[ns] = get_F(cb0, row_ofs0(i + 2)); rb0[ns] = get_F(cb0, row_ofs1(i + 2));
+                        ra1[ns] = get_F(cb1, row_ofs0(i + 2)); rb1[ns] = get_F(cb1, row_ofs1(i + 2));
+                    }
+                    f32x4 A00, A10, A01, A11;
+                    if (i < NRX) {
+                        A00 = ra0[slot]; A10 = w40 * rb0[slot];
+                        A01 = ra1[slot]; A11 = w41 * rb1[slot];
+                    } else {
+                        const f32x4 d10 = ra0[slot], d11 = ra1[slot];
+                        A00 = 0.25f * d10 * d10; A10 = d10 * (w40 * rb0[slot]);
+                        A01 = 0.25f * d11 * d11; A11 = d11 * (w41 * rb1[slot]);
+                    }
+                    if (i % WHc == wh) g3r[i] += hsum4(a40 * A00 + A10) + hsum4(a41 * A01 + A11);
+                    const bf16x8 PA0 = pack2(A00, A01), PA1 = pack2(A10, A11);
+#pragma unroll
+                    for (int t = 0; t < NIB; ++t) {
+                        if (i < NRX) {
+                            acc2x[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA0, pz2[t], acc2x[i][t], 0, 0, 0);
+                            acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA0, pz1[t], acc1[i][t], 0, 0, 0);
+                            acc2x[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA1, pz2t[t], acc2x[i][t], 0, 0, 0);
+                            acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA1, pz1t[t], acc1[i][t], 0, 0, 0);
+                        } else {
+                            acc2h[i - NRX][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA0, pz2[t], acc2h[i - NRX][t], 0, 0, 0);
+                            acc2h[i - NRX][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA1, pz2t[t], acc2h[i - NRX][t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
+        }
+    } else {
     // prologue: first two row items and the weights of this workgroup's first block
     {
         const int b0 = blk_at((long long)blockIdx.x * 4);
@@ -1081,6 +1170,7 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
         __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
     }
 
+    }
     // ---- write-out: tile (rbk, cbk): lane (col, qq), reg rr <-> dW[16 rbk + 4 qq + rr][16 cbk + col]   (weights are (in, out))
 #pragma unroll
     for (int s = 0; s < NRX; ++s)
@@ -1147,6 +1237,7 @@ struct GenInstance {
     int (*bwd2_lds_bytes)();
     hipError_t (*launch_bwd2)(const GenArgs&, int grid, hipStream_t);   // role-specialised variant, 512 threads
     hipError_t (*launch_fwd_bf16)(const GenArgs&, int grid, int block, hipStream_t);   // value-net products on bf16 MFMA
+    hipError_t (*launch_bwd2_bf16)(const GenArgs&, int grid, hipStream_t);             // adjoint products + weight-gradient outer products on bf16 MFMA
 };
 
 template <int D, int H>
@@ -1160,6 +1251,13 @@ struct GenLaunch {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bwd2_lds());
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((gen_bwd2_kernel<D, H>), dim3(grid), dim3(512), bwd2_lds(), s, a);
+        return hipGetLastError();
+    }
+    static hipError_t bwd2_bf16(const GenArgs& a, int grid, hipStream_t s) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_bwd2_kernel<D, H, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bwd2_lds());
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gen_bwd2_kernel<D, H, true>), dim3(grid), dim3(512), bwd2_lds(), s, a);
         return hipGetLastError();
     }
     static hipError_t fwd(const GenArgs& a, int grid, int block, hipStream_t s) {
@@ -1183,7 +1281,7 @@ struct GenLaunch {
         hipLaunchKernelGGL((gen_bwd_kernel<D, H>), dim3(grid), dim3(block), bwd_lds(), s, a);
         return hipGetLastError();
     }
-    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, &fwd_lds, &bwd_lds, &fwd, &bwd, &bwd2_lds, &bwd2, &fwd_bf16}; }
+    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, &fwd_lds, &bwd_lds, &fwd, &bwd, &bwd2_lds, &bwd2, &fwd_bf16, &bwd2_bf16}; }
 };
 
 }  // namespace psp

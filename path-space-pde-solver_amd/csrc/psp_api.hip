@@ -647,8 +647,8 @@ int psp_gen_rollout_fwd(const psp_gen_config* cfg, const float* params, const fl
     a.params = params; a.x0 = x0; a.t0 = t0; a.xi = xi; a.path = path; a.ahat = ahat;
     a.VN = VN; a.YN = YN; a.XN = XN; a.tN = tN; a.kcount = kcount;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    if (cfg->mlp_dtype != PSP_MLP_FP32 && cfg->mlp_dtype != PSP_MLP_BF16) return fail(-1, "mlp_dtype out of range");
-    hipError_t e = cfg->mlp_dtype == PSP_MLP_BF16 ? p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream)
+    if (cfg->mlp_dtype < PSP_MLP_FP32 || cfg->mlp_dtype > PSP_MLP_BF16) return fail(-1, "mlp_dtype out of range");
+    hipError_t e = cfg->mlp_dtype != PSP_MLP_FP32 ? p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream)
                                                   : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "gen_fwd_kernel launch");
     return 0;
@@ -665,8 +665,12 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
     fill_gen_args(cfg, p, &a);
     a.params = params; a.path = const_cast<float*>(path); a.ahat = const_cast<float*>(ahat);
     a.wY = wY; a.wV = wV; a.grad_partial = grad_partial;
-    hipError_t e = p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
-                                     : p.inst.launch_bwd(a, p.bwd_grid, 256, (hipStream_t)stream);
+    if (cfg->mlp_dtype < PSP_MLP_FP32 || cfg->mlp_dtype > PSP_MLP_BF16) return fail(-1, "mlp_dtype out of range");
+    if (cfg->mlp_dtype == PSP_MLP_BF16 && !p.bwd_specialised)
+        return fail(-3, "the bf16 backward exists for the role-specialised kernel only (LDS budget / PSP_BWD_VARIANT)");
+    hipError_t e = cfg->mlp_dtype == PSP_MLP_BF16 ? p.inst.launch_bwd2_bf16(a, p.bwd_grid, (hipStream_t)stream)
+                   : p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
+                                       : p.inst.launch_bwd(a, p.bwd_grid, 256, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "gen_bwd_kernel launch");
     const int P = p.inst.n_params;
     hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream,

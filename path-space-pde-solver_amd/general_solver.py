@@ -86,9 +86,10 @@ class GeneralSolver:
                  boundary_loss=True, full_hessian=False, uniform_square=False, solve_linear_L2_projection=False,
                  device=None, backend='auto', noise='reference', mlp_dtype='fp32'):
         self.problem, self.name = problem, name
-        if mlp_dtype not in ('fp32', 'bf16'):
-            raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
-        self.mlp_dtype = mlp_dtype      # 'bf16': value-net products of the native forward rollout on bf16 MFMA (own tolerance)
+        if mlp_dtype not in ('fp32', 'bf16', 'bf16_fwd'):
+            raise ValueError("mlp_dtype must be 'fp32', 'bf16' or 'bf16_fwd'")
+        self.mlp_dtype = mlp_dtype      # 'bf16': the matrix products of the native kernels on bf16 MFMA with fp32 accumulation
+                                        # ('bf16_fwd': forward rollout only); own tolerance, see include/psp.h
         self.d = problem.d
         self.device = torch.device(device) if device is not None else getattr(problem, 'device', _default_device())
         self.seed = seed

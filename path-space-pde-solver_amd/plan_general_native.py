@@ -88,7 +88,7 @@ class GeneralNativePlan:
             cfg.domain_kind = nat.DOM_BOX if not pb.one_boundary else \
                 (nat.DOM_BOX_UPPER_ALL if self.elliptic else nat.DOM_BOX_UPPER_ANY)
         cfg.d_real = s.d
-        cfg.mlp_dtype = nat.MLP_BF16 if getattr(s, 'mlp_dtype', 'fp32') == 'bf16' else nat.MLP_FP32
+        cfg.mlp_dtype = {'fp32': nat.MLP_FP32, 'bf16_fwd': nat.MLP_BF16_FWD, 'bf16': nat.MLP_BF16}[getattr(s, 'mlp_dtype', 'fp32')]
         for i, v in enumerate(spec.get('h_par', ())):
             cfg.h_par[i] = float(v)
         cfg.sigma_scale = float(spec['sigma_scale'])

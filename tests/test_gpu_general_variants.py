@@ -61,15 +61,44 @@ def test_bf16_forward_products_track_the_fp32_kernels():
     for name in ("dwgen_d10_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde", "heat_d6_diffusion"):
         rec = load_golden(name)
         res = {}
-        for dt in ("fp32", "bf16"):
+        for dt in ("fp32", "bf16_fwd", "bf16"):
             prob, model = build(rec["case"], mlp_dtype=dt)
             model.train()
             assert model.plan_name == "native"
             res[dt] = (model.loss_log, model.K_log, model._gen_plan.grad.double().cpu())
-        g32, g16 = res["fp32"][2], res["bf16"][2]
-        cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
-        assert res["fp32"][1] == res["bf16"][1], name
-        assert cos >= 0.999, (name, cos)
-        for a, b, g in zip(res["bf16"][0], res["fp32"][0], rec["expected"]["loss_log"]):
-            assert math.isclose(a, b, rel_tol=2e-2) and math.isclose(a, g, rel_tol=2e-2), (name, res["bf16"][0], res["fp32"][0])
-        assert res["bf16"][0] != res["fp32"][0], name            # the bf16 path really ran
+        g32 = res["fp32"][2]
+        for dt in ("bf16_fwd", "bf16"):                      # forward products only / forward + backward products
+            g16 = res[dt][2]
+            cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+            assert res["fp32"][1] == res[dt][1], name
+            assert cos >= 0.999, (name, dt, cos)
+            for a, b, g in zip(res[dt][0], res["fp32"][0], rec["expected"]["loss_log"]):
+                assert math.isclose(a, b, rel_tol=2e-2) and math.isclose(a, g, rel_tol=2e-2), (name, dt, res[dt][0], res["fp32"][0])
+            assert res[dt][0] != res["fp32"][0], (name, dt)    # the bf16 path really ran
+        assert not torch.equal(res["bf16"][2], res["bf16_fwd"][2]), name
+
+
+def test_bf16_backward_many_rounds():
+    """Every backward workgroup runs MANY rounds (the golden cases give one): the bf16 outer products pair the sample
+    blocks of a round, so round boundaries, ragged tails (K not a multiple of 64) and the final-point blocks all occur."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import path_space_pde_solver_amd as psp
+    dev = torch.device("cuda:0")
+    prob = psp.DoubleWell_multidim_for_general_solver(d=10, d_1=5, d_2=5, T=0.3, eta=1.0, kappa=1.0, modus="HJB", device=dev)
+    res = {}
+    for dt in ("fp32", "bf16"):
+        m = psp.GeneralSolver(prob, "var", seed=42, delta_t=0.01, N=20, lr=1e-3, L=2, K=19999, K_boundary=50,
+                              loss_method="diffusion", verbose=False, device=dev, backend="native", noise="philox",
+                              mlp_dtype=dt)
+        m.V = psp.DenseNet(d_in=11, d_out=1, lr=1e-3, arch=[48, 48], seed=42).to(dev)
+        m.train()
+        res[dt] = (m.loss_log, m.K_log, m._gen_plan.grad.double().cpu())
+    g32, g16 = res["fp32"][2], res["bf16"][2]
+    cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+    assert cos >= 0.9995, cos
+    assert float((g32 - g16).abs().max()) <= 2e-2 * float(g32.abs().max())
+    assert res["fp32"][1] == res["bf16"][1]
+    for a, b in zip(res["bf16"][0], res["fp32"][0]):
+        assert abs(a - b) <= 2e-2 * abs(b)
