@@ -132,12 +132,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # PSP_BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo -- a way to walk the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing
+    rehearsal = os.environ.get("PSP_BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world:
         print("note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)"
               % (args.gpus, world), file=sys.stderr)
