@@ -265,7 +265,8 @@ class Solver:
                 plan = DenseNativePlan(self, noise=self.noise)
                 self._native_plan = plan
             return plan
-        if isinstance(self.z_n, list) or isinstance(self.z_n, DenseNet):
+        z = getattr(self, 'z_n', None)                  # (approx_method='value_function' has y_n instead)
+        if isinstance(z, list) or isinstance(z, DenseNet):
             reason = dense_reason
         if self.backend == 'native':
             raise PlanUnsupported('native plan unavailable: ' + reason)
@@ -327,8 +328,11 @@ class Solver:
 
     def _train_composite(self):
         """The reference iteration restated with torch ops on self.device (solver.py:430-554)."""
-        if self.approx_method != 'control':
-            raise NotImplementedError("composite plan covers approx_method='control' only")
+        if self.approx_method not in ('control', 'value_function'):
+            raise NotImplementedError("approx_method %r is not built" % self.approx_method)
+        if self.approx_method == 'value_function' and self.time_approx != 'inner':
+            # the reference itself fails here: Y_n(X, n) turns the STEP index into ceil(n / delta_t) (solver.py:342-345)
+            raise NotImplementedError("approx_method='value_function' needs time_approx='inner' (as in the reference)")
         if self.compute_gradient_variance > 0:
             raise NotImplementedError('per-sample gradient-variance diagnostics are not implemented')
         dev, dt, sq = self.device, self.delta_t, self.sq_delta_t
@@ -338,7 +342,10 @@ class Solver:
             t_0 = time.time()
             X, Y, Z_sum, u_L2, _, _, _, xi = self.initialize_training_data()
             frozen = deepcopy(self.z_n) if repa else None
+            extra = torch.zeros(self.K).to(dev)
             for n in range(self.N):
+                if self.approx_method == 'value_function' and n > 0:
+                    extra = extra + (self.Y_n(X, n)[:, 0] - Y).pow(2)       # solver.py:438-440
                 Z = self.Z_n_(X, n)
                 c = torch.zeros(self.d, self.K).to(dev)
                 if self.adaptive_forward_process:
@@ -368,7 +375,7 @@ class Solver:
                 if self.u_l2_error_flag:
                     ref = torch.tensor(self.u_true(X.cpu().detach(), n * self.delta_t_np)).t().float().to(dev)
                     u_L2 = u_L2 + torch.sum((-Z - ref) ** 2 * dt, 1)
-            loss = self.gradient_descent(X, Y, Z_sum, l, torch.zeros(self.K).mean())
+            loss = self.gradient_descent(X, Y, Z_sum, l, extra.mean())
             if self.log_gradient:
                 flat = torch.cat([q.grad.reshape(-1) for q in self.z_n.parameters() if q.grad is not None])
                 self.gradient_log[l, :] = flat.cpu().detach()

@@ -148,11 +148,12 @@ def run_solver_case(case):
             model.z_n = ref_fs.DenseNet(d_in=problem.d + 1, d_out=problem.d, lr=skw["lr"],
                                         arch=net["arch"], seed=net["seed"])
         model.update_Phis()
-    init_fp = param_fingerprint(model.z_n) if not isinstance(model.z_n, list) else None
+    vf = skw.get("approx_method") == "value_function"
+    init_fp = param_fingerprint(model.y_n[0]) if vf else (param_fingerprint(model.z_n) if not isinstance(model.z_n, list) else None)
     model.train()
     xp = probe_points(problem.d)
     probes = []
-    for t in case.get("probe_times", [0.0]):
+    for t in ([] if vf else case.get("probe_times", [0.0])):
         with torch.no_grad():
             z = model.Z_n(xp, torch.tensor(t))
         probes.append({"t": t, "minus_Z": f32list(-z)})
@@ -162,7 +163,7 @@ def run_solver_case(case):
         "u_L2_loss": [float(v) for v in model.u_L2_loss],
         "Y_0_log": [float(v) for v in model.Y_0_log],
         "init_params": init_fp,
-        "final_params": param_fingerprint(model.z_n) if not isinstance(model.z_n, list) else None,
+        "final_params": param_fingerprint(model.y_n[0]) if vf else (param_fingerprint(model.z_n) if not isinstance(model.z_n, list) else None),
         "y_0_final": float(model.y_0.Y_0.detach()[0]) if hasattr(model, "y_0") else None,
         "probe_x": f32list(xp), "probes": probes,
     }
@@ -381,6 +382,12 @@ CASES = [
          problem=dict(kind="LQGC", kwargs=dict(d=6, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
          solver=dict(HJB, loss_method="variance", L=4, lr=0.005, seed=42, delta_t=0.05, K=128, u_l2_error_flag=False),
          net=dict(kind="densenet", arch=[24, 24], seed=7), probe_times=[0.0]),
+    # approx_method='value_function' (solver.py:93-97, 334-339, 438-440): Z = sigma grad_x Y_n, extra loss sum_n (Y_n(X_n) - Y)^2
+    dict(name="lqgc_d3_value_function", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=3, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
+         solver=dict(approx_method="value_function", loss_method="log-variance", time_approx="inner",
+                     adaptive_forward_process=True, detach_forward=False, early_stopping_time=None, L=4, lr=0.01, seed=42,
+                     delta_t=0.05, K=64, u_l2_error_flag=False)),
     # importance-sampling evaluation of the learned control, standalone and in the loop
     dict(name="llgc_d20_is_eval", family="is",
          problem=dict(kind="LLGC", kwargs=dict(d=20, off_diag=0.0, T=0.3, seed=42)),

@@ -9,7 +9,7 @@ import torch
 from conftest import load_golden
 from util_cases import make_pkg_solver
 
-CASES = ["lqgc_d2_logvar", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h64_logvar", "llgc_d100_densenet64_logvar",
+CASES = ["lqgc_d3_value_function", "lqgc_d2_logvar", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h64_logvar", "llgc_d100_densenet64_logvar",
          "dw_d10_logvar", "llgc_d20_diag_logvar", "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive",
          "lqgc_d2_outer", "lqgc_d2_variance", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
 
@@ -17,7 +17,8 @@ CASES = ["lqgc_d2_logvar", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2
 @pytest.mark.parametrize("name", CASES)
 def test_composite_plan_matches_reference(name):
     rec = load_golden(name)
-    exact = rec["torch"] == torch.__version__
+    # gradients through the state path: autograd's accumulation order depends on graph construction (last-bit differences)
+    exact = rec["torch"] == torch.__version__ and rec["case"]["solver"].get("detach_forward", True)
     torch.set_num_threads(1)
     model = make_pkg_solver(rec["case"], "cpu")
     model.train()
