@@ -91,6 +91,9 @@ typedef struct psp_hjb_sizes {
 
 int psp_version(void);
 const char* psp_last_error(void);
+/* sizeof() of the six structs above / below, in declaration order (psp_hjb_config, psp_hjb_sizes, psp_gen_config,
+ * psp_gen_sizes, psp_dnet_config, psp_dnet_sizes): lets a binding check its own struct declarations at load time. */
+int psp_abi_struct_sizes(int32_t out[6]);
 
 /* 1 if a compiled kernel instantiation exists for (d, H), else 0. */
 int psp_hjb_supported(int32_t d, int32_t H);

@@ -341,6 +341,13 @@ __global__ void control_eval_kernel(int d, int H, const float* __restrict__ P, c
 extern "C" {
 
 int psp_version(void) { return PSP_VERSION; }
+int psp_abi_struct_sizes(int32_t out[6]) {
+    if (!out) return fail(-1, "null output");
+    out[0] = (int32_t)sizeof(psp_hjb_config); out[1] = (int32_t)sizeof(psp_hjb_sizes);
+    out[2] = (int32_t)sizeof(psp_gen_config); out[3] = (int32_t)sizeof(psp_gen_sizes);
+    out[4] = (int32_t)sizeof(psp_dnet_config); out[5] = (int32_t)sizeof(psp_dnet_sizes);
+    return 0;
+}
 const char* psp_last_error(void) { return g_err; }
 
 // ---- DenseNet control (hjbd_kernels.h): time_approx='outer' and DenseNet(d+1 -> d) controls ---------------------

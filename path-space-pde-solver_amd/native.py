@@ -90,6 +90,7 @@ class GenSizes(C.Structure):
 _P = C.c_void_p
 SIGNATURES = {
     "psp_version": (C.c_int, []),
+    "psp_abi_struct_sizes": (C.c_int, [C.POINTER(C.c_int32 * 6)]),
     "psp_last_error": (C.c_char_p, []),
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_family": (C.c_int, [C.c_int32, C.c_int32]),
@@ -145,6 +146,12 @@ def load():
             raise NativeLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    sizes = (C.c_int32 * 6)()
+    lib.psp_abi_struct_sizes(C.byref(sizes))
+    mine = [C.sizeof(t) for t in (HjbConfig, HjbSizes, GenConfig, GenSizes, DnetConfig, DnetSizes)]
+    if list(sizes) != mine:          # a stale build or a drifted struct declaration would corrupt kernel arguments silently
+        raise NativeLibraryError("%s was built for other struct layouts (library %s, binding %s): rebuild it"
+                                 % (LIB_PATH, list(sizes), mine))
     _lib = lib
     return lib
 

@@ -73,3 +73,18 @@ def test_null_buffers_are_rejected_before_any_launch(lib):
     assert rc != 0 and "missing" in nat.last_error() or "null" in nat.last_error()
     rc = lib.psp_adam_step(None, None, None, None, 10, 1, 1e-3, 0.9, 0.999, 1e-8, None)
     assert rc != 0
+
+
+def test_struct_layouts_match_the_header():
+    """The ctypes structures of native.py against sizeof() of the C structs (psp_abi_struct_sizes); load() itself refuses a
+    library whose layouts differ, this test names the struct."""
+    import ctypes as C
+
+    from util_cases import psp
+    nat = psp.native
+    lib = nat.load()
+    sizes = (C.c_int32 * 6)()
+    assert lib.psp_abi_struct_sizes(C.byref(sizes)) == 0
+    names = ("HjbConfig", "HjbSizes", "GenConfig", "GenSizes", "DnetConfig", "DnetSizes")
+    for n, got in zip(names, sizes):
+        assert C.sizeof(getattr(nat, n)) == got, n
