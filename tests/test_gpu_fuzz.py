@@ -76,3 +76,73 @@ def test_random_configuration_matches_oracle(i):
     if s["loss_method"] in ("variance", "cross_entropy"):      # losses of exp(D): an absolute error in D is a relative one there
         tol = max(tol, 8.0 * err_D + 1e-5)
     assert math.isclose(model.loss_log[0], lref, rel_tol=tol, abs_tol=1e-7), (case, model.loss_log[0], lref)
+
+
+def _draw_general(i):
+    rng = random.Random(5000 + i)
+    fam = rng.choice(["general", "general", "general_bounded", "elliptic"])
+    d = rng.choice([1, 2, 3, 7, 16, 17, 33, 64, 100])
+    H = rng.choice([4, 16, 20, 33, 48, 64])
+    K = rng.choice([1, 5, 16, 17, 65, 150])
+    N = rng.choice([1, 2, 5, 11])
+    dt = rng.choice([0.01, 0.02])
+    loss = rng.choice(["diffusion", "diffusion", "BSDE"])
+    adaptive = rng.random() < 0.4
+    Kb = rng.choice([2, 6, 10])
+    solver = dict(seed=42, delta_t=dt, N=N, lr=0.001, L=1, K=K, K_boundary=min(Kb, K), loss_method=loss,
+                  adaptive_forward_process=adaptive)
+    attrs = None
+    if fam == "general":
+        kind = rng.choice(["DoubleWell_multidim_for_general_solver", "AllenCahn", "HeatEquation"])
+        T = rng.choice([0.5, 1.5]) * N * dt
+        if kind.startswith("DoubleWell"):
+            kwargs = dict(d=d, d_1=d // 2, d_2=d - d // 2, T=T, eta=0.1, kappa=0.5, modus=rng.choice(["HJB", "linear"]))
+        else:
+            kwargs = dict(d=d, T=T, seed=42) if kind == "HeatEquation" else dict(d=d, T=T, seed=42, modus="pt")
+        solver["alpha"] = [1.0, rng.choice([0.5, 1.0]), 1.0]
+    elif fam == "general_bounded":
+        kind = rng.choice(["ExponentialOnSphereNonlinearParabolic", "QuadraticOnBox"])
+        T = rng.choice([0.5, 1.5]) * N * dt
+        if kind == "QuadraticOnBox":
+            kwargs = dict(d=d, T=T, X_l=-1.0, X_r=rng.choice([0.7, 1.0]), one_boundary=rng.random() < 0.3, scale=1.0,
+                          quad_h=rng.random() < 0.5)
+        else:
+            kwargs = dict(d=d, T=T, alpha=0.2)
+            if loss == "diffusion" and rng.random() < 0.3:
+                attrs = dict(boundary_type="Neumann")
+        solver["alpha"] = [1.0, 1.0, rng.choice([0.5, 2.0])]
+    else:
+        kind = rng.choice(["ExponentialOnSphere", "ExponentialOnBallNonlinear", "ExponentialOnBallNonlinearSin", "QuadraticOnBox"])
+        if kind == "QuadraticOnBox":
+            kwargs = dict(d=d, X_l=-1.0, X_r=1.0, one_boundary=rng.random() < 0.3, parabolic=False, quad_h=rng.random() < 0.5)
+        else:
+            kwargs = dict(d=d, alpha=0.2)
+        solver["alpha"] = [1.0, rng.choice([0.5, 1.0])]
+    if d == 1 and kind == "QuadraticOnBox":
+        d = 2
+        kwargs["d"] = 2                      # (the reference's square boundary sampler needs d >= 2)
+    case = dict(name="gfuzz%d" % i, family=fam, problem=dict(kind=kind, kwargs=kwargs), solver=solver, net=dict(arch=[H, H], seed=42))
+    if attrs:
+        case["problem"]["attrs"] = attrs
+    if kind == "QuadraticOnBox":
+        case["numpy_seed"] = 9
+        solver["K_boundary"] = max(2, 2 * (solver["K_boundary"] // 2))
+    return case
+
+
+@pytest.mark.parametrize("i", range(24))
+def test_random_general_configuration_matches_oracle(i):
+    """GeneralSolver / EllipticSolver on unbounded, sphere and box domains: native first iteration against the oracle."""
+    from test_general_composite_golden import build as build_pkg
+    from test_gpu_bounded_elliptic import oracle_run
+    case = _draw_general(i)
+    prob, model = build_pkg(case, device=torch.device("cuda:0"), backend="native", L=1)
+    model.train()
+    assert model.plan_name == "native", case
+    ref = oracle_run(case, 1)
+    assert model.K_log == ref["K_log"], case
+    assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=1e-4, abs_tol=1e-7), (case, model.loss_log, ref["loss_log"])
+    g_ref = torch.cat([g.reshape(-1) for g in ref["traces"][0]["grads"]])
+    g = model._gen_plan.grad.cpu()
+    err = float((g - g_ref).abs().max())
+    assert err <= 5e-4 * float(g_ref.abs().max()) + 1e-10, (case, err, float(g_ref.abs().max()))
