@@ -38,6 +38,8 @@ WORKLOADS = {
     "hjb_llgc_d100_K8192_N50_h64": dict(d=100, H=64, K=8192, T=0.5, dt=0.01, off_diag=0.01),
     "hjb_llgc_d100_K16384_N50_h64": dict(d=100, H=64, K=16384, T=0.5, dt=0.01, off_diag=0.01),
     # structured variant A=-I, B=I (reported separately)
+    # opt-in mode: control-net products of the forward rollout on bf16 MFMA (SURVEY 8d "bf16-MLP runs"); NOT the headline
+    "hjb_llgc_d100_K65536_N100_h64_bf16mlp": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.01, mlp="bf16"),
     "hjb_llgc_d100_K65536_N100_h64_diag": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.0),
     # BASELINE.json configs[3]: d=200, K=262144 over 8 GPUs = 32768 per GPU, N=100 (wide kernel family)
     "hjb_llgc_d200_K32768_N100_h64": dict(d=200, H=64, K=32768, T=1.0, dt=0.01, off_diag=0.1 / 200 ** 0.5),
@@ -154,7 +156,7 @@ def main():
     model = psp.Solver("bench", prob, lr=1e-3, L=total, K=K_global, delta_t=w["dt"], loss_method="log-variance",
                        time_approx="inner", adaptive_forward_process=True, detach_forward=True,
                        u_l2_error_flag=False, verbose=False, seed=42, device=dev, backend="native",
-                       noise="philox", widths=(w["H"], w["H"]))
+                       noise="philox", widths=(w["H"], w["H"]), mlp_dtype=w.get("mlp", "fp32"))
     plan = model._choose_plan()
     assert model.plan_name == "native"
     N_t = model.N
@@ -209,7 +211,9 @@ def main():
         "metric": "trajectory-timesteps/sec (K*N/s), d=%d HJB log-variance training iteration" % w["d"],
         "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 control-net products in the forward rollout, f32 elsewhere" if w.get("mlp") == "bf16" else "f32",
+        "data": "synthetic",
         "config": {"workload": args.workload, "problem": "LLGC", "d": w["d"], "K_per_gpu": w["K"],
                    "K_global": K_global, "N": N_t, "mlp": "%d-%d-%d-%d tanh" % (w["d"] + 1, w["H"], w["H"], w["d"]),
                    "loss": "log-variance", "noise": "on-device Philox4x32-10",

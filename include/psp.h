@@ -47,6 +47,9 @@ enum { PSP_LOSS_LOG_VARIANCE = 0, PSP_LOSS_MOMENT = 1, PSP_LOSS_WEIGHTS = 2, PSP
 /* Brownian increments: supplied = the reference's host-generated xi (solver.py:381), philox = on device */
 enum { PSP_NOISE_SUPPLIED = 0, PSP_NOISE_PHILOX = 1 };
 
+/* arithmetic type of the matrix products (operands; accumulation is always fp32) */
+enum { PSP_MLP_FP32 = 0, PSP_MLP_BF16_FWD = 1, PSP_MLP_BF16 = 2 };
+
 /* POD description of one HJB rollout problem on one rank. */
 typedef struct psp_hjb_config {
     int32_t d;            /* state dimension                                    */
@@ -76,6 +79,11 @@ typedef struct psp_hjb_config {
                            * (LLGC, problems.py:51-53); enables the u_L2 log of solver.py:491-494 inside the
                            * forward kernels.  NULL: no logging                                             */
     float* u_l2_out;      /* (K_local): sum_n |-Z_n(X_n) - u*(t_n)|^2 dt per trajectory (mean = u_L2_loss)  */
+    int32_t mlp_dtype;    /* PSP_MLP_FP32 (0, the default and the only setting the 1e-4 parity bar applies to), or
+                           * PSP_MLP_BF16_FWD: the three products of the control net in the FORWARD rollout on
+                           * v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulate); drift / sigma products, state,
+                           * sums and the backward pass stay fp32.  Narrow kernel family only (-3 otherwise)          */
+    int32_t reserved2;
 } psp_hjb_config;
 
 /* Sizes of the caller-owned scratch buffers for a config. */
@@ -219,7 +227,6 @@ enum { PSP_GH_ZERO = 0, PSP_GH_QUAD = 1, PSP_GH_ALLEN_CAHN = 2, PSP_GH_EXPBALL_L
  *   BOX           dom_a <= X_proposal <= dom_b in every coordinate
  *   BOX_UPPER_ALL X_proposal <= dom_b in every coordinate   (EllipticSolver, one_boundary)
  *   BOX_UPPER_ANY X_proposal <= dom_b in some coordinate    (GeneralSolver, one_boundary) */
-enum { PSP_MLP_FP32 = 0, PSP_MLP_BF16_FWD = 1, PSP_MLP_BF16 = 2 };
 enum { PSP_DOM_NONE = 0, PSP_DOM_SPHERE = 1, PSP_DOM_BOX = 2, PSP_DOM_BOX_UPPER_ALL = 3, PSP_DOM_BOX_UPPER_ANY = 4 };
 
 typedef struct psp_gen_config {

@@ -79,45 +79,6 @@ struct GGeo {
     static int bwd_lds_floats() { return gEnd; }
 };
 
-// ---- bf16 MFMA variant of the register-chained products (BASELINE.json configs[2]: "bf16 MFMA MLP path") -----------
-// v_mfma_f32_16x16x32_bf16: A (16 x 32) lane (i, g) holds k = 8g..8g+7, B (32 x 16) lane (n, g) likewise, fp32 accumulate.
-// One k-step spans TWO 16-feature blocks of the T layout; lane (j, q) already holds in[2S][0..3], in[2S+1][0..3], so the
-// B operand is a pack of eight local registers (no shuffle): k = 8q + e  <->  feature 32 S + (e < 4 ? 4e : 16 + 4(e-4)) + q.
-// The A tables are laid out for that map (stage_aop_bf16), rows keep the rowmap of the fp32 tables, so the fp32
-// accumulators chain from layer to layer exactly as in the fp32 kernels.  State, accumulators, Y and the path store stay fp32.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-template <class F>
-__device__ __forceinline__ void stage_aop_bf16(float* dstf, int MB, int NS, int tid, int nthr, F src) {
-    bf16x8* dst = reinterpret_cast<bf16x8*>(dstf);
-    const int total = MB * NS * 64;
-    for (int idx = tid; idx < total; idx += nthr) {
-        const int lane = idx & 63, t = idx >> 6;
-        const int S = t % NS, mb = t / NS;
-        const int i = lane & 15, g = lane >> 4;
-        const int row = 16 * mb + 4 * (i & 3) + (i >> 2);
-        bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (__bf16)src(row, 32 * S + (e < 4 ? 4 * e : 16 + 4 * (e - 4)) + g);
-        dst[idx] = v;
-    }
-}
-template <int MB, int INB>
-__device__ __forceinline__ void gemm_Tb(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane) {
-    constexpr int NS = (INB + 1) / 2;
-    const bf16x8* tbl = reinterpret_cast<const bf16x8*>(wlds) + opaque_i(lane);
-#pragma unroll
-    for (int S = 0; S < NS; ++S) {
-        bf16x8 b;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            b[e] = (__bf16)in[2 * S][e];
-            b[4 + e] = (2 * S + 1 < INB) ? (__bf16)in[(2 * S + 1 < INB) ? 2 * S + 1 : 0][e] : (__bf16)0.0f;
-        }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tbl[(mb * NS + S) * 64], b, acc[mb], 0, 0, 0);
-    }
-}
 // dispatch of one product: fp32 16x16x4 chain (gemm_T) or the bf16 16x16x32 one
 template <bool BF16, int MB, int KS, int INB>
 __device__ __forceinline__ void gen_gemm(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane) {

@@ -14,6 +14,7 @@
         r.split_lds_bytes = &psp::HjbsLaunch<D_, H_>::lds_bytes;                           \
         r.launch_fwd_split = &psp::HjbsLaunch<D_, H_>::fwd;                                \
         r.launch_adj = &psp::HjbaLaunch<D_, H_>::adj;                                      \
+        r.launch_fwd_bf16 = &psp::HjbLaunch<D_, H_>::fwd_bf16;                             \
         return r;                                                                           \
     }
 PSP_DEFINE_(PSP_D, PSP_H)

@@ -223,6 +223,47 @@ __device__ __forceinline__ void gemm_T(f32x4 (&acc)[MB], const float* wlds,
     }
 }
 
+// ---- bf16 MFMA variant of the register-chained products (BASELINE.json configs[2]: "bf16 MFMA MLP path"; also the
+// opt-in bf16-MLP mode of the HJB forward kernel) --------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16: A (16 x 32) lane (i, g) holds k = 8g..8g+7, B (32 x 16) lane (n, g) likewise, fp32 accumulate.
+// One k-step spans TWO 16-feature blocks of the T layout; lane (j, q) already holds in[2S][0..3], in[2S+1][0..3], so the
+// B operand is a pack of eight local registers (no shuffle): k = 8q + e  <->  feature 32 S + (e < 4 ? 4e : 16 + 4(e-4)) + q.
+// The A tables are laid out for that map (stage_aop_bf16), rows keep the rowmap of the fp32 tables, so the fp32
+// accumulators chain from layer to layer exactly as in the fp32 kernels.  State, accumulators, Y and the path store stay fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <class F>
+__device__ __forceinline__ void stage_aop_bf16(float* dstf, int MB, int NS, int tid, int nthr, F src) {
+    bf16x8* dst = reinterpret_cast<bf16x8*>(dstf);
+    const int total = MB * NS * 64;
+    for (int idx = tid; idx < total; idx += nthr) {
+        const int lane = idx & 63, t = idx >> 6;
+        const int S = t % NS, mb = t / NS;
+        const int i = lane & 15, g = lane >> 4;
+        const int row = 16 * mb + 4 * (i & 3) + (i >> 2);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)src(row, 32 * S + (e < 4 ? 4 * e : 16 + 4 * (e - 4)) + g);
+        dst[idx] = v;
+    }
+}
+template <int MB, int INB>
+__device__ __forceinline__ void gemm_Tb(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane) {
+    constexpr int NS = (INB + 1) / 2;
+    const bf16x8* tbl = reinterpret_cast<const bf16x8*>(wlds) + opaque_i(lane);
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+        bf16x8 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b[e] = (__bf16)in[2 * S][e];
+            b[4 + e] = (2 * S + 1 < INB) ? (__bf16)in[(2 * S + 1 < INB) ? 2 * S + 1 : 0][e] : (__bf16)0.0f;
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tbl[(mb * NS + S) * 64], b, acc[mb], 0, 0, 0);
+    }
+}
+
 __device__ __forceinline__ float qsum(float v) {  // sum over the 4 q-lanes of a trajectory
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
@@ -307,7 +348,9 @@ struct Geo {
 // Forward rollout kernel: Euler-Maruyama + control MLP + running cost, all N steps.
 // Reference: solver.py:440-478 (step), :364-382 (init), :167-168 (D = Y - g).
 // =======================================================================================
-template <int D, int H>
+// BF16: the three products of the control net on v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulate) -- an opt-in
+// mode with its own tolerance (psp_hjb_config.mlp_dtype); the drift / sigma products, the state and every sum stay fp32.
+template <int D, int H, bool BF16 = false>
 __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
@@ -318,11 +361,15 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 
     // ---- stage weights (once per workgroup; parameters are constant during an iteration)
     const float* __restrict__ P = a.params;
-    stage_aop(lds + G::fW1, HB, KSD, tid, nthr, [&](int row, int col) {
+    auto stage_net = [&](float* dst, int MB, int KS, int INB, auto src) {
+        if constexpr (BF16) stage_aop_bf16(dst, MB, (INB + 1) / 2, tid, nthr, src);
+        else stage_aop(dst, MB, KS, tid, nthr, src);
+    };
+    stage_net(lds + G::fW1, HB, KSD, DB, [&](int row, int col) {
         return (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f; });
-    stage_aop(lds + G::fW2, HB, KSH, tid, nthr, [&](int row, int col) {
+    stage_net(lds + G::fW2, HB, KSH, HB, [&](int row, int col) {
         return (row < H && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
-    stage_aop(lds + G::fW3, DB, KSH, tid, nthr, [&](int row, int col) {
+    stage_net(lds + G::fW3, DB, KSH, HB, [&](int row, int col) {
         return (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f; });
     float* ldsA = lds + G::fA;
     float* ldsB = ldsA + (a.drift_kind == DRIFT_DENSE ? G::fB_dense_off : 0);
@@ -400,7 +447,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 h1[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
-            gemm_T<HB, KSD, DB>(h1, lds + G::fW1, X, lane);
+            if constexpr (BF16) gemm_Tb<HB, DB>(h1, lds + G::fW1, X, lane);
+            else gemm_T<HB, KSD, DB>(h1, lds + G::fW1, X, lane);
             PSP_STAMP(fs1);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = tanh4(h1[m]);
@@ -408,7 +456,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 h2[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
-            gemm_T<HB, KSH, HB>(h2, lds + G::fW2, h1, lane);
+            if constexpr (BF16) gemm_Tb<HB, HB>(h2, lds + G::fW2, h1, lane);
+            else gemm_T<HB, KSH, HB>(h2, lds + G::fW2, h1, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
             if (a.store_path) {                        // hidden activations for the backward pass (no recompute)
@@ -421,7 +470,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 Z[DB];
 #pragma unroll
             for (int m = 0; m < DB; ++m) Z[m] = vb3[m * 4];
-            gemm_T<DB, KSH, HB>(Z, lds + G::fW3, h2, lane);
+            if constexpr (BF16) gemm_Tb<DB, HB>(Z, lds + G::fW3, h2, lane);
+            else gemm_T<DB, KSH, HB>(Z, lds + G::fW3, h2, lane);
             PSP_STAMP(fs3);
 
             // ---- Brownian increment xi_{n+1} and the two row sums |Z|^2, Z.xi (solver.py:477-478)
@@ -1368,6 +1418,7 @@ struct HjbInstance {
     int (*split_lds_bytes)();        // hjbs_kernels.h: feature-split forward for small K (null: not built for this instance)
     hipError_t (*launch_fwd_split)(const HjbArgs&, int grid, hipStream_t);
     hipError_t (*launch_adj)(const HjbArgs&, int grid, int block, hipStream_t);   // hjba_kernels.h adjoint sweep (null: not built)
+    hipError_t (*launch_fwd_bf16)(const HjbArgs&, int grid, int block, hipStream_t);   // control net on bf16 MFMA (null: not built)
 };
 
 template <int D, int H>
@@ -1381,6 +1432,14 @@ struct HjbLaunch {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((hjb_fwd_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
+        return hipGetLastError();
+    }
+    static hipError_t fwd_bf16(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        const int bytes = fwd_lds(a.drift_kind, a.sigma_kind);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_fwd_kernel<D, H, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjb_fwd_kernel<D, H, true>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
     static hipError_t bwd(const HjbArgs& a, int grid, int block, hipStream_t s) {

@@ -147,6 +147,7 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     // It wins while one-wave-per-tile would leave SIMDs idle: up to 2 tiles per CU (PSP_FWD_VARIANT=1 / 2 force either)
     static const char* fv = getenv("PSP_FWD_VARIANT");
     p->fwd_split = !p->inst.wide && p->inst.launch_fwd_split && p->inst.split_lds_bytes() <= kMaxLds &&
+                   c->mlp_dtype != PSP_MLP_BF16_FWD &&           // (the bf16 control-net mode exists in hjb_fwd_kernel only)
                    ((fv && fv[0] == '2') || (!(fv && fv[0] == '1') && p->ntile16 <= 2 * cus));
     if (p->fwd_split) { p->fwd_waves = 4; p->fwd_grid = p->ntile16; }
     // backward: persistent over rounds of 4 sample blocks; 4-wave workgroups, two per CU
@@ -514,8 +515,16 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
     a.D = D_out; a.XN = XN_out; a.Yout = Y_out; a.fwd_partial = fwd_partial;
     a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    hipError_t e = p.fwd_split ? p.inst.launch_fwd_split(a, p.fwd_grid, (hipStream_t)stream)
-                               : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    hipError_t e;
+    if (cfg->mlp_dtype == PSP_MLP_BF16_FWD) {
+        if (!p.inst.launch_fwd_bf16) return fail(-3, "the bf16 control-net mode exists for the narrow kernel family only");
+        e = p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);      // make_plan kept the tile-per-wave forward
+    } else if (cfg->mlp_dtype != PSP_MLP_FP32) {
+        return fail(-1, "mlp_dtype out of range for the HJB rollout (fp32 or bf16_fwd)");
+    } else {
+        e = p.fwd_split ? p.inst.launch_fwd_split(a, p.fwd_grid, (hipStream_t)stream)
+                        : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel launch");
     return 0;
 }

@@ -45,6 +45,7 @@ class HjbConfig(C.Structure):
         ("sigma_scale", C.c_float), ("reserved", C.c_int32),
         ("drift", C.c_void_p), ("sigma", C.c_void_p), ("runcost", C.c_void_p), ("term", C.c_void_p),
         ("u_ref", C.c_void_p), ("u_l2_out", C.c_void_p),
+        ("mlp_dtype", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 

@@ -59,7 +59,7 @@ class Solver:
                  IS_variance_K=0, IS_variance_iter=1, metastability_logs=None, print_every=100,
                  plot_trajectories=None, seed=42, save_results=False, u_l2_error_flag=True,
                  log_gradient=False, burgers_drift=False, verbose=True,
-                 device=None, backend='auto', noise='reference', widths=(30, 30)):
+                 device=None, backend='auto', noise='reference', widths=(30, 30), mlp_dtype='fp32'):
         self.problem, self.name = problem, name
         self.date = date.today().strftime('%Y-%m-%d')
         self.d, self.T = problem.d, problem.T
@@ -72,6 +72,9 @@ class Solver:
         if noise not in ('reference', 'philox'):
             raise ValueError("noise must be 'reference' or 'philox'")
         self.backend, self.noise = backend, noise
+        if mlp_dtype not in ('fp32', 'bf16'):
+            raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
+        self.mlp_dtype = mlp_dtype       # 'bf16': control-net products of the native forward rollout on bf16 MFMA (opt-in, own tolerance)
 
         # hyper-parameters (reference solver.py:36-45): fp32 step, float64 step count
         self.seed = seed

@@ -242,3 +242,23 @@ def test_importance_sampling_large_K_philox():
     model._is_calls -= 1
     m2, v2, r2 = psp.do_importance_sampling_me(prob, model, 1 << 20)
     assert (m, v, r) == (m2, v2, r2)
+
+
+def test_bf16_control_net_mode_tracks_fp32():
+    """Opt-in mlp_dtype='bf16' (control-net products of the forward rollout on v_mfma_f32_16x16x32_bf16, fp32 accumulate;
+    SURVEY 8d 'bf16-MLP runs'): its OWN tolerance -- D within 1 % of max|D|, loss within 1 %, gradient cosine >= 0.999
+    against the fp32 kernels on the same noise; the fp32 mode remains the parity setting."""
+    for name in ("llgc_d100_h64_logvar", "lqgc_d33_h50_logvar", "dw_d10_logvar"):
+        case = load_golden(name)["case"]
+        res = {}
+        for dt in ("fp32", "bf16"):
+            model = make_pkg_solver(case, dev(), backend="native", L=1, mlp_dtype=dt)
+            model.train()
+            assert model.plan_name == "native"
+            res[dt] = (model.loss_log[0], model._native_plan.D.double().cpu(), model._native_plan.grad.double().cpu())
+        l32, D32, g32 = res["fp32"]
+        l16, D16, g16 = res["bf16"]
+        assert l16 != l32                                  # the bf16 kernel really ran
+        assert math.isclose(l16, l32, rel_tol=1e-2), (name, l16, l32)
+        assert float((D16 - D32).abs().max()) <= 1e-2 * float(D32.abs().max()), name
+        assert float(torch.dot(g16, g32) / (g16.norm() * g32.norm())) >= 0.999, name
