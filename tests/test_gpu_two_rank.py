@@ -75,3 +75,61 @@ def test_two_ranks_match_one_rank_attached(tmp_path):
         assert abs(a - b) <= 1e-6 * abs(b), (two["loss"], one["loss"])
     err = float((two["params"] - one["params"]).abs().max())
     assert err <= 2e-6, err
+
+
+# ---- the other native plans: DenseNet controls (time_approx='outer') and GeneralSolver on a bounded domain -----------------
+def _train_other(kind, noise, out=None, rank=0):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import path_space_pde_solver_amd as psp
+    dev = torch.device("cuda:0")
+    if kind == "outer":
+        prob = psp.LLGC(d=20, off_diag=0.05, T=0.1, seed=42, device=dev)
+        model = psp.Solver("two-rank-outer", prob, device=dev, noise=noise, lr=1e-3, L=3, K=256, delta_t=0.01,
+                           loss_method="log-variance", time_approx="outer", adaptive_forward_process=True, detach_forward=True,
+                           u_l2_error_flag=False, verbose=False, seed=42, backend="native")
+        model.train()
+        assert model.plan_name == "native"
+        plan = model._native_plan
+        params = torch.cat([p.detach().reshape(-1).cpu() for net in model.z_n for p in net.parameters()])
+    else:
+        prob = psp.ExponentialOnSphereNonlinearParabolic(d=6, T=0.5, alpha=0.3, device=dev)
+        model = psp.GeneralSolver(prob, "two-rank-sphere", seed=42, delta_t=0.01, N=20, lr=1e-3, L=3, K=256, K_boundary=16,
+                                  alpha=[1.0, 1.0, 1.0], loss_method="diffusion", verbose=False, device=dev, backend="native",
+                                  noise=noise)
+        np.random.seed(0)
+        model.train()
+        assert model.plan_name == "native"
+        plan = model._gen_plan
+        params = torch.cat([p.detach().reshape(-1).cpu() for p in model.V.parameters()])
+    res = dict(loss=list(model.loss_log), params=params, K_local=plan.K_local, K_log=list(getattr(model, "K_log", [])))
+    if out is not None and rank == 0:
+        torch.save(res, out)
+    return res
+
+
+def _worker_other(rank, world, port, kind, noise, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = _train_other(kind, noise, out, rank)
+    assert res["K_local"] == 256 // world
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,noise", [("outer", "philox"), ("outer", "reference"), ("sphere", "reference"), ("sphere", "philox")])
+def test_two_ranks_match_one_rank_other_plans(tmp_path, kind, noise):
+    """Sharded DenseNet-control and bounded-domain GeneralSolver runs reproduce the single-process run (global noise
+    indexing, global loss sums, summed gradients, and -- for the sphere with reference noise -- the globally agreed
+    number of noise draws the host consumes)."""
+    out = os.path.join(str(tmp_path), "two_%s_%s.pt" % (kind, noise))
+    mp.spawn(_worker_other, args=(2, _free_port(), kind, noise, out), nprocs=2, join=True)
+    two = torch.load(out)
+    one = _train_other(kind, noise)
+    assert two["K_log"] == one["K_log"]
+    for a, b in zip(two["loss"], one["loss"]):
+        assert abs(a - b) <= 2e-6 * abs(b), (two["loss"], one["loss"])
+    err = float((two["params"] - one["params"]).abs().max())
+    assert err <= 5e-6, err
