@@ -213,7 +213,7 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
 // LOGU: the u_L2 log of solver.py:491-494 (psp_hjb_config.u_ref); a separate instantiation because at d = 500 the kernel
 // sits on the 512-register limit and two more live accumulators cost the ordinary path 8 % (measured)
 template <int D, int H, bool LOGU = false>
-__global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void hjbw_fwd_kernel(const HjbArgs a) {
 //   split over the four waves).  One barrier per round (the dz2 exchange is double-buffered).
 // =======================================================================================
 template <int D, int H>
-__global__ __launch_bounds__(256) void hjbw_bwd_kernel(const HjbArgs a) {
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP, EXB = W::EXB;

@@ -161,7 +161,7 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     if (p->inst.wide) p->bwd_specialised = true;          // launch_bwd2 = hjbw_bwd_kernel (4 waves)
     p->bwd_waves = (p->bwd_specialised && !p->inst.wide) ? 8 : 4;
     long long g = nround;
-    const long long gmax = p->bwd_specialised ? cus : 2LL * cus;
+    const long long gmax = (p->bwd_specialised && !(p->inst.wide && c->d <= 256)) ? cus : 2LL * cus;   // wide, d <= 256: two per CU
     if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     p->bwd_grid = (int)g;
