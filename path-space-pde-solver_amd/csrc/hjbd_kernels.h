@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a) {
 }
 
 template <int D, int H>
-__global__ __launch_bounds__(256) void hjbd_fwd_kernel(const DnetArgs da) {
+__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const DnetArgs da) {   // d <= 128: two workgroups per CU
     using W = DGeo<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
     const HjbArgs& a = da.h;
