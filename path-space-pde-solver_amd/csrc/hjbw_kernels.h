@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
 // W3^T gZ is the third rolled product, W2^T and W1x^T are short unrolled ones.
 // =======================================================================================
 template <int D, int H>
-__global__ __launch_bounds__(256) void hjbw_adj_kernel(const HjbArgs a) {
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
