@@ -94,6 +94,29 @@ def cpu_baseline(w, seconds_budget=20.0):
                        % (Kc, w["K"], N, iters, el, torch.__version__))
 
 
+def loss_rel_err_vs_cpu(psp, dev, w):
+    """BASELINE.json's second metric: |L_gpu - L_ref| / |L_ref| per iteration on FIXED SEEDS -- the native plan with the
+    reference's host-generated noise (torch CPU generator, seed 42) against the CPU oracle consuming the same stream, on the
+    workload's problem at K = 1024 trajectories, 3 iterations.  Part of the cpu_baseline leg (the only place bench.py may
+    use oracle/)."""
+    from oracle import pathspace_oracle as orc
+    K, L = 1024, 3
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    oprob = orc.make_problem("LLGC", d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42)
+    ocfg = orc.HJBConfig(K=K, delta_t=w["dt"], lr=1e-3, L=L, seed=42, adaptive_forward_process=True, detach_forward=True)
+    z = orc.TanhMLP(w["d"] + 1, w["d"], 1e-3, seed=123, widths=(w["H"], w["H"]))
+    _, y0, N = orc.hjb_build(oprob, ocfg)
+    ref = orc.hjb_train(oprob, ocfg, step_models=(z, y0, N))["loss_log"]
+    prob = psp.LLGC(d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42, device=dev)
+    model = psp.Solver("bench-parity", prob, lr=1e-3, L=L, K=K, delta_t=w["dt"], loss_method="log-variance",
+                       time_approx="inner", adaptive_forward_process=True, detach_forward=True, u_l2_error_flag=False,
+                       verbose=False, seed=42, device=dev, backend="native", noise="reference", widths=(w["H"], w["H"]))
+    model.train()
+    errs = [abs(a - b) / abs(b) for a, b in zip(model.loss_log, ref)]
+    return dict(value=max(errs), per_iteration=errs, tolerance=1e-4,
+                case="LLGC d=%d, K=%d, N=%d, %d iterations, seed 42, reference noise stream" % (w["d"], K, N, L))
+
+
 def secondary(psp, dev, w, steps=100, warmup=10):
     prob = psp.LLGC(d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42, device=dev)
     model = psp.Solver("bench-cfg1", prob, lr=1e-3, L=steps + warmup, K=w["K"], delta_t=w["dt"],
@@ -231,6 +254,7 @@ def main():
         out["also_configs1_K1024_N50"] = secondary(psp, dev, WORKLOADS["hjb_llgc_d100_K1024_N50_h64"])
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
+        out["loss_rel_err_vs_cpu_ref"] = loss_rel_err_vs_cpu(psp, dev, w)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if dist is not None:
