@@ -300,6 +300,8 @@ typedef struct psp_dnet_config {
     int32_t d_real, H_real;
     int32_t time_input;   /* 1: the net's input is [t, x] (time = column 0) */
     int32_t per_step;     /* 1: one parameter set per time step            */
+    float* r1_out;        /* optional (N, K_local, H_real): relu(z1) and relu(z2) of every sample, row-major -- spares the   */
+    float* r2_out;        /* gradient pass the recomputation of the two hidden layers (both NULL: not stored)                */
 } psp_dnet_config;
 
 typedef struct psp_dnet_sizes {

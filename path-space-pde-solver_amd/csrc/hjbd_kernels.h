@@ -26,6 +26,8 @@ struct DnetArgs {
     float* tbl;                // table region (DGeo::table_floats(...) floats)
     float* px;                 // (N, K_local, d_real) X_n          (store_path)
     float* pxi;                // (N, K_local, d_real) image of xi_{n+1}: xi, or xi + sqrt(dt) Z for a non-adaptive process
+    float* pr1;                // optional (N, K_local, h_real) relu(z1) and relu(z2): saves the gradient pass their recomputation
+    float* pr2;
     int d_real, h_real;        // the net's real input / hidden widths (the instance is zero padded above them)
     int time_input;            // 1: input is [t, x] (time = column 0); 0: input is x
     int per_step;              // 1: N consecutive parameter sets, one per time step
@@ -207,15 +209,33 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 for (int b = 0; b < DB; ++b) Xn[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
             }
             f32x4 h1[HB], h2[HB];
+            const bool store_r = store && da.pr1 != nullptr;
+            const int hr = da.h_real;
+            auto put_r = [&](float* base, int m, const f32x4& r) __attribute__((always_inline)) {
+                float* pr = base + row * hr;
 #pragma unroll
-            for (int m = 0; m < HB; ++m) { const f32x4 r = relu4d(z12[m]); h1[m] = r * r; }
+                for (int e = 0; e < 4; ++e) {
+                    const int f = 16 * m + 4 * e + q;
+                    if (f < hr) pr[f] = r[e];
+                }
+            };
+#pragma unroll
+            for (int m = 0; m < HB; ++m) {
+                const f32x4 r = relu4d(z12[m]);
+                h1[m] = r * r;
+                if (store_r) put_r(da.pr1, m, r);
+            }
             {
                 f32x4 z2[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) z2[m] = z12[HB + m];
                 gemm_regs<HB, 4 * HB, HB>(z2, Ts + W::tW2h, h1, lane);
 #pragma unroll
-                for (int m = 0; m < HB; ++m) { const f32x4 r = relu4d(z2[m]); h2[m] = r * r; }
+                for (int m = 0; m < HB; ++m) {
+                    const f32x4 r = relu4d(z2[m]);
+                    h2[m] = r * r;
+                    if (store_r) put_r(da.pr2, m, r);
+                }
             }
             // ---- control output four state blocks at a time: Z_g = W3x[g] x + W3h1[g] h1 + W3h2[g] h2 + b3
             float S = 0.f, Pz = 0.f;

@@ -437,6 +437,8 @@ extern "C" int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* par
     h.D = D_out; h.Fint = Fint_out; h.XN = XN_out; h.Yout = Y_out; h.fwd_partial = fwd_partial;
     h.seed_lo = (uint32_t)seed; h.seed_hi = (uint32_t)(seed >> 32); h.iter = iter;
     a.tbl = tables; a.px = px; a.pxi = pxi;
+    if ((cfg->r1_out == nullptr) != (cfg->r2_out == nullptr)) return fail(-1, "r1_out and r2_out go together");
+    a.pr1 = cfg->r1_out; a.pr2 = cfg->r2_out;
     a.d_real = cfg->d_real; a.h_real = cfg->H_real; a.time_input = cfg->time_input ? 1 : 0; a.per_step = cfg->per_step ? 1 : 0;
     hipError_t e = p.inst.launch_fwd(a, p.grid, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjbd_fwd_kernel launch");

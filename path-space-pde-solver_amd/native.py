@@ -72,7 +72,7 @@ class GenConfig(C.Structure):
 
 class DnetConfig(C.Structure):
     _fields_ = [("base", HjbConfig), ("d_real", C.c_int32), ("H_real", C.c_int32), ("time_input", C.c_int32),
-                ("per_step", C.c_int32)]
+                ("per_step", C.c_int32), ("r1_out", C.c_void_p), ("r2_out", C.c_void_p)]
 
 
 class DnetSizes(C.Structure):

@@ -9,7 +9,7 @@ Per iteration (reference solver.py:430-514):
                              batches the gradient needs, X_n and the xi image, each (N, K, d) row-major
     psp_dnet_terminal_reduce (sum D, sum D^2)                      [all-reduce 1]
     parameter gradient       detach_forward=True makes dL/dZ_n[k] = w_k sqrt(dt) image_n[k], so the gradient
-                             of every net is that of a plain feed-forward batch: recomputed activations and ~12 library
+                             of every net is that of a plain feed-forward batch: the stored relu activations and ~12 library
                              GEMMs (batched over the time steps; 'inner' shares one net across the batch), written
                              analytically below -- no autograd graph                    [all-reduce 2]
     psp_adam_step            one fused Adam over the concatenation of all parameter sets (identical to the reference's
@@ -142,6 +142,9 @@ class DenseNativePlan:
         self.fwd_partial = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)
         self.PX = torch.empty(s.N, self.K_local, s.d, dtype=f32, device=dev)
         self.PXI = torch.empty(s.N, self.K_local, s.d, dtype=f32, device=dev)
+        self.PR1 = torch.empty(s.N, self.K_local, self.H, dtype=f32, device=dev)       # relu(z1), relu(z2) from the rollout
+        self.PR2 = torch.empty(s.N, self.K_local, self.H, dtype=f32, device=dev)
+        cfg.r1_out, cfg.r2_out = nat.ptr(self.PR1), nat.ptr(self.PR2)
         self.D = torch.empty(self.K_local, dtype=f32, device=dev)
         self.Yn = torch.empty(self.K_local, dtype=f32, device=dev) if self.generic_loss else None
         self.w = torch.empty(self.K_local, dtype=f32, device=dev) if self.generic_loss else None
@@ -160,7 +163,7 @@ class DenseNativePlan:
             self.y0_m = torch.zeros(1, dtype=f32, device=dev)
             self.y0_v = torch.zeros(1, dtype=f32, device=dev)
             self.y0_grad = torch.zeros(1, dtype=f32, device=dev)
-        # sample chunk of the gradient GEMMs: bounds the recomputed activations ((di + 2H + d) floats per sample)
+        # sample chunk of the gradient GEMMs: bounds their temporaries (~(2H + 2d) floats per sample)
         self.chunk = max(1, (1 << 21) // max(1, self.K_local)) if not self.outer else s.N
 
     # ------------------------------------------------------------------------------------
@@ -205,11 +208,11 @@ class DenseNativePlan:
         N, K = s.N, self.K_local
         grad = self.grad
         grad.zero_()
-        W1, b1, W2, b2, W3 = (self._set_view(self.flat, k) for k in ('W1', 'b1', 'W2', 'b2', 'W3'))
+        W2, W3 = self._set_view(self.flat, 'W2'), self._set_view(self.flat, 'W3')
         gW1, gb1, gW2, gb2, gW3, gb3 = (self._set_view(grad, k) for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'))
         # row blocks of the dense-concat weights: [input | h1 | h2]; every product below works on one block, so the
         # concatenated activations [u, h1, h2] are never materialised (the torch.cat copies were a quarter of this function)
-        W2u, W2h = W2[:, :di, :], W2[:, di:, :]
+        W2h = W2[:, di:, :]
         W3h1T, W3h2T = W3[:, di:di + H, :].transpose(1, 2), W3[:, di + H:, :].transpose(1, 2)     # (B, d, H)
         W2hT = W2h.transpose(1, 2)
         scale = (w * float(self.cfg.base.sqrt_dt)).view(1, K, 1)
@@ -226,10 +229,8 @@ class DenseNativePlan:
                 U, sl = torch.cat([self.tn[n0:n1].view(-1, 1, 1).expand(n1 - n0, K, 1), X], 2), slice(0, 1)
             red = (lambda t: t) if self.outer else (lambda t: t.sum(0, keepdim=True))
             UT = U.transpose(1, 2)
-            r1 = torch.relu(torch.matmul(U, W1[sl]) + b1[sl].unsqueeze(1))
-            h1 = r1 * r1
-            r2 = torch.relu(torch.matmul(U, W2u[sl]) + torch.matmul(h1, W2h[sl]) + b2[sl].unsqueeze(1))
-            h2 = r2 * r2
+            r1, r2 = self.PR1[n0:n1], self.PR2[n0:n1]             # stored by the rollout kernel (no recomputed forward)
+            h1, h2 = r1 * r1, r2 * r2
             gW3[sl][:, :di] += red(torch.matmul(UT, G))
             gW3[sl][:, di:di + H] += red(torch.matmul(h1.transpose(1, 2), G))
             gW3[sl][:, di + H:] += red(torch.matmul(h2.transpose(1, 2), G))
