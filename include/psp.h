@@ -302,6 +302,8 @@ typedef struct psp_dnet_config {
     int32_t per_step;     /* 1: one parameter set per time step            */
     float* r1_out;        /* optional (N, K_local, H_real): relu(z1) and relu(z2) of every sample, row-major -- spares the   */
     float* r2_out;        /* gradient pass the recomputation of the two hidden layers (both NULL: not stored)                */
+    float* images_out;    /* optional (psp_dnet_sizes.image_bytes): X_n, relu(z1), relu(z2) and the xi image as register images
+                           * for psp_dnet_rollout_bwd; when set they REPLACE the row-major stores (px, pxi, r1_out, r2_out) */
 } psp_dnet_config;
 
 typedef struct psp_dnet_sizes {
@@ -309,6 +311,10 @@ typedef struct psp_dnet_sizes {
     int64_t fwd_partial_bytes;
     int64_t n_params_per_set;
     int32_t fwd_workgroups, reserved;
+    /* hand-written backward (psp_dnet_rollout_bwd); bwd_supported = 0 when the instance's accumulators do not fit */
+    int64_t image_bytes;       /* N x ceil(K/16) image blocks                                          */
+    int64_t partial_bytes;     /* N x slices partial gradients of padded_params floats                 */
+    int32_t bwd_supported, slices, padded_params, bwd_workgroups;
 } psp_dnet_sizes;
 
 int psp_dnet_instance_count(void);
@@ -324,6 +330,14 @@ int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* params, const 
                          const float* y0, const float* xi, uint64_t seed, uint32_t iter, const float* tfeat,
                          float* px, float* pxi, float* D_out, float* Fint_out, float* XN_out, float* Y_out,
                          double* fwd_partial, float* tables, void* stream);
+
+/* Parameter gradient of sum_{n,k} w_k sqrt(dt) image_n[k] . Z_n(X_n[k]) (= dL/dtheta for a detached forward process) from the
+ * images the forward wrote (cfg->images_out).  w: per-trajectory weights dL/dD_k, zero padded to 16 * ceil(K_local/16).
+ * partial: (N * slices, padded_params) -- per work item (time step, slice of its tiles) in the PADDED layout of the instance
+ * (d x H etc., no time rows):  [W1 (d x H), b1 (H), W2 ((d+H) x H), b2, W3 ((d+2H) x d), b3 (d)];  the caller sums the slices of a
+ * step, cuts the real rows / columns out and -- with time_input -- forms the time rows as sum_n t_n * (bias gradient of step n). */
+int psp_dnet_rollout_bwd(const psp_dnet_config* cfg, const float* params, const float* images, const float* w,
+                         float* partial, void* stream);
 
 /* Diagnostics: device buffer that receives per-wave phase cycle sums (8 u64 per wave of the
  * backward kernel).  Returns 1 if the library was built with -DPSP_STAMPS (diagnostic build,

@@ -28,6 +28,11 @@ struct DnetArgs {
     float* pxi;                // (N, K_local, d_real) image of xi_{n+1}: xi, or xi + sqrt(dt) Z for a non-adaptive process
     float* pr1;                // optional (N, K_local, h_real) relu(z1) and relu(z2): saves the gradient pass their recomputation
     float* pr2;
+    float* pimg;               // optional: the same four quantities as T-layout register images, N x ntile16 blocks of DGeo::PBI
+                               // floats (what hjbd_bwd_kernel reads; written instead of the row-major stores when set)
+    const float* wts;          // backward: per-trajectory weights dL/dD_k, zero padded to 16 * ntile16
+    float* partial;            // backward: [N * slices][DGeo::PP] partial gradients in the padded (instance) layout
+    int slices;                // backward: work items per time step (tiles of a step are split into this many slices)
     int d_real, h_real;        // the net's real input / hidden widths (the instance is zero padded above them)
     int time_input;            // 1: input is [t, x] (time = column 0); 0: input is x
     int per_step;              // 1: N consecutive parameter sets, one per time step
@@ -56,6 +61,14 @@ struct DGeo {
     // LDS (floats): problem vectors, reduction scratch, two images per wave (X_n and the increment panel v)
     static constexpr int vdr = 0, vrun = vdr + DB * 16, vterm = vrun + DB * 16, fRed = vterm + DB * 16,
                          fImg = fRed + 64, IMG = KP * 64, lds_floats = fImg + 4 * 2 * IMG;
+    // image block of one (step, 16-trajectory tile) for the backward kernel: X_n, relu(z1), relu(z2), xi image
+    static constexpr int pX = 0, pR1 = pX + KP * 64, pR2 = pR1 + 4 * HB * 64, pXi = pR2 + 4 * HB * 64, PBI = pXi + KP * 64;
+    // padded gradient layout of one work item (instance sizes, no time rows): W1 (D x H), b1, W2 ((D+H) x H), b2, W3 ((D+2H) x D), b3
+    static constexpr int gW1 = 0, gb1 = gW1 + D * H, gW2 = gb1 + H, gb2 = gW2 + (D + H) * H, gW3 = gb2 + H,
+                         gb3 = gW3 + (D + 2 * H) * D, PP = gb3 + D;
+    // backward LDS (floats): three A-operand tables of the step's net, then the double-buffered dz2 / dz1 exchange
+    static constexpr int bW3h2 = 0, bW3h1 = bW3h2 + HB * KP * 64, bW2h = bW3h1 + HB * KP * 64, bEx = bW2h + HB * 4 * HB * 64,
+                         EXT = 2 * HB, bwd_lds_floats = bEx + 2 * 4 * EXT * 256;
     // real flat parameter layout of one net (registration order W1,b1,W2,b2,W3,b3; weights (in, out))
     static __host__ __device__ long long n_params(int d, int h, int time_input) {
         const long long di = d + (time_input ? 1 : 0);
@@ -180,7 +193,12 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
             // ---- X_n: LDS image (B operand of every product over x) and the row-major store for the backward pass
 #pragma unroll
             for (int ks = 0; ks < KP; ++ks) imgX[ks * 64 + lane] = X[ks >> 2][ks & 3];
-            if (store) {
+            float* iblk = da.pimg ? da.pimg + ((size_t)n * a.ntile16 + t16) * (size_t)W::PBI + lane : nullptr;
+            const bool store_img = a.store_path && wave_valid && da.pimg != nullptr;
+            if (store_img) {
+#pragma unroll
+                for (int ks = 0; ks < KP; ++ks) iblk[W::pX + ks * 64] = X[ks >> 2][ks & 3];
+            } else if (store) {
                 float* px = da.px + row * dr;
 #pragma unroll
                 for (int b = 0; b < DB; ++b)
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 for (int b = 0; b < DB; ++b) Xn[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
             }
             f32x4 h1[HB], h2[HB];
-            const bool store_r = store && da.pr1 != nullptr;
+            const bool store_r = store && da.pr1 != nullptr && !store_img;
             const int hr = da.h_real;
             auto put_r = [&](float* base, int m, const f32x4& r) __attribute__((always_inline)) {
                 float* pr = base + row * hr;
@@ -224,6 +242,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 const f32x4 r = relu4d(z12[m]);
                 h1[m] = r * r;
                 if (store_r) put_r(da.pr1, m, r);
+                if (store_img) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) iblk[W::pR1 + (4 * m + e) * 64] = r[e];
+                }
             }
             {
                 f32x4 z2[HB];
@@ -235,6 +257,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                     const f32x4 r = relu4d(z2[m]);
                     h2[m] = r * r;
                     if (store_r) put_r(da.pr2, m, r);
+                    if (store_img) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) iblk[W::pR2 + (4 * m + e) * 64] = r[e];
+                    }
                 }
             }
             // ---- control output four state blocks at a time: Z_g = W3x[g] x + W3h1[g] h1 + W3h2[g] h2 + b3
@@ -263,7 +289,11 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= dr || !kvalid) xi[r] = 0.f;   // padding carries no noise
-                    if (store) {
+                    if (store_img) {
+                        const f32x4 wv = xi + store_cz * Zg[m];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) iblk[W::pXi + (4 * b + r) * 64] = wv[r];
+                    } else if (store) {
                         float* pxi = da.pxi + row * dr;
                         const f32x4 wv = xi + store_cz * Zg[m];
 #pragma unroll
@@ -353,12 +383,189 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
     }
 }
 
+// =======================================================================================
+// Backward kernel of the DenseNet control: parameter gradient of sum_{n,k} G_n[k] . Z_n(X_n[k]),  G = w_k sqrt(dt) image
+// (dL/dZ_n for a detached forward process), per time step when every step has its own net.
+// One 4-wave workgroup per CU (one wave per SIMD: the 512-entry register file holds a wave's 30-odd accumulator tiles next
+// to the column operands), rounds of 4 sample blocks, double-buffered LDS exchange, one barrier per round.  A work item =
+// (step n, slice of its 16-trajectory tiles); its accumulators are flushed to partial[item] in the padded layout
+// (reduced over the slices, and mapped to the real shapes, by the host).  Per round every wave
+//   (1) T layout, own block:  G = w sqrt(dt) image;  dz2 = (W3h2 G) 2 r2;  dz1 = (W3h1 G + W2h dz2) 2 r1  (three register-
+//       chained products from LDS tables of the step's net) -> dz2 / dz1 tiles in the exchange buffer;  barrier;
+//   (2) feature-on-lane, all four blocks:  wave c owns the row items i = c (mod 4) of [x blocks | h1 blocks | h2 blocks]; row
+//       operands are reads of the stored images (h = r^2 on the fly), column operands the G tiles (the xi image read the
+//       same way, times w sqrt(dt)) and the exchanged dz2 / dz1 tiles:
+//           x rows:  dW3x += x^T G,  dW2x += x^T dz2,  dW1 += x^T dz1      h1 rows:  dW3h1 += h1^T G,  dW2h += h1^T dz2
+//           h2 rows: dW3h2 += h2^T G;   bias sums from the column tiles (wave 0).
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
+    using W = DGeo<D, H>;
+    constexpr int DB = W::DB, HB = W::HB, KP = W::KP, EXT = W::EXT, NC = DB + 2 * HB, NRI = DB + 2 * HB, NR = cdiv(NRI, 4);
+    const HjbArgs& a = da.h;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, sub = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, qq = lane >> 4, col = lane & 15;
+    const unsigned lofsU = (unsigned)image_lane_offset_F(lane);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int d = da.d_real, hh = da.h_real, to = da.time_input ? 1 : 0, di = d + to;
+    const long long Pset = W::n_params(d, hh, da.time_input);
+    const long long oW2 = (long long)di * hh + hh, oW3 = oW2 + (long long)(di + hh) * hh + hh;
+    float* bufs = lds + W::bEx;
+    const int S = da.slices, n_items = a.N * S;
+    const float gs = a.sqdt;
+    typedef const __attribute__((address_space(1))) float* gptr_t;
+
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int n = item / S, sl = item % S;
+        const int t_lo = (int)((long long)a.ntile16 * sl / S), t_hi = (int)((long long)a.ntile16 * (sl + 1) / S);
+        const int R = (t_hi - t_lo + 3) / 4;
+        // ---- the step's net as A-operand tables, real layout -> zero padded
+        const float* __restrict__ P = a.params + (long long)(da.per_step ? n : 0) * Pset;
+        __syncthreads();                                  // the previous item's readers are done with tables and exchange
+        stage_aop(lds + W::bW3h2, HB, KP, tid, nthr, [&](int row, int c2) {
+            return (row < hh && c2 < d) ? P[oW3 + (long long)(di + hh + row) * d + c2] : 0.f; });
+        stage_aop(lds + W::bW3h1, HB, KP, tid, nthr, [&](int row, int c2) {
+            return (row < hh && c2 < d) ? P[oW3 + (long long)(di + row) * d + c2] : 0.f; });
+        stage_aop(lds + W::bW2h, HB, 4 * HB, tid, nthr, [&](int row, int c2) {
+            return (row < hh && c2 < hh) ? P[oW2 + (long long)(di + row) * hh + c2] : 0.f; });
+        __syncthreads();
+        const float* img_n = da.pimg + (size_t)n * a.ntile16 * (size_t)W::PBI;
+        auto get_F = [&](int t16, int ofs) __attribute__((always_inline)) {
+            unsigned long long addr = (unsigned long long)img_n + 4ull * ((unsigned long long)t16 * (unsigned)W::PBI + (unsigned)ofs);
+            asm volatile("" : "+s"(addr));
+            return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((gptr_t)addr + lofsU);
+        };
+        f32x4 acc[NR][NC];
+        float bs[NC];
+#pragma unroll
+        for (int li = 0; li < NR; ++li)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[li][c] = zero4;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) bs[c] = 0.f;
+
+#pragma unroll 1
+        for (int it = 0; it < R; ++it) {
+            float* exch = bufs + (it & 1) * 4 * (EXT * 256);
+            {   // ---- (1) adjoint panels of the own block, T layout
+                const int t0 = t_lo + 4 * it + sub;
+                const bool bvalid = t0 < t_hi;
+                const int t16 = bvalid ? t0 : t_hi - 1;
+                const float* pb = img_n + (size_t)t16 * (size_t)W::PBI + lane;
+                const int k = t16 * 16 + j;
+                const float wk = (bvalid && k < a.K_local) ? da.wts[k] * gs : 0.f;
+                f32x4 G[DB];
+#pragma unroll
+                for (int b = 0; b < DB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) G[b][r] = wk * pb[W::pXi + (4 * b + r) * 64];
+                f32x4 dz2[HB], dz1[HB];
+#pragma unroll
+                for (int m = 0; m < HB; ++m) { dz2[m] = zero4; dz1[m] = zero4; }
+                gemm_T<HB, KP, DB>(dz2, lds + W::bW3h2, G, lane);                 // dh2 = W3h2 G
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz2[m][r] *= 2.0f * pb[W::pR2 + (4 * m + r) * 64];
+                gemm_T<HB, KP, DB>(dz1, lds + W::bW3h1, G, lane);                 // dh1 = W3h1 G + W2h dz2
+                gemm_T<HB, 4 * HB, HB>(dz1, lds + W::bW2h, dz2, lane);
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz1[m][r] *= 2.0f * pb[W::pR1 + (4 * m + r) * 64];
+                float* my_ex = exch + sub * (EXT * 256);
+#pragma unroll
+                for (int m = 0; m < HB; ++m) {
+                    tile_put(my_ex + m * 256, dz2[m], lane);
+                    tile_put(my_ex + (HB + m) * 256, dz1[m], lane);
+                }
+            }
+            __syncthreads();                              // (the buffer written two rounds ago is free: every wave has passed
+                                                          //  the previous round's barrier after reading it)
+#pragma unroll 1
+            for (int sb = 0; sb < 4; ++sb) {              // ---- (2) weight-gradient outer products, feature on lane
+                const int t0 = t_lo + 4 * it + sb;
+                const bool bvalid = t0 < t_hi;
+                const int t16 = __builtin_amdgcn_readfirstlane(bvalid ? t0 : t_hi - 1);
+                const float* ex = exch + sb * (EXT * 256);
+                f32x4 w4 = *reinterpret_cast<const f32x4*>(da.wts + t16 * 16 + 4 * qq);
+                if (!bvalid) w4 = zero4;
+                w4 = w4 * gs;
+                f32x4 ct[NC];
+#pragma unroll
+                for (int b = 0; b < DB; ++b) ct[b] = w4 * get_F(t16, W::pXi + b * 256);
+#pragma unroll
+                for (int m = 0; m < 2 * HB; ++m) ct[DB + m] = tile_get(ex + m * 256, lane);
+                if (sub == 0) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) bs[c] += hsum4(ct[c]);
+                }
+#pragma unroll
+                for (int li = 0; li < NR; ++li) {
+                    const int i = sub + 4 * li;            // row item (wave-uniform): x block, h1 block or h2 block
+                    if (i < NRI) {
+                        f32x4 A;
+                        int ncol;                          // h2 rows meet G only, h1 rows G and dz2, x rows everything
+                        if (i < DB) { A = get_F(t16, W::pX + i * 256); ncol = NC; }
+                        else if (i < DB + HB) { const f32x4 r = get_F(t16, W::pR1 + (i - DB) * 256); A = r * r; ncol = DB + HB; }
+                        else { const f32x4 r = get_F(t16, W::pR2 + (i - DB - HB) * 256); A = r * r; ncol = DB; }
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            if (c < ncol) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[li][c] = mfma16(A[r], ct[c][r], acc[li][c]);
+                            }
+                    }
+                }
+            }
+        }
+        // ---- flush the item: tile (row item i, column tile c): lane (col, qq), reg rr <-> dW[16 rb + 4 qq + rr][16 cb + col]
+        float* gp = da.partial + (size_t)item * (size_t)W::PP;
+#pragma unroll
+        for (int li = 0; li < NR; ++li) {
+            const int i = sub + 4 * li;
+            if (i < NRI) {
+                const int rbase = (i < DB) ? 16 * i : ((i < DB + HB) ? D + 16 * (i - DB) : D + H + 16 * (i - DB - HB));
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const bool used = (i < DB) || (i < DB + HB ? c < DB + HB : c < DB);
+                    if (used) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int row = rbase + 4 * qq + rr;
+                            if (c < DB) gp[W::gW3 + row * D + 16 * c + col] = acc[li][c][rr];                          // . G
+                            else if (c < DB + HB) gp[W::gW2 + row * H + 16 * (c - DB) + col] = acc[li][c][rr];          // . dz2
+                            else gp[W::gW1 + row * H + 16 * (c - DB - HB) + col] = acc[li][c][rr];                      // . dz1 (x rows only)
+                        }
+                    }
+                }
+            }
+        }
+        if (sub == 0) {                                   // bias gradients: column sums over the lane's samples, then over qq
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float v = bs[c];
+                v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                if (qq == 0) {
+                    if (c < DB) gp[W::gb3 + 16 * c + col] = v;
+                    else if (c < DB + HB) gp[W::gb2 + 16 * (c - DB) + col] = v;
+                    else gp[W::gb1 + 16 * (c - DB - HB) + col] = v;
+                }
+            }
+        }
+    }
+}
+
 // host-side launch table entry of this family
 struct DnetInstance {
     int d, H;
     int lds_bytes;
     int set_floats, vec_floats, shared_floats;
     hipError_t (*launch_fwd)(const DnetArgs&, int grid, hipStream_t);
+    int image_block_floats, partial_floats, bwd_lds_bytes;
+    hipError_t (*launch_bwd)(const DnetArgs&, int grid, hipStream_t);
 };
 
 template <int D, int H>
@@ -375,8 +582,17 @@ struct DnetLaunch {
         hipLaunchKernelGGL((hjbd_fwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
         return hipGetLastError();
     }
+    static hipError_t bwd(const DnetArgs& a, int grid, hipStream_t s) {
+        const int bytes = W::bwd_lds_floats * 4;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_bwd_kernel<D, H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbd_bwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
+        return hipGetLastError();
+    }
     static DnetInstance instance() {
-        return DnetInstance{D, H, W::lds_floats * 4, W::set_floats, W::vec_floats, W::oSets, &fwd};
+        return DnetInstance{D, H, W::lds_floats * 4, W::set_floats, W::vec_floats, W::oSets, &fwd,
+                            W::PBI, W::PP, W::bwd_lds_floats * 4, &bwd};
     }
 };
 

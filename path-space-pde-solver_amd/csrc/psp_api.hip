@@ -353,7 +353,7 @@ const char* psp_last_error(void) { return g_err; }
 
 // ---- DenseNet control (hjbd_kernels.h): time_approx='outer' and DenseNet(d+1 -> d) controls ---------------------
 namespace {
-struct DnetPlan { psp::DnetInstance inst; int ntile16, grid; long long table_floats, n_params; };
+struct DnetPlan { psp::DnetInstance inst; int ntile16, grid; long long table_floats, n_params; int slices, bwd_grid, bwd_ok; };
 int make_dnet_plan(const psp_dnet_config* c, DnetPlan* p) {
     if (!c) return fail(-1, "null config");
     const psp_hjb_config& b = c->base;
@@ -376,6 +376,16 @@ int make_dnet_plan(const psp_dnet_config* c, DnetPlan* p) {
                       (long long)b.N * p->inst.vec_floats;
     const long long di = c->d_real + (c->time_input ? 1 : 0), h = c->H_real, d = c->d_real;
     p->n_params = di * h + h + (di + h) * h + h + (di + 2 * h) * d + d;
+    // backward work items = (step, slice): about two waves of workgroups over the chip, at least one round per item
+    const int cus = n_cus();
+    int S = (2 * cus + b.N / 2) / b.N;
+    const int smax = (p->ntile16 + 3) / 4;
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    p->slices = S;
+    const long long items = (long long)b.N * S;
+    p->bwd_grid = (int)(items < cus ? items : cus);
+    p->bwd_ok = (p->inst.bwd_lds_bytes <= kMaxLds && b.H <= 32) ? 1 : 0;     // wider nets: too many accumulator tiles per wave
     return 0;
 }
 }  // namespace
@@ -397,6 +407,10 @@ extern "C" int psp_dnet_query(const psp_dnet_config* cfg, psp_dnet_sizes* out) {
     out->n_params_per_set = p.n_params;
     out->fwd_workgroups = p.grid;
     out->reserved = 0;
+    out->image_bytes = (int64_t)cfg->base.N * p.ntile16 * p.inst.image_block_floats * 4;
+    out->partial_bytes = (int64_t)cfg->base.N * p.slices * p.inst.partial_floats * 4;
+    out->bwd_supported = p.bwd_ok; out->slices = p.slices; out->padded_params = p.inst.partial_floats;
+    out->bwd_workgroups = p.bwd_grid;
     return 0;
 }
 
@@ -408,6 +422,24 @@ extern "C" int psp_dnet_terminal_reduce(const psp_dnet_config* cfg, const double
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fwd_partial, p.grid, sums_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_partials_kernel launch");
+    return 0;
+}
+
+extern "C" int psp_dnet_rollout_bwd(const psp_dnet_config* cfg, const float* params, const float* images, const float* w,
+                                    float* partial, void* stream) {
+    DnetPlan p;
+    int rc = make_dnet_plan(cfg, &p);
+    if (rc) return rc;
+    if (!p.bwd_ok) return fail(-3, "the hand-written DenseNet-control backward does not cover this instance (H > 32)");
+    if (!params || !images || !w || !partial) return fail(-1, "null buffer passed to psp_dnet_rollout_bwd");
+    const psp_hjb_config* b = &cfg->base;
+    psp::DnetArgs a;
+    memset(&a, 0, sizeof(a));
+    a.h.params = params; a.h.K_local = b->K_local; a.h.N = b->N; a.h.ntile16 = p.ntile16; a.h.sqdt = b->sqrt_dt; a.h.dt = b->dt;
+    a.pimg = const_cast<float*>(images); a.wts = w; a.partial = partial; a.slices = p.slices;
+    a.d_real = cfg->d_real; a.h_real = cfg->H_real; a.time_input = cfg->time_input ? 1 : 0; a.per_step = cfg->per_step ? 1 : 0;
+    hipError_t e = p.inst.launch_bwd(a, p.bwd_grid, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hjbd_bwd_kernel launch");
     return 0;
 }
 
@@ -423,7 +455,7 @@ extern "C" int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* par
     if (!params || !x0 || !D_out || !fwd_partial || !tables) return fail(-1, "null buffer passed to psp_dnet_rollout_fwd");
     if (x0_stride != 0 && x0_stride != b->d) return fail(-1, "x0_stride must be 0 or d");
     if (b->noise_mode == PSP_NOISE_SUPPLIED && !xi) return fail(-1, "supplied-noise mode needs xi");
-    if (b->store_path && (!px || !pxi)) return fail(-1, "store_path set but the X / xi stores are null");
+    if (b->store_path && !cfg->images_out && (!px || !pxi)) return fail(-1, "store_path set but the X / xi stores are null");
     psp::DnetArgs a;
     memset(&a, 0, sizeof(a));
     psp::HjbArgs& h = a.h;
@@ -438,7 +470,7 @@ extern "C" int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* par
     h.seed_lo = (uint32_t)seed; h.seed_hi = (uint32_t)(seed >> 32); h.iter = iter;
     a.tbl = tables; a.px = px; a.pxi = pxi;
     if ((cfg->r1_out == nullptr) != (cfg->r2_out == nullptr)) return fail(-1, "r1_out and r2_out go together");
-    a.pr1 = cfg->r1_out; a.pr2 = cfg->r2_out;
+    a.pr1 = cfg->r1_out; a.pr2 = cfg->r2_out; a.pimg = cfg->images_out;
     a.d_real = cfg->d_real; a.h_real = cfg->H_real; a.time_input = cfg->time_input ? 1 : 0; a.per_step = cfg->per_step ? 1 : 0;
     hipError_t e = p.inst.launch_fwd(a, p.grid, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjbd_fwd_kernel launch");

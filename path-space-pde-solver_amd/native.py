@@ -72,12 +72,14 @@ class GenConfig(C.Structure):
 
 class DnetConfig(C.Structure):
     _fields_ = [("base", HjbConfig), ("d_real", C.c_int32), ("H_real", C.c_int32), ("time_input", C.c_int32),
-                ("per_step", C.c_int32), ("r1_out", C.c_void_p), ("r2_out", C.c_void_p)]
+                ("per_step", C.c_int32), ("r1_out", C.c_void_p), ("r2_out", C.c_void_p), ("images_out", C.c_void_p)]
 
 
 class DnetSizes(C.Structure):
     _fields_ = [("table_bytes", C.c_int64), ("fwd_partial_bytes", C.c_int64), ("n_params_per_set", C.c_int64),
-                ("fwd_workgroups", C.c_int32), ("reserved", C.c_int32)]
+                ("fwd_workgroups", C.c_int32), ("reserved", C.c_int32),
+                ("image_bytes", C.c_int64), ("partial_bytes", C.c_int64),
+                ("bwd_supported", C.c_int32), ("slices", C.c_int32), ("padded_params", C.c_int32), ("bwd_workgroups", C.c_int32)]
 
 
 class GenSizes(C.Structure):
@@ -100,6 +102,7 @@ SIGNATURES = {
     "psp_dnet_instance_get": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "psp_dnet_query": (C.c_int, [C.POINTER(DnetConfig), C.POINTER(DnetSizes)]),
     "psp_dnet_terminal_reduce": (C.c_int, [C.POINTER(DnetConfig), _P, _P, _P]),
+    "psp_dnet_rollout_bwd": (C.c_int, [C.POINTER(DnetConfig), _P, _P, _P, _P, _P]),
     "psp_dnet_rollout_fwd": (C.c_int, [C.POINTER(DnetConfig), _P, _P, C.c_int32, _P, _P, C.c_uint64, C.c_uint32, _P,
                                        _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "psp_gen_instance_count": (C.c_int, []),

@@ -140,11 +140,23 @@ class DenseNativePlan:
         f32 = torch.float32
         self.tables = torch.empty(sizes.table_bytes // 4, dtype=f32, device=dev)
         self.fwd_partial = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)
-        self.PX = torch.empty(s.N, self.K_local, s.d, dtype=f32, device=dev)
-        self.PXI = torch.empty(s.N, self.K_local, s.d, dtype=f32, device=dev)
-        self.PR1 = torch.empty(s.N, self.K_local, self.H, dtype=f32, device=dev)       # relu(z1), relu(z2) from the rollout
-        self.PR2 = torch.empty(s.N, self.K_local, self.H, dtype=f32, device=dev)
-        cfg.r1_out, cfg.r2_out = nat.ptr(self.PR1), nat.ptr(self.PR2)
+        # gradient: the hand-written kernel (csrc/hjbd_kernels.h, hjbd_bwd_kernel) where the instance is covered, else the
+        # library-GEMM formulation on row-major stores (PSP_DENSE_BWD=gemm forces the latter: cross-check / timing)
+        import os
+        self.kernel_bwd = bool(sizes.bwd_supported) and os.environ.get('PSP_DENSE_BWD', 'kernel') != 'gemm'
+        if self.kernel_bwd:
+            self.images = torch.empty(sizes.image_bytes // 4, dtype=f32, device=dev)
+            self.partial = torch.zeros(s.N * sizes.slices, sizes.padded_params, dtype=f32, device=dev)
+            self.wpad = torch.zeros(16 * ((self.K_local + 15) // 16), dtype=f32, device=dev)
+            self.slices, self.PP = int(sizes.slices), int(sizes.padded_params)
+            cfg.images_out = nat.ptr(self.images)
+            self.PX = self.PXI = self.PR1 = self.PR2 = None
+        else:
+            self.PX = torch.empty(s.N, self.K_local, s.d, dtype=f32, device=dev)
+            self.PXI = torch.empty(s.N, self.K_local, s.d, dtype=f32, device=dev)
+            self.PR1 = torch.empty(s.N, self.K_local, self.H, dtype=f32, device=dev)   # relu(z1), relu(z2) from the rollout
+            self.PR2 = torch.empty(s.N, self.K_local, self.H, dtype=f32, device=dev)
+            cfg.r1_out, cfg.r2_out = nat.ptr(self.PR1), nat.ptr(self.PR2)
         self.D = torch.empty(self.K_local, dtype=f32, device=dev)
         self.Yn = torch.empty(self.K_local, dtype=f32, device=dev) if self.generic_loss else None
         self.w = torch.empty(self.K_local, dtype=f32, device=dev) if self.generic_loss else None
@@ -202,7 +214,41 @@ class DenseNativePlan:
     _generic_loss_weights = HjbNativePlan._generic_loss_weights
 
     # ------------------------------------------------------------------------------------
+    def _gradient_kernel(self, w):
+        """hjbd_bwd_kernel: per (step, slice) partial gradients in the instance's padded layout -> real shapes."""
+        s, H, di, d, N = self.s, self.H, self.di, self.s.d, self.s.N
+        D, Hp = self.d_pad, self.H_pad
+        self.wpad[:self.K_local].copy_(w)
+        nat.check(self.lib.psp_dnet_rollout_bwd(C.byref(self.cfg), nat.ptr(self.flat), nat.ptr(self.images), nat.ptr(self.wpad),
+                                                nat.ptr(self.partial), nat.stream_ptr(self.dev)), 'psp_dnet_rollout_bwd')
+        g = self.partial.view(N, self.slices, self.PP).sum(1)          # (N, PP): one padded gradient per time step
+        o = 0
+        W1 = g[:, o:o + D * Hp].view(N, D, Hp)[:, :d, :H]; o += D * Hp
+        b1 = g[:, o:o + Hp][:, :H]; o += Hp
+        W2 = g[:, o:o + (D + Hp) * Hp].view(N, D + Hp, Hp); o += (D + Hp) * Hp
+        b2 = g[:, o:o + Hp][:, :H]; o += Hp
+        W3 = g[:, o:o + (D + 2 * Hp) * D].view(N, D + 2 * Hp, D); o += (D + 2 * Hp) * D
+        b3 = g[:, o:o + D][:, :d]
+        W2r = torch.cat([W2[:, :d, :H], W2[:, D:D + H, :H]], 1)                                  # rows [x | h1]
+        W3r = torch.cat([W3[:, :d, :d], W3[:, D:D + H, :d], W3[:, D + Hp:D + Hp + H, :d]], 1)    # rows [x | h1 | h2]
+        grad = self.grad
+        if self.outer:
+            out = torch.cat([W1.reshape(N, -1), b1, W2r.reshape(N, -1), b2, W3r.reshape(N, -1), b3], 1)       # per-step sets
+            grad.copy_(out.reshape(-1))
+        else:                                                     # one net: sum over the steps; the time input is row 0 of
+            t = self.tn.view(N, 1)                                # every layer's input block: its gradient is sum_n t_n db_n
+            W1s = torch.cat([(t * b1).sum(0, keepdim=True), W1.sum(0)], 0)
+            W2s = torch.cat([(t * b2).sum(0, keepdim=True), W2r.sum(0)], 0)
+            W3s = torch.cat([(t * b3).sum(0, keepdim=True), W3r.sum(0)], 0)
+            grad.copy_(torch.cat([W1s.reshape(-1), b1.sum(0), W2s.reshape(-1), b2.sum(0), W3s.reshape(-1), b3.sum(0)]))
+        return grad
+
     def _gradient(self, w):
+        if self.kernel_bwd:
+            return self._gradient_kernel(w)
+        return self._gradient_gemm(w)
+
+    def _gradient_gemm(self, w):
         """grad of sum_{n,k} G_n[k] . Z_n(X_n[k]) over all parameter sets, G = w_k sqrt(dt) image (row-major stores)."""
         s, H, di, d = self.s, self.H, self.di, self.s.d
         N, K = s.N, self.K_local
