@@ -484,18 +484,35 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
             }
             __syncthreads();                              // (the buffer written two rounds ago is free: every wave has passed
                                                           //  the previous round's barrier after reading it)
-#pragma unroll 1
-            for (int sb = 0; sb < 4; ++sb) {              // ---- (2) weight-gradient outer products, feature on lane
+            // ---- (2) weight-gradient outer products, feature on lane.  One wave per SIMD: nothing else hides the latency of the
+            //      image reads, so the raw operands of block sb + 1 are requested before the MFMAs of block sb issue
+            f32x4 gx[2][DB], ax[2][NR], wv[2];
+            auto request = [&](int buf, int sb) __attribute__((always_inline)) {
                 const int t0 = t_lo + 4 * it + sb;
                 const bool bvalid = t0 < t_hi;
                 const int t16 = __builtin_amdgcn_readfirstlane(bvalid ? t0 : t_hi - 1);
-                const float* ex = exch + sb * (EXT * 256);
                 f32x4 w4 = *reinterpret_cast<const f32x4*>(da.wts + t16 * 16 + 4 * qq);
-                if (!bvalid) w4 = zero4;
-                w4 = w4 * gs;
+                wv[buf] = bvalid ? w4 * gs : zero4;
+#pragma unroll
+                for (int b = 0; b < DB; ++b) gx[buf][b] = get_F(t16, W::pXi + b * 256);
+#pragma unroll
+                for (int li = 0; li < NR; ++li) {
+                    const int i = sub + 4 * li;
+                    const int ofs = (i < DB) ? W::pX + i * 256
+                                  : ((i < DB + HB) ? W::pR1 + (i - DB) * 256 : W::pR2 + ((i < NRI ? i : NRI - 1) - DB - HB) * 256);
+                    ax[buf][li] = get_F(t16, ofs);
+                }
+            };
+            request(0, 0);
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+                const int cur = sb & 1;
+                if (sb < 3) request(cur ^ 1, sb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const float* ex = exch + sb * (EXT * 256);
                 f32x4 ct[NC];
 #pragma unroll
-                for (int b = 0; b < DB; ++b) ct[b] = w4 * get_F(t16, W::pXi + b * 256);
+                for (int b = 0; b < DB; ++b) ct[b] = wv[cur] * gx[cur][b];
 #pragma unroll
                 for (int m = 0; m < 2 * HB; ++m) ct[DB + m] = tile_get(ex + m * 256, lane);
                 if (sub == 0) {
@@ -506,11 +523,9 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
                 for (int li = 0; li < NR; ++li) {
                     const int i = sub + 4 * li;            // row item (wave-uniform): x block, h1 block or h2 block
                     if (i < NRI) {
-                        f32x4 A;
-                        int ncol;                          // h2 rows meet G only, h1 rows G and dz2, x rows everything
-                        if (i < DB) { A = get_F(t16, W::pX + i * 256); ncol = NC; }
-                        else if (i < DB + HB) { const f32x4 r = get_F(t16, W::pR1 + (i - DB) * 256); A = r * r; ncol = DB + HB; }
-                        else { const f32x4 r = get_F(t16, W::pR2 + (i - DB - HB) * 256); A = r * r; ncol = DB; }
+                        const f32x4 raw = ax[cur][li];
+                        const f32x4 A = (i < DB) ? raw : raw * raw;             // h = r^2
+                        const int ncol = (i < DB) ? NC : ((i < DB + HB) ? DB + HB : DB);   // h2 rows meet G only, h1 rows G and dz2
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
                             if (c < ncol) {
@@ -565,6 +580,8 @@ struct DnetInstance {
     int set_floats, vec_floats, shared_floats;
     hipError_t (*launch_fwd)(const DnetArgs&, int grid, hipStream_t);
     int image_block_floats, partial_floats, bwd_lds_bytes;
+    int bwd_acc_tiles;         // accumulator tiles per wave of hjbd_bwd_kernel (ceil((DB+2HB)/4) * (DB+2HB)): beyond ~48 the
+                               // 512-entry register file spills heavily and the library-GEMM formulation is used instead
     hipError_t (*launch_bwd)(const DnetArgs&, int grid, hipStream_t);
 };
 
@@ -592,7 +609,7 @@ struct DnetLaunch {
     }
     static DnetInstance instance() {
         return DnetInstance{D, H, W::lds_floats * 4, W::set_floats, W::vec_floats, W::oSets, &fwd,
-                            W::PBI, W::PP, W::bwd_lds_floats * 4, &bwd};
+                            W::PBI, W::PP, W::bwd_lds_floats * 4, cdiv(W::DB + 2 * W::HB, 4) * (W::DB + 2 * W::HB), &bwd};
     }
 };
 

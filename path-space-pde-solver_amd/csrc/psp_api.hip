@@ -385,7 +385,7 @@ int make_dnet_plan(const psp_dnet_config* c, DnetPlan* p) {
     p->slices = S;
     const long long items = (long long)b.N * S;
     p->bwd_grid = (int)(items < cus ? items : cus);
-    p->bwd_ok = (p->inst.bwd_lds_bytes <= kMaxLds && b.H <= 32) ? 1 : 0;     // wider nets: too many accumulator tiles per wave
+    p->bwd_ok = (p->inst.bwd_lds_bytes <= kMaxLds && p->inst.bwd_acc_tiles <= 48) ? 1 : 0;   // else: too many accumulator tiles per wave
     return 0;
 }
 }  // namespace
@@ -430,7 +430,7 @@ extern "C" int psp_dnet_rollout_bwd(const psp_dnet_config* cfg, const float* par
     DnetPlan p;
     int rc = make_dnet_plan(cfg, &p);
     if (rc) return rc;
-    if (!p.bwd_ok) return fail(-3, "the hand-written DenseNet-control backward does not cover this instance (H > 32)");
+    if (!p.bwd_ok) return fail(-3, "the hand-written DenseNet-control backward does not cover this instance (accumulator tiles)");
     if (!params || !images || !w || !partial) return fail(-1, "null buffer passed to psp_dnet_rollout_bwd");
     const psp_hjb_config* b = &cfg->base;
     psp::DnetArgs a;

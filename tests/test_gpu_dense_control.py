@@ -149,3 +149,20 @@ def test_dense_shape_sweep_matches_oracle(mode, kind, d, H, K, dt, T, adaptive):
     assert float((g - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max()), (plan.d_pad, plan.H_pad)
     cond = float((tr["D"].double() ** 2).mean()) / max(abs(ref["loss_log"][0]), 1e-30)
     assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=min(1e-4, max(2e-5, 4 * 6e-8 * cond)))
+
+
+@pytest.mark.parametrize("name", ["llgc_d12_outer_moment", "lqgc_d6_densenet_variance", "lqgc_d2_outer"])
+def test_kernel_backward_agrees_with_the_gemm_formulation(name, monkeypatch):
+    """hjbd_bwd_kernel (hand-written: adjoint panels + weight-gradient outer products per (step, slice)) against the
+    library-GEMM formulation of the same gradient (PSP_DENSE_BWD=gemm), same rollout, same noise."""
+    case = load_golden(name)["case"]
+    grads = {}
+    for mode in ("kernel", "gemm"):
+        monkeypatch.setenv("PSP_DENSE_BWD", mode)
+        model = make_pkg_solver(case, dev(), backend="native", L=1)
+        model.train()
+        plan = model._native_plan
+        assert plan.kernel_bwd == (mode == "kernel")
+        grads[mode] = plan.grad.double().cpu()
+    gk, gg = grads["kernel"], grads["gemm"]
+    assert float((gk - gg).abs().max()) <= 2e-5 * float(gg.abs().max())
