@@ -40,6 +40,10 @@ WORKLOADS = {
     # structured variant A=-I, B=I (reported separately)
     # opt-in mode: control-net products of the forward rollout on bf16 MFMA (SURVEY 8d "bf16-MLP runs"); NOT the headline
     "hjb_llgc_d100_K65536_N100_h64_bf16mlp": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.01, mlp="bf16"),
+    # the reference's constructor default: time_approx='outer', one DenseNet(d -> d, arch [30, 30]) per time step (solver.py:88)
+    # (T = 0.5: over T = 1 the reference ALGORITHM itself blows up at this size -- relu^2 nets at their default init are
+    #  expansive, single paths overflow; the CPU oracle shows the same [316, 4.0e5, nan] at K = 8192, tools/check_outer_d100.py)
+    "hjb_llgc_d100_K65536_N50_outer_h30": dict(d=100, H=30, K=65536, T=0.5, dt=0.01, off_diag=0.01, outer=True),
     "hjb_llgc_d100_K65536_N100_h64_diag": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.0),
     # BASELINE.json configs[3]: d=200, K=262144 over 8 GPUs = 32768 per GPU, N=100 (wide kernel family)
     "hjb_llgc_d200_K32768_N100_h64": dict(d=200, H=64, K=32768, T=1.0, dt=0.01, off_diag=0.1 / 200 ** 0.5),
@@ -57,6 +61,15 @@ GENERAL_WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
+
+
+def alg_flops_dense_control(d, H, dense):
+    """Same accounting for a DenseNet(d -> d, [H, H]) control: forward products W1, W2 = [W2x; W2h], W3 = [W3x; W3h1; W3h2];
+    backward = weight gradients of all of them + the two adjoint products through W3h, W2h (no input gradient)."""
+    f_fwd = 2 * (d * H + (d + H) * H + (d + 2 * H) * d)
+    f_bwd = f_fwd + 2 * (2 * H * d + H * H)
+    f_sde = 2 * d * d * (3 if dense else 0)
+    return dict(fwd_kernel=f_fwd + f_sde + 12 * d, bwd_kernel=f_bwd, total=f_fwd + f_bwd + f_sde + 12 * d)
 
 
 def alg_flops_per_traj_step(d, H, dense):
@@ -176,10 +189,15 @@ def main():
     K_global = w["K"] * world                           # weak scaling: fixed trajectories per GPU
     prob = psp.LLGC(d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42, device=dev)
     total = args.warmup + args.steps
-    model = psp.Solver("bench", prob, lr=1e-3, L=total, K=K_global, delta_t=w["dt"], loss_method="log-variance",
-                       time_approx="inner", adaptive_forward_process=True, detach_forward=True,
+    outer = bool(w.get("outer"))
+    model = psp.Solver("bench", prob, lr=w.get("lr", 1e-3), L=total, K=K_global, delta_t=w["dt"], loss_method="log-variance",
+                       time_approx="outer" if outer else "inner", adaptive_forward_process=True, detach_forward=True,
                        u_l2_error_flag=False, verbose=False, seed=42, device=dev, backend="native",
                        noise="philox", widths=(w["H"], w["H"]), mlp_dtype=w.get("mlp", "fp32"))
+    if outer:                                            # the constructor builds arch [30, 30]; honour the workload's H
+        model.z_n = [psp.DenseNet(d_in=w["d"], d_out=w["d"], lr=w.get("lr", 1e-3), arch=[w["H"], w["H"]], seed=42).to(dev)
+                     for _ in range(model.N)]
+        model.update_Phis()
     plan = model._choose_plan()
     assert model.plan_name == "native"
     N_t = model.N
@@ -212,14 +230,17 @@ def main():
         return
 
     dense = w["off_diag"] != 0.0
-    fl = alg_flops_per_traj_step(w["d"], w["H"], dense)
+    fl = alg_flops_dense_control(w["d"], w["H"], dense) if outer else alg_flops_per_traj_step(w["d"], w["H"], dense)
     units_local = w["K"] * N_t                           # trajectory-timesteps per launch on one GPU
     # kernel names as they appear in rocprof: family 1 = hjb_kernels.h (hjbs_kernels.h forward when there are at most two
     # tiles per CU), family 2 = hjbw_kernels.h
     ntile = (plan.K_local + 15) // 16
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    fwd_name = "hjbw_fwd_kernel" if plan.family == 2 else ("hjbs_fwd_kernel" if ntile <= 2 * cus else "hjb_fwd_kernel")
-    bwd_name = "hjbw_bwd_kernel" if plan.family == 2 else "hjb_bwd2_kernel"
+    if outer:
+        fwd_name, bwd_name = "hjbd_fwd_kernel", ("hjbd_bwd_kernel" if plan.kernel_bwd else "library GEMMs")
+    else:
+        fwd_name = "hjbw_fwd_kernel" if plan.family == 2 else ("hjbs_fwd_kernel" if ntile <= 2 * cus else "hjb_fwd_kernel")
+        bwd_name = "hjbw_bwd_kernel" if plan.family == 2 else "hjb_bwd2_kernel"
     bwd_dominant = bwd_ms >= fwd_ms
     dom = bwd_name if bwd_dominant else fwd_name
     dom_ms = max(bwd_ms, fwd_ms)
@@ -238,7 +259,9 @@ def main():
         "dtype": "bf16 control-net products in the forward rollout, f32 elsewhere" if w.get("mlp") == "bf16" else "f32",
         "data": "synthetic",
         "config": {"workload": args.workload, "problem": "LLGC", "d": w["d"], "K_per_gpu": w["K"],
-                   "K_global": K_global, "N": N_t, "mlp": "%d-%d-%d-%d tanh" % (w["d"] + 1, w["H"], w["H"], w["d"]),
+                   "K_global": K_global, "N": N_t,
+                   "mlp": ("%d x DenseNet %d-%d-%d-%d relu^2, one per time step (time_approx='outer')" % (N_t, w["d"], w["H"], w["H"], w["d"]))
+                          if outer else "%d-%d-%d-%d tanh" % (w["d"] + 1, w["H"], w["H"], w["d"]),
                    "loss": "log-variance", "noise": "on-device Philox4x32-10",
                    "parallelism": "trajectory-sharded x%d" % world},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
