@@ -166,3 +166,18 @@ def test_kernel_backward_agrees_with_the_gemm_formulation(name, monkeypatch):
         grads[mode] = plan.grad.double().cpu()
     gk, gg = grads["kernel"], grads["gemm"]
     assert float((gk - gg).abs().max()) <= 2e-5 * float(gg.abs().max())
+
+
+def test_outer_default_nets_at_d100_match_oracle():
+    """The reference's constructor defaults at the benchmark dimension: time_approx='outer', 100 DenseNet(100 -> 100, [30, 30])
+    nets (instance (112, 32), kernel backward), K = 512, N = 100, three full iterations on the reference noise stream."""
+    case = dict(name="outer100", family="solver", problem=dict(kind="LLGC", kwargs=dict(d=100, off_diag=0.01, T=1.0, seed=42)),
+                solver=dict(loss_method="log-variance", time_approx="outer", adaptive_forward_process=True, detach_forward=True,
+                            early_stopping_time=None, L=3, lr=1e-3, seed=42, delta_t=0.01, K=512, u_l2_error_flag=False))
+    model = make_pkg_solver(case, dev(), backend="native")
+    oprob, ocfg, omodels = make_oracle(case)
+    model.train()
+    assert model.plan_name == "native" and model._native_plan.kernel_bwd
+    ref = orc.hjb_train(oprob, ocfg, step_models=omodels)
+    for got, want in zip(model.loss_log, ref["loss_log"]):
+        assert math.isclose(got, want, rel_tol=1e-4), (model.loss_log, ref["loss_log"])
