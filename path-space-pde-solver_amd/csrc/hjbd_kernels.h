@@ -398,10 +398,18 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
 //           x rows:  dW3x += x^T G,  dW2x += x^T dz2,  dW1 += x^T dz1      h1 rows:  dW3h1 += h1^T G,  dW2h += h1^T dz2
 //           h2 rows: dW3h2 += h2^T G;   bias sums from the column tiles (wave 0).
 // =======================================================================================
-template <int D, int H>
+// PASS 0: everything in one launch.  Wider instances split the COLUMNS over two launches so that a wave's accumulators fit
+// its registers: PASS 1 = the G columns (dW3 and db3; needs no adjoint panels), PASS 2 = the dz2 / dz1 columns (dW2, dW1,
+// db2, db1; x and h1 rows only).  Both read the same images and write disjoint parts of partial[item].
+template <int D, int H, int PASS = 0>
 __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
     using W = DGeo<D, H>;
-    constexpr int DB = W::DB, HB = W::HB, KP = W::KP, EXT = W::EXT, NC = DB + 2 * HB, NRI = DB + 2 * HB, NR = cdiv(NRI, 4);
+    constexpr int DB = W::DB, HB = W::HB, KP = W::KP, EXT = W::EXT;
+    constexpr bool PH1 = PASS != 1;                                 // adjoint panels needed
+    constexpr bool GCOL = PASS != 2;                                // G columns handled here
+    constexpr int C0 = (PASS == 2) ? DB : 0;                        // first column (global numbering: G tiles, then dz2, dz1)
+    constexpr int NC = (PASS == 0) ? DB + 2 * HB : (PASS == 1 ? DB : 2 * HB);
+    constexpr int NRI = (PASS == 2) ? DB + HB : DB + 2 * HB, NR = cdiv(NRI, 4);
     const HjbArgs& a = da.h;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -424,12 +432,14 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
         // ---- the step's net as A-operand tables, real layout -> zero padded
         const float* __restrict__ P = a.params + (long long)(da.per_step ? n : 0) * Pset;
         __syncthreads();                                  // the previous item's readers are done with tables and exchange
+        if constexpr (PH1) {
         stage_aop(lds + W::bW3h2, HB, KP, tid, nthr, [&](int row, int c2) {
             return (row < hh && c2 < d) ? P[oW3 + (long long)(di + hh + row) * d + c2] : 0.f; });
         stage_aop(lds + W::bW3h1, HB, KP, tid, nthr, [&](int row, int c2) {
             return (row < hh && c2 < d) ? P[oW3 + (long long)(di + row) * d + c2] : 0.f; });
         stage_aop(lds + W::bW2h, HB, 4 * HB, tid, nthr, [&](int row, int c2) {
             return (row < hh && c2 < hh) ? P[oW2 + (long long)(di + row) * hh + c2] : 0.f; });
+        }
         __syncthreads();
         const float* img_n = da.pimg + (size_t)n * a.ntile16 * (size_t)W::PBI;
         auto get_F = [&](int t16, int ofs) __attribute__((always_inline)) {
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
 #pragma unroll 1
         for (int it = 0; it < R; ++it) {
             float* exch = bufs + (it & 1) * 4 * (EXT * 256);
-            {   // ---- (1) adjoint panels of the own block, T layout
+            if constexpr (PH1) {   // ---- (1) adjoint panels of the own block, T layout
                 const int t0 = t_lo + 4 * it + sub;
                 const bool bvalid = t0 < t_hi;
                 const int t16 = bvalid ? t0 : t_hi - 1;
@@ -486,20 +496,22 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
                                                           //  the previous round's barrier after reading it)
             // ---- (2) weight-gradient outer products, feature on lane.  One wave per SIMD: nothing else hides the latency of the
             //      image reads, so the raw operands of block sb + 1 are requested before the MFMAs of block sb issue
-            f32x4 gx[2][DB], ax[2][NR], wv[2];
+            f32x4 gx[2][GCOL ? DB : 1], ax[2][NR], wv[2];
             auto request = [&](int buf, int sb) __attribute__((always_inline)) {
                 const int t0 = t_lo + 4 * it + sb;
                 const bool bvalid = t0 < t_hi;
                 const int t16 = __builtin_amdgcn_readfirstlane(bvalid ? t0 : t_hi - 1);
                 f32x4 w4 = *reinterpret_cast<const f32x4*>(da.wts + t16 * 16 + 4 * qq);
                 wv[buf] = bvalid ? w4 * gs : zero4;
+                if constexpr (GCOL) {
 #pragma unroll
-                for (int b = 0; b < DB; ++b) gx[buf][b] = get_F(t16, W::pXi + b * 256);
+                    for (int b = 0; b < DB; ++b) gx[buf][b] = get_F(t16, W::pXi + b * 256);
+                }
 #pragma unroll
                 for (int li = 0; li < NR; ++li) {
-                    const int i = sub + 4 * li;
+                    const int i0 = sub + 4 * li, i = i0 < NRI ? i0 : NRI - 1;
                     const int ofs = (i < DB) ? W::pX + i * 256
-                                  : ((i < DB + HB) ? W::pR1 + (i - DB) * 256 : W::pR2 + ((i < NRI ? i : NRI - 1) - DB - HB) * 256);
+                                  : ((i < DB + HB) ? W::pR1 + (i - DB) * 256 : W::pR2 + (i - DB - HB) * 256);
                     ax[buf][li] = get_F(t16, ofs);
                 }
             };
@@ -510,11 +522,15 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
                 if (sb < 3) request(cur ^ 1, sb + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const float* ex = exch + sb * (EXT * 256);
-                f32x4 ct[NC];
+                f32x4 ct[NC];                              // local column c <-> global column C0 + c
+                if constexpr (GCOL) {
 #pragma unroll
-                for (int b = 0; b < DB; ++b) ct[b] = wv[cur] * gx[cur][b];
+                    for (int b = 0; b < DB; ++b) ct[b] = wv[cur] * gx[cur][b];
+                }
+                if constexpr (PH1) {
 #pragma unroll
-                for (int m = 0; m < 2 * HB; ++m) ct[DB + m] = tile_get(ex + m * 256, lane);
+                    for (int m = 0; m < 2 * HB; ++m) ct[DB - C0 + m] = tile_get(ex + m * 256, lane);
+                }
                 if (sub == 0) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) bs[c] += hsum4(ct[c]);
@@ -525,10 +541,10 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
                     if (i < NRI) {
                         const f32x4 raw = ax[cur][li];
                         const f32x4 A = (i < DB) ? raw : raw * raw;             // h = r^2
-                        const int ncol = (i < DB) ? NC : ((i < DB + HB) ? DB + HB : DB);   // h2 rows meet G only, h1 rows G and dz2
+                        const int ncol = (i < DB) ? DB + 2 * HB : ((i < DB + HB) ? DB + HB : DB);   // h2 rows meet G only, h1 rows G and dz2
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
-                            if (c < ncol) {
+                            if (C0 + c < ncol) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) acc[li][c] = mfma16(A[r], ct[c][r], acc[li][c]);
                             }
@@ -544,15 +560,16 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
             if (i < NRI) {
                 const int rbase = (i < DB) ? 16 * i : ((i < DB + HB) ? D + 16 * (i - DB) : D + H + 16 * (i - DB - HB));
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
+                for (int cl = 0; cl < NC; ++cl) {
+                    const int c = C0 + cl;
                     const bool used = (i < DB) || (i < DB + HB ? c < DB + HB : c < DB);
                     if (used) {
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const int row = rbase + 4 * qq + rr;
-                            if (c < DB) gp[W::gW3 + row * D + 16 * c + col] = acc[li][c][rr];                          // . G
-                            else if (c < DB + HB) gp[W::gW2 + row * H + 16 * (c - DB) + col] = acc[li][c][rr];          // . dz2
-                            else gp[W::gW1 + row * H + 16 * (c - DB - HB) + col] = acc[li][c][rr];                      // . dz1 (x rows only)
+                            if (c < DB) gp[W::gW3 + row * D + 16 * c + col] = acc[li][cl][rr];                          // . G
+                            else if (c < DB + HB) gp[W::gW2 + row * H + 16 * (c - DB) + col] = acc[li][cl][rr];          // . dz2
+                            else gp[W::gW1 + row * H + 16 * (c - DB - HB) + col] = acc[li][cl][rr];                      // . dz1 (x rows only)
                         }
                     }
                 }
@@ -560,8 +577,9 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
         }
         if (sub == 0) {                                   // bias gradients: column sums over the lane's samples, then over qq
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                float v = bs[c];
+            for (int cl = 0; cl < NC; ++cl) {
+                const int c = C0 + cl;
+                float v = bs[cl];
                 v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
                 if (qq == 0) {
                     if (c < DB) gp[W::gb3 + 16 * c + col] = v;
@@ -580,8 +598,8 @@ struct DnetInstance {
     int set_floats, vec_floats, shared_floats;
     hipError_t (*launch_fwd)(const DnetArgs&, int grid, hipStream_t);
     int image_block_floats, partial_floats, bwd_lds_bytes;
-    int bwd_acc_tiles;         // accumulator tiles per wave of hjbd_bwd_kernel (ceil((DB+2HB)/4) * (DB+2HB)): beyond ~48 the
-                               // 512-entry register file spills heavily and the library-GEMM formulation is used instead
+    int bwd_passes;            // launches of hjbd_bwd_kernel: 1, 2 (columns split so that a wave's accumulator tiles fit its
+                               // registers) or 0 (not covered: the library-GEMM formulation is used instead)
     hipError_t (*launch_bwd)(const DnetArgs&, int grid, hipStream_t);
 };
 
@@ -599,17 +617,33 @@ struct DnetLaunch {
         hipLaunchKernelGGL((hjbd_fwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
         return hipGetLastError();
     }
-    static hipError_t bwd(const DnetArgs& a, int grid, hipStream_t s) {
+    static constexpr int NALL = W::DB + 2 * W::HB;
+    static constexpr int kTiles0 = cdiv(NALL, 4) * NALL;                                      // accumulator tiles per wave, one launch
+    static constexpr int kTiles1 = cdiv(NALL, 4) * W::DB, kTiles2 = cdiv(W::DB + W::HB, 4) * 2 * W::HB;   // ... split by columns
+    static constexpr int kMaxTiles = 48;                  // beyond this the 512-entry register file spills heavily
+    static constexpr int kPasses = kTiles0 <= kMaxTiles ? 1 : ((kTiles1 <= kMaxTiles && kTiles2 <= kMaxTiles) ? 2 : 0);
+    template <int PASS>
+    static hipError_t bwd_pass(const DnetArgs& a, int grid, hipStream_t s) {
         const int bytes = W::bwd_lds_floats * 4;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_bwd_kernel<D, H>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_bwd_kernel<D, H, PASS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjbd_bwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
+        hipLaunchKernelGGL((hjbd_bwd_kernel<D, H, PASS>), dim3(grid), dim3(256), bytes, s, a);
         return hipGetLastError();
+    }
+    static hipError_t bwd(const DnetArgs& a, int grid, hipStream_t s) {
+        if constexpr (kPasses == 1) {
+            return bwd_pass<0>(a, grid, s);
+        } else if constexpr (kPasses == 2) {
+            hipError_t e = bwd_pass<1>(a, grid, s);
+            return e != hipSuccess ? e : bwd_pass<2>(a, grid, s);
+        } else {
+            return hipErrorNotSupported;
+        }
     }
     static DnetInstance instance() {
         return DnetInstance{D, H, W::lds_floats * 4, W::set_floats, W::vec_floats, W::oSets, &fwd,
-                            W::PBI, W::PP, W::bwd_lds_floats * 4, cdiv(W::DB + 2 * W::HB, 4) * (W::DB + 2 * W::HB), &bwd};
+                            W::PBI, W::PP, W::bwd_lds_floats * 4, kPasses, &bwd};
     }
 };
 

@@ -385,7 +385,7 @@ int make_dnet_plan(const psp_dnet_config* c, DnetPlan* p) {
     p->slices = S;
     const long long items = (long long)b.N * S;
     p->bwd_grid = (int)(items < cus ? items : cus);
-    p->bwd_ok = (p->inst.bwd_lds_bytes <= kMaxLds && p->inst.bwd_acc_tiles <= 48) ? 1 : 0;   // else: too many accumulator tiles per wave
+    p->bwd_ok = (p->inst.bwd_lds_bytes <= kMaxLds && p->inst.bwd_passes > 0) ? 1 : 0;   // else: too many accumulator tiles per wave
     return 0;
 }
 }  // namespace

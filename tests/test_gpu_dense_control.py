@@ -151,7 +151,8 @@ def test_dense_shape_sweep_matches_oracle(mode, kind, d, H, K, dt, T, adaptive):
     assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=min(1e-4, max(2e-5, 4 * 6e-8 * cond)))
 
 
-@pytest.mark.parametrize("name", ["llgc_d12_outer_moment", "lqgc_d6_densenet_variance", "lqgc_d2_outer"])
+@pytest.mark.parametrize("name", ["llgc_d12_outer_moment", "lqgc_d6_densenet_variance", "lqgc_d2_outer",
+                                  "llgc_d100_densenet64_logvar"])          # the last one runs the two-launch column split
 def test_kernel_backward_agrees_with_the_gemm_formulation(name, monkeypatch):
     """hjbd_bwd_kernel (hand-written: adjoint panels + weight-gradient outer products per (step, slice)) against the
     library-GEMM formulation of the same gradient (PSP_DENSE_BWD=gemm), same rollout, same noise."""
