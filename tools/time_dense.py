@@ -51,6 +51,6 @@ for backend, L in (("native", 12), ("torch", 3)):
             plan.iteration(l, losses)
         torch.cuda.synchronize()
         ev = plan.events[-1]
-        extra = "  (forward kernels %.2f ms, gradient GEMMs %.2f ms)" % (ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3]))
+        extra = "  (forward kernels %.2f ms, gradient %.2f ms: %s)" % (ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3]), "hjbd_bwd_kernel" if plan.kernel_bwd else "library GEMMs")
     print("%s  %s d=%d K=%d N=%d H=%d: %.2f ms per iteration = %.3g trajectory-timesteps/s%s"
           % (backend.ljust(6), mode, d, K, m.N, H, per * 1e3, K * m.N / per, extra), flush=True)
