@@ -456,35 +456,45 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) bs[c] = 0.f;
 
-#pragma unroll 1
-        for (int it = 0; it < R; ++it) {
-            float* exch = bufs + (it & 1) * 4 * (EXT * 256);
-            if constexpr (PH1) {   // ---- (1) adjoint panels of the own block, T layout
-                const int t0 = t_lo + 4 * it + sub;
+        // phase-1 operands of the own block (T layout), requested one round ahead: one wave per SIMD, nothing else hides them
+        f32x4 pG[PH1 ? DB : 1], pR2[PH1 ? HB : 1], pR1[PH1 ? HB : 1];
+        float pwk = 0.f;
+        auto request1 = [&](int it2) __attribute__((always_inline)) {
+            if constexpr (PH1) {
+                const int t0 = t_lo + 4 * it2 + sub;
                 const bool bvalid = t0 < t_hi;
                 const int t16 = bvalid ? t0 : t_hi - 1;
                 const float* pb = img_n + (size_t)t16 * (size_t)W::PBI + lane;
                 const int k = t16 * 16 + j;
-                const float wk = (bvalid && k < a.K_local) ? da.wts[k] * gs : 0.f;
-                f32x4 G[DB];
+                pwk = (bvalid && k < a.K_local) ? da.wts[k] * gs : 0.f;
 #pragma unroll
                 for (int b = 0; b < DB; ++b)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) G[b][r] = wk * pb[W::pXi + (4 * b + r) * 64];
+                    for (int r = 0; r < 4; ++r) pG[b][r] = pb[W::pXi + (4 * b + r) * 64];
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pR2[m][r] = pb[W::pR2 + (4 * m + r) * 64]; pR1[m][r] = pb[W::pR1 + (4 * m + r) * 64]; }
+            }
+        };
+        request1(0);
+#pragma unroll 1
+        for (int it = 0; it < R; ++it) {
+            float* exch = bufs + (it & 1) * 4 * (EXT * 256);
+            if constexpr (PH1) {   // ---- (1) adjoint panels of the own block, T layout (operands requested a round ahead)
+                f32x4 G[DB];
+#pragma unroll
+                for (int b = 0; b < DB; ++b) G[b] = pwk * pG[b];
                 f32x4 dz2[HB], dz1[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) { dz2[m] = zero4; dz1[m] = zero4; }
                 gemm_T<HB, KP, DB>(dz2, lds + W::bW3h2, G, lane);                 // dh2 = W3h2 G
 #pragma unroll
-                for (int m = 0; m < HB; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dz2[m][r] *= 2.0f * pb[W::pR2 + (4 * m + r) * 64];
+                for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (2.0f * pR2[m]);
                 gemm_T<HB, KP, DB>(dz1, lds + W::bW3h1, G, lane);                 // dh1 = W3h1 G + W2h dz2
                 gemm_T<HB, 4 * HB, HB>(dz1, lds + W::bW2h, dz2, lane);
 #pragma unroll
-                for (int m = 0; m < HB; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dz1[m][r] *= 2.0f * pb[W::pR1 + (4 * m + r) * 64];
+                for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (2.0f * pR1[m]);
                 float* my_ex = exch + sub * (EXT * 256);
 #pragma unroll
                 for (int m = 0; m < HB; ++m) {
@@ -494,6 +504,7 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
             }
             __syncthreads();                              // (the buffer written two rounds ago is free: every wave has passed
                                                           //  the previous round's barrier after reading it)
+            request1(it + 1 < R ? it + 1 : it);
             // ---- (2) weight-gradient outer products, feature on lane.  One wave per SIMD: nothing else hides the latency of the
             //      image reads, so the raw operands of block sb + 1 are requested before the MFMAs of block sb issue
             f32x4 gx[2][GCOL ? DB : 1], ax[2][NR], wv[2];
