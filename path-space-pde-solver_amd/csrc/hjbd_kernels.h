@@ -50,7 +50,11 @@ struct DGeo {
     static_assert(H % 16 == 0 && D % 16 == 0, "DenseNet-control instances are whole blocks (real sizes are runtime values)");
     // one weight set, k-step-major [ks][blocks][64]:  [W1 | W2x] over x (2 HB blocks), W2h over h1, W3x over x, [W3h1 ; W3h2] over h
     static constexpr int tW12 = 0, tW2h = tW12 + KP * 2 * HB * 64, tW3x = tW2h + 4 * HB * HB * 64,
-                         tW3h1 = tW3x + KP * DB * 64, tW3h2 = tW3h1 + 4 * HB * DB * 64, set_floats = tW3h2 + 4 * HB * DB * 64;
+                         tW3h1 = tW3x + KP * DB * 64, tW3h2 = tW3h1 + 4 * HB * DB * 64,
+                         // d <= 128: every product over the X image in ONE pass -- [W1 | W2x | W3x | dt A] as NXB output blocks
+                         // per k-step (the drift matrix is copied into every step's set: 45 KB a step at d = 112)
+                         MERGE = (D <= 128) ? 1 : 0, NXB = 2 * HB + 2 * DB, tXall = tW3h2 + 4 * HB * DB * 64,
+                         set_floats = tXall + MERGE * KP * NXB * 64;
     // per-step bias vectors (time column folded in), T-layout order [block][q][r]
     static constexpr int v1 = 0, v2 = v1 + HB * 16, v3 = v2 + HB * 16, vec_floats = v3 + DB * 16;
     // region: [dt A][B][sets ...][vectors of step 0 .. N-1]
@@ -113,6 +117,18 @@ __global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a) {
             return (row < d && col < hh) ? Pp[oW3 + (long long)(di + col) * d + row] : 0.f; });
         table_fill(Ts + W::tW3h2, W::DB, 4 * W::HB, gtid, gs, [&](int row, int col) {
             return (row < d && col < hh) ? Pp[oW3 + (long long)(di + hh + col) * d + row] : 0.f; });
+        if (W::MERGE) {
+            const bool denseA = h.drift_kind == DRIFT_DENSE;
+            const float dt = h.dt;
+            const float* __restrict__ A = h.drift;
+            table_fill(Ts + W::tXall, W::NXB, W::KP, gtid, gs, [&](int row, int col) {
+                const int blk = row >> 4, o = row & 15;
+                if (blk < W::HB) { const int u = 16 * blk + o; return (u < hh && col < d) ? Pp[oW1 + (long long)(to + col) * hh + u] : 0.f; }
+                if (blk < 2 * W::HB) { const int u = 16 * (blk - W::HB) + o; return (u < hh && col < d) ? Pp[oW2 + (long long)(to + col) * hh + u] : 0.f; }
+                if (blk < 2 * W::HB + W::DB) { const int f = 16 * (blk - 2 * W::HB) + o; return (f < d && col < d) ? Pp[oW3 + (long long)(to + col) * d + f] : 0.f; }
+                const int f = 16 * (blk - 2 * W::HB - W::DB) + o;
+                return (denseA && f < D && col < D) ? dt * A[f * D + col] : 0.f; });
+        }
     }
     // per-step bias vectors b + t_n W[0, :]  (time input = column 0 of every layer's input block; solver.py:355)
     float* V = T + W::oSets + (long long)nsets * W::set_floats;
@@ -208,17 +224,33 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                         if (f < dr) px[f] = X[b][r];
                     }
             }
-            // ---- z1 and the x-part of z2 in one pass over the image (function_space.py:133-140)
+            // ---- z1 and the x-part of z2 in one pass over the image (function_space.py:133-140); for d <= 128 the x-part of Z
+            //      and the drift product ride in the same pass (one operand ring instead of four short ones)
             f32x4 z12[2 * HB];
-#pragma unroll
-            for (int m = 0; m < HB; ++m) { z12[m] = Vn[(W::v1 / 16 + m) * 4]; z12[HB + m] = Vn[(W::v2 / 16 + m) * 4]; }
-            gemm_img<2 * HB, KP>(z12, Ts + W::tW12, imgX, lane);
-            // ---- drift part of X_{n+1} while the image still holds X_n (solver.py:471)
+            f32x4 Zx[W::MERGE ? DB : 1];
             f32x4 Xn[DB];
+            if constexpr (W::MERGE) {
+                f32x4 xa[W::NXB];
 #pragma unroll
-            for (int b = 0; b < DB; ++b) Xn[b] = X[b];
+                for (int m = 0; m < HB; ++m) { xa[m] = Vn[(W::v1 / 16 + m) * 4]; xa[HB + m] = Vn[(W::v2 / 16 + m) * 4]; }
+#pragma unroll
+                for (int b = 0; b < DB; ++b) { xa[2 * HB + b] = Vn[(W::v3 / 16 + b) * 4]; xa[2 * HB + DB + b] = X[b]; }
+                if (a.drift_kind == DRIFT_DENSE) gemm_img<W::NXB, KP, W::NXB>(xa, Ts + W::tXall, imgX, lane);
+                else gemm_img<2 * HB + DB, KP, W::NXB>(reinterpret_cast<f32x4 (&)[2 * HB + DB]>(xa), Ts + W::tXall, imgX, lane);
+#pragma unroll
+                for (int m = 0; m < 2 * HB; ++m) z12[m] = xa[m];
+#pragma unroll
+                for (int b = 0; b < DB; ++b) { Zx[b] = xa[2 * HB + b]; Xn[b] = xa[2 * HB + DB + b]; }
+            } else {
+#pragma unroll
+                for (int m = 0; m < HB; ++m) { z12[m] = Vn[(W::v1 / 16 + m) * 4]; z12[HB + m] = Vn[(W::v2 / 16 + m) * 4]; }
+                gemm_img<2 * HB, KP>(z12, Ts + W::tW12, imgX, lane);
+#pragma unroll
+                for (int b = 0; b < DB; ++b) Xn[b] = X[b];
+                if (a.drift_kind == DRIFT_DENSE) gemm_img<DB, KP>(Xn, T + W::oA, imgX, lane);
+            }
+            // ---- drift part of X_{n+1} (solver.py:471): the dense product is done above
             if (a.drift_kind == DRIFT_DENSE) {
-                gemm_img<DB, KP>(Xn, T + W::oA, imgX, lane);
             } else if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Xn[b] += dt * (vdr[b * 4] * X[b]);
@@ -268,9 +300,14 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
             auto z_group = [&](auto nbc, int g) __attribute__((always_inline)) {
                 constexpr int NB = decltype(nbc)::value;
                 f32x4 Zg[NB];
+                if constexpr (W::MERGE) {
 #pragma unroll
-                for (int m = 0; m < NB; ++m) Zg[m] = Vn[(W::v3 / 16 + 4 * g + m) * 4];
-                gemm_img<NB, KP, DB>(Zg, Ts + W::tW3x + 4 * g * 64, imgX, lane);
+                    for (int m = 0; m < NB; ++m) Zg[m] = Zx[4 * g + m];
+                } else {
+#pragma unroll
+                    for (int m = 0; m < NB; ++m) Zg[m] = Vn[(W::v3 / 16 + 4 * g + m) * 4];
+                    gemm_img<NB, KP, DB>(Zg, Ts + W::tW3x + 4 * g * 64, imgX, lane);
+                }
                 gemm_regs<NB, 4 * HB, HB, DB>(Zg, Ts + W::tW3h1 + 4 * g * 64, h1, lane);
                 gemm_regs<NB, 4 * HB, HB, DB>(Zg, Ts + W::tW3h2 + 4 * g * 64, h2, lane);
 #pragma unroll
