@@ -6,21 +6,35 @@
 One "step" = one full training iteration of Solver.train (forward SDE rollout over N_t time
 steps, log-variance loss, analytic backward, Adam) on synthetic d-dimensional HJB data with
 random-init weights.  Metric = trajectory-timesteps/s = K_traj * N_t * steps / wall time,
-inputs resident in HBM, on-device Philox noise.  For --gpus N > 1 the script is
-launched by torch.distributed.run (one rank per GPU, RCCL); every rank keeps the same
-per-GPU trajectory count (weak scaling) and the value is the whole-job aggregate.
+inputs resident in HBM, on-device Philox noise.
+
+--gpus N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, WORLD_SIZE set), or
+bench.py does it itself: with WORLD_SIZE unset the parent process -- which never touches the GPU --
+starts that same command as a child and relays its exit code; rank 0 prints the JSON line.
+Weak-scaling workloads keep the per-GPU trajectory count, strong-scaling ones (K_global in the
+workload) split a fixed global batch; `value` is always the whole-job aggregate.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- dominant kernel: algorithmic flops per launch / mean launch time (HIP events
-                  recorded on the launch stream inside the timed region) against the fp32
-                  MFMA peak of MI355X (157.3 TFLOP/s).
-  cpu_baseline -- the CPU oracle (a port of the reference algorithm, oracle/) timed on the
-                  host cores of this box on a bounded sample of the same workload; reported
-                  baseline, not the optimisation target.  Rank 0, N=1 only.
+  roofline     -- dominant kernel, from HIP events recorded on the launch stream inside the timed
+                  region.  `frac` = max(MFMA term, HBM term).  MFMA term = MINIMAL algorithmic flops
+                  (m = 2 dense d x d products per step: A x and B (c dt + xi sqrt dt) -- the
+                  reference's separate B c and B xi products are one product algebraically) over
+                  the kernel time against the fp32 MFMA peak (157.3 TFLOP/s); `frac_issued` counts
+                  the MFMA instructions the kernel really issues (incl. zero padding to 16-blocks);
+                  `frac_survey_m3` is SURVEY 8d's convention (m = 3), kept as a labelled extra.
+                  bf16 workloads are priced against the flop-weighted blend of the bf16 and fp32
+                  peaks, so no line can exceed 1.
+  collectives  -- N > 1: mean HIP-event time of the two all-reduces per iteration.
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm, oracle/) timed on the host
+                  cores of this box on bounded samples (configs[0], configs[1] and a K = 4096 cut
+                  of the workload; all cores and 1 thread).  Rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,19 +51,30 @@ WORKLOADS = {
     "hjb_llgc_d100_K4096_N50_h64": dict(d=100, H=64, K=4096, T=0.5, dt=0.01, off_diag=0.01),
     "hjb_llgc_d100_K8192_N50_h64": dict(d=100, H=64, K=8192, T=0.5, dt=0.01, off_diag=0.01),
     "hjb_llgc_d100_K16384_N50_h64": dict(d=100, H=64, K=16384, T=0.5, dt=0.01, off_diag=0.01),
-    # structured variant A=-I, B=I (SURVEY 8d: reported separately)
     # opt-in mode: control-net products of the forward rollout on bf16 MFMA (SURVEY 8d "bf16-MLP runs"); NOT the headline
     "hjb_llgc_d100_K65536_N100_h64_bf16mlp": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.01, mlp="bf16"),
     # the reference's constructor default: time_approx='outer', one DenseNet(d -> d, arch [30, 30]) per time step (solver.py:88)
     # (T = 0.5: over T = 1 the reference ALGORITHM itself blows up at this size -- relu^2 nets at their default init are
     #  expansive, single paths overflow; the CPU oracle shows the same [316, 4.0e5, nan] at K = 8192, tools/check_outer_d100.py)
     "hjb_llgc_d100_K65536_N50_outer_h30": dict(d=100, H=30, K=65536, T=0.5, dt=0.01, off_diag=0.01, outer=True),
+    # structured variant A=-I, B=I (SURVEY 8d: reported separately)
     "hjb_llgc_d100_K65536_N100_h64_diag": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.0),
-    # BASELINE.json configs[3]: d=200, K=262144 over 8 GPUs = 32768 per GPU, N=100 (wide kernel family)
+    # BASELINE.json configs[3]: d=200, K=262144 over 8 GPUs = 32768 per GPU, N=100 (wide kernel family) -- weak form
     "hjb_llgc_d200_K32768_N100_h64": dict(d=200, H=64, K=32768, T=1.0, dt=0.01, off_diag=0.1 / 200 ** 0.5),
-    # BASELINE.json configs[4] shape: d=500, N=200; K per GPU reduced from 131072 to 16384 (path store 15 GB)
+    # configs[3] as written: the GLOBAL batch K=262144 is fixed and split over the ranks (strong scaling); on one GPU the
+    # whole batch runs with its 57 GB path store resident
+    "hjb_llgc_d200_Kglobal262144_N100_h64": dict(d=200, H=64, K_global=262144, T=1.0, dt=0.01, off_diag=0.1 / 200 ** 0.5),
+    # BASELINE.json configs[4] shape: d=500, N=200 -- K per GPU cut to 16384 (path store 15 GB, no recompute)
     "hjb_llgc_d500_K16384_N200_h64": dict(d=500, H=64, K=16384, T=2.0, dt=0.01, off_diag=0.1 / 500 ** 0.5),
     "hjb_llgc_d500_K16384_N200_h64_diag": dict(d=500, H=64, K=16384, T=2.0, dt=0.01, off_diag=0.0),
+    # configs[4] at its per-GPU share of the 8-GPU job (K = 1048576 / 8) and at its full size on ONE GPU: the path store
+    # (118 GB / 946 GB) is bounded by the K-chunked two-pass plan (plan_native.py, path_budget_bytes)
+    "hjb_llgc_d500_K131072_N200_h64": dict(d=500, H=64, K=131072, T=2.0, dt=0.01, off_diag=0.1 / 500 ** 0.5,
+                                           path_budget_gb=32),
+    "hjb_llgc_d500_K1048576_N200_h64": dict(d=500, H=64, K=1048576, T=2.0, dt=0.01, off_diag=0.1 / 500 ** 0.5,
+                                            path_budget_gb=32),
+    # the headline shape forced through the chunked plan (recompute overhead measured against the resident-store run)
+    "hjb_llgc_d100_K65536_N100_h64_chunk4": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.01, chunks=4),
 }
 GENERAL_WORKLOADS = {
     # BASELINE.json configs[2] shape in fp32: d=100 diffusion loss, K=65536, N=100, V = DenseNet(101 -> 1, [64, 64])
@@ -59,52 +84,235 @@ GENERAL_WORKLOADS = {
     "diffusion_dw_d100_K65536_N100_h64_bf16": dict(d=100, H=64, K=65536, N=100, T=0.3, dt=0.001, loss="diffusion", mlp="bf16"),
     "diffusion_dw_d100_K65536_N100_h64_bf16fwd": dict(d=100, H=64, K=65536, N=100, T=0.3, dt=0.001, loss="diffusion", mlp="bf16_fwd"),
 }
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
+# MI355X_MICROARCH.md, chip-level parameters
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+MFMA_F32_16x16x4_FLOP = 2 * 16 * 16 * 4          # one v_mfma_f32_16x16x4_f32
+MFMA_BF16_16x16x32_FLOP = 2 * 16 * 16 * 32       # one v_mfma_f32_16x16x32_bf16
 
 
-def alg_flops_dense_control(d, H, dense):
-    """Same accounting for a DenseNet(d -> d, [H, H]) control: forward products W1, W2 = [W2x; W2h], W3 = [W3x; W3h1; W3h2];
-    backward = weight gradients of all of them + the two adjoint products through W3h, W2h (no input gradient)."""
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def alg_flops_dense_control(d, H, dense, m=2):
+    """DenseNet(d -> d, [H, H]) control: forward products W1, W2 = [W2x; W2h], W3 = [W3x; W3h1; W3h2]; backward = weight
+    gradients of all of them + the two adjoint products through W3h, W2h (no input gradient)."""
     f_fwd = 2 * (d * H + (d + H) * H + (d + 2 * H) * d)
     f_bwd = f_fwd + 2 * (2 * H * d + H * H)
-    f_sde = 2 * d * d * (3 if dense else 0)
-    return dict(fwd_kernel=f_fwd + f_sde + 12 * d, bwd_kernel=f_bwd, total=f_fwd + f_bwd + f_sde + 12 * d)
+    f_sde = 2 * d * d * (m if dense else 0)
+    return dict(fwd_kernel=f_fwd + f_sde + 12 * d, bwd_kernel=f_bwd, total=f_fwd + f_bwd + f_sde + 12 * d,
+                mlp_fwd=f_fwd, sde=f_sde + 12 * d)
 
 
-def alg_flops_per_traj_step(d, H, dense):
-    """algorithmic flops per trajectory-timestep of the training iteration."""
+def alg_flops_per_traj_step(d, H, dense, m=2):
+    """Algorithmic flops per trajectory-timestep of the training iteration.  SURVEY.md 8(d) counts m = 3 dense d x d
+    products (A x, B c, B xi); B c dt + B xi sqrt(dt) = B (c dt + xi sqrt(dt)) is ONE product, so the minimum is m = 2."""
     f_fwd = 2 * ((d + 1) * H + H * H + H * d)
     f_bwd = f_fwd + 2 * (H * H + H * d)
-    f_sde = 2 * d * d * (3 if dense else 0)
-    return dict(fwd_kernel=f_fwd + f_sde + 12 * d, bwd_kernel=f_bwd, total=f_fwd + f_bwd + f_sde + 12 * d)
+    f_sde = 2 * d * d * (m if dense else 0)
+    return dict(fwd_kernel=f_fwd + f_sde + 12 * d, bwd_kernel=f_bwd, total=f_fwd + f_bwd + f_sde + 12 * d,
+                mlp_fwd=f_fwd, sde=f_sde + 12 * d)
 
 
-def cpu_baseline(w, seconds_budget=20.0):
-    """Times oracle/pathspace_oracle.py (torch-CPU port of the reference iteration, including its
-    duplicate control evaluation and dense sigma products) on K=4096 trajectories of the workload."""
-    from oracle import pathspace_oracle as orc
-    Kc = min(4096, w["K"])
-    prob = orc.make_problem("LLGC", d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42)
-    # a 1-GPU box exposes a 16-core CPU share; more torch threads than that only adds contention
-    threads = min(16, os.cpu_count() or 1)
+def issued_mfma_per_tile_step(d_pad, H_pad, dense, family, bf16_mlp=False):
+    """MFMA instructions one 16-trajectory tile issues per time step (padded kernel instance).  Counted from the kernels'
+    loop bounds and confirmed by SQ_INSTS_MFMA at the headline shape (626 forward / 452 backward per tile-step,
+    profiles/r1_pmc_summary.md).  Returns (fwd_f32, fwd_bf16, bwd_f32)."""
+    DB, HB = _cdiv(d_pad, 16), _cdiv(H_pad, 16)
+    ks_d = _cdiv(d_pad + 1, 4) if family == 2 else _cdiv(d_pad, 4)     # wide family: the time row rides in the W1 product
+    ks_h = _cdiv(H_pad, 4)
+    net = ks_d * HB + ks_h * HB + ks_h * DB
+    sde = 2 * _cdiv(d_pad, 4) * DB if dense else 0
+    bwd = 4 * (DB * HB + HB * HB + HB * DB) + _cdiv(d_pad, 4) * HB + ks_h * HB
+    if bf16_mlp:                                                       # 16x16x32: one k-step spans 32 features
+        net_bf = _cdiv(d_pad, 32) * HB + _cdiv(H_pad, 32) * HB + _cdiv(H_pad, 32) * DB
+        return sde, net_bf, bwd
+    return net + sde, 0, bwd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks_if_needed(args):
+    """--gpus N > 1 without a launcher: start the N ranks as CHILD processes (torch.distributed.run) and relay their exit
+    code.  This runs before anything touches the GPU: the parent only counts devices (no HIP context) and never re-execs."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    rehearsal = os.environ.get("PSP_BENCH_REHEARSAL") == "1"
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not rehearsal:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this box (PSP_BENCH_REHEARSAL=1 walks the "
+                         "N > 1 code path with all ranks on cuda:0 over gloo; its numbers mean nothing)" % (args.gpus, n_dev))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def init_ranks(args):
+    """(dist or None, rank, world, device).  One process per GPU; RCCL (backend 'nccl') unless rehearsing."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    # PSP_BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo -- a way to walk the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing
+    rehearsal = os.environ.get("PSP_BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    return dist, rank, world, dev, rehearsal
+
+
+def timed_region(dist, dev, fn, steps, first):
+    """barrier + synchronize on both sides, MAX over ranks."""
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for l in range(first, first + steps):
+        fn(l)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def check_c_abi_allreduce(psp, dist, rank, world, dev, rehearsal):
+    """N > 1, outside the timed region: the C-ABI collective (psp_comm_* / psp_allreduce, include/psp.h) against
+    torch.distributed's all-reduce on the same buffers.  Reported, never fatal: the timed path uses torch.distributed."""
+    if dist is None or rehearsal:
+        return None
+    import ctypes as C
+    nat = psp.native
+    try:
+        lib = nat.load()
+        ident = torch.zeros(nat.COMM_ID_BYTES, dtype=torch.uint8)
+        # every rank binds RCCL through the C ABI first; the ranks then AGREE whether to go on, so that a rank that cannot
+        # never leaves the others waiting inside the collective communicator set-up
+        buf = (C.c_ubyte * nat.COMM_ID_BYTES)()
+        rc = lib.psp_comm_unique_id(buf)
+        flag = torch.tensor([1.0 if rc == 0 else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) != 1.0:
+            return {"ok": False, "error": "psp_comm_unique_id failed on some rank: %s" % nat.last_error()}
+        if rank == 0:
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = ident.to(dev)
+        dist.broadcast(ident, 0)
+        raw = (C.c_ubyte * nat.COMM_ID_BYTES)(*ident.cpu().tolist())
+        comm = C.c_void_p()
+        nat.check(lib.psp_comm_init(C.byref(comm), world, rank, raw), "psp_comm_init")
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        a = torch.randn(17188, generator=g, device=dev)
+        s = torch.randn(2, generator=g, device=dev, dtype=torch.float64)
+        a_ref, s_ref = a.clone(), s.clone()
+        dist.all_reduce(a_ref)
+        dist.all_reduce(s_ref)
+        st = nat.stream_ptr(dev)
+        nat.check(lib.psp_allreduce(nat.ptr(s), 2, nat.DT_F64, comm, st), "psp_allreduce f64")
+        nat.check(lib.psp_allreduce(nat.ptr(a), a.numel(), nat.DT_F32, comm, st), "psp_allreduce f32")
+        scratch = torch.zeros(17188, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 20
+        ev[0].record()
+        for _ in range(reps):
+            nat.check(lib.psp_allreduce(nat.ptr(scratch), scratch.numel(), nat.DT_F32, comm, st), "psp_allreduce f32")
+        ev[1].record()
+        torch.cuda.synchronize()
+        err = float((a - a_ref).abs().max())
+        ok = bool(torch.allclose(s, s_ref, rtol=1e-12, atol=0.0)) and err <= 1e-5
+        nat.check(lib.psp_comm_destroy(comm), "psp_comm_destroy")
+        return {"ok": ok, "max_abs_diff_vs_torch_distributed": err,
+                "grad_sized_allreduce_ms": ev[0].elapsed_time(ev[1]) / reps}
+    except Exception as e:                                  # noqa: BLE001 -- a diagnostic must not take the bench down
+        return {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
+
+
+def collective_summary(sharding, steps):
+    """Mean HIP-event time per iteration of the all-reduces recorded by sharding.allreduce_sum_ (N > 1 only)."""
+    evs = sharding.coll_events or []
+    if not evs:
+        return None
+    by_size = {}
+    for e0, e1, nbytes in evs:
+        by_size.setdefault(nbytes, []).append(e0.elapsed_time(e1))
+    items = [{"bytes": b, "calls_per_step": len(v) / float(steps), "mean_ms": sum(v) / len(v), "max_ms": max(v)}
+             for b, v in sorted(by_size.items())]
+    return {"per_step_ms": sum(sum(v) for v in by_size.values()) / float(steps), "all_reduces": items,
+            "backend": "rccl" if os.environ.get("PSP_BENCH_REHEARSAL") != "1" else "gloo (rehearsal)"}
+
+
+def _time_oracle(orc, prob, cfg, z, y0, N, threads, budget_s, max_iters):
     torch.set_num_threads(threads)
-    cfg = orc.HJBConfig(K=Kc, delta_t=w["dt"], lr=1e-3, L=1, seed=42, adaptive_forward_process=True,
-                        detach_forward=True)
-    z = orc.TanhMLP(w["d"] + 1, w["d"], 1e-3, seed=123, widths=(w["H"], w["H"]))
-    _, y0, N = orc.hjb_build(prob, cfg)
     orc.hjb_train(prob, cfg, step_models=(z, y0, N))          # warm-up iteration
     iters, t0 = 0, time.time()
     while True:
         orc.hjb_train(prob, cfg, step_models=(z, y0, N))
         iters += 1
         el = time.time() - t0
-        if el > seconds_budget or iters >= 24:        # ~13 s of CPU work on the 16-core share of a GPU box
+        if el > budget_s or iters >= max_iters:
             break
-    rate = Kc * N * iters / el
-    return dict(value=rate, unit="trajectory-timesteps/s", cores=threads, kind="port",
-                sample="oracle hjb_train, K=%d of %d trajectories, N=%d, %d iterations, %.1f s, torch %s"
-                       % (Kc, w["K"], N, iters, el, torch.__version__))
+    return cfg.K * N * iters / el, iters, el
+
+
+def cpu_baseline(w):
+    """Times oracle/pathspace_oracle.py (torch-CPU port of the reference iteration, including its duplicate control
+    evaluation and dense sigma products) on the GPU box's host cores: SURVEY 8d's legs -- configs[0] (LQGC d=2, K=128,
+    N=20), configs[1] (LLGC d=100, K=1024, N=50, 2x64 MLP) and a K=4096 cut of the workload, each with all cores of the
+    box's CPU share and with 1 thread.  About 20 s of CPU work in total.  The top-level value is the K=4096 cut at all cores."""
+    from oracle import pathspace_oracle as orc
+    # a 1-GPU box exposes a 16-core CPU share; more torch threads than that only adds contention
+    allc = min(16, os.cpu_count() or 1)
+    legs = []
+
+    def leg(name, prob, K, dt, widths, d, budget, max_iters):
+        for threads in (allc, 1):
+            cfg = orc.HJBConfig(K=K, delta_t=dt, lr=1e-3, L=1, seed=42, adaptive_forward_process=True, detach_forward=True)
+            z = orc.TanhMLP(d + 1, d, 1e-3, seed=123, widths=widths)
+            _, y0, N = orc.hjb_build(prob, cfg)
+            rate, iters, el = _time_oracle(orc, prob, cfg, z, y0, N, threads, budget, max_iters)
+            legs.append(dict(case=name, value=rate, unit="trajectory-timesteps/s", cores=threads, s_per_iter=el / iters,
+                             sample="K=%d, N=%d, %d iterations, %.1f s" % (K, N, iters, el)))
+
+    leg("configs[0] LQGC d=2 K=128 N=20 (default 30-30 MLP)",
+        orc.make_problem("LQGC", d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05), 128, 0.05, (30, 30), 2, 1.0, 200)
+    leg("configs[1] LLGC d=100 K=1024 N=50 (64-64 MLP)",
+        orc.make_problem("LLGC", d=100, off_diag=0.01, T=0.5, seed=42), 1024, 0.01, (64, 64), 100, 2.0, 40)
+    Kc = min(4096, w.get("K") or w.get("K_global"))
+    leg("workload cut: LLGC d=%d K=%d of %d" % (w["d"], Kc, w.get("K") or w.get("K_global")),
+        orc.make_problem("LLGC", d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42), Kc, w["dt"], (w["H"], w["H"]),
+        w["d"], 6.0, 24)
+    torch.set_num_threads(allc)
+    main = legs[4]
+    return dict(value=main["value"], unit="trajectory-timesteps/s", cores=main["cores"], kind="port",
+                sample="oracle hjb_train, %s, %s, torch %s" % (main["case"], main["sample"], torch.__version__),
+                legs=legs)
 
 
 def loss_rel_err_vs_cpu(psp, dev, w):
@@ -130,7 +338,7 @@ def loss_rel_err_vs_cpu(psp, dev, w):
                 case="LLGC d=%d, K=%d, N=%d, %d iterations, seed 42, reference noise stream" % (w["d"], K, N, L))
 
 
-def secondary(psp, dev, w, steps=100, warmup=10):
+def secondary(psp, dev, w, steps=200, warmup=20):
     prob = psp.LLGC(d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42, device=dev)
     model = psp.Solver("bench-cfg1", prob, lr=1e-3, L=steps + warmup, K=w["K"], delta_t=w["dt"],
                        loss_method="log-variance", time_approx="inner", adaptive_forward_process=True,
@@ -147,7 +355,40 @@ def secondary(psp, dev, w, steps=100, warmup=10):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     return {"value": w["K"] * model.N * steps / el, "unit": "trajectory-timesteps/s", "ms_per_step": 1e3 * el / steps,
-            "steps": steps, "K": w["K"], "N": model.N}
+            "steps": steps, "K": w["K"], "N": model.N, "graph": bool(getattr(plan, "graph_active", False))}
+
+
+def mfma_roofline(fl2, fl3, issued, units, tiles_steps, ms, bf16_mlp, which):
+    """Roofline terms of one kernel.  fl2 / fl3: algorithmic flop dictionaries (m = 2 / m = 3); issued: (f32, bf16, bwd_f32)
+    MFMA instructions per tile-step; which: 'fwd_kernel' | 'bwd_kernel'."""
+    t = ms * 1e-3
+    alg = fl2[which] * units
+    if bf16_mlp and which == "fwd_kernel":
+        # flop-weighted blend (SURVEY 8d): control-net products at the bf16 peak, everything else at the fp32 peak
+        floor_s = (fl2["mlp_fwd"] * units / (PEAK_BF16_MFMA_TFLOPS * 1e12) + fl2["sde"] * units / (PEAK_FP32_MFMA_TFLOPS * 1e12))
+        peak = alg / floor_s / 1e12
+        iss_floor_s = (issued[1] * MFMA_BF16_16x16x32_FLOP / (PEAK_BF16_MFMA_TFLOPS * 1e12) +
+                       issued[0] * MFMA_F32_16x16x4_FLOP / (PEAK_FP32_MFMA_TFLOPS * 1e12)) * tiles_steps
+        frac_issued = iss_floor_s / t
+    else:
+        peak = PEAK_FP32_MFMA_TFLOPS
+        n = issued[2] if which == "bwd_kernel" else issued[0]
+        frac_issued = n * MFMA_F32_16x16x4_FLOP * tiles_steps / t / 1e12 / PEAK_FP32_MFMA_TFLOPS
+    achieved = alg / t / 1e12
+    return dict(achieved=achieved, peak=peak, frac=achieved / peak, frac_issued=frac_issued,
+                frac_survey_m3=(fl3[which] * units / t / 1e12) / peak)
+
+
+def load_traffic(workload, kernel):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: FETCH_SIZE already carries the gfx950
+    correction for the stream widths this kernel uses, as calibrated by tools/fetch_calibrate)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    ent = json.load(open(tpath)).get(workload, {}).get(kernel)
+    if isinstance(ent, dict):
+        return ent.get("hbm_bytes")
+    return ent
 
 
 def main():
@@ -160,40 +401,35 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] side measurement")
     args = ap.parse_args()
+    spawn_ranks_if_needed(args)                          # N > 1 without a launcher: children do the work
 
     import path_space_pde_solver_amd as psp
+    from path_space_pde_solver_amd import sharding
     if args.workload in GENERAL_WORKLOADS:
-        return main_general(args, psp)
+        return main_general(args, psp, sharding)
     w = WORKLOADS[args.workload]
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    # PSP_BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo -- a way to walk the N > 1 code path on a
-    # one-GPU box (RCCL refuses two ranks on one device); numbers from such a run mean nothing
-    rehearsal = os.environ.get("PSP_BENCH_REHEARSAL") == "1"
-    dev = torch.device("cuda", 0 if rehearsal else local_rank)
-    torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-    if args.gpus != world:
-        print("note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)"
-              % (args.gpus, world), file=sys.stderr)
+    dist, rank, world, dev, rehearsal = init_ranks(args)
 
-    K_global = w["K"] * world                           # weak scaling: fixed trajectories per GPU
+    strong = "K_global" in w
+    if strong:
+        K_global = w["K_global"]
+        if K_global % (16 * world):
+            raise SystemExit("K_global=%d does not split into whole 16-trajectory tiles over %d ranks" % (K_global, world))
+        K_local = K_global // world
+    else:
+        K_local, K_global = w["K"], w["K"] * world       # weak scaling: fixed trajectories per GPU
     prob = psp.LLGC(d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42, device=dev)
     total = args.warmup + args.steps
     outer = bool(w.get("outer"))
+    extra = {}
+    if "path_budget_gb" in w:
+        extra["path_budget_bytes"] = int(w["path_budget_gb"] * 2 ** 30)
+    if "chunks" in w:
+        extra["path_chunks"] = int(w["chunks"])
     model = psp.Solver("bench", prob, lr=w.get("lr", 1e-3), L=total, K=K_global, delta_t=w["dt"], loss_method="log-variance",
                        time_approx="outer" if outer else "inner", adaptive_forward_process=True, detach_forward=True,
                        u_l2_error_flag=False, verbose=False, seed=42, device=dev, backend="native",
-                       noise="philox", widths=(w["H"], w["H"]), mlp_dtype=w.get("mlp", "fp32"))
+                       noise="philox", widths=(w["H"], w["H"]), mlp_dtype=w.get("mlp", "fp32"), **extra)
     if outer:                                            # the constructor builds arch [30, 30]; honour the workload's H
         model.z_n = [psp.DenseNet(d_in=w["d"], d_out=w["d"], lr=w.get("lr", 1e-3), arch=[w["H"], w["H"]], seed=42).to(dev)
                      for _ in range(model.N)]
@@ -205,24 +441,18 @@ def main():
     for l in range(args.warmup):
         plan.iteration(l, losses)
 
-    plan.events = []                                     # (fwd_start, fwd_end, bwd_start, bwd_end) per step
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for l in range(args.warmup, total):
-        plan.iteration(l, losses)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    c_abi = check_c_abi_allreduce(psp, dist, rank, world, dev, rehearsal)
+    plan.events = []                                     # (fwd_start, fwd_end, bwd_start, bwd_end) per launch pair
+    if getattr(plan, "n_chunks", 1) > 1:
+        plan.pass1_events = []
+    sharding.coll_events = [] if world > 1 else None
+    elapsed = timed_region(dist, dev, lambda l: plan.iteration(l, losses), args.steps, args.warmup)
 
-    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in plan.events) / max(1, len(plan.events))
-    bwd_ms = sum(e[2].elapsed_time(e[3]) for e in plan.events) / max(1, len(plan.events))
+    n_ev = max(1, len(plan.events))
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in plan.events) / n_ev
+    bwd_ms = sum(e[2].elapsed_time(e[3]) for e in plan.events) / n_ev
+    coll = collective_summary(sharding, args.steps)
+    sharding.coll_events = None
     loss_vals = losses.cpu().tolist()
     if rank != 0:
         if dist is not None:
@@ -230,47 +460,92 @@ def main():
         return
 
     dense = w["off_diag"] != 0.0
-    fl = alg_flops_dense_control(w["d"], w["H"], dense) if outer else alg_flops_per_traj_step(w["d"], w["H"], dense)
-    units_local = w["K"] * N_t                           # trajectory-timesteps per launch on one GPU
+    flops = alg_flops_dense_control if outer else alg_flops_per_traj_step
+    fl2, fl3 = flops(w["d"], w["H"], dense, m=2), flops(w["d"], w["H"], dense, m=3)
+    n_chunks = int(getattr(plan, "n_chunks", 1))
+    K_launch = K_local // n_chunks                       # trajectories per kernel launch
+    units_launch = K_launch * N_t                        # trajectory-timesteps per launch on one GPU
+    tiles_steps = _cdiv(K_launch, 16) * N_t
     # kernel names as they appear in rocprof: family 1 = hjb_kernels.h (hjbs_kernels.h forward when there are at most two
     # tiles per CU), family 2 = hjbw_kernels.h
-    ntile = (plan.K_local + 15) // 16
+    ntile = _cdiv(K_launch, 16)
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    bf16_mlp = w.get("mlp") == "bf16"
     if outer:
         fwd_name, bwd_name = "hjbd_fwd_kernel", ("hjbd_bwd_kernel" if plan.kernel_bwd else "library GEMMs")
+        issued = None
     else:
         fwd_name = "hjbw_fwd_kernel" if plan.family == 2 else ("hjbs_fwd_kernel" if ntile <= 2 * cus else "hjb_fwd_kernel")
         bwd_name = "hjbw_bwd_kernel" if plan.family == 2 else "hjb_bwd2_kernel"
+        issued = issued_mfma_per_tile_step(plan.d_pad, plan.H_pad, dense, plan.family, bf16_mlp)
     bwd_dominant = bwd_ms >= fwd_ms
-    dom = bwd_name if bwd_dominant else fwd_name
-    dom_ms = max(bwd_ms, fwd_ms)
-    dom_flops = (fl["bwd_kernel"] if bwd_dominant else fl["fwd_kernel"]) * units_local
-    achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-    traffic = None                                   # HBM bytes per launch, from the committed PMC passes
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+    dom, dom_ms, which = (bwd_name, bwd_ms, "bwd_kernel") if bwd_dominant else (fwd_name, fwd_ms, "fwd_kernel")
+    if issued is None:                                   # DenseNet control: algorithmic terms only
+        t = dom_ms * 1e-3
+        mf = dict(achieved=fl2[which] * units_launch / t / 1e12, peak=PEAK_FP32_MFMA_TFLOPS)
+        mf["frac"] = mf["achieved"] / mf["peak"]
+        mf["frac_issued"] = None
+        mf["frac_survey_m3"] = fl3[which] * units_launch / t / 1e12 / mf["peak"]
+    else:
+        mf = mfma_roofline(fl2, fl3, issued, units_launch, tiles_steps, dom_ms, bf16_mlp, which)
+    # HBM term: SURVEY 8d's algorithmic bytes (state streamed once per step, 8d + 8) and this design's real ones (the path
+    # store: state stays on chip, the forward writes / the backward reads one block of register images per unit)
+    path_B_unit = float(plan.sizes.path_bytes) / max(1, units_launch) if hasattr(plan, "sizes") else None
+    step_s = elapsed / args.steps
+    hbm = {"bytes_per_unit_survey": 8 * w["d"] + 8, "bytes_per_unit_path_store": path_B_unit,
+           "kernel_GBps_path_store": (path_B_unit * units_launch / (dom_ms * 1e-3) / 1e9) if path_B_unit else None,
+           "peak_GBps": PEAK_HBM_GBS}
+    hbm["frac"] = (hbm["kernel_GBps_path_store"] or 0.0) / PEAK_HBM_GBS
+    bound = "mfma" if mf["frac"] >= hbm["frac"] else "hbm"
     value = K_global * N_t * args.steps / elapsed
+    whole_tf = fl2["total"] * K_local * N_t / step_s / 1e12
+    roof = {"bound": bound, "kernel": dom,
+            "achieved": mf["achieved"] if bound == "mfma" else hbm["kernel_GBps_path_store"],
+            "peak": mf["peak"] if bound == "mfma" else PEAK_HBM_GBS,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": max(mf["frac"], hbm["frac"]),
+            "traffic": load_traffic(args.workload, dom),
+            "convention": "minimal algorithmic flops (m = 2 dense d x d products per step) / HIP-event kernel time / peak",
+            "mfma_term": mf, "hbm_term": hbm,
+            "alg_flops_per_traj_step": {k: fl2[k] for k in ("fwd_kernel", "bwd_kernel", "total")},
+            "alg_flops_per_traj_step_survey_m3": {k: fl3[k] for k in ("fwd_kernel", "bwd_kernel", "total")},
+            "issued_mfma_per_tile_step": ({"fwd_f32_16x16x4": issued[0], "fwd_bf16_16x16x32": issued[1],
+                                           "bwd_f32_16x16x4": issued[2]} if issued else None),
+            "units_per_launch": units_launch, "launches_per_step": n_chunks,
+            "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
+            "whole_step_tflops": whole_tf, "whole_step_frac_of_fp32_peak": whole_tf / PEAK_FP32_MFMA_TFLOPS}
     out = {
         "metric": "trajectory-timesteps/sec (K*N/s), d=%d HJB log-variance training iteration" % w["d"],
         "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 control-net products in the forward rollout, f32 elsewhere" if w.get("mlp") == "bf16" else "f32",
+        "warmup": args.warmup, "ms_per_step": 1e3 * step_s, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "bf16 control-net products in the forward rollout, f32 elsewhere" if bf16_mlp else "f32",
         "data": "synthetic",
-        "config": {"workload": args.workload, "problem": "LLGC", "d": w["d"], "K_per_gpu": w["K"],
+        "config": {"workload": args.workload, "problem": "LLGC", "d": w["d"], "K_per_gpu": K_local,
                    "K_global": K_global, "N": N_t,
                    "mlp": ("%d x DenseNet %d-%d-%d-%d relu^2, one per time step (time_approx='outer')" % (N_t, w["d"], w["H"], w["H"], w["d"]))
                           if outer else "%d-%d-%d-%d tanh" % (w["d"] + 1, w["H"], w["H"], w["d"]),
                    "loss": "log-variance", "noise": "on-device Philox4x32-10",
-                   "parallelism": "trajectory-sharded x%d" % world},
-        "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                     "alg_flops_per_traj_step": fl, "units_per_launch": units_local,
-                     "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
-                     "whole_step_tflops": fl["total"] * units_local / (1e-3 * (1e3 * elapsed / args.steps)) / 1e12},
+                   "parallelism": "trajectory-sharded x%d (%s)" % (world, "gloo rehearsal on one GPU" if rehearsal else
+                                                                    ("RCCL" if world > 1 else "single process")),
+                   "path_store": ("K-chunked two-pass plan: %d chunks of %d trajectories, forward recomputed once (%.1f GB store)"
+                                  % (n_chunks, K_launch, plan.sizes.path_bytes / 1e9)) if n_chunks > 1 else
+                                 ("resident (%.1f GB)" % (plan.sizes.path_bytes / 1e9) if hasattr(plan, "sizes") else "resident")},
+        "roofline": roof,
         "loss_first_last": [loss_vals[0], loss_vals[-1]],
     }
+    if n_chunks > 1:
+        # recompute overhead: pass 1 (forward without store) is extra work over the resident-store plan
+        p1 = getattr(plan, "pass1_events", None) or []
+        out["chunking"] = {"chunks": n_chunks, "mode": plan.chunk_mode,
+                           "pass1_forward_ms_per_step": (sum(a.elapsed_time(b) for a, b in p1) / len(p1)) if p1 else 0.0,
+                           "note": ("two_gradient: no forward recompute; each chunk's backward kernel runs twice (weights D_k - c "
+                                    "and 1), grad = (2/K)[G1 - (mean D - c) G0]" if plan.chunk_mode == "two_gradient" else
+                                    "recompute: pass 1 re-runs the forward rollout without the path store to obtain the global "
+                                    "(sum D, sum D^2)") + "; value counts each trajectory-timestep once"}
+    if coll is not None:
+        out["collectives"] = coll
+        out["collectives"]["c_abi_psp_allreduce_check"] = c_abi
     if world == 1 and args.workload == "hjb_llgc_d100_K65536_N100_h64" and not args.no_secondary:
         # BASELINE.json configs[1] (d=100, K=1024, N=50) measured in the same process, for readers who take
         # that as the quoted configuration (64 16-trajectory tiles: runs on the feature-split forward kernel)
@@ -280,22 +555,16 @@ def main():
         out["loss_rel_err_vs_cpu_ref"] = loss_rel_err_vs_cpu(psp, dev, w)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
+    sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 
 
-def main_general(args, psp):
+def main_general(args, psp, sharding):
     """GeneralSolver (diffusion / BSDE loss) workloads: metric counts ACTIVE trajectory-timesteps
     (K_log, reference solver.py:1152), as SURVEY.md 8d prescribes."""
     w = GENERAL_WORKLOADS[args.workload]
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    dist, rank, world, dev, rehearsal = init_ranks(args)
     prob = psp.DoubleWell_multidim_for_general_solver(d=w["d"], d_1=w["d"] // 2, d_2=w["d"] - w["d"] // 2, T=w["T"],
                                                       eta=1, kappa=1, modus="HJB", device=dev)
     total = args.warmup + args.steps
@@ -308,23 +577,17 @@ def main_general(args, psp):
     for l in range(args.warmup):
         plan.iteration(l)
     plan.events = []
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    sharding.coll_events = [] if world > 1 else None
     counts, losses = [], []
-    for l in range(args.warmup, total):
+
+    def one(l):
         loss, kc = plan.iteration(l)
         counts.append(kc)
         losses.append(loss)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    elapsed = timed_region(dist, dev, one, args.steps, args.warmup)
+    coll = collective_summary(sharding, args.steps)
+    sharding.coll_events = None
     active = float(torch.stack(counts).sum().item())
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in plan.events) / max(1, len(plan.events))
     bwd_ms = sum(e[2].elapsed_time(e[3]) for e in plan.events) / max(1, len(plan.events))
@@ -333,29 +596,46 @@ def main_general(args, psp):
     # 2F (+ F for the tangent part it pre-computes), backward kernel 3F  -> 6F per unit in total
     F = 2 * ((w["d"] + 1) * w["H"] + (w["d"] + 1 + w["H"]) * w["H"] + (w["d"] + 1 + 2 * w["H"]))
     units = w["K"] * w["N"]
-    dom, dom_ms, dom_fl = ("gen_bwd_kernel", bwd_ms, 3 * F) if bwd_ms >= fwd_ms else ("gen_fwd_kernel", fwd_ms, 3 * F)
+    mlp = w.get("mlp")
+    bwd_dom = bwd_ms >= fwd_ms
+    dom, dom_ms, dom_fl = ("gen_bwd2_kernel", bwd_ms, 3 * F) if bwd_dom else ("gen_fwd_kernel", fwd_ms, 3 * F)
+    # every product of these kernels is a value-net product: on bf16 workloads the whole kernel is priced at the bf16 MFMA
+    # peak (forward always; backward only with mlp == 'bf16')
+    on_bf16 = (mlp in ("bf16", "bf16_fwd") and not bwd_dom) or (mlp == "bf16" and bwd_dom)
+    peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
     achieved = dom_fl * units / (dom_ms * 1e-3) / 1e12
+    path_B = float(plan.sizes.path_bytes) / ((w["N"] + 1) * w["K"]) if hasattr(plan, "sizes") else None
+    hbm_gbps = (float(plan.sizes.path_bytes) / (dom_ms * 1e-3) / 1e9) if hasattr(plan, "sizes") else 0.0
+    mf_frac, hbm_frac = achieved / peak, hbm_gbps / PEAK_HBM_GBS
+    bound = "mfma" if mf_frac >= hbm_frac else "hbm"
     if rank == 0:
         out = {"metric": "active trajectory-timesteps/sec, d=100 %s loss training iteration" % w["loss"],
                "value": active / elapsed, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
                "dtype": {"bf16": "bf16 MFMA operands in both rollout kernels, f32 state / accumulate / element-wise",
-                         "bf16_fwd": "bf16 MFMA operands in the forward rollout, f32 state / accumulate / backward"}.get(w.get("mlp"), "f32"),
+                         "bf16_fwd": "bf16 MFMA operands in the forward rollout, f32 state / accumulate / backward"}.get(mlp, "f32"),
                "data": "synthetic",
                "config": {"workload": args.workload, "problem": "DoubleWell_multidim_for_general_solver",
                           "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%d-%d-1" % (w["d"] + 1, w["H"], w["H"]),
                           "loss": w["loss"], "active_fraction": active / (w["K"] * world * w["N"] * args.steps)},
-               "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                            "traffic": (json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                                        .get(args.workload, {}).get(dom)
-                                        if os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")) else None),
+               "roofline": {"bound": bound, "kernel": dom,
+                            "achieved": achieved if bound == "mfma" else hbm_gbps,
+                            "peak": peak if bound == "mfma" else PEAK_HBM_GBS,
+                            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                            "frac": max(mf_frac, hbm_frac),
+                            "traffic": load_traffic(args.workload, dom),
+                            "mfma_term": {"achieved": achieved, "peak": peak, "frac": mf_frac},
+                            "hbm_term": {"bytes_per_sample_slot_path_store": path_B, "kernel_GBps_path_store": hbm_gbps,
+                                         "peak_GBps": PEAK_HBM_GBS, "frac": hbm_frac},
                             "alg_flops_per_launched_unit": {"value_net_F": F, "fwd_kernel": 3 * F, "bwd_kernel": 3 * F},
                             "units_per_launch": units, "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms},
                "launched_units_per_s": w["K"] * world * w["N"] * args.steps / elapsed,
                "loss_first_last": [float(losses[0]), float(losses[-1])]}
+        if coll is not None:
+            out["collectives"] = coll
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -4,9 +4,20 @@
  * The reference (lorenzrichter/path-space-PDE-solver) is pure Python and exposes no
  * FFI; its boundary is the duck-typed Solver / Problem / FunctionSpace API.  This
  * library sits underneath this repo's Python mirror of that API and replaces the
- * body of Solver.train (reference solver.py:420-557) for the supported catalogue:
- *   approx_method='control', time_approx='inner' (one tanh MLP, two hidden layers),
- *   detach_forward=True, loss_method in {'log-variance','moment'}.
+ * body of the training iteration for the supported catalogue:
+ *   Solver.train (reference solver.py:420-557)
+ *     psp_hjb_*   approx_method='control', time_approx='inner', one tanh MLP with two hidden layers
+ *                 (function_space.py:177-195); losses log-variance / moment (in the kernels), variance /
+ *                 cross_entropy (caller-supplied trajectory weights), relative_entropy; detach_forward True, or
+ *                 False through psp_hjb_adjoint_sweep (gradients through the state path); importance-sampling
+ *                 evaluation (psp_hjb_rollout_eval, utilities.py:287-359)
+ *     psp_dnet_*  DenseNet controls (function_space.py:116-140): time_approx='outer' (one net per time step) and a
+ *                 DenseNet(d+1 -> d) swapped into z_n; forward rollout AND hand-written parameter gradient
+ *                 (psp_dnet_rollout_bwd; instances whose accumulators do not fit report bwd_supported = 0)
+ *   GeneralSolver.train / EllipticSolver.train (solver.py:1001-1206, :628-826)
+ *     psp_gen_*   diffusion / BSDE loss on unbounded, sphere and box domains, V = DenseNet(d+1 -> 1) / DenseNet(d -> 1)
+ *   shared: psp_adam_step (per-net Adam, function_space.py:185), psp_allreduce + psp_comm_* (trajectory sharding over
+ *   the GPUs of a node), diagnostics.
  *
  * Conventions
  *  - plain pointers and sizes only; every device buffer is owned by the caller
@@ -28,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PSP_VERSION 100 /* 0.1.0 */
+#define PSP_VERSION 200 /* 0.2.0 */
 
 /* drift b(x): reference problems.py:36-37,154-155 (dense), :311-315 (double well) */
 enum { PSP_DRIFT_ZERO = 0, PSP_DRIFT_DENSE = 1, PSP_DRIFT_DIAG = 2, PSP_DRIFT_DOUBLE_WELL = 3 };
@@ -338,6 +349,25 @@ int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* params, const 
  * step, cuts the real rows / columns out and -- with time_input -- forms the time rows as sum_n t_n * (bias gradient of step n). */
 int psp_dnet_rollout_bwd(const psp_dnet_config* cfg, const float* params, const float* images, const float* w,
                          float* partial, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, trajectories sharded in contiguous blocks, parameters replicated.
+ * Per iteration two in-place SUM all-reduces on the caller's stream: (sum D, sum D^2) after psp_hjb_terminal_reduce
+ * (2 x fp64; the log-variance loss needs the GLOBAL mean) and the flat gradient after psp_hjb_rollout_bwd (n_params
+ * fp32), then the same psp_adam_step on every rank.  The reference has no distributed code; these entry points are
+ * what a C / ctypes consumer of this library uses instead of torch.distributed.  They drive RCCL (librccl.so.1 is
+ * bound at first use, so the library loads on machines without it): both messages are latency-bound (16 B, 69 KB at
+ * d=100), far from the per-link xGMI bandwidth.
+ *   psp_comm_unique_id : rank 0 creates the 128-byte id and hands it to the other ranks by any host-side means
+ *   psp_comm_init      : collective over all ranks, after hipSetDevice; *comm_out is an ncclComm_t
+ *   psp_allreduce      : in-place SUM of n elements (dtype PSP_DT_F32 / PSP_DT_F64), asynchronous on `stream`
+ * ------------------------------------------------------------------------------------------------ */
+#define PSP_COMM_ID_BYTES 128
+enum { PSP_DT_F32 = 0, PSP_DT_F64 = 1 };
+int psp_comm_unique_id(unsigned char id_out[PSP_COMM_ID_BYTES]);
+int psp_comm_init(void** comm_out, int32_t nranks, int32_t rank, const unsigned char id[PSP_COMM_ID_BYTES]);
+int psp_comm_destroy(void* comm);
+int psp_allreduce(void* buf, int64_t n, int32_t dtype, void* comm, void* stream);
 
 /* Diagnostics: device buffer that receives per-wave phase cycle sums (8 u64 per wave of the
  * backward kernel).  Returns 1 if the library was built with -DPSP_STAMPS (diagnostic build,

@@ -1,9 +1,12 @@
 // psp_api.hip -- C ABI of libpsp_hip.so (see include/psp.h) + the small streaming kernels.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <rccl/rccl.h>   // types only: the entry points are bound with dlsym at first use (psp_comm_*)
 
 #include "../../include/psp.h"
 #include "hjb_kernels.h"
@@ -727,6 +730,89 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
                        grad_partial, p.bwd_grid, P, grad_out);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
+    return 0;
+}
+
+// ---- collectives: RCCL on the caller's stream, bound lazily so that the library loads without librccl ---------------
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+int bind_rccl() {
+    if (g_rccl.handle) return 0;
+    // a process that already loaded RCCL (torch ships its own librccl.so.1) gets that copy back: same soname
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(-20, "cannot load librccl.so.1: %s", dlerror());
+    Rccl r;
+    r.handle = h;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString)
+        return fail(-20, "librccl.so.1 lacks an expected entry point");
+    g_rccl = r;
+    return 0;
+}
+int fail_rccl(ncclResult_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "RCCL error");
+    return -21;
+}
+}  // namespace
+
+int psp_comm_unique_id(unsigned char id_out[PSP_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == PSP_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!id_out) return fail(-1, "null id buffer");
+    int rc = bind_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    ncclResult_t e = g_rccl.GetUniqueId(&id);
+    if (e != ncclSuccess) return fail_rccl(e, "ncclGetUniqueId");
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int psp_comm_init(void** comm_out, int32_t nranks, int32_t rank, const unsigned char id[PSP_COMM_ID_BYTES]) {
+    if (!comm_out || !id) return fail(-1, "null argument to psp_comm_init");
+    if (nranks <= 0 || rank < 0 || rank >= nranks) return fail(-1, "psp_comm_init needs 0 <= rank < nranks");
+    int rc = bind_rccl();
+    if (rc) return rc;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    ncclResult_t e = g_rccl.CommInitRank(&comm, nranks, uid, rank);
+    if (e != ncclSuccess) return fail_rccl(e, "ncclCommInitRank");
+    *comm_out = comm;
+    return 0;
+}
+
+int psp_comm_destroy(void* comm) {
+    if (!comm) return 0;
+    int rc = bind_rccl();
+    if (rc) return rc;
+    ncclResult_t e = g_rccl.CommDestroy(static_cast<ncclComm_t>(comm));
+    if (e != ncclSuccess) return fail_rccl(e, "ncclCommDestroy");
+    return 0;
+}
+
+int psp_allreduce(void* buf, int64_t n, int32_t dtype, void* comm, void* stream) {
+    if (!buf || !comm) return fail(-1, "null buffer / communicator passed to psp_allreduce");
+    if (n <= 0) return fail(-1, "psp_allreduce needs n > 0");
+    if (dtype != PSP_DT_F32 && dtype != PSP_DT_F64) return fail(-1, "psp_allreduce: dtype must be PSP_DT_F32 or PSP_DT_F64");
+    int rc = bind_rccl();
+    if (rc) return rc;
+    ncclResult_t e = g_rccl.AllReduce(buf, buf, (size_t)n, dtype == PSP_DT_F32 ? ncclFloat32 : ncclFloat64, ncclSum,
+                                      static_cast<ncclComm_t>(comm), (hipStream_t)stream);
+    if (e != ncclSuccess) return fail_rccl(e, "ncclAllReduce");
     return 0;
 }
 

@@ -178,6 +178,13 @@ class GeneralSolver:
             return plan.train()
         self._train_composite()
 
+    def _plan_key(self):
+        """What a native plan sizes its buffers / fixes its kernel configuration from (the value net is compared by identity:
+        `model.V = DenseNet(...)` after a first train() must rebuild the plan, Allen-Cahn.ipynb:72)."""
+        return (id(self.V), self.K, self.N, self.K_boundary, float(self.delta_t_np), self.loss_method, tuple(self.alpha),
+                bool(self.adaptive_forward_process), bool(self.detach_forward), getattr(self, 'noise', None),
+                getattr(self, 'mlp_dtype', None), bool(getattr(self, 'uniform_square', False)), id(self.problem))
+
     def _choose_plan(self):
         if self.backend == 'torch':
             self.plan_name, self.plan_reason = 'torch', "backend='torch' requested"
@@ -193,8 +200,10 @@ class GeneralSolver:
         if reason is None:
             self.plan_name = 'native'
             plan = getattr(self, '_gen_plan', None)
-            if plan is None or plan.s.V is not self.V:
+            key = self._plan_key()
+            if plan is None or plan.net is not self.V or plan.key != key:
                 plan = pgn.GeneralNativePlan(self)              # owns the flat parameters and Adam moments
+                plan.key = key
                 self._gen_plan = plan
             return plan
         if self.backend == 'native':
@@ -288,7 +297,8 @@ class EllipticSolver(GeneralSolver):
                  approx_method='Y', sample_center=False, loss_method='diffusion', loss_with_stopped=False,
                  K_test_log=None, PINN_log_variance=False, log_loss_parts=False, boundary_loss=True,
                  boundary_type='Dirichlet', variance_moment_split=False, full_hessian=False, uniform_square=False,
-                 device=None, backend='auto', noise='reference', mlp_dtype='fp32'):
+                 device=None, backend='auto', noise='reference', mlp_dtype='fp32', v_l2_error_flag=True):
+        self.v_l2_error_flag = v_l2_error_flag   # False: skip the V_L2 diagnostic of solver.py:738 on the native plan (timed runs)
         super().__init__(problem, name, seed=seed, delta_t=delta_t, N=N, lr=lr, L=L, K=K, K_boundary=K_boundary,
                          alpha=alpha, adaptive_forward_process=adaptive_forward_process, detach_forward=detach_forward,
                          print_every=print_every, verbose=verbose, approx_method='skip', sample_center=sample_center,

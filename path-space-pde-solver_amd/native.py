@@ -23,6 +23,8 @@ LOSS_LOG_VARIANCE, LOSS_MOMENT, LOSS_WEIGHTS, LOSS_REL_ENTROPY = 0, 1, 2, 3
 NOISE_SUPPLIED, NOISE_PHILOX = 0, 1
 GH_ZERO, GH_QUAD, GH_ALLEN_CAHN, GH_EXPBALL_LIN, GH_EXPBALL_SQ, GH_EXPBALL_SIN = 0, 1, 2, 3, 4, 5
 MLP_FP32, MLP_BF16_FWD, MLP_BF16 = 0, 1, 2
+DT_F32, DT_F64 = 0, 1
+COMM_ID_BYTES = 128
 DOM_NONE, DOM_SPHERE, DOM_BOX, DOM_BOX_UPPER_ALL, DOM_BOX_UPPER_ANY = 0, 1, 2, 3, 4
 
 
@@ -120,6 +122,10 @@ SIGNATURES = {
     "psp_philox_normal_fill": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32, _P]),
     "psp_hjb_control_eval": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
     "psp_debug_set_stamp_buffer": (C.c_int, [_P, C.c_int64]),
+    "psp_comm_unique_id": (C.c_int, [_P]),
+    "psp_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _P]),
+    "psp_comm_destroy": (C.c_int, [_P]),
+    "psp_allreduce": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
     "psp_gen_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_gen_query": (C.c_int, [C.POINTER(GenConfig), C.POINTER(GenSizes)]),
     "psp_gen_rollout_fwd": (C.c_int, [C.POINTER(GenConfig), _P, _P, _P, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P,
@@ -173,11 +179,11 @@ def check(rc, what):
         raise NativeCallError("%s failed (%d): %s" % (what, rc, last_error()))
 
 
-def ptr(t):
-    """Raw device/host pointer of a tensor (or None)."""
+def ptr(t, offset=0):
+    """Raw device/host pointer of a tensor (or None), optionally `offset` ELEMENTS into it."""
     if t is None:
         return None
-    return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.data_ptr() + int(offset) * t.element_size())
 
 
 def stream_ptr(device):

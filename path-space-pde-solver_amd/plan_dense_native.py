@@ -27,13 +27,13 @@ try:
     from . import native_shapes as shapes
     from . import sharding
     from .function_space import DenseNet
-    from .plan_native import HjbNativePlan, PlanUnsupported
+    from .plan_native import HjbNativePlan, PlanUnsupported, _overridden
 except ImportError:
     import native as nat
     import native_shapes as shapes
     import sharding
     from function_space import DenseNet
-    from plan_native import HjbNativePlan, PlanUnsupported
+    from plan_native import HjbNativePlan, PlanUnsupported, _overridden
 
 _LOSSES = ('log-variance', 'moment', 'variance', 'cross_entropy')
 
@@ -74,6 +74,9 @@ def dense_eligibility(solver):
     spec_fn = getattr(solver.problem, 'native_spec', None)
     if spec_fn is None or spec_fn() is None:
         return 'problem has no native_spec() (coefficients outside the native catalogue)'
+    over = _overridden(solver.problem)
+    if over is not None:
+        return 'problem.%s is not the catalogue implementation native_spec() describes' % over
     if not nat.is_built():
         raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
     if _instance_for(solver.d, dims0[1]) is None:
@@ -331,11 +334,32 @@ class DenseNativePlan:
             self.events.append(ev)
         sharding.allreduce_sum_(self.grad)                        # collective 2
         self.step += 1
+        lr, b1, b2, eps = self._adam_hyper(self.nets)
         nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
-                                    self.P, self.step, float(s.lr), 0.9, 0.999, 1e-8, st), 'psp_adam_step')
+                                    self.P, self.step, lr, b1, b2, eps, st), 'psp_adam_step')
         if self.learn_y0:
-            self.y0_grad[0] = sharding.y0_gradient(self.sums, s.K, s.loss_method)
+            self.y0_grad[0] = sharding.y0_gradient(self.sums, s.K, s.loss_method, self.w if self.generic_loss else None)
+            ylr, yb1, yb2, yeps = self._adam_hyper([s.y_0])
             nat.check(lib.psp_adam_step(nat.ptr(self.y0_param), nat.ptr(self.y0_grad), nat.ptr(self.y0_m),
-                                        nat.ptr(self.y0_v), 1, self.step, float(s.lr), 0.9, 0.999, 1e-8, st),
+                                        nat.ptr(self.y0_v), 1, self.step, ylr, yb1, yb2, yeps, st),
                       'psp_adam_step(Y_0)')
         return loss
+
+    def _adam_hyper(self, nets):
+        """lr / betas / eps of the nets' OWN optimisers (function_space.py:131; solver.py:198-200 steps every Phi's Adam).  One
+        fused Adam runs over the concatenation of all parameter sets, so the sets must agree."""
+        hyp = None
+        for net in nets:
+            opt = getattr(net, 'optim', None)
+            if opt is None or not opt.param_groups:
+                h = (float(self.s.lr), 0.9, 0.999, 1e-8)
+            else:
+                g = opt.param_groups[0]
+                if g.get('weight_decay', 0) or g.get('amsgrad', False):
+                    raise PlanUnsupported('the native Adam implements weight_decay = 0, amsgrad = False (the reference default)')
+                b = g.get('betas', (0.9, 0.999))
+                h = (float(g['lr']), float(b[0]), float(b[1]), float(g.get('eps', 1e-8)))
+            if hyp is not None and h != hyp:
+                raise PlanUnsupported('the per-step nets carry different Adam settings; the fused native Adam needs one')
+            hyp = h
+        return hyp

@@ -54,6 +54,13 @@ def native_eligibility(solver):
     spec_fn = getattr(solver.problem, 'general_native_spec', None)
     if spec_fn is None:
         return 'problem has no general_native_spec() (coefficients outside the native catalogue)'
+    try:
+        from .problems import coefficients_overridden
+    except ImportError:
+        from problems import coefficients_overridden
+    over = coefficients_overridden(solver.problem)
+    if over is not None:
+        return 'problem.%s is not the catalogue implementation general_native_spec() describes' % over
     if not nat.is_built():
         raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
     if not shapes.gen_candidates(solver.d, dims[1]):
@@ -70,6 +77,8 @@ class GeneralNativePlan:
         self.dist, self.rank, self.world = sharding.dist_info()
         lo, hi = sharding.shard_bounds(s.K, self.rank, self.world)
         self.lo, self.hi, self.K_local = lo, hi, hi - lo
+        self.net = s.V                           # the plan is rebuilt when the caller swaps model.V (general_solver._choose_plan)
+        self.key = None
         self.H = s.V.nn_dims[1]
         self._flatten(s.V)
         spec = s.problem.general_native_spec()
@@ -132,6 +141,7 @@ class GeneralNativePlan:
         self.wY = torch.zeros(self.Kpad, dtype=f32, device=dev)     # zero-padded (include/psp.h)
         self.wV = torch.zeros(self.Kpad, dtype=f32, device=dev)
         self.step = 0
+        self.last_v_l2 = None
         self.events = None   # bench.py: HIP-event pairs around the two rollout kernels
 
     def _flatten(self, V):
@@ -155,8 +165,12 @@ class GeneralNativePlan:
         self._gen.manual_seed(int(s.seed) * 1000003 + l)
         K, d = s.K, s.d
         if pb.boundary in ('unbounded', 'sphere'):
-            X = torch.randn(K, d, generator=self._gen, device=dev)
-            radial = torch.rand(K, generator=self._gen, device=dev).unsqueeze(1) ** (1 / d)
+            if s.uniform_square:                                 # solver.py:1042-1043
+                X = torch.rand(K, d, generator=self._gen, device=dev) * 2 - 1
+                radial = torch.rand(K, generator=self._gen, device=dev).unsqueeze(1)
+            else:
+                X = torch.randn(K, d, generator=self._gen, device=dev)
+                radial = torch.rand(K, generator=self._gen, device=dev).unsqueeze(1) ** (1 / d)
             return pb.boundary_distance * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * radial
         return (pb.X_r - pb.X_l) * torch.rand(K, d, generator=self._gen, device=dev) + pb.X_l
 
@@ -298,25 +312,71 @@ class GeneralNativePlan:
         if loss_T is not None:                                   # identical on every rank: add after the reduce
             self.grad += torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                                     for p in self.params])       # (a pure Neumann residual never touches b3)
+        self.last_v_l2 = self._v_l2_from_path() if self.log_v_l2 else None     # before the update, as the reference logs it
         self.step += 1
+        lr, b1, b2, eps = self._adam_hyper()
         nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
-                                    self.P, self.step, float(s.lr), 0.9, 0.999, 1e-8, st), 'psp_adam_step')
+                                    self.P, self.step, lr, b1, b2, eps, st), 'psp_adam_step')
         kc = self.kcount.clone()
         sharding.allreduce_sum_(kc)
         return loss, kc
 
-    def train(self):
+    def _adam_hyper(self):
+        """lr / betas / eps of V's OWN optimiser (function_space.py:131; solver.py:1188 steps V.optim)."""
+        opt = getattr(self.net, 'optim', None)
+        if opt is not None and len(opt.param_groups) > 0:
+            g = opt.param_groups[0]
+            if g.get('weight_decay', 0) or g.get('amsgrad', False):
+                raise NotImplementedError('the native Adam implements weight_decay = 0, amsgrad = False (the reference default)')
+            b = g.get('betas', (0.9, 0.999))
+            return float(g['lr']), float(b[0]), float(b[1]), float(g.get('eps', 1e-8))
+        return float(self.s.lr), 0.9, 0.999, 1e-8
+
+    @property
+    def log_v_l2(self):
         s = self.s
-        losses, counts = [], []
+        return self.elliptic and getattr(s, 'v_l2_error_flag', True) and hasattr(s.problem, 'v_true')
+
+    def _v_l2_from_path(self):
+        """EllipticSolver's V_L2 log (solver.py:718, 738, 813): mean_k sum_{n alive} (V(X_n) - v_true(X_n))^2 dt, from the X_n
+        register images the forward kernel left in the path store (slot n = the state BEFORE the move of step n; image
+        float ks * 64 + 16 q + j holds feature 4 ks + q of sample j).  A trajectory with m active steps is alive at steps
+        0..m (the step that finds it outside still counts it, :736-738), capped by the N steps of the loop.  Diagnostics:
+        K N small-net evaluations in torch, off the timed path (v_l2_error_flag=False skips it)."""
+        s, cfg = self.s, self.cfg
+        N, nt = s.N, (self.K_local + 15) // 16
+        PB = self.sizes.path_bytes // 4 // ((N + 1) * nt)
+        nx = 4 * ((self.d_pad + 1 + 15) // 16) * 64
+        img = self.path.view(N + 1, nt, PB)[:N, :, :nx].reshape(N, nt, nx // 64, 4, 16)
+        X = img.permute(0, 1, 4, 2, 3).reshape(N, nt * 16, nx // 16)[:, :self.K_local, :s.d]
+        m = torch.round(self.tN / cfg.dt)                                            # active steps per trajectory
+        alive = (torch.arange(N, device=self.dev).unsqueeze(1) <= m.unsqueeze(0)).float()
+        with torch.no_grad():
+            Xf = X.reshape(-1, s.d)
+            err = (s.V(Xf).squeeze() - torch.as_tensor(s.problem.v_true(Xf)).float().to(self.dev).squeeze()) ** 2
+        tot = (err.reshape(N, self.K_local) * alive).sum().reshape(1) * s.delta_t_np
+        sharding.allreduce_sum_(tot)
+        return tot[0] / float(s.K)
+
+    def train(self):
+        import time
+        s = self.s
+        losses, counts, vl2 = [], [], []
+        t_block = time.time()
         for l in range(s.L):
             loss, kc = self.iteration(l)
             losses.append(loss)
             counts.append(kc)
+            if self.last_v_l2 is not None:
+                vl2.append(self.last_v_l2)
             if (s.verbose and l % s.print_every == 0) or l == s.L - 1:
-                vals = torch.stack(losses).cpu().tolist()
+                vals = torch.stack(losses).cpu().tolist()          # one sync per block
+                now = time.time()
                 s.loss_log += vals
                 s.K_log += [int(c.item()) for c in counts]
-                s.V_L2_log += [0.0] * len(vals)
+                s.V_L2_log += torch.stack(vl2).cpu().tolist() if vl2 else [0.0] * len(vals)
+                s.times += [(now - t_block) / len(vals)] * len(vals)
+                t_block = now
                 if s.verbose and l % s.print_every == 0:
-                    print('%d - loss = %.4e' % (l, s.loss_log[-1]))
-                losses, counts = [], []
+                    print('%d - loss = %.4e, v L2 error = %.4e, %.4f s/iter' % (l, s.loss_log[-1], s.V_L2_log[-1], s.times[-1]))
+                losses, counts, vl2 = [], [], []

@@ -10,6 +10,16 @@ torch supplies device memory, the stream and (for world_size > 1) the RCCL all-r
 no arithmetic of the hot path runs in torch.  Trajectories are sharded across ranks by
 contiguous blocks; noise is indexed by GLOBAL trajectory id so the result does not depend
 on the number of ranks.
+
+Path stores larger than a budget (configs[4]: d=500, K=1048576, N=200 needs 946 GB) are bounded by K-CHUNKING: the
+rank's trajectories are processed in chunks that share one path-store buffer.  Because the log-variance weights
+w_k = (2/K)(D_k - mean D) need the GLOBAL mean, a chunked iteration is either
+  'two_gradient' (log-variance / moment, detached): per chunk forward + store, backward with weights D_k - c (c = mean of
+      the first chunk, any constant is exact) AND backward with unit weights; afterwards
+      grad = (2/K) [G1 - (mean D - c) G0].  No forward recompute; costs one extra backward launch per chunk.
+  'recompute' (every other native mode): pass 1 = forward per chunk WITHOUT the store -> global sums / weights,
+      pass 2 = forward with the store (same Philox counters: bit-identical), [adjoint sweep,] backward.
+The reference keeps the whole autograd graph instead (SURVEY.md 7 "Activation memory").
 """
 import ctypes as C
 
@@ -24,6 +34,14 @@ except ImportError:
     import native as nat
     import native_shapes as shapes
     import sharding
+
+
+def _overridden(problem):
+    try:
+        from .problems import coefficients_overridden
+    except ImportError:
+        from problems import coefficients_overridden
+    return coefficients_overridden(problem)
 
 
 class PlanUnsupported(Exception):
@@ -57,6 +75,9 @@ def native_eligibility(solver):
     spec = spec_fn() if spec_fn is not None else None
     if spec is None:
         return 'problem has no native_spec() (coefficients outside the native catalogue)'
+    over = _overridden(solver.problem)
+    if over is not None:
+        return 'problem.%s is not the catalogue implementation native_spec() describes' % over
     if not nat.is_built():
         raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
     probe = nat.HjbConfig()
@@ -136,12 +157,13 @@ class HjbNativePlan:
         cfg.term = nat.ptr(dev_f32(pad.vec(spec['term'][1])))
         self.cfg = cfg
         assert sizes.n_params == pad.Pp, (sizes.n_params, pad.Pp)
-        self.sizes = sizes
+        self._setup_chunks(solver, cfg, sizes)
+        sizes = self.sizes
         # kernel-side (padded) parameter and gradient vectors; identical to the real ones when nothing is padded
         self.flat_k = self.flat if pad.identity else pad.new_padded_params()
         self.grad_k = None
         self.path = torch.empty(sizes.path_bytes // 4, dtype=torch.float32, device=dev)
-        self.fwd_partial = torch.empty(sizes.fwd_partial_bytes // 8, dtype=torch.float64, device=dev)
+        self.fwd_partial = torch.empty(max(1, self.n_chunks) * (sizes.fwd_partial_bytes // 8), dtype=torch.float64, device=dev)
         self.grad_partial = torch.empty(sizes.grad_partial_bytes // 4, dtype=torch.float32, device=dev)
         self.D = torch.empty(self.K_local, dtype=torch.float32, device=dev)
         self.Yn = torch.empty(self.K_local, dtype=torch.float32, device=dev) if self.generic_loss else None
@@ -175,6 +197,9 @@ class HjbNativePlan:
                 self.wT = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
         self.step = 0
         self.events = None   # bench.py: list collecting HIP-event pairs around the two rollout kernels
+        self.pass1_events = None
+        if self.n_chunks > 1:
+            self._alloc_chunks()
         # learnable Y_0 (solver.py:372-374): tiny Adam in torch on a 1-element tensor
         self.learn_y0 = bool(solver.learn_Y_0)
         if self.learn_y0:
@@ -201,6 +226,233 @@ class HjbNativePlan:
     def _stream(self):
         return nat.stream_ptr(self.dev)
 
+    # ---- K-chunking (module docstring) -------------------------------------------------------------------------------
+    DEFAULT_PATH_BUDGET = 96 * 2 ** 30          # a third of the 288 GB of HBM3E: chunk only when the store would not fit beside the rest
+
+    def _setup_chunks(self, solver, cfg, sizes):
+        """Decides the number of trajectory chunks from the path-store budget and re-queries the scratch sizes for one
+        chunk.  Sets self.n_chunks, self.chunk_K (trajectories per chunk, a multiple of 16), self.sizes, self.chunk_mode."""
+        budget = getattr(solver, 'path_budget_bytes', None) or self.DEFAULT_PATH_BUDGET
+        forced = getattr(solver, 'path_chunks', None)
+        n = int(forced) if forced else max(1, -(-int(sizes.path_bytes) // int(budget)))
+        n = min(n, max(1, (self.K_local + 15) // 16))
+        self.n_chunks, self.chunk_K, self.sizes = 1, self.K_local, sizes
+        self.chunk_mode = None
+        if n <= 1:
+            return
+        Kc = -(-self.K_local // n)
+        Kc = -(-Kc // 16) * 16
+        n = -(-self.K_local // Kc)
+        if n <= 1:
+            return
+        probe = nat.HjbConfig.from_buffer_copy(cfg)
+        probe.K_local = Kc
+        self.sizes = nat.query(probe)                    # the largest chunk sizes every scratch buffer
+        self.n_chunks, self.chunk_K = n, Kc
+        mode = getattr(solver, 'chunk_mode', 'auto')
+        simple = (not self.attached and not self.relent and not self.generic_loss)      # log-variance / moment, detached
+        if mode == 'auto':
+            mode = 'two_gradient' if simple else 'recompute'
+        if mode == 'two_gradient' and not simple:
+            raise PlanUnsupported("chunk_mode='two_gradient' needs a detached log-variance or moment run")
+        if mode not in ('two_gradient', 'recompute'):
+            raise ValueError("chunk_mode must be 'auto', 'two_gradient' or 'recompute'")
+        self.chunk_mode = mode
+
+    def _alloc_chunks(self):
+        """Per-chunk configs (K_local, k_offset and the per-trajectory output pointers moved to the chunk) and the small
+        per-chunk result rows; the big scratch buffers (path store, partial gradients) are shared by all chunks."""
+        dev, cfg, n, Kc = self.dev, self.cfg, self.n_chunks, self.chunk_K
+        self.chunks = []
+        for i in range(n):
+            off = i * Kc
+            k = min(Kc, self.K_local - off)
+            c = nat.HjbConfig.from_buffer_copy(cfg)
+            c.K_local, c.k_offset = k, self.k_offset + off
+            if self.ul2 is not None:
+                c.u_l2_out = nat.ptr(self.ul2, off)
+            c0 = nat.HjbConfig.from_buffer_copy(c)       # pass 1 of 'recompute': no path store
+            c0.store_path = 0
+            cw = nat.HjbConfig.from_buffer_copy(c)       # backward with explicit trajectory weights
+            cw.loss_kind = nat.LOSS_WEIGHTS
+            self.chunks.append((off, k, c, c0, cw))
+        self.sums_c = torch.zeros(n, 2, dtype=torch.float64, device=dev)
+        Pp = self.pad.Pp
+        self.grad_rows = torch.zeros(n, Pp, dtype=torch.float32, device=dev)
+        if self.chunk_mode == 'two_gradient' and self.s.loss_method == 'log-variance':
+            self.grad_rows0 = torch.zeros(n, Pp, dtype=torch.float32, device=dev)
+            self.w_chunk = torch.empty(Kc, dtype=torch.float32, device=dev)
+            self.ones_chunk = torch.ones(Kc, dtype=torch.float32, device=dev)
+        self.fp_stride = self.sizes.fwd_partial_bytes // 8
+
+    def _iteration_chunked(self, l, loss_out, ul2_out=None):
+        s, lib, cfg = self.s, self.lib, self.cfg
+        st = self._stream()
+        seed = int(s.seed) & 0xFFFFFFFFFFFFFFFF
+        xi_full = x0 = None
+        if self.noise == 'reference':
+            xi_full, x0 = self._reference_noise()
+        elif s.random_X_0:
+            g = torch.Generator(device=self.dev)
+            g.manual_seed(int(s.seed) * 1000003 + l)
+            x0 = self.pad.last_dim(torch.randn(s.K, s.d, generator=g, device=self.dev)[
+                self.k_offset:self.k_offset + self.K_local].contiguous())
+        flat_k = self.pad.scatter_params(self.flat, self.flat_k)
+        y0_ptr = nat.ptr(self.y0_param) if self.learn_y0 else None
+        K = float(s.K)
+
+        def fwd(i, c, store):
+            off, k = self.chunks[i][0], self.chunks[i][1]
+            xi = xi_full[:, off:off + k].contiguous() if xi_full is not None else None
+            x0_p, x0_stride = (nat.ptr(x0, off * self.d_pad), self.d_pad) if x0 is not None else (nat.ptr(self.x0_vec), 0)
+            nat.check(lib.psp_hjb_rollout_fwd(C.byref(c), nat.ptr(flat_k), x0_p, x0_stride, y0_ptr, nat.ptr(xi), seed, l,
+                                              nat.ptr(self.path) if store else None, nat.ptr(self.D, off),
+                                              nat.ptr(self.XN_k, off * self.d_pad) if (self.attached and store) else None,
+                                              nat.ptr(self.Yn, off) if self.Yn is not None else None,
+                                              nat.ptr(self.fwd_partial, i * self.fp_stride), st), 'psp_hjb_rollout_fwd')
+            nat.check(lib.psp_hjb_terminal_reduce(C.byref(c), nat.ptr(self.fwd_partial, i * self.fp_stride),
+                                                  nat.ptr(self.sums_c, 2 * i), st), 'psp_hjb_terminal_reduce')
+            return xi
+
+        def bwd(i, c, w_t, w_off, out_rows, xi):
+            nat.check(lib.psp_hjb_rollout_bwd(C.byref(c), nat.ptr(flat_k), nat.ptr(xi), seed, l, nat.ptr(self.path),
+                                              nat.ptr(w_t, w_off), nat.ptr(self.sums), nat.ptr(self.grad_partial),
+                                              nat.ptr(out_rows, i * self.pad.Pp), st), 'psp_hjb_rollout_bwd')
+
+        def events():
+            if self.events is None:
+                return None
+            return [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+        if self.chunk_mode == 'two_gradient':
+            logvar = s.loss_method == 'log-variance'
+            for i, (off, k, c, c0, cw) in enumerate(self.chunks):
+                ev = events()
+                if ev:
+                    ev[0].record()
+                xi = fwd(i, c, True)
+                if ev:
+                    ev[1].record()
+                if logvar:
+                    if i == 0:
+                        shift = (self.sums_c[0, 0] / float(k)).to(torch.float32)       # device scalar, no sync
+                    torch.sub(self.D[off:off + k], shift, out=self.w_chunk[:k])
+                    if ev:
+                        ev[2].record()
+                    bwd(i, cw, self.w_chunk, 0, self.grad_rows, xi)
+                    if ev:
+                        ev[3].record()
+                        self.events.append(ev)
+                    bwd(i, cw, self.ones_chunk, 0, self.grad_rows0, xi)
+                else:                                    # moment: w_k = (2/K) D_k needs nothing global
+                    if ev:
+                        ev[2].record()
+                    bwd(i, c, self.D, off, self.grad_rows, xi)
+                    if ev:
+                        ev[3].record()
+                        self.events.append(ev)
+            torch.sum(self.sums_c, 0, out=self.sums)
+            sharding.allreduce_sum_(self.sums)           # collective 1: 16 bytes
+            loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
+            if logvar:
+                g1, g0 = self.grad_rows.sum(0), self.grad_rows0.sum(0)
+                corr = (self.sums[0] / K - shift.double()).to(torch.float32)
+                torch.mul(g1 - corr * g0, 2.0 / K, out=self.grad_k)
+            else:
+                torch.sum(self.grad_rows, 0, out=self.grad_k)
+        else:
+            # pass 1: forward without the path store -> D, global sums, loss weights
+            p1 = None
+            if self.pass1_events is not None:
+                p1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                p1[0].record()
+            for i, (off, k, c, c0, cw) in enumerate(self.chunks):
+                fwd(i, c0, False)
+            if p1:
+                p1[1].record()
+                self.pass1_events.append(p1)
+            torch.sum(self.sums_c, 0, out=self.sums)
+            sharding.allreduce_sum_(self.sums)           # collective 1
+            w_t, use_w = self.D, False
+            if self.generic_loss:
+                loss, w_t = self._generic_loss_weights()
+                use_w = True
+            else:
+                loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
+            if self.attached:
+                wT = None
+                if self.relent:
+                    self.mu.zero_()
+                    self.nu.fill_(1.0 / K)
+                elif self.generic_loss:
+                    self.mu.copy_(w_t)
+                    if s.loss_method == 'cross_entropy':
+                        wT = self.wT
+                        wT.copy_(-self.Yn * w_t)
+                else:
+                    self.mu.copy_(sharding.loss_weights(self.D, self.sums, s.K, s.loss_method))
+                self.w_bwd.fill_(1.0)
+                w_t, use_w = self.w_bwd, True
+            elif self.relent:
+                self.w_bwd.fill_(float(cfg.sqrt_dt) / K)
+                w_t, use_w = self.w_bwd, True
+            # pass 2: forward with the store (bit-identical rollout), [adjoint sweep,] backward
+            for i, (off, k, c, c0, cw) in enumerate(self.chunks):
+                ev = events()
+                if ev:
+                    ev[0].record()
+                xi = fwd(i, c, True)
+                if ev:
+                    ev[1].record()
+                    ev[2].record()
+                if self.attached:
+                    nat.check(lib.psp_hjb_adjoint_sweep(C.byref(c), nat.ptr(flat_k), nat.ptr(self.path),
+                                                        nat.ptr(self.XN_k, off * self.d_pad), nat.ptr(self.mu, off),
+                                                        nat.ptr(self.nu, off) if self.relent else None,
+                                                        nat.ptr(wT, off) if wT is not None else None,
+                                                        nat.ptr(self.fwd_partial, i * self.fp_stride), st), 'psp_hjb_adjoint_sweep')
+                bwd(i, cw if use_w else c, w_t, off, self.grad_rows, xi)
+                if ev:
+                    ev[3].record()
+                    self.events.append(ev)
+            torch.sum(self.grad_rows, 0, out=self.grad_k)
+        loss_out[l] = loss.to(torch.float32)
+        if self.ul2 is not None and ul2_out is not None:
+            m = (self.ul2.sum() / K).reshape(1)
+            sharding.allreduce_sum_(m)
+            ul2_out[l:l + 1] = m
+        self._finish_step(st, self.w if self.generic_loss else None)
+        return loss
+
+    def _finish_step(self, st, w_generic):
+        """Gather the real gradient entries, all-reduce, Adam on the net and on the learnable Y_0."""
+        s, lib = self.s, self.lib
+        self.pad.gather_grad(self.grad_k, self.grad)    # real entries of the (possibly padded) gradient
+        sharding.allreduce_sum_(self.grad)              # collective 2: p floats
+        self.step += 1
+        lr, b1, b2, eps = self._adam_hyper()
+        nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
+                                    self.P, self.step, lr, b1, b2, eps, st), 'psp_adam_step')
+        if self.learn_y0:
+            # dL/dY_0 = sum_k dL/dY_k ; log-variance: exactly 0 ; moment: (2/K) sum D (global sums) ; variance: sum of the weights
+            self.y0_grad[0] = sharding.y0_gradient(self.sums, s.K, s.loss_method, w_generic)
+            ylr, yb1, yb2, yeps = self._adam_hyper(s.y_0)
+            nat.check(lib.psp_adam_step(nat.ptr(self.y0_param), nat.ptr(self.y0_grad), nat.ptr(self.y0_m),
+                                        nat.ptr(self.y0_v), 1, self.step, ylr, yb1, yb2, yeps, st),
+                      'psp_adam_step(Y_0)')
+
+    def _adam_hyper(self, net=None):
+        """lr, betas, eps of the net's OWN optimiser (function_space.py:185: each ansatz space builds its Adam in its
+        constructor, solver.py:198-200 steps every Phi's) -- a swapped-in net keeps its learning rate."""
+        opt = getattr(net if net is not None else self.net, 'optim', None)
+        if opt is not None and len(opt.param_groups) > 0:
+            g = opt.param_groups[0]
+            if g.get('weight_decay', 0) or g.get('amsgrad', False):
+                raise PlanUnsupported('the native Adam implements weight_decay = 0, amsgrad = False (the reference default)')
+            b = g.get('betas', (0.9, 0.999))
+            return float(g['lr']), float(b[0]), float(b[1]), float(g.get('eps', 1e-8))
+        return float(self.s.lr), 0.9, 0.999, 1e-8
+
     def _reference_noise(self):
         """The reference's per-iteration draws from the CPU generator (solver.py:367,381),
         re-laid-out as (N+1, K_local, d) for coalesced per-step reads."""
@@ -217,6 +469,8 @@ class HjbNativePlan:
     def iteration(self, l, loss_out, ul2_out=None):
         """One training iteration; writes the fp32 loss into loss_out[l] (and mean u_L2 into ul2_out[l]) on the
         device, no sync."""
+        if self.n_chunks > 1:
+            return self._iteration_chunked(l, loss_out, ul2_out)
         s, lib, cfg = self.s, self.lib, self.cfg
         st = self._stream()
         seed = int(s.seed) & 0xFFFFFFFFFFFFFFFF
@@ -287,17 +541,7 @@ class HjbNativePlan:
         if ev is not None:
             ev[3].record()
             self.events.append(ev)
-        self.pad.gather_grad(self.grad_k, self.grad)    # real entries of the (possibly padded) gradient
-        sharding.allreduce_sum_(self.grad)              # collective 2: p floats
-        self.step += 1
-        nat.check(lib.psp_adam_step(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v),
-                                    self.P, self.step, float(s.lr), 0.9, 0.999, 1e-8, st), 'psp_adam_step')
-        if self.learn_y0:
-            # dL/dY_0 = sum_k w_k ; log-variance: exactly 0 ; moment: (2/K) sum D (global sums)
-            self.y0_grad[0] = sharding.y0_gradient(self.sums, s.K, s.loss_method)
-            nat.check(lib.psp_adam_step(nat.ptr(self.y0_param), nat.ptr(self.y0_grad), nat.ptr(self.y0_m),
-                                        nat.ptr(self.y0_v), 1, self.step, float(s.lr), 0.9, 0.999, 1e-8, st),
-                      'psp_adam_step(Y_0)')
+        self._finish_step(st, self.w if self.generic_loss else None)
         # keep xi alive until the kernels that read it are enqueued on this stream (they are);
         # torch's caching allocator is stream-ordered, so freeing here is safe.
         return loss

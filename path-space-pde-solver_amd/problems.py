@@ -31,6 +31,19 @@ def _resolve(device):
     return default_device() if device is None else torch.device(device)
 
 
+def coefficients_overridden(problem, names=('b', 'sigma', 'h', 'f', 'g')):
+    """Name of a coefficient method that is NOT this module's catalogue implementation (a subclass override or an attribute
+    patched onto the instance), else None.  native_spec() / general_native_spec() describe the catalogue formulas, so a
+    problem whose b / sigma / h / f / g was replaced must run on the composite torch plan, which calls the Python methods."""
+    for name in names:
+        if name in getattr(problem, '__dict__', {}):
+            return name
+        fn = getattr(type(problem), name, None)
+        if fn is not None and getattr(fn, '__module__', None) != __name__:
+            return name
+    return None
+
+
 def _classify_matrix(M):
     """'identity' | ('scaled', s) | ('diag', vec) | 'dense' for a square matrix."""
     Mc = M.detach().cpu()

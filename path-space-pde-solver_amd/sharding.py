@@ -30,11 +30,23 @@ def shard_bounds(K, rank, world):
     return rank * per, (rank + 1) * per
 
 
+# bench.py sets this to a list to collect (start_event, end_event, bytes) of every device all-reduce: HIP events on the
+# launch stream, which waits for the collective (torch's synchronous all_reduce makes the current stream wait on RCCL's)
+coll_events = None
+
+
 def allreduce_sum_(t):
     """In-place SUM all-reduce when a process group is initialised; no-op otherwise."""
     dist, _, world = dist_info()
     if world > 1:
-        dist.all_reduce(t)
+        if coll_events is not None and t.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(t)
+            e1.record()
+            coll_events.append((e0, e1, t.numel() * t.element_size()))
+        else:
+            dist.all_reduce(t)
     return t
 
 
@@ -62,8 +74,14 @@ def loss_weights(D_local, sums, K_global, loss_method):
     raise ValueError(loss_method)
 
 
-def y0_gradient(sums, K_global, loss_method):
-    """d loss / d Y_0 = sum_k w_k over ALL ranks: (2/K) sum D for moment, exactly 0 for log-variance."""
+def y0_gradient(sums, K_global, loss_method, w_local=None):
+    """d loss / d Y_0 = sum_k dLoss/dY_k over ALL ranks (Y = y_0(X) + ..., solver.py:372-373): (2/K) sum D for moment,
+    exactly 0 for log-variance and relative entropy; for the losses whose weights are formed on the host side (variance,
+    cross_entropy: w_local = this rank's dLoss/dY_k) the all-reduced sum of the weights."""
     if loss_method == 'moment':
         return (2.0 / float(K_global)) * sums[0]
+    if w_local is not None and loss_method not in ('log-variance', 'relative_entropy'):
+        tot = w_local.double().sum().reshape(1)
+        allreduce_sum_(tot)
+        return tot[0]
     return torch.zeros((), dtype=sums.dtype, device=sums.device)

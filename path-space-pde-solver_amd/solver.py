@@ -18,7 +18,9 @@ save_logs``) as the reference, so notebooks written against it run unchanged, in
 Extra keywords (all optional, appended after the reference's): ``device``, ``backend``
 ('auto' | 'native' | 'torch'), ``noise`` ('reference' = the reference's CPU-generator stream,
 bit-compatible with its fixed-seed runs; 'philox' = on-device counter-based stream),
-``widths`` (hidden widths of the default control net; the reference hard-codes [30, 30]).
+``widths`` (hidden widths of the default control net; the reference hard-codes [30, 30]),
+``path_budget_bytes`` / ``path_chunks`` / ``chunk_mode`` (K-chunking of the native plan when the path store
+would not fit in HBM; the reference holds the whole autograd graph instead).
 """
 import json
 import os
@@ -59,7 +61,8 @@ class Solver:
                  IS_variance_K=0, IS_variance_iter=1, metastability_logs=None, print_every=100,
                  plot_trajectories=None, seed=42, save_results=False, u_l2_error_flag=True,
                  log_gradient=False, burgers_drift=False, verbose=True,
-                 device=None, backend='auto', noise='reference', widths=(30, 30), mlp_dtype='fp32'):
+                 device=None, backend='auto', noise='reference', widths=(30, 30), mlp_dtype='fp32',
+                 path_budget_bytes=None, path_chunks=None, chunk_mode='auto'):
         self.problem, self.name = problem, name
         self.date = date.today().strftime('%Y-%m-%d')
         self.d, self.T = problem.d, problem.T
@@ -75,6 +78,9 @@ class Solver:
         if mlp_dtype not in ('fp32', 'bf16'):
             raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
         self.mlp_dtype = mlp_dtype       # 'bf16': control-net products of the native forward rollout on bf16 MFMA (opt-in, own tolerance)
+        # native plan: HBM budget of the path store kept for the backward pass (None: a third of the HBM); a larger store is
+        # processed in K-chunks (plan_native.py).  path_chunks forces a chunk count; chunk_mode 'auto' | 'two_gradient' | 'recompute'
+        self.path_budget_bytes, self.path_chunks, self.chunk_mode = path_budget_bytes, path_chunks, chunk_mode
 
         # hyper-parameters (reference solver.py:36-45): fp32 step, float64 step count
         self.seed = seed
@@ -248,6 +254,15 @@ class Solver:
         return (X, Y, *zeros, xi)
 
     # ---- training -----------------------------------------------------------------------------
+    def _plan_key(self):
+        """Everything a native plan sizes its buffers / fixes its kernel configuration from: a plan built for other values
+        must not be reused (the nets themselves are compared by identity)."""
+        nets = tuple(id(z) for z in self.z_n) if isinstance(getattr(self, 'z_n', None), list) else (id(getattr(self, 'z_n', None)),)
+        return (nets, self.noise, self.K, self.N, float(self.delta_t_np), self.loss_method, self.approx_method,
+                self.time_approx, bool(self.learn_Y_0), bool(self.adaptive_forward_process), bool(self.detach_forward),
+                bool(self.random_X_0), bool(self.u_l2_error_flag), self.mlp_dtype, self.path_budget_bytes, self.path_chunks,
+                self.chunk_mode, id(self.problem), id(self.y_0) if hasattr(self, 'y_0') else None)
+
     def _choose_plan(self):
         if self.backend == 'torch':
             self.plan_name, self.plan_reason = 'torch', "backend='torch' requested"
@@ -256,16 +271,18 @@ class Solver:
         if reason is None:
             self.plan_name, self.plan_reason = 'native', None
             plan = getattr(self, '_native_plan', None)
-            if plan is None or plan.net is not self.z_n or plan.noise != self.noise:
+            if plan is None or not isinstance(plan, HjbNativePlan) or getattr(plan, 'key', None) != self._plan_key():
                 plan = HjbNativePlan(self, noise=self.noise)     # owns the flat parameters and Adam moments
+                plan.key = self._plan_key()
                 self._native_plan = plan
             return plan
         dense_reason = dense_eligibility(self)  # DenseNet controls: time_approx='outer', DenseNet swapped into z_n
         if dense_reason is None:
             self.plan_name, self.plan_reason = 'native', None
             plan = getattr(self, '_native_plan', None)
-            if plan is None or plan.net is not self.z_n or plan.noise != self.noise or not isinstance(plan, DenseNativePlan):
+            if plan is None or not isinstance(plan, DenseNativePlan) or getattr(plan, 'key', None) != self._plan_key():
                 plan = DenseNativePlan(self, noise=self.noise)
+                plan.key = self._plan_key()
                 self._native_plan = plan
             return plan
         z = getattr(self, 'z_n', None)                  # (approx_method='value_function' has y_n instead)

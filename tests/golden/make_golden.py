@@ -343,6 +343,11 @@ CASES = [
          problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
          solver=dict(HJB, loss_method="variance", L=5, lr=0.01, seed=42, delta_t=0.05, K=128,
                      u_l2_error_flag=False)),
+    # variance loss with a learnable Y_0: Y = y_0 + ... enters var(exp(-g + Y)), so dL/dY_0 = sum_k w_k != 0 (solver.py:171-172, 372-374)
+    dict(name="lqgc_d2_variance_learn_y0", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
+         solver=dict(HJB, loss_method="variance", learn_Y_0=True, L=6, lr=0.01, seed=42, delta_t=0.05, K=128,
+                     u_l2_error_flag=False)),
     dict(name="lqgc_d2_cross_entropy", family="solver",
          problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=1, seed=42, delta_t=0.05)),
          solver=dict(HJB, loss_method="cross_entropy", L=5, lr=0.01, seed=42, delta_t=0.05, K=128,

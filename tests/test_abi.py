@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_support_table(lib):
-    assert lib.psp_version() == 100
+    assert lib.psp_version() == 200
     assert nat.supported(100, 64) and nat.supported(2, 30)
     assert not nat.supported(3, 7)
 
@@ -88,3 +88,17 @@ def test_struct_layouts_match_the_header():
     names = ("HjbConfig", "HjbSizes", "GenConfig", "GenSizes", "DnetConfig", "DnetSizes")
     for n, got in zip(names, sizes):
         assert C.sizeof(getattr(nat, n)) == got, n
+
+
+def test_collective_entry_points_validate_arguments(lib):
+    """psp_allreduce / psp_comm_* (include/psp.h): argument checks only -- a communicator needs a GPU."""
+    assert lib.psp_allreduce(None, 4, nat.DT_F32, None, None) != 0
+    assert "null" in nat.last_error()
+    buf = (C.c_float * 4)()
+    fake = C.c_void_p(1)
+    assert lib.psp_allreduce(buf, 0, nat.DT_F32, fake, None) != 0
+    assert lib.psp_allreduce(buf, 4, 7, fake, None) != 0 and "dtype" in nat.last_error()
+    comm = C.c_void_p()
+    ident = (C.c_ubyte * nat.COMM_ID_BYTES)()
+    assert lib.psp_comm_init(C.byref(comm), 2, 5, ident) != 0
+    assert lib.psp_comm_destroy(None) == 0

@@ -23,7 +23,7 @@ NATIVE_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_l
                 "llgc_d500_h64_logvar", "llgc_d7_default_logvar", "lqgc_d33_h50_logvar", "dw_d70_h64_logvar", "llgc_d105_h64_logvar",
                 "llgc_d300_h40_logvar", "dw_d10_logvar",
                 "llgc_d20_diag_logvar", "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive",
-                "lqgc_d2_variance", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive",
+                "lqgc_d2_variance", "lqgc_d2_variance_learn_y0", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive",
                 # gradients through the state path (adjoint sweep) and the relative-entropy loss
                 "lqgc_d2_attached_logvar", "llgc_d100_h64_attached_logvar", "dw_d10_attached_moment",
                 "lqgc_d4_relative_entropy", "llgc_d20_relative_entropy_detached",

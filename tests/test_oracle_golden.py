@@ -20,7 +20,7 @@ SOLVER_CASES = ["llgc_d12_outer_moment", "dw_d20_densenet_nonadaptive", "lqgc_d6
                 "lqgc_d2_attached_cross_entropy", "llgc_d200_nonadaptive_logvar",
                 "llgc_d100_densenet64_logvar", "dw_d10_logvar", "llgc_d20_diag_logvar",
                 "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive", "lqgc_d2_outer",
-                "lqgc_d2_variance", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
+                "lqgc_d2_variance", "lqgc_d2_variance_learn_y0", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
 GENERAL_CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
                  "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde"]
 
