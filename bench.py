@@ -121,11 +121,13 @@ def issued_mfma_per_tile_step(d_pad, H_pad, dense, family, bf16_mlp=False):
     loop bounds and confirmed by SQ_INSTS_MFMA at the headline shape (626 forward / 452 backward per tile-step,
     profiles/r1_pmc_summary.md).  Returns (fwd_f32, fwd_bf16, bwd_f32)."""
     DB, HB = _cdiv(d_pad, 16), _cdiv(H_pad, 16)
-    ks_d = _cdiv(d_pad + 1, 4) if family == 2 else _cdiv(d_pad, 4)     # wide family: the time row rides in the W1 product
-    ks_h = _cdiv(H_pad, 4)
+    # k-steps of a d-deep contraction: the narrow family stops at ceil(d / 4); the wide family's rolled loops run over whole
+    # 16-feature blocks (GeoW::KP = 4 * DB)
+    ks_d = 4 * DB if family == 2 else _cdiv(d_pad, 4)
+    ks_h = 16 if family == 2 else _cdiv(H_pad, 4)
     net = ks_d * HB + ks_h * HB + ks_h * DB
-    sde = 2 * _cdiv(d_pad, 4) * DB if dense else 0
-    bwd = 4 * (DB * HB + HB * HB + HB * DB) + _cdiv(d_pad, 4) * HB + ks_h * HB
+    sde = 2 * ks_d * DB if dense else 0
+    bwd = 4 * (DB * HB + HB * HB + HB * DB) + ks_d * HB + ks_h * HB
     if bf16_mlp:                                                       # 16x16x32: one k-step spans 32 features
         net_bf = _cdiv(d_pad, 32) * HB + _cdiv(H_pad, 32) * HB + _cdiv(H_pad, 32) * DB
         return sde, net_bf, bwd
@@ -437,23 +439,35 @@ def main():
     plan = model._choose_plan()
     assert model.plan_name == "native"
     N_t = model.N
-    losses = torch.zeros(total, dtype=torch.float32, device=dev)
+    n_eager = 6                                          # eager iterations after the timed region (graph workloads only)
+    losses = torch.zeros(total + n_eager, dtype=torch.float32, device=dev)
     for l in range(args.warmup):
         plan.iteration(l, losses)
 
     c_abi = check_c_abi_allreduce(psp, dist, rank, world, dev, rehearsal)
-    plan.events = []                                     # (fwd_start, fwd_end, bwd_start, bwd_end) per launch pair
+    graph = bool(getattr(plan, "_graph_wanted", lambda: False)())
     if getattr(plan, "n_chunks", 1) > 1:
         plan.pass1_events = []
     sharding.coll_events = [] if world > 1 else None
-    elapsed = timed_region(dist, dev, lambda l: plan.iteration(l, losses), args.steps, args.warmup)
+    if graph:
+        # launch-bound iteration replayed as a hipGraph: `value` is timed on the replay; the per-kernel HIP events of the
+        # roofline come from a few eager iterations of the same kernels AFTER the timed region
+        elapsed = timed_region(dist, dev, lambda l: plan.iteration(l, losses), args.steps, args.warmup)
+        plan.events = []
+        for l in range(total, total + n_eager):
+            plan.iteration(l, losses)
+        torch.cuda.synchronize()
+        plan.events = plan.events[1:]
+    else:
+        plan.events = []                                 # (fwd_start, fwd_end, bwd_start, bwd_end) per launch pair
+        elapsed = timed_region(dist, dev, lambda l: plan.iteration(l, losses), args.steps, args.warmup)
 
     n_ev = max(1, len(plan.events))
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in plan.events) / n_ev
     bwd_ms = sum(e[2].elapsed_time(e[3]) for e in plan.events) / n_ev
     coll = collective_summary(sharding, args.steps)
     sharding.coll_events = None
-    loss_vals = losses.cpu().tolist()
+    loss_vals = losses.cpu().tolist()[:total]
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -526,10 +540,11 @@ def main():
                    "mlp": ("%d x DenseNet %d-%d-%d-%d relu^2, one per time step (time_approx='outer')" % (N_t, w["d"], w["H"], w["H"], w["d"]))
                           if outer else "%d-%d-%d-%d tanh" % (w["d"] + 1, w["H"], w["H"], w["d"]),
                    "loss": "log-variance", "noise": "on-device Philox4x32-10",
+                   "launch": "hipGraph replay of the captured iteration" if graph else "eager launches",
                    "parallelism": "trajectory-sharded x%d (%s)" % (world, "gloo rehearsal on one GPU" if rehearsal else
                                                                     ("RCCL" if world > 1 else "single process")),
-                   "path_store": ("K-chunked two-pass plan: %d chunks of %d trajectories, forward recomputed once (%.1f GB store)"
-                                  % (n_chunks, K_launch, plan.sizes.path_bytes / 1e9)) if n_chunks > 1 else
+                   "path_store": ("K-chunked plan (%s): %d chunks of %d trajectories share a %.1f GB store"
+                                  % (plan.chunk_mode, n_chunks, K_launch, plan.sizes.path_bytes / 1e9)) if n_chunks > 1 else
                                  ("resident (%.1f GB)" % (plan.sizes.path_bytes / 1e9) if hasattr(plan, "sizes") else "resident")},
         "roofline": roof,
         "loss_first_last": [loss_vals[0], loss_vals[-1]],

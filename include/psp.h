@@ -95,6 +95,9 @@ typedef struct psp_hjb_config {
                            * v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulate); drift / sigma products, state,
                            * sums and the backward pass stay fp32.  Narrow kernel family only (-3 otherwise)          */
     int32_t reserved2;
+    const uint32_t* iter_dev; /* optional DEVICE-resident iteration counter (the `iter` member of a psp_iter_state): when set, the
+                           * forward kernels key Philox with *iter_dev instead of the `iter` argument, so that a captured
+                           * hipGraph of the iteration can be replayed without per-iteration host arguments.  NULL: `iter` */
 } psp_hjb_config;
 
 /* Sizes of the caller-owned scratch buffers for a config. */
@@ -209,6 +212,36 @@ int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float*
  * (function_space.py:185, solver.py:198-200).  step is 1-based. */
 int psp_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   int32_t step, float lr, float beta1, float beta2, float eps, void* stream);
+
+/*
+ * Launch-bound regime (BASELINE.json configs[1]: K = 1024, N = 50 -- a whole iteration is ~0.3 ms): the six launches of an
+ * iteration are captured ONCE into a hipGraph by the caller (any stream-capture API: the entry points only enqueue
+ * kernels on the given stream) and replayed.  Everything that changes from one iteration to the next then has to live in
+ * device memory: psp_iter_state holds the Philox iteration index and Adam's step count / running beta powers;
+ *   psp_hjb_config.iter_dev = &state->iter         forward kernels
+ *   psp_hjb_terminal_reduce_loss(..., &state->iter) partial sums -> (sum D, sum D^2) AND the loss value of solver.py:167-168 /
+ *                                                   :165-166 / :179-180 into loss_log[state->iter] (single rank: the local
+ *                                                   sums are the global ones; replaces six tiny element-wise launches)
+ *   psp_adam_step_dev                               Adam with bias corrections 1 - beta^step taken from the state
+ *   psp_iter_state_advance                          iter += 1, step += 1, beta powers *= beta (last node of the graph)
+ */
+typedef struct psp_iter_state {
+    uint32_t iter;        /* iteration index l of Solver.train (Philox counter, index into the loss log) */
+    uint32_t step;        /* 1-based Adam step the NEXT psp_adam_step_dev applies                        */
+    double beta1_pow;     /* beta1 ** step, beta2 ** step (fp64, as torch forms its bias corrections)    */
+    double beta2_pow;
+} psp_iter_state;
+/* Fills a HOST copy (the caller uploads it): state for iteration `iter` whose Adam step is `step` (1-based). */
+int psp_iter_state_init(psp_iter_state* host_out, uint32_t iter, int32_t step, float beta1, float beta2);
+int psp_iter_state_advance(psp_iter_state* dev_state, float beta1, float beta2, void* stream);
+/* psp_hjb_terminal_reduce + the loss of cfg->loss_kind (log-variance / moment / relative entropy) from these sums with
+ * K = cfg->K_global, written as fp32 to loss_log[index_dev ? *index_dev : 0].  Only valid when the rank's sums ARE the
+ * global sums (one rank); with several ranks call psp_hjb_terminal_reduce, all-reduce, and form the loss from the result. */
+int psp_hjb_terminal_reduce_loss(const psp_hjb_config* cfg, const double* fwd_partial, double* sums_out, float* loss_log,
+                                 const uint32_t* index_dev, void* stream);
+/* psp_adam_step with step / bias corrections read from a device psp_iter_state. */
+int psp_adam_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const psp_iter_state* dev_state, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* Materialises the device noise stream exactly as the rollout kernels consume it:
  * out is (N+1, K_local, d) fp32 with slice 0 zero.  Test / diagnostics helper. */

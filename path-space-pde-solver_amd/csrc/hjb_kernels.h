@@ -47,6 +47,7 @@ struct HjbArgs {
     const float* adj_mu;       // adjoint sweep (hjba_kernels.h): dL/dY_N per trajectory
     const float* adj_nu;       //                                  dL/dZsum_N per trajectory (relative entropy), may be null
     const float* adj_wT;       //   weight of grad g(X_N) in lambda_N per trajectory; null: nu - mu (losses of Y_N - g(X_N))
+    const uint32_t* iter_dev;  // optional device-resident iteration counter (hipGraph replay); null: `iter` below
     long long k_offset;
     long long K_global;
     int x0_stride;
@@ -352,6 +353,7 @@ struct Geo {
 // mode with its own tolerance (psp_hjb_config.mlp_dtype); the drift / sigma products, the state and every sum stay fp32.
 template <int D, int H, bool BF16 = false>
 __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
+    const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             for (int b = 0; b < DB; ++b) {
                 f32x4 xi;
                 if (a.noise_mode == NOISE_PHILOX) {
-                    xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
+                    xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), iter_now, a.seed_lo, a.seed_hi);
                 } else {
                     // unconditional clamped loads + select: no per-element branch around the load
                     const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;

@@ -31,6 +31,7 @@ struct GeoS {
 
 template <int D, int H>
 __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
+    const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     using S_ = GeoS<D, H>;
     constexpr int DB = S_::DB, HB = S_::HB, KP = S_::KP, KH = S_::KH, NBo = S_::NBo, NHo = S_::NHo;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
             if (sb < DB) {
                 f32x4 xi;
                 if (a.noise_mode == NOISE_PHILOX) {
-                    xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * sb + qn), a.iter, a.seed_lo, a.seed_hi);
+                    xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * sb + qn), iter_now, a.seed_lo, a.seed_hi);
                 } else {
                     const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
 #pragma unroll

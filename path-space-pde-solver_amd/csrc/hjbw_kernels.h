@@ -214,6 +214,7 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
 // sits on the 512-register limit and two more live accumulators cost the ordinary path 8 % (measured)
 template <int D, int H, bool LOGU = false>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const HjbArgs a) {
+    const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
                     const int b = 4 * g + m;
                     f32x4 xi;
                     if (a.noise_mode == NOISE_PHILOX) {
-                        xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + qn), a.iter, a.seed_lo, a.seed_hi);
+                        xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + qn), iter_now, a.seed_lo, a.seed_hi);
                     } else {
                         const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
 #pragma unroll

@@ -180,6 +180,7 @@ void fill_args(const psp_hjb_config* c, const Plan& p, psp::HjbArgs* a) {
     a->term_kind = c->term_kind; a->adaptive = c->adaptive; a->loss_kind = c->loss_kind;
     a->noise_mode = c->noise_mode; a->store_path = c->store_path;
     a->uref = c->u_ref; a->ul2 = c->u_l2_out;
+    a->iter_dev = c->iter_dev;
     // diagnostic stamp buffer: [forward: fwd_grid x 8 waves x 8][backward: bwd_grid x 4 waves x 8]
     a->dbg = (g_dbg && g_dbg_n >= ((long long)p.fwd_grid * 8 + (long long)p.bwd_grid * 8) * 8) ? g_dbg : nullptr;
 }
@@ -259,6 +260,51 @@ __global__ void reduce_partials_kernel(const double* __restrict__ part, int n, d
         __syncthreads();
     }
     if (threadIdx.x == 0) { out[0] = s0[0]; out[1] = s1[0]; }
+}
+
+// partial sums -> (sum D, sum D^2) and the loss value (single rank: local sums are global)
+__global__ void reduce_partials_loss_kernel(const double* __restrict__ part, int n, double* __restrict__ out, int loss_kind,
+                                            double invK, float* __restrict__ loss_log, const uint32_t* __restrict__ index_dev) {
+    __shared__ double s0[256], s1[256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { s0[threadIdx.x] += s0[threadIdx.x + w]; s1[threadIdx.x] += s1[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = s0[0]; out[1] = s1[0];
+        if (loss_log) {
+            const double m = s0[0] * invK;
+            double loss = s1[0] * invK - m * m;                       // log-variance: mean(D^2) - mean(D)^2 (solver.py:167-168)
+            if (loss_kind == PSP_LOSS_MOMENT) loss = s1[0] * invK;    // :165-166
+            if (loss_kind == PSP_LOSS_REL_ENTROPY) loss = -m;         // D = -(Zsum + g) (:179-180)
+            loss_log[index_dev ? *index_dev : 0u] = (float)loss;
+        }
+    }
+}
+
+__global__ void iter_advance_kernel(psp_iter_state* st, double b1, double b2) {
+    st->iter += 1u; st->step += 1u; st->beta1_pow *= b1; st->beta2_pow *= b2;
+}
+
+// Adam with the bias corrections of the step held in a device psp_iter_state (same arithmetic as adam_kernel: the host
+// path forms step_size = lr / (1 - b1^step) and sqrt(1 - b2^step) in double and rounds to fp32, so does every thread here)
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long long n, const psp_iter_state* __restrict__ st, float lr, float b1,
+                                float b2, float eps) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float step_size = (float)((double)lr / (1.0 - st->beta1_pow));
+    const float bc2_sqrt = (float)sqrt(1.0 - st->beta2_pow);
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
 }
 
 __global__ void reduce_grad_kernel(const float* __restrict__ part, int nwg, int P, float* __restrict__ out) {
@@ -346,6 +392,7 @@ extern "C" {
 
 int psp_version(void) { return PSP_VERSION; }
 int psp_abi_struct_sizes(int32_t out[6]) {
+    static_assert(sizeof(psp_iter_state) == 24, "psp_iter_state layout");
     if (!out) return fail(-1, "null output");
     out[0] = (int32_t)sizeof(psp_hjb_config); out[1] = (int32_t)sizeof(psp_hjb_sizes);
     out[2] = (int32_t)sizeof(psp_gen_config); out[3] = (int32_t)sizeof(psp_gen_sizes);
@@ -599,6 +646,49 @@ int psp_hjb_terminal_reduce(const psp_hjb_config* cfg, const double* fwd_partial
                        p.fwd_grid, sums_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_partials_kernel launch");
+    return 0;
+}
+
+int psp_hjb_terminal_reduce_loss(const psp_hjb_config* cfg, const double* fwd_partial, double* sums_out, float* loss_log,
+                                 const uint32_t* index_dev, void* stream) {
+    Plan p;
+    int rc = make_plan(cfg, &p);
+    if (rc) return rc;
+    if (!fwd_partial || !sums_out) return fail(-1, "null buffer passed to psp_hjb_terminal_reduce_loss");
+    if (loss_log && cfg->loss_kind == PSP_LOSS_WEIGHTS)
+        return fail(-1, "psp_hjb_terminal_reduce_loss: the caller forms the loss of a PSP_LOSS_WEIGHTS run");
+    if (cfg->K_global <= 0) return fail(-1, "K_global must be positive");
+    hipLaunchKernelGGL(reduce_partials_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fwd_partial, p.fwd_grid,
+                       sums_out, cfg->loss_kind, 1.0 / (double)cfg->K_global, loss_log, index_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "reduce_partials_loss_kernel launch");
+    return 0;
+}
+
+int psp_iter_state_init(psp_iter_state* host_out, uint32_t iter, int32_t step, float beta1, float beta2) {
+    if (!host_out || step <= 0) return fail(-1, "psp_iter_state_init needs an output struct and a 1-based step");
+    host_out->iter = iter; host_out->step = (uint32_t)step;
+    host_out->beta1_pow = pow((double)beta1, (double)step);
+    host_out->beta2_pow = pow((double)beta2, (double)step);
+    return 0;
+}
+
+int psp_iter_state_advance(psp_iter_state* dev_state, float beta1, float beta2, void* stream) {
+    if (!dev_state) return fail(-1, "null state passed to psp_iter_state_advance");
+    hipLaunchKernelGGL(iter_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dev_state, (double)beta1, (double)beta2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "iter_advance_kernel launch");
+    return 0;
+}
+
+int psp_adam_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const psp_iter_state* dev_state, float lr, float beta1, float beta2, float eps, void* stream) {
+    if (!params || !grad || !exp_avg || !exp_avg_sq || !dev_state) return fail(-1, "null buffer passed to psp_adam_step_dev");
+    if (n <= 0) return fail(-1, "psp_adam_step_dev needs n > 0");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad,
+                       exp_avg, exp_avg_sq, (long long)n, dev_state, lr, beta1, beta2, eps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "adam_dev_kernel launch");
     return 0;
 }
 

@@ -48,7 +48,12 @@ class HjbConfig(C.Structure):
         ("drift", C.c_void_p), ("sigma", C.c_void_p), ("runcost", C.c_void_p), ("term", C.c_void_p),
         ("u_ref", C.c_void_p), ("u_l2_out", C.c_void_p),
         ("mlp_dtype", C.c_int32), ("reserved2", C.c_int32),
+        ("iter_dev", C.c_void_p),
     ]
+
+
+class IterState(C.Structure):
+    _fields_ = [("iter", C.c_uint32), ("step", C.c_uint32), ("beta1_pow", C.c_double), ("beta2_pow", C.c_double)]
 
 
 class HjbSizes(C.Structure):
@@ -122,6 +127,10 @@ SIGNATURES = {
     "psp_philox_normal_fill": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32, _P]),
     "psp_hjb_control_eval": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
     "psp_debug_set_stamp_buffer": (C.c_int, [_P, C.c_int64]),
+    "psp_iter_state_init": (C.c_int, [C.POINTER(IterState), C.c_uint32, C.c_int32, C.c_float, C.c_float]),
+    "psp_iter_state_advance": (C.c_int, [_P, C.c_float, C.c_float, _P]),
+    "psp_hjb_terminal_reduce_loss": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P, _P, _P]),
+    "psp_adam_step_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "psp_comm_unique_id": (C.c_int, [_P]),
     "psp_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _P]),
     "psp_comm_destroy": (C.c_int, [_P]),

@@ -200,6 +200,12 @@ class HjbNativePlan:
         self.pass1_events = None
         if self.n_chunks > 1:
             self._alloc_chunks()
+        # hipGraph replay of the launch-bound small-K iteration (module docstring of include/psp.h: psp_iter_state)
+        self._graph = None
+        self._graph_key = None
+        self._graph_iter = -1
+        self._eager_done = 0
+        self.graph_active = False
         # learnable Y_0 (solver.py:372-374): tiny Adam in torch on a 1-element tensor
         self.learn_y0 = bool(solver.learn_Y_0)
         if self.learn_y0:
@@ -424,6 +430,99 @@ class HjbNativePlan:
         self._finish_step(st, self.w if self.generic_loss else None)
         return loss
 
+    # ---- hipGraph replay ---------------------------------------------------------------------------------------------
+    def _graph_wanted(self):
+        """The iteration is captured into a hipGraph when it is launch-bound (at most two 16-trajectory tiles per CU, the
+        regime of the feature-split forward kernel) and nothing in it needs a per-iteration host argument: on-device noise,
+        fixed X_0, a loss the kernels form themselves, one rank, no u_L2 log.  Solver(use_graph=True / False) overrides
+        the size rule (never the eligibility)."""
+        want = getattr(self.s, 'use_graph', 'auto')
+        if want is False:
+            return False
+        ok = (self.world == 1 and self.noise == 'philox' and not self.s.random_X_0 and not self.generic_loss
+              and not self.attached and self.ul2 is None and self.n_chunks == 1)
+        if not ok:
+            return False
+        if want is True:
+            return True
+        cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        return (self.K_local + 15) // 16 <= 2 * cus
+
+    def _graph_state_upload(self, l):
+        b = self._graph_hyper
+        st = nat.IterState()
+        nat.check(self.lib.psp_iter_state_init(C.byref(st), int(l), int(self.step) + 1, b[1], b[2]), 'psp_iter_state_init')
+        host = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8)
+        self._gstate.copy_(host)
+        self._graph_iter = l
+
+    def _graph_body(self, loss_out):
+        """The launches of one iteration with every per-iteration quantity read from the device psp_iter_state."""
+        s, lib, cfg = self.s, self.lib, self._gcfg
+        st = self._stream()
+        state = nat.ptr(self._gstate)
+        flat_k = self.pad.scatter_params(self.flat, self.flat_k)
+        y0_ptr = nat.ptr(self.y0_param) if self.learn_y0 else None
+        seed = int(s.seed) & 0xFFFFFFFFFFFFFFFF
+        nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.x0_vec), 0, y0_ptr, None, seed, 0,
+                                          nat.ptr(self.path), nat.ptr(self.D), None, None, nat.ptr(self.fwd_partial), st),
+                  'psp_hjb_rollout_fwd')
+        nat.check(lib.psp_hjb_terminal_reduce_loss(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums),
+                                                   nat.ptr(loss_out), state, st), 'psp_hjb_terminal_reduce_loss')
+        d_or_w, bcfg = self.D, cfg
+        if self.relent:                                  # detached relative entropy: weight sqrt(dt) / K on the Z image
+            d_or_w, bcfg = self.w_bwd, self._gcfg_w
+        nat.check(lib.psp_hjb_rollout_bwd(C.byref(bcfg), nat.ptr(flat_k), None, seed, 0, nat.ptr(self.path),
+                                          nat.ptr(d_or_w), nat.ptr(self.sums), nat.ptr(self.grad_partial),
+                                          nat.ptr(self.grad_k), st), 'psp_hjb_rollout_bwd')
+        self.pad.gather_grad(self.grad_k, self.grad)
+        lr, b1, b2, eps = self._graph_hyper
+        nat.check(lib.psp_adam_step_dev(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v), self.P,
+                                        state, lr, b1, b2, eps, st), 'psp_adam_step_dev')
+        if self.learn_y0:
+            self.y0_grad[0] = sharding.y0_gradient(self.sums, s.K, s.loss_method)
+            ylr = self._adam_hyper(s.y_0)[0]
+            nat.check(lib.psp_adam_step_dev(nat.ptr(self.y0_param), nat.ptr(self.y0_grad), nat.ptr(self.y0_m),
+                                            nat.ptr(self.y0_v), 1, state, ylr, b1, b2, eps, st), 'psp_adam_step_dev(Y_0)')
+        nat.check(lib.psp_iter_state_advance(state, b1, b2, st), 'psp_iter_state_advance')
+
+    def _iteration_graph(self, l, loss_out):
+        hyper = self._adam_hyper()
+        if self.learn_y0 and self._adam_hyper(self.s.y_0)[1:] != hyper[1:]:
+            self.s.use_graph = False                     # different betas for Y_0: one psp_iter_state cannot serve both
+            return self.iteration(l, loss_out)
+        if self._eager_done < 1:
+            # the first iteration runs eagerly: kernels are loaded and every buffer exists before anything is captured
+            self._eager_done += 1
+            ev, self.events = self.events, []
+            try:
+                return self.iteration(l, loss_out)
+            finally:
+                self.events = ev
+        key = (loss_out.data_ptr(), hyper)
+        if self._graph is None or self._graph_key != key:
+            self._graph_hyper = hyper
+            self._gstate = torch.zeros(24, dtype=torch.uint8, device=self.dev)
+            self._gcfg = nat.HjbConfig.from_buffer_copy(self.cfg)
+            self._gcfg.iter_dev = nat.ptr(self._gstate)
+            if self.relent:
+                self._gcfg_w = nat.HjbConfig.from_buffer_copy(self._gcfg)
+                self._gcfg_w.loss_kind = nat.LOSS_WEIGHTS
+                self.w_bwd.fill_(float(self.cfg.sqrt_dt) / float(self.s.K))
+            self._graph_state_upload(l)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_body(loss_out)
+            self._graph, self._graph_key = g, key
+        if self._graph_iter != l:                        # the caller jumped to another iteration index
+            self._graph_state_upload(l)
+        self._graph.replay()
+        self._graph_iter += 1
+        self.step += 1
+        self.graph_active = True
+        return loss_out[l]
+
     def _finish_step(self, st, w_generic):
         """Gather the real gradient entries, all-reduce, Adam on the net and on the learnable Y_0."""
         s, lib = self.s, self.lib
@@ -471,6 +570,8 @@ class HjbNativePlan:
         device, no sync."""
         if self.n_chunks > 1:
             return self._iteration_chunked(l, loss_out, ul2_out)
+        if self._graph_wanted() and self.events is None:
+            return self._iteration_graph(l, loss_out)
         s, lib, cfg = self.s, self.lib, self.cfg
         st = self._stream()
         seed = int(s.seed) & 0xFFFFFFFFFFFFFFFF
@@ -496,15 +597,21 @@ class HjbNativePlan:
                                           nat.ptr(self.Yn), nat.ptr(self.fwd_partial), st), 'psp_hjb_rollout_fwd')
         if ev is not None:
             ev[1].record()
-        nat.check(lib.psp_hjb_terminal_reduce(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums), st),
-                  'psp_hjb_terminal_reduce')
-        sharding.allreduce_sum_(self.sums)              # collective 1: 16 bytes
         d_or_w, bcfg = self.D, cfg
-        if self.generic_loss:
-            loss, d_or_w = self._generic_loss_weights()
+        if self.world == 1 and not self.generic_loss:
+            # one rank: the local sums are the global ones -- sums and the loss value in ONE launch (no element-wise torch kernels)
+            nat.check(lib.psp_hjb_terminal_reduce_loss(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums),
+                                                       nat.ptr(loss_out, l), None, st), 'psp_hjb_terminal_reduce_loss')
+            loss = loss_out[l]
         else:
-            loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
-        loss_out[l] = loss.to(torch.float32)
+            nat.check(lib.psp_hjb_terminal_reduce(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums), st),
+                      'psp_hjb_terminal_reduce')
+            sharding.allreduce_sum_(self.sums)              # collective 1: 16 bytes
+            if self.generic_loss:
+                loss, d_or_w = self._generic_loss_weights()
+            else:
+                loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
+            loss_out[l] = loss.to(torch.float32)
         if self.ul2 is not None and ul2_out is not None:
             m = (self.ul2.sum() / float(s.K)).reshape(1)
             sharding.allreduce_sum_(m)

@@ -62,7 +62,7 @@ class Solver:
                  plot_trajectories=None, seed=42, save_results=False, u_l2_error_flag=True,
                  log_gradient=False, burgers_drift=False, verbose=True,
                  device=None, backend='auto', noise='reference', widths=(30, 30), mlp_dtype='fp32',
-                 path_budget_bytes=None, path_chunks=None, chunk_mode='auto'):
+                 path_budget_bytes=None, path_chunks=None, chunk_mode='auto', use_graph='auto'):
         self.problem, self.name = problem, name
         self.date = date.today().strftime('%Y-%m-%d')
         self.d, self.T = problem.d, problem.T
@@ -81,6 +81,8 @@ class Solver:
         # native plan: HBM budget of the path store kept for the backward pass (None: a third of the HBM); a larger store is
         # processed in K-chunks (plan_native.py).  path_chunks forces a chunk count; chunk_mode 'auto' | 'two_gradient' | 'recompute'
         self.path_budget_bytes, self.path_chunks, self.chunk_mode = path_budget_bytes, path_chunks, chunk_mode
+        # native plan: replay the iteration as a captured hipGraph ('auto': when it is launch-bound, K <= 8192 on MI355X)
+        self.use_graph = use_graph
 
         # hyper-parameters (reference solver.py:36-45): fp32 step, float64 step count
         self.seed = seed

@@ -1,7 +1,7 @@
 """GPU parity of the native plan on bounded domains (sphere / box exit tests inside the forward kernel, Dirichlet /
 Neumann terms, BSDE with boundary data) and of EllipticSolver (same kernels, no time input) against the oracle's
 autograd and the reference's golden runs.  Tolerances as in test_gpu_general.py: gradient <= 5e-4 * max|g|,
-loss per iteration <= 2e-4 relative, active-step counts exact."""
+loss per iteration <= 1e-4 relative (BASELINE.json's bar; observed errors are printed), active-step counts exact."""
 import math
 
 import numpy as np
@@ -62,8 +62,16 @@ def test_loss_log_matches_reference_golden(name):
     model.train()
     exp = rec["expected"]
     assert model.K_log == exp["K_log"]
+    errs = [abs(got - want) / abs(want) for got, want in zip(model.loss_log, exp["loss_log"])]
+    print("%s: loss rel err per iteration vs the reference %s" % (name, ["%.1e" % e for e in errs]))
     for l, (got, want) in enumerate(zip(model.loss_log, exp["loss_log"])):
-        assert math.isclose(got, want, rel_tol=2e-4), (l, model.loss_log, exp["loss_log"])
+        assert math.isclose(got, want, rel_tol=1e-4), (l, model.loss_log, exp["loss_log"])     # BASELINE.json: 1e-4
+    assert len(model.times) == len(model.loss_log)
+    if rec["case"]["family"] == "elliptic":
+        # V_L2 log of EllipticSolver.train (solver.py:718, 738, 813): decoded from the X_n images of the path store
+        assert len(model.V_L2_log) == len(exp["V_L2_log"])
+        for got, want in zip(model.V_L2_log, exp["V_L2_log"]):
+            assert math.isclose(got, want, rel_tol=1e-4, abs_tol=1e-9), (model.V_L2_log, exp["V_L2_log"])
     xp = torch.tensor(exp["probe_x"]).reshape(-1, prob.d).to(dev())
     if rec["case"]["family"] != "elliptic":
         xp = torch.cat([xp, torch.full((xp.shape[0], 1), exp["probe_t"], device=dev())], 1)

@@ -1,6 +1,6 @@
 """GPU parity of the native GeneralSolver plan (diffusion / BSDE loss) against the oracle's autograd
 and the reference's golden loss logs.  Tolerances: gradient <= 5e-4 * max|g| (second-order sweep in
-fp32 on both sides), loss per iteration <= 2e-4 relative, active-step counts exact."""
+fp32 on both sides), loss per iteration <= 1e-4 relative (BASELINE.json's bar; observed errors are printed), active-step counts exact."""
 import math
 
 import pytest
@@ -64,8 +64,10 @@ def test_loss_log_matches_reference_golden(name):
     model.train()
     exp = rec["expected"]
     assert model.K_log == exp["K_log"]
+    errs = [abs(got - want) / abs(want) for got, want in zip(model.loss_log, exp["loss_log"])]
+    print("%s: loss rel err per iteration vs the reference %s" % (name, ["%.1e" % e for e in errs]))
     for l, (got, want) in enumerate(zip(model.loss_log, exp["loss_log"])):
-        assert math.isclose(got, want, rel_tol=2e-4), (l, model.loss_log, exp["loss_log"])
+        assert math.isclose(got, want, rel_tol=1e-4), (l, model.loss_log, exp["loss_log"])     # BASELINE.json: 1e-4
     xp = torch.tensor(exp["probe_x"]).reshape(-1, prob.d).to(dev())
     tp = torch.full((xp.shape[0], 1), exp["probe_t"], device=dev())
     with torch.no_grad():
@@ -119,3 +121,26 @@ def test_full_size_properties_diffusion():
     torch.cuda.synchronize()
     # the full run's outputs were produced with the ORIGINAL weights too (L=1: outputs precede the Adam step)
     assert torch.equal(plan.YN, pa.YN[K // 2:]) and torch.equal(plan.VN, pa.VN[K // 2:])
+
+
+def test_plan_follows_a_swapped_value_net():
+    """`model.V = DenseNet(...)` after a first train() (the notebook pattern, Allen-Cahn.ipynb:72) must rebuild the native
+    plan: the new net is the one that trains, starting from ITS initial weights and fresh Adam moments."""
+    case = load_golden("dwgen_d10_diffusion")["case"]
+    prob, model = build(case, L=2)
+    model.train()
+    first = model._gen_plan
+    V2 = psp.DenseNet(d_in=prob.d + 1, d_out=1, lr=case["solver"]["lr"], arch=[16, 16], seed=7).to(dev())
+    w0 = torch.cat([p.detach().reshape(-1).clone() for p in V2.W])
+    model.V = V2
+    model.loss_log.clear()
+    model.K_log.clear()
+    model.train()
+    assert model._gen_plan is not first and model._gen_plan.net is V2
+    w1 = torch.cat([p.detach().reshape(-1) for p in V2.W])
+    assert float((w1 - w0).abs().max()) > 0.0                  # V2 was updated ...
+    # ... and the run equals a fresh solver that had V2 from the start
+    prob_b, fresh = build(case, L=2)
+    fresh.V = psp.DenseNet(d_in=prob.d + 1, d_out=1, lr=case["solver"]["lr"], arch=[16, 16], seed=7).to(dev())
+    fresh.train()
+    assert model.loss_log == fresh.loss_log
