@@ -1,8 +1,8 @@
 // hjbs_kernels.h -- feature-split forward rollout for SMALL trajectory counts.
 //
 // hjb_fwd_kernel gives every wave a whole 16-trajectory tile: with K = 1024 that is 64 waves on a chip with 1024 SIMDs,
-// and the N time steps of a tile are sequential (36 k cycles each).  Here the four waves of a workgroup share ONE tile
-// and split every product by OUTPUT block (wave w owns state blocks w, w+4, ... and hidden blocks w, w+4, ...):
+// and the N time steps of a tile are sequential (36 k cycles each).  Here the W (4 or 8) waves of a workgroup share ONE tile
+// and split every product by OUTPUT block (wave w owns state blocks w, w+W, ... and hidden blocks w, w+W, ...):
 //   * a wave's slice of all five weight tables (W1, W2, W3, dt A, B rows of its blocks) is a few hundred A-operand
 //     fragments -- they are loaded once and stay IN REGISTERS for the whole kernel; the time loop issues no table loads;
 //   * activations travel through four small LDS images (X_n, h1, h2, v: the B operands, one dword per lane and k-step),
@@ -21,25 +21,31 @@ template <int D, int H>
 struct GeoS {
     using G = Geo<D, H>;
     static constexpr int DB = G::DB, HB = G::HB, KP = 4 * DB, KH = 4 * HB;
-    static constexpr int NBo = cdiv(DB, 4), NHo = cdiv(HB, 4);       // owned state / hidden blocks per wave
+    static constexpr int KD = G::KSD;                                // k-steps of a d-deep contraction that carry real features (<= KP)
+    // waves per workgroup (= per tile).  More than four state or hidden blocks: EIGHT waves, two per SIMD -- the matrix-pipe
+    // time of a step is the same (the pipe is per SIMD), but one wave's Philox / tanh / LDS round trips and barrier waits
+    // now run under the other wave's MFMAs, and a wave owns half the blocks (half the dependent-chain length per phase)
+    static constexpr int W = (DB > 4 || HB > 4) ? 8 : 4;
+    static constexpr int NBo = cdiv(DB, W), NHo = cdiv(HB, W);       // owned state / hidden blocks per wave
     // LDS (floats): per-feature vectors, the four images, cross-wave reduction scratch
     static constexpr int vb1 = 0, vw1t = vb1 + HB * 16, vb2 = vw1t + HB * 16, vb3 = vb2 + HB * 16,
                          vdr = vb3 + DB * 16, vrun = vdr + DB * 16, vterm = vrun + DB * 16,
                          iX = vterm + DB * 16, iH1 = iX + KP * 64, iH2 = iH1 + KH * 64, iV = iH2 + KH * 64,
-                         fRed = iV + KP * 64, lds_floats = fRed + 4 * 64;
+                         fRed = iV + KP * 64, lds_floats = fRed + W * 64;
 };
 
 template <int D, int H>
-__global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
+__global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const HjbArgs a) {
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     using S_ = GeoS<D, H>;
-    constexpr int DB = S_::DB, HB = S_::HB, KP = S_::KP, KH = S_::KH, NBo = S_::NBo, NHo = S_::NHo;
+    constexpr int DB = S_::DB, HB = S_::HB, KP = S_::KP, KH = S_::KH, NBo = S_::NBo, NHo = S_::NHo, W = S_::W, KD = S_::KD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, q = lane >> 4;
     const float* __restrict__ P = a.params;
+    const bool hasH = wave < HB, hasS = wave < DB;     // owns at least one hidden / state block (wave-uniform)
 
     stage_vec(lds + S_::vb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
     stage_vec(lds + S_::vw1t, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW1 + f * (D + 1)] : 0.f; });
@@ -54,13 +60,13 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
     // ---- this wave's weight slices as A-operand fragments: lane (i, q) of fragment (block mb, k-step ks) holds
     //      W[16 mb + rowmap(i)][4 ks + q]  (rowmap as in stage_aop)
     const int ri = 4 * ((lane & 15) & 3) + ((lane & 15) >> 2);
-    float w1r[NHo][KP], w2r[NHo][KH], w3r[NBo][KH], ar[NBo][KP], br[NBo][KP];
+    float w1r[NHo][KD], w2r[NHo][KH], w3r[NBo][KH], ar[NBo][KD], br[NBo][KD];
     const bool denseA = a.drift_kind == DRIFT_DENSE, denseB = a.sigma_kind == SIGMA_DENSE;
 #pragma unroll
     for (int io = 0; io < NHo; ++io) {
-        const int row = 16 * (wave + 4 * io) + ri;
+        const int row = 16 * (wave + W * io) + ri;
 #pragma unroll
-        for (int ks = 0; ks < KP; ++ks) {
+        for (int ks = 0; ks < KD; ++ks) {
             const int col = 4 * ks + q;
             w1r[io][ks] = (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f;
         }
@@ -72,14 +78,14 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
     }
 #pragma unroll
     for (int io = 0; io < NBo; ++io) {
-        const int row = 16 * (wave + 4 * io) + ri;
+        const int row = 16 * (wave + W * io) + ri;
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
             const int col = 4 * ks + q;
             w3r[io][ks] = (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f;
         }
 #pragma unroll
-        for (int ks = 0; ks < KP; ++ks) {
+        for (int ks = 0; ks < KD; ++ks) {
             const int col = 4 * ks + q;
             const bool in = row < D && col < D;
             ar[io][ks] = (denseA && in) ? a.dt * a.drift[row * D + col] : 0.f;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
     for (int io = 0; io < NBo; ++io)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int f = 16 * (wave + 4 * io) + 4 * r + q;
+            const int f = 16 * (wave + W * io) + 4 * r + q;
             const float v = a.x0[(size_t)(kvalid ? k : 0) * a.x0_stride + (f < D ? f : D - 1)];
             X[io][r] = (f < D && kvalid) ? v : 0.f;
         }
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         // ---- P0: own blocks of X_n -> image (B operand of the W1 and drift products) and path store
 #pragma unroll
         for (int io = 0; io < NBo; ++io) {
-            const int sb = wave + 4 * io;
+            const int sb = wave + W * io;
             if (sb < DB) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) imgX[(4 * sb + r) * 64 + lane] = X[io][r];
@@ -148,16 +154,20 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         f32x4 h1[NHo];
 #pragma unroll
         for (int io = 0; io < NHo; ++io) {
-            const int hb = (wave + 4 * io) < HB ? (wave + 4 * io) : HB - 1;
+            const int hb = (wave + W * io) < HB ? (wave + W * io) : HB - 1;
             h1[io] = vb1[hb * 4] + tn * vw1t[hb * 4];
         }
-        {
-            float bx[KP];
+        // (wave-uniform tests stay OUTSIDE the unrolled k-loops: inside, every k-step became a branch with accumulator moves
+        //  and hazard nops around it).  With eight waves some own no hidden block / no state block: they skip the product
+        //  instead of multiplying zero weights (the matrix pipe is shared by the two waves of a SIMD), and a wave WITHOUT a
+        //  hidden block defers its drift product to phase P2, where the pipe only carries the short W2 product
+        if (hasH) {
+            float bx[KD];
 #pragma unroll
-            for (int ks = 0; ks < KP; ++ks) bx[ks] = imgX[ks * 64 + lane];
-            if (denseA) {                              // (the wave-uniform test stays OUTSIDE the unrolled k-loop: inside, every
-#pragma unroll                                         // k-step became a branch with accumulator moves and hazard nops around it)
-                for (int ks = 0; ks < KP; ++ks) {
+            for (int ks = 0; ks < KD; ++ks) bx[ks] = imgX[ks * 64 + lane];
+            if (denseA && hasS) {
+#pragma unroll
+                for (int ks = 0; ks < KD; ++ks) {
 #pragma unroll
                     for (int io = 0; io < NHo; ++io) h1[io] = mfma16(w1r[io][ks], bx[ks], h1[io]);
 #pragma unroll
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
                 }
             } else {
 #pragma unroll
-                for (int ks = 0; ks < KP; ++ks)
+                for (int ks = 0; ks < KD; ++ks)
 #pragma unroll
                     for (int io = 0; io < NHo; ++io) h1[io] = mfma16(w1r[io][ks], bx[ks], h1[io]);
             }
@@ -173,19 +183,20 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
             for (int io = 0; io < NBo; ++io) {
-                const int sb = (wave + 4 * io) < DB ? (wave + 4 * io) : DB - 1;
+                const int sb = (wave + W * io) < DB ? (wave + W * io) : DB - 1;
                 X[io] += dt * (vdr[sb * 4] * X[io]);
             }
         } else if (a.drift_kind == DRIFT_DWELL) {
 #pragma unroll
             for (int io = 0; io < NBo; ++io) {
-                const int sb = (wave + 4 * io) < DB ? (wave + 4 * io) : DB - 1;
+                const int sb = (wave + W * io) < DB ? (wave + W * io) : DB - 1;
                 X[io] -= dt * (4.0f * vdr[sb * 4] * (X[io] * (X[io] * X[io] - 1.0f)));
             }
         }
+        if (hasH)
 #pragma unroll
         for (int io = 0; io < NHo; ++io) {
-            const int hb = wave + 4 * io;
+            const int hb = wave + W * io;
             h1[io] = tanh4(h1[io]);
             if (hb < HB) {
 #pragma unroll
@@ -202,10 +213,19 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         f32x4 h2[NHo];
 #pragma unroll
         for (int io = 0; io < NHo; ++io) {
-            const int hb = (wave + 4 * io) < HB ? (wave + 4 * io) : HB - 1;
+            const int hb = (wave + W * io) < HB ? (wave + W * io) : HB - 1;
             h2[io] = vb2[hb * 4];
         }
-        {
+        if (!hasH && hasS && denseA) {                 // deferred from P1: the X_n image stays valid until the end of P4
+            float bx[KD];
+#pragma unroll
+            for (int ks = 0; ks < KD; ++ks) bx[ks] = imgX[ks * 64 + lane];
+#pragma unroll
+            for (int ks = 0; ks < KD; ++ks)
+#pragma unroll
+                for (int io = 0; io < NBo; ++io) X[io] = mfma16(ar[io][ks], bx[ks], X[io]);
+        }
+        if (hasH) {
             float bh[KH];
 #pragma unroll
             for (int ks = 0; ks < KH; ++ks) bh[ks] = imgH1[ks * 64 + lane];
@@ -214,9 +234,10 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                 for (int io = 0; io < NHo; ++io) h2[io] = mfma16(w2r[io][ks], bh[ks], h2[io]);
         }
+        if (hasH)
 #pragma unroll
         for (int io = 0; io < NHo; ++io) {
-            const int hb = wave + 4 * io;
+            const int hb = wave + W * io;
             h2[io] = tanh4(h2[io]);
             if (hb < HB) {
 #pragma unroll
@@ -233,10 +254,10 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         f32x4 Z[NBo];
 #pragma unroll
         for (int io = 0; io < NBo; ++io) {
-            const int sb = (wave + 4 * io) < DB ? (wave + 4 * io) : DB - 1;
+            const int sb = (wave + W * io) < DB ? (wave + W * io) : DB - 1;
             Z[io] = vb3[sb * 4];
         }
-        {
+        if (hasS) {
             float bh[KH];
 #pragma unroll
             for (int ks = 0; ks < KH; ++ks) bh[ks] = imgH2[ks * 64 + lane];
@@ -248,7 +269,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         float S = 0.f, Pz = 0.f, UL = 0.f;
 #pragma unroll
         for (int io = 0; io < NBo; ++io) {
-            const int sb = wave + 4 * io;
+            const int sb = wave + W * io;
             if (sb < DB) {
                 f32x4 xi;
                 if (a.noise_mode == NOISE_PHILOX) {
@@ -298,13 +319,15 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         if (denseB) {
             __syncthreads();
             // ---- P4: X += B v for the own state blocks
-            float bv[KP];
+            if (hasS) {
+                float bv[KD];
 #pragma unroll
-            for (int ks = 0; ks < KP; ++ks) bv[ks] = imgV[ks * 64 + lane];
+                for (int ks = 0; ks < KD; ++ks) bv[ks] = imgV[ks * 64 + lane];
 #pragma unroll
-            for (int ks = 0; ks < KP; ++ks)
+                for (int ks = 0; ks < KD; ++ks)
 #pragma unroll
-                for (int io = 0; io < NBo; ++io) X[io] = mfma16(br[io][ks], bv[ks], X[io]);
+                    for (int io = 0; io < NBo; ++io) X[io] = mfma16(br[io][ks], bv[ks], X[io]);
+            }
         }
         // ---- running cost f(X_{n+1}) over the own blocks and the wave's partial of the Y update (solver.py:477-478):
         //      Y += (f -/+ 0.5 |Z|^2) dt + Z.xi sqrt(dt) is linear in the three row sums
@@ -312,7 +335,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
         if (a.runcost_kind == RUN_DIAGQ) {
 #pragma unroll
             for (int io = 0; io < NBo; ++io) {
-                const int sb = wave + 4 * io;
+                const int sb = wave + W * io;
                 if (sb < DB) {
                     const f32x4 pv = vrun[sb * 4];
 #pragma unroll
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
     float g = 0.f;
 #pragma unroll
     for (int io = 0; io < NBo; ++io) {
-        const int sb = wave + 4 * io;
+        const int sb = wave + W * io;
         if (sb < DB) {
             const f32x4 tv = vterm[sb * 4];
 #pragma unroll
@@ -372,14 +395,17 @@ __global__ __launch_bounds__(256) void hjbs_fwd_kernel(const HjbArgs a) {
     if (q == 3) red[wave * 64 + 48 + j] = Up;
     __syncthreads();
     if (wave == 0) {
-        const float Y = (a.y0 ? a.y0[0] : 0.f) + ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j]));
-        const float F = (red[16 + j] + red[64 + 16 + j]) + (red[128 + 16 + j] + red[192 + 16 + j]);
-        const float gt = (red[32 + j] + red[64 + 32 + j]) + (red[128 + 32 + j] + red[192 + 32 + j]);
+        float Ys = 0.f, F = 0.f, gt = 0.f, Us = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {                  // fixed order: bitwise reproducible
+            Ys += red[w * 64 + j]; F += red[w * 64 + 16 + j]; gt += red[w * 64 + 32 + j]; Us += red[w * 64 + 48 + j];
+        }
+        const float Y = (a.y0 ? a.y0[0] : 0.f) + Ys;
         const float Dk = Y - gt;
         if (kvalid && q == 0) {
             a.D[k] = Dk;
             if (a.Fint) a.Fint[k] = F;
-            if (a.uref) a.ul2[k] = (red[48 + j] + red[64 + 48 + j]) + (red[128 + 48 + j] + red[192 + 48 + j]);
+            if (a.uref) a.ul2[k] = Us;
             if (a.Yout) a.Yout[k] = Y;
         }
         double sD = (kvalid && q == 0) ? (double)Dk : 0.0, sD2 = (kvalid && q == 0) ? (double)Dk * (double)Dk : 0.0;
@@ -396,7 +422,7 @@ struct HjbsLaunch {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbs_fwd_kernel<D, H>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjbs_fwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
+        hipLaunchKernelGGL((hjbs_fwd_kernel<D, H>), dim3(grid), dim3(64 * GeoS<D, H>::W), bytes, s, a);
         return hipGetLastError();
     }
 };

@@ -152,7 +152,7 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     p->fwd_split = !p->inst.wide && p->inst.launch_fwd_split && p->inst.split_lds_bytes() <= kMaxLds &&
                    c->mlp_dtype != PSP_MLP_BF16_FWD &&           // (the bf16 control-net mode exists in hjb_fwd_kernel only)
                    ((fv && fv[0] == '2') || (!(fv && fv[0] == '1') && p->ntile16 <= 2 * cus));
-    if (p->fwd_split) { p->fwd_waves = 4; p->fwd_grid = p->ntile16; }
+    if (p->fwd_split) { p->fwd_waves = 8; p->fwd_grid = p->ntile16; }   // (the kernel itself fixes 4 or 8 waves per tile)
     // backward: persistent over rounds of 4 sample blocks; 4-wave workgroups, two per CU
     // (<= 256 VGPRs and <= 80 KiB LDS each), fewer when there is little work
     const long long nblk = (long long)c->N * p->ntile16;
