@@ -279,13 +279,13 @@ typedef struct psp_gen_config {
     float dt, sqrt_dt;    /* fp32 step and its fp32 square root (solver.py:950-951)          */
     float T;              /* terminal time: a trajectory freezes once t + dt > T (:1131)     */
     float sigma_scale;    /* sigma = s I (problems.py:493 s = 1; :1183,1740 s = sqrt 2)      */
-    int32_t drift_kind;   /* PSP_DRIFT_ZERO or PSP_DRIFT_DOUBLE_WELL                          */
+    int32_t drift_kind;   /* PSP_DRIFT_ZERO, PSP_DRIFT_DIAG or PSP_DRIFT_DOUBLE_WELL               */
     int32_t h_kind;
     int32_t adaptive;     /* 1: c = -Z detached (solver.py:1111-1114), 0: c = 0              */
     int32_t noise_mode;   /* PSP_NOISE_SUPPLIED: xi is (N, K_local, d); PSP_NOISE_PHILOX      */
     int32_t store_path;   /* 1: keep what the backward pass needs                            */
     int32_t domain_kind;  /* PSP_DOM_*                                                         */
-    const float* drift;   /* DOUBLE_WELL: kappa (d); else NULL                               */
+    const float* drift;   /* DOUBLE_WELL: kappa (d); DIAG: a (d); else NULL                  */
     float dom_a, dom_b;   /* sphere radius (dom_a) or box bounds X_l, X_r                     */
     float h_par[4];       /* PSP_GH_EXPBALL_*: al, d (the REAL dimension, not a padded one), e, tau */
     int32_t d_real;       /* components the exit test and |x|^2 read when d is a zero-padded instance (0: all d);
@@ -294,6 +294,14 @@ typedef struct psp_gen_config {
                            * tangent pass) on v_mfma_f32_16x16x32_bf16 -- bf16 operands, fp32 accumulate; PSP_MLP_BF16: also the
                            * adjoint products and the weight-gradient outer products of the backward kernel.  State, Y,
                            * accumulators, the path store and every element-wise step stay fp32 (BASELINE.json configs[2]) */
+    /* Solver.train with approx_method='value_function' (solver.py:93-97, 334-339, 438-440: Z = sigma grad_x Y_n(X), loss +
+     * mean_k sum_{n>=1} (Y_n(X_n) - Y)^2) runs on these kernels too (plan_value_native.py):                              */
+    float* v_steps_out;   /* optional (N, 16*ceil(K_local/16)): V(X_n, t_n) at every step, written by psp_gen_rollout_fwd       */
+    float* y_steps_out;   /* optional, same shape: the running Y before the increment of step n (both or neither)               */
+    int32_t per_sample_weights; /* psp_gen_rollout_bwd: 1 -> wY is (N+1, 16*ceil(K_local/16)) = weight of the TANGENT part of every
+                           * sample (0 in slot N) and `ahat` holds the coefficient of grad_theta V of every sample itself
+                           * (wV is ignored): losses with a term at every step.  0: per-trajectory wY, wV as described below     */
+    int32_t reserved;
 } psp_gen_config;
 
 typedef struct psp_gen_sizes {

@@ -19,6 +19,7 @@ from .general_solver import GeneralSolver, EllipticSolver  # noqa: F401
 from .plan_native import PlanUnsupported  # noqa: F401
 from . import native  # noqa: F401
 from . import native_shapes  # noqa: F401
+from . import plan_native, plan_dense_native, plan_general_native, plan_value_native  # noqa: F401
 from .utilities import do_importance_sampling_me  # noqa: F401
 
 __all__ = ['Solver', 'GeneralSolver', 'EllipticSolver', 'ExponentialOnSphere', 'ExponentialOnBallNonlinear',

@@ -34,6 +34,9 @@ struct GenArgs {
     const float* drift;   // kappa (d) for the double well
     const float* wY;      // (K_local) dLoss/dY_N      (backward)
     const float* wV;      // (K_local) dLoss/dV(X_N)   (backward)
+    float* Vsteps;        // optional (N, 16*ntile16): V(X_n, t_n) of every step (value_function ansatz of Solver, solver.py:438-440)
+    float* Ysteps;        // optional (N, 16*ntile16): the running Y BEFORE the increment of step n
+    int per_sample;       // backward: wY is (N+1, 16*ntile16) tangent weights per sample and ahat holds the value-gradient coefficient itself
     float* grad_partial;
     long long k_offset;
     int K_local, N, ntile16;
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
     stage_vec(lds + G::vw3h1, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + f] : 0.f; });
     stage_vec(lds + G::vw3h2, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + H + f] : 0.f; });
     stage_vec(lds + G::vw3x, DBI, tid, nthr, [&](int f) { return f < DI ? P[G::oW3 + f] : 0.f; });
-    stage_vec(lds + G::vdr, DBI, tid, nthr, [&](int f) { return (f < D && a.drift_kind == DRIFT_DWELL) ? a.drift[f] : 0.f; });
+    stage_vec(lds + G::vdr, DBI, tid, nthr, [&](int f) {
+        return (f < D && (a.drift_kind == DRIFT_DWELL || a.drift_kind == DRIFT_DIAG)) ? a.drift[f] : 0.f; });
     __syncthreads();
     const float b3 = P[G::ob3];
 
@@ -223,6 +227,10 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             f32x4 r1[HB], r2[HB];
             const float Vnow = net_value(vecs, r1, r2);
             if (n == 0) Y = Vnow;                                   // solver.py:1081
+            if (a.Vsteps && q == 0) {                               // Solver's value_function ansatz: sum_n (Y_n(X_n) - Y)^2 (solver.py:438-440)
+                a.Vsteps[(size_t)n * (a.ntile16 * 16) + k] = Vnow;
+                a.Ysteps[(size_t)n * (a.ntile16 * 16) + k] = Y;
+            }
             // ---- grad_x V by the reverse sweep (replaces autograd.grad of solver.py:1103)
             f32x4 gz2[HB], gz1[HB], gx[DBI];
 #pragma unroll
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 const f32x4 cdt = a.adaptive ? (-dt) * Z : 0.f * Z;
                 f32x4 drift = 0.f * Z;
                 if (a.drift_kind == DRIFT_DWELL) drift = -(4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
+                else if (a.drift_kind == DRIFT_DIAG) drift = vdr[b * 4] * X[b];          // b(x) = diag(a) x (problems.py:36-37 with a diagonal A)
                 const f32x4 step = (drift * dt + sig * cdt + (sig * sqdt) * xi) * alivef;
                 return step;
             };
@@ -524,9 +533,10 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
             const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
             const bool fin = (n == a.N);
             // wY / wV / ahat are zero-padded to 16*ntile16 entries: plain loads, no branch around them
-            const float wy = a.wY[k], wv = a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
+            const size_t wofs = a.per_sample ? (size_t)n * Kpad : 0;            // per-sample mode: wY is (N+1, Kpad), ahat IS the coefficient
+            const float wy = a.wY[wofs + k], wv = a.per_sample ? 0.f : a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
             const float wsv = (bvalid && !fin) ? wy : 0.f;                             // weight of the tangent part
-            const float av = bvalid ? (fin ? wv : wy * ah) : 0.f;
+            const float av = bvalid ? (a.per_sample ? ah : (fin ? wv : wy * ah)) : 0.f;
             const int o0 = opaque_i(0);
             f32x4 gz2[HB], gz2t[HB];
             {
@@ -614,12 +624,12 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
                 // per-sample weights of the 4 samples this lane sees in F layout (samples 4q'..4q'+3)
                 const bool fin = (n == a.N);
                 const int k4 = t16 * 16 + 4 * qq;
-                const f32x4 wy4 = *reinterpret_cast<const f32x4*>(a.wY + k4);
-                const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wV + k4);
+                const f32x4 wy4 = *reinterpret_cast<const f32x4*>(a.wY + (a.per_sample ? (size_t)n * Kpad : 0) + k4);
+                const f32x4 wv4 = a.per_sample ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.wV + k4);
                 const f32x4 ah4 = *reinterpret_cast<const f32x4*>(a.ahat + (size_t)n * Kpad + k4);
                 const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
                 const f32x4 w4 = (sval && !fin) ? wy4 : z4;
-                const f32x4 a4 = sval ? (fin ? wv4 : wy4 * ah4) : z4;
+                const f32x4 a4 = sval ? (a.per_sample ? ah4 : (fin ? wv4 : wy4 * ah4)) : z4;
                 f32x4 bz2[NIB], bz2t[NIB], bz1[NIB], bz1t[NIB];
 #pragma unroll
                 for (int t = 0; t < NIB; ++t) {
@@ -842,9 +852,10 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
                     const bool fin = (n == a.N);
                     // wY / wV / ahat are zero-padded to 16*ntile16 entries: plain loads, no branch around them
-                    const float wy = a.wY[k], wv = a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
+                    const size_t wofs = a.per_sample ? (size_t)n * Kpad : 0;            // per-sample mode: wY is (N+1, Kpad), ahat IS the coefficient
+            const float wy = a.wY[wofs + k], wv = a.per_sample ? 0.f : a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
                     const float wsv = (bvalid && !fin) ? wy : 0.f;                             // weight of the tangent part
-                    const float av = bvalid ? (fin ? wv : wy * ah) : 0.f;
+                    const float av = bvalid ? (a.per_sample ? ah : (fin ? wv : wy * ah)) : 0.f;
                     const int o0 = opaque_i(0);
                     f32x4 gz2[HB], gz2t[HB];
                     {
@@ -964,11 +975,11 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
         const int n = cb / a.ntile16, t16 = cb % a.ntile16;
         const bool fin = (n == a.N);
         const int k4 = t16 * 16 + 4 * qq;
-        const f32x4 wy4 = *reinterpret_cast<const f32x4*>(a.wY + k4);
-        const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wV + k4);
+        const f32x4 wy4 = *reinterpret_cast<const f32x4*>(a.wY + (a.per_sample ? (size_t)n * Kpad : 0) + k4);
+        const f32x4 wv4 = a.per_sample ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.wV + k4);
         const f32x4 ah4 = *reinterpret_cast<const f32x4*>(a.ahat + (size_t)n * Kpad + k4);
         w4n = (sval && !fin) ? wy4 : zero4;
-        a4n = sval ? (fin ? wv4 : wy4 * ah4) : zero4;
+        a4n = sval ? (a.per_sample ? ah4 : (fin ? wv4 : wy4 * ah4)) : zero4;
     };
     if constexpr (BF16) {
         // bf16 outer products (v_mfma_f32_16x16x32_bf16): the 32-deep k-step is the sample index of TWO sample blocks --
@@ -987,11 +998,11 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
             const int n = cb / a.ntile16, t16 = cb % a.ntile16;
             const bool fin = (n == a.N);
             const int k4 = t16 * 16 + 4 * qq;
-            const f32x4 wy4 = *reinterpret_cast<const f32x4*>(a.wY + k4);
-            const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wV + k4);
+            const f32x4 wy4 = *reinterpret_cast<const f32x4*>(a.wY + (a.per_sample ? (size_t)n * Kpad : 0) + k4);
+            const f32x4 wv4 = a.per_sample ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.wV + k4);
             const f32x4 ah4 = *reinterpret_cast<const f32x4*>(a.ahat + (size_t)n * Kpad + k4);
             w4 = (sval && !fin) ? wy4 : zero4;
-            a4 = sval ? (fin ? wv4 : wy4 * ah4) : zero4;
+            a4 = sval ? (a.per_sample ? ah4 : (fin ? wv4 : wy4 * ah4)) : zero4;
         };
         __syncthreads();                                      // pairs with producer iteration 0
         for (int it = 1; it <= R; ++it) {

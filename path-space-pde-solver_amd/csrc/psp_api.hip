@@ -209,13 +209,14 @@ int make_gen_plan(const psp_gen_config* c, GenPlan* p) {
         snprintf(g_err, sizeof(g_err), "no compiled GeneralSolver kernel instance for d=%d H=%d", c->d, c->H);
         return -2;
     }
-    if ((c->drift_kind != PSP_DRIFT_ZERO && c->drift_kind != PSP_DRIFT_DOUBLE_WELL) || c->h_kind < 0 ||
+    if ((c->drift_kind != PSP_DRIFT_ZERO && c->drift_kind != PSP_DRIFT_DOUBLE_WELL && c->drift_kind != PSP_DRIFT_DIAG) || c->h_kind < 0 ||
         c->h_kind > PSP_GH_EXPBALL_SIN || c->noise_mode < 0 || c->noise_mode > 1 || c->domain_kind < 0 ||
         c->domain_kind > PSP_DOM_BOX_UPPER_ANY)
         return fail(-1, "config enum out of range");
     if (c->domain_kind == PSP_DOM_SPHERE && !(c->dom_a > 0.f)) return fail(-1, "sphere radius must be positive");
     if (c->domain_kind == PSP_DOM_BOX && !(c->dom_a < c->dom_b)) return fail(-1, "box bounds must satisfy X_l < X_r");
-    if (c->drift_kind == PSP_DRIFT_DOUBLE_WELL && !c->drift) return fail(-1, "double-well kappa vector missing");
+    if (c->drift_kind != PSP_DRIFT_ZERO && !c->drift) return fail(-1, "drift vector missing (double-well kappa / diagonal of A)");
+    if ((c->v_steps_out == nullptr) != (c->y_steps_out == nullptr)) return fail(-1, "v_steps_out and y_steps_out go together");
     if (p->inst.fwd_lds_bytes() > kMaxLds || p->inst.bwd_lds_bytes() > kMaxLds)
         return fail(-3, "GeneralSolver kernel tables do not fit the 160 KiB LDS for this (d,H)");
     p->ntile16 = (c->K_local + 15) / 16;
@@ -245,6 +246,7 @@ void fill_gen_args(const psp_gen_config* c, const GenPlan& p, psp::GenArgs* a) {
     a->domain_kind = c->domain_kind; a->dom_a = c->dom_a; a->dom_b = c->dom_b;
     a->d_real = (c->d_real > 0 && c->d_real < c->d) ? c->d_real : c->d;
     for (int i = 0; i < 4; ++i) a->h_par[i] = c->h_par[i];
+    a->Vsteps = c->v_steps_out; a->Ysteps = c->y_steps_out; a->per_sample = c->per_sample_weights ? 1 : 0;
 }
 
 // ---- small kernels -------------------------------------------------------------------
@@ -802,7 +804,7 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
     GenPlan p;
     int rc = make_gen_plan(cfg, &p);
     if (rc) return rc;
-    if (!params || !path || !ahat || !wY || !wV || !grad_partial || !grad_out)
+    if (!params || !path || !ahat || !wY || (!wV && !cfg->per_sample_weights) || !grad_partial || !grad_out)
         return fail(-1, "null buffer passed to psp_gen_rollout_bwd");
     psp::GenArgs a;
     fill_gen_args(cfg, p, &a);

@@ -74,6 +74,8 @@ class GenConfig(C.Structure):
         ("drift", C.c_void_p),
         ("dom_a", C.c_float), ("dom_b", C.c_float), ("h_par", C.c_float * 4),
         ("d_real", C.c_int32), ("mlp_dtype", C.c_int32),
+        ("v_steps_out", C.c_void_p), ("y_steps_out", C.c_void_p),
+        ("per_sample_weights", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

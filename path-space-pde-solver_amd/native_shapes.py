@@ -152,11 +152,15 @@ class GenParamPad(ParamPad):
     """Index map for the DenseNet flat vector [W1 (DI x H), b1, W2 ((DI+H) x H), b2, W3 (DI+2H), b3], DI = d + 1.
     Input rows are [x (d), t]: padding moves the t row from index d to index d_pad and shifts the h1 / h2 row blocks."""
 
-    def __init__(self, d, H, dp, Hp, dev, time_input=True):
+    def __init__(self, d, H, dp, Hp, dev, time_input=True, time_first=False, time_scale=1.0):
         """time_input=False: the real net is DenseNet(d -> 1) (EllipticSolver, reference solver.py:606); the kernels'
-        time row then stays zero in the padded vector, so the (finite) time register never reaches the value."""
+        time row then stays zero in the padded vector, so the (finite) time register never reaches the value.
+        time_first=True: the real net's input is [t, x] (Solver's value-function ansatz, solver.py:343-344) -- its row 0 goes
+        to the kernels' time row; time_scale multiplies the time rows on the way in and the gradient on the way out (the
+        kernels' time register holds n * dt where that ansatz feeds the step index n)."""
         self.d, self.H, self.dp, self.Hp, self.dev = d, H, dp, Hp, dev
-        self.identity = (d == dp and H == Hp and time_input)
+        self.identity = (d == dp and H == Hp and time_input and not time_first and time_scale == 1.0)
+        self.scale = None
         DI, DIp = d + (1 if time_input else 0), dp + 1
         self.P = DI * H + H + (DI + H) * H + H + (DI + 2 * H) + 1
         self.Pp = DIp * Hp + Hp + (DIp + Hp) * Hp + Hp + (DIp + 2 * Hp) + 1
@@ -164,7 +168,10 @@ class GenParamPad(ParamPad):
             self.idx = None
             return
         ar = torch.arange
-        rows_in = torch.cat([ar(d), torch.tensor([dp])]) if time_input else ar(d)  # x rows, then t
+        if time_input and time_first:
+            rows_in = torch.cat([torch.tensor([dp]), ar(d)])                             # t row first, then the x rows
+        else:
+            rows_in = torch.cat([ar(d), torch.tensor([dp])]) if time_input else ar(d)  # x rows, then t
         rows2 = torch.cat([rows_in, DIp + ar(H)])                                    # ... then h1
         rows3 = torch.cat([rows2, DIp + Hp + ar(H)])                                 # ... then h2
         oW1, ob1 = 0, DIp * Hp

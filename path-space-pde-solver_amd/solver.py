@@ -36,6 +36,7 @@ try:
     from .function_space import DenseNet, MySequential, SingleParam
     from .plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
     from .plan_dense_native import DenseNativePlan, dense_eligibility
+    from .plan_value_native import ValueNativePlan, value_eligibility
     from . import native as _nat
     from .general_solver import GeneralSolver, EllipticSolver  # noqa: F401  (reference: `from solver import GeneralSolver`)
     from .utilities import do_importance_sampling_me
@@ -43,6 +44,7 @@ except ImportError:  # flat import: this directory itself is on sys.path, as wit
     from function_space import DenseNet, MySequential, SingleParam
     from plan_native import HjbNativePlan, PlanUnsupported, native_eligibility
     from plan_dense_native import DenseNativePlan, dense_eligibility
+    from plan_value_native import ValueNativePlan, value_eligibility
     import native as _nat
     from general_solver import GeneralSolver, EllipticSolver  # noqa: F401
     from utilities import do_importance_sampling_me
@@ -260,6 +262,7 @@ class Solver:
         """Everything a native plan sizes its buffers / fixes its kernel configuration from: a plan built for other values
         must not be reused (the nets themselves are compared by identity)."""
         nets = tuple(id(z) for z in self.z_n) if isinstance(getattr(self, 'z_n', None), list) else (id(getattr(self, 'z_n', None)),)
+        nets = nets + tuple(id(v) for v in getattr(self, 'y_n', []))
         return (nets, self.noise, self.K, self.N, float(self.delta_t_np), self.loss_method, self.approx_method,
                 self.time_approx, bool(self.learn_Y_0), bool(self.adaptive_forward_process), bool(self.detach_forward),
                 bool(self.random_X_0), bool(self.u_l2_error_flag), self.mlp_dtype, self.path_budget_bytes, self.path_chunks,
@@ -268,6 +271,23 @@ class Solver:
     def _choose_plan(self):
         if self.backend == 'torch':
             self.plan_name, self.plan_reason = 'torch', "backend='torch' requested"
+            return None
+        if self.approx_method == 'value_function':
+            # value-net ansatz (solver.py:93-97, 334-339, 438-440): the GeneralSolver kernels with per-sample weights
+            reason = value_eligibility(self)
+            if reason is None:
+                self.plan_name, self.plan_reason = 'native', None
+                plan = getattr(self, '_native_plan', None)
+                if plan is None or not isinstance(plan, ValueNativePlan) or plan.key != self._plan_key():
+                    plan = ValueNativePlan(self, noise=self.noise)
+                    plan.key = self._plan_key()
+                    self._native_plan = plan
+                return plan
+            if self.backend == 'native':
+                raise PlanUnsupported('native plan unavailable: ' + reason)
+            if self.device.type == 'cuda':
+                warnings.warn('path-space solver: running the composite torch plan (%s)' % reason)
+            self.plan_name, self.plan_reason = 'torch', reason
             return None
         reason = native_eligibility(self)      # raises NativeLibraryError if the .so is missing on a GPU run
         if reason is None:

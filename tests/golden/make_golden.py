@@ -393,6 +393,22 @@ CASES = [
          solver=dict(approx_method="value_function", loss_method="log-variance", time_approx="inner",
                      adaptive_forward_process=True, detach_forward=False, early_stopping_time=None, L=4, lr=0.01, seed=42,
                      delta_t=0.05, K=64, u_l2_error_flag=False)),
+    # the same ansatz inside the native catalogue (plan_value_native.py): sigma = I, elementwise drift, h = -|z|^2 / 2, state path detached
+    dict(name="dw_d10_value_function", family="solver",
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=10, d_1=5, d_2=5, T=0.3, eta=0.5, kappa=2.0)),
+         solver=dict(approx_method="value_function", loss_method="log-variance", time_approx="inner",
+                     adaptive_forward_process=True, detach_forward=True, early_stopping_time=None, L=4, lr=0.005, seed=42,
+                     delta_t=0.01, K=96, u_l2_error_flag=False)),
+    dict(name="llgc_d8_diag_value_function_moment", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=8, off_diag=0.0, T=0.4, seed=42)),
+         solver=dict(approx_method="value_function", loss_method="moment", time_approx="inner",
+                     adaptive_forward_process=False, detach_forward=False, early_stopping_time=None, L=4, lr=0.003, seed=42,
+                     delta_t=0.02, K=80, u_l2_error_flag=False)),
+    dict(name="dw_d20_value_function_randx0", family="solver",
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=20, d_1=10, d_2=10, T=0.2, eta=1.0, kappa=1.0)),
+         solver=dict(approx_method="value_function", loss_method="log-variance", time_approx="inner",
+                     adaptive_forward_process=True, detach_forward=True, early_stopping_time=None, L=3, lr=0.002, seed=7,
+                     delta_t=0.01, K=112, u_l2_error_flag=False, random_X_0=True)),
     # importance-sampling evaluation of the learned control, standalone and in the loop
     dict(name="llgc_d20_is_eval", family="is",
          problem=dict(kind="LLGC", kwargs=dict(d=20, off_diag=0.0, T=0.3, seed=42)),
