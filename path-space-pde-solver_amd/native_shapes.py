@@ -189,3 +189,25 @@ class GenParamPad(ParamPad):
         ]
         self.idx = torch.cat(parts).to(dev)
         assert self.idx.numel() == self.P
+        if time_input and time_scale != 1.0:
+            tpos = 0 if time_first else d                                                # time row of W1 / W2 / W3 in the REAL net
+            sc = torch.ones(self.P)
+            oW1r, oW2r = 0, DI * H + H
+            oW3r = oW2r + (DI + H) * H + H
+            sc[oW1r + tpos * H:oW1r + (tpos + 1) * H] = time_scale
+            sc[oW2r + tpos * H:oW2r + (tpos + 1) * H] = time_scale
+            sc[oW3r + tpos] = time_scale
+            self.scale = sc.to(dev)
+
+    def scatter_params(self, flat, flat_pad):
+        if self.scale is None:
+            return super().scatter_params(flat, flat_pad)
+        flat_pad.index_copy_(0, self.idx, flat * self.scale)
+        return flat_pad
+
+    def gather_grad(self, grad_pad, out):
+        if self.scale is None:
+            return super().gather_grad(grad_pad, out)
+        torch.index_select(grad_pad, 0, self.idx, out=out)
+        out.mul_(self.scale)
+        return out

@@ -190,8 +190,8 @@ class Solver:
 
     # ---- control evaluation (solver.py:334-362) -----------------------------------------------
     def Y_n(self, X, t):
-        n = int(np.ceil(t / self.delta_t))
         if self.time_approx == 'outer':
+            n = int(torch.ceil(torch.as_tensor(t / self.delta_t)).item())     # (np.ceil of a device tensor fails on a GPU)
             return self.y_n[n](X)
         t_X = torch.cat([torch.ones([X.shape[0], 1]).to(X.device) * t, X], 1)
         return self.y_n[0](t_X)
