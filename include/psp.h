@@ -293,7 +293,9 @@ typedef struct psp_gen_config {
     int32_t mlp_dtype;    /* PSP_MLP_FP32 (0); PSP_MLP_BF16_FWD: the value-net products of the forward rollout (V, grad_x V,
                            * tangent pass) on v_mfma_f32_16x16x32_bf16 -- bf16 operands, fp32 accumulate; PSP_MLP_BF16: also the
                            * adjoint products and the weight-gradient outer products of the backward kernel.  State, Y,
-                           * accumulators, the path store and every element-wise step stay fp32 (BASELINE.json configs[2]) */
+                           * accumulators and every element-wise step stay fp32 (BASELINE.json configs[2]); with PSP_MLP_BF16 the
+                           * path store holds the six images as bf16 pairs (960 instead of 1 920 bytes per sample:
+                           * psp_gen_query reports the size), with PSP_MLP_BF16_FWD it stays fp32                           */
     /* Solver.train with approx_method='value_function' (solver.py:93-97, 334-339, 438-440: Z = sigma grad_x Y_n(X), loss +
      * mean_k sum_{n>=1} (Y_n(X_n) - Y)^2) runs on these kernels too (plan_value_native.py):                              */
     float* v_steps_out;   /* optional (N, 16*ceil(K_local/16)): V(X_n, t_n) at every step, written by psp_gen_rollout_fwd       */

@@ -36,6 +36,7 @@ struct GenArgs {
     const float* wV;      // (K_local) dLoss/dV(X_N)   (backward)
     float* Vsteps;        // optional (N, 16*ntile16): V(X_n, t_n) of every step (value_function ansatz of Solver, solver.py:438-440)
     float* Ysteps;        // optional (N, 16*ntile16): the running Y BEFORE the increment of step n
+    int path16;           // bf16-pair path block (GGeo::q*) instead of the fp32 register images: set with mlp_dtype == PSP_MLP_BF16
     int per_sample;       // backward: wY is (N+1, 16*ntile16) tangent weights per sample and ahat holds the value-gradient coefficient itself
     float* grad_partial;
     long long k_offset;
@@ -61,6 +62,13 @@ struct GGeo {
     // path block (16 samples): register images padded to whole blocks
     static constexpr int pX = 0, pU = pX + 4 * DBI * 64, pD1 = pU + 4 * DBI * 64, pD2 = pD1 + 4 * HB * 64,
                          pZ1 = pD2 + 4 * HB * 64, pZ2 = pZ1 + 4 * HB * 64, PB = pZ2 + 4 * HB * 64;
+    // bf16 path block (psp_gen_config.mlp_dtype == PSP_MLP_BF16: both rollout kernels on bf16 MFMA, whose operands are rounded
+    // to bf16 anyway): every image as bf16 PAIRS -- dword (2b + r', lane) packs k-steps 4b + r' (low half) and 4b + r' + 2
+    // (high half) of lane (j, q).  One dword per lane is two T-layout registers; the 16 bytes a lane reads in F layout hold
+    // four samples of feature 16b + 4r' + q (low halves) and of feature + 8 (high halves).  960 instead of 1 920 bytes per
+    // sample: both kernels of that mode are bound by the path store, not by the matrix pipe.
+    static constexpr int qX = 0, qU = qX + 2 * DBI * 64, qD1 = qU + 2 * DBI * 64, qD2 = qD1 + 2 * HB * 64,
+                         qZ1 = qD2 + 2 * HB * 64, qZ2 = qZ1 + 2 * HB * 64, PB16 = qZ2 + 2 * HB * 64;
     // forward LDS carve (floats): six A-operand tables + per-feature vectors
     static constexpr int fW1f = 0, fW2xf = fW1f + HB * KSI * 64, fW2hf = fW2xf + HB * KSI * 64,
                          fW2hr = fW2hf + HB * KSH * 64, fW2xr = fW2hr + HB * KSH * 64,
@@ -115,6 +123,29 @@ __device__ __forceinline__ f32x4 step2(f32x4 d) {
 // =======================================================================================
 // Forward kernel
 // =======================================================================================
+// ---- bf16-pair images (GGeo::q*): pack / unpack
+__device__ __forceinline__ float pk_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v;
+    v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(float, v);
+}
+__device__ __forceinline__ float bf_lo(float packed) { return __uint_as_float(__float_as_uint(packed) << 16); }
+__device__ __forceinline__ float bf_hi(float packed) { return __uint_as_float(__float_as_uint(packed) & 0xffff0000u); }
+// T-layout read of hidden block m of an image: `base` = block pointer + lane; fp32 image at float offset o32, pair image at o16
+template <bool P16>
+__device__ __forceinline__ f32x4 image_get_T(const float* base, int o32, int o16, int m) {
+    f32x4 v;
+    if constexpr (P16) {
+        const float u0 = base[o16 + (2 * m) * 64], u1 = base[o16 + (2 * m + 1) * 64];
+        v[0] = bf_lo(u0); v[2] = bf_hi(u0); v[1] = bf_lo(u1); v[3] = bf_hi(u1);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = base[o32 + (4 * m + r) * 64];
+    }
+    return v;
+}
+
 template <int D, int H, bool BF16 = false>
 __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
     using G = GGeo<D, H>;
@@ -222,6 +253,13 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 asm volatile("" : "+s"(addr));
                 return (gwptr_t)addr;
             };
+            auto pbase16 = [&](int slot, int ofs) __attribute__((always_inline)) {      // bf16-pair path block (GGeo::q*)
+                unsigned long long addr = (unsigned long long)a.path +
+                    4ull * (((unsigned long long)slot * a.ntile16 + t16) * (unsigned)G::PB16 + (unsigned)ofs);
+                asm volatile("" : "+s"(addr));
+                return (gwptr_t)addr;
+            };
+            const bool p16 = BF16 && a.path16;                    // wave-uniform
             const unsigned ul = (unsigned)lane;
             // ---- V(X,t) and the activations (solver.py:1100)
             f32x4 r1[HB], r2[HB];
@@ -339,11 +377,17 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 }
                 // keep the OLD X in the path store (the sample point), move afterwards
                 if (a.store_path) {
-                    gwptr_t px = pbase(n, G::pX + b * 256), pu = pbase(n, G::pU + b * 256);
+                    if (p16) {
+                        gwptr_t px = pbase16(n, G::qX + b * 128), pu = pbase16(n, G::qU + b * 128);
+                        px[ul] = pk_bf16(X[b][0], X[b][2]); px[64 + ul] = pk_bf16(X[b][1], X[b][3]);
+                        pu[ul] = pk_bf16(U[b][0], U[b][2]); pu[64 + ul] = pk_bf16(U[b][1], U[b][3]);
+                    } else {
+                        gwptr_t px = pbase(n, G::pX + b * 256), pu = pbase(n, G::pU + b * 256);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        px[r * 64 + ul] = X[b][r];
-                        pu[r * 64 + ul] = U[b][r];
+                        for (int r = 0; r < 4; ++r) {
+                            px[r * 64 + ul] = X[b][r];
+                            pu[r * 64 + ul] = U[b][r];
+                        }
                     }
                 }
                 X[b] = Xn;
@@ -381,7 +425,19 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 for (int m = 0; m < HB; ++m) h1d[m] = (2.0f * r1[m]) * z1h[m];
                 gen_gemm<BF16, HB, KSI, DBI>(z2h, lds + G::fW2xf, U, lane);
                 gen_gemm<BF16, HB, KSH, HB>(z2h, lds + G::fW2hf, h1d, lane);
-                {
+                if (p16) {
+                    gwptr_t p1 = pbase16(n, G::qD1), p2 = pbase16(n, G::qD2), p3 = pbase16(n, G::qZ1), p4 = pbase16(n, G::qZ2);
+#pragma unroll
+                    for (int m = 0; m < HB; ++m)
+#pragma unroll
+                        for (int rp = 0; rp < 2; ++rp) {
+                            const unsigned o = (unsigned)(2 * m + rp) * 64 + ul;
+                            p1[o] = pk_bf16(2.0f * r1[m][rp], 2.0f * r1[m][rp + 2]);
+                            p2[o] = pk_bf16(2.0f * r2[m][rp], 2.0f * r2[m][rp + 2]);
+                            p3[o] = pk_bf16(z1h[m][rp], z1h[m][rp + 2]);
+                            p4[o] = pk_bf16(z2h[m][rp], z2h[m][rp + 2]);
+                        }
+                } else {
                     gwptr_t p1 = pbase(n, G::pD1), p2 = pbase(n, G::pD2), p3 = pbase(n, G::pZ1), p4 = pbase(n, G::pZ2);
 #pragma unroll
                     for (int ks = 0; ks < 4 * HB; ++ks) {
@@ -405,7 +461,26 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             const f32x4* vecs = opaque(vecs0);
             f32x4 r1[HB], r2[HB];
             const float VN = net_value(vecs, r1, r2);
-            if (a.store_path) {
+            if (a.store_path && BF16 && a.path16) {
+                float* pblk = a.path + ((size_t)a.N * a.ntile16 + t16) * (size_t)G::PB16 + lane;
+#pragma unroll
+                for (int b = 0; b < DBI; ++b)
+#pragma unroll
+                    for (int rp = 0; rp < 2; ++rp) {
+                        pblk[G::qX + (2 * b + rp) * 64] = pk_bf16(X[b][rp], X[b][rp + 2]);
+                        pblk[G::qU + (2 * b + rp) * 64] = 0.f;
+                    }
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int rp = 0; rp < 2; ++rp) {
+                        pblk[G::qD1 + (2 * m + rp) * 64] = pk_bf16(2.0f * r1[m][rp], 2.0f * r1[m][rp + 2]);
+                        pblk[G::qD2 + (2 * m + rp) * 64] = pk_bf16(2.0f * r2[m][rp], 2.0f * r2[m][rp + 2]);
+                        pblk[G::qZ1 + (2 * m + rp) * 64] = 0.f;
+                        pblk[G::qZ2 + (2 * m + rp) * 64] = 0.f;
+                    }
+                if (q == 0) a.ahat[(size_t)a.N * (a.ntile16 * 16) + k] = 1.f;
+            } else if (a.store_path) {
                 float* pblk = a.path + ((size_t)a.N * a.ntile16 + t16) * (size_t)G::PB + lane;
 #pragma unroll
                 for (int ks = 0; ks < 4 * DBI; ++ks) { pblk[G::pX + ks * 64] = X[ks >> 2][ks & 3]; pblk[G::pU + ks * 64] = 0.f; }
@@ -783,8 +858,12 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     const int j = lane & 15, q = lane >> 4;
     const bool producer = wave < 4;
     const int sub = wave & 3;
-    const unsigned lofsU = (unsigned)image_lane_offset_F(lane);
     const int qq = lane >> 4, col = lane & 15;
+    // bf16 mode reads the bf16-pair path block (GGeo::q*): block stride PB16, F-layout lane offset inside a pair image, and
+    // the v_perm selector that turns the lane's half of a dword into an fp32 (features 4r+q with r >= 2 sit in the high halves)
+    constexpr unsigned PBx = BF16 ? (unsigned)G::PB16 : (unsigned)G::PB;
+    const unsigned lofsU = BF16 ? (unsigned)(64 * ((col >> 2) & 1) + 16 * (col & 3) + 4 * qq) : (unsigned)image_lane_offset_F(lane);
+    const unsigned selF = (col >> 3) ? 0x03020c0cu : 0x01000c0cu;
     const float* __restrict__ P = a.params;
 
     gen_stage<BF16>(lds + G::gW2hr, HB, KSH, HB, tid, nthr, [&](int row, int c2) {
@@ -813,16 +892,14 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
         f32x4 pd2[HB], pz2[HB], pd1[HB], pz1[HB];
         auto prefetch_block = [&](int it2) __attribute__((always_inline)) {
             const long long b0 = ((long long)blockIdx.x + (long long)it2 * gridDim.x) * 4 + sub;
-            const float* pb = a.path + (size_t)(b0 < nblk ? b0 : nblk - 1) * (size_t)G::PB + lane;
+            const float* pb = a.path + (size_t)(b0 < nblk ? b0 : nblk - 1) * (size_t)PBx + lane;
 #pragma unroll
-            for (int m = 0; m < HB; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pd2[m][r] = pb[G::pD2 + (4 * m + r) * 64];
-                    pz2[m][r] = pb[G::pZ2 + (4 * m + r) * 64];
-                    pd1[m][r] = pb[G::pD1 + (4 * m + r) * 64];
-                    pz1[m][r] = pb[G::pZ1 + (4 * m + r) * 64];
-                }
+            for (int m = 0; m < HB; ++m) {
+                pd2[m] = image_get_T<BF16>(pb, G::pD2, G::qD2, m);
+                pz2[m] = image_get_T<BF16>(pb, G::pZ2, G::qZ2, m);
+                pd1[m] = image_get_T<BF16>(pb, G::pD1, G::qD1, m);
+                pz1[m] = image_get_T<BF16>(pb, G::pZ1, G::qZ1, m);
+            }
         };
         prefetch_block(0);
         for (int it = 0; it <= R; ++it) {
@@ -834,11 +911,12 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                 float touch[5];
                 {
                     const long long xb0 = rb + sub;
-                    const float* xt = a.path + (size_t)(xb0 < nblk ? xb0 : nblk - 1) * (size_t)G::PB;
-                    constexpr int NA = G::pD2;                   // X, U, d1 images are contiguous: [0, pD2)
+                    const float* xt = a.path + (size_t)(xb0 < nblk ? xb0 : nblk - 1) * (size_t)PBx;
+                    constexpr int NA = BF16 ? G::qD2 : G::pD2;   // X, U, d1 images are contiguous: [0, pD2)
+                    constexpr int oZ1 = BF16 ? G::qZ1 : G::pZ1, nZ1 = (BF16 ? 2 : 4) * HB * 64;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { const int o = lane * 32 + i * 2048; touch[i] = xt[o < NA ? o : 0]; }
-                    touch[4] = xt[G::pZ1 + ((lane * 32 < 4 * HB * 64) ? lane * 32 : 0)];
+                    touch[4] = xt[oZ1 + ((lane * 32 < nZ1) ? lane * 32 : 0)];
                 }
                         // ---------------------------------------------------------- adjoints of the own block
                 {
@@ -849,7 +927,7 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
                     const int k = t16 * 16 + j;
                     const bool kvalid = bvalid && k < a.K_local;
-                    const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+                    const float* pb = a.path + (size_t)blk * (size_t)PBx + lane;
                     const bool fin = (n == a.N);
                     // wY / wV / ahat are zero-padded to 16*ntile16 entries: plain loads, no branch around them
                     const size_t wofs = a.per_sample ? (size_t)n * Kpad : 0;            // per-sample mode: wY is (N+1, Kpad), ahat IS the coefficient
@@ -861,12 +939,10 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     {
                         f32x4 d2[HB], z2t[HB];
         #pragma unroll
-                        for (int m = 0; m < HB; ++m)
-        #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                d2[m][r] = pb[G::pD2 + (4 * m + r) * 64];
-                                z2t[m][r] = wsv * pb[G::pZ2 + (4 * m + r) * 64];
-                            }
+                        for (int m = 0; m < HB; ++m) {
+                            d2[m] = image_get_T<BF16>(pb, G::pD2, G::qD2, m);
+                            z2t[m] = wsv * image_get_T<BF16>(pb, G::pZ2, G::qZ2, m);
+                        }
         #pragma unroll
                         for (int m = 0; m < HB; ++m) {
                             const f32x4 w3h2 = w3_T(G::oW3 + DI + H, m, o0);
@@ -884,12 +960,10 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     {   // d1 / z1^ are L2-resident (touch-prefetched one round ahead): fetch them only now
                         f32x4 d1[HB], z1t[HB];
         #pragma unroll
-                        for (int m = 0; m < HB; ++m)
-        #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                d1[m][r] = pb[G::pD1 + (4 * m + r) * 64];
-                                z1t[m][r] = wsv * pb[G::pZ1 + (4 * m + r) * 64];
-                            }
+                        for (int m = 0; m < HB; ++m) {
+                            d1[m] = image_get_T<BF16>(pb, G::pD1, G::qD1, m);
+                            z1t[m] = wsv * image_get_T<BF16>(pb, G::pZ1, G::qZ1, m);
+                        }
         #pragma unroll
                         for (int m = 0; m < HB; ++m) {
                             gz1[m] = gz1[m] * d1[m] + gz1t[m] * step2(d1[m]) * z1t[m];
@@ -952,10 +1026,12 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
 #pragma unroll
     for (int t = 0; t < NIB; ++t) cbc[t] = ((wh + WHc * t) < HB ? (wh + WHc * t) : HB - 1) * 256;
     // row item i of a block: i < NRX -> x rows (images X, U), else h rows (images d1, z1^); image offsets of the pair
-    auto row_ofs0 = [&](int i) { return i < NRX ? G::pX + ((wd + WDc * i) < DBI ? (wd + WDc * i) : DBI - 1) * 256
-                                               : G::pD1 + ((wd + WDc * (i - NRX)) < HB ? (wd + WDc * (i - NRX)) : HB - 1) * 256; };
-    auto row_ofs1 = [&](int i) { return i < NRX ? G::pU + ((wd + WDc * i) < DBI ? (wd + WDc * i) : DBI - 1) * 256
-                                               : G::pZ1 + ((wd + WDc * (i - NRX)) < HB ? (wd + WDc * (i - NRX)) : HB - 1) * 256; };
+    constexpr int oX = BF16 ? G::qX : G::pX, oU = BF16 ? G::qU : G::pU, oD1 = BF16 ? G::qD1 : G::pD1, oZ1c = BF16 ? G::qZ1 : G::pZ1;
+    constexpr int BLK = BF16 ? 128 : 256;              // dwords of one 16-feature block of an image
+    auto row_ofs0 = [&](int i) { return i < NRX ? oX + ((wd + WDc * i) < DBI ? (wd + WDc * i) : DBI - 1) * BLK
+                                               : oD1 + ((wd + WDc * (i - NRX)) < HB ? (wd + WDc * (i - NRX)) : HB - 1) * BLK; };
+    auto row_ofs1 = [&](int i) { return i < NRX ? oU + ((wd + WDc * i) < DBI ? (wd + WDc * i) : DBI - 1) * BLK
+                                               : oZ1c + ((wd + WDc * (i - NRX)) < HB ? (wd + WDc * (i - NRX)) : HB - 1) * BLK; };
     const int nblk_i = (int)nblk;
     auto blk_at = [&](long long c0) __attribute__((always_inline)) {
         const int c = (c0 < (long long)nblk_i) ? (int)c0 : nblk_i - 1;
@@ -963,9 +1039,17 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     };
     typedef const __attribute__((address_space(1))) float* gptr_t;
     auto get_F = [&](int blk, int ofs) __attribute__((always_inline)) {
-        unsigned long long addr = (unsigned long long)a.path + 4ull * ((unsigned long long)blk * (unsigned)G::PB + (unsigned)ofs);
+        unsigned long long addr = (unsigned long long)a.path + 4ull * ((unsigned long long)blk * PBx + (unsigned)ofs);
         asm volatile("" : "+s"(addr));
-        return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((gptr_t)addr + lofsU);
+        f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((gptr_t)addr + lofsU);
+        if constexpr (BF16) {                              // four samples of this lane's feature: its half of each dword -> fp32
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned u = __float_as_uint(v[e]);
+                v[e] = __uint_as_float(__builtin_amdgcn_perm(u, u, selF));
+            }
+        }
+        return v;
     };
     f32x4 ra[3], rb_[3];                               // 3-deep ring of row-operand pairs
     f32x4 w4n = zero4, a4n = zero4;                    // per-sample weights of the NEXT block (4 samples per lane)
@@ -1202,6 +1286,7 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
 
 struct GenInstance {
     int d, H, n_params, path_floats_per_block;
+    int path_dwords_per_block16;     // bf16-pair path block (mlp_dtype == PSP_MLP_BF16)
     int (*fwd_lds_bytes)();
     int (*bwd_lds_bytes)();
     hipError_t (*launch_fwd)(const GenArgs&, int grid, int block, hipStream_t);
@@ -1253,7 +1338,7 @@ struct GenLaunch {
         hipLaunchKernelGGL((gen_bwd_kernel<D, H>), dim3(grid), dim3(block), bwd_lds(), s, a);
         return hipGetLastError();
     }
-    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, &fwd_lds, &bwd_lds, &fwd, &bwd, &bwd2_lds, &bwd2, &fwd_bf16, &bwd2_bf16}; }
+    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, G::PB16, &fwd_lds, &bwd_lds, &fwd, &bwd, &bwd2_lds, &bwd2, &fwd_bf16, &bwd2_bf16}; }
 };
 
 }  // namespace psp

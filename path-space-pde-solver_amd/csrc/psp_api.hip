@@ -247,6 +247,7 @@ void fill_gen_args(const psp_gen_config* c, const GenPlan& p, psp::GenArgs* a) {
     a->d_real = (c->d_real > 0 && c->d_real < c->d) ? c->d_real : c->d;
     for (int i = 0; i < 4; ++i) a->h_par[i] = c->h_par[i];
     a->Vsteps = c->v_steps_out; a->Ysteps = c->y_steps_out; a->per_sample = c->per_sample_weights ? 1 : 0;
+    a->path16 = (c->mlp_dtype == PSP_MLP_BF16) ? 1 : 0;       // both kernels on bf16 MFMA: bf16-pair path block
 }
 
 // ---- small kernels -------------------------------------------------------------------
@@ -771,7 +772,8 @@ int psp_gen_query(const psp_gen_config* cfg, psp_gen_sizes* out) {
     out->n_params = p.inst.n_params;
     out->fwd_workgroups = p.fwd_grid;
     out->bwd_workgroups = p.bwd_grid;
-    out->path_bytes = cfg->store_path ? (int64_t)(cfg->N + 1) * p.ntile16 * (int64_t)p.inst.path_floats_per_block * 4 : 0;
+    const int64_t blk = cfg->mlp_dtype == PSP_MLP_BF16 ? p.inst.path_dwords_per_block16 : p.inst.path_floats_per_block;
+    out->path_bytes = cfg->store_path ? (int64_t)(cfg->N + 1) * p.ntile16 * blk * 4 : 0;
     out->ahat_bytes = (int64_t)(cfg->N + 1) * p.ntile16 * 16 * 4;
     out->grad_partial_bytes = (int64_t)p.bwd_grid * p.inst.n_params * 4;
     return 0;

@@ -335,7 +335,8 @@ class GeneralNativePlan:
     @property
     def log_v_l2(self):
         s = self.s
-        return self.elliptic and getattr(s, 'v_l2_error_flag', True) and hasattr(s.problem, 'v_true')
+        return (self.elliptic and getattr(s, 'v_l2_error_flag', True) and hasattr(s.problem, 'v_true')
+                and getattr(s, 'mlp_dtype', 'fp32') != 'bf16')          # (the bf16 mode keeps its X_n images as bf16 pairs)
 
     def _v_l2_from_path(self):
         """EllipticSolver's V_L2 log (solver.py:718, 738, 813): mean_k sum_{n alive} (V(X_n) - v_true(X_n))^2 dt, from the X_n
