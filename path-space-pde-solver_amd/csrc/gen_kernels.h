@@ -1331,6 +1331,8 @@ struct GenLaunch {
         hipLaunchKernelGGL((gen_fwd_kernel<D, H, true>), dim3(grid), dim3(block), fwd_lds(), s, a);
         return hipGetLastError();
     }
+#ifdef PSP_LEGACY_BWD
+    // gen_bwd_kernel: superseded by gen_bwd2_kernel; diagnostic builds only (-DPSP_LEGACY_BWD + PSP_BWD_VARIANT=1)
     static hipError_t bwd(const GenArgs& a, int grid, int block, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_bwd_kernel<D, H>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds());
@@ -1338,7 +1340,11 @@ struct GenLaunch {
         hipLaunchKernelGGL((gen_bwd_kernel<D, H>), dim3(grid), dim3(block), bwd_lds(), s, a);
         return hipGetLastError();
     }
-    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, G::PB16, &fwd_lds, &bwd_lds, &fwd, &bwd, &bwd2_lds, &bwd2, &fwd_bf16, &bwd2_bf16}; }
+    static constexpr auto legacy_bwd = &bwd;
+#else
+    static constexpr hipError_t (*legacy_bwd)(const GenArgs&, int, int, hipStream_t) = nullptr;
+#endif
+    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, G::PB16, &fwd_lds, &bwd_lds, &fwd, legacy_bwd, &bwd2_lds, &bwd2, &fwd_bf16, &bwd2_bf16}; }
 };
 
 }  // namespace psp

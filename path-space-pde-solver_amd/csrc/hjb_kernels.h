@@ -1444,6 +1444,10 @@ struct HjbLaunch {
         hipLaunchKernelGGL((hjb_fwd_kernel<D, H, true>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
+#ifdef PSP_LEGACY_BWD
+    // hjb_bwd_kernel (the second backward version: two 4-wave workgroups per CU, every wave runs all phases) is superseded by
+    // hjb_bwd2_kernel for every shipped instance; it is only instantiated in diagnostic builds (-DPSP_LEGACY_BWD, selected at
+    // run time with PSP_BWD_VARIANT=1) for A/B timing
     static hipError_t bwd(const HjbArgs& a, int grid, int block, hipStream_t s) {
         const int bytes = bwd_lds(a.adaptive);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_bwd_kernel<D, H>),
@@ -1452,6 +1456,10 @@ struct HjbLaunch {
         hipLaunchKernelGGL((hjb_bwd_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
+    static constexpr auto legacy_bwd = &bwd;
+#else
+    static constexpr hipError_t (*legacy_bwd)(const HjbArgs&, int, int, hipStream_t) = nullptr;
+#endif
     static int bwd2_lds() { return G::bwd2_lds_floats() * 4; }
     static hipError_t bwd2(const HjbArgs& a, int grid, hipStream_t s) {
         const int bytes = bwd2_lds();
@@ -1462,7 +1470,7 @@ struct HjbLaunch {
         return hipGetLastError();
     }
     static HjbInstance instance() {
-        return HjbInstance{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::PB, &bwd2_lds, &bwd2};
+        return HjbInstance{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, legacy_bwd, G::PB, &bwd2_lds, &bwd2};
     }
 };
 

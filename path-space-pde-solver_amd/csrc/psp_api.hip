@@ -133,8 +133,6 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
         return fail(-1, "config enum out of range");
     if (p->inst.fwd_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
         return fail(-3, "forward kernel weights do not fit the 160 KiB LDS for this (d,H,drift,sigma)");
-    if (p->inst.bwd_lds_bytes(c->adaptive) > kMaxLds)
-        return fail(-3, "backward kernel staging does not fit the 160 KiB LDS for this (d,H)");
     p->ntile16 = (c->K_local + 15) / 16;
     if ((long long)c->N * p->ntile16 >= (1LL << 31)) return fail(-1, "N * ceil(K/16) must stay below 2^31");
     const int cus = n_cus();
@@ -160,8 +158,13 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     // adaptive runs use the role-specialised kernel (one 8-wave workgroup per CU) when its double-buffered
     // exchange area fits the LDS; PSP_BWD_VARIANT=1 forces the two-workgroups-per-CU kernel (A/B timing)
     static const char* force = getenv("PSP_BWD_VARIANT");
-    p->bwd_specialised = p->inst.bwd2_lds_bytes() <= kMaxLds && !(force && force[0] == '1');
+    p->bwd_specialised = p->inst.bwd2_lds_bytes() <= kMaxLds && !(force && force[0] == '1' && p->inst.launch_bwd);
     if (p->inst.wide) p->bwd_specialised = true;          // launch_bwd2 = hjbw_bwd_kernel (4 waves)
+    if (!p->bwd_specialised && !p->inst.launch_bwd)
+        return fail(-3, "the role-specialised backward does not fit the LDS for this (d,H) and the library was built without "
+                        "the legacy backward kernels (-DPSP_LEGACY_BWD)");
+    if (!p->bwd_specialised && p->inst.bwd_lds_bytes(c->adaptive) > kMaxLds)
+        return fail(-3, "backward kernel staging does not fit the 160 KiB LDS for this (d,H)");
     p->bwd_waves = (p->bwd_specialised && !p->inst.wide) ? 8 : 4;
     long long g = nround;
     const long long gmax = (p->bwd_specialised && !(p->inst.wide && c->d <= 256)) ? cus : 2LL * cus;   // wide, d <= 256: two per CU
@@ -217,7 +220,7 @@ int make_gen_plan(const psp_gen_config* c, GenPlan* p) {
     if (c->domain_kind == PSP_DOM_BOX && !(c->dom_a < c->dom_b)) return fail(-1, "box bounds must satisfy X_l < X_r");
     if (c->drift_kind != PSP_DRIFT_ZERO && !c->drift) return fail(-1, "drift vector missing (double-well kappa / diagonal of A)");
     if ((c->v_steps_out == nullptr) != (c->y_steps_out == nullptr)) return fail(-1, "v_steps_out and y_steps_out go together");
-    if (p->inst.fwd_lds_bytes() > kMaxLds || p->inst.bwd_lds_bytes() > kMaxLds)
+    if (p->inst.fwd_lds_bytes() > kMaxLds)
         return fail(-3, "GeneralSolver kernel tables do not fit the 160 KiB LDS for this (d,H)");
     p->ntile16 = (c->K_local + 15) / 16;
     const int cus = n_cus();
@@ -228,7 +231,10 @@ int make_gen_plan(const psp_gen_config* c, GenPlan* p) {
     p->fwd_grid = (p->ntile16 + fw - 1) / fw;
     const long long nround = ((long long)(c->N + 1) * p->ntile16 + 3) / 4;
     static const char* force = getenv("PSP_BWD_VARIANT");
-    p->bwd_specialised = p->inst.bwd2_lds_bytes() <= kMaxLds && !(force && force[0] == '1');
+    p->bwd_specialised = p->inst.bwd2_lds_bytes() <= kMaxLds && !(force && force[0] == '1' && p->inst.launch_bwd);
+    if (!p->bwd_specialised && !p->inst.launch_bwd)
+        return fail(-3, "the role-specialised backward does not fit the LDS for this (d,H) and the library was built without "
+                        "the legacy backward kernels (-DPSP_LEGACY_BWD)");
     long long g = nround;
     const long long gmax = p->bwd_specialised ? cus : 2LL * cus;
     if (g > gmax) g = gmax;

@@ -1,7 +1,9 @@
-"""GeneralSolver backward: the role-specialised kernel (gen_bwd2_kernel) against the two-workgroups-per-CU kernel
-(gen_bwd_kernel, PSP_BWD_VARIANT=1) on a problem large enough that every workgroup runs MANY rounds (the golden cases
-are one round per workgroup, which cannot see cross-round pipeline bugs).  The variant is fixed when the library is
-loaded, so each runs in a child process.  Tolerance: fp32 with different summation orders -> 2e-4 of max|grad|."""
+"""GeneralSolver kernels beyond the golden cases:
+  * MANY rounds per persistent workgroup (the golden cases are one round each, which cannot see cross-round pipeline bugs):
+    K = 32768 / 20000 trajectories, N = 20, against the CPU oracle's autograd on the reference's noise stream;
+  * the bf16 MFMA modes (BASELINE.json configs[2]) against the fp32 kernels and the goldens, with their own tolerance.
+(The two-workgroups-per-CU backward gen_bwd_kernel that this file used to cross-check is no longer part of the shipped
+library: -DPSP_LEGACY_BWD diagnostic builds only.)"""
 import json
 import os
 import subprocess
@@ -12,38 +14,37 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-CHILD = r"""
-import json, sys, torch
-sys.path.insert(0, %(root)r)
-import path_space_pde_solver_amd as psp
-dev = torch.device('cuda:0')
-from path_space_pde_solver_amd import problems
-prob = problems.DoubleWell_multidim_for_general_solver(d=10, d_1=5, d_2=5, T=0.3, eta=1.0, kappa=1.0, modus='HJB', device=dev)
-m = psp.GeneralSolver(prob, 'var', seed=42, delta_t=0.01, N=20, lr=1e-3, L=2, K=%(K)d, K_boundary=50,
-                      loss_method='%(loss)s', verbose=False, device=dev, backend='native', noise='philox')
-m.V = psp.DenseNet(d_in=11, d_out=1, lr=1e-3, arch=[%(H)d, %(H)d], seed=42).to(dev)
-m.train()
-plan = m._gen_plan
-print(json.dumps({'loss': m.loss_log, 'K_log': m.K_log, 'gmax': float(plan.grad.abs().max()), 'g': plan.grad.cpu().tolist()}))
-"""
-
-
-def run_child(variant, K, H, loss):
-    env = dict(os.environ)
-    env['PSP_BWD_VARIANT'] = variant
-    out = subprocess.run([sys.executable, '-c', CHILD % dict(root=ROOT, K=K, H=H, loss=loss)], env=env,
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
-
 
 @pytest.mark.parametrize("K,H,loss", [(32768, 24, 'diffusion'), (20000, 32, 'BSDE')])
-def test_role_specialised_backward_matches_two_workgroup_backward(K, H, loss):
-    a, b = run_child('1', K, H, loss), run_child('0', K, H, loss)
-    assert a['K_log'] == b['K_log']
-    for x, y in zip(a['loss'], b['loss']):
-        assert abs(x - y) <= 2e-5 * max(1.0, abs(x)), (a['loss'], b['loss'])
-    assert max(abs(x - y) for x, y in zip(a['g'], b['g'])) <= 2e-4 * a['gmax']
+def test_many_rounds_match_the_oracle(K, H, loss):
+    import math
+
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util_cases import orc, psp
+    dev = torch.device('cuda:0')
+    pk = dict(d=10, d_1=5, d_2=5, T=0.3, eta=1.0, kappa=1.0, modus='HJB')
+    prob = psp.DoubleWell_multidim_for_general_solver(device=dev, **pk)
+    m = psp.GeneralSolver(prob, 'rounds', seed=42, delta_t=0.01, N=20, lr=1e-3, L=1, K=K, K_boundary=50,
+                          loss_method=loss, verbose=False, device=dev, backend='native', noise='reference')
+    m.V = psp.DenseNet(d_in=11, d_out=1, lr=1e-3, arch=[H, H], seed=42).to(dev)
+    m.train()
+    plan = m._gen_plan
+    nround = ((m.N + 1) * ((K + 15) // 16) + 3) // 4
+    assert nround >= 4 * plan.sizes.bwd_workgroups, (nround, plan.sizes.bwd_workgroups)
+    torch.set_num_threads(16)
+    oprob = orc.make_problem("DoubleWell_multidim_for_general_solver", **pk)
+    cfg = orc.GeneralConfig(K=K, N=20, delta_t=0.01, lr=1e-3, L=1, seed=42, K_boundary=50, alpha=(1.0, 1.0, 1.0),
+                            loss_method=loss)
+    ref = orc.general_train(oprob, cfg, V=orc.general_build(oprob, cfg, arch=[H, H]), trace=True)
+    assert m.K_log == ref["K_log"]
+    assert math.isclose(m.loss_log[0], ref["loss_log"][0], rel_tol=5e-5), (m.loss_log, ref["loss_log"])
+    g_ref = torch.cat([g.reshape(-1) for g in ref["traces"][0]["grads"]])
+    g = plan.grad.cpu()
+    err = float((g - g_ref).abs().max()) / float(g_ref.abs().max())
+    print("K=%d H=%d %s: %d rounds on %d workgroups, gradient rel err %.1e" % (K, H, loss, nround, plan.sizes.bwd_workgroups, err))
+    assert err <= 5e-4
 
 
 def test_bf16_forward_products_track_the_fp32_kernels():
