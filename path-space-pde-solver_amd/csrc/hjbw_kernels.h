@@ -206,6 +206,26 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
     }
 }
 
+// The four waves of a workgroup stream the SAME operand tables in the same order, each for its own tile.  A workgroup
+// barrier in front of every long product keeps them within a few k-steps of one another, so that a table line one wave
+// misses in the CU's vector L1 is a hit (or a merged in-flight miss) for the other three: the L2 -> L1 stream, which bounds
+// these kernels, is then shared instead of fetched per wave.  Every wave runs every step (surplus waves of the last
+// workgroup run along on the last tile), so the barriers are uniform.  -DPSP_WIDE_NOSYNC restores free-running waves (A/B).
+// Measured (round 2, d = 200 and d = 500): no gain (6.94 vs 6.9 ms, 38.9 vs 37 ms) -- the kernels are not bound by a per-wave
+// L2 -> L1 stream after all; the barriers stay available as -DPSP_WIDE_SYNC_ON for A/B runs.
+#if defined(PSP_WIDE_SYNC_ON) && PSP_WIDE_SYNC_ON
+#define PSP_WIDE_SYNC() __syncthreads()
+#else
+#define PSP_WIDE_SYNC()
+#endif
+// Path-store writes are a pure stream (read back by the next kernel, never by this one): non-temporal stores keep them from
+// displacing the operand tables in L2.  -DPSP_PATH_STORE_PLAIN restores ordinary stores (A/B).
+#if defined(PSP_PATH_STORE_PLAIN) && PSP_PATH_STORE_PLAIN
+#define PSP_PATH_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define PSP_PATH_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+
 // =======================================================================================
 // Wide forward kernel: one wave = one 16-trajectory tile for all N steps (same per-step algebra, same
 // reference lines as hjb_fwd_kernel)
@@ -300,7 +320,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
                     gwptr_t px = pbase(G::pX + g * 16 * 64);
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        if (g * 16 + e < KP) px[e * 64 + ul] = X[(g * 16 + e) >> 2][(g * 16 + e) & 3];
+                        if (g * 16 + e < KP) PSP_PATH_STORE(px + e * 64 + ul, X[(g * 16 + e) >> 2][(g * 16 + e) & 3]);
                 }
             }
             PSP_STAMP(ws1);
@@ -308,10 +328,12 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
             f32x4 h1[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
+            PSP_WIDE_SYNC();
             gemm_img<HB, KP>(h1, T + W::tW1, img, lane);
             PSP_STAMP(ws2);
             // ---- X_{n+1} = X + b(X) dt + sigma v (solver.py:471-472): the drift part now, while the image still holds X_n
             if (a.drift_kind == DRIFT_DENSE) {
+                PSP_WIDE_SYNC();
                 gemm_img<DB, KP>(X, T + W::tA, img, lane);                       // X += (dt A) X_n
             } else if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
@@ -333,8 +355,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
                 gwptr_t ph1 = pbase(G::pH1), ph2 = pbase(G::pH2);
 #pragma unroll
                 for (int ks = 0; ks < 4 * HB; ++ks) {
-                    ph1[ks * 64 + ul] = h1[ks >> 2][ks & 3];
-                    ph2[ks * 64 + ul] = h2[ks >> 2][ks & 3];
+                    PSP_PATH_STORE(ph1 + ks * 64 + ul, h1[ks >> 2][ks & 3]);
+                    PSP_PATH_STORE(ph2 + ks * 64 + ul, h2[ks >> 2][ks & 3]);
                 }
             }
             PSP_STAMP(ws4);
@@ -372,7 +394,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
                         gwptr_t pxi = pbase(G::pXi + b * 256);
                         const f32x4 wv = store_cxi * xi + store_cz * Zg[m];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pxi[r * 64 + ul] = wv[r];
+                        for (int r = 0; r < 4; ++r) PSP_PATH_STORE(pxi + r * 64 + ul, wv[r]);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -406,7 +428,10 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
             Pz = qsum(Pz);
             if constexpr (LOGU) ULsum = fmaf(UL, dt, ULsum);
             PSP_STAMP(ws5);
-            if (a.sigma_kind == SIGMA_DENSE) gemm_img<DB, KP>(X, T + W::tB, img, lane);     // X += B v
+            if (a.sigma_kind == SIGMA_DENSE) {
+                PSP_WIDE_SYNC();
+                gemm_img<DB, KP>(X, T + W::tB, img, lane);     // X += B v
+            }
 
             // ---- running cost f(X_{n+1}) and Y update (solver.py:477-478)
             float fX = 0.f;

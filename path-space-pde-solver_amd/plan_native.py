@@ -248,6 +248,18 @@ class HjbNativePlan:
             return
         Kc = -(-self.K_local // n)
         Kc = -(-Kc // 16) * 16
+        if not forced:
+            # whole launch waves: a chunk of a multiple of (16 trajectories x 4 tiles per workgroup x CUs) fills every CU the
+            # same number of times (K = 1048576 under a 32 GiB budget: 32 chunks of 32768 instead of 29 ragged ones, +24 %)
+            per_b = max(1, int(sizes.path_bytes) // max(1, self.K_local))          # store bytes per trajectory
+            fit = int(budget) // per_b
+            try:
+                cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            except Exception:                                                    # (size queries on a machine without a GPU)
+                cus = 256
+            quantum = 16 * 4 * cus
+            if fit >= quantum:
+                Kc = min(Kc if Kc % quantum == 0 else (fit // quantum) * quantum, (fit // quantum) * quantum)
         n = -(-self.K_local // Kc)
         if n <= 1:
             return
