@@ -239,6 +239,13 @@ int psp_iter_state_advance(psp_iter_state* dev_state, float beta1, float beta2, 
  * global sums (one rank); with several ranks call psp_hjb_terminal_reduce, all-reduce, and form the loss from the result. */
 int psp_hjb_terminal_reduce_loss(const psp_hjb_config* cfg, const double* fwd_partial, double* sums_out, float* loss_log,
                                  const uint32_t* index_dev, void* stream);
+/* psp_hjb_rollout_bwd + gradient reduction + Adam + psp_iter_state_advance as TWO launches instead of four (launch-bound sizes:
+ * each tiny launch costs ~4 us inside a replayed graph): the reduction kernel applies the Adam update to the parameter it has
+ * just summed and the last of its workgroups advances the state.  Only for the exact (unpadded) parameter layout, one rank,
+ * loss kinds the kernels weight themselves; `ticket` is one zero-initialised device uint32 owned by the caller. */
+int psp_hjb_rollout_bwd_step(const psp_hjb_config* cfg, float* params, const float* path, const float* D, const double* sums,
+                             float* grad_partial, float* grad_out, float* exp_avg, float* exp_avg_sq, psp_iter_state* dev_state,
+                             uint32_t* ticket, float lr, float beta1, float beta2, float eps, void* stream);
 /* psp_adam_step with step / bias corrections read from a device psp_iter_state. */
 int psp_adam_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const psp_iter_state* dev_state, float lr, float beta1, float beta2, float eps, void* stream);

@@ -316,6 +316,44 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
     p[i] = p[i] - step_size * (mi / denom);
 }
 
+// Launch-bound sizes (graph replay): partial gradients -> gradient -> Adam -> iteration state, ONE launch instead of three.
+// Every thread owns one parameter: fixed-order sum of the workgroup partials (as reduce_grad_kernel), the Adam update of
+// adam_dev_kernel with the bias corrections of the CURRENT state, then the last workgroup to finish advances the state
+// (every other workgroup has read it before its ticket).  grad_out still receives the gradient (diagnostics, tests).
+__global__ void reduce_grad_adam_advance_kernel(const float* __restrict__ part, int nwg, int P, float* __restrict__ grad_out,
+                                                float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                psp_iter_state* st, unsigned int* ticket, float lr, float b1, float b2, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double b1p = st->beta1_pow, b2p = st->beta2_pow;
+    if (i < P) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int w = 0;
+        for (; w + 8 <= nwg; w += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(w + u) * P + i];
+        }
+        for (int u = 0; w < nwg; ++w, ++u) s[u] += part[(size_t)w * P + i];
+        const float gi = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        grad_out[i] = gi;
+        const float step_size = (float)((double)lr / (1.0 - b1p));
+        const float bc2_sqrt = (float)sqrt(1.0 - b2p);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+    __syncthreads();                                           // every thread of this workgroup has read the state
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int t = atomicAdd(ticket, 1u);
+        if (t == gridDim.x - 1) {                              // last workgroup: all others read the state before their ticket
+            st->iter += 1u; st->step += 1u; st->beta1_pow = b1p * (double)b1; st->beta2_pow = b2p * (double)b2;
+            *ticket = 0u;
+        }
+    }
+}
+
 __global__ void reduce_grad_kernel(const float* __restrict__ part, int nwg, int P, float* __restrict__ out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
@@ -725,6 +763,31 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
                        grad_partial, p.bwd_grid, P, grad_out);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
+    return 0;
+}
+
+int psp_hjb_rollout_bwd_step(const psp_hjb_config* cfg, float* params, const float* path, const float* D, const double* sums,
+                             float* grad_partial, float* grad_out, float* exp_avg, float* exp_avg_sq, psp_iter_state* dev_state,
+                             uint32_t* ticket, float lr, float beta1, float beta2, float eps, void* stream) {
+    Plan p;
+    int rc = make_plan(cfg, &p);
+    if (rc) return rc;
+    if (!params || !path || !D || !sums || !grad_partial || !grad_out || !exp_avg || !exp_avg_sq || !dev_state || !ticket)
+        return fail(-1, "null buffer passed to psp_hjb_rollout_bwd_step");
+    psp::HjbArgs a;
+    fill_args(cfg, p, &a);
+    a.params = params; a.path = const_cast<float*>(path); a.D = const_cast<float*>(D);
+    a.sums = sums; a.grad_partial = grad_partial;
+    a.tables = reinterpret_cast<float*>(reinterpret_cast<char*>(grad_partial) + grad_rows_bytes(p));
+    if (a.dbg) a.dbg += (size_t)p.fwd_grid * 8 * 8;
+    hipError_t e = p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
+                                     : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");
+    const int P = p.inst.n_params;
+    hipLaunchKernelGGL(reduce_grad_adam_advance_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, grad_partial,
+                       p.bwd_grid, P, grad_out, params, exp_avg, exp_avg_sq, dev_state, ticket, lr, beta1, beta2, eps);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "reduce_grad_adam_advance_kernel launch");
     return 0;
 }
 

@@ -132,6 +132,8 @@ SIGNATURES = {
     "psp_iter_state_init": (C.c_int, [C.POINTER(IterState), C.c_uint32, C.c_int32, C.c_float, C.c_float]),
     "psp_iter_state_advance": (C.c_int, [_P, C.c_float, C.c_float, _P]),
     "psp_hjb_terminal_reduce_loss": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P, _P, _P]),
+    "psp_hjb_rollout_bwd_step": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float,
+                                           C.c_float, C.c_float, _P]),
     "psp_adam_step_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "psp_comm_unique_id": (C.c_int, [_P]),
     "psp_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _P]),

@@ -59,10 +59,11 @@ def native_eligibility(solver):
                 % solver.loss_method)
     if solver.burgers_drift:
         return 'burgers_drift is not native'
-    if solver.u_l2_error_flag and getattr(solver.problem, 'u_true_x_independent', False) is not True:
+    if solver.u_l2_error_flag and getattr(solver.problem, 'u_true_x_independent', False) is not True \
+            and getattr(solver.problem, 'u_true_linear_in_x', False) is not True:
         return ('u_l2_error_flag=True evaluates problem.u_true(X_n, t_n) on the host every step '
-                '(reference solver.py:491-494); only a u_true that does not depend on x (LLGC) is logged inside '
-                'the kernels -- pass u_l2_error_flag=False for the native plan')
+                '(reference solver.py:491-494); a u_true that does not depend on x (LLGC) is logged inside the kernels, one '
+                'that is linear in x (LQGC) from the path store -- pass u_l2_error_flag=False for the native plan otherwise')
     if solver.compute_gradient_variance > 0 or solver.log_gradient:
         return 'per-iteration diagnostics (gradient variance / gradient log) are not native'
     if solver.metastability_logs is not None:
@@ -175,7 +176,17 @@ class HjbNativePlan:
         self.v = torch.zeros(self.P, dtype=torch.float32, device=dev)
         self.x0_vec = dev_f32(pad.vec(solver.X_0.detach().to(dev)))
         self.ul2 = None
-        if solver.u_l2_error_flag:
+        self.ul2_gain = None
+        if solver.u_l2_error_flag and getattr(solver.problem, 'u_true_x_independent', False) is not True:
+            # u*(x, t_n) = M_n x (LQGC, problems.py:169-171): M_n once per plan by probing u_true with the unit vectors; the log
+            # is then formed from the X_n and h2 images of the path store after the forward kernel (_ul2_from_path)
+            import numpy as np
+            eye = torch.eye(solver.d)
+            gains = [torch.tensor(np.asarray(solver.problem.u_true(eye, n * solver.delta_t_np))).reshape(solver.d, solver.d).float()
+                     for n in range(solver.N)]                                       # u_true returns (d, K): column i = M e_i
+            self.ul2_gain = torch.stack(gains).to(dev)                             # (N, d, d) = M_n
+            self.XN_k = torch.empty(self.K_local, self.d_pad, dtype=torch.float32, device=dev)
+        elif solver.u_l2_error_flag:
             # u_L2 log (solver.py:491-494) for an x-independent reference control: u*(t_n) once per plan instead of
             # problem.u_true(X.cpu(), t_n) every step of every iteration; the kernels accumulate |-Z_n - u*(t_n)|^2 dt
             import numpy as np
@@ -246,6 +257,8 @@ class HjbNativePlan:
         self.chunk_mode = None
         if n <= 1:
             return
+        if solver.u_l2_error_flag and getattr(solver.problem, 'u_true_x_independent', False) is not True:
+            raise PlanUnsupported('the u_L2 log of an x-dependent reference control reads the whole path store: not with K-chunking')
         Kc = -(-self.K_local // n)
         Kc = -(-Kc // 16) * 16
         if not forced:
@@ -452,7 +465,7 @@ class HjbNativePlan:
         if want is False:
             return False
         ok = (self.world == 1 and self.noise == 'philox' and not self.s.random_X_0 and not self.generic_loss
-              and not self.attached and self.ul2 is None and self.n_chunks == 1)
+              and not self.attached and self.ul2 is None and self.ul2_gain is None and self.n_chunks == 1)
         if not ok:
             return False
         if want is True:
@@ -484,11 +497,18 @@ class HjbNativePlan:
         d_or_w, bcfg = self.D, cfg
         if self.relent:                                  # detached relative entropy: weight sqrt(dt) / K on the Z image
             d_or_w, bcfg = self.w_bwd, self._gcfg_w
+        lr, b1, b2, eps = self._graph_hyper
+        if self.pad.identity and not self.learn_y0:
+            # backward + (gradient reduction, Adam, state advance) as two launches
+            nat.check(lib.psp_hjb_rollout_bwd_step(C.byref(bcfg), nat.ptr(self.flat), nat.ptr(self.path), nat.ptr(d_or_w),
+                                                   nat.ptr(self.sums), nat.ptr(self.grad_partial), nat.ptr(self.grad),
+                                                   nat.ptr(self.m), nat.ptr(self.v), state, nat.ptr(self._gticket),
+                                                   lr, b1, b2, eps, st), 'psp_hjb_rollout_bwd_step')
+            return
         nat.check(lib.psp_hjb_rollout_bwd(C.byref(bcfg), nat.ptr(flat_k), None, seed, 0, nat.ptr(self.path),
                                           nat.ptr(d_or_w), nat.ptr(self.sums), nat.ptr(self.grad_partial),
                                           nat.ptr(self.grad_k), st), 'psp_hjb_rollout_bwd')
         self.pad.gather_grad(self.grad_k, self.grad)
-        lr, b1, b2, eps = self._graph_hyper
         nat.check(lib.psp_adam_step_dev(nat.ptr(self.flat), nat.ptr(self.grad), nat.ptr(self.m), nat.ptr(self.v), self.P,
                                         state, lr, b1, b2, eps, st), 'psp_adam_step_dev')
         if self.learn_y0:
@@ -515,6 +535,7 @@ class HjbNativePlan:
         if self._graph is None or self._graph_key != key:
             self._graph_hyper = hyper
             self._gstate = torch.zeros(24, dtype=torch.uint8, device=self.dev)
+            self._gticket = torch.zeros(1, dtype=torch.int32, device=self.dev)
             self._gcfg = nat.HjbConfig.from_buffer_copy(self.cfg)
             self._gcfg.iter_dev = nat.ptr(self._gstate)
             if self.relent:
@@ -534,6 +555,30 @@ class HjbNativePlan:
         self.step += 1
         self.graph_active = True
         return loss_out[l]
+
+    def _ul2_from_path(self):
+        """u_L2 log (solver.py:491-494) for a reference control that is linear in x: sum_k sum_n |-Z_n - M_n X_n|^2 dt / K over this
+        rank's trajectories, from the register images the forward kernel left in the path store -- block (n, tile): X_n image at
+        float 0, h2 image behind the h1 image; image float ks * 64 + 16 q + j holds feature 4 ks + q of sample j (csrc/hjb_kernels.h
+        Geo::pX / pH2).  Z_n = W3 h2 + b3 with the net's own parameters.  A diagnostic: K N small products in torch, skipped
+        with u_l2_error_flag=False (as the timed runs do)."""
+        s = self.s
+        N, nt = s.N, (self.K_local + 15) // 16
+        PB = self.sizes.path_bytes // 4 // (N * nt)
+        DBp, HBp = (self.d_pad + 15) // 16, (self.H_pad + 15) // 16
+        blocks = self.path.view(N, nt, PB)
+
+        def image(off, nb):
+            img = blocks[:, :, off:off + 4 * nb * 64].reshape(N, nt, 4 * nb, 4, 16)
+            return img.permute(0, 1, 4, 2, 3).reshape(N, nt * 16, 16 * nb)[:, :self.K_local]
+        # the reference compares -Z_n(X_n) with u*(X_{n+1}, t_n): the log line sits AFTER the Euler step (solver.py:471-472, 491-494)
+        X = torch.cat([image(0, DBp)[1:, :, :s.d], self.XN_k[:, :s.d].unsqueeze(0)], 0)
+        h2 = image(4 * DBp * 64 + 4 * HBp * 64, HBp)[:, :, :self.H]
+        lin = self.net.linears[-1]
+        with torch.no_grad():
+            Z = h2 @ lin.weight.t() + lin.bias                                  # (N, K, d)
+            u_ref = torch.bmm(X, self.ul2_gain.transpose(1, 2))                 # M_n X_n
+            return ((-Z - u_ref) ** 2).sum() * s.delta_t / float(s.K)
 
     def _finish_step(self, st, w_generic):
         """Gather the real gradient entries, all-reduce, Adam on the net and on the learnable Y_0."""
@@ -605,7 +650,7 @@ class HjbNativePlan:
             ev[0].record()
         nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(x0_t), x0_stride, y0_ptr,
                                           nat.ptr(xi), seed, l, nat.ptr(self.path), nat.ptr(self.D),
-                                          nat.ptr(self.XN_k) if self.attached else None,
+                                          nat.ptr(self.XN_k) if (self.attached or self.ul2_gain is not None) else None,
                                           nat.ptr(self.Yn), nat.ptr(self.fwd_partial), st), 'psp_hjb_rollout_fwd')
         if ev is not None:
             ev[1].record()
@@ -626,6 +671,10 @@ class HjbNativePlan:
             loss_out[l] = loss.to(torch.float32)
         if self.ul2 is not None and ul2_out is not None:
             m = (self.ul2.sum() / float(s.K)).reshape(1)
+            sharding.allreduce_sum_(m)
+            ul2_out[l:l + 1] = m
+        elif self.ul2_gain is not None and ul2_out is not None:
+            m = self._ul2_from_path().reshape(1)
             sharding.allreduce_sum_(m)
             ul2_out[l:l + 1] = m
         if ev is not None:

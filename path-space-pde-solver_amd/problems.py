@@ -170,6 +170,8 @@ class LQGC(_LinearDriftMixin):
     def h(self, t, x, y, z):
         return -0.5 * torch.sum(z ** 2, dim=1) - self.f(x, t)
 
+    u_true_linear_in_x = True      # u*(x, t) = M(t) x: the native plan tabulates M(t_n) once and logs u_L2 from its path store
+
     def u_true(self, x, t):
         n = int(np.ceil(t / self.delta_t))
         gain = self.Q.cpu().inverse() @ self.B.cpu().t() @ self.F[n]

@@ -29,7 +29,9 @@ NATIVE_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_l
                 "lqgc_d4_relative_entropy", "llgc_d20_relative_entropy_detached",
                 "lqgc_d2_attached_cross_entropy", "llgc_d200_nonadaptive_logvar",
                 # u_L2 logging on (the reference default): accumulated inside the forward kernels
-                "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2"]
+                "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2",
+                # ... and for a reference control that is LINEAR in x (LQGC, u* = M_n x): from the path store
+                "lqgc_d2_logvar"]
 
 
 def dev():
