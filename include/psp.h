@@ -348,8 +348,10 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
  *                                                              -> per_step = 1, time_input = 0
  *   a DenseNet(d+1 -> d) swapped into z_n with time_approx='inner' (solver.py:142-162, 355: input [t, x])
  *                                                              -> per_step = 0, time_input = 1
- * Forward rollout only: the parameter gradient of this family is formed by library GEMMs on the flat batches the
- * rollout stores (X_n and the xi image, row-major with the REAL widths), see plan_dense_native.py.
+ * Forward rollout (psp_dnet_rollout_fwd) and parameter gradient (psp_dnet_rollout_bwd, a hand-written kernel over the register
+ * images the rollout leaves in psp_dnet_config.images_out).  Instances whose accumulator tiles do not fit a wave's
+ * registers (psp_dnet_sizes.bwd_supported = 0: d = 256) get the rollout's row-major stores instead (px, pxi, r1_out, r2_out)
+ * and the caller forms the same gradient with library GEMMs, see plan_dense_native.py.
  * base.d / base.H name the compiled instance (psp_dnet_instance_get; whole 16-blocks); d_real <= d, H_real <= H are
  * the net's sizes.  params = per_step ? N : 1 consecutive parameter sets in the DenseNet's registration order
  *     [W1 (di x H_real), b1, W2 ((di+H_real) x H_real), b2, W3 ((di+2 H_real) x d_real), b3],  di = d_real + time_input,
