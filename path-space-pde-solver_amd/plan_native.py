@@ -206,7 +206,7 @@ class HjbNativePlan:
                 self.mu = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
                 self.nu = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
                 self.wT = torch.zeros(self.K_local, dtype=torch.float32, device=dev)
-        self.step = 0
+        self.step = sharding.adam_state_import(net.flat_layout(), self.m, self.v, getattr(net, 'optim', None))
         self.events = None   # bench.py: list collecting HIP-event pairs around the two rollout kernels
         self.pass1_events = None
         if self.n_chunks > 1:
@@ -224,6 +224,7 @@ class HjbNativePlan:
             self.y0_m = torch.zeros(1, dtype=torch.float32, device=dev)
             self.y0_v = torch.zeros(1, dtype=torch.float32, device=dev)
             self.y0_grad = torch.zeros(1, dtype=torch.float32, device=dev)
+            sharding.adam_state_import([self.y0_param], self.y0_m, self.y0_v, getattr(solver.y_0, 'optim', None))
 
     # ------------------------------------------------------------------------------------
     def _flatten(self, net):
@@ -596,6 +597,12 @@ class HjbNativePlan:
             nat.check(lib.psp_adam_step(nat.ptr(self.y0_param), nat.ptr(self.y0_grad), nat.ptr(self.y0_m),
                                         nat.ptr(self.y0_v), 1, self.step, ylr, yb1, yb2, yeps, st),
                       'psp_adam_step(Y_0)')
+
+    def export_optimizer_state(self):
+        """Called by Solver._train_native when training returns: the nets' own optimisers see the moments this plan kept."""
+        sharding.adam_state_export(self.net.flat_layout(), self.m, self.v, self.step, getattr(self.net, 'optim', None))
+        if self.learn_y0:
+            sharding.adam_state_export([self.y0_param], self.y0_m, self.y0_v, self.step, getattr(self.s.y_0, 'optim', None))
 
     def _adam_hyper(self, net=None):
         """lr, betas, eps of the net's OWN optimiser (function_space.py:185: each ansatz space builds its Adam in its

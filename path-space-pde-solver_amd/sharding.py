@@ -85,3 +85,37 @@ def y0_gradient(sums, K_global, loss_method, w_local=None):
         allreduce_sum_(tot)
         return tot[0]
     return torch.zeros((), dtype=sums.dtype, device=sums.device)
+
+
+# ---- Adam state hand-over between a native plan and the nets' own torch optimisers -----------------------------------
+def adam_state_export(params, m_flat, v_flat, step, optim):
+    """Mirrors a plan's flat Adam moments into `optim.state` (torch.optim.Adam layout: step / exp_avg / exp_avg_sq per
+    parameter, in `params` order), so that a later torch-side step, a state_dict() or a composite-plan run continues the same
+    optimiser instead of restarting it -- the reference keeps this state in phi.optim (function_space.py:185)."""
+    if optim is None or step <= 0:
+        return
+    off = 0
+    for p in params:
+        n = p.numel()
+        st = optim.state[p]
+        st['step'] = torch.tensor(float(step))
+        st['exp_avg'] = m_flat[off:off + n].view(p.shape).clone()
+        st['exp_avg_sq'] = v_flat[off:off + n].view(p.shape).clone()
+        off += n
+
+
+def adam_state_import(params, m_flat, v_flat, optim):
+    """The reverse at plan construction: if the net's optimiser already carries Adam state (a previous torch run, a loaded
+    checkpoint), the plan continues from it.  Returns the step count (0: fresh)."""
+    if optim is None:
+        return 0
+    steps, off = [], 0
+    for p in params:
+        st = optim.state.get(p, {})
+        n = p.numel()
+        if 'exp_avg' in st and 'exp_avg_sq' in st:
+            m_flat[off:off + n].copy_(st['exp_avg'].reshape(-1).to(m_flat.device))
+            v_flat[off:off + n].copy_(st['exp_avg_sq'].reshape(-1).to(v_flat.device))
+            steps.append(int(float(st.get('step', 0))))
+        off += n
+    return max(steps) if steps else 0

@@ -367,6 +367,8 @@ class Solver:
                     recent = self.u_L2_loss[-self.early_stopping_time:]
                     if np.std(recent) / self.u_L2_loss[-1] < 0.02:
                         break
+        if hasattr(plan, 'export_optimizer_state'):
+            plan.export_optimizer_state()       # phi.optim carries the Adam state, as in the reference (function_space.py:185)
 
     def _train_composite(self):
         """The reference iteration restated with torch ops on self.device (solver.py:430-554)."""

@@ -59,3 +59,27 @@ def test_graph_is_the_default_for_small_K_and_follows_the_loss_buffer():
     ref = make_pkg_solver(case, dev(), backend="native", noise="reference", L=2, K=1024, use_graph=True)
     ref.train()
     assert not ref._native_plan.graph_active
+
+
+def test_adam_state_is_handed_to_the_nets_own_optimiser_and_back():
+    """The reference keeps Adam's state in phi.optim (function_space.py:185).  After a native train() the net's optimiser holds
+    the plan's moments, so (a) a composite-plan continuation and (b) a rebuilt native plan both continue the SAME optimiser:
+    native 3 + native 3 iterations (second train() after the plan was dropped) equals native 6 iterations."""
+    case = load_golden("lqgc_d2_logvar_noul2")["case"]
+    six = make_pkg_solver(case, dev(), backend="native", noise="philox", L=6, use_graph=False)
+    six.train()
+    a = make_pkg_solver(case, dev(), backend="native", noise="philox", L=3, use_graph=False)
+    a.train()
+    st = a.z_n.optim.state[a.z_n.linears[0].weight]
+    assert int(float(st["step"])) == 3 and float(st["exp_avg_sq"].abs().max()) > 0.0
+    a._native_plan = None                                  # force a new plan: it must pick the optimiser state up again
+    plan = a._choose_plan()
+    assert plan.step == 3
+    losses = torch.zeros(6, device=dev())
+    for l in range(3, 6):                                  # same Philox iteration indices as the 6-iteration run
+        plan.iteration(l, losses)
+    torch.cuda.synchronize()
+    got = a.loss_log + losses[3:].cpu().tolist()
+    for x, y in zip(got, six.loss_log):
+        assert math.isclose(x, y, rel_tol=1e-6), (got, six.loss_log)
+    assert float((flat_params(a.z_n) - flat_params(six.z_n)).abs().max()) <= 1e-6
