@@ -553,18 +553,10 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
     for (int b = 0; b < DB; ++b) { acc3[b] = zero4; acc1[b] = zero4; }
 #pragma unroll
     for (int m = 0; m < HB; ++m) acc2[m] = zero4;
-    f32x4 sZ2[HB], bs1 = zero4, bt1 = zero4;
-    float bs3[OBW];
-#pragma unroll
-    for (int m = 0; m < HB; ++m) sZ2[m] = zero4;
+    f32x4 bs1 = zero4, bt1 = zero4;
+    float bs3[OBW], bs2 = 0.f;                        // bs2: db2 of hidden block `wave`, from the exchange tiles in phase B
 #pragma unroll
     for (int i = 0; i < OBW; ++i) bs3[i] = 0.f;
-    float w2b[16];                                    // B operands of the dz1 product: W2[4 ks + q][16 ib + n]
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-        const int o = 4 * ks + q, i = 16 * wave + j;
-        w2b[ks] = (o < H && i < H) ? P[G::oW2 + o * H + i] : 0.f;
-    }
 
     int par = 0;
 #pragma unroll 1
@@ -582,18 +574,29 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
             const float wk = kvalid ? (a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)) : 0.f;
             const float wks = wk * sqdt;
             const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+            // (An L2 touch-prefetch of the images phase B streams, and of the next round's xi image, was tried in round 2 and
+            //  made both kernels slower -- d=200 3.52 -> 3.73 ms, d=500 8.0 -> 8.8 ms: a whole round of d=500 images per CU is
+            //  the size of the XCD's L2, the touched lines are evicted before they are used.)
+            // under the 256-register cap of the d <= 256 instances (two workgroups per CU) the persistent accumulators leave
+            // this phase ~90 registers: a two-stage operand ring and h2 loaded AFTER the k-loop instead of before it keep the
+            // phase inside the budget (round 1: three stages + early h2 = 54 spilled registers, 1.65 GB of scratch traffic
+            // per launch at d = 200)
+            constexpr bool TIGHT = (D <= 256);
+            constexpr int NSTG = TIGHT ? 2 : 3;
             f32x4 h2[HB];
+            if constexpr (!TIGHT) {
 #pragma unroll
-            for (int m = 0; m < HB; ++m)
+                for (int m = 0; m < HB; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
+                    for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
+            }
             f32x4 dz2[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) dz2[m] = zero4;
             // rolled k-loop, 4 k-steps per iteration, operands of the next iteration in flight
             const float* xip = pb + G::pXi;
             const unsigned ul = (unsigned)lane;
-            float xb[3][4], ab[3][4 * HB];
+            float xb[NSTG][4], ab[NSTG][4 * HB];
             auto load = [&](int st, int ks0) __attribute__((always_inline)) {
                 gptr_t tp = sgpr_ptr(T + (size_t)ks0 * (HB * 64));
 #pragma unroll
@@ -615,19 +618,24 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
             // MFMAs of stage g issue (two stages = 32 MFMAs = ~1 k cycles of lead for the L2-resident table / xi image)
             constexpr int NG = KP / 4;
             load(0, 0);
-            if (NG > 1) load(1, 4);
+            if (NSTG > 2 && NG > 1) load(1, 4);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if (g + 2 < NG) load((g + 2) % 3, 4 * (g + 2));
+                if (g + NSTG - 1 < NG) load((g + NSTG - 1) % NSTG, 4 * (g + NSTG - 1));
                 __builtin_amdgcn_sched_barrier(0);
-                fma_stage(g % 3);
+                fma_stage(g % NSTG);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (TIGHT) {
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
             }
             float* ex = exch + wave * EXB + lane;
 #pragma unroll
             for (int m = 0; m < HB; ++m) {
                 dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
-                sZ2[m] += dz2[m];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ex[(4 * m + r) * 64] = dz2[m][r];
             }
@@ -652,14 +660,25 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
             }
             const f32x4 h2t = *reinterpret_cast<const f32x4*>(bp + G::pH2 + wave * 256 + lofsU);
             const f32x4 h1t = *reinterpret_cast<const f32x4*>(bp + G::pH1 + wave * 256 + lofsU);
-            // dz1 tile of hidden block ib: (dz2^T W2[:, ib]) (1 - h1^2)
+            // dz1 tile of hidden block ib: (dz2^T W2[:, ib]) (1 - h1^2).  The B operands W2[4 ks + q][16 ib + n] are re-read per
+            // sample block (16 cache-resident loads) so that they are live neither through phase A nor through the state-block
+            // stream below: under the 256-register cap every persistent register is a spill somewhere else
             f32x4 dzt = zero4;
+            {
+                float w2b[16];
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) dzt = mfma16(ex[ks * 64 + lane], w2b[ks], dzt);
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int o = 4 * ks + q, i = 16 * wave + j;
+                    w2b[ks] = (o < H && i < H) ? P[G::oW2 + opaque_i(0) + o * H + i] : 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) dzt = mfma16(ex[ks * 64 + lane], w2b[ks], dzt);
+            }
             // dW2[:, ib] += dz2^T h1
 #pragma unroll
             for (int m = 0; m < HB; ++m) {
                 const f32x4 a2 = tile_get(ex + m * 256, lane);
+                if (m == wave) bs2 += hsum4(a2);      // db2[16 m + (lane & 15)]: this lane's four samples of the dz2 tile
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc2[m] = mfma16(a2[r], h1t[r], acc2[m]);
             }
@@ -669,7 +688,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
             // stream over the state blocks: xi tile -> G tile -> dW3, X tile -> dW1 (tiles of block ob + 2 in flight)
             const float* xib = bp + G::pXi + lofsU;
             const float* xb = bp + G::pX + lofsU;
-            constexpr int RD = 6;                                     // ring depth: RD - 1 tiles (~1.3 k cycles) ahead
+            constexpr int RD = (D <= 208) ? 5 : (D <= 256 ? 3 : 6);                    // ring depth: RD - 1 tiles ahead (6: ~1.3 k cycles; 4 under the register cap)
             f32x4 xit[RD], xt[RD];
 #pragma unroll
             for (int i = 0; i < RD - 1; ++i) {
@@ -728,17 +747,12 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
         const int f = 16 * ob + col;
         if (qq == 0 && ob < DB && f < D) gp[G::ob3 + f] = v;
     }
-    // db2: the four waves' phase-A sums (lane (j, q), component r of block m <-> feature 16 m + 4 r + q), fixed order
-    float* red = lds + wave * 64;
-#pragma unroll
-    for (int m = 0; m < HB; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v2 = jsumf(sZ2[m][r]);
-            if (j == 0) red[16 * m + 4 * r + q] = v2;
-        }
-    __syncthreads();
-    if (tid < H) gp[G::ob2 + tid] = (lds[tid] + lds[64 + tid]) + (lds[128 + tid] + lds[192 + tid]);
+    // db2 of hidden block `wave`: lane (col, qq) holds the sum over its sample quarters; fixed-order sum over qq
+    {
+        const float v2 = qsum(bs2);
+        const int f = 16 * ib + col;
+        if (qq == 0 && f < H) gp[G::ob2 + f] = v2;
+    }
 }
 
 // =======================================================================================
