@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
             // stream over the state blocks: xi tile -> G tile -> dW3, X tile -> dW1 (tiles of block ob + 2 in flight)
             const float* xib = bp + G::pXi + lofsU;
             const float* xb = bp + G::pX + lofsU;
-            constexpr int RD = (D <= 208) ? 5 : (D <= 256 ? 3 : 6);                    // ring depth: RD - 1 tiles ahead (6: ~1.3 k cycles; 4 under the register cap)
+            constexpr int RD = (D <= 208) ? 5 : (D <= 256 ? 3 : 10);                    // ring depth: RD - 1 tiles ahead (6: ~1.3 k cycles; 4 under the register cap)
             f32x4 xit[RD], xt[RD];
 #pragma unroll
             for (int i = 0; i < RD - 1; ++i) {
