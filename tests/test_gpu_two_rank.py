@@ -27,12 +27,12 @@ def _free_port():
     return p
 
 
-def _train(noise, out=None, rank=0, detach=True):
+def _train(noise, out=None, rank=0, detach=True, **extra):
     sys.path.insert(0, ROOT)
     import path_space_pde_solver_amd as psp
     dev = torch.device("cuda:0")
     prob = psp.LLGC(d=100, off_diag=0.01, T=0.2, seed=42, device=dev)
-    model = psp.Solver("two-rank", prob, device=dev, noise=noise, **dict(CFG, detach_forward=detach))
+    model = psp.Solver("two-rank", prob, device=dev, noise=noise, **dict(CFG, detach_forward=detach), **extra)
     model.train()
     assert model.plan_name == "native"
     res = dict(loss=model.loss_log, params=torch.cat([p.detach().reshape(-1).cpu() for p in model.z_n.parameters()]),
@@ -42,12 +42,12 @@ def _train(noise, out=None, rank=0, detach=True):
     return res
 
 
-def _worker(rank, world, port, noise, out, detach=True):
+def _worker(rank, world, port, noise, out, detach=True, extra=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = _train(noise, out, rank, detach)
+    res = _train(noise, out, rank, detach, **(extra or {}))
     assert res["K_local"] == CFG["K"] // world and res["k_offset"] == rank * res["K_local"]
     dist.barrier()
     dist.destroy_process_group()
@@ -77,6 +77,21 @@ def test_two_ranks_match_one_rank_attached(tmp_path):
     assert err <= 2e-6, err
 
 
+@pytest.mark.parametrize("mode,detach", [("two_gradient", True), ("recompute", True), ("recompute", False)])
+def test_two_ranks_with_k_chunking_match_one_rank_without(tmp_path, mode, detach):
+    """Sharding AND K-chunking together: every rank processes its 256 trajectories in two chunks (global k_offset per chunk);
+    the result equals the single-process, resident-store run."""
+    out = os.path.join(str(tmp_path), "two_chunk.pt")
+    extra = dict(path_chunks=2, chunk_mode=mode)
+    mp.spawn(_worker, args=(2, _free_port(), "philox", out, detach, extra), nprocs=2, join=True)
+    two = torch.load(out)
+    one = _train("philox", detach=detach)
+    for a, b in zip(two["loss"], one["loss"]):
+        assert abs(a - b) <= 1e-6 * abs(b), (two["loss"], one["loss"])
+    err = float((two["params"] - one["params"]).abs().max())
+    assert err <= 5e-6, err
+
+
 # ---- the other native plans: DenseNet controls (time_approx='outer') and GeneralSolver on a bounded domain -----------------
 def _train_other(kind, noise, out=None, rank=0):
     sys.path.insert(0, ROOT)
@@ -92,6 +107,18 @@ def _train_other(kind, noise, out=None, rank=0):
         assert model.plan_name == "native"
         plan = model._native_plan
         params = torch.cat([p.detach().reshape(-1).cpu() for net in model.z_n for p in net.parameters()])
+    elif kind == "value":
+        prob = psp.DoubleWell_multidim(d=10, d_1=5, d_2=5, T=0.2, eta=0.5, kappa=2.0, device=dev)
+        model = psp.Solver("two-rank-value", prob, device=dev, noise=noise, lr=2e-3, L=3, K=256, delta_t=0.01,
+                           approx_method="value_function", loss_method="log-variance", time_approx="inner",
+                           adaptive_forward_process=True, detach_forward=True, u_l2_error_flag=False, verbose=False, seed=42,
+                           backend="native")
+        model.train()
+        assert model.plan_name == "native"
+        plan = model._native_plan
+        # without the output bias b3: V's additive constant cancels in D = Y_N - g and in every V(X_n) - Y_n, so its gradient is
+        # rounding noise and Adam moves it by +-lr per step whatever the noise's sign (in the reference as well)
+        params = torch.cat([p.detach().reshape(-1).cpu() for p in model.y_n[0].parameters()])[:-1]
     else:
         prob = psp.ExponentialOnSphereNonlinearParabolic(d=6, T=0.5, alpha=0.3, device=dev)
         model = psp.GeneralSolver(prob, "two-rank-sphere", seed=42, delta_t=0.01, N=20, lr=1e-3, L=3, K=256, K_boundary=16,
@@ -119,7 +146,8 @@ def _worker_other(rank, world, port, kind, noise, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,noise", [("outer", "philox"), ("outer", "reference"), ("sphere", "reference"), ("sphere", "philox")])
+@pytest.mark.parametrize("kind,noise", [("outer", "philox"), ("outer", "reference"), ("sphere", "reference"), ("sphere", "philox"),
+                                        ("value", "philox"), ("value", "reference")])
 def test_two_ranks_match_one_rank_other_plans(tmp_path, kind, noise):
     """Sharded DenseNet-control and bounded-domain GeneralSolver runs reproduce the single-process run (global noise
     indexing, global loss sums, summed gradients, and -- for the sphere with reference noise -- the globally agreed
