@@ -1,0 +1,61 @@
+"""bench.py's flop / MFMA accounting against the counters measured on the MI355X (profiles/traffic.json, written by
+tools/pmc_traffic.sh + tools/make_traffic_json.py from rocprofv3 --pmc SQ_INSTS_MFMA passes): the `frac_issued` figure of the
+roofline object rests on `issued_mfma_per_tile_step`, which must reproduce the measured instruction counts exactly."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _traffic():
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+        return json.load(fh)
+
+
+# workload -> (padded d, H, dense, kernel family, forward kernel name, backward kernel name)
+CASES = {
+    "hjb_llgc_d100_K65536_N100_h64": (100, 64, True, 1, "hjb_fwd_kernel", "hjb_bwd2_kernel"),
+    "hjb_llgc_d100_K1024_N50_h64": (100, 64, True, 1, "hjbs_fwd_kernel", "hjb_bwd2_kernel"),
+    "hjb_llgc_d200_K32768_N100_h64": (200, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd_kernel"),
+    "hjb_llgc_d500_K16384_N200_h64": (500, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd_kernel"),
+}
+
+
+@pytest.mark.parametrize("workload", sorted(CASES))
+def test_issued_mfma_formula_matches_the_pmc_counts(workload):
+    d, H, dense, family, fwd_name, bwd_name = CASES[workload]
+    meas = _traffic()[workload]
+    w = bench.WORKLOADS[workload]
+    N = int(round(w["T"] / w["dt"]))
+    tiles_steps = (w["K"] // 16) * N
+    fwd, _, bwd = bench.issued_mfma_per_tile_step(d, H, dense, family)
+    assert fwd * tiles_steps == pytest.approx(meas[fwd_name]["mfma_instructions"], rel=2e-3), (fwd, meas[fwd_name])
+    assert bwd * tiles_steps == pytest.approx(meas[bwd_name]["mfma_instructions"], rel=2e-3), (bwd, meas[bwd_name])
+
+
+def test_minimal_flops_are_below_issued_flops_and_survey_m3_above_minimal():
+    for d in (100, 200, 500):
+        fl2 = bench.alg_flops_per_traj_step(d, 64, True, m=2)
+        fl3 = bench.alg_flops_per_traj_step(d, 64, True, m=3)
+        fwd, _, bwd = bench.issued_mfma_per_tile_step(d, 64, True, 2 if d > 112 else 1)
+        assert fl3["fwd_kernel"] - fl2["fwd_kernel"] == 2 * d * d          # one dense d x d product
+        assert fl2["fwd_kernel"] <= fwd * bench.MFMA_F32_16x16x4_FLOP / 16.0 + 12 * d   # issued >= minimal (padding to 16-blocks)
+        assert fl2["bwd_kernel"] <= bwd * bench.MFMA_F32_16x16x4_FLOP / 16.0
+
+
+def test_path_store_traffic_equals_the_algorithmic_store():
+    """WRITE_SIZE of the forward kernels is the path store to within 0.5 % (nothing else is written), and the calibrated read
+    traffic of the backward kernels lies between one and two passes over it."""
+    t = _traffic()
+    store = 1408 * 65536 * 100                                              # d=100, H=64: X_n, xi, h1, h2 images
+    f = t["hjb_llgc_d100_K65536_N100_h64"]["hjb_fwd_kernel"]
+    assert f["write_bytes"] == pytest.approx(store, rel=5e-3)
+    b = t["hjb_llgc_d100_K65536_N100_h64"]["hjb_bwd2_kernel"]
+    assert store <= 2 * b["fetch_raw_bytes"] <= 2 * store
+    bf = t["diffusion_dw_d100_K65536_N100_h64_bf16"]["gen_fwd_kernel"]
+    assert bf["write_bytes"] == pytest.approx(960 * 65536 * 101 + 4 * 65536 * 101, rel=2e-2)   # bf16-pair images + ahat
