@@ -379,6 +379,11 @@ class Solver:
             raise NotImplementedError("approx_method='value_function' needs time_approx='inner' (as in the reference)")
         if self.compute_gradient_variance > 0:
             raise NotImplementedError('per-sample gradient-variance diagnostics are not implemented')
+        if self.loss_method == 'log-variance-repa':
+            # the reference alternates per iteration between a FROZEN copy of the control in Z (even l) and a detached drift (odd
+            # l), solver.py:444-447, 468-469; only the sign flip of its loss (:169-170) is restated here, so refuse rather than
+            # train something else under that name
+            raise NotImplementedError("loss_method='log-variance-repa' (alternating frozen control / detached drift) is not built")
         dev, dt, sq = self.device, self.delta_t, self.sq_delta_t
         repa = self.loss_method == 'reparametrization'
         rel_ent = 'relative_entropy' in self.loss_method
