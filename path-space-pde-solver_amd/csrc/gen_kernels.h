@@ -136,6 +136,10 @@ __device__ __forceinline__ float bf_hi(float packed) { return __uint_as_float(__
 template <bool P16>
 __device__ __forceinline__ f32x4 image_get_T(const float* base, int o32, int o16, int m) {
     f32x4 v;
+#if defined(PSP_GEN_ABLATE) && (PSP_GEN_ABLATE & 2)
+    v[0] = v[1] = v[2] = v[3] = 1.f;                        // diagnostic build: producers skip their path-store loads
+    return v;
+#endif
     if constexpr (P16) {
         const float u0 = base[o16 + (2 * m) * 64], u1 = base[o16 + (2 * m + 1) * 64];
         v[0] = bf_lo(u0); v[2] = bf_hi(u0); v[1] = bf_lo(u1); v[3] = bf_hi(u1);
@@ -833,6 +837,9 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
 }
 
 
+#ifndef PSP_GEN_BF16_RING
+#define PSP_GEN_BF16_RING 4       // depth of the bf16 consumers' row-operand ring (A/B: -DPSP_GEN_BF16_RING=3 is round 1's)
+#endif
 // =======================================================================================
 // Backward kernel, role-specialised variant (same scheme as hjb_bwd2_kernel).
 // One 8-wave workgroup per CU, rounds of 4 sample blocks, one barrier per round, double-buffered LDS exchange.
@@ -914,9 +921,18 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     const float* xt = a.path + (size_t)(xb0 < nblk ? xb0 : nblk - 1) * (size_t)PBx;
                     constexpr int NA = BF16 ? G::qD2 : G::pD2;   // X, U, d1 images are contiguous: [0, pD2)
                     constexpr int oZ1 = BF16 ? G::qZ1 : G::pZ1, nZ1 = (BF16 ? 2 : 4) * HB * 64;
+                    // measured in round 2 (A/B builds): the touch is worth 8 % to the bf16 kernel, whose consumers wait for loads
+                    // (3.38 against 3.67 ms), and COSTS the fp32 kernel 4.5 % (6.31 against 6.02 ms: MFMA-bound, its consumers'
+                    // 3-deep ring already covers an L2 hit; the touches only add requests) -- so only the bf16 kernel touches
+                    if constexpr (BF16) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { const int o = lane * 32 + i * 2048; touch[i] = xt[o < NA ? o : 0]; }
-                    touch[4] = xt[oZ1 + ((lane * 32 < nZ1) ? lane * 32 : 0)];
+                        for (int i = 0; i < 4; ++i) { const int o = lane * 32 + i * 2048; touch[i] = xt[o < NA ? o : 0]; }
+                        touch[4] = xt[oZ1 + ((lane * 32 < nZ1) ? lane * 32 : 0)];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) touch[i] = 0.f;
+                        (void)xt; (void)NA; (void)oZ1; (void)nZ1;
+                    }
                 }
                         // ---------------------------------------------------------- adjoints of the own block
                 {
@@ -1041,7 +1057,12 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     auto get_F = [&](int blk, int ofs) __attribute__((always_inline)) {
         unsigned long long addr = (unsigned long long)a.path + 4ull * ((unsigned long long)blk * PBx + (unsigned)ofs);
         asm volatile("" : "+s"(addr));
+#if defined(PSP_GEN_ABLATE) && (PSP_GEN_ABLATE & 1)
+        f32x4 v = {1.f, 1.f, 1.f, 1.f};                     // diagnostic build: consumers skip their path-store loads
+        (void)addr;
+#else
         f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((gptr_t)addr + lofsU);
+#endif
         if constexpr (BF16) {                              // four samples of this lane's feature: its half of each dword -> fp32
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1088,24 +1109,45 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
             w4 = (sval && !fin) ? wy4 : zero4;
             a4 = sval ? (a.per_sample ? ah4 : (fin ? wv4 : wy4 * ah4)) : zero4;
         };
+        // Row-operand ring that runs THROUGH pair and round boundaries (round 2).  The path store is an input: the blocks a
+        // workgroup will visit are known in advance, so the loads of the next pair's first items are requested while the last
+        // items of the current pair are still being multiplied, and the per-sample weights of a pair a whole pair ahead.
+        // Measured before: the ring was refilled from empty at every pair and the weight loads were issued BEHIND the refill
+        // (vmcnt retires in order), so the first item of every pair waited a full memory latency -- without the consumers'
+        // loads the kernel ran 1.89 instead of 3.56 ms.  Slots stay compile-time: items are counted modulo NROWP, the item
+        // count padded to a multiple of the ring depth (the padding item loads and multiplies nothing).
+        constexpr int RB = PSP_GEN_BF16_RING;
+        constexpr int NROWP = cdiv(NROW, RB) * RB;
+        f32x4 ra0[RB], rb0[RB], ra1[RB], rb1[RB];
+        // block ids of pair unit u (two per round): round blockIdx.x + (u / 2) gridDim.x, blocks 2 (u % 2), 2 (u % 2) + 1
+        auto unit_blk = [&](int u, int which) __attribute__((always_inline)) {
+            const long long rbu = ((long long)blockIdx.x + (long long)(u >> 1) * gridDim.x) * 4 + 2 * (u & 1) + which;
+            return rbu;
+        };
+        f32x4 w40n, a40n, w41n, a41n;
+        {
+            const int c0 = blk_at(unit_blk(0, 0)), c1 = blk_at(unit_blk(0, 1));
+            weights_of(unit_blk(0, 0), w40n, a40n);
+            weights_of(unit_blk(0, 1), w41n, a41n);
+#pragma unroll
+            for (int i = 0; i < RB - 1 && i < NROW; ++i) {
+                ra0[i] = get_F(c0, row_ofs0(i)); rb0[i] = get_F(c0, row_ofs1(i));
+                ra1[i] = get_F(c1, row_ofs0(i)); rb1[i] = get_F(c1, row_ofs1(i));
+            }
+        }
         __syncthreads();                                      // pairs with producer iteration 0
         for (int it = 1; it <= R; ++it) {
-            const long long rb = ((long long)blockIdx.x + (long long)(it - 1) * gridDim.x) * 4;
             const float* exch = bufs + ((it - 1) & 1) * 4 * (EXT * 256);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
+                const int u = 2 * (it - 1) + p;
                 const float* ex0 = exch + (2 * p) * (EXT * 256);
                 const float* ex1 = ex0 + EXT * 256;
-                const int cb0 = blk_at(rb + 2 * p), cb1 = blk_at(rb + 2 * p + 1);
-                f32x4 ra0[3], rb0[3], ra1[3], rb1[3];          // 3-deep ring over the row items of the pair
-#pragma unroll
-                for (int i = 0; i < 2 && i < NROW; ++i) {
-                    ra0[i] = get_F(cb0, row_ofs0(i)); rb0[i] = get_F(cb0, row_ofs1(i));
-                    ra1[i] = get_F(cb1, row_ofs0(i)); rb1[i] = get_F(cb1, row_ofs1(i));
-                }
-                f32x4 w40, a40, w41, a41;
-                weights_of(rb + 2 * p, w40, a40);
-                weights_of(rb + 2 * p + 1, w41, a41);
+                const int cb0 = blk_at(unit_blk(u, 0)), cb1 = blk_at(unit_blk(u, 1));
+                const int nb0 = blk_at(unit_blk(u + 1, 0)), nb1 = blk_at(unit_blk(u + 1, 1));   // next unit (clamped past the end)
+                const f32x4 w40 = w40n, a40 = a40n, w41 = w41n, a41 = a41n;
+                weights_of(unit_blk(u + 1, 0), w40n, a40n);   // consumed a whole pair later
+                weights_of(unit_blk(u + 1, 1), w41n, a41n);
                 bf16x8 pz2[NIB], pz2t[NIB], pz1[NIB], pz1t[NIB];
 #pragma unroll
                 for (int t = 0; t < NIB; ++t) {
@@ -1119,34 +1161,44 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     pz1t[t] = pack2(tile_get(ex0 + 3 * HB * 256 + cbc[t], lane), tile_get(ex1 + 3 * HB * 256 + cbc[t], lane));
                 }
 #pragma unroll
-                for (int i = 0; i < NROW; ++i) {
-                    const int slot = i % 3;
-                    if (i + 2 < NROW) {
-                        const int ns = (i + 2) % 3;
-                        ra0[ns] = get_F(cb0, row_ofs0(i + 2)); rb0[ns] = get_F(cb0, row_ofs1(i + 2));
-                        ra1[ns] = get_F(cb1, row_ofs0(i + 2)); rb1[ns] = get_F(cb1, row_ofs1(i + 2));
+                for (int i = 0; i < NROWP; ++i) {
+                    const int slot = i % RB;
+                    {   // request the item RB - 1 ahead: same pair, or the first items of the next one
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int jn = i + RB - 1;
+                        const int ns = jn % RB;
+                        if (jn < NROW) {
+                            ra0[ns] = get_F(cb0, row_ofs0(jn)); rb0[ns] = get_F(cb0, row_ofs1(jn));
+                            ra1[ns] = get_F(cb1, row_ofs0(jn)); rb1[ns] = get_F(cb1, row_ofs1(jn));
+                        } else if (jn >= NROWP && jn - NROWP < NROW) {
+                            ra0[ns] = get_F(nb0, row_ofs0(jn - NROWP)); rb0[ns] = get_F(nb0, row_ofs1(jn - NROWP));
+                            ra1[ns] = get_F(nb1, row_ofs0(jn - NROWP)); rb1[ns] = get_F(nb1, row_ofs1(jn - NROWP));
+                        }
                     }
-                    f32x4 A00, A10, A01, A11;
-                    if (i < NRX) {
-                        A00 = ra0[slot]; A10 = w40 * rb0[slot];
-                        A01 = ra1[slot]; A11 = w41 * rb1[slot];
-                    } else {
-                        const f32x4 d10 = ra0[slot], d11 = ra1[slot];
-                        A00 = 0.25f * d10 * d10; A10 = d10 * (w40 * rb0[slot]);
-                        A01 = 0.25f * d11 * d11; A11 = d11 * (w41 * rb1[slot]);
-                    }
-                    if (i % WHc == wh) g3r[i] += hsum4(a40 * A00 + A10) + hsum4(a41 * A01 + A11);
-                    const bf16x8 PA0 = pack2(A00, A01), PA1 = pack2(A10, A11);
-#pragma unroll
-                    for (int t = 0; t < NIB; ++t) {
+                    if (i < NROW) {
+                        f32x4 A00, A10, A01, A11;
                         if (i < NRX) {
-                            acc2x[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA0, pz2[t], acc2x[i][t], 0, 0, 0);
-                            acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA0, pz1[t], acc1[i][t], 0, 0, 0);
-                            acc2x[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA1, pz2t[t], acc2x[i][t], 0, 0, 0);
-                            acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA1, pz1t[t], acc1[i][t], 0, 0, 0);
+                            A00 = ra0[slot]; A10 = w40 * rb0[slot];
+                            A01 = ra1[slot]; A11 = w41 * rb1[slot];
                         } else {
-                            acc2h[i - NRX][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA0, pz2[t], acc2h[i - NRX][t], 0, 0, 0);
-                            acc2h[i - NRX][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA1, pz2t[t], acc2h[i - NRX][t], 0, 0, 0);
+                            const f32x4 d10 = ra0[slot], d11 = ra1[slot];
+                            A00 = 0.25f * d10 * d10; A10 = d10 * (w40 * rb0[slot]);
+                            A01 = 0.25f * d11 * d11; A11 = d11 * (w41 * rb1[slot]);
+                        }
+                        if (i % WHc == wh) g3r[i] += hsum4(a40 * A00 + A10) + hsum4(a41 * A01 + A11);
+                        const bf16x8 PA0 = pack2(A00, A01), PA1 = pack2(A10, A11);
+#pragma unroll
+                        for (int t = 0; t < NIB; ++t) {
+                            if (i < NRX) {
+                                acc2x[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA0, pz2[t], acc2x[i][t], 0, 0, 0);
+                                acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA0, pz1[t], acc1[i][t], 0, 0, 0);
+                                acc2x[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA1, pz2t[t], acc2x[i][t], 0, 0, 0);
+                                acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA1, pz1t[t], acc1[i][t], 0, 0, 0);
+                            } else {
+                                acc2h[i - NRX][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA0, pz2[t], acc2h[i - NRX][t], 0, 0, 0);
+                                acc2h[i - NRX][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(PA1, pz2t[t], acc2h[i - NRX][t], 0, 0, 0);
+                            }
                         }
                     }
                 }
