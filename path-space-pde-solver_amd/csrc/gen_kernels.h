@@ -252,16 +252,10 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             // waits with vmcnt(0) behind the store in front of it)
             typedef __attribute__((address_space(1))) float* gwptr_t;
             auto pbase = [&](int slot, int ofs) __attribute__((always_inline)) {
-                unsigned long long addr = (unsigned long long)a.path +
-                    4ull * (((unsigned long long)slot * a.ntile16 + t16) * (unsigned)G::PB + (unsigned)ofs);
-                asm volatile("" : "+s"(addr));
-                return (gwptr_t)addr;
+                return (gwptr_t)sgpr_block_addr(a.path, (unsigned long long)slot * a.ntile16 + t16, (unsigned)G::PB, (unsigned)ofs);
             };
             auto pbase16 = [&](int slot, int ofs) __attribute__((always_inline)) {      // bf16-pair path block (GGeo::q*)
-                unsigned long long addr = (unsigned long long)a.path +
-                    4ull * (((unsigned long long)slot * a.ntile16 + t16) * (unsigned)G::PB16 + (unsigned)ofs);
-                asm volatile("" : "+s"(addr));
-                return (gwptr_t)addr;
+                return (gwptr_t)sgpr_block_addr(a.path, (unsigned long long)slot * a.ntile16 + t16, (unsigned)G::PB16, (unsigned)ofs);
             };
             const bool p16 = BF16 && a.path16;                    // wave-uniform
             const unsigned ul = (unsigned)lane;
@@ -1055,8 +1049,16 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     };
     typedef const __attribute__((address_space(1))) float* gptr_t;
     auto get_F = [&](int blk, int ofs) __attribute__((always_inline)) {
-        unsigned long long addr = (unsigned long long)a.path + 4ull * ((unsigned long long)blk * PBx + (unsigned)ofs);
-        asm volatile("" : "+s"(addr));
+        // fp32: block address opaque before the offset is added (sgpr_block_addr: no hoisted per-offset bases, 17 -> 0 spilled
+        // SGPRs); the bf16 kernel sits on its 256-register cap and the same form costs it 10-14 spilled VGPRs, so it keeps
+        // the single sum
+        unsigned long long addr;
+        if constexpr (BF16) {
+            addr = (unsigned long long)a.path + 4ull * ((unsigned long long)blk * PBx + (unsigned)ofs);
+            asm volatile("" : "+s"(addr));
+        } else {
+            addr = sgpr_block_addr(a.path, (unsigned long long)blk, (unsigned)PBx, (unsigned)ofs);
+        }
 #if defined(PSP_GEN_ABLATE) && (PSP_GEN_ABLATE & 1)
         f32x4 v = {1.f, 1.f, 1.f, 1.f};                     // diagnostic build: consumers skip their path-store loads
         (void)addr;

@@ -98,6 +98,18 @@ __device__ __forceinline__ int opaque_i(int x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// Byte address base + 4 (blk * stride + ofs) of a path-store block as an SGPR pair (loads / stores through it are "SGPR base +
+// lane offset + immediate").  The block part is made opaque BEFORE the constant offset is added: `base + 4 ofs` alone is
+// invariant over the time / round loops, and the compiler used to hoist one such 64-bit sum per distinct offset out of them
+// and spill it to VGPR lanes (189 pairs in the d = 500 forward, two v_readlane per load group to get them back).
+__device__ __forceinline__ unsigned long long sgpr_block_addr(const void* base, unsigned long long blk, unsigned stride,
+                                                              unsigned ofs) {
+    unsigned long long addr = (unsigned long long)base + 4ull * (blk * stride);
+    asm volatile("" : "+s"(addr));
+    addr += 4ull * ofs;
+    asm volatile("" : "+s"(addr));
+    return addr;
+}
 template <class T>
 __device__ __forceinline__ const T* opaque(const T* p) {   // same pointer + opaque zero offset
     return p + opaque_i(0);
@@ -1227,9 +1239,7 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     // wave-uniform tile base pointers are forced into SGPRs so every load is "SGPR base + lane offset"
     typedef const __attribute__((address_space(1))) float* gptr_t;
     auto sbase = [&](int blk, int ofs) __attribute__((always_inline)) {
-        unsigned long long addr = (unsigned long long)a.path + 4ull * ((unsigned long long)blk * (unsigned)G::PB + (unsigned)ofs);
-        asm volatile("" : "+s"(addr));                               // byte address of the tile, SGPR pair
-        return (gptr_t)addr;
+        return (gptr_t)sgpr_block_addr(a.path, (unsigned long long)blk, (unsigned)G::PB, (unsigned)ofs);
     };
     const unsigned lofsU = (unsigned)lofsF;
     auto get_F = [&](gptr_t base) __attribute__((always_inline)) {

@@ -480,8 +480,7 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
         __syncthreads();
         const float* img_n = da.pimg + (size_t)n * a.ntile16 * (size_t)W::PBI;
         auto get_F = [&](int t16, int ofs) __attribute__((always_inline)) {
-            unsigned long long addr = (unsigned long long)img_n + 4ull * ((unsigned long long)t16 * (unsigned)W::PBI + (unsigned)ofs);
-            asm volatile("" : "+s"(addr));
+            const unsigned long long addr = sgpr_block_addr(img_n, (unsigned long long)t16, (unsigned)W::PBI, (unsigned)ofs);
             return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((gptr_t)addr + lofsU);
         };
         f32x4 acc[NR][NC];

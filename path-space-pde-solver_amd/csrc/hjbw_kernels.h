@@ -120,6 +120,15 @@ __device__ __forceinline__ gptr_t sgpr_ptr(const float* p) {
     return (gptr_t)addr;
 }
 
+// The INPUT of sgpr_ptr is still ordinary arithmetic: `table + constant` is invariant over the time loop, so every distinct
+// constant became a hoisted 64-bit SGPR pair -- 189 of them at d = 500, all spilled to VGPR lanes and read back with two
+// v_readlane per load group.  Laundering the table pointer where the product starts makes those sums two SALU adds at the use.
+__device__ __forceinline__ const float* opaque_base(const float* p) {
+    unsigned long long addr = (unsigned long long)p;
+    asm volatile("" : "+s"(addr));
+    return (const float*)addr;
+}
+
 // acc[MB] += T . in,  T: k-step-major global table with KS k-steps, in: register panel (static indices, unrolled)
 // LD = number of output blocks per k-step in the table (MB of them, starting at tbl, are used)
 template <int MB, int KS, int INB, int LD = MB>
@@ -128,6 +137,7 @@ __device__ __forceinline__ void gemm_regs(f32x4 (&acc)[MB], const float* __restr
     constexpr int CH = (MB >= 16) ? 1 : (MB >= 8 ? 2 : 4);
     constexpr int NCH = cdiv(KS, CH);
     const unsigned ul = (unsigned)lane;
+    tbl = opaque_base(tbl);
     float buf[2][CH * MB];
     // one SGPR base per (k-step, 16 output blocks): every load is base + lane * 4 + immediate < 4096
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
@@ -172,6 +182,7 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
     static_assert(KP % (NST * U) == 0, "k padding");
     float ab[NST][U * MB], bb[NST][U];
     const unsigned ul = (unsigned)lane;
+    tbl = opaque_base(tbl);
     auto load = [&](int st, int ks0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -305,10 +316,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
             // path block of (n, tile): wave-uniform base in SGPRs, stores are "base + lane + immediate"
             typedef __attribute__((address_space(1))) float* gwptr_t;
             auto pbase = [&](int ofs) __attribute__((always_inline)) {
-                unsigned long long addr = (unsigned long long)a.path +
-                    4ull * (((unsigned long long)n * a.ntile16 + t16) * (unsigned)G::PB + (unsigned)ofs);
-                asm volatile("" : "+s"(addr));
-                return (gwptr_t)addr;
+                return (gwptr_t)sgpr_block_addr(a.path, (unsigned long long)n * a.ntile16 + t16, (unsigned)G::PB, (unsigned)ofs);
             };
             const unsigned ul = (unsigned)lane;
             // X_n: LDS image (B operand of the W1 and drift products) and path store
@@ -821,10 +829,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const
         // path blocks through wave-uniform SGPR bases (loads / stores are "base + lane * 4 + immediate < 4 KiB")
         typedef __attribute__((address_space(1))) float* gwptr_t;
         auto pbase = [&](int nn, int ofs) __attribute__((always_inline)) {
-            unsigned long long addr = (unsigned long long)a.path +
-                4ull * (((unsigned long long)nn * a.ntile16 + t16) * (unsigned)G::PB + (unsigned)ofs);
-            asm volatile("" : "+s"(addr));
-            return (gwptr_t)addr;
+            return (gwptr_t)sgpr_block_addr(a.path, (unsigned long long)nn * a.ntile16 + t16, (unsigned)G::PB, (unsigned)ofs);
         };
         const unsigned ul = (unsigned)lane;
         // lambda' = lambda_{n+1} + (mu + nu) dt grad f(X_{n+1});  X_{n+1} from the next path block (or X_N)
