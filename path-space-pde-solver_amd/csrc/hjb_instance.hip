@@ -2,6 +2,7 @@
 #include "hjb_kernels.h"
 #include "hjbs_kernels.h"
 #include "hjba_kernels.h"
+#include "hjbq_kernels.h"
 #ifndef PSP_D
 #error "compile with -DPSP_D=<d> -DPSP_H=<H>"
 #endif
@@ -15,6 +16,8 @@
         r.launch_fwd_split = &psp::HjbsLaunch<D_, H_>::fwd;                                \
         r.launch_adj = &psp::HjbaLaunch<D_, H_>::adj;                                      \
         r.launch_fwd_bf16 = &psp::HjbLaunch<D_, H_>::fwd_bf16;                             \
+        r.quad_lds_bytes = &psp::HjbqLaunch<D_, H_>::lds_bytes;                            \
+        r.launch_fwd_quad = &psp::HjbqLaunch<D_, H_>::fwd;                                 \
         return r;                                                                           \
     }
 PSP_DEFINE_(PSP_D, PSP_H)

@@ -1431,6 +1431,8 @@ struct HjbInstance {
     hipError_t (*launch_fwd_split)(const HjbArgs&, int grid, hipStream_t);
     hipError_t (*launch_adj)(const HjbArgs&, int grid, int block, hipStream_t);   // hjba_kernels.h adjoint sweep (null: not built)
     hipError_t (*launch_fwd_bf16)(const HjbArgs&, int grid, int block, hipStream_t);   // control net on bf16 MFMA (null: not built)
+    int (*quad_lds_bytes)();         // hjbq_kernels.h: four trajectories per workgroup for the smallest K (null: not built)
+    hipError_t (*launch_fwd_quad)(const HjbArgs&, int grid, hipStream_t);
 };
 
 template <int D, int H>

@@ -105,6 +105,7 @@ struct Plan {
     int ntile16, fwd_waves, fwd_grid, bwd_waves, bwd_grid;
     bool bwd_specialised;       // hjb_bwd2_kernel (producer / consumer waves) instead of hjb_bwd_kernel
     bool fwd_split;             // hjbs_fwd_kernel (four waves per tile) instead of hjb_fwd_kernel
+    bool fwd_quad;              // hjbq_fwd_kernel (four trajectories per workgroup) for the smallest K
 };
 
 int n_cus() {
@@ -145,12 +146,19 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     p->fwd_waves = fw;
     p->fwd_grid = (p->ntile16 + fw - 1) / fw;
     // few tiles: the feature-split forward (four waves per tile, weights in registers) cuts the per-step latency ~3x.
-    // It wins while one-wave-per-tile would leave SIMDs idle: up to 2 tiles per CU (PSP_FWD_VARIANT=1 / 2 force either)
-    static const char* fv = getenv("PSP_FWD_VARIANT");
+    // It wins while one-wave-per-tile would leave SIMDs idle: up to 2 tiles per CU (PSP_FWD_VARIANT=1 / 2 / 3 force the
+    // tile-per-wave, the feature-split or the quad kernel)
+    const char* fv = getenv("PSP_FWD_VARIANT");       // (read per call: tests switch variants inside one process)
     p->fwd_split = !p->inst.wide && p->inst.launch_fwd_split && p->inst.split_lds_bytes() <= kMaxLds &&
                    c->mlp_dtype != PSP_MLP_BF16_FWD &&           // (the bf16 control-net mode exists in hjb_fwd_kernel only)
                    ((fv && fv[0] == '2') || (!(fv && fv[0] == '1') && p->ntile16 <= 2 * cus));
     if (p->fwd_split) { p->fwd_waves = 8; p->fwd_grid = p->ntile16; }   // (the kernel itself fixes 4 or 8 waves per tile)
+    // fewer tiles than a quarter of the CUs: four trajectories per workgroup (hjbq_kernels.h), so that K = 1024 still covers the
+    // chip (PSP_FWD_VARIANT=3 forces it, 1 / 2 exclude it)
+    p->fwd_quad = !p->inst.wide && p->inst.launch_fwd_quad && p->inst.quad_lds_bytes() <= kMaxLds &&
+                  c->mlp_dtype != PSP_MLP_BF16_FWD &&
+                  ((fv && fv[0] == '3') || (!fv && 4 * p->ntile16 <= cus));
+    if (p->fwd_quad) { p->fwd_split = false; p->fwd_waves = 8; p->fwd_grid = 4 * p->ntile16; }
     // backward: persistent over rounds of 4 sample blocks; 4-wave workgroups, two per CU
     // (<= 256 VGPRs and <= 80 KiB LDS each), fewer when there is little work
     const long long nblk = (long long)c->N * p->ntile16;
@@ -653,8 +661,9 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
     } else if (cfg->mlp_dtype != PSP_MLP_FP32) {
         return fail(-1, "mlp_dtype out of range for the HJB rollout (fp32 or bf16_fwd)");
     } else {
-        e = p.fwd_split ? p.inst.launch_fwd_split(a, p.fwd_grid, (hipStream_t)stream)
-                        : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+        e = p.fwd_quad ? p.inst.launch_fwd_quad(a, p.fwd_grid, (hipStream_t)stream)
+            : p.fwd_split ? p.inst.launch_fwd_split(a, p.fwd_grid, (hipStream_t)stream)
+                          : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     }
     if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel launch");
     return 0;
@@ -678,8 +687,9 @@ int psp_hjb_rollout_eval(const psp_hjb_config* cfg, const float* params, const f
     a.D = D_out; a.Fint = Fint_out; a.XN = XN_out; a.fwd_partial = fwd_partial;
     a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    hipError_t e = p.fwd_split ? p.inst.launch_fwd_split(a, p.fwd_grid, (hipStream_t)stream)
-                               : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    hipError_t e = p.fwd_quad ? p.inst.launch_fwd_quad(a, p.fwd_grid, (hipStream_t)stream)
+                   : p.fwd_split ? p.inst.launch_fwd_split(a, p.fwd_grid, (hipStream_t)stream)
+                                 : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_fwd_kernel (eval) launch");
     return 0;
 }
