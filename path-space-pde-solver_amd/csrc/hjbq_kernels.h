@@ -33,7 +33,7 @@ struct GeoQ {
     static constexpr int NS = cdiv(NG, W);               // group slots per wave
     static constexpr int KO = 4 * NS;                    // owned state features per wave: block kk = 4 s + r of the register
     static constexpr int KHo = 2 * HB;                   // owned hidden units per wave (16 HB / 8)
-    static constexpr int SD = cdiv(16 * DB, 64);         // 64-row slabs of a product with d output rows
+    static constexpr int SD = cdiv(W * KO, 64);          // 64-row slabs of a product with d output rows (rows in OWNER order)
     static constexpr int RD = 64 * SD, RH = 64;          // rows of the partial-product buffers
     static constexpr bool fits = KO <= 16 && HB <= 4;    // one A-operand register per vector
     static constexpr int NP = cdiv(NG, 16);              // noise-producer waves (64 Philox calls each: 16 groups x 4 trajectories)
@@ -111,6 +111,20 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
     //      (coalesced copy, odd row stride so that the column reads are free of bank conflicts), in the area the partial
     //      products use later.
     float w1q[KO], aq[SD][KO], bq[SD][KO], w2q[KHo], w3q[SD][KHo];
+    // Output rows of the d-row products (dt A x, W3 h2, B v) are numbered in OWNER order, rho = KO * owner wave + slot kk: the
+    // 16 owner lanes-blocks of a wave then read 64 consecutive words of each partial (row = feature made the four-feature stride
+    // of a group hit 8 of the 32 LDS banks: an 8-way conflict on every read of phases D and E)
+    auto row_feature = [&](int rho, bool& valid) __attribute__((always_inline)) {
+        const int w = rho / KO, kk = rho - w * KO;
+        const int g = w + W * (kk >> 2);
+        const int fr = 16 * (g >> 2) + 4 * (kk & 3) + (g & 3);
+        valid = w < W && g < NG && fr < D;
+        return valid ? fr : 0;
+    };
+    bool rowok[SD];
+    int rowf[SD];
+#pragma unroll
+    for (int sl = 0; sl < SD; ++sl) rowf[sl] = row_feature(64 * sl + wrow, rowok[sl]);
     constexpr int LSD = D | 1, LSH = H | 1;              // LDS row strides (floats)
     static_assert((D > H ? D : H) * LSD <= Q::fRed && (D > H ? D : H) * LSH <= Q::fRed, "staging area");
     auto stage = [&](const float* __restrict__ M, int R, int C, int gstride, int lstride) __attribute__((always_inline)) {
@@ -147,9 +161,8 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
         for (int sl = 0; sl < SD; ++sl)
 #pragma unroll
             for (int kk = 0; kk < KO; ++kk) {
-                const int row = 64 * sl + wrow;
-                const bool in = oko[kk] && row < D;
-                const float v = lds[(in ? row : 0) * LSD + fko[kk]];
+                const bool in = oko[kk] && rowok[sl];
+                const float v = lds[rowf[sl] * LSD + fko[kk]];
                 aq[sl][kk] = in ? dt * v : 0.f;
             }
     }
@@ -159,9 +172,8 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
         for (int sl = 0; sl < SD; ++sl)
 #pragma unroll
             for (int kk = 0; kk < KO; ++kk) {
-                const int row = 64 * sl + wrow;
-                const bool in = oko[kk] && row < D;
-                const float v = lds[(in ? row : 0) * LSD + fko[kk]];
+                const bool in = oko[kk] && rowok[sl];
+                const float v = lds[rowf[sl] * LSD + fko[kk]];
                 bq[sl][kk] = in ? v : 0.f;
             }
     }
@@ -179,9 +191,8 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
 #pragma unroll
         for (int kk = 0; kk < KHo; ++kk) {
             const int mk = KHo * wave + kk;
-            const int row = 64 * sl + wrow;
-            const bool in = mk < H && row < D;
-            const float v = lds[(in ? row : 0) * LSH + (mk < H ? mk : 0)];
+            const bool in = mk < H && rowok[sl];
+            const float v = lds[rowf[sl] * LSH + (mk < H ? mk : 0)];
             w3q[sl][kk] = in ? v : 0.f;
         }
     __syncthreads();                                     // the staging area becomes the partial-product buffers
@@ -219,7 +230,7 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
     f32x4* myZ = reinterpret_cast<f32x4*>(partZ) + wave * RD + wrow;
     f32x4* myBV = reinterpret_cast<f32x4*>(partBV) + wave * RD + wrow;
     // owner reads: element (row, tr) of each wave's partial
-    const int rdH = mc * 4 + tr, rdD = fc * 4 + tr;
+    const int rdH = mc * 4 + tr, rdD = (KO * wave + (blk < KO ? blk : 0)) * 4 + tr;
 
     // ---- Brownian increments.  Philox + Box-Muller are ~150 VALU instructions whichever lanes are active; done by every
     //      wave for its own features they cost 1.0 k of the 6.1 k cycles of a step (two waves per SIMD, nothing to hide them
@@ -264,34 +275,47 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
         float tn = (float)n * dt;
         if constexpr (!FAST) { if (a.tfeat) tn = a.tfeat[n]; }
         float* pblk = a.path + ((size_t)n * a.ntile16 + t16) * (size_t)G::PB;
-        // ---- A: partial products of W1 x (h1 pre-activation) and of dt A x over the own state features
+        // ---- A: partial products of W1 x (h1 pre-activation) over the own state features
         if (storing && gvalid) pblk[offX] = x;
         {
-            f32x4 h1p = zero4, dr[SD];
-#pragma unroll
-            for (int sl = 0; sl < SD; ++sl) dr[sl] = zero4;
-            if (denseA) {
-                static_for<0, KO>([&](auto kk) {
-                    h1p = mfma4<decltype(kk)::value>(x, w1q[decltype(kk)::value], h1p);
-#pragma unroll
-                    for (int sl = 0; sl < SD; ++sl) dr[sl] = mfma4<decltype(kk)::value>(x, aq[sl][decltype(kk)::value], dr[sl]);
-                });
-#pragma unroll
-                for (int sl = 0; sl < SD; ++sl) myDR[64 * sl] = dr[sl];
-            } else {
-                static_for<0, KO>([&](auto kk) { h1p = mfma4<decltype(kk)::value>(x, w1q[decltype(kk)::value], h1p); });
-            }
-            *myH1 = h1p;
+            f32x4 h1a = zero4, h1b = zero4;              // two accumulators: half the dependent-chain length
+            static_for<0, KO>([&](auto kk) {
+                if constexpr (decltype(kk)::value & 1) h1b = mfma4<decltype(kk)::value>(x, w1q[decltype(kk)::value], h1b);
+                else h1a = mfma4<decltype(kk)::value>(x, w1q[decltype(kk)::value], h1a);
+            });
+            *myH1 = h1a + h1b;
         }
         PSP_STAMP(qa1);
         __syncthreads();
         PSP_STAMP(qb0);
+        // The drift product dt A x needs X_n only and its result only at the end of the step: its MFMAs (2 SD per owned feature)
+        // go in FRONT of phases B and C, where the matrix pipe would otherwise idle while the partial sums come back from LDS
+        constexpr int SDB = (SD + 1) / 2;                // slabs of the drift product done in phase B, the rest in phase C
+        auto drift_slabs = [&](auto lo, auto hi) __attribute__((always_inline)) {
+            constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+            if constexpr (HI > LO) {
+                f32x4 dr[HI - LO][2];                    // two accumulators per slab (even / odd features)
+#pragma unroll
+                for (int sl = 0; sl < HI - LO; ++sl) { dr[sl][0] = zero4; dr[sl][1] = zero4; }
+                static_for<0, KO>([&](auto kk) {
+#pragma unroll
+                    for (int sl = 0; sl < HI - LO; ++sl)
+                        dr[sl][decltype(kk)::value & 1] =
+                            mfma4<decltype(kk)::value>(x, aq[LO + sl][decltype(kk)::value], dr[sl][decltype(kk)::value & 1]);
+                });
+#pragma unroll
+                for (int sl = 0; sl < HI - LO; ++sl) myDR[64 * (LO + sl)] = dr[sl][0] + dr[sl][1];
+            }
+        };
         // ---- B: h1 = tanh(W1 [t, x] + b1) for the own hidden units, partial products of W2 h1
-        float drs = 0.f;
         {
+            float hp[W];
+#pragma unroll
+            for (int p = 0; p < W; ++p) hp[p] = partH1[p * RH * 4 + rdH];
+            if (denseA) drift_slabs(std::integral_constant<int, 0>{}, std::integral_constant<int, SDB>{});
             float h1 = fmaf(tn, w1tm, b1m);
 #pragma unroll
-            for (int p = 0; p < W; ++p) h1 += partH1[p * RH * 4 + rdH];
+            for (int p = 0; p < W; ++p) h1 += hp[p];
             h1 = mvalid ? tanh_f32(h1) : 0.f;             // padded rows of the images hold zeros
             if (storing && hslot) pblk[G::pH1 + offH] = h1;
             f32x4 h2a = zero4, h2b = zero4;              // two accumulators: the chain is only KHo long
@@ -306,14 +330,14 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
         PSP_STAMP(qc0);
         // ---- C: h2 = tanh(W2 h1 + b2), partial products of W3 h2
         {
+            float hp[W];
+#pragma unroll
+            for (int p = 0; p < W; ++p) hp[p] = partH2[p * RH * 4 + rdH];
+            if (denseA) drift_slabs(std::integral_constant<int, SDB>{}, std::integral_constant<int, SD>{});
             float h2 = b2m;
 #pragma unroll
-            for (int p = 0; p < W; ++p) h2 += partH2[p * RH * 4 + rdH];
+            for (int p = 0; p < W; ++p) h2 += hp[p];
             h2 = mvalid ? tanh_f32(h2) : 0.f;
-            if (denseA) {                                // (the drift partials of phase A: read here, the shortest phase)
-#pragma unroll
-                for (int p = 0; p < W; ++p) drs += partDR[p * RD * 4 + rdD];
-            }
             if (storing && hslot) pblk[G::pH2 + offH] = h2;
             f32x4 zp[SD];
 #pragma unroll
@@ -333,9 +357,22 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
         __syncthreads();
         PSP_STAMP(qd0);
         // ---- D: Z = W3 h2 + b3 for the own feature, row-sum terms, increment v, partial products of B v
-        float Z = b3f;
+        float Z = b3f, drs = 0.f;
+        {
+            float zp[W], dp[W];
 #pragma unroll
-        for (int p = 0; p < W; ++p) Z += partZ[p * RD * 4 + rdD];
+            for (int p = 0; p < W; ++p) zp[p] = partZ[p * RD * 4 + rdD];
+            if (denseA) {
+#pragma unroll
+                for (int p = 0; p < W; ++p) dp[p] = partDR[p * RD * 4 + rdD];
+            }
+#pragma unroll
+            for (int p = 0; p < W; ++p) Z += zp[p];
+            if (denseA) {
+#pragma unroll
+                for (int p = 0; p < W; ++p) drs += dp[p];
+            }
+        }
         Z = fvalid ? Z : 0.f;
         if (storing && gvalid) pblk[offXi] = store_cxi * xi + store_cz * Z;     // 1: xi, 2: xi - sqrt(dt) Z, 3: Z (hjb_fwd_kernel)
         float UL = 0.f;
