@@ -86,13 +86,28 @@ def test_chunked_training_matches_reference_golden(name, modes):
 def test_budget_selects_the_chunk_count():
     """path_budget_bytes -> number of chunks: the store of one chunk stays under the budget, chunks are whole 16-tiles."""
     case = load_golden("llgc_d100_h64_logvar")["case"]
+    import os
+    old_variant = os.environ.get("PSP_FWD_VARIANT")
+    try:
+        # the library picks the forward kernel from the trajectory count of a LAUNCH (K <= 1024: four trajectories per
+        # workgroup, K <= 8192: feature split): D is bit-identical between chunked and resident runs of the SAME kernel,
+        # and equal to summation order (a few ulp) when the chunk size moves the launch to another one
+        os.environ["PSP_FWD_VARIANT"] = "2"
+        full, fplan = _run(case, 1, "philox", K=4096)
+        store = int(fplan.sizes.path_bytes)
+        m, plan = _run(case, 1, "philox", K=4096, path_budget_bytes=store // 5 + 1)
+        assert torch.equal(plan.D, fplan.D)
+    finally:
+        if old_variant is None:
+            os.environ.pop("PSP_FWD_VARIANT", None)
+        else:
+            os.environ["PSP_FWD_VARIANT"] = old_variant
     full, fplan = _run(case, 1, "philox", K=4096)
-    store = int(fplan.sizes.path_bytes)
     m, plan = _run(case, 1, "philox", K=4096, path_budget_bytes=store // 5 + 1)
     assert plan.n_chunks >= 5 and plan.chunk_K % 16 == 0
     assert int(plan.sizes.path_bytes) <= store // 5 + 1 + 16 * store // 4096
     assert plan.path.numel() * 4 == int(plan.sizes.path_bytes)
-    assert torch.equal(plan.D, fplan.D)
+    assert float((plan.D - fplan.D).abs().max()) <= 2e-6 * max(1.0, float(fplan.D.abs().max()))
     assert math.isclose(m.loss_log[0], full.loss_log[0], rel_tol=1e-6)
     err = float((plan.grad - fplan.grad).abs().max()) / float(fplan.grad.abs().max())
     assert err <= 5e-6, err
