@@ -134,6 +134,17 @@ def issued_mfma_per_tile_step(d_pad, H_pad, dense, family, bf16_mlp=False):
     return net + sde, 0, bwd
 
 
+def issued_mfma_quad_kernel(d_pad, H_pad, dense):
+    """hjbq_fwd_kernel (four trajectories per workgroup, K <= 4 x CUs): v_mfma_f32_4x4x1_16b_f32 (512 flop) per workgroup and
+    step, from GeoQ in csrc/hjbq_kernels.h, returned in 16x16x4 equivalents (2048 flop) per 16 trajectories so that it plugs
+    into the same roofline arithmetic: 4 quads x 8 waves x (KO (1 + 2 SD) + KHo (1 + SD)) / 4."""
+    DB, HB = _cdiv(d_pad, 16), _cdiv(H_pad, 16)
+    KO, KHo = 4 * _cdiv(4 * DB, 8), 2 * HB
+    SD = _cdiv(8 * KO, 64)
+    per_wave = KO * (1 + (2 * SD if dense else 0)) + KHo * (1 + SD)
+    return 8 * per_wave
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -479,7 +490,7 @@ def main():
     units_launch = K_launch * N_t                        # trajectory-timesteps per launch on one GPU
     tiles_steps = _cdiv(K_launch, 16) * N_t
     # kernel names as they appear in rocprof: family 1 = hjb_kernels.h (hjbs_kernels.h forward when there are at most two
-    # tiles per CU), family 2 = hjbw_kernels.h
+    # tiles per CU, hjbq_kernels.h when there are at most CUs / 4), family 2 = hjbw_kernels.h
     ntile = _cdiv(K_launch, 16)
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     bf16_mlp = w.get("mlp") == "bf16"
@@ -487,9 +498,13 @@ def main():
         fwd_name, bwd_name = "hjbd_fwd_kernel", ("hjbd_bwd_kernel" if plan.kernel_bwd else "library GEMMs")
         issued = None
     else:
-        fwd_name = "hjbw_fwd_kernel" if plan.family == 2 else ("hjbs_fwd_kernel" if ntile <= 2 * cus else "hjb_fwd_kernel")
+        quad = plan.family != 2 and 4 * ntile <= cus and not bf16_mlp and os.environ.get("PSP_FWD_VARIANT") in (None, "3")
+        fwd_name = "hjbw_fwd_kernel" if plan.family == 2 else (
+            "hjbq_fwd_kernel" if quad else ("hjbs_fwd_kernel" if ntile <= 2 * cus else "hjb_fwd_kernel"))
         bwd_name = "hjbw_bwd_kernel" if plan.family == 2 else "hjb_bwd2_kernel"
         issued = issued_mfma_per_tile_step(plan.d_pad, plan.H_pad, dense, plan.family, bf16_mlp)
+        if quad:
+            issued = (issued_mfma_quad_kernel(plan.d_pad, plan.H_pad, dense), 0, issued[2])
     bwd_dominant = bwd_ms >= fwd_ms
     dom, dom_ms, which = (bwd_name, bwd_ms, "bwd_kernel") if bwd_dominant else (fwd_name, fwd_ms, "fwd_kernel")
     if issued is None:                                   # DenseNet control: algorithmic terms only

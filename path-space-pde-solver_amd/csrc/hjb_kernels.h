@@ -363,7 +363,13 @@ struct Geo {
 // =======================================================================================
 // BF16: the three products of the control net on v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulate) -- an opt-in
 // mode with its own tolerance (psp_hjb_config.mlp_dtype); the drift / sigma products, the state and every sum stay fp32.
-template <int D, int H, bool BF16 = false>
+// FAST: on-device noise, no u_L2 log, no time-feature table (decided at launch) -- the time loop of that instance has no
+// vector-memory LOAD.  A load in a wave-uniform branch (the time feature of evaluation rollouts, supplied noise, the
+// reference control) leaves an `s_waitcnt vmcnt(0)` at the join on the common path; vmcnt counts stores too and in order, so
+// every step waited right behind its burst of 28 X-image stores for them to be acknowledged before the first product
+// started.  Worth 1.3 % here (4.78 -> 4.72 ms, same-box A/B), 2 % in hjbs_fwd_kernel, 5 % in hjbq_fwd_kernel, whose steps
+// are short; the larger part of the path store's cost stays (finding 7).
+template <int D, int H, bool BF16 = false, bool FAST = false>
 __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
@@ -444,7 +450,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
         for (int n = 0; n < a.N; ++n) {
             PSP_STAMP(fs0);
             // solver.py:355: ones * n * delta_t ; evaluation rollouts pass the table of solver.py:360-362
-            const float tn = a.tfeat ? a.tfeat[n] : (float)n * dt;
+            float tn = (float)n * dt;
+            if constexpr (!FAST) { if (a.tfeat) tn = a.tfeat[n]; }
             const f32x4* vecs = opaque(vecs0);         // re-read the small vectors each step (no hoisting)
             const f32x4* vb1 = vecs + (G::vb1 - G::fVec) / 4;
             const f32x4* vw1t = vecs + (G::vw1t - G::fVec) / 4;
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) {
                 f32x4 xi;
-                if (a.noise_mode == NOISE_PHILOX) {
+                if (FAST || a.noise_mode == NOISE_PHILOX) {
                     xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), iter_now, a.seed_lo, a.seed_hi);
                 } else {
                     // unconditional clamped loads + select: no per-element branch around the load
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
                     S = fmaf(Z[b][r], Z[b][r], S);
                     Pz = fmaf(Z[b][r], xi[r], Pz);
                 }
-                if (a.uref) {                          // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494)
+                if (!FAST && a.uref) {                 // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494)
                     const float* ur = a.uref + (size_t)n * D;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1440,21 +1447,22 @@ struct HjbLaunch {
     using G = Geo<D, H>;
     static int fwd_lds(int dk, int sk) { return G::fwd_lds_floats(dk, sk) * 4; }
     static int bwd_lds(int ad) { return G::bwd_lds_floats(ad) * 4; }
-    static hipError_t fwd(const HjbArgs& a, int grid, int block, hipStream_t s) {
+    template <bool BF16, bool FAST>
+    static hipError_t fwd_as(const HjbArgs& a, int grid, int block, hipStream_t s) {
         const int bytes = fwd_lds(a.drift_kind, a.sigma_kind);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_fwd_kernel<D, H>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_fwd_kernel<D, H, BF16, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjb_fwd_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
+        hipLaunchKernelGGL((hjb_fwd_kernel<D, H, BF16, FAST>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
+    // FAST (no vector-memory load in the time loop): Philox noise, no u_L2 log, no time-feature table -- every training launch
+    static bool fast(const HjbArgs& a) { return a.noise_mode == NOISE_PHILOX && a.uref == nullptr && a.tfeat == nullptr; }
+    static hipError_t fwd(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        return fast(a) ? fwd_as<false, true>(a, grid, block, s) : fwd_as<false, false>(a, grid, block, s);
+    }
     static hipError_t fwd_bf16(const HjbArgs& a, int grid, int block, hipStream_t s) {
-        const int bytes = fwd_lds(a.drift_kind, a.sigma_kind);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_fwd_kernel<D, H, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjb_fwd_kernel<D, H, true>), dim3(grid), dim3(block), bytes, s, a);
-        return hipGetLastError();
+        return fast(a) ? fwd_as<true, true>(a, grid, block, s) : fwd_as<true, false>(a, grid, block, s);
     }
 #ifdef PSP_LEGACY_BWD
     // hjb_bwd_kernel (the second backward version: two 4-wave workgroups per CU, every wave runs all phases) is superseded by

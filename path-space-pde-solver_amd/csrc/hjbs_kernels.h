@@ -34,7 +34,10 @@ struct GeoS {
                          fRed = iV + KP * 64, lds_floats = fRed + W * 64;
 };
 
-template <int D, int H>
+// FAST: on-device noise, no u_L2 log, no time-feature table (decided at launch).  The time loop of that instance has no
+// vector-memory LOAD: a load in a wave-uniform branch leaves an `s_waitcnt vmcnt(0)` at the join on the common path, and
+// vmcnt counts in order, so every step waited for its own path-store writes (hjbq_kernels.h has the same split).
+template <int D, int H, bool FAST>
 __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const HjbArgs a) {
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
@@ -125,7 +128,8 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
 #pragma unroll 1
     for (int n = 0; n < a.N; ++n) {
         PSP_STAMP(ss0);
-        const float tn = a.tfeat ? a.tfeat[n] : (float)n * dt;
+        float tn = (float)n * dt;
+        if constexpr (!FAST) { if (a.tfeat) tn = a.tfeat[n]; }
         const f32x4* vecs = opaque(vecs0);             // re-read the small vectors each step (no hoisting)
         const int qn = opaque_i(q);
         const f32x4* vb1 = vecs + S_::vb1 / 4;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
             const int sb = wave + W * io;
             if (sb < DB) {
                 f32x4 xi;
-                if (a.noise_mode == NOISE_PHILOX) {
+                if (FAST || a.noise_mode == NOISE_PHILOX) {
                     xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * sb + qn), iter_now, a.seed_lo, a.seed_hi);
                 } else {
                     const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
@@ -295,7 +299,7 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
                     S = fmaf(Z[io][r], Z[io][r], S);
                     Pz = fmaf(Z[io][r], xi[r], Pz);
                 }
-                if (a.uref) {                          // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494)
+                if (!FAST && a.uref) {                 // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494)
                     const float* ur = a.uref + (size_t)n * D;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -417,13 +421,18 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
 template <int D, int H>
 struct HjbsLaunch {
     static int lds_bytes() { return GeoS<D, H>::lds_floats * 4; }
-    static hipError_t fwd(const HjbArgs& a, int grid, hipStream_t s) {
+    template <bool FAST>
+    static hipError_t fwd_as(const HjbArgs& a, int grid, hipStream_t s) {
         const int bytes = lds_bytes();
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbs_fwd_kernel<D, H>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbs_fwd_kernel<D, H, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjbs_fwd_kernel<D, H>), dim3(grid), dim3(64 * GeoS<D, H>::W), bytes, s, a);
+        hipLaunchKernelGGL((hjbs_fwd_kernel<D, H, FAST>), dim3(grid), dim3(64 * GeoS<D, H>::W), bytes, s, a);
         return hipGetLastError();
+    }
+    static hipError_t fwd(const HjbArgs& a, int grid, hipStream_t s) {
+        const bool fast = a.noise_mode == NOISE_PHILOX && a.uref == nullptr && a.tfeat == nullptr;
+        return fast ? fwd_as<true>(a, grid, s) : fwd_as<false>(a, grid, s);
     }
 };
 

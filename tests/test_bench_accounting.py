@@ -59,3 +59,11 @@ def test_path_store_traffic_equals_the_algorithmic_store():
     assert store <= 2 * b["fetch_raw_bytes"] <= 2 * store
     bf = t["diffusion_dw_d100_K65536_N100_h64_bf16"]["gen_fwd_kernel"]
     assert bf["write_bytes"] == pytest.approx(960 * 65536 * 101 + 4 * 65536 * 101, rel=2e-2)   # bf16-pair images + ahat
+
+
+def test_quad_kernel_mfma_count():
+    """hjbq_fwd_kernel at the configs[1] shape: 104 v_mfma_f32_4x4x1 per wave and step (W1 16, dt A 32, B 32, W2 8, W3 16),
+    8 waves, 4 quads per 16 trajectories, 512 flop each = 832 16x16x4 equivalents; without dense drift / sigma 40 per wave."""
+    assert bench.issued_mfma_quad_kernel(100, 64, True) == 832
+    assert bench.issued_mfma_quad_kernel(100, 64, False) == 8 * 40
+    assert bench.issued_mfma_quad_kernel(16, 16, True) == 8 * (4 * 3 + 2 * 2)
