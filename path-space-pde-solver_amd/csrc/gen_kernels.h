@@ -150,7 +150,8 @@ __device__ __forceinline__ f32x4 image_get_T(const float* base, int o32, int o16
     return v;
 }
 
-template <int D, int H, bool BF16 = false>
+// PHILOX: on-device noise decided at launch -- no supplied-noise loads (and no join behind them) in the time loop
+template <int D, int H, bool BF16 = false, bool PHILOX = false>
 __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, KSI = G::KSI, HB = G::HB, KSH = G::KSH;
@@ -284,8 +285,13 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             const float alivef = stopped ? 0.f : 1.f;
             auto noise_block = [&](int b) __attribute__((always_inline)) {
                 f32x4 xi;
-                if (a.noise_mode == NOISE_PHILOX) {
-                    xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), a.iter, a.seed_lo, a.seed_hi);
+                if (PHILOX || a.noise_mode == NOISE_PHILOX) {
+                    // (trajectory id and block index made opaque per call: the first Philox round multiplies them by constants,
+                    //  which is invariant over the time loop -- hoisted, that was three registers per state block, spilled
+                    //  under the 256-register cap and reloaded per block behind an s_waitcnt vmcnt(0) that also waits for
+                    //  every path store in flight)
+                    xi = philox_block((uint32_t)opaque_i((int)kglob), (uint32_t)n, (uint32_t)(4 * b + opaque_i(q)), a.iter,
+                                      a.seed_lo, a.seed_hi);
                 } else {
                     const float* xrow = a.xi + ((size_t)n * a.K_local + (kvalid ? k : 0)) * D;
 #pragma unroll
@@ -1371,19 +1377,19 @@ struct GenLaunch {
         hipLaunchKernelGGL((gen_bwd2_kernel<D, H, true>), dim3(grid), dim3(512), bwd2_lds(), s, a);
         return hipGetLastError();
     }
-    static hipError_t fwd(const GenArgs& a, int grid, int block, hipStream_t s) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_fwd_kernel<D, H>),
+    template <bool BF16, bool PHILOX>
+    static hipError_t fwd_as(const GenArgs& a, int grid, int block, hipStream_t s) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_fwd_kernel<D, H, BF16, PHILOX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds());
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((gen_fwd_kernel<D, H>), dim3(grid), dim3(block), fwd_lds(), s, a);
+        hipLaunchKernelGGL((gen_fwd_kernel<D, H, BF16, PHILOX>), dim3(grid), dim3(block), fwd_lds(), s, a);
         return hipGetLastError();
     }
+    static hipError_t fwd(const GenArgs& a, int grid, int block, hipStream_t s) {
+        return a.noise_mode == NOISE_PHILOX ? fwd_as<false, true>(a, grid, block, s) : fwd_as<false, false>(a, grid, block, s);
+    }
     static hipError_t fwd_bf16(const GenArgs& a, int grid, int block, hipStream_t s) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_fwd_kernel<D, H, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds());
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((gen_fwd_kernel<D, H, true>), dim3(grid), dim3(block), fwd_lds(), s, a);
-        return hipGetLastError();
+        return a.noise_mode == NOISE_PHILOX ? fwd_as<true, true>(a, grid, block, s) : fwd_as<true, false>(a, grid, block, s);
     }
 #ifdef PSP_LEGACY_BWD
     // gen_bwd_kernel: superseded by gen_bwd2_kernel; diagnostic builds only (-DPSP_LEGACY_BWD + PSP_BWD_VARIANT=1)
