@@ -20,7 +20,7 @@ def _traffic():
 # workload -> (padded d, H, dense, kernel family, forward kernel name, backward kernel name)
 CASES = {
     "hjb_llgc_d100_K65536_N100_h64": (100, 64, True, 1, "hjb_fwd_kernel", "hjb_bwd2_kernel"),
-    "hjb_llgc_d100_K1024_N50_h64": (100, 64, True, 1, "hjbs_fwd_kernel", "hjb_bwd2_kernel"),
+    "hjb_llgc_d100_K1024_N50_h64": (100, 64, True, 1, "hjbq_fwd_kernel", "hjb_bwd2_kernel"),
     "hjb_llgc_d200_K32768_N100_h64": (200, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd_kernel"),
     "hjb_llgc_d500_K16384_N200_h64": (500, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd_kernel"),
 }
@@ -34,6 +34,8 @@ def test_issued_mfma_formula_matches_the_pmc_counts(workload):
     N = int(round(w["T"] / w["dt"]))
     tiles_steps = (w["K"] // 16) * N
     fwd, _, bwd = bench.issued_mfma_per_tile_step(d, H, dense, family)
+    if fwd_name == "hjbq_fwd_kernel":           # 4x4x1 instructions: four per 16x16x4 equivalent
+        fwd = 4 * bench.issued_mfma_quad_kernel(d, H, dense)
     assert fwd * tiles_steps == pytest.approx(meas[fwd_name]["mfma_instructions"], rel=2e-3), (fwd, meas[fwd_name])
     assert bwd * tiles_steps == pytest.approx(meas[bwd_name]["mfma_instructions"], rel=2e-3), (bwd, meas[bwd_name])
 
