@@ -229,13 +229,6 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
 #else
 #define PSP_WIDE_SYNC()
 #endif
-// Path-store writes are a pure stream (read back by the next kernel, never by this one): non-temporal stores keep them from
-// displacing the operand tables in L2.  -DPSP_PATH_STORE_PLAIN restores ordinary stores (A/B).
-#if defined(PSP_PATH_STORE_PLAIN) && PSP_PATH_STORE_PLAIN
-#define PSP_PATH_STORE(ptr, val) (*(ptr) = (val))
-#else
-#define PSP_PATH_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#endif
 
 // =======================================================================================
 // Wide forward kernel: one wave = one 16-trajectory tile for all N steps (same per-step algebra, same
