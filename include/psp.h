@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PSP_VERSION 200 /* 0.2.0 */
+#define PSP_VERSION 201 /* 0.2.1 */
 
 /* drift b(x): reference problems.py:36-37,154-155 (dense), :311-315 (double well) */
 enum { PSP_DRIFT_ZERO = 0, PSP_DRIFT_DENSE = 1, PSP_DRIFT_DIAG = 2, PSP_DRIFT_DOUBLE_WELL = 3 };
@@ -393,6 +393,21 @@ int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* params, const 
                          const float* y0, const float* xi, uint64_t seed, uint32_t iter, const float* tfeat,
                          float* px, float* pxi, float* D_out, float* Fint_out, float* XN_out, float* Y_out,
                          double* fwd_partial, float* tables, void* stream);
+
+/* Gradients THROUGH the state path for a DenseNet control (adaptive_forward_process=True with detach_forward=False -- the
+ * reference's constructor defaults, solver.py:23-24, 451-469) and the relative-entropy loss (:179-180, 484-486): the
+ * counterpart of psp_hjb_adjoint_sweep.  Call sequence per iteration:
+ *     psp_dnet_rollout_fwd   with base.store_path = 2 (losses of Y_N - g(X_N)) or 3 (PSP_LOSS_REL_ENTROPY), images_out and
+ *                            XN_out given
+ *     [loss and per-trajectory weights mu_k = dL/dY_N[k], nu_k = dL/dZsum_N[k] from D on the caller's side]
+ *     psp_dnet_adjoint_sweep reverse-time adjoint recursion per trajectory tile (csrc/hjbd_kernels.h: hjbd_adj_kernel, with the
+ *                            Jacobian of the dense-concat net from the stored relu images); rewrites the xi slot of `images`
+ *                            with dL/dZ_n / sqrt(dt)
+ *     psp_dnet_rollout_bwd   with w = 1 for every trajectory
+ *   XN : (K_local, base.d) terminal states;  mu, nu, wT as for psp_hjb_adjoint_sweep (nu / wT may be NULL);
+ *   tables : the forward call's table scratch (the sweep rebuilds it with the transposed orientations). */
+int psp_dnet_adjoint_sweep(const psp_dnet_config* cfg, const float* params, float* images, const float* XN,
+                           const float* mu, const float* nu, const float* wT, float* tables, void* stream);
 
 /* Parameter gradient of sum_{n,k} w_k sqrt(dt) image_n[k] . Z_n(X_n[k]) (= dL/dtheta for a detached forward process) from the
  * images the forward wrote (cfg->images_out).  w: per-trajectory weights dL/dD_k, zero padded to 16 * ceil(K_local/16).

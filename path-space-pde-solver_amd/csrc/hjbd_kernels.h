@@ -80,8 +80,12 @@ struct DGeo {
     }
 };
 
+// adjoint = 1: the TRANSPOSED orientations the adjoint sweep (hjbd_adj_kernel) contracts with, in the same region and with
+// the same offsets / shapes as the forward set:  tW12 <- [W3h2^T | W3h1^T] (rows: hidden units, over the d outputs),
+// tW2h <- W2h^T, tW3x <- W3x^T, tW3h1 <- W2x^T, tW3h2 <- W1^T (rows: state components, over the hidden units), oA <- (dt A)^T,
+// oB <- B^T.  (The forward tables are dead once the rollout has finished; the backward kernel stages its own from the parameters.)
 template <int D, int H>
-__global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a) {
+__global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a, int adjoint) {
     using W = DGeo<D, H>;
     const HjbArgs& h = a.h;
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gs = (long long)gridDim.x * blockDim.x;
@@ -90,6 +94,37 @@ __global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a) {
     const long long oW1 = 0, ob1 = (long long)di * hh, oW2 = ob1 + hh, ob2 = oW2 + (long long)(di + hh) * hh,
                     oW3 = ob2 + hh, ob3 = oW3 + (long long)(di + 2 * hh) * d;
     float* T = a.tbl;
+    if (adjoint) {
+        if (h.drift_kind == DRIFT_DENSE) {
+            const float dt = h.dt;
+            const float* __restrict__ A = h.drift;
+            table_fill(T + W::oA, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+                return (row < D && col < D) ? dt * A[col * D + row] : 0.f; });
+        }
+        if (h.sigma_kind == SIGMA_DENSE) {
+            const float* __restrict__ B = h.sigma;
+            table_fill(T + W::oB, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+                return (row < D && col < D) ? B[col * D + row] : 0.f; });
+        }
+        const int nsets = a.per_step ? h.N : 1;
+        for (int s = 0; s < nsets; ++s) {
+            const float* __restrict__ Pp = h.params + (long long)s * P;
+            float* Ts = T + W::oSets + (long long)s * W::set_floats;
+            table_fill(Ts + W::tW12, 2 * W::HB, W::KP, gtid, gs, [&](int row, int col) {     // rows: [h2 units | h1 units]
+                const int u = row < 16 * W::HB ? row : row - 16 * W::HB;
+                if (u >= hh || col >= d) return 0.f;
+                return row < 16 * W::HB ? Pp[oW3 + (long long)(di + hh + u) * d + col] : Pp[oW3 + (long long)(di + u) * d + col]; });
+            table_fill(Ts + W::tW2h, W::HB, 4 * W::HB, gtid, gs, [&](int row, int col) {
+                return (row < hh && col < hh) ? Pp[oW2 + (long long)(di + row) * hh + col] : 0.f; });
+            table_fill(Ts + W::tW3x, W::DB, W::KP, gtid, gs, [&](int row, int col) {
+                return (row < d && col < d) ? Pp[oW3 + (long long)(to + row) * d + col] : 0.f; });
+            table_fill(Ts + W::tW3h1, W::DB, 4 * W::HB, gtid, gs, [&](int row, int col) {
+                return (row < d && col < hh) ? Pp[oW2 + (long long)(to + row) * hh + col] : 0.f; });
+            table_fill(Ts + W::tW3h2, W::DB, 4 * W::HB, gtid, gs, [&](int row, int col) {
+                return (row < d && col < hh) ? Pp[oW1 + (long long)(to + row) * hh + col] : 0.f; });
+        }
+        return;
+    }
     if (h.drift_kind == DRIFT_DENSE) {
         const float dt = h.dt;
         const float* __restrict__ A = h.drift;
@@ -177,7 +212,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
     float* imgX = lds + W::fImg + wave * 2 * W::IMG;  // this wave's image of X_n   [KP][64]
     float* imgV = imgX + W::IMG;                      // ... and of the increment panel v (dense sigma)
     const bool store = a.store_path && kvalid;
-    const float store_cz = a.adaptive ? 0.f : a.sqdt; // image: xi, or xi + sqrt(dt) Z for a non-adaptive process (hjb_fwd_kernel)
+    // image in the xi slot: c_xi xi + c_z Z.  store_path 1: xi, or xi + sqrt(dt) Z for a non-adaptive process; 2: xi - sqrt(dt) Z
+    // and 3: Z for the adjoint sweep (attached forward process / relative entropy), as in hjb_fwd_kernel
+    const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;
+    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
     const int nsets_m1 = da.per_step ? a.N - 1 : 0;
     const float* Vbase = T + W::oSets + (long long)(nsets_m1 + 1) * W::set_floats;
 
@@ -327,12 +365,12 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= dr || !kvalid) xi[r] = 0.f;   // padding carries no noise
                     if (store_img) {
-                        const f32x4 wv = xi + store_cz * Zg[m];
+                        const f32x4 wv = store_cxi * xi + store_cz * Zg[m];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) iblk[W::pXi + (4 * b + r) * 64] = wv[r];
                     } else if (store) {
                         float* pxi = da.pxi + row * dr;
-                        const f32x4 wv = xi + store_cz * Zg[m];
+                        const f32x4 wv = store_cxi * xi + store_cz * Zg[m];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int f = 16 * b + 4 * r + q;
@@ -374,8 +412,12 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 }
                 fX = qsum(fX);
             }
-            const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
-            Y = Y + drift_y * dt + Pz * sqdt;
+            if (a.loss_kind == LOSS_RELENT) {
+                Y = Y - (0.5f * S + fX) * dt;           // Y carries -Zsum (hjb_fwd_kernel): D = -(Zsum + g), loss = -mean D
+            } else {
+                const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
+                Y = Y + drift_y * dt + Pz * sqdt;
+            }
             Fsum = fmaf(fX, dt, Fsum);
         }
 
@@ -417,6 +459,171 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
         for (int w = 0; w < nwave; ++w) { t0 += red[2 * w]; t1 += red[2 * w + 1]; }
         a.fwd_partial[2 * blockIdx.x] = t0;
         a.fwd_partial[2 * blockIdx.x + 1] = t1;
+    }
+}
+
+// =======================================================================================
+// Reverse-time adjoint sweep for a DenseNet control (gradients THROUGH the state path: adaptive_forward_process=True with
+// detach_forward=False -- the reference's default flags, solver.py:451-469 -- and the relative-entropy loss, :179-180,
+// 484-486).  Same recursion as hjb_adj_kernel / hjbw_adj_kernel (hjba_kernels.h has the derivation):
+//     lambda'  = lambda_{n+1} + (mu + nu) dt grad f(X_{n+1})
+//     gZ_n     = coefW W_n - dt B^T lambda'        (W_n = the image the forward left in the xi slot: store_path 2 or 3)
+//     lambda_n = lambda' + dt b'(X_n)^T lambda' + J_n^T gZ_n
+// with the Jacobian of the dense-concat net  Z = W3^T [x, h1, h2] + b3,  h = relu(z)^2:
+//     dz2 = (W3h2^T gZ) 2 r2,   dz1 = (W3h1^T gZ + W2h^T dz2) 2 r1,   J^T gZ = W3x^T gZ + W2x^T dz2 + W1^T dz1
+// from the relu images the forward stored.  gZ_n / sqrt(dt) overwrites the xi slot; hjbd_bwd_kernel then runs with unit
+// weights.  One wave per 16-trajectory tile like the forward; the step's TRANSPOSED tables come from hjbd_tables_kernel
+// (adjoint = 1) in the forward's table region.
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const DnetArgs da) {
+    using W = DGeo<D, H>;
+    constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
+    const HjbArgs& a = da.h;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const float* __restrict__ T = da.tbl;
+
+    stage_vec(lds + W::vdr, DB, tid, nthr, [&](int f) {
+        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+    stage_vec(lds + W::vrun, DB, tid, nthr, [&](int f) {
+        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+    stage_vec(lds + W::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
+    __syncthreads();
+
+    const int t16 = blockIdx.x * nwave + wave;
+    if (t16 >= a.ntile16) return;                      // no workgroup barriers below
+    const int k = t16 * 16 + j;
+    const bool kvalid = k < a.K_local;
+    const float dt = a.dt, sqdt = a.sqdt, rsq = 1.0f / a.sqdt;
+    const float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
+    const float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    const float coefW = (a.store_path == 3) ? nu * dt : mu * sqdt;
+    const float wf = (mu + nu) * dt;
+    const float wT = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);      // weight of grad g(X_N) in lambda_N
+    float* img = lds + W::fImg + wave * 2 * W::IMG;
+    const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds) + q;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned ul = (unsigned)lane;
+    typedef __attribute__((address_space(1))) float* gwptr_t;
+
+    f32x4 lam[DB];                                     // lambda_N = wT grad g(X_N)
+    {
+        const f32x4* vterm = vecs0 + W::vterm / 4;
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            const f32x4 tv = vterm[b * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * b + 4 * r + q;
+                const float x = (f < D && kvalid) ? a.XN[(size_t)k * D + f] : 0.f;
+                float gg;
+                if (a.term_kind == TERM_LINEAR) gg = tv[r];
+                else if (a.term_kind == TERM_DIAGQ) gg = 2.0f * tv[r] * x;
+                else gg = 2.0f * tv[r] * (x - 1.0f);
+                lam[b][r] = wT * gg;
+            }
+        }
+    }
+
+#pragma unroll 1
+    for (int n = a.N - 1; n >= 0; --n) {
+        const f32x4* vecs = opaque(vecs0);
+        const f32x4* vdr = vecs + W::vdr / 4;
+        const f32x4* vrun = vecs + W::vrun / 4;
+        const float* Ts = T + W::oSets + (long long)(da.per_step ? n : 0) * W::set_floats;     // this step's transposed set
+        auto pbase = [&](int nn, int ofs) __attribute__((always_inline)) {
+            return (gwptr_t)sgpr_block_addr(da.pimg, (unsigned long long)nn * a.ntile16 + t16, (unsigned)W::PBI, (unsigned)ofs);
+        };
+        // lambda' = lambda_{n+1} + (mu + nu) dt grad f(X_{n+1});  X_{n+1} from the next image block (or X_N)
+        if (a.runcost_kind == RUN_DIAGQ) {
+            const int nx = n + 1 < a.N ? n + 1 : n;
+#pragma unroll
+            for (int b = 0; b < DB; ++b) {
+                gwptr_t px = pbase(nx, W::pX + b * 256);
+                f32x4 x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * b + 4 * r + q;
+                    const float xp = px[r * 64 + ul];
+                    const float xn = (f < D && kvalid) ? a.XN[(size_t)k * D + (f < D ? f : 0)] : 0.f;
+                    x[r] = (n + 1 < a.N) ? xp : xn;
+                }
+                lam[b] += (2.0f * wf) * (vrun[b * 4] * x);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = lam[ks >> 2][ks & 3];
+        // q = B^T lambda'
+        f32x4 qv[DB];
+        if (a.sigma_kind == SIGMA_DENSE) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) qv[b] = zero4;
+            gemm_img<DB, KP>(qv, T + W::oB, img, lane);
+        } else if (a.sigma_kind == SIGMA_SCALE) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) qv[b] = a.sigma_scale * lam[b];
+        } else {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) qv[b] = lam[b];
+        }
+        // lambda += dt b'(X_n)^T lambda'   (in place; the image still holds lambda')
+        if (a.drift_kind == DRIFT_DENSE) {
+            gemm_img<DB, KP>(lam, T + W::oA, img, lane);
+        } else if (a.drift_kind == DRIFT_DIAG) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) lam[b] += dt * (vdr[b * 4] * lam[b]);
+        } else if (a.drift_kind == DRIFT_DWELL) {
+#pragma unroll
+            for (int b = 0; b < DB; ++b) {
+                gwptr_t px = pbase(n, W::pX + b * 256);
+                f32x4 x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = px[r * 64 + ul];
+                lam[b] -= dt * (4.0f * vdr[b * 4] * ((3.0f * x * x - 1.0f) * lam[b]));
+            }
+        }
+        // gZ_n: back into the xi slot (as gZ / sqrt(dt)) and into the image (B operand of the transposed products)
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            gwptr_t pw = pbase(n, W::pXi + b * 256);
+            f32x4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = pw[r * 64 + ul];
+            const f32x4 gz = coefW * w - dt * qv[b];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pw[r * 64 + ul] = rsq * gz[r];
+                img[(4 * b + r) * 64 + lane] = gz[r];
+            }
+        }
+        // adjoints of the hidden layers
+        f32x4 u[2 * HB], dz2[HB], dz1[HB];
+#pragma unroll
+        for (int m = 0; m < 2 * HB; ++m) u[m] = zero4;
+        gemm_img<2 * HB, KP>(u, Ts + W::tW12, img, lane);                 // [W3h2^T gZ | W3h1^T gZ]
+#pragma unroll
+        for (int m = 0; m < HB; ++m) {
+            f32x4 r2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r2[e] = pbase(n, W::pR2)[(4 * m + e) * 64 + ul];
+            dz2[m] = u[m] * (2.0f * r2);
+            dz1[m] = u[HB + m];
+        }
+        gemm_regs<HB, 4 * HB, HB>(dz1, Ts + W::tW2h, dz2, lane);           // + W2h^T dz2
+#pragma unroll
+        for (int m = 0; m < HB; ++m) {
+            f32x4 r1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r1[e] = pbase(n, W::pR1)[(4 * m + e) * 64 + ul];
+            dz1[m] = dz1[m] * (2.0f * r1);
+        }
+        // lambda_n += J_n^T gZ_n
+        gemm_img<DB, KP>(lam, Ts + W::tW3x, img, lane);                   // W3x^T gZ
+        gemm_regs<DB, 4 * HB, HB>(lam, Ts + W::tW3h1, dz2, lane);         // W2x^T dz2
+        gemm_regs<DB, 4 * HB, HB>(lam, Ts + W::tW3h2, dz1, lane);         // W1^T dz1
     }
 }
 
@@ -648,13 +855,25 @@ struct DnetInstance {
     int bwd_passes;            // launches of hjbd_bwd_kernel: 1, 2 (columns split so that a wave's accumulator tiles fit its
                                // registers) or 0 (not covered: the library-GEMM formulation is used instead)
     hipError_t (*launch_bwd)(const DnetArgs&, int grid, hipStream_t);
+    hipError_t (*launch_adj)(const DnetArgs&, int grid, hipStream_t);      // adjoint sweep (transposed tables + hjbd_adj_kernel)
 };
 
 template <int D, int H>
 struct DnetLaunch {
     using W = DGeo<D, H>;
+    static hipError_t adj(const DnetArgs& a, int grid, hipStream_t s) {
+        hipLaunchKernelGGL((hjbd_tables_kernel<D, H>), dim3(512), dim3(256), 0, s, a, 1);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const int bytes = W::lds_floats * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_adj_kernel<D, H>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbd_adj_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
+        return hipGetLastError();
+    }
     static hipError_t fwd(const DnetArgs& a, int grid, hipStream_t s) {
-        hipLaunchKernelGGL((hjbd_tables_kernel<D, H>), dim3(512), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((hjbd_tables_kernel<D, H>), dim3(512), dim3(256), 0, s, a, 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const int bytes = W::lds_floats * 4;
@@ -690,7 +909,7 @@ struct DnetLaunch {
     }
     static DnetInstance instance() {
         return DnetInstance{D, H, W::lds_floats * 4, W::set_floats, W::vec_floats, W::oSets, &fwd,
-                            W::PBI, W::PP, W::bwd_lds_floats * 4, kPasses, &bwd};
+                            W::PBI, W::PP, W::bwd_lds_floats * 4, kPasses, &bwd, &adj};
     }
 };
 

@@ -471,9 +471,8 @@ int make_dnet_plan(const psp_dnet_config* c, DnetPlan* p) {
         return fail(-1, "d_real / H_real must lie in [1, d] / [1, H] of the instance");
     if (b.drift_kind < 0 || b.drift_kind > 3 || b.sigma_kind < 0 || b.sigma_kind > 2 || b.runcost_kind < 0 ||
         b.runcost_kind > 1 || b.term_kind < 0 || b.term_kind > 2 || b.noise_mode < 0 || b.noise_mode > 1 ||
-        b.store_path < 0 || b.store_path > 1)
+        b.store_path < 0 || b.store_path > 3 || b.loss_kind < 0 || b.loss_kind > 3)
         return fail(-1, "config enum out of range");
-    if (b.loss_kind == PSP_LOSS_REL_ENTROPY) return fail(-1, "relative entropy is not built for the DenseNet control");
     if (p->inst.lds_bytes > kMaxLds) return fail(-3, "DenseNet-control kernel images do not fit the 160 KiB LDS");
     p->ntile16 = (b.K_local + 15) / 16;
     p->grid = (p->ntile16 + 3) / 4;
@@ -548,6 +547,31 @@ extern "C" int psp_dnet_rollout_bwd(const psp_dnet_config* cfg, const float* par
     return 0;
 }
 
+extern "C" int psp_dnet_adjoint_sweep(const psp_dnet_config* cfg, const float* params, float* images, const float* XN,
+                                      const float* mu, const float* nu, const float* wT, float* tables, void* stream) {
+    DnetPlan p;
+    int rc = make_dnet_plan(cfg, &p);
+    if (rc) return rc;
+    const psp_hjb_config* b = &cfg->base;
+    if ((rc = check_ptrs(b))) return rc;
+    if (!params || !images || !XN || !mu || !tables) return fail(-1, "null buffer passed to psp_dnet_adjoint_sweep");
+    if (b->store_path != 2 && b->store_path != 3) return fail(-1, "psp_dnet_adjoint_sweep needs store_path 2 or 3 (the forward's image kind)");
+    if (b->store_path == 3 && !nu) return fail(-1, "store_path 3 (relative entropy) needs nu");
+    psp::DnetArgs a;
+    memset(&a, 0, sizeof(a));
+    psp::HjbArgs& h = a.h;
+    h.drift = b->drift; h.sigma = b->sigma; h.runcost = b->runcost; h.term = b->term;
+    h.K_local = b->K_local; h.N = b->N; h.ntile16 = p.ntile16; h.dt = b->dt; h.sqdt = b->sqrt_dt; h.sigma_scale = b->sigma_scale;
+    h.drift_kind = b->drift_kind; h.sigma_kind = b->sigma_kind; h.runcost_kind = b->runcost_kind; h.term_kind = b->term_kind;
+    h.adaptive = b->adaptive; h.store_path = b->store_path;
+    h.params = params; h.XN = const_cast<float*>(XN); h.adj_mu = mu; h.adj_nu = nu; h.adj_wT = wT;
+    a.tbl = tables; a.pimg = images;
+    a.d_real = cfg->d_real; a.h_real = cfg->H_real; a.time_input = cfg->time_input ? 1 : 0; a.per_step = cfg->per_step ? 1 : 0;
+    hipError_t e = p.inst.launch_adj(a, p.grid, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hjbd_adj_kernel launch");
+    return 0;
+}
+
 extern "C" int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* params, const float* x0, int32_t x0_stride,
                                     const float* y0, const float* xi, uint64_t seed, uint32_t iter, const float* tfeat,
                                     float* px, float* pxi, float* D_out, float* Fint_out, float* XN_out, float* Y_out,
@@ -561,6 +585,8 @@ extern "C" int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* par
     if (x0_stride != 0 && x0_stride != b->d) return fail(-1, "x0_stride must be 0 or d");
     if (b->noise_mode == PSP_NOISE_SUPPLIED && !xi) return fail(-1, "supplied-noise mode needs xi");
     if (b->store_path && !cfg->images_out && (!px || !pxi)) return fail(-1, "store_path set but the X / xi stores are null");
+    if (b->store_path >= 2 && !cfg->images_out)
+        return fail(-1, "store_path 2 / 3 (adjoint sweep) need the register images (psp_dnet_config.images_out)");
     psp::DnetArgs a;
     memset(&a, 0, sizeof(a));
     psp::HjbArgs& h = a.h;

@@ -112,6 +112,7 @@ SIGNATURES = {
     "psp_dnet_query": (C.c_int, [C.POINTER(DnetConfig), C.POINTER(DnetSizes)]),
     "psp_dnet_terminal_reduce": (C.c_int, [C.POINTER(DnetConfig), _P, _P, _P]),
     "psp_dnet_rollout_bwd": (C.c_int, [C.POINTER(DnetConfig), _P, _P, _P, _P, _P]),
+    "psp_dnet_adjoint_sweep": (C.c_int, [C.POINTER(DnetConfig), _P, _P, _P, _P, _P, _P, _P, _P]),
     "psp_dnet_rollout_fwd": (C.c_int, [C.POINTER(DnetConfig), _P, _P, C.c_int32, _P, _P, C.c_uint64, C.c_uint32, _P,
                                        _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "psp_gen_instance_count": (C.c_int, []),

@@ -15,8 +15,13 @@ Per iteration (reference solver.py:430-514):
     psp_adam_step            one fused Adam over the concatenation of all parameter sets (identical to the reference's
                              per-net Adams: same lr, betas and step count)
 The rollout is the sequential, launch-bound part of the reference (N steps x ~70 eager kernels) and is the hand-written
-kernel; the gradient is GEMM-shaped and is left to rocBLAS.  Relative entropy and gradients through the state path
-(detach_forward=False) are outside this plan and keep the composite one.
+kernel; the gradient is GEMM-shaped and is left to rocBLAS.
+Gradients THROUGH the state path (adaptive_forward_process=True with detach_forward=False: the reference's constructor
+defaults, solver.py:23-24, 451-469) and the relative-entropy loss (:179-180, 484-486) run natively on the instances the
+hand-written backward covers: the rollout leaves xi - sqrt(dt) Z (or Z) in the xi slot of the register images,
+psp_dnet_adjoint_sweep (csrc/hjbd_kernels.h: hjbd_adj_kernel) walks the adjoint recursion backwards in time with the
+Jacobian of the dense-concat net and overwrites the slot with dL/dZ_n / sqrt(dt), and the backward kernel runs with unit
+weights -- the scheme of plan_native.py / psp_hjb_adjoint_sweep.
 """
 import ctypes as C
 
@@ -35,7 +40,7 @@ except ImportError:
     from function_space import DenseNet
     from plan_native import HjbNativePlan, PlanUnsupported, _overridden
 
-_LOSSES = ('log-variance', 'moment', 'variance', 'cross_entropy')
+_LOSSES = ('log-variance', 'moment', 'variance', 'cross_entropy', 'relative_entropy')
 
 
 def _nets(solver):
@@ -55,8 +60,8 @@ def dense_eligibility(solver):
         return "only approx_method='control' is native"
     if solver.loss_method not in _LOSSES:
         return 'loss_method %r is not native for a DenseNet control (%s are)' % (solver.loss_method, ', '.join(_LOSSES))
-    if solver.adaptive_forward_process and not solver.detach_forward:
-        return 'detach_forward=False back-propagates through the state path (composite plan for DenseNet controls)'
+    if solver.loss_method == 'relative_entropy' and not solver.adaptive_forward_process:
+        return 'relative_entropy with a non-adaptive forward process is not native for a DenseNet control'
     if solver.burgers_drift or solver.u_l2_error_flag or solver.compute_gradient_variance > 0 or solver.log_gradient \
             or solver.metastability_logs is not None:
         return 'per-step / per-iteration diagnostics (u_L2, gradient logs, metastability) are not native here'
@@ -125,10 +130,13 @@ class DenseNativePlan:
         b.drift_kind, b.sigma_kind, b.sigma_scale = spec['drift'][0], spec['sigma'][0], float(spec['sigma'][2])
         b.runcost_kind, b.term_kind = spec['runcost'][0], spec['term'][0]
         b.adaptive = 1 if s.adaptive_forward_process else 0
-        b.loss_kind = {'log-variance': nat.LOSS_LOG_VARIANCE, 'moment': nat.LOSS_MOMENT}.get(s.loss_method, nat.LOSS_WEIGHTS)
+        b.loss_kind = {'log-variance': nat.LOSS_LOG_VARIANCE, 'moment': nat.LOSS_MOMENT,
+                       'relative_entropy': nat.LOSS_REL_ENTROPY}.get(s.loss_method, nat.LOSS_WEIGHTS)
         self.generic_loss = b.loss_kind == nat.LOSS_WEIGHTS
+        self.relent = s.loss_method == 'relative_entropy'
+        self.attached = bool(s.adaptive_forward_process and not s.detach_forward)
         b.noise_mode = nat.NOISE_PHILOX if noise == 'philox' else nat.NOISE_SUPPLIED
-        b.store_path = 1
+        b.store_path = 3 if self.relent else (2 if self.attached else 1)
         pad = self.pad
         b.drift = nat.ptr(dev_f32(pad.drift_or_sigma(spec['drift'][1]))) if spec['drift'][1] is not None else None
         b.sigma = nat.ptr(dev_f32(pad.drift_or_sigma(spec['sigma'][1]))) if spec['sigma'][1] is not None else None
@@ -147,6 +155,16 @@ class DenseNativePlan:
         # library-GEMM formulation on row-major stores (PSP_DENSE_BWD=gemm forces the latter: cross-check / timing)
         import os
         self.kernel_bwd = bool(sizes.bwd_supported) and os.environ.get('PSP_DENSE_BWD', 'kernel') != 'gemm'
+        if (self.attached or self.relent) and not self.kernel_bwd:
+            raise PlanUnsupported('the adjoint sweep of a DenseNet control works on the register images of the hand-written '
+                                  'backward, which does not cover the (%d, %d) instance' % (self.d_pad, self.H_pad))
+        if self.attached or self.relent:
+            self.w_bwd = torch.empty(self.K_local, dtype=f32, device=dev)
+        if self.attached:
+            self.XN_k = torch.empty(self.K_local, self.d_pad, dtype=f32, device=dev)
+            self.mu = torch.zeros(self.K_local, dtype=f32, device=dev)
+            self.nu = torch.zeros(self.K_local, dtype=f32, device=dev)
+            self.wT = torch.zeros(self.K_local, dtype=f32, device=dev)
         if self.kernel_bwd:
             self.images = torch.empty(sizes.image_bytes // 4, dtype=f32, device=dev)
             self.partial = torch.zeros(s.N * sizes.slices, sizes.padded_params, dtype=f32, device=dev)
@@ -312,7 +330,8 @@ class DenseNativePlan:
             ev[0].record()
         nat.check(lib.psp_dnet_rollout_fwd(C.byref(cfg), nat.ptr(self.flat), nat.ptr(x0_t), self.d_pad if x0 is not None else 0,
                                            nat.ptr(self.y0_param) if self.learn_y0 else None, nat.ptr(xi), seed, l, None,
-                                           nat.ptr(self.PX), nat.ptr(self.PXI), nat.ptr(self.D), None, None,
+                                           nat.ptr(self.PX), nat.ptr(self.PXI), nat.ptr(self.D), None,
+                                           nat.ptr(self.XN_k) if self.attached else None,
                                            nat.ptr(self.Yn), nat.ptr(self.fwd_partial), nat.ptr(self.tables), st),
                   'psp_dnet_rollout_fwd')
         if ev is not None:
@@ -324,10 +343,32 @@ class DenseNativePlan:
             loss, w = self._generic_loss_weights()
         else:
             loss = sharding.loss_from_sums(self.sums, s.K, s.loss_method)
-            w = sharding.loss_weights(self.D, self.sums, s.K, s.loss_method)
+            w = None if self.relent else sharding.loss_weights(self.D, self.sums, s.K, s.loss_method)
         loss_out[l] = loss.to(torch.float32)
         if ev is not None:
             ev[2].record()
+        if self.attached:
+            # per-trajectory weights mu = dL/dY_N, nu = dL/dZsum_N (global K and global mean: rank-independent), as in
+            # plan_native.py; the sweep leaves dL/dZ_n / sqrt(dt) in the xi slot of the images
+            wT = None
+            if self.relent:
+                self.mu.zero_()
+                self.nu.fill_(1.0 / float(s.K))
+            else:
+                self.mu.copy_(w)
+                if s.loss_method == 'cross_entropy':
+                    # mean(Y exp(-g(X_N) + Y.detach())) (solver.py:183-185) also depends on X_N through exp(-g)
+                    wT = self.wT
+                    wT.copy_(-self.Yn * w)
+            nat.check(lib.psp_dnet_adjoint_sweep(C.byref(cfg), nat.ptr(self.flat), nat.ptr(self.images), nat.ptr(self.XN_k),
+                                                 nat.ptr(self.mu), nat.ptr(self.nu) if self.relent else None, nat.ptr(wT),
+                                                 nat.ptr(self.tables), st), 'psp_dnet_adjoint_sweep')
+            self.w_bwd.fill_(1.0)
+            w = self.w_bwd
+        elif self.relent:
+            # detached relative entropy: dL/dZ_n = Z_n dt / K, and the xi slot holds Z_n  ->  weight sqrt(dt) / K
+            self.w_bwd.fill_(float(cfg.base.sqrt_dt) / float(s.K))
+            w = self.w_bwd
         self._gradient(w)
         if ev is not None:
             ev[3].record()

@@ -387,6 +387,33 @@ CASES = [
          problem=dict(kind="LQGC", kwargs=dict(d=6, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
          solver=dict(HJB, loss_method="variance", L=4, lr=0.005, seed=42, delta_t=0.05, K=128, u_l2_error_flag=False),
          net=dict(kind="densenet", arch=[24, 24], seed=7), probe_times=[0.0]),
+    # DenseNet controls with gradients THROUGH the state path (detach_forward=False: the constructor default) and the
+    # relative-entropy loss: native through psp_dnet_adjoint_sweep (csrc/hjbd_kernels.h: hjbd_adj_kernel)
+    dict(name="lqgc_d2_outer_attached", family="solver",                 # the reference's default flags
+         problem=dict(kind="LQGC", kwargs=dict(d=2, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
+         solver=dict(loss_method="log-variance", time_approx="outer", adaptive_forward_process=True,
+                     detach_forward=False, early_stopping_time=None, L=4, lr=0.01, seed=42,
+                     delta_t=0.05, K=64, u_l2_error_flag=False)),
+    dict(name="llgc_d12_outer_relative_entropy", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=12, off_diag=0.05, T=0.2, seed=42)),
+         solver=dict(loss_method="relative_entropy", time_approx="outer", adaptive_forward_process=True,
+                     detach_forward=False, early_stopping_time=None, L=4, lr=0.003, seed=42, delta_t=0.02, K=80,
+                     u_l2_error_flag=False)),
+    dict(name="llgc_d12_outer_relative_entropy_detached", family="solver",
+         problem=dict(kind="LLGC", kwargs=dict(d=12, off_diag=0.05, T=0.2, seed=42)),
+         solver=dict(loss_method="relative_entropy", time_approx="outer", adaptive_forward_process=True,
+                     detach_forward=True, early_stopping_time=None, L=4, lr=0.003, seed=42, delta_t=0.02, K=80,
+                     u_l2_error_flag=False)),
+    dict(name="dw_d20_densenet_attached_moment", family="solver",
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=20, d_1=10, d_2=10, T=0.2, eta=0.3, kappa=1.0)),
+         solver=dict(HJB, detach_forward=False, loss_method="moment", L=4, lr=0.002, seed=42, delta_t=0.01, K=96,
+                     u_l2_error_flag=False),
+         net=dict(kind="densenet", arch=[40, 40], seed=7), probe_times=[0.0, 0.1]),
+    dict(name="lqgc_d6_densenet_attached_cross_entropy", family="solver",
+         problem=dict(kind="LQGC", kwargs=dict(d=6, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),
+         solver=dict(HJB, detach_forward=False, loss_method="cross_entropy", L=4, lr=0.005, seed=42, delta_t=0.05, K=128,
+                     u_l2_error_flag=False),
+         net=dict(kind="densenet", arch=[24, 24], seed=7), probe_times=[0.0]),
     # approx_method='value_function' (solver.py:93-97, 334-339, 438-440): Z = sigma grad_x Y_n, extra loss sum_n (Y_n(X_n) - Y)^2
     dict(name="lqgc_d3_value_function", family="solver",
          problem=dict(kind="LQGC", kwargs=dict(d=3, off_diag=0.1, T=0.5, seed=42, delta_t=0.05)),

@@ -11,7 +11,10 @@ from conftest import load_golden
 from util_cases import flat_params, make_oracle, make_pkg_solver, orc, psp
 
 pytestmark = pytest.mark.gpu
-CASES = ["lqgc_d2_outer", "llgc_d100_densenet64_logvar", "llgc_d12_outer_moment", "dw_d20_densenet_nonadaptive", "lqgc_d6_densenet_variance"]
+CASES = ["lqgc_d2_outer", "llgc_d100_densenet64_logvar", "llgc_d12_outer_moment", "dw_d20_densenet_nonadaptive", "lqgc_d6_densenet_variance",
+         # gradients through the state path (the reference's default flags) and relative entropy: psp_dnet_adjoint_sweep
+         "lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "llgc_d12_outer_relative_entropy_detached",
+         "dw_d20_densenet_attached_moment", "lqgc_d6_densenet_attached_cross_entropy"]
 
 
 def dev():
@@ -28,7 +31,8 @@ def test_first_iteration_D_and_gradient_match_oracle(name):
     plan = model._native_plan
     ref = orc.hjb_train(oprob, ocfg, step_models=omodels, trace=True)
     tr = ref["traces"][0]
-    D, D_ref = plan.D.cpu(), tr["D"]
+    # relative entropy: the kernel's D is -(Zsum + g(X_N)) (include/psp.h)
+    D, D_ref = plan.D.cpu(), (-tr["Zsum_g"] if case["solver"]["loss_method"] == "relative_entropy" else tr["D"])
     assert float((D - D_ref).abs().max()) <= 2e-5 * max(1.0, float(D_ref.abs().max()))
     g, g_ref = plan.grad.cpu(), torch.cat([x.reshape(-1) for x in tr["grads"]])
     assert g.shape == g_ref.shape
@@ -149,6 +153,73 @@ def test_dense_shape_sweep_matches_oracle(mode, kind, d, H, K, dt, T, adaptive):
     assert float((g - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max()), (plan.d_pad, plan.H_pad)
     cond = float((tr["D"].double() ** 2).mean()) / max(abs(ref["loss_log"][0]), 1e-30)
     assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=min(1e-4, max(2e-5, 4 * 6e-8 * cond)))
+
+
+# (time_approx, problem kind, d, H, K, delta_t, T, loss): gradients through the state path on instances the hand-written
+# backward covers (d <= 128): padded shapes, ragged K, the two-launch column split, elementwise and dense drifts, running costs
+ATTACHED_SHAPES = [
+    ("outer", "LLGC", 3, 5, 37, 0.05, 0.2, "log-variance"),
+    ("outer", "LQGC", 17, 33, 16, 0.05, 0.05, "moment"),                  # N = 1; running + terminal quadratic costs
+    ("inner", "LLGC", 64, 64, 100, 0.05, 0.15, "log-variance"),           # exact (64, 64)
+    ("inner", "DoubleWell_multidim", 65, 30, 50, 0.05, 0.1, "log-variance"),   # -> (128, 32), drift Jacobian of the double well
+    ("outer", "LLGC", 100, 30, 200, 0.02, 0.1, "relative_entropy"),       # -> (112, 32): the bench instance, nu weights
+    ("inner", "LQGC", 100, 64, 40, 0.05, 0.1, "cross_entropy"),           # -> (112, 64): column-split backward, explicit wT
+    ("outer", "LLGC", 20, 30, 5000, 0.05, 0.15, "log-variance"),          # many workgroups (313 tiles)
+]
+
+
+@pytest.mark.parametrize("mode,kind,d,H,K,dt,T,loss", ATTACHED_SHAPES)
+def test_attached_shape_sweep_matches_oracle(mode, kind, d, H, K, dt, T, loss):
+    if kind == "DoubleWell_multidim":
+        kwargs = dict(d=d, d_1=d // 2, d_2=d - d // 2, T=T, eta=0.05, kappa=1.0)
+    elif kind == "LQGC":
+        kwargs = dict(d=d, off_diag=0.05, T=T, seed=42, delta_t=dt)
+    else:
+        kwargs = dict(d=d, off_diag=0.3 / d ** 0.5, T=T, seed=42)
+    solver = dict(loss_method=loss, time_approx=mode, adaptive_forward_process=True, detach_forward=False,
+                  early_stopping_time=None, L=1, lr=0.002, seed=42, delta_t=dt, K=K, u_l2_error_flag=False)
+    case = dict(name="asweep", family="solver", problem=dict(kind=kind, kwargs=kwargs), solver=solver)
+    if mode == "inner":
+        case["net"] = dict(kind="densenet", arch=[H, H], seed=5)
+    model = make_pkg_solver(case, dev(), backend="native", L=1)
+    oprob, ocfg, omodels = make_oracle(case, L=1)
+    if mode == "outer":
+        model.z_n = [psp.DenseNet(d_in=d, d_out=d, lr=0.002, arch=[H, H], seed=5 + n).to(dev()) for n in range(model.N)]
+        model.update_Phis()
+        z = [orc.DenseNetOracle(d, d, 0.002, arch=[H, H], seed=5 + n) for n in range(model.N)]
+        omodels = (z, omodels[1], omodels[2])
+    model.train()
+    assert model.plan_name == "native" and isinstance(model._native_plan, psp.plan_dense_native.DenseNativePlan)
+    plan = model._native_plan
+    assert plan.attached
+    ref = orc.hjb_train(oprob, ocfg, step_models=omodels, trace=True)
+    tr = ref["traces"][0]
+    D, D_ref = plan.D.cpu(), (-tr["Zsum_g"] if loss == "relative_entropy" else tr["D"])
+    assert float((D - D_ref).abs().max()) <= 2e-5 * max(1.0, float(D_ref.abs().max()))
+    g, g_ref = plan.grad.cpu(), torch.cat([x.reshape(-1) for x in tr["grads"]])
+    assert g.shape == g_ref.shape
+    err = float((g - g_ref).abs().max()) / float(g_ref.abs().max())
+    print("attached %s %s d=%d H=%d K=%d %s: gradient rel err %.1e" % (mode, kind, d, H, K, loss, err))
+    assert err <= 2e-4, (plan.d_pad, plan.H_pad, err)
+    cond = float((D_ref.double() ** 2).mean()) / max(abs(ref["loss_log"][0]), 1e-30)
+    assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=min(1e-4, max(2e-5, 4 * 6e-8 * cond)))
+
+
+def test_attached_outer_philox_is_deterministic_and_finite():
+    """K = 2^14, d = 40, N = 20, device noise, the reference's default flags: two runs agree bitwise, the gradient is finite."""
+    prob = psp.LLGC(d=40, off_diag=0.05, T=0.2, seed=42, device=dev())
+
+    def make():
+        return psp.Solver(name="big", problem=prob, loss_method="log-variance", time_approx="outer", L=2, lr=1e-3, seed=42,
+                          delta_t=0.01, K=1 << 14, adaptive_forward_process=True, detach_forward=False, u_l2_error_flag=False,
+                          verbose=False, device=dev(), backend="native", noise="philox")
+
+    a, b = make(), make()
+    a.train()
+    b.train()
+    assert a.plan_name == "native" and a._native_plan.attached
+    assert a.loss_log == b.loss_log and all(math.isfinite(v) for v in a.loss_log)
+    assert torch.equal(a._native_plan.grad, b._native_plan.grad) and bool(torch.isfinite(a._native_plan.grad).all())
 
 
 @pytest.mark.parametrize("name", ["llgc_d12_outer_moment", "lqgc_d6_densenet_variance", "lqgc_d2_outer",
