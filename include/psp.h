@@ -13,7 +13,8 @@
  *                 evaluation (psp_hjb_rollout_eval, utilities.py:287-359)
  *     psp_dnet_*  DenseNet controls (function_space.py:116-140): time_approx='outer' (one net per time step) and a
  *                 DenseNet(d+1 -> d) swapped into z_n; forward rollout AND hand-written parameter gradient
- *                 (psp_dnet_rollout_bwd; instances whose accumulators do not fit report bwd_supported = 0)
+ *                 (psp_dnet_rollout_bwd; instances whose accumulators do not fit report bwd_supported = 0);
+ *                 detach_forward False and relative_entropy through psp_dnet_adjoint_sweep
  *   GeneralSolver.train / EllipticSolver.train (solver.py:1001-1206, :628-826)
  *     psp_gen_*   diffusion / BSDE loss on unbounded, sphere and box domains, V = DenseNet(d+1 -> 1) / DenseNet(d -> 1)
  *   shared: psp_adam_step (per-net Adam, function_space.py:185), psp_allreduce + psp_comm_* (trajectory sharding over
@@ -356,7 +357,8 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
  * the net's sizes.  params = per_step ? N : 1 consecutive parameter sets in the DenseNet's registration order
  *     [W1 (di x H_real), b1, W2 ((di+H_real) x H_real), b2, W3 ((di+2 H_real) x d_real), b3],  di = d_real + time_input,
  * read with their real strides (no padded copy).  Problem vectors / matrices, x0 and supplied noise are padded to
- * base.d as for the other entry points.  relative_entropy and attached forward processes are not built here.
+ * base.d as for the other entry points.  Gradients through the state path and the relative-entropy loss run through
+ * psp_dnet_adjoint_sweep (below) on the instances with bwd_supported = 1.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct psp_dnet_config {
     psp_hjb_config base;
