@@ -149,6 +149,11 @@ int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out);
  *   XN_out   : optional (K_local, d) final states or NULL
  *   Y_out    : optional (K_local) Y_N (losses that need Y and g separately) or NULL
  *   fwd_partial: fwd_partial_bytes scratch
+ * Three kernels implement this call for the narrow family (d <= 112), chosen from the trajectory count of the launch so that
+ * the chip stays busy: one 16-trajectory tile per wave (hjb_fwd_kernel), a tile split over the eight waves of a workgroup
+ * when there are at most two tiles per CU (hjbs_fwd_kernel, K <= 8192 on 256 CUs), four trajectories per workgroup on
+ * v_mfma_f32_4x4x1 when there are at most CUs / 4 tiles (hjbq_fwd_kernel, K <= 1024).  Same Philox counters and path-store
+ * format; D agrees to summation order.  The environment variable PSP_FWD_VARIANT=1 / 2 / 3 forces one (tests, A/B timing).
  */
 int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const float* x0, int32_t x0_stride,
                         const float* y0, const float* xi, uint64_t seed, uint32_t iter, float* path,
