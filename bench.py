@@ -65,6 +65,8 @@ WORKLOADS = {
     # whole batch runs with its 57 GB path store resident
     "hjb_llgc_d200_Kglobal262144_N100_h64": dict(d=200, H=64, K_global=262144, T=1.0, dt=0.01, off_diag=0.1 / 200 ** 0.5),
     # BASELINE.json configs[4] shape: d=500, N=200 -- K per GPU cut to 16384 (path store 15 GB, no recompute)
+    "hjb_llgc_d256_K32768_N100_h64": dict(d=256, H=64, K=32768, T=1.0, dt=0.01, off_diag=0.1 / 256 ** 0.5),
+    "hjb_llgc_d128_K65536_N100_h64": dict(d=128, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.1 / 128 ** 0.5),
     "hjb_llgc_d500_K16384_N200_h64": dict(d=500, H=64, K=16384, T=2.0, dt=0.01, off_diag=0.1 / 500 ** 0.5),
     "hjb_llgc_d500_K16384_N200_h64_diag": dict(d=500, H=64, K=16384, T=2.0, dt=0.01, off_diag=0.0),
     # configs[4] at its per-GPU share of the 8-GPU job (K = 1048576 / 8) and at its full size on ONE GPU: the path store

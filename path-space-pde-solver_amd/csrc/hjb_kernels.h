@@ -15,6 +15,7 @@
 // fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision), which is what lets
 // the loss match the reference's fp32 CPU path to ~1e-6.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -72,6 +73,15 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N - 1 (indices usable as template arguments / immediates)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // In-kernel phase stamps (diagnostic build only; the shipped kernels execute none of this).
 #ifdef PSP_STAMPS
@@ -1448,6 +1458,7 @@ struct HjbInstance {
     hipError_t (*launch_fwd_bf16)(const HjbArgs&, int grid, int block, hipStream_t);   // control net on bf16 MFMA (null: not built)
     int (*quad_lds_bytes)();         // hjbq_kernels.h: four trajectories per workgroup for the smallest K (null: not built)
     hipError_t (*launch_fwd_quad)(const HjbArgs&, int grid, hipStream_t);
+    int bwd2_one_per_cu;             // wide family: 1 when launch_bwd2 is the 8-wave hjbw_bwd2_kernel (one workgroup per CU)
 };
 
 template <int D, int H>

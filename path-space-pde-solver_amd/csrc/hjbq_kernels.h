@@ -18,8 +18,6 @@
 // Same algebra, reference lines, Philox counters and path-store format as hjb_fwd_kernel / hjbs_fwd_kernel (the backward
 // kernels are unchanged: a quad writes its four columns of the 16-trajectory block); summation orders differ by a few ulp.
 #pragma once
-#include <type_traits>
-
 #include "hjb_kernels.h"
 
 namespace psp {
@@ -45,13 +43,6 @@ struct GeoQ {
                          lds_floats = fXi + 2 * XIB;
 };
 
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 // acc[i] (lane (blk, c)) += act[lane (KK, i)] * w[lane (blk, c)]
 template <int KK>
 __device__ __forceinline__ f32x4 mfma4(float act, float w, f32x4 acc) {

@@ -916,13 +916,303 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const
     }
 }
 
+// =======================================================================================
+// Role-specialised backward for the wide family, d <= 256 (the design of hjb_bwd2_kernel; round 2).
+// hjbw_bwd_kernel lets every wave run every phase (two 4-wave workgroups per CU): at d = 200 it reaches 57 % of the
+// matrix-pipe time of its 752 MFMAs per tile-step, as hjb_bwd_kernel did at d = 100 before it was split into roles.  Here
+// one 8-wave workgroup per CU; rounds of four sample blocks; one barrier per round; double-buffered exchange:
+//   * producers (waves 0-3), one block each:  G = w sqrt(dt) xi from the stored image (T layout, next round's image
+//     requested a round ahead),  dz2 = (W3^T G)(1 - h2^2) as a register-chained product against the W3^T table in LDS;
+//     the dz2 k-step image and the block's 16 trajectory weights go to the exchange buffer of the NEXT round; db3 / db2 are
+//     element-wise running sums.  G itself is NOT exchanged (the panels of a d = 200 round would be 100 KB of LDS):
+//   * consumers (waves 4-7), wave ib owns hidden block ib of every weight-gradient tile row (8 DB + 16 accumulator
+//     registers): per block  dz1 = (dz2^T W2[:, ib])(1 - h1^2)  as the transposed product (W2's block in 16 registers),
+//     dW3 += xi^T (w h2)  with the xi tiles read feature-on-lane straight from the path store -- the sample weight moves
+//     to the h2 operand, four multiplies per block --,  dW2 += dz2^T h1,  dW1 += dz1^T X_n.  The 2 DB streamed tiles of a
+//     block (xi, then X_n) run through ONE register ring that continues across block and round boundaries (the store is an
+//     input: the addresses of the next round are known), requested RD - 1 tiles before their four MFMAs issue.
+// Same flush layout and reduction as hjb_bwd2_kernel; parity: tests/test_gpu_wide_family.py, test_gpu_full_size.py.
+// =======================================================================================
+template <int D, int H>
+struct GeoB2 {
+    using G = Geo<D, H>;
+    static constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
+    static constexpr int oWts = 4 * HB * 64, EXQ = oWts + 64;           // per block: dz2 k-step image, 16 trajectory weights
+    static constexpr int bufs = HB * KSD * 64, lds_floats = bufs + 2 * 4 * EXQ;
+    static constexpr int RD = 8;                                        // ring depth (streamed 16-feature tiles in flight); a round is
+    static_assert((8 * DB) % RD == 0, "ring slots must line up across rounds");   // 8 DB tiles, so slot = tile % RD carries over
+    static constexpr int RS = 16 * DB + 16 * HB;                        // per-producer bias-sum slots
+    static_assert(4 * RS <= 2 * 4 * EXQ, "bias sums reuse the exchange area");
+};
+
+template <int D, int H>
+__global__ __launch_bounds__(512) void hjbw_bwd2_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    using B2 = GeoB2<D, H>;
+    constexpr int DB = B2::DB, HB = B2::HB, KSD = B2::KSD, KSH = B2::KSH, EXQ = B2::EXQ, RD = B2::RD, RS = B2::RS;
+    static_assert(HB == 4, "one consumer wave per hidden block");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const bool producer = wave < 4;
+    const int sub = wave & 3;
+    const float* __restrict__ P = a.params;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    stage_aop(lds, HB, KSD, tid, nthr, [&](int row, int col) {          // W3^T as A-operand table (producers)
+        return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+    __syncthreads();
+    float* bufs = lds + B2::bufs;                     // [2 buffers][4 blocks][EXQ]
+
+    const double invK = 1.0 / (double)a.K_global;
+    const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
+    const float coef = (float)(2.0 * invK);
+    const float sqdt = a.sqdt, dt = a.dt;
+    const long long nblk = (long long)a.N * a.ntile16;
+    const long long nround = (nblk + 3) / 4;
+    const int R = (int)((nround - blockIdx.x + gridDim.x - 1) / gridDim.x);   // rounds of this workgroup (>= 1)
+
+    if (producer) {
+        // ================================================================================ producers
+        f32x4 sG[DB], sZ2[HB];
+#pragma unroll
+        for (int b = 0; b < DB; ++b) sG[b] = zero4;
+#pragma unroll
+        for (int m = 0; m < HB; ++m) sZ2[m] = zero4;
+        auto own_block = [&](int it2) __attribute__((always_inline)) {
+            const long long b0 = ((long long)blockIdx.x + (long long)it2 * gridDim.x) * 4 + sub;
+            return b0 < nblk ? b0 : -1LL;
+        };
+        f32x4 xin[DB];
+        float dkn;
+        {
+            const long long b0 = own_block(0);
+            const long long blk = b0 >= 0 ? b0 : nblk - 1;
+            const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+            const int k0 = (int)(blk % a.ntile16) * 16 + j;
+            dkn = a.D[k0 < a.K_local ? k0 : 0];
+#pragma unroll
+            for (int b = 0; b < DB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xin[b][r] = pb[G::pXi + (4 * b + r) * 64];
+        }
+        for (int it = 0; it <= R; ++it) {
+            if (it < R) {
+                const long long blk0 = own_block(it);
+                const bool bvalid = blk0 >= 0;
+                const long long blk = bvalid ? blk0 : nblk - 1;
+                const int t16 = (int)(blk % a.ntile16);
+                const int k = t16 * 16 + j;
+                const bool kvalid = bvalid && k < a.K_local;
+                const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+                float* ex = bufs + ((it & 1) * 4 + sub) * EXQ;
+                const float dk = dkn;                 // LOSS_WEIGHTS: the caller supplies w_k = dLoss/dY_k directly in D
+                const float wk = kvalid ? (a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)) : 0.f;
+                const float wks = wk * sqdt;
+                f32x4 Gt[DB];
+#pragma unroll
+                for (int b = 0; b < DB; ++b) {
+                    Gt[b] = wks * xin[b];             // adaptive: the (Z + c) dt term cancels; else the image holds xi + sqrt(dt) Z
+                    sG[b] += Gt[b];
+                }
+                f32x4 h2[HB];
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
+                {
+                    const long long n0 = own_block(it + 1);
+                    const long long nblk1 = n0 >= 0 ? n0 : nblk - 1;
+                    const float* pn = a.path + (size_t)nblk1 * (size_t)G::PB + lane;
+                    const int k1 = (int)(nblk1 % a.ntile16) * 16 + j;
+                    dkn = a.D[k1 < a.K_local ? k1 : 0];
+#pragma unroll
+                    for (int b = 0; b < DB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xin[b][r] = pn[G::pXi + (4 * b + r) * 64];
+                }
+                if (q == 0) ex[B2::oWts + j] = wks;   // the consumers weight their h2 operand with it
+                f32x4 dz2[HB];
+#pragma unroll
+                for (int m = 0; m < HB; ++m) dz2[m] = zero4;
+                gemm_T<HB, KSD, DB>(dz2, lds, Gt, lane);
+#pragma unroll
+                for (int m = 0; m < HB; ++m) { dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]); sZ2[m] += dz2[m]; }
+#pragma unroll
+                for (int ks = 0; ks < 4 * HB; ++ks) ex[ks * 64 + lane] = dz2[ks >> 2][ks & 3];
+            }
+            __syncthreads();                              // swap the exchange buffers (pairs with the consumer loop)
+        }
+        float* red = bufs + sub * RS;                     // bias sums -> LDS (the exchange area is free after the last barrier)
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = jsumf(sG[b][r]);
+                if (j == 0) red[16 * b + 4 * r + q] = v;
+            }
+#pragma unroll
+        for (int m = 0; m < HB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v2 = jsumf(sZ2[m][r]);
+                if (j == 0) red[16 * DB + 16 * m + 4 * r + q] = v2;
+            }
+        __syncthreads();                                  // pairs with the consumers' barrier before the bias write-out
+        return;
+    }
+    // ==================================================================================== consumers
+    const int ib = sub;                                   // hidden block of this wave
+    f32x4 acc3[DB], acc1[DB], acc2[HB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b) { acc3[b] = zero4; acc1[b] = zero4; }
+#pragma unroll
+    for (int m = 0; m < HB; ++m) acc2[m] = zero4;
+    f32x4 bs1 = zero4, bt1 = zero4;                       // element-wise partial sums of the dz1 tiles (db1, time column)
+    float w2b[KSH];                                       // B operands of the dz1 product: W2[4 ks + q][16 ib + j]
+#pragma unroll
+    for (int ks = 0; ks < KSH; ++ks) {
+        const int o = 4 * ks + q, i = 16 * ib + j;
+        w2b[ks] = (o < H && i < H) ? P[G::oW2 + o * H + i] : 0.f;
+    }
+    const int nblk_i = (int)nblk;                         // N * ntile16 < 2^31 is checked by the host
+    auto blk_at = [&](long long c0) __attribute__((always_inline)) {
+        const int c = (c0 < (long long)nblk_i) ? (int)c0 : nblk_i - 1;
+        return __builtin_amdgcn_readfirstlane(c);
+    };
+    typedef const __attribute__((address_space(1))) float* gptr_t;
+    const unsigned lofsU = (unsigned)image_lane_offset_F(lane);
+    auto get_F = [&](int blk, int ofs) __attribute__((always_inline)) {
+        gptr_t base = (gptr_t)sgpr_block_addr(a.path, (unsigned long long)blk, (unsigned)G::PB, (unsigned)ofs);
+        return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + lofsU);
+    };
+    constexpr int NI = 2 * DB;                            // streamed tiles of a block: xi tiles 0..DB-1, then X tiles 0..DB-1
+    f32x4 st[RD];                                         // the ring
+    f32x4 oh1[2], oh2[2];                                 // h1 / h2 tiles (hidden block ib) of the current and the next block
+    int bb[5];                                            // blocks of the round, and the first block of the next round
+    auto item_load = [&](auto gi) __attribute__((always_inline)) {     // streamed tile number gi of the round (4 NI and beyond: next round)
+        constexpr int g = decltype(gi)::value, sb = g / NI, itm = g % NI;
+        static_assert(sb <= 4, "ring reaches at most into the next round's first block");
+        st[g % RD] = get_F(bb[sb], itm < DB ? G::pXi + itm * 256 : G::pX + (itm - DB) * 256);
+    };
+    const int rb0 = blockIdx.x * 4;
+    bb[0] = blk_at(rb0);
+    static_for<0, RD - 1>([&](auto gi) { item_load(gi); });             // (only bb[0] is needed: RD - 1 <= NI)
+    static_assert(RD - 1 <= NI, "prologue stays inside the first block");
+    oh1[0] = get_F(bb[0], G::pH1 + ib * 256);
+    oh2[0] = get_F(bb[0], G::pH2 + ib * 256);
+    __syncthreads();                                      // pairs with producer iteration 0
+    for (int it = 1; it <= R; ++it) {
+        const int rb = (blockIdx.x + (it - 1) * gridDim.x) * 4;
+        const float* exch = bufs + ((it - 1) & 1) * 4 * EXQ;
+        bb[0] = blk_at(rb); bb[1] = blk_at((long long)rb + 1); bb[2] = blk_at((long long)rb + 2); bb[3] = blk_at((long long)rb + 3);
+        bb[4] = blk_at((long long)rb + 4LL * gridDim.x);
+        static_for<0, 4>([&](auto sbc) {
+            constexpr int sb = decltype(sbc)::value, cur = sb & 1;
+            const float* ex = exch + sb * EXQ;
+            // block prologue: LDS operands of this block, h1 / h2 tiles of the next one
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(ex + B2::oWts + 4 * q);    // weights of the lane's samples 4 q' .. 4 q' + 3
+            f32x4 a2[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) a2[m] = tile_get(ex + m * 256, lane);
+            float azk[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) azk[i] = ex[i * 64 + lane];
+            oh1[cur ^ 1] = get_F(bb[sb + 1], G::pH1 + ib * 256);
+            oh2[cur ^ 1] = get_F(bb[sb + 1], G::pH2 + ib * 256);
+            const f32x4 h2w = oh2[cur] * w4;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7" ::: "memory");         // (the tied MFMAs below are inline asm: no hazard tracking for h2w)
+            // ---- layer 3: dW3[:, ib] += xi^T (w h2), with the dz1 product spread over the same slots
+            f32x4 dzt = zero4;
+            static_for<0, DB>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, g = sb * NI + i;
+                item_load(std::integral_constant<int, g + RD - 1>{});
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mfma16_inplace(acc3[i], st[g % RD][r], h2w[r]);
+#pragma unroll
+                for (int c = 0; c < KSH; ++c) {                       // dz1 product, spread evenly over the DB slots
+                    if (c * DB / KSH == i) {
+                        dzt = mfma16(azk[c & 3], w2b[c], dzt);
+                        if (c + 4 < KSH) azk[c & 3] = ex[(c + 4) * 64 + lane];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            const float tn = (float)(bb[sb] / a.ntile16) * dt;
+            const f32x4 a1 = dzt * (1.0f - oh1[cur] * oh1[cur]);
+            bs1 += a1;
+            bt1 += tn * a1;
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- layer 2: dW2[:, ib] += dz2^T h1 (the dz1 tile settles meanwhile), layer 1: dW1[ib, :] += dz1^T X_n
+#pragma unroll
+            for (int m = 0; m < HB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mfma16_inplace(acc2[m], a2[m][r], oh1[cur][r]);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, DB>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, g = sb * NI + DB + i;
+                item_load(std::integral_constant<int, g + RD - 1>{});
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mfma16_inplace(acc1[i], a1[r], st[g % RD][r]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        // the ring now holds the first RD - 1 tiles of the next round's first block; its h tiles sit in oh1[0] / oh2[0]
+        __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
+    }
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // matrix-pipe results settle before VALU / stores read them
+    // ---- flush: same mapping as hjb_bwd2_kernel (tile rows = 16 ob + 4 qq + rr, columns = 16 ib + col)
+    float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
+    const int col = lane & 15, qq = lane >> 4;
+#pragma unroll
+    for (int ob = 0; ob < DB; ++ob)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int o3 = 16 * ob + 4 * qq + rr, i3 = 16 * ib + col;
+            if (o3 < D && i3 < H) gp[G::oW3 + o3 * H + i3] = acc3[ob][rr];
+            const int o1 = 16 * ib + 4 * qq + rr, i1 = 16 * ob + col;
+            if (o1 < H && i1 < D) gp[G::oW1 + o1 * (D + 1) + 1 + i1] = acc1[ob][rr];
+        }
+#pragma unroll
+    for (int ob = 0; ob < HB; ++ob)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int o2 = 16 * ob + 4 * qq + rr, i2 = 16 * ib + col;
+            if (o2 < H && i2 < H) gp[G::oW2 + o2 * H + i2] = acc2[ob][rr];
+        }
+    {
+        const float v1 = qsum(hsum4(bs1)), vt = qsum(hsum4(bt1));
+        const int f = 16 * ib + col;
+        if (qq == 0 && f < H) {
+            gp[G::ob1 + f] = v1;
+            gp[G::oW1 + f * (D + 1)] = vt;
+        }
+    }
+    __syncthreads();                                      // pairs with the producers' barrier after their LDS write
+    {
+        const float* red = bufs;
+        const int ct = tid - 256;
+        for (int f = ct; f < D; f += 256)
+            gp[G::ob3 + f] = (red[f] + red[RS + f]) + (red[2 * RS + f] + red[3 * RS + f]);
+        for (int f = ct; f < H; f += 256) {
+            const float* r2 = red + 16 * DB + f;
+            gp[G::ob2 + f] = (r2[0] + r2[RS]) + (r2[2 * RS] + r2[3 * RS]);
+        }
+    }
+}
+
 template <int D, int H>
 struct HjbwLaunch {
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     static int fwd_lds(int, int) { return W::fwd_lds_floats * 4; }
     static int bwd_lds(int) { return W::bwd_lds_floats * 4; }
-    static int bwd2_lds() { return W::bwd_lds_floats * 4; }
+    static int bwd2_lds() {
+        return ((D <= 256) && (GeoB2<D, H>::lds_floats * 4 <= 160 * 1024) && (G::HB == 4)) ? GeoB2<D, H>::lds_floats * 4 : W::bwd_lds_floats * 4;
+    }
     static hipError_t tables(const HjbArgs& a, int backward, hipStream_t s) {
         hipLaunchKernelGGL((hjbw_tables_kernel<D, H>), dim3(256), dim3(256), 0, s, a, backward);
         return hipGetLastError();
@@ -945,7 +1235,17 @@ struct HjbwLaunch {
         return hipGetLastError();
     }
     static hipError_t bwd(const HjbArgs&, int, int, hipStream_t) { return hipErrorNotSupported; }
+    // d <= 256: the role-specialised kernel (8 waves, W3^T staged in LDS from the parameters: no table pass), if its LDS fits
+    static constexpr bool kRoles = (D <= 256) && (GeoB2<D, H>::lds_floats * 4 <= 160 * 1024) && (G::HB == 4);
     static hipError_t bwd2(const HjbArgs& a, int grid, hipStream_t s) {
+        if constexpr (kRoles) {
+            const int bytes = GeoB2<D, H>::lds_floats * 4;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_bwd2_kernel<D, H>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((hjbw_bwd2_kernel<D, H>), dim3(grid), dim3(512), bytes, s, a);
+            return hipGetLastError();
+        }
         hipError_t e = tables(a, 1, s);
         if (e != hipSuccess) return e;
         const int bytes = W::bwd_lds_floats * 4;
@@ -969,6 +1269,7 @@ struct HjbwLaunch {
         HjbInstance r{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::PB, &bwd2_lds, &bwd2};
         r.launch_adj = &adj;
         r.wide = 1;
+        r.bwd2_one_per_cu = kRoles ? 1 : 0;
         r.fwd_table_floats = W::fwd_table_floats;
         r.bwd_table_floats = W::bwd_table_floats;
         return r;

@@ -175,7 +175,7 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
         return fail(-3, "backward kernel staging does not fit the 160 KiB LDS for this (d,H)");
     p->bwd_waves = (p->bwd_specialised && !p->inst.wide) ? 8 : 4;
     long long g = nround;
-    const long long gmax = (p->bwd_specialised && !(p->inst.wide && c->d <= 256)) ? cus : 2LL * cus;   // wide, d <= 256: two per CU
+    const long long gmax = (p->bwd_specialised && !(p->inst.wide && c->d <= 256 && !p->inst.bwd2_one_per_cu)) ? cus : 2LL * cus;   // hjbw_bwd_kernel, d <= 256: two per CU
     if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     p->bwd_grid = (int)g;
