@@ -129,7 +129,10 @@ def issued_mfma_per_tile_step(d_pad, H_pad, dense, family, bf16_mlp=False):
     ks_h = 16 if family == 2 else _cdiv(H_pad, 4)
     net = ks_d * HB + ks_h * HB + ks_h * DB
     sde = 2 * ks_d * DB if dense else 0
-    bwd = 4 * (DB * HB + HB * HB + HB * DB) + ks_d * HB + ks_h * HB
+    # backward: the wide family's role-specialised kernel (d <= 256, hjbw_bwd2_kernel) contracts over the real k-steps like the
+    # narrow one; hjbw_bwd_kernel (d > 256) over whole 16-blocks
+    ks_db = _cdiv(d_pad, 4) if (family == 2 and d_pad <= 256) else ks_d
+    bwd = 4 * (DB * HB + HB * HB + HB * DB) + ks_db * HB + ks_h * HB
     if bf16_mlp:                                                       # 16x16x32: one k-step spans 32 features
         net_bf = _cdiv(d_pad, 32) * HB + _cdiv(H_pad, 32) * HB + _cdiv(H_pad, 32) * DB
         return sde, net_bf, bwd
@@ -503,7 +506,7 @@ def main():
         quad = plan.family != 2 and 4 * ntile <= cus and not bf16_mlp and os.environ.get("PSP_FWD_VARIANT") in (None, "3")
         fwd_name = "hjbw_fwd_kernel" if plan.family == 2 else (
             "hjbq_fwd_kernel" if quad else ("hjbs_fwd_kernel" if ntile <= 2 * cus else "hjb_fwd_kernel"))
-        bwd_name = "hjbw_bwd_kernel" if plan.family == 2 else "hjb_bwd2_kernel"
+        bwd_name = ("hjbw_bwd2_kernel" if plan.d_pad <= 256 else "hjbw_bwd_kernel") if plan.family == 2 else "hjb_bwd2_kernel"
         issued = issued_mfma_per_tile_step(plan.d_pad, plan.H_pad, dense, plan.family, bf16_mlp)
         if quad:
             issued = (issued_mfma_quad_kernel(plan.d_pad, plan.H_pad, dense), 0, issued[2])

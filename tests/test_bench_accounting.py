@@ -21,7 +21,7 @@ def _traffic():
 CASES = {
     "hjb_llgc_d100_K65536_N100_h64": (100, 64, True, 1, "hjb_fwd_kernel", "hjb_bwd2_kernel"),
     "hjb_llgc_d100_K1024_N50_h64": (100, 64, True, 1, "hjbq_fwd_kernel", "hjb_bwd2_kernel"),
-    "hjb_llgc_d200_K32768_N100_h64": (200, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd_kernel"),
+    "hjb_llgc_d200_K32768_N100_h64": (200, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd2_kernel"),
     "hjb_llgc_d500_K16384_N200_h64": (500, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd_kernel"),
 }
 
