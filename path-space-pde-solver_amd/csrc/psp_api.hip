@@ -325,23 +325,38 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
 }
 
 // Launch-bound sizes (graph replay): partial gradients -> gradient -> Adam -> iteration state, ONE launch instead of three.
-// Every thread owns one parameter: fixed-order sum of the workgroup partials (as reduce_grad_kernel), the Adam update of
+// Per parameter: fixed-order sum of the workgroup partials (reduce_partials_8way, as reduce_grad_kernel), the Adam update of
 // adam_dev_kernel with the bias corrections of the CURRENT state, then the last workgroup to finish advances the state
 // (every other workgroup has read it before its ticket).  grad_out still receives the gradient (diagnostics, tests).
+// Fixed-order sum over the workgroup partials of parameter i, spread over EIGHT threads (slice u sums the workgroups
+// w = u (mod 8) in increasing order, the slices meet in LDS as ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7))): the same grouping -- and
+// the same bits -- as one thread with eight accumulators, but nwg / 8 dependent loads deep instead of nwg (256 partials of a
+// 17 k-parameter net took 12.7 us, a fifteenth of the K = 1024 iteration).  blockDim = (32 parameters) x (8 slices).
+__device__ __forceinline__ float reduce_partials_8way(const float* __restrict__ part, int nwg, int P, int i, float* sh) {
+    const int tx = threadIdx.x & 31, u = threadIdx.x >> 5;
+    float s = 0.f;
+    if (i < P) {
+        int w = u;
+        for (; w + 24 < nwg; w += 32) {                        // four loads in flight
+            const float a0 = part[(size_t)w * P + i], a1 = part[(size_t)(w + 8) * P + i];
+            const float a2 = part[(size_t)(w + 16) * P + i], a3 = part[(size_t)(w + 24) * P + i];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; w < nwg; w += 8) s += part[(size_t)w * P + i];
+    }
+    sh[u * 32 + tx] = s;
+    __syncthreads();
+    return ((sh[tx] + sh[32 + tx]) + (sh[64 + tx] + sh[96 + tx])) + ((sh[128 + tx] + sh[160 + tx]) + (sh[192 + tx] + sh[224 + tx]));
+}
+
 __global__ void reduce_grad_adam_advance_kernel(const float* __restrict__ part, int nwg, int P, float* __restrict__ grad_out,
                                                 float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                 psp_iter_state* st, unsigned int* ticket, float lr, float b1, float b2, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float sh[256];
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31);
     const double b1p = st->beta1_pow, b2p = st->beta2_pow;
-    if (i < P) {
-        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int w = 0;
-        for (; w + 8 <= nwg; w += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(w + u) * P + i];
-        }
-        for (int u = 0; w < nwg; ++w, ++u) s[u] += part[(size_t)w * P + i];
-        const float gi = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    const float gi = reduce_partials_8way(part, nwg, P, i, sh);
+    if (i < P && threadIdx.x < 32) {
         grad_out[i] = gi;
         const float step_size = (float)((double)lr / (1.0 - b1p));
         const float bc2_sqrt = (float)sqrt(1.0 - b2p);
@@ -363,18 +378,10 @@ __global__ void reduce_grad_adam_advance_kernel(const float* __restrict__ part, 
 }
 
 __global__ void reduce_grad_kernel(const float* __restrict__ part, int nwg, int P, float* __restrict__ out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    // eight independent partial sums (eight loads in flight instead of a 256-deep dependent chain), combined in a
-    // fixed order -> still bitwise reproducible
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int w = 0;
-    for (; w + 8 <= nwg; w += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(w + u) * P + p];
-    }
-    for (int u = 0; w < nwg; ++w, ++u) s[u] += part[(size_t)w * P + p];
-    out[p] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __shared__ float sh[256];
+    const int p = blockIdx.x * 32 + (threadIdx.x & 31);
+    const float g = reduce_partials_8way(part, nwg, P, p, sh);
+    if (p < P && threadIdx.x < 32) out[p] = g;
 }
 
 // torch.optim.Adam single-tensor semantics (torch/optim/adam.py, _single_tensor_adam)
@@ -795,7 +802,7 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
                                      : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");
     const int P = p.inst.n_params;
-    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                        grad_partial, p.bwd_grid, P, grad_out);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
@@ -820,7 +827,7 @@ int psp_hjb_rollout_bwd_step(const psp_hjb_config* cfg, float* params, const flo
                                      : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");
     const int P = p.inst.n_params;
-    hipLaunchKernelGGL(reduce_grad_adam_advance_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, grad_partial,
+    hipLaunchKernelGGL(reduce_grad_adam_advance_kernel, dim3((P + 31) / 32), dim3(256), 0, (hipStream_t)stream, grad_partial,
                        p.bwd_grid, P, grad_out, params, exp_avg, exp_avg_sq, dev_state, ticket, lr, beta1, beta2, eps);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_grad_adam_advance_kernel launch");
@@ -925,7 +932,7 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
                                        : p.inst.launch_bwd(a, p.bwd_grid, 256, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "gen_bwd_kernel launch");
     const int P = p.inst.n_params;
-    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                        grad_partial, p.bwd_grid, P, grad_out);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
