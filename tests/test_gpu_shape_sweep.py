@@ -26,6 +26,12 @@ SHAPES = [
     ("LLGC", 112, [20, 20], 48, True),
     ("LLGC", 200, [64, 64], 80, False),     # wide family with the adjoint sweep (hjbw_adj_kernel)
     ("LQGC", 130, [40, 40], 40, False),     # -> wide (192, 64), running cost + quadratic terminal cost, attached
+    # hjbw_bwd2_kernel (role-specialised wide backward, d <= 256): several rounds per workgroup, so that the consumers' register
+    # ring runs through block AND round boundaries, on every instance it is built for
+    ("LLGC", 120, [64, 64], 9000, True),    # -> wide (128, 64)
+    ("LQGC", 180, [64, 64], 8200, True),    # -> wide (192, 64), ragged last tile
+    ("LLGC", 200, [64, 64], 9000, True),    # (200, 64)
+    ("LLGC", 250, [50, 50], 9000, True),    # -> wide (256, 64)
     ("LLGC", 500, [64, 64], 36, False),      # (112, 32) does not fit the LDS with dense A and B -> wide family (128, 64)
 ]
 
