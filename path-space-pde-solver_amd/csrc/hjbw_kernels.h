@@ -236,7 +236,8 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
 // =======================================================================================
 // LOGU: the u_L2 log of solver.py:491-494 (psp_hjb_config.u_ref); a separate instantiation because at d = 500 the kernel
 // sits on the 512-register limit and two more live accumulators cost the ordinary path 8 % (measured)
-template <int D, int H, bool LOGU = false>
+// FAST: Philox noise and no time-feature table, decided at launch (no conditional loads and joins in the time loop; training)
+template <int D, int H, bool LOGU = false, bool FAST = false>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const HjbArgs a) {
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
 #pragma unroll 1
         for (int n = 0; n < a.N; ++n) {
             PSP_STAMP(ws0);
-            const float tn = a.tfeat ? a.tfeat[n] : (float)n * dt;
+            float tn = (float)n * dt;
+            if constexpr (!FAST) { if (a.tfeat) tn = a.tfeat[n]; }
             const f32x4* vecs = opaque(vecs0);         // re-read the small vectors each step (no hoisting)
             const int qn = opaque_i(q);                // ... and rebuild the per-block Philox counters (else 3 registers
                                                        // per state block are hoisted out of the step loop)
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
                 for (int m = 0; m < NB; ++m) {
                     const int b = 4 * g + m;
                     f32x4 xi;
-                    if (a.noise_mode == NOISE_PHILOX) {
+                    if (FAST || a.noise_mode == NOISE_PHILOX) {
                         xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + qn), iter_now, a.seed_lo, a.seed_hi);
                     } else {
                         const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
@@ -1226,6 +1228,13 @@ struct HjbwLaunch {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((hjbw_fwd_kernel<D, H, true>), dim3(grid), dim3(block), bytes, s, a);
+            return hipGetLastError();
+        }
+        if (a.noise_mode == NOISE_PHILOX && a.tfeat == nullptr) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((hjbw_fwd_kernel<D, H, false, true>), dim3(grid), dim3(block), bytes, s, a);
             return hipGetLastError();
         }
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, false>),
