@@ -18,6 +18,7 @@
         r.launch_fwd_bf16 = &psp::HjbLaunch<D_, H_>::fwd_bf16;                             \
         r.quad_lds_bytes = &psp::HjbqLaunch<D_, H_>::lds_bytes;                            \
         r.launch_fwd_quad = &psp::HjbqLaunch<D_, H_>::fwd;                                 \
+        r.launch_adj_quad = &psp::HjbqLaunch<D_, H_>::adj;                                 \
         return r;                                                                           \
     }
 PSP_DEFINE_(PSP_D, PSP_H)

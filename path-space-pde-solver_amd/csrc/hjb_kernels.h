@@ -1458,6 +1458,7 @@ struct HjbInstance {
     hipError_t (*launch_fwd_bf16)(const HjbArgs&, int grid, int block, hipStream_t);   // control net on bf16 MFMA (null: not built)
     int (*quad_lds_bytes)();         // hjbq_kernels.h: four trajectories per workgroup for the smallest K (null: not built)
     hipError_t (*launch_fwd_quad)(const HjbArgs&, int grid, hipStream_t);
+    hipError_t (*launch_adj_quad)(const HjbArgs&, int grid, hipStream_t);          // quad-trajectory adjoint sweep (same selection rule)
     int bwd2_one_per_cu;             // wide family: 1 when launch_bwd2 is the 8-wave hjbw_bwd2_kernel (one workgroup per CU)
 };
 

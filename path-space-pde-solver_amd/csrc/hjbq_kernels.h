@@ -460,6 +460,287 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
     }
 }
 
+// =======================================================================================
+// Quad-trajectory adjoint sweep (gradients through the state path at the smallest K): hjb_adj_kernel walks one
+// 16-trajectory tile per wave, 626 MFMAs per step on ONE SIMD -- at K = 1024 that is 64 waves and 0.42 ms of the 0.66 ms
+// iteration with the reference's default flags.  The recursion of hjba_kernels.h has the forward's shape with transposed
+// matrices,
+//     lambda' --B^T--> q,  gZ = coefW W - dt q  --W3^T--> (.)(1 - h2^2) = dz2 --W2^T--> (.)(1 - h1^2) = dz1 --W1x^T--> + lambda' + A^T lambda'
+// so it runs on the machinery of hjbq_fwd_kernel: four trajectories per workgroup, products split over eight waves along the
+// contraction index, partial products reduced by the owner lanes through LDS, four barriers per step.  The images of a step
+// (W, h2, h1, X_n: one dword per owner lane) are requested a step ahead.
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(512) void hjbq_adj_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    using Q = GeoQ<D, H>;
+    constexpr int NG = Q::NG, KO = Q::KO, KHo = Q::KHo, SD = Q::SD, RD = Q::RD, RH = Q::RH, W = Q::W;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = lane >> 2, tr = lane & 3;
+    const int wrow = lane;
+    const float* __restrict__ P = a.params;
+    const float dt = a.dt, sqdt = a.sqdt, rsq = 1.0f / a.sqdt;
+    const bool denseA = a.drift_kind == DRIFT_DENSE, denseB = a.sigma_kind == SIGMA_DENSE;
+
+    // ---- ownership as in hjbq_fwd_kernel
+    const int s = blk >> 2, r = blk & 3;
+    const int gam = wave + W * s;
+    const int fb = gam >> 2, fq = gam & 3;
+    const int f = 16 * fb + 4 * r + fq;
+    const bool gvalid = blk < KO && gam < NG;
+    const bool fvalid = gvalid && f < D;
+    const int fc = fvalid ? f : 0;
+    const int m = KHo * wave + blk;
+    const bool hslot = blk < KHo;
+    const bool mvalid = hslot && m < H;
+    const int mc = mvalid ? m : 0;
+    const float vdrf = (fvalid && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[fc] : 0.f;
+    const float vrunf = (fvalid && a.runcost_kind == RUN_DIAGQ) ? a.runcost[fc] : 0.f;
+    const float vtermf = fvalid ? a.term[fc] : 0.f;
+
+    // ---- TRANSPOSED weight slices as B operands: lane `wrow` of fragment (slab, owned input kk) holds M^T[row][kk-th input]
+    float w3Tq[KO], aTq[SD][KO], bTq[SD][KO], w2Tq[KHo], w1Tq[SD][KHo];
+    auto row_feature = [&](int rho, bool& valid) __attribute__((always_inline)) {
+        const int w = rho / KO, kk = rho - w * KO;
+        const int g = w + W * (kk >> 2);
+        const int fr = 16 * (g >> 2) + 4 * (kk & 3) + (g & 3);
+        valid = w < W && g < NG && fr < D;
+        return valid ? fr : 0;
+    };
+    bool rowok[SD];
+    int rowf[SD];
+#pragma unroll
+    for (int sl = 0; sl < SD; ++sl) rowf[sl] = row_feature(64 * sl + wrow, rowok[sl]);
+    constexpr int LSD = D | 1, LSH = H | 1;
+    auto stage = [&](const float* __restrict__ M, int R, int C, int gstride, int lstride) __attribute__((always_inline)) {
+        __syncthreads();
+        for (int idx = tid; idx < R * C; idx += 512) {
+            const int row = idx / C, col = idx - row * C;
+            lds[row * lstride + col] = M[row * gstride + col];
+        }
+        __syncthreads();
+    };
+    int fko[KO];
+    bool oko[KO];
+#pragma unroll
+    for (int kk = 0; kk < KO; ++kk) {
+        const int g = wave + W * (kk >> 2);
+        const int fk = 16 * (g >> 2) + 4 * (kk & 3) + (g & 3);
+        oko[kk] = g < NG && fk < D;
+        fko[kk] = oko[kk] ? fk : 0;
+    }
+    stage(P + G::oW3, D, H, H, LSH);                     // W3 (d x H): W3^T[m][f] = W3[f][m]
+#pragma unroll
+    for (int kk = 0; kk < KO; ++kk) {
+        const bool in = oko[kk] && wrow < H;
+        const float v = lds[fko[kk] * LSH + (in ? wrow : 0)];
+        w3Tq[kk] = in ? v : 0.f;
+    }
+#pragma unroll
+    for (int sl = 0; sl < SD; ++sl)
+#pragma unroll
+        for (int kk = 0; kk < KO; ++kk) { aTq[sl][kk] = 0.f; bTq[sl][kk] = 0.f; }
+    if (denseA) {
+        stage(a.drift, D, D, D, LSD);                    // (dt A)^T[row][f] = dt A[f][row]
+#pragma unroll
+        for (int sl = 0; sl < SD; ++sl)
+#pragma unroll
+            for (int kk = 0; kk < KO; ++kk) {
+                const bool in = oko[kk] && rowok[sl];
+                const float v = lds[fko[kk] * LSD + rowf[sl]];
+                aTq[sl][kk] = in ? dt * v : 0.f;
+            }
+    }
+    if (denseB) {
+        stage(a.sigma, D, D, D, LSD);                    // B^T[row][f] = B[f][row]
+#pragma unroll
+        for (int sl = 0; sl < SD; ++sl)
+#pragma unroll
+            for (int kk = 0; kk < KO; ++kk) {
+                const bool in = oko[kk] && rowok[sl];
+                const float v = lds[fko[kk] * LSD + rowf[sl]];
+                bTq[sl][kk] = in ? v : 0.f;
+            }
+    }
+    stage(P + G::oW2, H, H, H, LSH);                     // W2^T[m][mk] = W2[mk][m]
+#pragma unroll
+    for (int kk = 0; kk < KHo; ++kk) {
+        const int mk = KHo * wave + kk;
+        const bool in = mk < H && wrow < H;
+        const float v = lds[(mk < H ? mk : 0) * LSH + (in ? wrow : 0)];
+        w2Tq[kk] = in ? v : 0.f;
+    }
+    stage(P + G::oW1 + 1, H, D, D + 1, LSD);            // W1 without its time column: W1x^T[row][mk] = W1[mk][1 + row]
+#pragma unroll
+    for (int sl = 0; sl < SD; ++sl)
+#pragma unroll
+        for (int kk = 0; kk < KHo; ++kk) {
+            const int mk = KHo * wave + kk;
+            const bool in = mk < H && rowok[sl];
+            const float v = lds[(mk < H ? mk : 0) * LSD + rowf[sl]];
+            w1Tq[sl][kk] = in ? v : 0.f;
+        }
+    __syncthreads();                                     // the staging area becomes the partial-product buffers
+
+    const int t16 = blockIdx.x >> 2, j16 = 4 * (blockIdx.x & 3) + tr;
+    const int k = t16 * 16 + j16;
+    const bool kvalid = k < a.K_local;
+    const int offX = G::pX + (4 * fb + r) * 64 + 16 * fq + j16;
+    const int offXi = G::pXi + (4 * fb + r) * 64 + 16 * fq + j16;
+    const int offH = (4 * (m >> 4) + ((m >> 2) & 3)) * 64 + 16 * (m & 3) + j16;
+    const float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
+    const float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    const float coefW = (a.store_path == 3) ? nu * dt : mu * sqdt;
+    const float wf = (mu + nu) * dt;                     // weight of grad f(X_{n+1})
+    const float wT = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);      // weight of grad g(X_N) in lambda_N
+    const bool need_x = a.runcost_kind == RUN_DIAGQ || a.drift_kind == DRIFT_DWELL;
+
+    float* partU2 = lds + Q::pH1;                        // (the forward's buffers, same shapes)
+    float* partA = lds + Q::pDR;
+    float* partU1 = lds + Q::pH2;
+    float* partL = lds + Q::pZ;
+    float* partQ = lds + Q::pBV;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4* myU2 = reinterpret_cast<f32x4*>(partU2) + wave * RH + wrow;
+    f32x4* myU1 = reinterpret_cast<f32x4*>(partU1) + wave * RH + wrow;
+    f32x4* myA = reinterpret_cast<f32x4*>(partA) + wave * RD + wrow;
+    f32x4* myL = reinterpret_cast<f32x4*>(partL) + wave * RD + wrow;
+    f32x4* myQ = reinterpret_cast<f32x4*>(partQ) + wave * RD + wrow;
+    const int rdH = mc * 4 + tr, rdD = (KO * wave + (blk < KO ? blk : 0)) * 4 + tr;
+
+    // lambda_N = wT grad g(X_N);  X_N also serves grad f at the last step
+    float xn1 = (fvalid && kvalid) ? a.XN[(size_t)k * D + fc] : 0.f;
+    float lam;
+    {
+        float gg;
+        if (a.term_kind == TERM_LINEAR) gg = vtermf;
+        else if (a.term_kind == TERM_DIAGQ) gg = 2.0f * vtermf * xn1;
+        else gg = 2.0f * vtermf * (xn1 - 1.0f);
+        lam = fvalid ? wT * gg : 0.f;
+    }
+    // images of step n, requested during step n + 1 (one dword per owner lane and image)
+    auto blk_ptr = [&](int nn) __attribute__((always_inline)) { return a.path + ((size_t)nn * a.ntile16 + t16) * (size_t)G::PB; };
+    float wimg_n, xin_n = 0.f, h2_n, h1_n;
+    {
+        const float* pb = blk_ptr(a.N - 1);
+        wimg_n = pb[gvalid ? offXi : 0];
+        h2_n = pb[G::pH2 + (hslot ? offH : 0)];
+        h1_n = pb[G::pH1 + (hslot ? offH : 0)];
+        if (need_x) xin_n = pb[gvalid ? offX : 0];
+    }
+
+#pragma unroll 1
+    for (int n = a.N - 1; n >= 0; --n) {
+        float* pblk = blk_ptr(n);
+        const float wimg = gvalid ? wimg_n : 0.f, xin = gvalid ? xin_n : 0.f;
+        const float h2 = hslot ? h2_n : 0.f, h1 = hslot ? h1_n : 0.f;
+        {
+            const float* pb = blk_ptr(n > 0 ? n - 1 : 0);          // (step 0 re-reads its own block: unused)
+            wimg_n = pb[gvalid ? offXi : 0];
+            h2_n = pb[G::pH2 + (hslot ? offH : 0)];
+            h1_n = pb[G::pH1 + (hslot ? offH : 0)];
+            if (need_x) xin_n = pb[gvalid ? offX : 0];
+        }
+        // lambda' = lambda_{n+1} + (mu + nu) dt grad f(X_{n+1})
+        const float lamp = fvalid ? lam + (2.0f * wf) * (vrunf * xn1) : 0.f;
+        // ---- A: partial products of B^T lambda' and (dt A)^T lambda' over the own state features
+        {
+            f32x4 qp[SD][2], ap[SD][2];
+#pragma unroll
+            for (int sl = 0; sl < SD; ++sl) { qp[sl][0] = zero4; qp[sl][1] = zero4; ap[sl][0] = zero4; ap[sl][1] = zero4; }
+            if (denseB) {
+                static_for<0, KO>([&](auto kk) {
+#pragma unroll
+                    for (int sl = 0; sl < SD; ++sl)
+                        qp[sl][decltype(kk)::value & 1] =
+                            mfma4<decltype(kk)::value>(lamp, bTq[sl][decltype(kk)::value], qp[sl][decltype(kk)::value & 1]);
+                });
+#pragma unroll
+                for (int sl = 0; sl < SD; ++sl) myQ[64 * sl] = qp[sl][0] + qp[sl][1];
+            }
+            if (denseA) {
+                static_for<0, KO>([&](auto kk) {
+#pragma unroll
+                    for (int sl = 0; sl < SD; ++sl)
+                        ap[sl][decltype(kk)::value & 1] =
+                            mfma4<decltype(kk)::value>(lamp, aTq[sl][decltype(kk)::value], ap[sl][decltype(kk)::value & 1]);
+                });
+#pragma unroll
+                for (int sl = 0; sl < SD; ++sl) myA[64 * sl] = ap[sl][0] + ap[sl][1];
+            }
+        }
+        if (denseA || denseB) __syncthreads();
+        // ---- B: q = B^T lambda', gZ = coefW W - dt q (back into the xi slot as gZ / sqrt(dt)), partial products of W3^T gZ
+        float qv, drl = 0.f;
+        if (denseB) {
+            qv = 0.f;
+#pragma unroll
+            for (int p = 0; p < W; ++p) qv += partQ[p * RD * 4 + rdD];
+        } else if (a.sigma_kind == SIGMA_SCALE) {
+            qv = a.sigma_scale * lamp;
+        } else {
+            qv = lamp;
+        }
+        if (denseA) {
+#pragma unroll
+            for (int p = 0; p < W; ++p) drl += partA[p * RD * 4 + rdD];
+        }
+        const float gz = fvalid ? coefW * wimg - dt * qv : 0.f;
+        if (gvalid) pblk[offXi] = rsq * gz;
+        {
+            f32x4 ua = zero4, ub = zero4;
+            static_for<0, KO>([&](auto kk) {
+                if constexpr (decltype(kk)::value & 1) ub = mfma4<decltype(kk)::value>(gz, w3Tq[decltype(kk)::value], ub);
+                else ua = mfma4<decltype(kk)::value>(gz, w3Tq[decltype(kk)::value], ua);
+            });
+            *myU2 = ua + ub;
+        }
+        __syncthreads();
+        // ---- C: dz2 = (W3^T gZ)(1 - h2^2) for the own hidden units, partial products of W2^T dz2
+        {
+            float u2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < W; ++p) u2 += partU2[p * RH * 4 + rdH];
+            const float dz2 = mvalid ? u2 * (1.0f - h2 * h2) : 0.f;
+            f32x4 ua = zero4, ub = zero4;
+            static_for<0, KHo>([&](auto kk) {
+                if constexpr (decltype(kk)::value & 1) ub = mfma4<decltype(kk)::value>(dz2, w2Tq[decltype(kk)::value], ub);
+                else ua = mfma4<decltype(kk)::value>(dz2, w2Tq[decltype(kk)::value], ua);
+            });
+            *myU1 = ua + ub;
+        }
+        __syncthreads();
+        // ---- D: dz1 = (W2^T dz2)(1 - h1^2), partial products of W1x^T dz1
+        {
+            float u1 = 0.f;
+#pragma unroll
+            for (int p = 0; p < W; ++p) u1 += partU1[p * RH * 4 + rdH];
+            const float dz1 = mvalid ? u1 * (1.0f - h1 * h1) : 0.f;
+            f32x4 lp[SD];
+#pragma unroll
+            for (int sl = 0; sl < SD; ++sl) lp[sl] = zero4;
+            static_for<0, KHo>([&](auto kk) {
+#pragma unroll
+                for (int sl = 0; sl < SD; ++sl) lp[sl] = mfma4<decltype(kk)::value>(dz1, w1Tq[sl][decltype(kk)::value], lp[sl]);
+            });
+#pragma unroll
+            for (int sl = 0; sl < SD; ++sl) myL[64 * sl] = lp[sl];
+        }
+        __syncthreads();
+        // ---- E: lambda_n = lambda' + dt b'(X_n)^T lambda' + W1x^T dz1
+        float ln = lamp;
+#pragma unroll
+        for (int p = 0; p < W; ++p) ln += partL[p * RD * 4 + rdD];
+        if (denseA) ln += drl;
+        else if (a.drift_kind == DRIFT_DIAG) ln += dt * (vdrf * lamp);
+        else if (a.drift_kind == DRIFT_DWELL) ln -= dt * (4.0f * vdrf * ((3.0f * xin * xin - 1.0f) * lamp));   // b' = -4 kappa (3 x^2 - 1)
+        lam = fvalid ? ln : 0.f;
+        if (need_x) xn1 = xin;                           // X_n is X_{n+1} of the next (earlier) step
+    }
+}
+
 template <int D, int H>
 struct HjbqLaunch {
     static int lds_bytes() { return GeoQ<D, H>::fits ? GeoQ<D, H>::lds_floats * 4 : (1 << 30); }
@@ -471,6 +752,18 @@ struct HjbqLaunch {
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((hjbq_fwd_kernel<D, H, FAST>), dim3(grid), dim3(GeoQ<D, H>::NT), bytes, s, a);
         return hipGetLastError();
+    }
+    static hipError_t adj(const HjbArgs& a, int grid, hipStream_t s) {
+        if constexpr (GeoQ<D, H>::fits) {
+            const int bytes = lds_bytes();
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbq_adj_kernel<D, H>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((hjbq_adj_kernel<D, H>), dim3(grid), dim3(512), bytes, s, a);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
     }
     static hipError_t fwd(const HjbArgs& a, int grid, hipStream_t s) {
         if constexpr (GeoQ<D, H>::fits) {

@@ -851,6 +851,11 @@ int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float*
     // the wide family keeps its (transposed) operand tables where the forward kernel kept its own: behind the partial
     // sums of the forward scratch, whatever forward variant wrote them
     a.tables = reinterpret_cast<float*>(fwd_partial + 2 * (size_t)p.fwd_grid);
+    if (p.fwd_quad && p.inst.launch_adj_quad) {           // smallest K: four trajectories per workgroup (hjbq_adj_kernel)
+        hipError_t eq = p.inst.launch_adj_quad(a, 4 * p.ntile16, (hipStream_t)stream);
+        if (eq != hipSuccess) return fail_hip(eq, "hjbq_adj_kernel launch");
+        return 0;
+    }
     // one wave per 16-trajectory tile, like the forward kernels (the recursion is sequential in time)
     int fw = (p.ntile16 + n_cus() - 1) / n_cus();
     if (fw < 1) fw = 1;
