@@ -460,13 +460,14 @@ class HjbNativePlan:
     def _graph_wanted(self):
         """The iteration is captured into a hipGraph when it is launch-bound (at most two 16-trajectory tiles per CU, the
         regime of the feature-split forward kernel) and nothing in it needs a per-iteration host argument: on-device noise,
-        fixed X_0, a loss the kernels form themselves, one rank, no u_L2 log.  Solver(use_graph=True / False) overrides
+        fixed X_0, a loss the kernels form themselves (with or without the adjoint sweep of an attached forward process: its
+        trajectory weights are device arithmetic on D and the sums), one rank, no u_L2 log.  Solver(use_graph=True / False) overrides
         the size rule (never the eligibility)."""
         want = getattr(self.s, 'use_graph', 'auto')
         if want is False:
             return False
         ok = (self.world == 1 and self.noise == 'philox' and not self.s.random_X_0 and not self.generic_loss
-              and not self.attached and self.ul2 is None and self.ul2_gain is None and self.n_chunks == 1)
+              and self.ul2 is None and self.ul2_gain is None and self.n_chunks == 1)
         if not ok:
             return False
         if want is True:
@@ -491,12 +492,23 @@ class HjbNativePlan:
         y0_ptr = nat.ptr(self.y0_param) if self.learn_y0 else None
         seed = int(s.seed) & 0xFFFFFFFFFFFFFFFF
         nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.x0_vec), 0, y0_ptr, None, seed, 0,
-                                          nat.ptr(self.path), nat.ptr(self.D), None, None, nat.ptr(self.fwd_partial), st),
-                  'psp_hjb_rollout_fwd')
+                                          nat.ptr(self.path), nat.ptr(self.D), nat.ptr(self.XN_k) if self.attached else None,
+                                          None, nat.ptr(self.fwd_partial), st), 'psp_hjb_rollout_fwd')
         nat.check(lib.psp_hjb_terminal_reduce_loss(C.byref(cfg), nat.ptr(self.fwd_partial), nat.ptr(self.sums),
                                                    nat.ptr(loss_out), state, st), 'psp_hjb_terminal_reduce_loss')
         d_or_w, bcfg = self.D, cfg
-        if self.relent:                                  # detached relative entropy: weight sqrt(dt) / K on the Z image
+        if self.attached:
+            # trajectory weights of the adjoint sweep (plain iteration: same lines), sweep, backward with unit weights (w_bwd = 1)
+            if self.relent:
+                self.mu.zero_()
+                self.nu.fill_(1.0 / float(s.K))
+            else:
+                self.mu.copy_(sharding.loss_weights(self.D, self.sums, s.K, s.loss_method))
+            nat.check(lib.psp_hjb_adjoint_sweep(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.path), nat.ptr(self.XN_k),
+                                                nat.ptr(self.mu), nat.ptr(self.nu) if self.relent else None, None,
+                                                nat.ptr(self.fwd_partial), st), 'psp_hjb_adjoint_sweep')
+            d_or_w, bcfg = self.w_bwd, self._gcfg_w
+        elif self.relent:                                # detached relative entropy: weight sqrt(dt) / K on the Z image
             d_or_w, bcfg = self.w_bwd, self._gcfg_w
         lr, b1, b2, eps = self._graph_hyper
         if self.pad.identity and not self.learn_y0:
@@ -539,10 +551,10 @@ class HjbNativePlan:
             self._gticket = torch.zeros(1, dtype=torch.int32, device=self.dev)
             self._gcfg = nat.HjbConfig.from_buffer_copy(self.cfg)
             self._gcfg.iter_dev = nat.ptr(self._gstate)
-            if self.relent:
+            if self.relent or self.attached:
                 self._gcfg_w = nat.HjbConfig.from_buffer_copy(self._gcfg)
                 self._gcfg_w.loss_kind = nat.LOSS_WEIGHTS
-                self.w_bwd.fill_(float(self.cfg.sqrt_dt) / float(self.s.K))
+                self.w_bwd.fill_(1.0 if self.attached else float(self.cfg.sqrt_dt) / float(self.s.K))
             self._graph_state_upload(l)
             torch.cuda.synchronize(self.dev)
             g = torch.cuda.CUDAGraph()

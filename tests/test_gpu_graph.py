@@ -20,7 +20,10 @@ def dev():
 
 
 @pytest.mark.parametrize("name", ["llgc_d100_h64_logvar", "lqgc_d2_moment", "lqgc_d33_h50_logvar",
-                                  "llgc_d20_relative_entropy_detached", "dw_d10_logvar"])
+                                  "llgc_d20_relative_entropy_detached", "dw_d10_logvar",
+                                  # attached forward process (the reference's default flags): the adjoint sweep and its
+                                  # trajectory weights are part of the captured iteration
+                                  "llgc_d100_h64_attached_logvar", "dw_d10_attached_moment", "lqgc_d4_relative_entropy"])
 def test_graph_replay_equals_eager_iterations(name):
     case = load_golden(name)["case"]
     L = 7
