@@ -60,7 +60,7 @@ enum { PSP_LOSS_LOG_VARIANCE = 0, PSP_LOSS_MOMENT = 1, PSP_LOSS_WEIGHTS = 2, PSP
 enum { PSP_NOISE_SUPPLIED = 0, PSP_NOISE_PHILOX = 1 };
 
 /* arithmetic type of the matrix products (operands; accumulation is always fp32) */
-enum { PSP_MLP_FP32 = 0, PSP_MLP_BF16_FWD = 1, PSP_MLP_BF16 = 2 };
+enum { PSP_MLP_FP32 = 0, PSP_MLP_BF16_FWD = 1, PSP_MLP_BF16 = 2, PSP_MLP_F16X3 = 3 };
 
 /* POD description of one HJB rollout problem on one rank. */
 typedef struct psp_hjb_config {

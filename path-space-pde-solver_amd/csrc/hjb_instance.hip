@@ -16,6 +16,8 @@
         r.launch_fwd_split = &psp::HjbsLaunch<D_, H_>::fwd;                                \
         r.launch_adj = &psp::HjbaLaunch<D_, H_>::adj;                                      \
         r.launch_fwd_bf16 = &psp::HjbLaunch<D_, H_>::fwd_bf16;                             \
+        r.fwd_x3_lds_bytes = &psp::HjbLaunch<D_, H_>::fwd_x3_lds;                          \
+        r.launch_fwd_x3 = &psp::HjbLaunch<D_, H_>::fwd_x3;                                 \
         r.quad_lds_bytes = &psp::HjbqLaunch<D_, H_>::lds_bytes;                            \
         r.launch_fwd_quad = &psp::HjbqLaunch<D_, H_>::fwd;                                 \
         r.launch_adj_quad = &psp::HjbqLaunch<D_, H_>::adj;                                 \

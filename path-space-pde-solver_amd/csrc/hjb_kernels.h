@@ -295,6 +295,161 @@ __device__ __forceinline__ void gemm_Tb(f32x4 (&acc)[MB], const float* wlds, con
     }
 }
 
+// ---- fp32 products on the f16 matrix pipe: error-compensated split ("f16x3") ------------------------------------------
+// An fp32 MFMA runs at 1/16 of the f16 rate on this chip (157 TFLOP/s against 2.5 PFLOP/s), so an fp32-grade product is
+// cheaper as THREE f16 MFMAs than as one fp32 MFMA per four k:  every operand is split into two f16 numbers
+//     x = hi + lo / 2048,   hi = f16(x) (round to nearest, 11 significant bits),   lo = f16((x - hi) * 2048)  (the next 11)
+// (the residual x - hi is exact in fp32; the power-of-two scale keeps lo out of the f16 subnormals) and
+//     a.b = hi_a hi_b + (hi_a lo_b + lo_a hi_b) / 2048 + O(2^-22 |a||b|)
+// with both sums accumulated in fp32 by v_mfma_f32_16x16x32_f16 (main chain on the caller's accumulator, correction chain on
+// its own).  Measured product error against fp64: 1.07 x that of the fp32 MFMA chain (oracle/..., tests/test_split_product.py)
+// -- the same parity bar as the fp32 kernels, which is why this is a mode of the fp32 path and not a reduced-precision one.
+// Range: |x| < 65504 for every operand (states, activations, matrix entries); beyond that the f16 hi part overflows.
+// Layout: one k-step of 32 spans TWO 16-feature blocks of the T layout exactly as in gemm_Tb (B operand = pack of eight local
+// registers, k = 8q + e <-> feature 32 S + (e < 4 ? 4e : 16 + 4(e-4)) + q); an odd trailing block runs as ONE exact fp32
+// k-step when it holds at most four real features (d = 100: 3 split steps + features 96..99 in fp32; the table is then
+// exactly as large as the fp32 one) and as a 16x16x16 f16 step (three MFMAs again) otherwise.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr float kSplitScale = 2048.0f, kSplitInv = 1.0f / 2048.0f;
+template <int KS, int INB>
+struct SplitGeo {
+    static constexpr int NS = INB / 2;                       // full 32-feature steps
+    static constexpr bool ODD = (INB & 1) != 0;
+    static constexpr int NKR = ODD ? KS - 8 * NS : 0;        // real fp32 k-steps of the trailing block (1..4)
+    static constexpr bool ODD_F32 = ODD && NKR <= 1;
+    static constexpr bool ODD_H16 = ODD && NKR > 1;
+    static constexpr int per_mb = NS * 512 + (ODD_F32 ? 64 : 0) + (ODD_H16 ? 256 : 0);   // floats per 16-row block
+    static constexpr int floats(int MB) { return MB * per_mb; }
+};
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * kSplitScale);
+}
+// dst: per 16-row block mb [S][hi | lo][lane] f16x8, then the trailing block ([lane] fp32 or [hi | lo][lane] f16x4)
+template <int KS, int INB, class F>
+__device__ __forceinline__ void stage_aop_x3(float* dstf, int MB, int tid, int nthr, F src) {
+    using SG = SplitGeo<KS, INB>;
+    if constexpr (SG::NS > 0) {
+        for (int idx = tid; idx < MB * SG::NS * 64; idx += nthr) {
+            const int lane = idx & 63, t = idx >> 6;
+            const int S = t % SG::NS, mb = t / SG::NS;
+            const int i = lane & 15, g = lane >> 4;
+            const int row = 16 * mb + 4 * (i & 3) + (i >> 2);
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h, l;
+                split_f16(src(row, 32 * S + (e < 4 ? 4 * e : 16 + 4 * (e - 4)) + g), h, l);
+                hi[e] = h; lo[e] = l;
+            }
+            f16x8* p = reinterpret_cast<f16x8*>(dstf + mb * SG::per_mb + S * 512);
+            p[lane] = hi; p[64 + lane] = lo;
+        }
+    }
+    if constexpr (SG::ODD) {
+        for (int idx = tid; idx < MB * 64; idx += nthr) {
+            const int lane = idx & 63, mb = idx >> 6;
+            const int i = lane & 15, g = lane >> 4;
+            const int row = 16 * mb + 4 * (i & 3) + (i >> 2);
+            if constexpr (SG::ODD_F32) {
+                dstf[mb * SG::per_mb + SG::NS * 512 + lane] = src(row, 32 * SG::NS + g);
+            } else {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 h, l;
+                    split_f16(src(row, 32 * SG::NS + 4 * e + g), h, l);
+                    hi[e] = h; lo[e] = l;
+                }
+                f16x4* p = reinterpret_cast<f16x4*>(dstf + mb * SG::per_mb + SG::NS * 512);
+                p[lane] = hi; p[64 + lane] = lo;
+            }
+        }
+    }
+}
+// out^T (MB blocks) += W . in^T with fp32-grade products on the f16 pipe; A operands prefetched one chunk of units ahead
+template <int MB, int KS, int INB>
+__device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane) {
+    using SG = SplitGeo<KS, INB>;
+    constexpr int NS = SG::NS;
+    static_assert(MB * SG::per_mb * 4 <= 65536, "table exceeds the 16-bit ds_read immediate offset");
+    lane = opaque_i(lane);
+    f32x4 corr[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) corr[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NS > 0) {
+        const f16x8* tbl = reinterpret_cast<const f16x8*>(wlds) + lane;
+        constexpr int NU = NS * MB, CU = 2, NCH = cdiv(NU, CU);
+        f16x8 ah[2][CU], al[2][CU];
+#pragma unroll
+        for (int kk = 0; kk < CU; ++kk)
+            if (kk < NU) {
+                ah[0][kk] = tbl[((kk % MB) * SG::per_mb + (kk / MB) * 512) / 4];
+                al[0][kk] = tbl[((kk % MB) * SG::per_mb + (kk / MB) * 512) / 4 + 64];
+            }
+        f16x8 bh, bl;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int kk = 0; kk < CU; ++kk) {
+                    const int u = (c + 1) * CU + kk;
+                    if (u < NU) {
+                        ah[(c + 1) & 1][kk] = tbl[((u % MB) * SG::per_mb + (u / MB) * 512) / 4];
+                        al[(c + 1) & 1][kk] = tbl[((u % MB) * SG::per_mb + (u / MB) * 512) / 4 + 64];
+                    }
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < CU; ++kk) {
+                const int u = c * CU + kk;
+                if (u < NU) {
+                    const int S = u / MB, mb = u % MB;
+                    if (mb == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            _Float16 h, l;
+                            split_f16(in[2 * S][e], h, l);
+                            bh[e] = h; bl[e] = l;
+                            split_f16(in[2 * S + 1][e], h, l);
+                            bh[4 + e] = h; bl[4 + e] = l;
+                        }
+                    }
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c & 1][kk], bh, acc[mb], 0, 0, 0);
+                    corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c & 1][kk], bl, corr[mb], 0, 0, 0);
+                    corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c & 1][kk], bh, corr[mb], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(kFenceMask);
+        }
+    }
+    if constexpr (SG::ODD_F32) {
+        const float bop = in[INB - 1][0];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma16(wlds[mb * SG::per_mb + NS * 512 + lane], bop, acc[mb]);
+    }
+    if constexpr (SG::ODD_H16) {
+        f16x4 bh, bl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 h, l;
+            split_f16(in[INB - 1][e], h, l);
+            bh[e] = h; bl[e] = l;
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const f16x4* p = reinterpret_cast<const f16x4*>(wlds + mb * SG::per_mb + NS * 512) + lane;
+            const f16x4 a_hi = p[0], a_lo = p[64];
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_hi, bh, acc[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_hi, bl, corr[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_lo, bh, corr[mb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = acc[mb] + kSplitInv * corr[mb];
+}
+
 __device__ __forceinline__ float qsum(float v) {  // sum over the 4 q-lanes of a trajectory
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
@@ -348,6 +503,14 @@ struct Geo {
                          fRed = vterm + DB * 16;           // 2 doubles per wave, 16 waves max
     static constexpr int fA = fRed + 64;
     static constexpr int fB_dense_off = DB * KSD * 64;      // size of one dense d x d table
+    // split-product mode (gemm_Tx): table sizes of SplitGeo, the vectors / reduction area / d x d tables behind them in the
+    // same order as above
+    static constexpr int xW1 = 0, xW2 = xW1 + SplitGeo<KSD, DB>::floats(HB), xW3 = xW2 + SplitGeo<KSH, HB>::floats(HB),
+                         xVec = xW3 + SplitGeo<KSH, HB>::floats(DB), xA = xVec + (fA - fVec);
+    static constexpr int xB_dense_off = SplitGeo<KSD, DB>::floats(DB);
+    static int fwd_x3_lds_floats(int drift_kind, int sigma_kind) {
+        return xA + (drift_kind == DRIFT_DENSE ? xB_dense_off : 0) + (sigma_kind == SIGMA_DENSE ? xB_dense_off : 0);
+    }
     static int fwd_lds_floats(int drift_kind, int sigma_kind) {
         return fA + (drift_kind == DRIFT_DENSE ? fB_dense_off : 0) + (sigma_kind == SIGMA_DENSE ? fB_dense_off : 0);
     }
@@ -387,11 +550,16 @@ struct Geo {
 // every step waited right behind its burst of 28 X-image stores for them to be acknowledged before the first product
 // started.  Worth 1.3 % here (4.78 -> 4.72 ms, same-box A/B), 2 % in hjbs_fwd_kernel, 5 % in hjbq_fwd_kernel, whose steps
 // are short; the larger part of the path store's cost stays (finding 7).
-template <int D, int H, bool BF16 = false, bool FAST = false>
+template <int D, int H, int MODE = 0, bool FAST = false>
 __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
+    // MODE 0: fp32 MFMA; 1 (BF16): control net on bf16 MFMA; 2 (X3): every product fp32-grade on the f16 pipe (gemm_Tx)
+    constexpr bool BF16 = MODE == 1, X3 = MODE == 2;
+    constexpr int oW1 = X3 ? G::xW1 : G::fW1, oW2 = X3 ? G::xW2 : G::fW2, oW3 = X3 ? G::xW3 : G::fW3;
+    constexpr int VEC = X3 ? G::xVec : G::fVec;              // the vectors, the reduction area and the d x d tables follow
+    constexpr int VSH = VEC - G::fVec;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
@@ -403,34 +571,42 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
         if constexpr (BF16) stage_aop_bf16(dst, MB, (INB + 1) / 2, tid, nthr, src);
         else stage_aop(dst, MB, KS, tid, nthr, src);
     };
-    stage_net(lds + G::fW1, HB, KSD, DB, [&](int row, int col) {
-        return (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f; });
-    stage_net(lds + G::fW2, HB, KSH, HB, [&](int row, int col) {
-        return (row < H && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
-    stage_net(lds + G::fW3, DB, KSH, HB, [&](int row, int col) {
-        return (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f; });
-    float* ldsA = lds + G::fA;
-    float* ldsB = ldsA + (a.drift_kind == DRIFT_DENSE ? G::fB_dense_off : 0);
+    auto w1src = [&](int row, int col) { return (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f; };
+    auto w2src = [&](int row, int col) { return (row < H && col < H) ? P[G::oW2 + row * H + col] : 0.f; };
+    auto w3src = [&](int row, int col) { return (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f; };
+    if constexpr (X3) {
+        stage_aop_x3<KSD, DB>(lds + oW1, HB, tid, nthr, w1src);
+        stage_aop_x3<KSH, HB>(lds + oW2, HB, tid, nthr, w2src);
+        stage_aop_x3<KSH, HB>(lds + oW3, DB, tid, nthr, w3src);
+    } else {
+        stage_net(lds + oW1, HB, KSD, DB, w1src);
+        stage_net(lds + oW2, HB, KSH, HB, w2src);
+        stage_net(lds + oW3, DB, KSH, HB, w3src);
+    }
+    float* ldsA = lds + G::fA + VSH;
+    float* ldsB = ldsA + (a.drift_kind == DRIFT_DENSE ? (X3 ? G::xB_dense_off : G::fB_dense_off) : 0);
     if (a.drift_kind == DRIFT_DENSE) {
         const float dt = a.dt;
         const float* __restrict__ A = a.drift;
-        stage_aop(ldsA, DB, KSD, tid, nthr, [&](int row, int col) {
-            return (row < D && col < D) ? dt * A[row * D + col] : 0.f; });
+        auto asrc = [&](int row, int col) { return (row < D && col < D) ? dt * A[row * D + col] : 0.f; };
+        if constexpr (X3) stage_aop_x3<KSD, DB>(ldsA, DB, tid, nthr, asrc);
+        else stage_aop(ldsA, DB, KSD, tid, nthr, asrc);
     }
     if (a.sigma_kind == SIGMA_DENSE) {
         const float* __restrict__ B = a.sigma;
-        stage_aop(ldsB, DB, KSD, tid, nthr, [&](int row, int col) {
-            return (row < D && col < D) ? B[row * D + col] : 0.f; });
+        auto bsrc = [&](int row, int col) { return (row < D && col < D) ? B[row * D + col] : 0.f; };
+        if constexpr (X3) stage_aop_x3<KSD, DB>(ldsB, DB, tid, nthr, bsrc);
+        else stage_aop(ldsB, DB, KSD, tid, nthr, bsrc);
     }
-    stage_vec(lds + G::vb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
-    stage_vec(lds + G::vw1t, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW1 + f * (D + 1)] : 0.f; });
-    stage_vec(lds + G::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
-    stage_vec(lds + G::vb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
-    stage_vec(lds + G::vdr, DB, tid, nthr, [&](int f) {
+    stage_vec(lds + VSH + G::vb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
+    stage_vec(lds + VSH + G::vw1t, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW1 + f * (D + 1)] : 0.f; });
+    stage_vec(lds + VSH + G::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
+    stage_vec(lds + VSH + G::vb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
+    stage_vec(lds + VSH + G::vdr, DB, tid, nthr, [&](int f) {
         return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
-    stage_vec(lds + G::vrun, DB, tid, nthr, [&](int f) {
+    stage_vec(lds + VSH + G::vrun, DB, tid, nthr, [&](int f) {
         return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
-    stage_vec(lds + G::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
+    stage_vec(lds + VSH + G::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
     __syncthreads();
 
     const int t16 = blockIdx.x * nwave + wave;        // 16-trajectory tile owned by this wave
@@ -445,7 +621,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     double sD = 0.0, sD2 = 0.0;
     if (wave_valid) {
         // per-lane-q views of the staged vectors
-        const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::fVec) + q;   // index by block*4
+        const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + VEC) + q;   // index by block*4
         const f32x4* vterm = vecs0 + (G::vterm - G::fVec) / 4;
 
         // ---- X_0 (solver.py:365-367) in T layout
@@ -486,8 +662,9 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 h1[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
-            if constexpr (BF16) gemm_Tb<HB, DB>(h1, lds + G::fW1, X, lane);
-            else gemm_T<HB, KSD, DB>(h1, lds + G::fW1, X, lane);
+            if constexpr (X3) gemm_Tx<HB, KSD, DB>(h1, lds + oW1, X, lane);
+            else if constexpr (BF16) gemm_Tb<HB, DB>(h1, lds + oW1, X, lane);
+            else gemm_T<HB, KSD, DB>(h1, lds + oW1, X, lane);
             PSP_STAMP(fs1);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = tanh4(h1[m]);
@@ -495,8 +672,9 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 h2[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
-            if constexpr (BF16) gemm_Tb<HB, HB>(h2, lds + G::fW2, h1, lane);
-            else gemm_T<HB, KSH, HB>(h2, lds + G::fW2, h1, lane);
+            if constexpr (X3) gemm_Tx<HB, KSH, HB>(h2, lds + oW2, h1, lane);
+            else if constexpr (BF16) gemm_Tb<HB, HB>(h2, lds + oW2, h1, lane);
+            else gemm_T<HB, KSH, HB>(h2, lds + oW2, h1, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
             if (a.store_path) {                        // hidden activations for the backward pass (no recompute)
@@ -509,8 +687,9 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 Z[DB];
 #pragma unroll
             for (int m = 0; m < DB; ++m) Z[m] = vb3[m * 4];
-            if constexpr (BF16) gemm_Tb<DB, HB>(Z, lds + G::fW3, h2, lane);
-            else gemm_T<DB, KSH, HB>(Z, lds + G::fW3, h2, lane);
+            if constexpr (X3) gemm_Tx<DB, KSH, HB>(Z, lds + oW3, h2, lane);
+            else if constexpr (BF16) gemm_Tb<DB, HB>(Z, lds + oW3, h2, lane);
+            else gemm_T<DB, KSH, HB>(Z, lds + oW3, h2, lane);
             PSP_STAMP(fs3);
 
             // ---- Brownian increment xi_{n+1} and the two row sums |Z|^2, Z.xi (solver.py:477-478)
@@ -571,7 +750,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) Tn[b] = X[b];
             if (a.drift_kind == DRIFT_DENSE) {
-                gemm_T<DB, KSD, DB>(Tn, ldsA, X, lane);          // + (dt A) X
+                if constexpr (X3) gemm_Tx<DB, KSD, DB>(Tn, ldsA, X, lane);
+                else gemm_T<DB, KSD, DB>(Tn, ldsA, X, lane);     // + (dt A) X
             } else if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Tn[b] += dt * (vdr[b * 4] * X[b]);
@@ -580,7 +760,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
                 for (int b = 0; b < DB; ++b) Tn[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
             }
             if (a.sigma_kind == SIGMA_DENSE) {
-                gemm_T<DB, KSD, DB>(Tn, ldsB, Z, lane);          // + B v
+                if constexpr (X3) gemm_Tx<DB, KSD, DB>(Tn, ldsB, Z, lane);
+                else gemm_T<DB, KSD, DB>(Tn, ldsB, Z, lane);     // + B v
             } else if (a.sigma_kind == SIGMA_SCALE) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Tn[b] += a.sigma_scale * Z[b];
@@ -664,7 +845,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     }
     // ---- per-workgroup partial (sum D, sum D^2) in fp64, fixed order
     sD = jsum(sD); sD2 = jsum(sD2);
-    double* red = reinterpret_cast<double*>(lds + G::fRed);
+    double* red = reinterpret_cast<double*>(lds + G::fRed + VSH);
     if (lane == 0) { red[2 * wave] = sD; red[2 * wave + 1] = sD2; }
     __syncthreads();
     if (tid == 0) {
@@ -1460,6 +1641,8 @@ struct HjbInstance {
     hipError_t (*launch_fwd_quad)(const HjbArgs&, int grid, hipStream_t);
     hipError_t (*launch_adj_quad)(const HjbArgs&, int grid, hipStream_t);          // quad-trajectory adjoint sweep (same selection rule)
     int bwd2_one_per_cu;             // wide family: 1 when launch_bwd2 is the 8-wave hjbw_bwd2_kernel (one workgroup per CU)
+    int (*fwd_x3_lds_bytes)(int drift_kind, int sigma_kind);                           // split-product forward (null: not built)
+    hipError_t (*launch_fwd_x3)(const HjbArgs&, int grid, int block, hipStream_t);
 };
 
 template <int D, int H>
@@ -1467,22 +1650,27 @@ struct HjbLaunch {
     using G = Geo<D, H>;
     static int fwd_lds(int dk, int sk) { return G::fwd_lds_floats(dk, sk) * 4; }
     static int bwd_lds(int ad) { return G::bwd_lds_floats(ad) * 4; }
-    template <bool BF16, bool FAST>
+    static int fwd_x3_lds(int dk, int sk) { return G::fwd_x3_lds_floats(dk, sk) * 4; }
+    template <int MODE, bool FAST>
     static hipError_t fwd_as(const HjbArgs& a, int grid, int block, hipStream_t s) {
-        const int bytes = fwd_lds(a.drift_kind, a.sigma_kind);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_fwd_kernel<D, H, BF16, FAST>),
+        const int bytes = MODE == 2 ? fwd_x3_lds(a.drift_kind, a.sigma_kind) : fwd_lds(a.drift_kind, a.sigma_kind);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_fwd_kernel<D, H, MODE, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjb_fwd_kernel<D, H, BF16, FAST>), dim3(grid), dim3(block), bytes, s, a);
+        hipLaunchKernelGGL((hjb_fwd_kernel<D, H, MODE, FAST>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
     // FAST (no vector-memory load in the time loop): Philox noise, no u_L2 log, no time-feature table -- every training launch
     static bool fast(const HjbArgs& a) { return a.noise_mode == NOISE_PHILOX && a.uref == nullptr && a.tfeat == nullptr; }
     static hipError_t fwd(const HjbArgs& a, int grid, int block, hipStream_t s) {
-        return fast(a) ? fwd_as<false, true>(a, grid, block, s) : fwd_as<false, false>(a, grid, block, s);
+        return fast(a) ? fwd_as<0, true>(a, grid, block, s) : fwd_as<0, false>(a, grid, block, s);
     }
     static hipError_t fwd_bf16(const HjbArgs& a, int grid, int block, hipStream_t s) {
-        return fast(a) ? fwd_as<true, true>(a, grid, block, s) : fwd_as<true, false>(a, grid, block, s);
+        return fast(a) ? fwd_as<1, true>(a, grid, block, s) : fwd_as<1, false>(a, grid, block, s);
+    }
+    // every product fp32-grade on the f16 matrix pipe (gemm_Tx)
+    static hipError_t fwd_x3(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        return fast(a) ? fwd_as<2, true>(a, grid, block, s) : fwd_as<2, false>(a, grid, block, s);
     }
 #ifdef PSP_LEGACY_BWD
     // hjb_bwd_kernel (the second backward version: two 4-wave workgroups per CU, every wave runs all phases) is superseded by

@@ -132,7 +132,11 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
         c->loss_kind < 0 || c->loss_kind > 3 || c->noise_mode < 0 || c->noise_mode > 1 || c->store_path < 0 ||
         c->store_path > 3)
         return fail(-1, "config enum out of range");
-    if (p->inst.fwd_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
+    if (c->mlp_dtype == PSP_MLP_F16X3) {
+        if (!p->inst.launch_fwd_x3) return fail(-3, "the split-product mode (PSP_MLP_F16X3) is not built for this kernel family");
+        if (p->inst.fwd_x3_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
+            return fail(-3, "split-product forward tables do not fit the 160 KiB LDS for this (d,H,drift,sigma)");
+    } else if (p->inst.fwd_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
         return fail(-3, "forward kernel weights do not fit the 160 KiB LDS for this (d,H,drift,sigma)");
     p->ntile16 = (c->K_local + 15) / 16;
     if ((long long)c->N * p->ntile16 >= (1LL << 31)) return fail(-1, "N * ceil(K/16) must stay below 2^31");
@@ -150,13 +154,13 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     // tile-per-wave, the feature-split or the quad kernel)
     const char* fv = getenv("PSP_FWD_VARIANT");       // (read per call: tests switch variants inside one process)
     p->fwd_split = !p->inst.wide && p->inst.launch_fwd_split && p->inst.split_lds_bytes() <= kMaxLds &&
-                   c->mlp_dtype != PSP_MLP_BF16_FWD &&           // (the bf16 control-net mode exists in hjb_fwd_kernel only)
+                   c->mlp_dtype != PSP_MLP_BF16_FWD && c->mlp_dtype != PSP_MLP_F16X3 &&   // (these modes exist in hjb_fwd_kernel only)
                    ((fv && fv[0] == '2') || (!(fv && fv[0] == '1') && p->ntile16 <= 2 * cus));
     if (p->fwd_split) { p->fwd_waves = 8; p->fwd_grid = p->ntile16; }   // (the kernel itself fixes 4 or 8 waves per tile)
     // fewer tiles than a quarter of the CUs: four trajectories per workgroup (hjbq_kernels.h), so that K = 1024 still covers the
     // chip (PSP_FWD_VARIANT=3 forces it, 1 / 2 exclude it)
     p->fwd_quad = !p->inst.wide && p->inst.launch_fwd_quad && p->inst.quad_lds_bytes() <= kMaxLds &&
-                  c->mlp_dtype != PSP_MLP_BF16_FWD &&
+                  c->mlp_dtype != PSP_MLP_BF16_FWD && c->mlp_dtype != PSP_MLP_F16X3 &&
                   ((fv && fv[0] == '3') || (!fv && 4 * p->ntile16 <= cus));
     if (p->fwd_quad) { p->fwd_split = false; p->fwd_waves = 8; p->fwd_grid = 4 * p->ntile16; }
     // backward: persistent over rounds of 4 sample blocks; 4-wave workgroups, two per CU
@@ -691,8 +695,10 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
     if (cfg->mlp_dtype == PSP_MLP_BF16_FWD) {
         if (!p.inst.launch_fwd_bf16) return fail(-3, "the bf16 control-net mode exists for the narrow kernel family only");
         e = p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);      // make_plan kept the tile-per-wave forward
+    } else if (cfg->mlp_dtype == PSP_MLP_F16X3) {
+        e = p.inst.launch_fwd_x3(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     } else if (cfg->mlp_dtype != PSP_MLP_FP32) {
-        return fail(-1, "mlp_dtype out of range for the HJB rollout (fp32 or bf16_fwd)");
+        return fail(-1, "mlp_dtype out of range for the HJB rollout (fp32, bf16_fwd or f16x3)");
     } else {
         e = p.fwd_quad ? p.inst.launch_fwd_quad(a, p.fwd_grid, (hipStream_t)stream)
             : p.fwd_split ? p.inst.launch_fwd_split(a, p.fwd_grid, (hipStream_t)stream)

@@ -22,7 +22,7 @@ TERM_LINEAR, TERM_DIAG_QUAD, TERM_SHIFTED_QUAD = 0, 1, 2
 LOSS_LOG_VARIANCE, LOSS_MOMENT, LOSS_WEIGHTS, LOSS_REL_ENTROPY = 0, 1, 2, 3
 NOISE_SUPPLIED, NOISE_PHILOX = 0, 1
 GH_ZERO, GH_QUAD, GH_ALLEN_CAHN, GH_EXPBALL_LIN, GH_EXPBALL_SQ, GH_EXPBALL_SIN = 0, 1, 2, 3, 4, 5
-MLP_FP32, MLP_BF16_FWD, MLP_BF16 = 0, 1, 2
+MLP_FP32, MLP_BF16_FWD, MLP_BF16, MLP_F16X3 = 0, 1, 2, 3
 DT_F32, DT_F64 = 0, 1
 COMM_ID_BYTES = 128
 DOM_NONE, DOM_SPHERE, DOM_BOX, DOM_BOX_UPPER_ALL, DOM_BOX_UPPER_ANY = 0, 1, 2, 3, 4

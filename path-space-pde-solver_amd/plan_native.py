@@ -144,7 +144,7 @@ class HjbNativePlan:
         self.attached = bool(solver.adaptive_forward_process and not solver.detach_forward)
         cfg.noise_mode = nat.NOISE_PHILOX if noise == 'philox' else nat.NOISE_SUPPLIED
         cfg.store_path = 3 if self.relent else (2 if self.attached else 1)
-        cfg.mlp_dtype = nat.MLP_BF16_FWD if getattr(solver, 'mlp_dtype', 'fp32') == 'bf16' else nat.MLP_FP32
+        cfg.mlp_dtype = {'fp32': nat.MLP_FP32, 'bf16': nat.MLP_BF16_FWD, 'f16x3': nat.MLP_F16X3}[getattr(solver, 'mlp_dtype', 'fp32')]
         # kernel instance: the exact (d, H) if compiled, else the cheapest larger one (zero padding, native_shapes.py)
         chosen, why = shapes.choose(cfg, solver.d, self.H)
         if chosen is None:

@@ -77,8 +77,8 @@ class Solver:
         if noise not in ('reference', 'philox'):
             raise ValueError("noise must be 'reference' or 'philox'")
         self.backend, self.noise = backend, noise
-        if mlp_dtype not in ('fp32', 'bf16'):
-            raise ValueError("mlp_dtype must be 'fp32' or 'bf16'")
+        if mlp_dtype not in ('fp32', 'bf16', 'f16x3'):
+            raise ValueError("mlp_dtype must be 'fp32', 'f16x3' or 'bf16'")
         self.mlp_dtype = mlp_dtype       # 'bf16': control-net products of the native forward rollout on bf16 MFMA (opt-in, own tolerance)
         # native plan: HBM budget of the path store kept for the backward pass (None: a third of the HBM); a larger store is
         # processed in K-chunks (plan_native.py).  path_chunks forces a chunk count; chunk_mode 'auto' | 'two_gradient' | 'recompute'

@@ -45,9 +45,14 @@ def oracle_flat_grads(trace):
 
 @pytest.mark.parametrize("name", NATIVE_CASES)
 def test_first_iteration_D_and_gradient_match_oracle(name):
+    check_first_iteration(name)
+
+
+def check_first_iteration(name, **over):
+    """(also called by tests/test_gpu_split_product.py with mlp_dtype='f16x3': same bounds)"""
     rec = load_golden(name)
     case = rec["case"]
-    model = make_pkg_solver(case, dev(), backend="native", L=1)
+    model = make_pkg_solver(case, dev(), backend="native", L=1, **over)
     oprob, ocfg, omodels = make_oracle(case, L=1)
     # identical initial weights (same RNG recipe)
     assert torch.equal(flat_params(model.z_n), flat_params(omodels[0]))
@@ -64,6 +69,7 @@ def test_first_iteration_D_and_gradient_match_oracle(name):
     g = plan.grad.cpu()
     g_ref = oracle_flat_grads(tr)
     assert g.shape == g_ref.shape
+    check_first_iteration.observed = (float((D - D_ref).abs().max()) / scale, float((g - g_ref).abs().max()) / float(g_ref.abs().max()))
     assert float((g - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
     # the reference forms mean(D^2) - mean(D)^2 in fp32: its own rounding error is ~eps * mean(D^2) / var (the kernel
     # sums in fp64), so the first-iteration bound follows the conditioning, capped by the contract's 1e-4
@@ -76,8 +82,12 @@ def test_first_iteration_D_and_gradient_match_oracle(name):
 def test_loss_log_matches_reference_golden(name):
     """Full training iterations (rollout + loss + backward + Adam) against the reference's own
     loss_log on fixed seeds."""
+    check_loss_log(name)
+
+
+def check_loss_log(name, **over):
     rec = load_golden(name)
-    model = make_pkg_solver(rec["case"], dev(), backend="native")
+    model = make_pkg_solver(rec["case"], dev(), backend="native", **over)
     model.train()
     exp = rec["expected"]
     assert len(model.loss_log) == len(exp["loss_log"])
