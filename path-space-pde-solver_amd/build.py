@@ -92,7 +92,7 @@ def _build(force, jobs, verbose, only):
     for d, H in instances():
         tasks.append((inst_src, os.path.join(OBJ, "inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [inst_src, hdr, os.path.join(CSRC, "hjbs_kernels.h"), os.path.join(CSRC, "hjba_kernels.h"),
-                       os.path.join(CSRC, "hjbq_kernels.h")]))
+                       os.path.join(CSRC, "hjbq_kernels.h"), os.path.join(CSRC, "hjbx_kernels.h")]))
     for d, H in instances("wide_instances.def"):
         tasks.append((winst_src, os.path.join(OBJ, "wide_inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [winst_src, whdr, hdr]))

@@ -3,6 +3,7 @@
 #include "hjbs_kernels.h"
 #include "hjba_kernels.h"
 #include "hjbq_kernels.h"
+#include "hjbx_kernels.h"
 #ifndef PSP_D
 #error "compile with -DPSP_D=<d> -DPSP_H=<H>"
 #endif
@@ -18,8 +19,8 @@
         r.launch_fwd_bf16 = &psp::HjbLaunch<D_, H_>::fwd_bf16;                             \
         r.fwd_x3_lds_bytes = &psp::HjbLaunch<D_, H_>::fwd_x3_lds;                          \
         r.launch_fwd_x3 = &psp::HjbLaunch<D_, H_>::fwd_x3;                                 \
-        r.bwd2_x3_lds_bytes = &psp::HjbLaunch<D_, H_>::bwd2_x3_lds;                        \
-        r.launch_bwd2_x3 = &psp::HjbLaunch<D_, H_>::bwd2_x3;                               \
+        r.bwd2_x3_lds_bytes = &psp::HjbxLaunch<D_, H_>::lds_bytes;                         \
+        r.launch_bwd2_x3 = &psp::HjbxLaunch<D_, H_>::bwd;                                  \
         r.quad_lds_bytes = &psp::HjbqLaunch<D_, H_>::lds_bytes;                            \
         r.launch_fwd_quad = &psp::HjbqLaunch<D_, H_>::fwd;                                 \
         r.launch_adj_quad = &psp::HjbqLaunch<D_, H_>::adj;                                 \

@@ -536,7 +536,6 @@ struct Geo {
     // an exact k-step image (KSD x 64 floats) followed by the dz2 and dz1 panels; two buffers of 4 blocks
     static constexpr int EXB = KSD * 64 + 4 * HB * 64;
     static int bwd2_lds_floats() { return HB * KSD * 64 + 2 * 4 * EXB; }
-    static int bwd2_x3_lds_floats() { return SplitGeo<KSD, DB>::floats(HB) + 2 * 4 * EXB; }
 };
 
 // =======================================================================================
@@ -1247,12 +1246,10 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
 // other by construction instead of by the accident of two workgroups being out of phase; the two
 // exchange buffers are swapped at the single barrier per round.
 // =======================================================================================
-// X3: the producers' data-gradient product W3^T G as split f16 products (gemm_Tx; psp_hjb_config.mlp_dtype = PSP_MLP_F16X3)
-template <int D, int H, bool X3 = false>
+template <int D, int H>
 __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH, EXB = G::EXB;
-    constexpr int TBL = X3 ? SplitGeo<KSD, DB>::floats(HB) : HB * KSD * 64;      // W3^T table (floats)
     constexpr int WH = G::WH, WD = G::WD, NIB = G::NIB, NOBD = G::NOBD, NOBH = G::NOBH;
     constexpr int oDZ2 = KSD * 64;                                     // dz2 panel inside one block's exchange area
     constexpr int RS = 16 * DB + 16 * HB;                              // per-producer bias-sum slots (G | dz2)
@@ -1266,11 +1263,10 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     const int lofsF = image_lane_offset_F(lane);
     const float* __restrict__ P = a.params;
 
-    auto w3t = [&](int row, int col) { return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; };
-    if constexpr (X3) stage_aop_x3<KSD, DB>(lds, HB, tid, nthr, w3t);   // W3^T as A-operand table (producers)
-    else stage_aop(lds, HB, KSD, tid, nthr, w3t);
+    stage_aop(lds, HB, KSD, tid, nthr, [&](int row, int col) {          // W3^T as A-operand table (producers)
+        return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
     __syncthreads();
-    float* bufs = lds + TBL;                          // [2 buffers][4 blocks][EXB]
+    float* bufs = lds + HB * KSD * 64;                // [2 buffers][4 blocks][EXB]
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     const double invK = 1.0 / (double)a.K_global;
@@ -1358,8 +1354,7 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
                 f32x4 dz2[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) dz2[m] = zero4;
-                if constexpr (X3) gemm_Tx<HB, KSD, DB>(dz2, lds, Gt, lane);
-                else gemm_T<HB, KSD, DB>(dz2, lds, Gt, lane);
+                gemm_T<HB, KSD, DB>(dz2, lds, Gt, lane);
 #pragma unroll
                 for (int m = 0; m < HB; ++m) { dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]); sZ2[m] += dz2[m]; }
                 PSP_STAMP(tp2);
@@ -1648,8 +1643,8 @@ struct HjbInstance {
     int bwd2_one_per_cu;             // wide family: 1 when launch_bwd2 is the 8-wave hjbw_bwd2_kernel (one workgroup per CU)
     int (*fwd_x3_lds_bytes)(int drift_kind, int sigma_kind);                           // split-product forward (null: not built)
     hipError_t (*launch_fwd_x3)(const HjbArgs&, int grid, int block, hipStream_t);
-    int (*bwd2_x3_lds_bytes)();                                                        // split-product backward (null: not built)
-    hipError_t (*launch_bwd2_x3)(const HjbArgs&, int grid, hipStream_t);
+    int (*bwd2_x3_lds_bytes)();                                                        // split-product backward, hjbx_kernels.h
+    hipError_t (*launch_bwd2_x3)(const HjbArgs&, int grid, hipStream_t);               // (null: not built)
 };
 
 template <int D, int H>
@@ -1696,18 +1691,14 @@ struct HjbLaunch {
     static constexpr hipError_t (*legacy_bwd)(const HjbArgs&, int, int, hipStream_t) = nullptr;
 #endif
     static int bwd2_lds() { return G::bwd2_lds_floats() * 4; }
-    static int bwd2_x3_lds() { return G::bwd2_x3_lds_floats() * 4; }
-    template <bool X3>
-    static hipError_t bwd2_as(const HjbArgs& a, int grid, hipStream_t s) {
-        const int bytes = X3 ? bwd2_x3_lds() : bwd2_lds();
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_bwd2_kernel<D, H, X3>),
+    static hipError_t bwd2(const HjbArgs& a, int grid, hipStream_t s) {
+        const int bytes = bwd2_lds();
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_bwd2_kernel<D, H>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjb_bwd2_kernel<D, H, X3>), dim3(grid), dim3(512), bytes, s, a);
+        hipLaunchKernelGGL((hjb_bwd2_kernel<D, H>), dim3(grid), dim3(512), bytes, s, a);
         return hipGetLastError();
     }
-    static hipError_t bwd2(const HjbArgs& a, int grid, hipStream_t s) { return bwd2_as<false>(a, grid, s); }
-    static hipError_t bwd2_x3(const HjbArgs& a, int grid, hipStream_t s) { return bwd2_as<true>(a, grid, s); }
     static HjbInstance instance() {
         return HjbInstance{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, legacy_bwd, G::PB, &bwd2_lds, &bwd2};
     }
