@@ -139,6 +139,47 @@ def issued_mfma_per_tile_step(d_pad, H_pad, dense, family, bf16_mlp=False):
     return net + sde, 0, bwd
 
 
+def issued_mfma_x3(d_pad, H_pad, dense):
+    """Split-product kernels (hjb_fwd_kernel<.., 2, ..>, hjb_bwd3_kernel): MFMA instructions per tile-step from SplitGeo in
+    csrc/hjb_kernels.h -- a contraction over K features runs K // 32 steps of three v_mfma_f32_16x16x32_f16 per 16-row block;
+    an odd trailing 16-feature block is one exact fp32 k-step when it holds at most four features, else three
+    v_mfma_f32_16x16x16_f16.  Returns dicts {f16_32, f16_16, f32} for the forward and the backward."""
+    DB, HB = _cdiv(d_pad, 16), _cdiv(H_pad, 16)
+
+    def prod(K, MB):
+        inb, ks = _cdiv(K, 16), _cdiv(K, 4)
+        ns, odd = inb // 2, inb % 2
+        nkr = ks - 8 * ns if odd else 0
+        return {"f16_32": 3 * ns * MB, "f16_16": 3 * MB if (odd and nkr > 1) else 0, "f32": MB if (odd and nkr <= 1) else 0}
+
+    def add(*ds):
+        return {k: sum(d[k] for d in ds) for k in ("f16_32", "f16_16", "f32")}
+
+    fwd = add(prod(d_pad, HB), prod(H_pad, HB), prod(H_pad, DB), *([prod(d_pad, DB)] * (2 if dense else 0)))
+    # backward: producers W3^T G and W2^T dz2 per block; consumers, per PAIR of blocks and wave, three MFMAs per owned tile
+    # (dW3: DB, dW2: HB, dW1: HB x ceil(DB / 4)), four waves
+    cons = 4 * 3 * (DB + HB + HB * _cdiv(DB, 4)) / 2.0
+    bwd = add(prod(d_pad, HB), prod(H_pad, HB), {"f16_32": cons, "f16_16": 0, "f32": 0})
+    return fwd, bwd
+
+
+def x3_roofline(fl2, fl3, issued, units, tiles_steps, ms, which):
+    """Split-product kernels: an algorithmic fp32 flop costs three f16 flops, so the matrix floor of the kernel is
+    3 x algorithmic flops at the f16 peak (`frac`); `frac_issued` prices the instructions actually issued (padding included,
+    exact fp32 k-steps at the fp32 peak)."""
+    t = ms * 1e-3
+    alg = fl2[which] * units
+    floor_s = 3.0 * alg / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    n = issued[1] if which == "bwd_kernel" else issued[0]
+    iss_s = (n["f16_32"] * MFMA_BF16_16x16x32_FLOP / (PEAK_BF16_MFMA_TFLOPS * 1e12) +
+             n["f16_16"] * (MFMA_BF16_16x16x32_FLOP / 2) / (PEAK_BF16_MFMA_TFLOPS * 1e12) +
+             n["f32"] * MFMA_F32_16x16x4_FLOP / (PEAK_FP32_MFMA_TFLOPS * 1e12)) * tiles_steps
+    achieved = alg / t / 1e12
+    return dict(achieved=achieved, peak=PEAK_BF16_MFMA_TFLOPS / 3.0, frac=floor_s / t, frac_issued=iss_s / t,
+                frac_survey_m3=(3.0 * fl3[which] * units / (PEAK_BF16_MFMA_TFLOPS * 1e12)) / t,
+                achieved_over_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS)
+
+
 def issued_mfma_quad_kernel(d_pad, H_pad, dense):
     """hjbq_fwd_kernel (four trajectories per workgroup, K <= 4 x CUs): v_mfma_f32_4x4x1_16b_f32 (512 flop) per workgroup and
     step, from GeoQ in csrc/hjbq_kernels.h, returned in 16x16x4 equivalents (2048 flop) per 16 trajectories so that it plugs
@@ -333,11 +374,12 @@ def cpu_baseline(w):
                 legs=legs)
 
 
-def loss_rel_err_vs_cpu(psp, dev, w):
+def loss_rel_err_vs_cpu(psp, dev, w, mode="fp32"):
     """BASELINE.json's second metric: |L_gpu - L_ref| / |L_ref| per iteration on FIXED SEEDS -- the native plan with the
     reference's host-generated noise (torch CPU generator, seed 42) against the CPU oracle consuming the same stream, on the
     workload's problem at K = 1024 trajectories, 3 iterations.  Part of the cpu_baseline leg (the only place bench.py may
-    use oracle/)."""
+    use oracle/).  `mode`: the matrix-product mode of the timed kernels (Solver(mlp_dtype=...)), forced here so that the check runs
+    the same kernels at this smaller K."""
     from oracle import pathspace_oracle as orc
     K, L = 1024, 3
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -349,11 +391,13 @@ def loss_rel_err_vs_cpu(psp, dev, w):
     prob = psp.LLGC(d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42, device=dev)
     model = psp.Solver("bench-parity", prob, lr=1e-3, L=L, K=K, delta_t=w["dt"], loss_method="log-variance",
                        time_approx="inner", adaptive_forward_process=True, detach_forward=True, u_l2_error_flag=False,
-                       verbose=False, seed=42, device=dev, backend="native", noise="reference", widths=(w["H"], w["H"]))
+                       verbose=False, seed=42, device=dev, backend="native", noise="reference", widths=(w["H"], w["H"]),
+                       mlp_dtype=mode)
     model.train()
+    assert model._native_plan.matrix_mode == mode
     errs = [abs(a - b) / abs(b) for a, b in zip(model.loss_log, ref)]
     return dict(value=max(errs), per_iteration=errs, tolerance=1e-4,
-                case="LLGC d=%d, K=%d, N=%d, %d iterations, seed 42, reference noise stream" % (w["d"], K, N, L))
+                case="LLGC d=%d, K=%d, N=%d, %d iterations, seed 42, reference noise stream, matrix products %s" % (w["d"], K, N, L, mode))
 
 
 def secondary(psp, dev, w, steps=200, warmup=20):
@@ -361,7 +405,7 @@ def secondary(psp, dev, w, steps=200, warmup=20):
     model = psp.Solver("bench-cfg1", prob, lr=1e-3, L=steps + warmup, K=w["K"], delta_t=w["dt"],
                        loss_method="log-variance", time_approx="inner", adaptive_forward_process=True,
                        detach_forward=True, u_l2_error_flag=False, verbose=False, seed=42, device=dev,
-                       backend="native", noise="philox", widths=(w["H"], w["H"]))
+                       backend="native", noise="philox", widths=(w["H"], w["H"]), mlp_dtype=w.get("mlp", "auto"))
     plan = model._choose_plan()
     losses = torch.zeros(steps + warmup, dtype=torch.float32, device=dev)
     for l in range(warmup):
@@ -373,7 +417,8 @@ def secondary(psp, dev, w, steps=200, warmup=20):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     return {"value": w["K"] * model.N * steps / el, "unit": "trajectory-timesteps/s", "ms_per_step": 1e3 * el / steps,
-            "steps": steps, "K": w["K"], "N": model.N, "graph": bool(getattr(plan, "graph_active", False))}
+            "steps": steps, "K": w["K"], "N": model.N, "graph": bool(getattr(plan, "graph_active", False)),
+            "matrix_products": getattr(plan, "matrix_mode", "fp32")}
 
 
 def mfma_roofline(fl2, fl3, issued, units, tiles_steps, ms, bf16_mlp, which):
@@ -447,7 +492,7 @@ def main():
     model = psp.Solver("bench", prob, lr=w.get("lr", 1e-3), L=total, K=K_global, delta_t=w["dt"], loss_method="log-variance",
                        time_approx="outer" if outer else "inner", adaptive_forward_process=True, detach_forward=True,
                        u_l2_error_flag=False, verbose=False, seed=42, device=dev, backend="native",
-                       noise="philox", widths=(w["H"], w["H"]), mlp_dtype=w.get("mlp", "fp32"), **extra)
+                       noise="philox", widths=(w["H"], w["H"]), mlp_dtype=w.get("mlp", "auto"), **extra)
     if outer:                                            # the constructor builds arch [30, 30]; honour the workload's H
         model.z_n = [psp.DenseNet(d_in=w["d"], d_out=w["d"], lr=w.get("lr", 1e-3), arch=[w["H"], w["H"]], seed=42).to(dev)
                      for _ in range(model.N)]
@@ -499,6 +544,7 @@ def main():
     ntile = _cdiv(K_launch, 16)
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     bf16_mlp = w.get("mlp") == "bf16"
+    x3 = getattr(plan, "matrix_mode", "fp32") == "f16x3"      # split-product kernels (three f16 MFMAs per fp32 product)
     if outer:
         fwd_name, bwd_name = "hjbd_fwd_kernel", ("hjbd_bwd_kernel" if plan.kernel_bwd else "library GEMMs")
         issued = None
@@ -508,6 +554,9 @@ def main():
             "hjbq_fwd_kernel" if quad else ("hjbs_fwd_kernel" if ntile <= 2 * cus else "hjb_fwd_kernel"))
         bwd_name = ("hjbw_bwd2_kernel" if plan.d_pad <= 256 else "hjbw_bwd_kernel") if plan.family == 2 else "hjb_bwd2_kernel"
         issued = issued_mfma_per_tile_step(plan.d_pad, plan.H_pad, dense, plan.family, bf16_mlp)
+        if x3:
+            bwd_name = "hjb_bwd3_kernel"
+            issued_x3 = issued_mfma_x3(plan.d_pad, plan.H_pad, dense)
         if quad:
             issued = (issued_mfma_quad_kernel(plan.d_pad, plan.H_pad, dense), 0, issued[2])
     bwd_dominant = bwd_ms >= fwd_ms
@@ -518,6 +567,8 @@ def main():
         mf["frac"] = mf["achieved"] / mf["peak"]
         mf["frac_issued"] = None
         mf["frac_survey_m3"] = fl3[which] * units_launch / t / 1e12 / mf["peak"]
+    elif x3:
+        mf = x3_roofline(fl2, fl3, issued_x3, units_launch, tiles_steps, dom_ms, which)
     else:
         mf = mfma_roofline(fl2, fl3, issued, units_launch, tiles_steps, dom_ms, bf16_mlp, which)
     # HBM term: SURVEY 8d's algorithmic bytes (state streamed once per step, 8d + 8) and this design's real ones (the path
@@ -541,7 +592,8 @@ def main():
             "mfma_term": mf, "hbm_term": hbm,
             "alg_flops_per_traj_step": {k: fl2[k] for k in ("fwd_kernel", "bwd_kernel", "total")},
             "alg_flops_per_traj_step_survey_m3": {k: fl3[k] for k in ("fwd_kernel", "bwd_kernel", "total")},
-            "issued_mfma_per_tile_step": ({"fwd_f32_16x16x4": issued[0], "fwd_bf16_16x16x32": issued[1],
+            "issued_mfma_per_tile_step": ({"fwd": issued_x3[0], "bwd": issued_x3[1]} if x3 else
+                                          {"fwd_f32_16x16x4": issued[0], "fwd_bf16_16x16x32": issued[1],
                                            "bwd_f32_16x16x4": issued[2]} if issued else None),
             "units_per_launch": units_launch, "launches_per_step": n_chunks,
             "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
@@ -558,6 +610,12 @@ def main():
                    "mlp": ("%d x DenseNet %d-%d-%d-%d relu^2, one per time step (time_approx='outer')" % (N_t, w["d"], w["H"], w["H"], w["d"]))
                           if outer else "%d-%d-%d-%d tanh" % (w["d"] + 1, w["H"], w["H"], w["d"]),
                    "loss": "log-variance", "noise": "on-device Philox4x32-10",
+                   "matrix_products": ("fp32-grade split products on the f16 matrix pipe: x = hi + lo/2048 (two f16 numbers), "
+                                       "a.b = hi.hi + (hi.lo + lo.hi)/2048 as three v_mfma_f32_16x16x32_f16 with fp32 accumulation "
+                                       "(product error 1.07x that of v_mfma_f32_16x16x4_f32; same parity bounds, "
+                                       "tests/test_gpu_split_product.py); state, sums and the path store are fp32") if x3 else
+                                      ("v_mfma_f32_16x16x32_bf16 for the control net, v_mfma_f32_16x16x4_f32 elsewhere" if bf16_mlp
+                                       else "v_mfma_f32_16x16x4_f32"),
                    "launch": "hipGraph replay of the captured iteration" if graph else "eager launches",
                    "parallelism": "trajectory-sharded x%d (%s)" % (world, "gloo rehearsal on one GPU" if rehearsal else
                                                                     ("RCCL" if world > 1 else "single process")),
@@ -582,9 +640,14 @@ def main():
         # BASELINE.json configs[1] (d=100, K=1024, N=50) measured in the same process, for readers who take
         # that as the quoted configuration (64 16-trajectory tiles: runs on the feature-split forward kernel)
         out["also_configs1_K1024_N50"] = secondary(psp, dev, WORKLOADS["hjb_llgc_d100_K1024_N50_h64"])
+    if world == 1 and x3 and not args.no_secondary:
+        # the same workload on the fp32-MFMA kernels (Solver(mlp_dtype='fp32')), same process, for comparison
+        w32 = dict(w)
+        w32["mlp"] = "fp32"
+        out["also_fp32_mfma_kernels"] = secondary(psp, dev, w32, steps=args.steps, warmup=min(args.warmup, 3))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)
-        out["loss_rel_err_vs_cpu_ref"] = loss_rel_err_vs_cpu(psp, dev, w)
+        out["loss_rel_err_vs_cpu_ref"] = loss_rel_err_vs_cpu(psp, dev, w, getattr(plan, "matrix_mode", "fp32"))
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     sys.stdout.flush()

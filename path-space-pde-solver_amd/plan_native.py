@@ -144,12 +144,27 @@ class HjbNativePlan:
         self.attached = bool(solver.adaptive_forward_process and not solver.detach_forward)
         cfg.noise_mode = nat.NOISE_PHILOX if noise == 'philox' else nat.NOISE_SUPPLIED
         cfg.store_path = 3 if self.relent else (2 if self.attached else 1)
-        cfg.mlp_dtype = {'fp32': nat.MLP_FP32, 'bf16': nat.MLP_BF16_FWD, 'f16x3': nat.MLP_F16X3}[getattr(solver, 'mlp_dtype', 'fp32')]
+        # matrix products: 'fp32' = v_mfma_f32_16x16x4_f32; 'f16x3' = fp32-grade split products on the f16 pipe (three
+        # v_mfma_f32_16x16x32_f16 per fp32 product, csrc/hjb_kernels.h gemm_Tx, csrc/hjbx_kernels.h -- same parity bounds);
+        # 'auto' (the default) = 'f16x3' where those kernels exist, fit the LDS and the tile-per-wave forward would run anyway
+        # (more than two 16-trajectory tiles per CU: the small-K forward kernels are fp32 only), else 'fp32'
+        want = getattr(solver, 'mlp_dtype', 'auto')
+        cfg.mlp_dtype = {'auto': nat.MLP_FP32, 'fp32': nat.MLP_FP32, 'bf16': nat.MLP_BF16_FWD, 'f16x3': nat.MLP_F16X3}[want]
         # kernel instance: the exact (d, H) if compiled, else the cheapest larger one (zero padding, native_shapes.py)
         chosen, why = shapes.choose(cfg, solver.d, self.H)
         if chosen is None:
             raise PlanUnsupported(why)
         self.d_pad, self.H_pad, self.family, sizes = chosen
+        if want == 'auto' and self.family == 1 and torch.device(dev).type == 'cuda':
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            if (self.K_local + 15) // 16 > 2 * cus:
+                cfg.mlp_dtype = nat.MLP_F16X3
+                rc, sizes_x3, _ = nat.query_rc(cfg)
+                if rc == 0:
+                    sizes = sizes_x3
+                else:
+                    cfg.mlp_dtype = nat.MLP_FP32
+        self.matrix_mode = {nat.MLP_FP32: 'fp32', nat.MLP_BF16_FWD: 'bf16', nat.MLP_F16X3: 'f16x3'}[cfg.mlp_dtype]
         self.pad = shapes.ParamPad(solver.d, self.H, self.d_pad, self.H_pad, dev)
         pad = self.pad
         cfg.drift = nat.ptr(dev_f32(pad.drift_or_sigma(spec['drift'][1]))) if spec['drift'][1] is not None else None

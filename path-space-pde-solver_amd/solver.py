@@ -63,7 +63,7 @@ class Solver:
                  IS_variance_K=0, IS_variance_iter=1, metastability_logs=None, print_every=100,
                  plot_trajectories=None, seed=42, save_results=False, u_l2_error_flag=True,
                  log_gradient=False, burgers_drift=False, verbose=True,
-                 device=None, backend='auto', noise='reference', widths=(30, 30), mlp_dtype='fp32',
+                 device=None, backend='auto', noise='reference', widths=(30, 30), mlp_dtype='auto',
                  path_budget_bytes=None, path_chunks=None, chunk_mode='auto', use_graph='auto'):
         self.problem, self.name = problem, name
         self.date = date.today().strftime('%Y-%m-%d')
@@ -77,9 +77,12 @@ class Solver:
         if noise not in ('reference', 'philox'):
             raise ValueError("noise must be 'reference' or 'philox'")
         self.backend, self.noise = backend, noise
-        if mlp_dtype not in ('fp32', 'bf16', 'f16x3'):
-            raise ValueError("mlp_dtype must be 'fp32', 'f16x3' or 'bf16'")
-        self.mlp_dtype = mlp_dtype       # 'bf16': control-net products of the native forward rollout on bf16 MFMA (opt-in, own tolerance)
+        if mlp_dtype not in ('auto', 'fp32', 'bf16', 'f16x3'):
+            raise ValueError("mlp_dtype must be 'auto', 'fp32', 'f16x3' or 'bf16'")
+        # matrix products of the native HJB kernels: 'fp32' (fp32 MFMA), 'f16x3' (fp32-grade split products on the f16 matrix pipe,
+        # same parity bounds, ~1.8x faster at large K), 'auto' (f16x3 where it exists and pays, plan_native.py); 'bf16': control-net
+        # products of the forward rollout on bf16 MFMA (opt-in, own tolerance)
+        self.mlp_dtype = mlp_dtype
         # native plan: HBM budget of the path store kept for the backward pass (None: a third of the HBM); a larger store is
         # processed in K-chunks (plan_native.py).  path_chunks forces a chunk count; chunk_mode 'auto' | 'two_gradient' | 'recompute'
         self.path_budget_bytes, self.path_chunks, self.chunk_mode = path_budget_bytes, path_chunks, chunk_mode
