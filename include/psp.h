@@ -91,10 +91,17 @@ typedef struct psp_hjb_config {
                            * (LLGC, problems.py:51-53); enables the u_L2 log of solver.py:491-494 inside the
                            * forward kernels.  NULL: no logging                                             */
     float* u_l2_out;      /* (K_local): sum_n |-Z_n(X_n) - u*(t_n)|^2 dt per trajectory (mean = u_L2_loss)  */
-    int32_t mlp_dtype;    /* PSP_MLP_FP32 (0, the default and the only setting the 1e-4 parity bar applies to), or
+    int32_t mlp_dtype;    /* how the matrix products are computed (accumulation is fp32 in every mode):
+                           * PSP_MLP_FP32 (0): v_mfma_f32_16x16x4_f32.
+                           * PSP_MLP_F16X3: fp32-GRADE split products on the f16 matrix pipe -- every operand x = hi + lo / 2048 as
+                           * two f16 numbers, a.b = hi.hi + (hi.lo + lo.hi) / 2048 as three v_mfma_f32_16x16x32_f16 (16x the
+                           * fp32 matrix rate); same parity bounds as PSP_MLP_FP32 (D within 2e-5, gradient 2e-4, loss 1e-4 of the
+                           * reference; observed 1e-6), operands must stay below 65504 in magnitude.  Forward (hjb_fwd_kernel mode 2)
+                           * and backward (hjb_bwd3_kernel) of the narrow family, tile-per-wave forward only; -3 where the instance
+                           * does not have it or its tables do not fit the LDS.
                            * PSP_MLP_BF16_FWD: the three products of the control net in the FORWARD rollout on
-                           * v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulate); drift / sigma products, state,
-                           * sums and the backward pass stay fp32.  Narrow kernel family only (-3 otherwise)          */
+                           * v_mfma_f32_16x16x32_bf16 (bf16 operands: its OWN tolerance, not the 1e-4 bar); drift / sigma
+                           * products, state, sums and the backward pass stay fp32.  Narrow kernel family only (-3 otherwise) */
     int32_t reserved2;
     const uint32_t* iter_dev; /* optional DEVICE-resident iteration counter (the `iter` member of a psp_iter_state): when set, the
                            * forward kernels key Philox with *iter_dev instead of the `iter` argument, so that a captured
