@@ -21,6 +21,7 @@
         r.launch_fwd_x3 = &psp::HjbLaunch<D_, H_>::fwd_x3;                                 \
         r.bwd2_x3_lds_bytes = &psp::HjbxLaunch<D_, H_>::lds_bytes;                         \
         r.launch_bwd2_x3 = &psp::HjbxLaunch<D_, H_>::bwd;                                  \
+        r.launch_adj_x3 = &psp::HjbaLaunch<D_, H_>::adj_x3;                                \
         r.quad_lds_bytes = &psp::HjbqLaunch<D_, H_>::lds_bytes;                            \
         r.launch_fwd_quad = &psp::HjbqLaunch<D_, H_>::fwd;                                 \
         r.launch_adj_quad = &psp::HjbqLaunch<D_, H_>::adj;                                 \

@@ -1645,6 +1645,7 @@ struct HjbInstance {
     hipError_t (*launch_fwd_x3)(const HjbArgs&, int grid, int block, hipStream_t);
     int (*bwd2_x3_lds_bytes)();                                                        // split-product backward, hjbx_kernels.h
     hipError_t (*launch_bwd2_x3)(const HjbArgs&, int grid, hipStream_t);               // (null: not built)
+    hipError_t (*launch_adj_x3)(const HjbArgs&, int grid, int block, hipStream_t);     // split-product adjoint sweep (same LDS as the forward)
 };
 
 template <int D, int H>

@@ -21,10 +21,15 @@
 
 namespace psp {
 
-template <int D, int H>
+// X3 (psp_hjb_config.mlp_dtype = PSP_MLP_F16X3): the five products as split f16 products (gemm_Tx, hjb_kernels.h) on tables in the
+// split-product forward's LDS carve.  The recursion is linear in the trajectory weights (mu, nu, wT ~ 1 / K: lambda would sit below
+// the f16 normal range), so each wave scales them by a power of two taken from the largest weight of its 16 trajectories and scales
+// the image it writes back -- exact.
+template <int D, int H, bool X3 = false>
 __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
+    constexpr int VSH = X3 ? G::xVec - G::fVec : 0;    // the vectors and the d x d tables follow the (larger) split tables
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
@@ -32,47 +37,75 @@ __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
     const float* __restrict__ P = a.params;
 
     // transposed A-operand tables in the forward kernel's LDS carve (same sizes, orientations swapped)
-    float* tW3T = lds + G::fW1;                        // HB x KSD : W3^T
-    float* tW2T = lds + G::fW2;                        // HB x KSH : W2^T
-    float* tW1T = lds + G::fW3;                        // DB x KSH : W1x^T
-    float* tAT = lds + G::fA;                          // DB x KSD : (dt A)^T
-    float* tBT = tAT + (a.drift_kind == DRIFT_DENSE ? G::fB_dense_off : 0);
-    stage_aop(tW3T, HB, KSD, tid, nthr, [&](int row, int col) {
+    float* tW3T = lds + (X3 ? G::xW1 : G::fW1);        // HB x KSD : W3^T
+    float* tW2T = lds + (X3 ? G::xW2 : G::fW2);        // HB x KSH : W2^T
+    float* tW1T = lds + (X3 ? G::xW3 : G::fW3);        // DB x KSH : W1x^T
+    float* tAT = lds + G::fA + VSH;                    // DB x KSD : (dt A)^T
+    float* tBT = tAT + (a.drift_kind == DRIFT_DENSE ? (X3 ? G::xB_dense_off : G::fB_dense_off) : 0);
+    auto stage = [&](float* dst, auto ksc, auto inbc, int MB, auto src) __attribute__((always_inline)) {
+        constexpr int KS = decltype(ksc)::value, INB = decltype(inbc)::value;
+        if constexpr (X3) stage_aop_x3<KS, INB>(dst, MB, tid, nthr, src);
+        else stage_aop(dst, MB, KS, tid, nthr, src);
+    };
+    using cKSD = std::integral_constant<int, KSD>;
+    using cKSH = std::integral_constant<int, KSH>;
+    using cDB = std::integral_constant<int, DB>;
+    using cHB = std::integral_constant<int, HB>;
+    stage(tW3T, cKSD{}, cDB{}, HB, [&](int row, int col) {
         return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
-    stage_aop(tW2T, HB, KSH, tid, nthr, [&](int row, int col) {
+    stage(tW2T, cKSH{}, cHB{}, HB, [&](int row, int col) {
         return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
-    stage_aop(tW1T, DB, KSH, tid, nthr, [&](int row, int col) {
+    stage(tW1T, cKSH{}, cHB{}, DB, [&](int row, int col) {
         return (row < D && col < H) ? P[G::oW1 + col * (D + 1) + 1 + row] : 0.f; });
     if (a.drift_kind == DRIFT_DENSE) {
         const float dt = a.dt;
         const float* __restrict__ A = a.drift;
-        stage_aop(tAT, DB, KSD, tid, nthr, [&](int row, int col) {
+        stage(tAT, cKSD{}, cDB{}, DB, [&](int row, int col) {
             return (row < D && col < D) ? dt * A[col * D + row] : 0.f; });
     }
     if (a.sigma_kind == SIGMA_DENSE) {
         const float* __restrict__ B = a.sigma;
-        stage_aop(tBT, DB, KSD, tid, nthr, [&](int row, int col) {
+        stage(tBT, cKSD{}, cDB{}, DB, [&](int row, int col) {
             return (row < D && col < D) ? B[col * D + row] : 0.f; });
     }
-    stage_vec(lds + G::vdr, DB, tid, nthr, [&](int f) {
+    stage_vec(lds + VSH + G::vdr, DB, tid, nthr, [&](int f) {
         return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
-    stage_vec(lds + G::vrun, DB, tid, nthr, [&](int f) {
+    stage_vec(lds + VSH + G::vrun, DB, tid, nthr, [&](int f) {
         return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
-    stage_vec(lds + G::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
+    stage_vec(lds + VSH + G::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
     __syncthreads();
 
     const int t16 = blockIdx.x * nwave + wave;
     if (t16 >= a.ntile16) return;
     const int k = t16 * 16 + j;
     const bool kvalid = k < a.K_local;
-    const float dt = a.dt, sqdt = a.sqdt, rsq = 1.0f / a.sqdt;
-    const float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
-    const float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    const float dt = a.dt, sqdt = a.sqdt;
+    float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
+    float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    float wT = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);            // weight of grad g(X_N) in lambda_N
+    float ginv = 1.0f;
+    if constexpr (X3) {
+        float am = fmaxf(fmaxf(fabsf(mu), fabsf(nu)), fabsf(wT));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+        const unsigned e = (__float_as_uint(am) >> 23) & 0xFFu;
+        if (e >= 1u && e <= 253u) {
+            const float gs = __uint_as_float((254u - e) << 23);
+            ginv = __uint_as_float(e << 23);
+            mu *= gs; nu *= gs; wT *= gs;
+        }
+    }
     const float coefW = (a.store_path == 3) ? nu * dt : mu * sqdt;
     const float wf = (mu + nu) * dt;                   // weight of grad f(X_{n+1})
-    const float wT = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);      // weight of grad g(X_N) in lambda_N
+    const float rsq = ginv / a.sqdt;
     const bool need_x = a.runcost_kind == RUN_DIAGQ || a.drift_kind == DRIFT_DWELL;
-    const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::fVec) + q;
+    const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + VSH + G::fVec) + q;
+    auto prod = [&](auto& acc, auto ksc, const float* tbl, const auto& in) __attribute__((always_inline)) {
+        constexpr int KS = decltype(ksc)::value;
+        constexpr int MB = sizeof(acc) / sizeof(f32x4), INB = sizeof(in) / sizeof(f32x4);
+        if constexpr (X3) gemm_Tx<MB, KS, INB>(acc, tbl, in, lane);
+        else gemm_T<MB, KS, INB>(acc, tbl, in, lane);
+    };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // lambda_N = (nu - mu) grad g(X_N)   (problems.py:49,164,334) and X_N for grad f at the last step
@@ -112,7 +145,7 @@ __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
         if (a.sigma_kind == SIGMA_DENSE) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) qv[b] = zero4;
-            gemm_T<DB, KSD, DB>(qv, tBT, lam, lane);
+            prod(qv, cKSD{}, tBT, lam);
         } else if (a.sigma_kind == SIGMA_SCALE) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) qv[b] = a.sigma_scale * lam[b];
@@ -141,7 +174,7 @@ __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
                 for (int r = 0; r < 4; ++r) h2[m][r] = pblk[G::pH2 + (4 * m + r) * 64];
 #pragma unroll
             for (int m = 0; m < HB; ++m) dz2[m] = zero4;
-            gemm_T<HB, KSD, DB>(dz2, tW3T, gz, lane);
+            prod(dz2, cKSD{}, tW3T, gz);
 #pragma unroll
             for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
         }
@@ -153,7 +186,7 @@ __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
                 for (int r = 0; r < 4; ++r) h1[m][r] = pblk[G::pH1 + (4 * m + r) * 64];
 #pragma unroll
             for (int m = 0; m < HB; ++m) dz1[m] = zero4;
-            gemm_T<HB, KSH, HB>(dz1, tW2T, dz2, lane);
+            prod(dz1, cKSH{}, tW2T, dz2);
 #pragma unroll
             for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
         }
@@ -161,7 +194,7 @@ __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
         f32x4 ln[DB];
 #pragma unroll
         for (int b = 0; b < DB; ++b) ln[b] = lam[b];
-        gemm_T<DB, KSH, HB>(ln, tW1T, dz1, lane);
+        prod(ln, cKSH{}, tW1T, dz1);
         if (need_x) {
 #pragma unroll
             for (int b = 0; b < DB; ++b)
@@ -169,7 +202,7 @@ __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
                 for (int r = 0; r < 4; ++r) Xn1[b][r] = pblk[G::pX + (4 * b + r) * 64];          // X_n
         }
         if (a.drift_kind == DRIFT_DENSE) {
-            gemm_T<DB, KSD, DB>(ln, tAT, lam, lane);
+            prod(ln, cKSD{}, tAT, lam);
         } else if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) ln[b] += dt * (vdr[b * 4] * lam[b]);
@@ -185,14 +218,17 @@ __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
 template <int D, int H>
 struct HjbaLaunch {
     using G = Geo<D, H>;
-    static hipError_t adj(const HjbArgs& a, int grid, int block, hipStream_t s) {
-        const int bytes = G::fwd_lds_floats(a.drift_kind, a.sigma_kind) * 4;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_adj_kernel<D, H>),
+    template <bool X3>
+    static hipError_t adj_as(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        const int bytes = (X3 ? G::fwd_x3_lds_floats(a.drift_kind, a.sigma_kind) : G::fwd_lds_floats(a.drift_kind, a.sigma_kind)) * 4;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_adj_kernel<D, H, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjb_adj_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
+        hipLaunchKernelGGL((hjb_adj_kernel<D, H, X3>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
+    static hipError_t adj(const HjbArgs& a, int grid, int block, hipStream_t s) { return adj_as<false>(a, grid, block, s); }
+    static hipError_t adj_x3(const HjbArgs& a, int grid, int block, hipStream_t s) { return adj_as<true>(a, grid, block, s); }
 };
 
 }  // namespace psp
