@@ -139,7 +139,7 @@ def issued_mfma_per_tile_step(d_pad, H_pad, dense, family, bf16_mlp=False):
     return net + sde, 0, bwd
 
 
-def issued_mfma_x3(d_pad, H_pad, dense):
+def issued_mfma_x3(d_pad, H_pad, dense, family=1):
     """Split-product kernels (hjb_fwd_kernel<.., 2, ..>, hjb_bwd3_kernel): MFMA instructions per tile-step from SplitGeo in
     csrc/hjb_kernels.h -- a contraction over K features runs K // 32 steps of three v_mfma_f32_16x16x32_f16 per 16-row block;
     an odd trailing 16-feature block is one exact fp32 k-step when it holds at most four features, else three
@@ -155,6 +155,12 @@ def issued_mfma_x3(d_pad, H_pad, dense):
     def add(*ds):
         return {k: sum(d[k] for d in ds) for k in ("f16_32", "f16_16", "f32")}
 
+    if family == 2:
+        # wide family (hjbw_fwd_kernel<.., X3>): S-steps of 32 features over whole 16-blocks (KS8 = ceil(DB / 2)), three MFMAs per
+        # (S, output block); its backward kernels stay on fp32 MFMA
+        ks8 = _cdiv(DB, 2)
+        n = 3 * (ks8 * HB + 2 * HB + 2 * DB + (2 * ks8 * DB if dense else 0))
+        return {"f16_32": n, "f16_16": 0, "f32": 0}, None
     fwd = add(prod(d_pad, HB), prod(H_pad, HB), prod(H_pad, DB), *([prod(d_pad, DB)] * (2 if dense else 0)))
     # backward: producers W3^T G and W2^T dz2 per block; consumers, per PAIR of blocks and wave, three MFMAs per owned tile
     # (dW3: DB, dW2: HB, dW1: HB x ceil(DB / 4)), four waves
@@ -555,8 +561,9 @@ def main():
         bwd_name = ("hjbw_bwd2_kernel" if plan.d_pad <= 256 else "hjbw_bwd_kernel") if plan.family == 2 else "hjb_bwd2_kernel"
         issued = issued_mfma_per_tile_step(plan.d_pad, plan.H_pad, dense, plan.family, bf16_mlp)
         if x3:
-            bwd_name = "hjb_bwd3_kernel"
-            issued_x3 = issued_mfma_x3(plan.d_pad, plan.H_pad, dense)
+            if plan.family != 2:
+                bwd_name = "hjb_bwd3_kernel"
+            issued_x3 = issued_mfma_x3(plan.d_pad, plan.H_pad, dense, plan.family)
         if quad:
             issued = (issued_mfma_quad_kernel(plan.d_pad, plan.H_pad, dense), 0, issued[2])
     bwd_dominant = bwd_ms >= fwd_ms
@@ -567,7 +574,7 @@ def main():
         mf["frac"] = mf["achieved"] / mf["peak"]
         mf["frac_issued"] = None
         mf["frac_survey_m3"] = fl3[which] * units_launch / t / 1e12 / mf["peak"]
-    elif x3:
+    elif x3 and not (which == "bwd_kernel" and issued_x3[1] is None):
         mf = x3_roofline(fl2, fl3, issued_x3, units_launch, tiles_steps, dom_ms, which)
     else:
         mf = mfma_roofline(fl2, fl3, issued, units_launch, tiles_steps, dom_ms, bf16_mlp, which)
@@ -613,7 +620,9 @@ def main():
                    "matrix_products": ("fp32-grade split products on the f16 matrix pipe: x = hi + lo/2048 (two f16 numbers), "
                                        "a.b = hi.hi + (hi.lo + lo.hi)/2048 as three v_mfma_f32_16x16x32_f16 with fp32 accumulation "
                                        "(product error 1.07x that of v_mfma_f32_16x16x4_f32; same parity bounds, "
-                                       "tests/test_gpu_split_product.py); state, sums and the path store are fp32") if x3 else
+                                       "tests/test_gpu_split_product.py); state, sums and the path store are fp32"
+                                       + ("; forward kernel only (the wide family's backward runs v_mfma_f32_16x16x4_f32)"
+                                          if plan.family == 2 else "")) if x3 else
                                       ("v_mfma_f32_16x16x32_bf16 for the control net, v_mfma_f32_16x16x4_f32 elsewhere" if bf16_mlp
                                        else "v_mfma_f32_16x16x4_f32"),
                    "launch": "hipGraph replay of the captured iteration" if graph else "eager launches",

@@ -43,6 +43,13 @@ struct GeoW {
     static constexpr int vb1 = 0, vw1t = vb1 + HB * 16, vb2 = vw1t + HB * 16, vb3 = vb2 + HB * 16,
                          vdr = vb3 + DB * 16, vrun = vdr + DB * 16, vterm = vrun + DB * 16, fRed = vterm + DB * 16,
                          fImg = fRed + 64, IMG = KP * 64, fwd_lds_floats = fImg + 4 * IMG;
+    // split-product forward (hjbw_fwd_kernel<.., X3>): S-step-major tables, element ((S * MB + mb) * 2 + hi/lo) * 64 + lane of
+    // f16x8 (one S-step = 32 features = two 16-feature blocks; an odd last block leaves the upper half zero), and the wave's
+    // input image as hi / lo packs [S][hi | lo][64] of f16x8
+    static constexpr int KS8 = cdiv(DB, 2);
+    static constexpr int xW1 = 0, xW2 = xW1 + KS8 * HB * 512, xW3 = xW2 + 2 * HB * 512, xA = xW3 + 2 * DB * 512,
+                         xB = xA + KS8 * DB * 512, fwd_x3_table_floats = xB + KS8 * DB * 512;
+    static constexpr int IMGX = KS8 * 512, fwd_x3_lds_floats = fImg + 4 * IMGX;
     // backward LDS (floats): dz2 k-step images of the four blocks of a round, double-buffered; bias staging reuses it
     static constexpr int EXB = 4 * HB * 64, bwd_lds_floats = 2 * 4 * EXB + 4 * 16 * DB;
 };
@@ -70,6 +77,46 @@ __global__ __launch_bounds__(256) void hjbw_tables_kernel(const HjbArgs a, int b
     if (backward == 1) {
         table_fill(T, W::HB, W::KP, gtid, gs, [&](int row, int col) {
             return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+        return;
+    }
+    if (backward == 3) {                               // split-product forward tables (hi / lo f16 images)
+        auto fill = [&](float* dstf, int MB, int NS, auto src) {
+            f16x8* dst = reinterpret_cast<f16x8*>(dstf);
+            const long long total = (long long)NS * MB * 64;
+            for (long long idx = gtid; idx < total; idx += gs) {
+                const int lane = (int)(idx & 63);
+                const int t = (int)(idx >> 6);
+                const int mb = t % MB, S = t / MB;
+                const int i = lane & 15, g = lane >> 4;
+                const int row = 16 * mb + 4 * (i & 3) + (i >> 2);
+                f16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 h, l;
+                    split_f16(src(row, 32 * S + (e < 4 ? 4 * e : 16 + 4 * (e - 4)) + g), h, l);
+                    hi[e] = h; lo[e] = l;
+                }
+                dst[((long long)t * 2) * 64 + lane] = hi;
+                dst[((long long)t * 2 + 1) * 64 + lane] = lo;
+            }
+        };
+        fill(T + W::xW1, W::HB, W::KS8, [&](int row, int col) {
+            return (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f; });
+        fill(T + W::xW2, W::HB, 2, [&](int row, int col) {
+            return (row < H && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
+        fill(T + W::xW3, W::DB, 2, [&](int row, int col) {
+            return (row < D && col < H) ? P[G::oW3 + row * H + col] : 0.f; });
+        if (a.drift_kind == DRIFT_DENSE) {
+            const float dt = a.dt;
+            const float* __restrict__ A = a.drift;
+            fill(T + W::xA, W::DB, W::KS8, [&](int row, int col) {
+                return (row < D && col < D) ? dt * A[row * D + col] : 0.f; });
+        }
+        if (a.sigma_kind == SIGMA_DENSE) {
+            const float* __restrict__ B = a.sigma;
+            fill(T + W::xB, W::DB, W::KS8, [&](int row, int col) {
+                return (row < D && col < D) ? B[row * D + col] : 0.f; });
+        }
         return;
     }
     if (backward == 2) {                               // adjoint sweep: B^T, (dt A)^T, W3^T, W2^T, W1x^T
@@ -217,6 +264,117 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
     }
 }
 
+// ---- split-product versions (three v_mfma_f32_16x16x32_f16 per fp32 product; the split and its error are described at gemm_Tx
+// in hjb_kernels.h).  Tables: S-step-major hi / lo images in global memory (GeoW::xW1 ...), 2 KiB per (S, output block).
+typedef const __attribute__((address_space(1))) f16x8* gptr8_t;
+__device__ __forceinline__ gptr8_t sgpr_ptr8(const float* p) {
+    unsigned long long addr = (unsigned long long)p;
+    asm volatile("" : "+s"(addr));
+    return (gptr8_t)addr;
+}
+__device__ __forceinline__ void split_pack(const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split_f16(u0[e], h, l);
+        hi[e] = h; lo[e] = l;
+        split_f16(u1[e], h, l);
+        hi[4 + e] = h; lo[4 + e] = l;
+    }
+}
+// acc[MB] += T . img over KS8 S-steps; img: this wave's LDS image of hi / lo packs.  Rolled over S; within an S-step the output
+// blocks run in chunks of CH with the operands of the next chunk (or of the next S-step's first chunk) requested one chunk ahead.
+template <int MB, int KS8, int LD = MB>
+__device__ __forceinline__ void gemm_img_x3(f32x4 (&acc)[MB], const float* __restrict__ tbl, const float* img, int lane) {
+    constexpr int CH = MB >= 4 ? 4 : MB;                                // (8 spills at d = 500 and under the 256-register cap of d <= 256)
+    constexpr int NC = cdiv(MB, CH);
+    f16x8 ah[2][CH], al[2][CH], bh[2], bl[2];
+    f32x4 corr[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) corr[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned ul = (unsigned)lane;
+    tbl = opaque_base(tbl);
+    const f16x8* imgp = reinterpret_cast<const f16x8*>(img) + lane;
+    auto load_a = [&](int st, int S, int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < CH; m += 2) {                               // fresh SGPR base every 4 KiB (two output blocks)
+            if (c * CH + m < MB) {
+                gptr8_t tp = sgpr_ptr8(tbl + ((size_t)S * LD + c * CH + m) * 512);
+                ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
+                if (m + 1 < CH && c * CH + m + 1 < MB) { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul]; }
+            }
+        }
+    };
+    auto load_b = [&](int st, int S) __attribute__((always_inline)) {
+        bh[st] = imgp[(S * 2) * 64]; bl[st] = imgp[(S * 2 + 1) * 64];
+    };
+    load_b(0, 0);
+    load_a(0, 0, 0);
+#pragma unroll 1
+    for (int S = 0; S < KS8; S += 2) {                                  // two S-steps per trip: static ring indices
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int Sc = S + h;
+            if (Sc < KS8) {
+                const int Sn = Sc + 1 < KS8 ? Sc + 1 : KS8 - 1;         // past the end: re-read the last step (unused)
+                load_b((h + 1) & 1, Sn);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int cur = (h * NC + c) & 1, nxt = cur ^ 1;
+                    if (c + 1 < NC) load_a(nxt, Sc, c + 1);
+                    else load_a(nxt, Sn, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < CH; ++m) {
+                        const int mb = c * CH + m;
+                        if (mb < MB) {
+                            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bh[h & 1], acc[mb], 0, 0, 0);
+                            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bl[h & 1], corr[mb], 0, 0, 0);
+                            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][m], bh[h & 1], corr[mb], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = acc[mb] + kSplitInv * corr[mb];
+}
+// acc[MB] += T . in, in: register panel of INB <= 4 blocks (the hidden layers: two S-steps), fully unrolled
+template <int MB, int INB, int LD = MB>
+__device__ __forceinline__ void gemm_regs_x3(f32x4 (&acc)[MB], const float* __restrict__ tbl, const f32x4 (&in)[INB], int lane) {
+    constexpr int NS = (INB + 1) / 2;
+    const unsigned ul = (unsigned)lane;
+    tbl = opaque_base(tbl);
+    f32x4 corr[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) corr[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+        f16x8 ah[MB], al[MB];
+#pragma unroll
+        for (int m = 0; m < MB; m += 2) {
+            gptr8_t tp = sgpr_ptr8(tbl + ((size_t)S * LD + m) * 512);
+            ah[m] = tp[ul]; al[m] = tp[64 + ul];
+            if (m + 1 < MB) { ah[m + 1] = tp[128 + ul]; al[m + 1] = tp[192 + ul]; }
+        }
+        f16x8 bh, bl;
+        split_pack(in[2 * S], (2 * S + 1 < INB) ? in[(2 * S + 1 < INB) ? 2 * S + 1 : 0] : zero4, bh, bl);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], bh, acc[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mb], bl, corr[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mb], bh, corr[mb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = acc[mb] + kSplitInv * corr[mb];
+}
+
 // The four waves of a workgroup stream the SAME operand tables in the same order, each for its own tile.  A workgroup
 // barrier in front of every long product keeps them within a few k-steps of one another, so that a table line one wave
 // misses in the CU's vector L1 is a hit (or a merged in-flight miss) for the other three: the L2 -> L1 stream, which bounds
@@ -237,7 +395,8 @@ __device__ __forceinline__ void gemm_img(f32x4 (&acc)[MB], const float* __restri
 // LOGU: the u_L2 log of solver.py:491-494 (psp_hjb_config.u_ref); a separate instantiation because at d = 500 the kernel
 // sits on the 512-register limit and two more live accumulators cost the ordinary path 8 % (measured)
 // FAST: Philox noise and no time-feature table, decided at launch (no conditional loads and joins in the time loop; training)
-template <int D, int H, bool LOGU = false, bool FAST = false>
+// X3: every product as split f16 products (psp_hjb_config.mlp_dtype = PSP_MLP_F16X3; tables built by hjbw_tables_kernel(.., 3))
+template <int D, int H, bool LOGU = false, bool FAST = false, bool X3 = false>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const HjbArgs a) {
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
@@ -268,7 +427,9 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
     const bool kvalid = wave_valid && k < a.K_local;
     const uint32_t kglob = (uint32_t)(a.k_offset + k);
     const float dt = a.dt, sqdt = a.sqdt;
-    float* img = lds + W::fImg + wave * W::IMG;       // this wave's input image [KP][64]
+    float* img = lds + W::fImg + wave * (X3 ? W::IMGX : W::IMG);       // this wave's input image [KP][64] (X3: hi / lo packs)
+    [[maybe_unused]] f16x8* img8 = reinterpret_cast<f16x8*>(img) + lane;
+    [[maybe_unused]] const f32x4 zero4x = {0.f, 0.f, 0.f, 0.f};
     const bool store_path = a.store_path && wave_valid;
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;
     const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
@@ -315,8 +476,17 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
             };
             const unsigned ul = (unsigned)lane;
             // X_n: LDS image (B operand of the W1 and drift products) and path store
+            if constexpr (X3) {
 #pragma unroll
-            for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = X[ks >> 2][ks & 3];
+                for (int S = 0; S < W::KS8; ++S) {
+                    f16x8 ph, pl;
+                    split_pack(X[2 * S], (2 * S + 1 < DB) ? X[(2 * S + 1 < DB) ? 2 * S + 1 : 0] : zero4x, ph, pl);
+                    img8[(2 * S) * 64] = ph; img8[(2 * S + 1) * 64] = pl;
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = X[ks >> 2][ks & 3];
+            }
             if (store_path) {
 #pragma unroll
                 for (int g = 0; g < KP / 16 + 1; ++g) {               // fresh SGPR base every 4 KiB: immediates stay < 4096
@@ -332,12 +502,14 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
             PSP_WIDE_SYNC();
-            gemm_img<HB, KP>(h1, T + W::tW1, img, lane);
+            if constexpr (X3) gemm_img_x3<HB, W::KS8>(h1, T + W::xW1, img, lane);
+            else gemm_img<HB, KP>(h1, T + W::tW1, img, lane);
             PSP_STAMP(ws2);
             // ---- X_{n+1} = X + b(X) dt + sigma v (solver.py:471-472): the drift part now, while the image still holds X_n
             if (a.drift_kind == DRIFT_DENSE) {
                 PSP_WIDE_SYNC();
-                gemm_img<DB, KP>(X, T + W::tA, img, lane);                       // X += (dt A) X_n
+                if constexpr (X3) gemm_img_x3<DB, W::KS8>(X, T + W::xA, img, lane);
+                else gemm_img<DB, KP>(X, T + W::tA, img, lane);                  // X += (dt A) X_n
             } else if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) X[b] += dt * (vdr[b * 4] * X[b]);
@@ -351,7 +523,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
             f32x4 h2[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
-            gemm_regs<HB, 16, HB>(h2, T + W::tW2, h1, lane);
+            if constexpr (X3) gemm_regs_x3<HB, HB>(h2, T + W::xW2, h1, lane);
+            else gemm_regs<HB, 16, HB>(h2, T + W::tW2, h1, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
             if (store_path) {
@@ -373,7 +546,9 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
                 f32x4 Zg[NB];
 #pragma unroll
                 for (int m = 0; m < NB; ++m) Zg[m] = vb3[(4 * g + m) * 4];
-                gemm_regs<NB, 16, HB, DB>(Zg, T + W::tW3 + 4 * g * 64, h2, lane);
+                if constexpr (X3) gemm_regs_x3<NB, HB, DB>(Zg, T + W::xW3 + 4 * g * 512, h2, lane);
+                else gemm_regs<NB, 16, HB, DB>(Zg, T + W::tW3 + 4 * g * 64, h2, lane);
+                [[maybe_unused]] f32x4 vg[4] = {zero4x, zero4x, zero4x, zero4x};
 #pragma unroll
                 for (int m = 0; m < NB; ++m) {
                     const int b = 4 * g + m;
@@ -415,12 +590,25 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
                     }
                     const f32x4 v = a.adaptive ? (sqdt * xi - dt * Zg[m]) : (sqdt * xi);
                     if (a.sigma_kind == SIGMA_DENSE) {
+                        if constexpr (X3) vg[m] = v;
+                        else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) img[(4 * b + r) * 64 + lane] = v[r];
+                            for (int r = 0; r < 4; ++r) img[(4 * b + r) * 64 + lane] = v[r];
+                        }
                     } else if (a.sigma_kind == SIGMA_SCALE) {
                         X[b] += a.sigma_scale * v;
                     } else {
                         X[b] += v;
+                    }
+                }
+                if constexpr (X3) {                    // increment panel of this group as hi / lo packs (two S-steps per group)
+                    if (a.sigma_kind == SIGMA_DENSE) {
+#pragma unroll
+                        for (int s2 = 0; s2 < (NB + 1) / 2; ++s2) {
+                            f16x8 ph, pl;
+                            split_pack(vg[2 * s2], vg[2 * s2 + 1], ph, pl);
+                            img8[(2 * (2 * g + s2)) * 64] = ph; img8[(2 * (2 * g + s2) + 1) * 64] = pl;
+                        }
                     }
                 }
             };
@@ -433,7 +621,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
             PSP_STAMP(ws5);
             if (a.sigma_kind == SIGMA_DENSE) {
                 PSP_WIDE_SYNC();
-                gemm_img<DB, KP>(X, T + W::tB, img, lane);     // X += B v
+                if constexpr (X3) gemm_img_x3<DB, W::KS8>(X, T + W::xB, img, lane);
+                else gemm_img<DB, KP>(X, T + W::tB, img, lane); // X += B v
             }
 
             // ---- running cost f(X_{n+1}) and Y update (solver.py:477-478)
@@ -1243,6 +1432,26 @@ struct HjbwLaunch {
         hipLaunchKernelGGL((hjbw_fwd_kernel<D, H, false>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
+    // split-product forward (training launches and supplied-noise runs; the u_L2-logging instance stays fp32)
+    static int fwd_x3_lds(int, int) { return W::fwd_x3_lds_floats * 4; }
+    static hipError_t fwd_x3(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        if (a.uref) return fwd(a, grid, block, s);
+        hipError_t e = tables(a, 3, s);
+        if (e != hipSuccess) return e;
+        const int bytes = W::fwd_x3_lds_floats * 4;
+        if (a.noise_mode == NOISE_PHILOX && a.tfeat == nullptr) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, false, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((hjbw_fwd_kernel<D, H, false, true, true>), dim3(grid), dim3(block), bytes, s, a);
+            return hipGetLastError();
+        }
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbw_fwd_kernel<D, H, false, false, true>), dim3(grid), dim3(block), bytes, s, a);
+        return hipGetLastError();
+    }
     static hipError_t bwd(const HjbArgs&, int, int, hipStream_t) { return hipErrorNotSupported; }
     // d <= 256: the role-specialised kernel (8 waves, W3^T staged in LDS from the parameters: no table pass), if its LDS fits
     static constexpr bool kRoles = (D <= 256) && (GeoB2<D, H>::lds_floats * 4 <= 160 * 1024) && (G::HB == 4);
@@ -1279,7 +1488,9 @@ struct HjbwLaunch {
         r.launch_adj = &adj;
         r.wide = 1;
         r.bwd2_one_per_cu = kRoles ? 1 : 0;
-        r.fwd_table_floats = W::fwd_table_floats;
+        r.fwd_table_floats = W::fwd_table_floats > W::fwd_x3_table_floats ? W::fwd_table_floats : W::fwd_x3_table_floats;
+        r.fwd_x3_lds_bytes = &fwd_x3_lds;
+        r.launch_fwd_x3 = &fwd_x3;
         r.bwd_table_floats = W::bwd_table_floats;
         return r;
     }

@@ -155,9 +155,10 @@ class HjbNativePlan:
         if chosen is None:
             raise PlanUnsupported(why)
         self.d_pad, self.H_pad, self.family, sizes = chosen
-        if want == 'auto' and self.family == 1 and torch.device(dev).type == 'cuda':
+        if want == 'auto' and torch.device(dev).type == 'cuda':
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            if (self.K_local + 15) // 16 > 2 * cus:
+            # (the wide family has no small-K kernels: its split-product forward serves every K)
+            if self.family == 2 or (self.K_local + 15) // 16 > 2 * cus:
                 cfg.mlp_dtype = nat.MLP_F16X3
                 rc, sizes_x3, _ = nat.query_rc(cfg)
                 if rc == 0:

@@ -49,7 +49,9 @@ def test_first_iteration_D_and_gradient_match_oracle(name):
 
 
 def check_first_iteration(name, **over):
-    """(also called by tests/test_gpu_split_product.py with mlp_dtype='f16x3': same bounds)"""
+    """This suite pins the fp32-MFMA kernels (mlp_dtype='fp32'); tests/test_gpu_split_product.py calls the same checks with
+    mlp_dtype='f16x3' (same bounds on D, gradient and loss), and the default 'auto' is covered by the full-size tests."""
+    over.setdefault("mlp_dtype", "fp32")
     rec = load_golden(name)
     case = rec["case"]
     model = make_pkg_solver(case, dev(), backend="native", L=1, **over)
@@ -85,7 +87,8 @@ def test_loss_log_matches_reference_golden(name):
     check_loss_log(name)
 
 
-def check_loss_log(name, **over):
+def check_loss_log(name, probe_rtol=1e-4, **over):
+    over.setdefault("mlp_dtype", "fp32")
     rec = load_golden(name)
     model = make_pkg_solver(rec["case"], dev(), backend="native", **over)
     model.train()
@@ -106,7 +109,7 @@ def check_loss_log(name, **over):
             with torch.no_grad():
                 u = (-model.Z_n(xp, pr["t"])).cpu()
             want = torch.tensor(pr["minus_Z"]).reshape(u.shape)
-            assert float((u - want).abs().max()) <= 1e-4 * max(1e-2, float(want.abs().max()))
+            assert float((u - want).abs().max()) <= probe_rtol * max(1e-2, float(want.abs().max()))
 
 
 def test_philox_stream_consistent_between_fill_fwd_and_bwd():
