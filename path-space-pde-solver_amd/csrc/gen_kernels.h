@@ -76,6 +76,12 @@ struct GGeo {
     static constexpr int vb1 = fVec, vb2 = vb1 + HB * 16, vw3h1 = vb2 + HB * 16, vw3h2 = vw3h1 + HB * 16,
                          vw3x = vw3h2 + HB * 16, vdr = vw3x + DBI * 16, fRed = vdr + DBI * 16, fEnd = fRed + 64;
     static int fwd_lds_floats() { return fEnd; }
+    // split-product forward (gen_fwd_kernel<.., X3>): the same six tables as hi / lo f16 images (SplitGeo, hjb_kernels.h); the
+    // vectors and the reduction slot follow in the same order
+    static constexpr int xW1f = 0, xW2xf = xW1f + SplitGeo<KSI, DBI>::floats(HB), xW2hf = xW2xf + SplitGeo<KSI, DBI>::floats(HB),
+                         xW2hr = xW2hf + SplitGeo<KSH, HB>::floats(HB), xW2xr = xW2hr + SplitGeo<KSH, HB>::floats(HB),
+                         xW1r = xW2xr + SplitGeo<KSH, HB>::floats(DBI), xVec = xW1r + SplitGeo<KSH, HB>::floats(DBI);
+    static int fwd_x3_lds_floats() { return xVec + (fEnd - fVec); }
     // backward: 4 waves arranged WH (column blocks of H) x WD (row blocks).  Rows are split first: the
     // A operands (X, U, d1, z1^ images) then go to exactly one wave each, while the B operands (adjoint
     // panels) are shared through the LDS exchange tiles.
@@ -91,14 +97,17 @@ struct GGeo {
 };
 
 // dispatch of one product: fp32 16x16x4 chain (gemm_T) or the bf16 16x16x32 one
-template <bool BF16, int MB, int KS, int INB>
+// (MODE 0: fp32, 1: bf16, 2: fp32-grade split products on the f16 pipe, gemm_Tx)
+template <int MODE, int MB, int KS, int INB>
 __device__ __forceinline__ void gen_gemm(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane) {
-    if constexpr (BF16) gemm_Tb<MB, INB>(acc, wlds, in, lane);
+    if constexpr (MODE == 2) gemm_Tx<MB, KS, INB, 1>(acc, wlds, in, lane);   // (one unit per chunk: the kernel sits on its 256 registers)
+    else if constexpr (MODE == 1) gemm_Tb<MB, INB>(acc, wlds, in, lane);
     else gemm_T<MB, KS, INB>(acc, wlds, in, lane);
 }
-template <bool BF16, class F>
-__device__ __forceinline__ void gen_stage(float* dst, int MB, int KS, int INB, int tid, int nthr, F src) {
-    if constexpr (BF16) stage_aop_bf16(dst, MB, (INB + 1) / 2, tid, nthr, src);
+template <int MODE, int KS, int INB, class F>
+__device__ __forceinline__ void gen_stage(float* dst, int MB, int tid, int nthr, F src) {
+    if constexpr (MODE == 2) stage_aop_x3<KS, INB>(dst, MB, tid, nthr, src);
+    else if constexpr (MODE == 1) stage_aop_bf16(dst, MB, (INB + 1) / 2, tid, nthr, src);
     else stage_aop(dst, MB, KS, tid, nthr, src);
 }
 
@@ -151,10 +160,15 @@ __device__ __forceinline__ f32x4 image_get_T(const float* base, int o32, int o16
 }
 
 // PHILOX: on-device noise decided at launch -- no supplied-noise loads (and no join behind them) in the time loop
-template <int D, int H, bool BF16 = false, bool PHILOX = false>
+// X3 (psp_gen_config.mlp_dtype = PSP_MLP_F16X3): the nine value-net products per step as split f16 products, fp32-grade
+template <int D, int H, bool BF16 = false, bool PHILOX = false, bool X3 = false>
 __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, KSI = G::KSI, HB = G::HB, KSH = G::KSH;
+    constexpr int MODE = X3 ? 2 : (BF16 ? 1 : 0);
+    constexpr int oW1f = X3 ? G::xW1f : G::fW1f, oW2xf = X3 ? G::xW2xf : G::fW2xf, oW2hf = X3 ? G::xW2hf : G::fW2hf,
+                  oW2hr = X3 ? G::xW2hr : G::fW2hr, oW2xr = X3 ? G::xW2xr : G::fW2xr, oW1r = X3 ? G::xW1r : G::fW1r;
+    constexpr int VSH = X3 ? G::xVec - G::fVec : 0;    // the vectors and the reduction slot follow the (larger) split tables
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
@@ -162,25 +176,25 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
     const float* __restrict__ P = a.params;
 
     // forward tables: out^T = W^T in^T  ->  A[row = out][k = in] = W[in][out]
-    gen_stage<BF16>(lds + G::fW1f, HB, KSI, DBI, tid, nthr, [&](int row, int col) {
+    gen_stage<MODE, KSI, DBI>(lds + oW1f, HB, tid, nthr, [&](int row, int col) {
         return (row < H && col < DI) ? P[G::oW1 + col * H + row] : 0.f; });
-    gen_stage<BF16>(lds + G::fW2xf, HB, KSI, DBI, tid, nthr, [&](int row, int col) {
+    gen_stage<MODE, KSI, DBI>(lds + oW2xf, HB, tid, nthr, [&](int row, int col) {
         return (row < H && col < DI) ? P[G::oW2 + col * H + row] : 0.f; });
-    gen_stage<BF16>(lds + G::fW2hf, HB, KSH, HB, tid, nthr, [&](int row, int col) {
+    gen_stage<MODE, KSH, HB>(lds + oW2hf, HB, tid, nthr, [&](int row, int col) {
         return (row < H && col < H) ? P[G::oW2 + (DI + col) * H + row] : 0.f; });
     // reverse tables: g_in = W g_out  ->  A[row = in][k = out] = W[in][out]
-    gen_stage<BF16>(lds + G::fW2hr, HB, KSH, HB, tid, nthr, [&](int row, int col) {
+    gen_stage<MODE, KSH, HB>(lds + oW2hr, HB, tid, nthr, [&](int row, int col) {
         return (row < H && col < H) ? P[G::oW2 + (DI + row) * H + col] : 0.f; });
-    gen_stage<BF16>(lds + G::fW2xr, DBI, KSH, HB, tid, nthr, [&](int row, int col) {
+    gen_stage<MODE, KSH, HB>(lds + oW2xr, DBI, tid, nthr, [&](int row, int col) {
         return (row < DI && col < H) ? P[G::oW2 + row * H + col] : 0.f; });
-    gen_stage<BF16>(lds + G::fW1r, DBI, KSH, HB, tid, nthr, [&](int row, int col) {
+    gen_stage<MODE, KSH, HB>(lds + oW1r, DBI, tid, nthr, [&](int row, int col) {
         return (row < DI && col < H) ? P[G::oW1 + row * H + col] : 0.f; });
-    stage_vec(lds + G::vb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
-    stage_vec(lds + G::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
-    stage_vec(lds + G::vw3h1, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + f] : 0.f; });
-    stage_vec(lds + G::vw3h2, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + H + f] : 0.f; });
-    stage_vec(lds + G::vw3x, DBI, tid, nthr, [&](int f) { return f < DI ? P[G::oW3 + f] : 0.f; });
-    stage_vec(lds + G::vdr, DBI, tid, nthr, [&](int f) {
+    stage_vec(lds + VSH + G::vb1, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob1 + f] : 0.f; });
+    stage_vec(lds + VSH + G::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
+    stage_vec(lds + VSH + G::vw3h1, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + f] : 0.f; });
+    stage_vec(lds + VSH + G::vw3h2, HB, tid, nthr, [&](int f) { return f < H ? P[G::oW3 + DI + H + f] : 0.f; });
+    stage_vec(lds + VSH + G::vw3x, DBI, tid, nthr, [&](int f) { return f < DI ? P[G::oW3 + f] : 0.f; });
+    stage_vec(lds + VSH + G::vdr, DBI, tid, nthr, [&](int f) {
         return (f < D && (a.drift_kind == DRIFT_DWELL || a.drift_kind == DRIFT_DIAG)) ? a.drift[f] : 0.f; });
     __syncthreads();
     const float b3 = P[G::ob3];
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
     unsigned long long nact = 0;
 
     if (wave_valid) {
-        const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + G::fVec) + q;
+        const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds + VSH + G::fVec) + q;
         // feature masks of this lane: f < D (state features) ; f == D is the time input
         f32x4 X[DBI];
 #pragma unroll
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             const f32x4* vw3x = vecs + (G::vw3x - G::fVec) / 4;
 #pragma unroll
             for (int m = 0; m < HB; ++m) r1[m] = vb1[m * 4];
-            gen_gemm<BF16, HB, KSI, DBI>(r1, lds + G::fW1f, X, lane);
+            gen_gemm<MODE, HB, KSI, DBI>(r1, lds + oW1f, X, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) r1[m] = relu4(r1[m]);
             f32x4 h1[HB];
@@ -226,8 +240,8 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             for (int m = 0; m < HB; ++m) h1[m] = r1[m] * r1[m];
 #pragma unroll
             for (int m = 0; m < HB; ++m) r2[m] = vb2[m * 4];
-            gen_gemm<BF16, HB, KSI, DBI>(r2, lds + G::fW2xf, X, lane);
-            gen_gemm<BF16, HB, KSH, HB>(r2, lds + G::fW2hf, h1, lane);
+            gen_gemm<MODE, HB, KSI, DBI>(r2, lds + oW2xf, X, lane);
+            gen_gemm<MODE, HB, KSH, HB>(r2, lds + oW2hf, h1, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) r2[m] = relu4(r2[m]);
             float v = 0.f;
@@ -274,13 +288,13 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             for (int m = 0; m < HB; ++m) gz2[m] = vw3h2[m * 4] * (2.0f * r2[m]);
 #pragma unroll
             for (int m = 0; m < HB; ++m) gz1[m] = vw3h1[m * 4];
-            gen_gemm<BF16, HB, KSH, HB>(gz1, lds + G::fW2hr, gz2, lane);     // g_h1 = w3h1 + W2h g_z2
+            gen_gemm<MODE, HB, KSH, HB>(gz1, lds + oW2hr, gz2, lane);     // g_h1 = w3h1 + W2h g_z2
 #pragma unroll
             for (int m = 0; m < HB; ++m) gz1[m] = gz1[m] * (2.0f * r1[m]);
 #pragma unroll
             for (int b = 0; b < DBI; ++b) gx[b] = vw3x[b * 4];
-            gen_gemm<BF16, DBI, KSH, HB>(gx, lds + G::fW2xr, gz2, lane);
-            gen_gemm<BF16, DBI, KSH, HB>(gx, lds + G::fW1r, gz1, lane);
+            gen_gemm<MODE, DBI, KSH, HB>(gx, lds + oW2xr, gz2, lane);
+            gen_gemm<MODE, DBI, KSH, HB>(gx, lds + oW1r, gz1, lane);
             // Z = sigma^T grad_x V (sigma = s I), state features only (solver.py:1104)
             const float alivef = stopped ? 0.f : 1.f;
             auto noise_block = [&](int b) __attribute__((always_inline)) {
@@ -423,12 +437,12 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < HB; ++m) { z1h[m] = zero4; z2h[m] = zero4; }
-                gen_gemm<BF16, HB, KSI, DBI>(z1h, lds + G::fW1f, U, lane);
+                gen_gemm<MODE, HB, KSI, DBI>(z1h, lds + oW1f, U, lane);
                 f32x4 h1d[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) h1d[m] = (2.0f * r1[m]) * z1h[m];
-                gen_gemm<BF16, HB, KSI, DBI>(z2h, lds + G::fW2xf, U, lane);
-                gen_gemm<BF16, HB, KSH, HB>(z2h, lds + G::fW2hf, h1d, lane);
+                gen_gemm<MODE, HB, KSI, DBI>(z2h, lds + oW2xf, U, lane);
+                gen_gemm<MODE, HB, KSH, HB>(z2h, lds + oW2hf, h1d, lane);
                 if (p16) {
                     gwptr_t p1 = pbase16(n, G::qD1), p2 = pbase16(n, G::qD2), p3 = pbase16(n, G::qZ1), p4 = pbase16(n, G::qZ2);
 #pragma unroll
@@ -873,7 +887,7 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     const unsigned selF = (col >> 3) ? 0x03020c0cu : 0x01000c0cu;
     const float* __restrict__ P = a.params;
 
-    gen_stage<BF16>(lds + G::gW2hr, HB, KSH, HB, tid, nthr, [&](int row, int c2) {
+    gen_stage<(BF16 ? 1 : 0), KSH, HB>(lds + G::gW2hr, HB, tid, nthr, [&](int row, int c2) {
         return (row < H && c2 < H) ? P[G::oW2 + (DI + row) * H + c2] : 0.f; });
     __syncthreads();
     float* bufs = lds + G::gEx;                       // [2 buffers][4 blocks][EXT tiles][256]
@@ -971,8 +985,8 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     g3b += (q == 0) ? av : 0.f;
         #pragma unroll
                     for (int m = 0; m < HB; ++m) { gz1t[m] = w3_T(G::oW3 + DI, m, o0); gz1[m] = av * gz1t[m]; }
-                    gen_gemm<BF16, HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
-                    gen_gemm<BF16, HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
+                    gen_gemm<(BF16 ? 1 : 0), HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
+                    gen_gemm<(BF16 ? 1 : 0), HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
                     {   // d1 / z1^ are L2-resident (touch-prefetched one round ahead): fetch them only now
                         f32x4 d1[HB], z1t[HB];
         #pragma unroll
@@ -1355,6 +1369,8 @@ struct GenInstance {
     hipError_t (*launch_bwd2)(const GenArgs&, int grid, hipStream_t);   // role-specialised variant, 512 threads
     hipError_t (*launch_fwd_bf16)(const GenArgs&, int grid, int block, hipStream_t);   // value-net products on bf16 MFMA
     hipError_t (*launch_bwd2_bf16)(const GenArgs&, int grid, hipStream_t);             // adjoint products + weight-gradient outer products on bf16 MFMA
+    int (*fwd_x3_lds_bytes)();                                                         // split-product forward (PSP_MLP_F16X3)
+    hipError_t (*launch_fwd_x3)(const GenArgs&, int grid, int block, hipStream_t);
 };
 
 template <int D, int H>
@@ -1391,6 +1407,18 @@ struct GenLaunch {
     static hipError_t fwd_bf16(const GenArgs& a, int grid, int block, hipStream_t s) {
         return a.noise_mode == NOISE_PHILOX ? fwd_as<true, true>(a, grid, block, s) : fwd_as<true, false>(a, grid, block, s);
     }
+    static int fwd_x3_lds() { return G::fwd_x3_lds_floats() * 4; }
+    template <bool PHILOX>
+    static hipError_t fwd_x3_as(const GenArgs& a, int grid, int block, hipStream_t s) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_fwd_kernel<D, H, false, PHILOX, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, fwd_x3_lds());
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gen_fwd_kernel<D, H, false, PHILOX, true>), dim3(grid), dim3(block), fwd_x3_lds(), s, a);
+        return hipGetLastError();
+    }
+    static hipError_t fwd_x3(const GenArgs& a, int grid, int block, hipStream_t s) {
+        return a.noise_mode == NOISE_PHILOX ? fwd_x3_as<true>(a, grid, block, s) : fwd_x3_as<false>(a, grid, block, s);
+    }
 #ifdef PSP_LEGACY_BWD
     // gen_bwd_kernel: superseded by gen_bwd2_kernel; diagnostic builds only (-DPSP_LEGACY_BWD + PSP_BWD_VARIANT=1)
     static hipError_t bwd(const GenArgs& a, int grid, int block, hipStream_t s) {
@@ -1404,7 +1432,10 @@ struct GenLaunch {
 #else
     static constexpr hipError_t (*legacy_bwd)(const GenArgs&, int, int, hipStream_t) = nullptr;
 #endif
-    static GenInstance instance() { return GenInstance{D, H, G::P, G::PB, G::PB16, &fwd_lds, &bwd_lds, &fwd, legacy_bwd, &bwd2_lds, &bwd2, &fwd_bf16, &bwd2_bf16}; }
+    static GenInstance instance() {
+        return GenInstance{D, H, G::P, G::PB, G::PB16, &fwd_lds, &bwd_lds, &fwd, legacy_bwd, &bwd2_lds, &bwd2, &fwd_bf16, &bwd2_bf16,
+                           &fwd_x3_lds, &fwd_x3};
+    }
 };
 
 }  // namespace psp

@@ -369,7 +369,8 @@ __device__ __forceinline__ void stage_aop_x3(float* dstf, int MB, int tid, int n
     }
 }
 // out^T (MB blocks) += W . in^T with fp32-grade products on the f16 pipe; A operands prefetched one chunk of units ahead
-template <int MB, int KS, int INB>
+// (CU: units (16-row block x 32-deep step) fetched per chunk -- 2 hides the LDS latency better, 1 costs 16 registers less)
+template <int MB, int KS, int INB, int CU = 2>
 __device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane) {
     using SG = SplitGeo<KS, INB>;
     constexpr int NS = SG::NS;
@@ -380,7 +381,7 @@ __device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, con
     for (int mb = 0; mb < MB; ++mb) corr[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (NS > 0) {
         const f16x8* tbl = reinterpret_cast<const f16x8*>(wlds) + lane;
-        constexpr int NU = NS * MB, CU = 2, NCH = cdiv(NU, CU);
+        constexpr int NU = NS * MB, NCH = cdiv(NU, CU);
         f16x8 ah[2][CU], al[2][CU];
 #pragma unroll
         for (int kk = 0; kk < CU; ++kk)

@@ -234,6 +234,8 @@ int make_gen_plan(const psp_gen_config* c, GenPlan* p) {
     if ((c->v_steps_out == nullptr) != (c->y_steps_out == nullptr)) return fail(-1, "v_steps_out and y_steps_out go together");
     if (p->inst.fwd_lds_bytes() > kMaxLds)
         return fail(-3, "GeneralSolver kernel tables do not fit the 160 KiB LDS for this (d,H)");
+    if (c->mlp_dtype == PSP_MLP_F16X3 && (!p->inst.launch_fwd_x3 || p->inst.fwd_x3_lds_bytes() > kMaxLds))
+        return fail(-3, "split-product forward tables do not fit the 160 KiB LDS for this (d,H)");
     p->ntile16 = (c->K_local + 15) / 16;
     const int cus = n_cus();
     int fw = (p->ntile16 + cus - 1) / cus;
@@ -925,9 +927,12 @@ int psp_gen_rollout_fwd(const psp_gen_config* cfg, const float* params, const fl
     a.params = params; a.x0 = x0; a.t0 = t0; a.xi = xi; a.path = path; a.ahat = ahat;
     a.VN = VN; a.YN = YN; a.XN = XN; a.tN = tN; a.kcount = kcount;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    if (cfg->mlp_dtype < PSP_MLP_FP32 || cfg->mlp_dtype > PSP_MLP_BF16) return fail(-1, "mlp_dtype out of range");
-    hipError_t e = cfg->mlp_dtype != PSP_MLP_FP32 ? p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream)
-                                                  : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    if (cfg->mlp_dtype < PSP_MLP_FP32 || cfg->mlp_dtype > PSP_MLP_F16X3) return fail(-1, "mlp_dtype out of range");
+    if (cfg->mlp_dtype == PSP_MLP_F16X3 && (!p.inst.launch_fwd_x3 || p.inst.fwd_x3_lds_bytes() > kMaxLds))
+        return fail(-3, "split-product forward tables do not fit the 160 KiB LDS for this (d,H)");
+    hipError_t e = cfg->mlp_dtype == PSP_MLP_F16X3 ? p.inst.launch_fwd_x3(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream)
+                   : cfg->mlp_dtype != PSP_MLP_FP32 ? p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream)
+                                                    : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "gen_fwd_kernel launch");
     return 0;
 }
@@ -943,7 +948,8 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
     fill_gen_args(cfg, p, &a);
     a.params = params; a.path = const_cast<float*>(path); a.ahat = const_cast<float*>(ahat);
     a.wY = wY; a.wV = wV; a.grad_partial = grad_partial;
-    if (cfg->mlp_dtype < PSP_MLP_FP32 || cfg->mlp_dtype > PSP_MLP_BF16) return fail(-1, "mlp_dtype out of range");
+    if (cfg->mlp_dtype < PSP_MLP_FP32 || cfg->mlp_dtype > PSP_MLP_F16X3) return fail(-1, "mlp_dtype out of range");
+    // (PSP_MLP_F16X3: split products in the forward rollout; this kernel stays on fp32 MFMA, same path store)
     if (cfg->mlp_dtype == PSP_MLP_BF16 && !p.bwd_specialised)
         return fail(-3, "the bf16 backward exists for the role-specialised kernel only (LDS budget / PSP_BWD_VARIANT)");
     hipError_t e = cfg->mlp_dtype == PSP_MLP_BF16 ? p.inst.launch_bwd2_bf16(a, p.bwd_grid, (hipStream_t)stream)

@@ -84,10 +84,10 @@ class GeneralSolver:
                  verbose=True, approx_method='Y', sample_center=False, loss_method='diffusion',
                  loss_with_stopped=False, K_test_log=None, PINN_log_variance=False, log_loss_parts=False,
                  boundary_loss=True, full_hessian=False, uniform_square=False, solve_linear_L2_projection=False,
-                 device=None, backend='auto', noise='reference', mlp_dtype='fp32'):
+                 device=None, backend='auto', noise='reference', mlp_dtype='auto'):
         self.problem, self.name = problem, name
-        if mlp_dtype not in ('fp32', 'bf16', 'bf16_fwd'):
-            raise ValueError("mlp_dtype must be 'fp32', 'bf16' or 'bf16_fwd'")
+        if mlp_dtype not in ('auto', 'fp32', 'f16x3', 'bf16', 'bf16_fwd'):
+            raise ValueError("mlp_dtype must be 'auto', 'fp32', 'f16x3', 'bf16' or 'bf16_fwd'")
         self.mlp_dtype = mlp_dtype      # 'bf16': the matrix products of the native kernels on bf16 MFMA with fp32 accumulation
                                         # ('bf16_fwd': forward rollout only); own tolerance, see include/psp.h
         self.d = problem.d
@@ -297,7 +297,7 @@ class EllipticSolver(GeneralSolver):
                  approx_method='Y', sample_center=False, loss_method='diffusion', loss_with_stopped=False,
                  K_test_log=None, PINN_log_variance=False, log_loss_parts=False, boundary_loss=True,
                  boundary_type='Dirichlet', variance_moment_split=False, full_hessian=False, uniform_square=False,
-                 device=None, backend='auto', noise='reference', mlp_dtype='fp32', v_l2_error_flag=True):
+                 device=None, backend='auto', noise='reference', mlp_dtype='auto', v_l2_error_flag=True):
         self.v_l2_error_flag = v_l2_error_flag   # False: skip the V_L2 diagnostic of solver.py:738 on the native plan (timed runs)
         super().__init__(problem, name, seed=seed, delta_t=delta_t, N=N, lr=lr, L=L, K=K, K_boundary=K_boundary,
                          alpha=alpha, adaptive_forward_process=adaptive_forward_process, detach_forward=detach_forward,

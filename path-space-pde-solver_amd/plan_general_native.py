@@ -97,7 +97,11 @@ class GeneralNativePlan:
             cfg.domain_kind = nat.DOM_BOX if not pb.one_boundary else \
                 (nat.DOM_BOX_UPPER_ALL if self.elliptic else nat.DOM_BOX_UPPER_ANY)
         cfg.d_real = s.d
-        cfg.mlp_dtype = {'fp32': nat.MLP_FP32, 'bf16_fwd': nat.MLP_BF16_FWD, 'bf16': nat.MLP_BF16}[getattr(s, 'mlp_dtype', 'fp32')]
+        # 'f16x3': fp32-grade split products on the f16 matrix pipe in the forward rollout (csrc/hjb_kernels.h gemm_Tx; same parity
+        # bounds as 'fp32'); 'auto' (the default): 'f16x3' where the instance has it and its tables fit the LDS (decided below)
+        self._mlp_want = getattr(s, 'mlp_dtype', 'auto')
+        cfg.mlp_dtype = {'auto': nat.MLP_FP32, 'fp32': nat.MLP_FP32, 'f16x3': nat.MLP_F16X3, 'bf16_fwd': nat.MLP_BF16_FWD,
+                         'bf16': nat.MLP_BF16}[self._mlp_want]
         for i, v in enumerate(spec.get('h_par', ())):
             cfg.h_par[i] = float(v)
         cfg.sigma_scale = float(spec['sigma_scale'])
@@ -114,6 +118,14 @@ class GeneralNativePlan:
         if chosen is None:
             raise NotImplementedError('native plan unavailable: ' + why)
         self.d_pad, self.H_pad, sz = chosen
+        if self._mlp_want == 'auto':
+            cfg.mlp_dtype = nat.MLP_F16X3
+            rc, sz_x3, _ = nat.gen_query_rc(cfg)
+            if rc == 0:
+                sz = sz_x3
+            else:
+                cfg.mlp_dtype = nat.MLP_FP32
+        self.matrix_mode = {nat.MLP_FP32: 'fp32', nat.MLP_F16X3: 'f16x3', nat.MLP_BF16_FWD: 'bf16_fwd', nat.MLP_BF16: 'bf16'}[cfg.mlp_dtype]
         self.pad = shapes.GenParamPad(s.d, self.H, self.d_pad, self.H_pad, self.dev, time_input=not self.elliptic)
         if spec['drift'][1] is not None:
             t = self.pad.vec(spec['drift'][1].detach().to(device=self.dev, dtype=torch.float32)).contiguous()
