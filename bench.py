@@ -51,6 +51,10 @@ WORKLOADS = {
     "hjb_llgc_d100_K4096_N50_h64": dict(d=100, H=64, K=4096, T=0.5, dt=0.01, off_diag=0.01),
     "hjb_llgc_d100_K8192_N50_h64": dict(d=100, H=64, K=8192, T=0.5, dt=0.01, off_diag=0.01),
     "hjb_llgc_d100_K16384_N50_h64": dict(d=100, H=64, K=16384, T=0.5, dt=0.01, off_diag=0.01),
+    # the same shapes on the fp32-MFMA kernels (Solver(mlp_dtype='fp32')); the default workloads run the split-product kernels
+    "hjb_llgc_d100_K65536_N100_h64_fp32mfma": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.01, mlp="fp32"),
+    "hjb_llgc_d200_K32768_N100_h64_fp32mfma": dict(d=200, H=64, K=32768, T=1.0, dt=0.01, off_diag=0.1 / 200 ** 0.5, mlp="fp32"),
+    "hjb_llgc_d500_K16384_N200_h64_fp32mfma": dict(d=500, H=64, K=16384, T=2.0, dt=0.01, off_diag=0.1 / 500 ** 0.5, mlp="fp32"),
     # opt-in mode: control-net products of the forward rollout on bf16 MFMA (SURVEY 8d "bf16-MLP runs"); NOT the headline
     "hjb_llgc_d100_K65536_N100_h64_bf16mlp": dict(d=100, H=64, K=65536, T=1.0, dt=0.01, off_diag=0.01, mlp="bf16"),
     # the reference's constructor default: time_approx='outer', one DenseNet(d -> d, arch [30, 30]) per time step (solver.py:88)
@@ -692,7 +696,7 @@ def main_general(args, psp, sharding):
     total = args.warmup + args.steps
     model = psp.GeneralSolver(problem=prob, name="bench", seed=42, delta_t=w["dt"], N=w["N"], lr=1e-3, L=total,
                               K=w["K"] * world, K_boundary=50, alpha=[1.0, 1.0, 1.0], loss_method=w["loss"],
-                              verbose=False, device=dev, backend="native", noise="philox", mlp_dtype=w.get("mlp", "fp32"))
+                              verbose=False, device=dev, backend="native", noise="philox", mlp_dtype=w.get("mlp", "auto"))
     model.V = psp.DenseNet(d_in=w["d"] + 1, d_out=1, lr=1e-3, arch=[w["H"], w["H"]], seed=42).to(dev)
     plan = model._choose_plan()
     assert model.plan_name == "native"
@@ -725,6 +729,10 @@ def main_general(args, psp, sharding):
     # peak (forward always; backward only with mlp == 'bf16')
     on_bf16 = (mlp in ("bf16", "bf16_fwd") and not bwd_dom) or (mlp == "bf16" and bwd_dom)
     peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
+    # split-product forward (mlp_dtype 'auto' / 'f16x3'): three f16 flops per algorithmic fp32 flop; the backward kernel stays fp32 MFMA
+    x3 = getattr(plan, "matrix_mode", "fp32") == "f16x3"
+    if x3 and not bwd_dom:
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0
     achieved = dom_fl * units / (dom_ms * 1e-3) / 1e12
     path_B = float(plan.sizes.path_bytes) / ((w["N"] + 1) * w["K"]) if hasattr(plan, "sizes") else None
     hbm_gbps = (float(plan.sizes.path_bytes) / (dom_ms * 1e-3) / 1e9) if hasattr(plan, "sizes") else 0.0

@@ -287,59 +287,71 @@ __device__ __forceinline__ void split_pack(const f32x4& u0, const f32x4& u1, f16
 template <int MB, int KS8, int LD = MB>
 __device__ __forceinline__ void gemm_img_x3(f32x4 (&acc)[MB], const float* __restrict__ tbl, const float* img, int lane) {
     constexpr int CH = MB >= 4 ? 4 : MB;                                // (8 spills at d = 500 and under the 256-register cap of d <= 256)
-    constexpr int NC = cdiv(MB, CH);
-    f16x8 ah[2][CH], al[2][CH], bh[2], bl[2];
-    f32x4 corr[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) corr[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // output blocks in groups of at most 16: the correction chain of a group is 64 registers instead of 4 MB (d = 500: 128, which
+    // spilled 45 dwords per step); every (S, block) operand is still read once, only the input packs are re-read from LDS per group
+    constexpr int NG = cdiv(MB, 16), GB = cdiv(MB, NG);
     const unsigned ul = (unsigned)lane;
     tbl = opaque_base(tbl);
     const f16x8* imgp = reinterpret_cast<const f16x8*>(img) + lane;
-    auto load_a = [&](int st, int S, int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int m = 0; m < CH; m += 2) {                               // fresh SGPR base every 4 KiB (two output blocks)
-            if (c * CH + m < MB) {
-                gptr8_t tp = sgpr_ptr8(tbl + ((size_t)S * LD + c * CH + m) * 512);
-                ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
-                if (m + 1 < CH && c * CH + m + 1 < MB) { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul]; }
+    for (int grp = 0; grp < NG; ++grp) {
+        constexpr int dummy = 0; (void)dummy;
+        const int g0 = grp * GB;                                        // first output block of the group (compile-time after unrolling)
+        const int gn = (g0 + GB <= MB) ? GB : MB - g0;
+        const int NC = (gn + CH - 1) / CH;
+        f16x8 ah[2][CH], al[2][CH], bh[2], bl[2];
+        f32x4 corr[GB];
+#pragma unroll
+        for (int m = 0; m < GB; ++m) corr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto load_a = [&](int st, int S, int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < CH; m += 2) {                           // fresh SGPR base every 4 KiB (two output blocks)
+                if (c * CH + m < gn) {
+                    gptr8_t tp = sgpr_ptr8(tbl + ((size_t)S * LD + g0 + c * CH + m) * 512);
+                    ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
+                    if (m + 1 < CH && c * CH + m + 1 < gn) { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul]; }
+                }
             }
-        }
-    };
-    auto load_b = [&](int st, int S) __attribute__((always_inline)) {
-        bh[st] = imgp[(S * 2) * 64]; bl[st] = imgp[(S * 2 + 1) * 64];
-    };
-    load_b(0, 0);
-    load_a(0, 0, 0);
+        };
+        auto load_b = [&](int st, int S) __attribute__((always_inline)) {
+            bh[st] = imgp[(S * 2) * 64]; bl[st] = imgp[(S * 2 + 1) * 64];
+        };
+        load_b(0, 0);
+        load_a(0, 0, 0);
 #pragma unroll 1
-    for (int S = 0; S < KS8; S += 2) {                                  // two S-steps per trip: static ring indices
+        for (int S = 0; S < KS8; S += 2) {                              // two S-steps per trip: static ring indices
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int Sc = S + h;
-            if (Sc < KS8) {
-                const int Sn = Sc + 1 < KS8 ? Sc + 1 : KS8 - 1;         // past the end: re-read the last step (unused)
-                load_b((h + 1) & 1, Sn);
+            for (int h = 0; h < 2; ++h) {
+                const int Sc = S + h;
+                if (Sc < KS8) {
+                    const int Sn = Sc + 1 < KS8 ? Sc + 1 : KS8 - 1;     // past the end: re-read the last step (unused)
+                    load_b((h + 1) & 1, Sn);
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const int cur = (h * NC + c) & 1, nxt = cur ^ 1;
-                    if (c + 1 < NC) load_a(nxt, Sc, c + 1);
-                    else load_a(nxt, Sn, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int c = 0; c < cdiv(GB, CH); ++c) {
+                        if (c < NC) {
+                            const int cur = (h * NC + c) & 1, nxt = cur ^ 1;
+                            if (c + 1 < NC) load_a(nxt, Sc, c + 1);
+                            else load_a(nxt, Sn, 0);
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < CH; ++m) {
-                        const int mb = c * CH + m;
-                        if (mb < MB) {
-                            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bh[h & 1], acc[mb], 0, 0, 0);
-                            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bl[h & 1], corr[mb], 0, 0, 0);
-                            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][m], bh[h & 1], corr[mb], 0, 0, 0);
+                            for (int m = 0; m < CH; ++m) {
+                                const int mg = c * CH + m;
+                                if (mg < gn) {
+                                    acc[g0 + mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bh[h & 1], acc[g0 + mg], 0, 0, 0);
+                                    corr[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bl[h & 1], corr[mg], 0, 0, 0);
+                                    corr[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][m], bh[h & 1], corr[mg], 0, 0, 0);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-    }
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb] = acc[mb] + kSplitInv * corr[mb];
+        for (int m = 0; m < GB; ++m)
+            if (m < gn) acc[g0 + m] = acc[g0 + m] + kSplitInv * corr[m];
+    }
 }
 // acc[MB] += T . in, in: register panel of INB <= 4 blocks (the hidden layers: two S-steps), fully unrolled
 template <int MB, int INB, int LD = MB>

@@ -19,11 +19,30 @@ def _traffic():
 
 # workload -> (padded d, H, dense, kernel family, forward kernel name, backward kernel name)
 CASES = {
-    "hjb_llgc_d100_K65536_N100_h64": (100, 64, True, 1, "hjb_fwd_kernel", "hjb_bwd2_kernel"),
+    "hjb_llgc_d100_K65536_N100_h64_fp32mfma": (100, 64, True, 1, "hjb_fwd_kernel", "hjb_bwd2_kernel"),
     "hjb_llgc_d100_K1024_N50_h64": (100, 64, True, 1, "hjbq_fwd_kernel", "hjb_bwd2_kernel"),
-    "hjb_llgc_d200_K32768_N100_h64": (200, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd2_kernel"),
-    "hjb_llgc_d500_K16384_N200_h64": (500, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd_kernel"),
+    "hjb_llgc_d200_K32768_N100_h64_fp32mfma": (200, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd2_kernel"),
+    "hjb_llgc_d500_K16384_N200_h64_fp32mfma": (500, 64, True, 2, "hjbw_fwd_kernel", "hjbw_bwd_kernel"),
 }
+# the default workloads run the split-product kernels: (padded d, H, family, forward kernel, backward kernel or None)
+X3_CASES = {
+    "hjb_llgc_d100_K65536_N100_h64": (100, 64, 1, "hjb_fwd_kernel", "hjb_bwd3_kernel"),
+    "hjb_llgc_d200_K32768_N100_h64": (200, 64, 2, "hjbw_fwd_kernel", None),
+    "hjb_llgc_d500_K16384_N200_h64": (500, 64, 2, "hjbw_fwd_kernel", None),
+}
+
+
+@pytest.mark.parametrize("workload", sorted(X3_CASES))
+def test_issued_mfma_formula_of_the_split_kernels_matches_the_pmc_counts(workload):
+    d, H, family, fwd_name, bwd_name = X3_CASES[workload]
+    meas = _traffic()[workload]
+    w = bench.WORKLOADS[workload]
+    N = int(round(w["T"] / w["dt"]))
+    tiles_steps = (w["K"] // 16) * N
+    fwd, bwd = bench.issued_mfma_x3(d, H, True, family)
+    assert sum(fwd.values()) * tiles_steps == pytest.approx(meas[fwd_name]["mfma_instructions"], rel=2e-3), (fwd, meas[fwd_name])
+    if bwd_name:
+        assert sum(bwd.values()) * tiles_steps == pytest.approx(meas[bwd_name]["mfma_instructions"], rel=2e-3), (bwd, meas[bwd_name])
 
 
 @pytest.mark.parametrize("workload", sorted(CASES))
@@ -55,9 +74,9 @@ def test_path_store_traffic_equals_the_algorithmic_store():
     traffic of the backward kernels lies between one and two passes over it."""
     t = _traffic()
     store = 1408 * 65536 * 100                                              # d=100, H=64: X_n, xi, h1, h2 images
-    f = t["hjb_llgc_d100_K65536_N100_h64"]["hjb_fwd_kernel"]
-    assert f["write_bytes"] == pytest.approx(store, rel=5e-3)
-    b = t["hjb_llgc_d100_K65536_N100_h64"]["hjb_bwd2_kernel"]
+    for wl in ("hjb_llgc_d100_K65536_N100_h64", "hjb_llgc_d100_K65536_N100_h64_fp32mfma"):
+        assert t[wl]["hjb_fwd_kernel"]["write_bytes"] == pytest.approx(store, rel=5e-3)
+    b = t["hjb_llgc_d100_K65536_N100_h64_fp32mfma"]["hjb_bwd2_kernel"]
     assert store <= 2 * b["fetch_raw_bytes"] <= 2 * store
     bf = t["diffusion_dw_d100_K65536_N100_h64_bf16"]["gen_fwd_kernel"]
     assert bf["write_bytes"] == pytest.approx(960 * 65536 * 101 + 4 * 65536 * 101, rel=2e-2)   # bf16-pair images + ahat
