@@ -49,7 +49,14 @@ struct GeoW {
     static constexpr int KS8 = cdiv(DB, 2);
     static constexpr int xW1 = 0, xW2 = xW1 + KS8 * HB * 512, xW3 = xW2 + 2 * HB * 512, xA = xW3 + 2 * DB * 512,
                          xB = xA + KS8 * DB * 512, fwd_x3_table_floats = xB + KS8 * DB * 512;
-    static constexpr int IMGX = KS8 * 512, fwd_x3_lds_floats = fImg + 4 * IMGX;
+    static constexpr int IMGX = KS8 * 512, fStage = fImg + 4 * IMGX;
+    // the shared table stream (gemm_img_x3s) where TWO workgroups fit a CU with the stage (d <= 256 runs two per CU and they cover
+    // each other's barriers); with one wave per SIMD (d > 256) the lock-step costs more than the L2 stream saves (d = 500: 24.7 ->
+    // 26.5 ms), and at d = 256 the stage would cost the second workgroup (12.6 -> 12.0 ms only)
+    static constexpr bool kShare = D <= 256 && 2 * (fStage + 2 * 4 * 512) * 4 <= 160 * 1024;
+    static constexpr int fwd_x3_lds_floats = fStage + (kShare ? 2 * 4 * 512 : 0);
+    // (fStage: two buffers of four output blocks' hi / lo operands, 2 x 8 KiB: the table stream of the long products is fetched
+    //  ONCE per workgroup and read by its four waves from LDS, gemm_img_x3s)
     // backward LDS (floats): dz2 k-step images of the four blocks of a round, double-buffered; bias staging reuses it
     static constexpr int EXB = 4 * HB * 64, bwd_lds_floats = 2 * 4 * EXB + 4 * 16 * DB;
 };
@@ -353,6 +360,105 @@ __device__ __forceinline__ void gemm_img_x3(f32x4 (&acc)[MB], const float* __res
             if (m < gn) acc[g0 + m] = acc[g0 + m] + kSplitInv * corr[m];
     }
 }
+// gemm_img_x3 with the table stream SHARED by the four waves of the workgroup.  With split products the matrix time of a long
+// product fell 4.7x while every wave still pulled its own copy of the table from L2 (d = 500: 2.2 MB per wave and step, ~26 TB/s
+// over the chip: the L2 -> CU stream became the bound).  Here a chunk of four output blocks (8 KiB: hi and lo of 4 x 16 rows x
+// 32 features) is fetched once per workgroup -- wave w loads block 4 c + w -- written to a double-buffered LDS stage and read by
+// all four waves (8 ds_read_b128 per 12 MFMAs); one workgroup barrier per chunk.  Every wave runs every chunk (surplus waves
+// of the last workgroup run along on the last tile), so the barriers are uniform.
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding vector-memory load
+// (s_waitcnt vmcnt(0)), i.e. for the table fetch just issued for the NEXT chunk -- one L2 latency per chunk
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <int MB, int KS8, int LD = MB>
+__device__ __forceinline__ void gemm_img_x3s(f32x4 (&acc)[MB], const float* __restrict__ tbl, const float* img, float* stage,
+                                             int lane, int wave) {
+    constexpr int CH = 4, NC = cdiv(MB, CH);
+    constexpr int NG = cdiv(MB, 16), GC = cdiv(NC, NG);                 // groups of at most 16 output blocks (correction chain 64 regs)
+    const unsigned ul = (unsigned)lane;
+    tbl = opaque_base(tbl);
+    const f16x8* imgp = reinterpret_cast<const f16x8*>(img) + lane;
+    f16x8* st8 = reinterpret_cast<f16x8*>(stage);
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+        const int c0 = grp * GC;                                        // first chunk of the group
+        const int cn = (c0 + GC <= NC) ? GC : NC - c0;                  // chunks in this group
+        // Pipeline of unit u = (S, chunk), all indices static by the parity of u (an S-pair holds an even number of units):
+        //   top of unit u - 3   table fetch of this wave's block (global -> registers lh / ll[(u) & 1])
+        //   end of unit u - 2   published to LDS stage buffer u & 1, then the unit's barrier
+        //   top of unit u - 1   all four blocks read back into ah / al[u & 1] -- in flight beside the MFMAs of unit u - 1
+        //   unit u              12 MFMAs
+        f16x8 lh[2], ll[2], ah[2][CH], al[2][CH], bh[2], bl[2];
+        f32x4 corr[GC * CH];
+#pragma unroll
+        for (int m = 0; m < GC * CH; ++m) corr[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto fetch = [&](int r, int S, int c) __attribute__((always_inline)) {
+            while (c >= cn) { c -= cn; S += 1; }
+            if (S > KS8 - 1) S = KS8 - 1;                               // past the end: re-read the last step (unused)
+            const int mb = (c0 + c) * CH + wave;
+            if (mb < MB) {
+                gptr8_t tp = sgpr_ptr8(tbl + ((size_t)S * LD + mb) * 512);
+                lh[r] = tp[ul]; ll[r] = tp[64 + ul];
+            }
+        };
+        auto publish = [&](int buf) __attribute__((always_inline)) {
+            st8[(buf * 4 + wave) * 128 + lane] = lh[buf];
+            st8[(buf * 4 + wave) * 128 + 64 + lane] = ll[buf];
+        };
+        auto readback = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < CH; ++m) {
+                ah[buf][m] = st8[(buf * 4 + m) * 128 + lane];
+                al[buf][m] = st8[(buf * 4 + m) * 128 + 64 + lane];
+            }
+        };
+        bh[0] = imgp[0]; bl[0] = imgp[64];
+        fetch(0, 0, 0);
+        fetch(1, 0, 1);
+        publish(0);
+        publish(1);
+        lds_barrier();
+        readback(0);
+        lds_barrier();                                                  // (unit 0 publishes into the buffer just read)
+        fetch(0, 0, 2);
+#pragma unroll 1
+        for (int S = 0; S < KS8; S += 2) {                              // two S-steps per trip: static ring indices
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int Sc = S + h;
+                if (Sc < KS8) {
+                    const int Sn = Sc + 1 < KS8 ? Sc + 1 : KS8 - 1;     // past the end: re-read the last step (unused)
+                    bh[(h + 1) & 1] = imgp[(Sn * 2) * 64]; bl[(h + 1) & 1] = imgp[(Sn * 2 + 1) * 64];
+#pragma unroll
+                    for (int c = 0; c < GC; ++c) {
+                        if (c < cn) {
+                            const int cur = (h * cn + c) & 1, nxt = cur ^ 1;
+                            readback(nxt);                              // unit u + 1 (published during unit u - 1)
+                            fetch(nxt, Sc, c + 3);                      // unit u + 3
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int m = 0; m < CH; ++m) {
+                                const int mg = c * CH + m, mb = c0 * CH + mg;
+                                if (mb < MB) {
+                                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bh[h & 1], acc[mb], 0, 0, 0);
+                                    corr[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bl[h & 1], corr[mg], 0, 0, 0);
+                                    corr[mg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][m], bh[h & 1], corr[mg], 0, 0, 0);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            publish(cur);                               // unit u + 2 into the buffer unit u was read from
+                            lds_barrier();
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < GC * CH; ++m)
+            if (c0 * CH + m < MB) acc[c0 * CH + m] = acc[c0 * CH + m] + kSplitInv * corr[m];
+    }
+}
 // acc[MB] += T . in, in: register panel of INB <= 4 blocks (the hidden layers: two S-steps), fully unrolled
 template <int MB, int INB, int LD = MB>
 __device__ __forceinline__ void gemm_regs_x3(f32x4 (&acc)[MB], const float* __restrict__ tbl, const f32x4 (&in)[INB], int lane) {
@@ -441,6 +547,9 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
     const float dt = a.dt, sqdt = a.sqdt;
     float* img = lds + W::fImg + wave * (X3 ? W::IMGX : W::IMG);       // this wave's input image [KP][64] (X3: hi / lo packs)
     [[maybe_unused]] f16x8* img8 = reinterpret_cast<f16x8*>(img) + lane;
+    // table stream of the long products shared through LDS by the four waves (gemm_img_x3s; GeoW::kShare): d = 200 iteration
+    // 7.08 -> 5.96 ms; the other instances keep per-wave streams (gemm_img_x3)
+    constexpr bool kShare = W::kShare;
     [[maybe_unused]] const f32x4 zero4x = {0.f, 0.f, 0.f, 0.f};
     const bool store_path = a.store_path && wave_valid;
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;
@@ -514,13 +623,15 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
             PSP_WIDE_SYNC();
-            if constexpr (X3) gemm_img_x3<HB, W::KS8>(h1, T + W::xW1, img, lane);
+            if constexpr (X3 && kShare) gemm_img_x3s<HB, W::KS8>(h1, T + W::xW1, img, lds + W::fStage, lane, wave);
+            else if constexpr (X3) gemm_img_x3<HB, W::KS8>(h1, T + W::xW1, img, lane);
             else gemm_img<HB, KP>(h1, T + W::tW1, img, lane);
             PSP_STAMP(ws2);
             // ---- X_{n+1} = X + b(X) dt + sigma v (solver.py:471-472): the drift part now, while the image still holds X_n
             if (a.drift_kind == DRIFT_DENSE) {
                 PSP_WIDE_SYNC();
-                if constexpr (X3) gemm_img_x3<DB, W::KS8>(X, T + W::xA, img, lane);
+                if constexpr (X3 && kShare) gemm_img_x3s<DB, W::KS8>(X, T + W::xA, img, lds + W::fStage, lane, wave);
+                else if constexpr (X3) gemm_img_x3<DB, W::KS8>(X, T + W::xA, img, lane);
                 else gemm_img<DB, KP>(X, T + W::tA, img, lane);                  // X += (dt A) X_n
             } else if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
@@ -633,7 +744,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
             PSP_STAMP(ws5);
             if (a.sigma_kind == SIGMA_DENSE) {
                 PSP_WIDE_SYNC();
-                if constexpr (X3) gemm_img_x3<DB, W::KS8>(X, T + W::xB, img, lane);
+                if constexpr (X3 && kShare) gemm_img_x3s<DB, W::KS8>(X, T + W::xB, img, lds + W::fStage, lane, wave);
+                else if constexpr (X3) gemm_img_x3<DB, W::KS8>(X, T + W::xB, img, lane);
                 else gemm_img<DB, KP>(X, T + W::tB, img, lane); // X += B v
             }
 

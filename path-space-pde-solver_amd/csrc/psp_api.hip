@@ -147,6 +147,7 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     if (fw < 1) fw = 1;
     if (fw > 8) fw = 8;
     if (p->inst.wide && fw > 4) fw = 4;   // wide family: one wave per SIMD
+    if (p->inst.wide && c->mlp_dtype == PSP_MLP_F16X3) fw = 4;   // its split-product forward shares the table stream between FOUR waves
     p->fwd_waves = fw;
     p->fwd_grid = (p->ntile16 + fw - 1) / fw;
     // few tiles: the feature-split forward (four waves per tile, weights in registers) cuts the per-step latency ~3x.
