@@ -302,7 +302,7 @@ __device__ __forceinline__ void gemm_Tb(f32x4 (&acc)[MB], const float* wlds, con
 // (the residual x - hi is exact in fp32; the power-of-two scale keeps lo out of the f16 subnormals) and
 //     a.b = hi_a hi_b + (hi_a lo_b + lo_a hi_b) / 2048 + O(2^-22 |a||b|)
 // with both sums accumulated in fp32 by v_mfma_f32_16x16x32_f16 (main chain on the caller's accumulator, correction chain on
-// its own).  Measured product error against fp64: 1.07 x that of the fp32 MFMA chain (oracle/..., tests/test_split_product.py)
+// its own).  Product error against fp64: 1.07 x that of an fp32 chain (numpy model of this arithmetic: tests/test_split_product.py)
 // -- the same parity bar as the fp32 kernels, which is why this is a mode of the fp32 path and not a reduced-precision one.
 // Range: |x| < 65504 for every operand (states, activations, matrix entries); beyond that the f16 hi part overflows.
 // Layout: one k-step of 32 spans TWO 16-feature blocks of the T layout exactly as in gemm_Tb (B operand = pack of eight local
