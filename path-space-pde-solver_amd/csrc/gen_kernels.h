@@ -851,6 +851,9 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
 }
 
 
+#ifndef PSP_GEN_X3_RING
+#define PSP_GEN_X3_RING 2         // depth of the split-product consumers' row-operand ring (3 spills 32 dwords under the 256-register cap)
+#endif
 #ifndef PSP_GEN_BF16_RING
 #define PSP_GEN_BF16_RING 4       // depth of the bf16 consumers' row-operand ring (A/B: -DPSP_GEN_BF16_RING=3 is round 1's)
 #endif
@@ -867,8 +870,17 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
 //           h rows:  dW2h += h1^T gz2 + h1'^T gz2',     h1 = (d1/2)^2, h1' = d1 w z1^    ( 8 MFMAs per tile)
 //       biases from the exchange tiles, the feature-on-lane parts of dW3 from the row tiles (rows split over the waves).
 // =======================================================================================
-template <int D, int H, bool BF16 = false>
+// X3 (psp_gen_config.mlp_dtype = PSP_MLP_F16X3, fp32 path store, shared trajectory weights): the consumers' weight-gradient
+// outer products as split f16 products over PAIRS of sample blocks (the bf16 consumers' structure with hi / lo packs: three
+// v_mfma_f32_16x16x32_f16 per fp32-grade product instead of eight fp32 MFMAs).  The whole kernel is linear in the trajectory weights
+// (~1 / K: below the f16 normal range), so they are scaled by a power of two that maps the largest |wY|, |wV| (one scan of the two
+// K-vectors per workgroup) to [2^7, 2^8) and the partial gradient is scaled back.  Every weighted operand then sits in the upper
+// f16 range, where the UNSCALED residual lo = f16(x - hi) is a normal number (for the unweighted O(1) operands a subnormal lo
+// costs at most 3e-8 absolute: fp32's own epsilon), so a.b = hi_a hi_b + hi_a lo_b + lo_a hi_b runs on ONE accumulator with no
+// 2048 anywhere.  Range: weighted adjoints stay below 65504 as long as the network factors (w3 phi', W2 products) stay below 256.
+template <int D, int H, bool BF16 = false, bool X3 = false>
 __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
+    static_assert(!(BF16 && X3), "one matrix-product mode");
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, HB = G::HB, KSH = G::KSH, EXT = G::EXT;
     constexpr int WHc = (HB >= 4) ? 4 : (HB >= 2 ? 2 : 1), WDc = 4 / WHc;      // consumers: columns first
@@ -887,12 +899,27 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     const unsigned selF = (col >> 3) ? 0x03020c0cu : 0x01000c0cu;
     const float* __restrict__ P = a.params;
 
-    gen_stage<(BF16 ? 1 : 0), KSH, HB>(lds + G::gW2hr, HB, tid, nthr, [&](int row, int c2) {
+    gen_stage<(X3 ? 2 : (BF16 ? 1 : 0)), KSH, HB>(lds + G::gW2hr, HB, tid, nthr, [&](int row, int c2) {
         return (row < H && c2 < H) ? P[G::oW2 + (DI + row) * H + c2] : 0.f; });
     __syncthreads();
-    float* bufs = lds + G::gEx;                       // [2 buffers][4 blocks][EXT tiles][256]
+    // (the split table pads the contraction to whole 32-feature steps: larger than the fp32 table unless H is a multiple of 32)
+    constexpr int TBL = X3 ? SplitGeo<KSH, HB>::floats(HB) : G::gEx - G::gW2hr;
+    float* bufs = lds + G::gW2hr + TBL;               // [2 buffers][4 blocks][EXT tiles][256]
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int Kpad = a.ntile16 * 16;
+    float gs = 1.0f, ginv = 1.0f;                     // X3: power-of-two scale of the trajectory weights and its inverse
+    if constexpr (X3) {
+        float am = 0.f;
+        for (int k0 = tid; k0 < Kpad; k0 += nthr) am = fmaxf(am, fmaxf(fabsf(a.wY[k0]), fabsf(a.wV[k0])));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+        if (lane == 0) bufs[wave] = am;
+        __syncthreads();
+        am = fmaxf(fmaxf(fmaxf(bufs[0], bufs[1]), fmaxf(bufs[2], bufs[3])), fmaxf(fmaxf(bufs[4], bufs[5]), fmaxf(bufs[6], bufs[7])));
+        const unsigned e = (__float_as_uint(am) >> 23) & 0xFFu;
+        if (e >= 8u && e <= 249u) { gs = __uint_as_float((261u - e) << 23); ginv = __uint_as_float((e - 7u) << 23); }
+        __syncthreads();                              // (the slots are part of the exchange area)
+    }
     const long long nblk = (long long)(a.N + 1) * a.ntile16;
     const long long nround = (nblk + 3) / 4;
     const int R = (int)((nround - blockIdx.x + gridDim.x - 1) / gridDim.x);
@@ -961,7 +988,7 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     const bool fin = (n == a.N);
                     // wY / wV / ahat are zero-padded to 16*ntile16 entries: plain loads, no branch around them
                     const size_t wofs = a.per_sample ? (size_t)n * Kpad : 0;            // per-sample mode: wY is (N+1, Kpad), ahat IS the coefficient
-            const float wy = a.wY[wofs + k], wv = a.per_sample ? 0.f : a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
+            const float wy = gs * a.wY[wofs + k], wv = a.per_sample ? 0.f : gs * a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
                     const float wsv = (bvalid && !fin) ? wy : 0.f;                             // weight of the tangent part
                     const float av = bvalid ? (a.per_sample ? ah : (fin ? wv : wy * ah)) : 0.f;
                     const int o0 = opaque_i(0);
@@ -985,8 +1012,8 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     g3b += (q == 0) ? av : 0.f;
         #pragma unroll
                     for (int m = 0; m < HB; ++m) { gz1t[m] = w3_T(G::oW3 + DI, m, o0); gz1[m] = av * gz1t[m]; }
-                    gen_gemm<(BF16 ? 1 : 0), HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
-                    gen_gemm<(BF16 ? 1 : 0), HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
+                    gen_gemm<(X3 ? 2 : (BF16 ? 1 : 0)), HB, KSH, HB>(gz1t, lds + G::gW2hr, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
+                    gen_gemm<(X3 ? 2 : (BF16 ? 1 : 0)), HB, KSH, HB>(gz1, lds + G::gW2hr, gz2, lane);        // gh1  = a w3h1 + W2h gz2
                     {   // d1 / z1^ are L2-resident (touch-prefetched one round ahead): fetch them only now
                         f32x4 d1[HB], z1t[HB];
         #pragma unroll
@@ -1024,12 +1051,12 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
         for (int m = 0; m < HB; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = g3h2T[m][r];
+                float v = ginv * g3h2T[m][r];
                 v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
                 if (j == 0) red[sub * (HB * 16 + 1) + 16 * m + 4 * r + q] = v;
             }
         {
-            float v = g3b;
+            float v = ginv * g3b;
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
             if (lane == 0) red[sub * (HB * 16 + 1) + HB * 16] = v;
         }
@@ -1108,7 +1135,126 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
         w4n = (sval && !fin) ? wy4 : zero4;
         a4n = sval ? (a.per_sample ? ah4 : (fin ? wv4 : wy4 * ah4)) : zero4;
     };
-    if constexpr (BF16) {
+    if constexpr (X3) {
+        // split f16 outer products over pairs of sample blocks (the structure of the bf16 consumers below; fp32 path store)
+        auto split2 = [&](const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                 // hi = f16(x), lo = f16(x - hi): the unscaled residual (header comment)
+                _Float16 h = (_Float16)u0[e];
+                hi[e] = h; lo[e] = (_Float16)(u0[e] - (float)h);
+                h = (_Float16)u1[e];
+                hi[4 + e] = h; lo[4 + e] = (_Float16)(u1[e] - (float)h);
+            }
+        };
+        auto weights_of = [&](long long c0, f32x4& w4, f32x4& a4) __attribute__((always_inline)) {
+            const bool sval = c0 < nblk;
+            const int cb = blk_at(c0);
+            const int n = cb / a.ntile16, t16 = cb % a.ntile16;
+            const bool fin = (n == a.N);
+            const int k4 = t16 * 16 + 4 * qq;
+            const f32x4 wy4 = gs * *reinterpret_cast<const f32x4*>(a.wY + k4);
+            const f32x4 wv4 = gs * *reinterpret_cast<const f32x4*>(a.wV + k4);
+            const f32x4 ah4 = *reinterpret_cast<const f32x4*>(a.ahat + (size_t)n * Kpad + k4);
+            w4 = (sval && !fin) ? wy4 : zero4;
+            a4 = sval ? (fin ? wv4 : wy4 * ah4) : zero4;
+        };
+        constexpr int RB = PSP_GEN_X3_RING;
+        constexpr int NROWP = cdiv(NROW, RB) * RB;
+        f32x4 ra0[RB], rb0[RB], ra1[RB], rb1[RB];
+        auto unit_blk = [&](int u, int which) __attribute__((always_inline)) {
+            const long long rbu = ((long long)blockIdx.x + (long long)(u >> 1) * gridDim.x) * 4 + 2 * (u & 1) + which;
+            return rbu;
+        };
+        f32x4 w40n, a40n, w41n, a41n;
+        {
+            const int c0 = blk_at(unit_blk(0, 0)), c1 = blk_at(unit_blk(0, 1));
+            weights_of(unit_blk(0, 0), w40n, a40n);
+            weights_of(unit_blk(0, 1), w41n, a41n);
+#pragma unroll
+            for (int i = 0; i < RB - 1 && i < NROW; ++i) {
+                ra0[i] = get_F(c0, row_ofs0(i)); rb0[i] = get_F(c0, row_ofs1(i));
+                ra1[i] = get_F(c1, row_ofs0(i)); rb1[i] = get_F(c1, row_ofs1(i));
+            }
+        }
+        __syncthreads();                                      // pairs with producer iteration 0
+        for (int it = 1; it <= R; ++it) {
+            const float* exch = bufs + ((it - 1) & 1) * 4 * (EXT * 256);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int u = 2 * (it - 1) + p;
+                const float* ex0 = exch + (2 * p) * (EXT * 256);
+                const float* ex1 = ex0 + EXT * 256;
+                const int cb0 = blk_at(unit_blk(u, 0)), cb1 = blk_at(unit_blk(u, 1));
+                const int nb0 = blk_at(unit_blk(u + 1, 0)), nb1 = blk_at(unit_blk(u + 1, 1));   // next unit (clamped past the end)
+                const f32x4 w40 = w40n, a40 = a40n, w41 = w41n, a41 = a41n;
+                weights_of(unit_blk(u + 1, 0), w40n, a40n);   // consumed a whole pair later
+                weights_of(unit_blk(u + 1, 1), w41n, a41n);
+                // B operands: the adjoint panels of the pair as (hi, 2048 hi, lo) packs
+                f16x8 z2h[NIB], z2l[NIB], z2th[NIB], z2tl[NIB], z1h[NIB], z1l[NIB], z1th[NIB], z1tl[NIB];
+#pragma unroll
+                for (int t = 0; t < NIB; ++t) {
+                    const f32x4 u0 = tile_get(ex0 + cbc[t], lane), u1 = tile_get(ex1 + cbc[t], lane);
+                    const f32x4 v0 = tile_get(ex0 + 2 * HB * 256 + cbc[t], lane), v1 = tile_get(ex1 + 2 * HB * 256 + cbc[t], lane);
+                    bs2[t] += hsum4(u0) + hsum4(u1);
+                    bs1[t] += hsum4(v0) + hsum4(v1);
+                    split2(u0, u1, z2h[t], z2l[t]);
+                    split2(v0, v1, z1h[t], z1l[t]);
+                    split2(tile_get(ex0 + HB * 256 + cbc[t], lane), tile_get(ex1 + HB * 256 + cbc[t], lane), z2th[t], z2tl[t]);
+                    split2(tile_get(ex0 + 3 * HB * 256 + cbc[t], lane), tile_get(ex1 + 3 * HB * 256 + cbc[t], lane), z1th[t], z1tl[t]);
+                }
+#pragma unroll
+                for (int i = 0; i < NROWP; ++i) {
+                    const int slot = i % RB;
+                    {   // request the item RB - 1 ahead: same pair, or the first items of the next one
+                        const int jn = i + RB - 1;
+                        const int ns = jn % RB;
+                        if (jn < NROW) {
+                            ra0[ns] = get_F(cb0, row_ofs0(jn)); rb0[ns] = get_F(cb0, row_ofs1(jn));
+                            ra1[ns] = get_F(cb1, row_ofs0(jn)); rb1[ns] = get_F(cb1, row_ofs1(jn));
+                        } else if (jn >= NROWP && jn - NROWP < NROW) {
+                            ra0[ns] = get_F(nb0, row_ofs0(jn - NROWP)); rb0[ns] = get_F(nb0, row_ofs1(jn - NROWP));
+                            ra1[ns] = get_F(nb1, row_ofs0(jn - NROWP)); rb1[ns] = get_F(nb1, row_ofs1(jn - NROWP));
+                        }
+                    }
+                    if (i < NROW) {
+                        f32x4 A00, A10, A01, A11;
+                        if (i < NRX) {
+                            A00 = ra0[slot]; A10 = w40 * rb0[slot];
+                            A01 = ra1[slot]; A11 = w41 * rb1[slot];
+                        } else {
+                            const f32x4 d10 = ra0[slot], d11 = ra1[slot];
+                            A00 = 0.25f * d10 * d10; A10 = d10 * (w40 * rb0[slot]);
+                            A01 = 0.25f * d11 * d11; A11 = d11 * (w41 * rb1[slot]);
+                        }
+                        if (i % WHc == wh) g3r[i] += hsum4(a40 * A00 + A10) + hsum4(a41 * A01 + A11);
+                        f16x8 P0h, P0l, P1h, P1l;
+                        split2(A00, A01, P0h, P0l);
+                        split2(A10, A11, P1h, P1l);
+                        // PA . pz = hi_a hi_b + hi_a lo_b + lo_a hi_b on one accumulator
+                        auto fma3 = [&](f32x4& acc, const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl)
+                                        __attribute__((always_inline)) {
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+                        };
+#pragma unroll
+                        for (int t = 0; t < NIB; ++t) {
+                            if (i < NRX) {
+                                fma3(acc2x[i][t], P0h, P0l, z2h[t], z2l[t]);
+                                fma3(acc1[i][t], P0h, P0l, z1h[t], z1l[t]);
+                                fma3(acc2x[i][t], P1h, P1l, z2th[t], z2tl[t]);
+                                fma3(acc1[i][t], P1h, P1l, z1th[t], z1tl[t]);
+                            } else {
+                                fma3(acc2h[i - NRX][t], P0h, P0l, z2h[t], z2l[t]);
+                                fma3(acc2h[i - NRX][t], P1h, P1l, z2th[t], z2tl[t]);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
+        }
+    } else if constexpr (BF16) {
         // bf16 outer products (v_mfma_f32_16x16x32_bf16): the 32-deep k-step is the sample index of TWO sample blocks --
         // lane (row / col, qq) holds samples 4qq..4qq+3 of either block in both operands, so a k-step is a pack of the two
         // blocks' registers on both sides (the sum over k does not care which slot a sample sits in).  One MFMA replaces
@@ -1302,6 +1448,7 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
 
     }
     // ---- write-out: tile (rbk, cbk): lane (col, qq), reg rr <-> dW[16 rbk + 4 qq + rr][16 cbk + col]   (weights are (in, out))
+    const float osc = ginv;                            // X3: un-scale the weights' power of two (1 otherwise)
 #pragma unroll
     for (int s = 0; s < NRX; ++s)
 #pragma unroll
@@ -1311,8 +1458,8 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
             for (int rr = 0; rr < 4; ++rr) {
                 const int i = 16 * rbk + 4 * qq + rr, jo = 16 * cbk + col;
                 if (rbk < DBI && cbk < HB && i < DI && jo < H) {
-                    gp[G::oW2 + i * H + jo] = acc2x[s][t][rr];
-                    gp[G::oW1 + i * H + jo] = acc1[s][t][rr];
+                    gp[G::oW2 + i * H + jo] = osc * acc2x[s][t][rr];
+                    gp[G::oW1 + i * H + jo] = osc * acc1[s][t][rr];
                 }
             }
         }
@@ -1324,19 +1471,19 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int i = 16 * rbk + 4 * qq + rr, jo = 16 * cbk + col;
-                if (rbk < HB && cbk < HB && i < H && jo < H) gp[G::oW2 + (DI + i) * H + jo] = acc2h[s][t][rr];
+                if (rbk < HB && cbk < HB && i < H && jo < H) gp[G::oW2 + (DI + i) * H + jo] = osc * acc2h[s][t][rr];
             }
         }
 #pragma unroll
     for (int t = 0; t < NIB; ++t) {
-        const float v2 = qsum(bs2[t]), v1 = qsum(bs1[t]);
+        const float v2 = ginv * qsum(bs2[t]), v1 = ginv * qsum(bs1[t]);
         const int f = 16 * (wh + WHc * t) + col;
         if (wd == 0 && qq == 0 && (wh + WHc * t) < HB && f < H) { gp[G::ob2 + f] = v2; gp[G::ob1 + f] = v1; }
     }
     // dW3, x and h1 rows: lane = feature; row item i belongs to the wave with i % WHc == wh
 #pragma unroll
     for (int i = 0; i < NROW; ++i) {
-        const float v = qsum(g3r[i]);
+        const float v = ginv * qsum(g3r[i]);
         if (i % WHc == wh && qq == 0) {
             if (i < NRX) {
                 const int f = 16 * (wd + WDc * i) + col;
@@ -1371,6 +1518,7 @@ struct GenInstance {
     hipError_t (*launch_bwd2_bf16)(const GenArgs&, int grid, hipStream_t);             // adjoint products + weight-gradient outer products on bf16 MFMA
     int (*fwd_x3_lds_bytes)();                                                         // split-product forward (PSP_MLP_F16X3)
     hipError_t (*launch_fwd_x3)(const GenArgs&, int grid, int block, hipStream_t);
+    hipError_t (*launch_bwd2_x3)(const GenArgs&, int grid, hipStream_t);               // split-product weight gradients (shared weights only)
 };
 
 template <int D, int H>
@@ -1407,6 +1555,15 @@ struct GenLaunch {
     static hipError_t fwd_bf16(const GenArgs& a, int grid, int block, hipStream_t s) {
         return a.noise_mode == NOISE_PHILOX ? fwd_as<true, true>(a, grid, block, s) : fwd_as<true, false>(a, grid, block, s);
     }
+    static int bwd2_x3_lds() { return (G::gW2hr + SplitGeo<G::KSH, G::HB>::floats(G::HB) + 2 * 4 * G::EXT * 256) * 4; }
+    static hipError_t bwd2_x3(const GenArgs& a, int grid, hipStream_t s) {
+        if (bwd2_x3_lds() > 160 * 1024) return bwd2(a, grid, s);       // (split table does not fit: the fp32-MFMA kernel, same results)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_bwd2_kernel<D, H, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bwd2_x3_lds());
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gen_bwd2_kernel<D, H, false, true>), dim3(grid), dim3(512), bwd2_x3_lds(), s, a);
+        return hipGetLastError();
+    }
     static int fwd_x3_lds() { return G::fwd_x3_lds_floats() * 4; }
     template <bool PHILOX>
     static hipError_t fwd_x3_as(const GenArgs& a, int grid, int block, hipStream_t s) {
@@ -1434,7 +1591,7 @@ struct GenLaunch {
 #endif
     static GenInstance instance() {
         return GenInstance{D, H, G::P, G::PB, G::PB16, &fwd_lds, &bwd_lds, &fwd, legacy_bwd, &bwd2_lds, &bwd2, &fwd_bf16, &bwd2_bf16,
-                           &fwd_x3_lds, &fwd_x3};
+                           &fwd_x3_lds, &fwd_x3, &bwd2_x3};
     }
 };
 

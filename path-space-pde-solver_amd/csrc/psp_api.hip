@@ -950,10 +950,12 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
     a.params = params; a.path = const_cast<float*>(path); a.ahat = const_cast<float*>(ahat);
     a.wY = wY; a.wV = wV; a.grad_partial = grad_partial;
     if (cfg->mlp_dtype < PSP_MLP_FP32 || cfg->mlp_dtype > PSP_MLP_F16X3) return fail(-1, "mlp_dtype out of range");
-    // (PSP_MLP_F16X3: split products in the forward rollout; this kernel stays on fp32 MFMA, same path store)
     if (cfg->mlp_dtype == PSP_MLP_BF16 && !p.bwd_specialised)
         return fail(-3, "the bf16 backward exists for the role-specialised kernel only (LDS budget / PSP_BWD_VARIANT)");
+    // (PSP_MLP_F16X3 with shared trajectory weights: the split-product consumers; per-sample weights keep the fp32 kernel)
+    const bool bwd_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.bwd_specialised && !cfg->per_sample_weights && p.inst.launch_bwd2_x3;
     hipError_t e = cfg->mlp_dtype == PSP_MLP_BF16 ? p.inst.launch_bwd2_bf16(a, p.bwd_grid, (hipStream_t)stream)
+                   : bwd_x3 ? p.inst.launch_bwd2_x3(a, p.bwd_grid, (hipStream_t)stream)
                    : p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
                                        : p.inst.launch_bwd(a, p.bwd_grid, 256, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "gen_bwd_kernel launch");
