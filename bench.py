@@ -729,9 +729,9 @@ def main_general(args, psp, sharding):
     # peak (forward always; backward only with mlp == 'bf16')
     on_bf16 = (mlp in ("bf16", "bf16_fwd") and not bwd_dom) or (mlp == "bf16" and bwd_dom)
     peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
-    # split-product forward (mlp_dtype 'auto' / 'f16x3'): three f16 flops per algorithmic fp32 flop; the backward kernel stays fp32 MFMA
+    # split-product kernels (mlp_dtype 'auto' / 'f16x3', forward and backward): three f16 flops per algorithmic fp32 flop
     x3 = getattr(plan, "matrix_mode", "fp32") == "f16x3"
-    if x3 and not bwd_dom:
+    if x3:
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0
     achieved = dom_fl * units / (dom_ms * 1e-3) / 1e12
     path_B = float(plan.sizes.path_bytes) / ((w["N"] + 1) * w["K"]) if hasattr(plan, "sizes") else None

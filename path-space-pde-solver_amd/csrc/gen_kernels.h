@@ -878,6 +878,10 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
 // f16 range, where the UNSCALED residual lo = f16(x - hi) is a normal number (for the unweighted O(1) operands a subnormal lo
 // costs at most 3e-8 absolute: fp32's own epsilon), so a.b = hi_a hi_b + hi_a lo_b + lo_a hi_b runs on ONE accumulator with no
 // 2048 anywhere.  Range: weighted adjoints stay below 65504 as long as the network factors (w3 phi', W2 products) stay below 256.
+// (Tried and dropped: the role cut of hjb_bwd3_kernel -- producers writing the four adjoint panels pre-split as pair images,
+//  consumers owning ROW items for all column blocks so that each row operand is loaded and split by one wave only: 656 instead of
+//  2 111 VALU instructions per round in the consumers, correct on all 59 tests, but 20 accumulator tiles + three row items'
+//  packs + their landing registers do not fit 256 registers: 57 spilled dwords in the consumer loop, 5.3 ms against 4.47.)
 template <int D, int H, bool BF16 = false, bool X3 = false>
 __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     static_assert(!(BF16 && X3), "one matrix-product mode");
@@ -1505,344 +1509,6 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     }
 }
 
-// =======================================================================================
-// gen_bwd3_kernel: split-product backward with the roles of hjb_bwd3_kernel (hjbx_kernels.h).  gen_bwd2_kernel<.., X3> lets all
-// four consumers load and split the SAME row operands (each owns one column block); here
-//   PRODUCERS (waves 0-3, one sample block each per round) form the four adjoint panels gz2, gz2', gz1, gz1' as before and write
-//     them ONCE, already split (hi | unscaled lo), as pair-interleaved f16 images (feature-major; per feature and sample quad the
-//     four samples of block c0, then of block c1), and keep db2 / db1 as element-wise sums in registers;
-//   CONSUMERS (waves 4-7) own ROW items (x rows: images X, U; h rows: images d1, z1^) i = w, w + 4, w + 8 of every block pair and
-//     ALL column blocks: each row operand is loaded and split by exactly one wave (a quarter of the loads and of the VALU work),
-//     the column operands are 16-byte LDS reads of the producers' images.
-// Trajectory weights scaled by a power of two as in gen_bwd2_kernel<.., X3> (same one-accumulator products on unscaled residuals);
-// shared weights only (per-sample weights run gen_bwd2_kernel).  Same gradient layout; dW3 rows from the row owners.
-// =======================================================================================
-template <int D, int H>
-__global__ __launch_bounds__(512) void gen_bwd3_kernel(const GenArgs a) {
-    using G = GGeo<D, H>;
-    constexpr int DI = G::DI, DBI = G::DBI, HB = G::HB, KSH = G::KSH;
-    constexpr int NROW = DBI + HB, MAXR = cdiv(NROW, 4);               // row items; per consumer wave
-    constexpr int TBL = SplitGeo<KSH, HB>::floats(HB);                 // W2h (reverse) split table, floats
-    constexpr int IMG = HB * 512;                                      // halves of one panel image of a PAIR (16 HB features x 32 samples)
-    constexpr int PAIRH = 8 * IMG;                                     // gz2 | gz2' | gz1 | gz1', each hi then lo
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, q = lane >> 4;
-    const bool producer = wave < 4;
-    const int sub = wave & 3;
-    const int qq = lane >> 4, col = lane & 15;
-    const float* __restrict__ P = a.params;
-
-    gen_stage<2, KSH, HB>(lds, HB, tid, nthr, [&](int row, int c2) {
-        return (row < H && c2 < H) ? P[G::oW2 + (DI + row) * H + c2] : 0.f; });
-    __syncthreads();
-    _Float16* exh = reinterpret_cast<_Float16*>(lds + TBL);             // [2 buffers][2 pairs][PAIRH] halves
-    float* scratchf = lds + TBL;                                        // (float view of the same area: scan slots, bias sums)
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const int Kpad = a.ntile16 * 16;
-    const long long nblk = (long long)(a.N + 1) * a.ntile16;
-    const long long nround = (nblk + 3) / 4;
-    const int R = (int)((nround - blockIdx.x + gridDim.x - 1) / gridDim.x);
-    float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
-
-    // power-of-two scale of the trajectory weights: largest |wY|, |wV| -> [2^7, 2^8)   (gen_bwd2_kernel<.., X3>)
-    float gs = 1.0f, ginv = 1.0f;
-    {
-        float am = 0.f;
-        for (int k0 = tid; k0 < Kpad; k0 += nthr) am = fmaxf(am, fmaxf(fabsf(a.wY[k0]), fabsf(a.wV[k0])));
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
-        if (lane == 0) scratchf[wave] = am;
-        __syncthreads();
-        am = fmaxf(fmaxf(fmaxf(scratchf[0], scratchf[1]), fmaxf(scratchf[2], scratchf[3])),
-                   fmaxf(fmaxf(scratchf[4], scratchf[5]), fmaxf(scratchf[6], scratchf[7])));
-        const unsigned e = (__float_as_uint(am) >> 23) & 0xFFu;
-        if (e >= 8u && e <= 249u) { gs = __uint_as_float((261u - e) << 23); ginv = __uint_as_float((e - 7u) << 23); }
-        __syncthreads();
-    }
-
-    if (producer) {
-        auto w3_T = [&](int base, int m, int o0) {          // o0 = opaque zero: keeps the loads inside the round loop
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const int f = 16 * m + 4 * r + q; v[r] = f < H ? P[base + o0 + (f < H ? f : 0)] : 0.f; }
-            return v;
-        };
-        f32x4 g3h2T[HB], sB2[HB], sB1[HB];              // dW3 (h2 part), db2, db1 in T layout, reduced over lanes at the end
-        float g3b = 0.f;
-#pragma unroll
-        for (int m = 0; m < HB; ++m) { g3h2T[m] = zero4; sB2[m] = zero4; sB1[m] = zero4; }
-        // one image as split halves: element (feature f, block c of the pair, sample j) at f * 32 + (j >> 2) * 8 + c * 4 + (j & 3)
-        auto put_panel = [&](_Float16* img, const f32x4 (&v)[HB]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int m = 0; m < HB; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const _Float16 h = (_Float16)v[m][r];
-                    const int f = 16 * m + 4 * r + q;
-                    img[f * 32] = h;
-                    img[IMG + f * 32] = (_Float16)(v[m][r] - (float)h);
-                }
-        };
-        for (int it = 0; it <= R; ++it) {
-            if (it < R) {
-                const long long round = blockIdx.x + (long long)it * gridDim.x;
-                const long long blk0 = round * 4 + sub;
-                const bool bvalid = blk0 < nblk;
-                const long long blk = bvalid ? blk0 : nblk - 1;
-                const int n = (int)(blk / a.ntile16), t16 = (int)(blk % a.ntile16);
-                const int k = t16 * 16 + j;
-                const bool kvalid = bvalid && k < a.K_local;
-                const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
-                const bool fin = (n == a.N);
-                const float wy = gs * a.wY[k], wv = gs * a.wV[k], ah = a.ahat[(size_t)n * Kpad + k];
-                const float wsv = (bvalid && !fin) ? wy : 0.f;                             // weight of the tangent part
-                const float av = bvalid ? (fin ? wv : wy * ah) : 0.f;
-                const int o0 = opaque_i(0);
-                _Float16* ex = exh + ((it & 1) * 2 + (sub >> 1)) * PAIRH + (j >> 2) * 8 + (sub & 1) * 4 + (j & 3);
-                f32x4 gz2[HB], gz2t[HB], gz1[HB], gz1t[HB];
-                {
-                    f32x4 d2[HB], z2t[HB];
-#pragma unroll
-                    for (int m = 0; m < HB; ++m) {
-                        d2[m] = image_get_T<false>(pb, G::pD2, G::qD2, m);
-                        z2t[m] = wsv * image_get_T<false>(pb, G::pZ2, G::qZ2, m);
-                    }
-#pragma unroll
-                    for (int m = 0; m < HB; ++m) {
-                        const f32x4 w3h2 = w3_T(G::oW3 + DI + H, m, o0);
-                        gz2t[m] = w3h2 * d2[m];
-                        gz2[m] = av * gz2t[m] + w3h2 * step2(d2[m]) * z2t[m];
-                        g3h2T[m] += av * (0.25f * d2[m] * d2[m]) + d2[m] * z2t[m];      // dW3 (h2 part): a h2 + h2'
-                    }
-                }
-                g3b += (q == 0) ? av : 0.f;
-                if (!kvalid) {
-#pragma unroll
-                    for (int m = 0; m < HB; ++m) { gz2[m] = zero4; gz2t[m] = zero4; }
-                }
-#pragma unroll
-                for (int m = 0; m < HB; ++m) sB2[m] += gz2[m];
-                put_panel(ex, gz2);
-                put_panel(ex + 2 * IMG, gz2t);
-#pragma unroll
-                for (int m = 0; m < HB; ++m) { gz1t[m] = w3_T(G::oW3 + DI, m, o0); gz1[m] = av * gz1t[m]; }
-                gen_gemm<2, HB, KSH, HB>(gz1t, lds, gz2t, lane);      // gh1' = w3h1 + W2h gz2'
-                gen_gemm<2, HB, KSH, HB>(gz1, lds, gz2, lane);        // gh1  = a w3h1 + W2h gz2
-                {
-                    f32x4 d1[HB], z1t[HB];
-#pragma unroll
-                    for (int m = 0; m < HB; ++m) {
-                        d1[m] = image_get_T<false>(pb, G::pD1, G::qD1, m);
-                        z1t[m] = wsv * image_get_T<false>(pb, G::pZ1, G::qZ1, m);
-                    }
-#pragma unroll
-                    for (int m = 0; m < HB; ++m) {
-                        gz1[m] = gz1[m] * d1[m] + gz1t[m] * step2(d1[m]) * z1t[m];
-                        gz1t[m] = gz1t[m] * d1[m];
-                    }
-                }
-                if (!kvalid) {
-#pragma unroll
-                    for (int m = 0; m < HB; ++m) { gz1[m] = zero4; gz1t[m] = zero4; }
-                }
-#pragma unroll
-                for (int m = 0; m < HB; ++m) sB1[m] += gz1[m];
-                put_panel(ex + 4 * IMG, gz1);
-                put_panel(ex + 6 * IMG, gz1t);
-            }
-            __syncthreads();                              // swap the exchange buffers (pairs with the consumer loop)
-        }
-        // T-layout partial sums: reduce over the 16 trajectory lanes, then (by the consumers) over the 4 producers
-        constexpr int RS = 3 * HB * 16 + 1;
-        float* red = scratchf + sub * RS;                 // the exchange area is free after the last barrier
-        auto lane_sum = [&](float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; };
-#pragma unroll
-        for (int m = 0; m < HB; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v3 = ginv * lane_sum(g3h2T[m][r]), v2 = ginv * lane_sum(sB2[m][r]), v1 = ginv * lane_sum(sB1[m][r]);
-                if (j == 0) {
-                    red[16 * m + 4 * r + q] = v3;
-                    red[HB * 16 + 16 * m + 4 * r + q] = v2;
-                    red[2 * HB * 16 + 16 * m + 4 * r + q] = v1;
-                }
-            }
-        {
-            const float v = ginv * lane_sum(g3b);
-            if (lane == 0) red[3 * HB * 16] = v;
-        }
-        __syncthreads();                                  // pairs with the consumers' barrier before the write-out of these sums
-        return;
-    }
-    // ==================================================================================== consumers
-    // row item i = sub + 4 s (s < MAXR): i < DBI -> x rows (images X, U) of state block i, else h rows (d1, z1^) of hidden block i - DBI
-    constexpr int MAXRX = cdiv(DBI, 4);                // slots that can hold an x row (i = sub + 4 s >= 4 s)
-    f32x4 accA[MAXR][HB], accB[MAXRX][HB];             // x rows: dW2 (x part), dW1;  h rows: dW2 (h part), --
-    float g3r[MAXR];
-#pragma unroll
-    for (int s = 0; s < MAXR; ++s) {
-        g3r[s] = 0.f;
-#pragma unroll
-        for (int t = 0; t < HB; ++t) { accA[s][t] = zero4; if (s < MAXRX) accB[s < MAXRX ? s : 0][t] = zero4; }
-    }
-    const int nblk_i = (int)nblk;
-    auto blk_at = [&](long long c0) __attribute__((always_inline)) {
-        const int c = (c0 < (long long)nblk_i) ? (int)c0 : nblk_i - 1;
-        return __builtin_amdgcn_readfirstlane(c);
-    };
-    typedef const __attribute__((address_space(1))) float* gptr_t;
-    const unsigned lofsU = (unsigned)image_lane_offset_F(lane);
-    auto get_F = [&](int blk, int ofs) __attribute__((always_inline)) {
-        const unsigned long long addr = sgpr_block_addr(a.path, (unsigned long long)blk, (unsigned)G::PB, (unsigned)ofs);
-        return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((gptr_t)addr + lofsU);
-    };
-    // image offsets of row item i (clamped to a valid block: results of i >= NROW are discarded)
-    auto item_of = [&](int s) __attribute__((always_inline)) { const int i = sub + 4 * s; return i < NROW ? i : NROW - 1; };
-    auto ofs0 = [&](int i) __attribute__((always_inline)) { return i < DBI ? G::pX + i * 256 : G::pD1 + (i - DBI) * 256; };
-    auto ofs1 = [&](int i) __attribute__((always_inline)) { return i < DBI ? G::pU + i * 256 : G::pZ1 + (i - DBI) * 256; };
-    auto unit_blk = [&](int u, int which) __attribute__((always_inline)) {
-        return ((long long)blockIdx.x + (long long)(u >> 1) * gridDim.x) * 4 + 2 * (u & 1) + which;
-    };
-    auto weights_of = [&](long long c0, f32x4& w4, f32x4& a4) __attribute__((always_inline)) {
-        const bool sval = c0 < nblk;
-        const int cb = blk_at(c0);
-        const int n = cb / a.ntile16, t16 = cb % a.ntile16;
-        const bool fin = (n == a.N);
-        const int k4 = t16 * 16 + 4 * qq;
-        const f32x4 wy4 = gs * *reinterpret_cast<const f32x4*>(a.wY + k4);
-        const f32x4 wv4 = gs * *reinterpret_cast<const f32x4*>(a.wV + k4);
-        const f32x4 ah4 = *reinterpret_cast<const f32x4*>(a.ahat + (size_t)n * Kpad + k4);
-        w4 = (sval && !fin) ? wy4 : zero4;
-        a4 = sval ? (fin ? wv4 : wy4 * ah4) : zero4;
-    };
-    auto split2 = [&](const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                     // hi = f16(x), lo = f16(x - hi): the unscaled residual
-            _Float16 h = (_Float16)u0[e];
-            hi[e] = h; lo[e] = (_Float16)(u0[e] - (float)h);
-            h = (_Float16)u1[e];
-            hi[4 + e] = h; lo[4 + e] = (_Float16)(u1[e] - (float)h);
-        }
-    };
-    auto fma3 = [&](f32x4& acc, const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl) __attribute__((always_inline)) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-    };
-    // landing registers of the unit one ahead: both images of this wave's row items, both blocks of the pair; and its weights
-    f32x4 La[MAXR][2], Lb[MAXR][2], w40n, a40n, w41n, a41n;
-    auto issue = [&](int u) __attribute__((always_inline)) {
-        const int c0 = blk_at(unit_blk(u, 0)), c1 = blk_at(unit_blk(u, 1));
-        weights_of(unit_blk(u, 0), w40n, a40n);
-        weights_of(unit_blk(u, 1), w41n, a41n);
-#pragma unroll
-        for (int s = 0; s < MAXR; ++s) {
-            const int i = item_of(s);
-            La[s][0] = get_F(c0, ofs0(i)); Lb[s][0] = get_F(c0, ofs1(i));
-            La[s][1] = get_F(c1, ofs0(i)); Lb[s][1] = get_F(c1, ofs1(i));
-        }
-    };
-    const int bofs = opaque_i((lane & 15) * 32 + (lane >> 4) * 8);      // B operand: lane (column feature, sample quad)
-    issue(0);
-    __syncthreads();                                      // pairs with producer iteration 0
-    for (int it = 1; it <= R; ++it) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int u = 2 * (it - 1) + p;
-            const _Float16* ex = exh + (((it - 1) & 1) * 2 + p) * PAIRH + bofs;
-            const f32x4 w40 = w40n, a40 = a40n, w41 = w41n, a41 = a41n;
-            f16x8 P0h[MAXR], P0l[MAXR], P1h[MAXR], P1l[MAXR];
-#pragma unroll
-            for (int s = 0; s < MAXR; ++s) {
-                const bool isx = item_of(s) < DBI;           // wave-uniform
-                f32x4 A00, A10, A01, A11;
-                if (isx) {
-                    A00 = La[s][0]; A10 = w40 * Lb[s][0];                                   // x0, x0' = w U
-                    A01 = La[s][1]; A11 = w41 * Lb[s][1];
-                } else {
-                    const f32x4 d10 = La[s][0], d11 = La[s][1];
-                    A00 = 0.25f * d10 * d10; A10 = d10 * (w40 * Lb[s][0]);                   // h1, h1'
-                    A01 = 0.25f * d11 * d11; A11 = d11 * (w41 * Lb[s][1]);
-                }
-                g3r[s] += hsum4(a40 * A00 + A10) + hsum4(a41 * A01 + A11);                  // dW3 row of this item
-                split2(A00, A01, P0h[s], P0l[s]);
-                split2(A10, A11, P1h[s], P1l[s]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            issue(u + 1);                                     // next unit (clamped past the end); consumed a whole pair later
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < HB; ++t) {
-                {
-                    const f16x8 z2h = *reinterpret_cast<const f16x8*>(ex + 0 * IMG + t * 512), z2l = *reinterpret_cast<const f16x8*>(ex + 1 * IMG + t * 512);
-                    const f16x8 z2th = *reinterpret_cast<const f16x8*>(ex + 2 * IMG + t * 512), z2tl = *reinterpret_cast<const f16x8*>(ex + 3 * IMG + t * 512);
-#pragma unroll
-                    for (int s = 0; s < MAXR; ++s) {
-                        fma3(accA[s][t], P0h[s], P0l[s], z2h, z2l);
-                        fma3(accA[s][t], P1h[s], P1l[s], z2th, z2tl);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(kFenceMask);
-                {
-                    const f16x8 z1h = *reinterpret_cast<const f16x8*>(ex + 4 * IMG + t * 512), z1l = *reinterpret_cast<const f16x8*>(ex + 5 * IMG + t * 512);
-                    const f16x8 z1th = *reinterpret_cast<const f16x8*>(ex + 6 * IMG + t * 512), z1tl = *reinterpret_cast<const f16x8*>(ex + 7 * IMG + t * 512);
-#pragma unroll
-                    for (int s = 0; s < MAXRX; ++s) {        // x rows also feed dW1 (a slot that holds an h row in this wave runs
-                        fma3(accB[s][t], P0h[s], P0l[s], z1h, z1l);      // along: no branch around the accumulators; discarded below)
-                        fma3(accB[s][t], P1h[s], P1l[s], z1th, z1tl);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(kFenceMask);
-            }
-        }
-        __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
-    }
-    // ---- write-out: tile (row block, column block t): lane (col, qq), reg rr <-> dW[16 rb + 4 qq + rr][16 t + col]   (weights are (in, out))
-#pragma unroll
-    for (int s = 0; s < MAXR; ++s) {
-        const int i = sub + 4 * s;
-        if (i < NROW) {
-            const bool isx = i < DBI;
-            const int rb = isx ? i : i - DBI;
-#pragma unroll
-            for (int t = 0; t < HB; ++t)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int row = 16 * rb + 4 * qq + rr, jo = 16 * t + col;
-                    if (isx) {
-                        if (row < DI && jo < H) {
-                            gp[G::oW2 + row * H + jo] = ginv * accA[s][t][rr];
-                            if (s < MAXRX) gp[G::oW1 + row * H + jo] = ginv * accB[s < MAXRX ? s : 0][t][rr];
-                        }
-                    } else if (row < H && jo < H) {
-                        gp[G::oW2 + (DI + row) * H + jo] = ginv * accA[s][t][rr];
-                    }
-                }
-            // dW3, x and h1 rows: lane = feature of the row block
-            const float v = ginv * qsum(g3r[s]);
-            const int f = 16 * rb + col;
-            if (qq == 0) {
-                if (isx) { if (f < DI) gp[G::oW3 + f] = v; }
-                else if (f < H) gp[G::oW3 + DI + f] = v;
-            }
-        }
-    }
-    __syncthreads();                                      // pairs with the producers' barrier after their LDS write
-    {
-        constexpr int RS = 3 * HB * 16 + 1;
-        const float* red = scratchf;
-        for (int f = tid - 256; f < RS; f += 256) {
-            const float v = (red[f] + red[RS + f]) + (red[2 * RS + f] + red[3 * RS + f]);
-            if (f < HB * 16) { if (f < H) gp[G::oW3 + DI + H + f] = v; }
-            else if (f < 2 * HB * 16) { if (f - HB * 16 < H) gp[G::ob2 + (f - HB * 16)] = v; }
-            else if (f < 3 * HB * 16) { if (f - 2 * HB * 16 < H) gp[G::ob1 + (f - 2 * HB * 16)] = v; }
-            else gp[G::ob3] = v;
-        }
-    }
-}
-
 struct GenInstance {
     int d, H, n_params, path_floats_per_block;
     int path_dwords_per_block16;     // bf16-pair path block (mlp_dtype == PSP_MLP_BF16)
@@ -1894,17 +1560,7 @@ struct GenLaunch {
         return a.noise_mode == NOISE_PHILOX ? fwd_as<true, true>(a, grid, block, s) : fwd_as<true, false>(a, grid, block, s);
     }
     static int bwd2_x3_lds() { return (G::gW2hr + SplitGeo<G::KSH, G::HB>::floats(G::HB) + 2 * 4 * G::EXT * 256) * 4; }
-    static int bwd3_lds() { return (SplitGeo<G::KSH, G::HB>::floats(G::HB) + 2 * 2 * (8 * G::HB * 512) / 2) * 4; }
-    static hipError_t bwd3(const GenArgs& a, int grid, hipStream_t s) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_bwd3_kernel<D, H>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, bwd3_lds());
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((gen_bwd3_kernel<D, H>), dim3(grid), dim3(512), bwd3_lds(), s, a);
-        return hipGetLastError();
-    }
     static hipError_t bwd2_x3(const GenArgs& a, int grid, hipStream_t s) {
-        static const char* v = getenv("PSP_GEN_BWD_X3");               // diagnostic: PSP_GEN_BWD_X3=2 keeps gen_bwd2_kernel<.., X3>
-        if (bwd3_lds() <= 160 * 1024 && !(v && v[0] == '2')) return bwd3(a, grid, s);
         if (bwd2_x3_lds() > 160 * 1024) return bwd2(a, grid, s);       // (split table does not fit: the fp32-MFMA kernel, same results)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_bwd2_kernel<D, H, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bwd2_x3_lds());
