@@ -18,10 +18,24 @@ def dev():
     return torch.device("cuda:0")
 
 
+MODE = "auto"
+
+
+@pytest.fixture(autouse=True, params=["fp32", "f16x3"])
+def matrix_mode(request):
+    """Every test of this file runs on the fp32-MFMA kernels and on the split-product kernels (the default 'auto' resolves to the
+    latter): same golden logs, same oracle gradients, same bounds."""
+    global MODE
+    MODE = request.param
+    yield
+    MODE = "auto"
+
+
 def build(case, **over):
     prob = getattr(psp, case["problem"]["kind"])(device=dev(), **case["problem"]["kwargs"])
     kw = dict(case["solver"])
     kw.update(over)
+    kw.setdefault("mlp_dtype", MODE)
     model = psp.GeneralSolver(problem=prob, name=case["name"], verbose=False, device=dev(), backend="native", **kw)
     if "net" in case:
         model.V = psp.DenseNet(d_in=prob.d + 1, d_out=1, lr=kw["lr"], arch=case["net"]["arch"],
