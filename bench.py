@@ -558,6 +558,7 @@ def main():
     if outer:
         fwd_name, bwd_name = "hjbd_fwd_kernel", ("hjbd_bwd_kernel" if plan.kernel_bwd else "library GEMMs")
         issued = None
+        issued_x3 = None
     else:
         quad = plan.family != 2 and 4 * ntile <= cus and not bf16_mlp and os.environ.get("PSP_FWD_VARIANT") in (None, "3")
         fwd_name = "hjbw_fwd_kernel" if plan.family == 2 else (
@@ -574,7 +575,9 @@ def main():
     dom, dom_ms, which = (bwd_name, bwd_ms, "bwd_kernel") if bwd_dominant else (fwd_name, fwd_ms, "fwd_kernel")
     if issued is None:                                   # DenseNet control: algorithmic terms only
         t = dom_ms * 1e-3
-        mf = dict(achieved=fl2[which] * units_launch / t / 1e12, peak=PEAK_FP32_MFMA_TFLOPS)
+        # (split-product forward: three f16 flops per algorithmic fp32 flop; its backward kernel runs fp32 MFMA)
+        mf = dict(achieved=fl2[which] * units_launch / t / 1e12,
+                  peak=(PEAK_BF16_MFMA_TFLOPS / 3.0) if (x3 and which == "fwd_kernel") else PEAK_FP32_MFMA_TFLOPS)
         mf["frac"] = mf["achieved"] / mf["peak"]
         mf["frac_issued"] = None
         mf["frac_survey_m3"] = fl3[which] * units_launch / t / 1e12 / mf["peak"]
@@ -603,7 +606,7 @@ def main():
             "mfma_term": mf, "hbm_term": hbm,
             "alg_flops_per_traj_step": {k: fl2[k] for k in ("fwd_kernel", "bwd_kernel", "total")},
             "alg_flops_per_traj_step_survey_m3": {k: fl3[k] for k in ("fwd_kernel", "bwd_kernel", "total")},
-            "issued_mfma_per_tile_step": ({"fwd": issued_x3[0], "bwd": issued_x3[1]} if x3 else
+            "issued_mfma_per_tile_step": ({"fwd": issued_x3[0], "bwd": issued_x3[1]} if (x3 and issued_x3) else
                                           {"fwd_f32_16x16x4": issued[0], "fwd_bf16_16x16x32": issued[1],
                                            "bwd_f32_16x16x4": issued[2]} if issued else None),
             "units_per_launch": units_launch, "launches_per_step": n_chunks,
@@ -626,7 +629,7 @@ def main():
                                        "(product error 1.07x that of v_mfma_f32_16x16x4_f32; same parity bounds, "
                                        "tests/test_gpu_split_product.py); state, sums and the path store are fp32"
                                        + ("; forward kernel only (the wide family's backward runs v_mfma_f32_16x16x4_f32)"
-                                          if plan.family == 2 else "")) if x3 else
+                                          if getattr(plan, "family", 1) == 2 else "")) if x3 else
                                       ("v_mfma_f32_16x16x32_bf16 for the control net, v_mfma_f32_16x16x4_f32 elsewhere" if bf16_mlp
                                        else "v_mfma_f32_16x16x4_f32"),
                    "launch": "hipGraph replay of the captured iteration" if graph else "eager launches",

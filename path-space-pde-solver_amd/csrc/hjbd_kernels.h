@@ -55,6 +55,14 @@ struct DGeo {
                          // per k-step (the drift matrix is copied into every step's set: 45 KB a step at d = 112)
                          MERGE = (D <= 128) ? 1 : 0, NXB = 2 * HB + 2 * DB, tXall = tW3h2 + 4 * HB * DB * 64,
                          set_floats = tXall + MERGE * KP * NXB * 64;
+    // split-product forward (hjbd_fwd_kernel<.., X3>): the same tables as S-step-major hi / lo f16 images (table_fill_x3), 512 floats
+    // per (32-feature step, 16-row block); KS8 / KH8 steps over the state / the hidden units
+    static constexpr int KS8 = cdiv(DB, 2), KH8 = cdiv(HB, 2);
+    static constexpr int xW12 = 0, xW2h = xW12 + KS8 * 2 * HB * 512, xW3x = xW2h + KH8 * HB * 512, xW3h1 = xW3x + KS8 * DB * 512,
+                         xW3h2 = xW3h1 + KH8 * DB * 512, xXall = xW3h2 + KH8 * DB * 512,
+                         set_floats_x3 = xXall + MERGE * KS8 * NXB * 512;
+    static constexpr int oA_x = 0, oB_x = oA_x + KS8 * DB * 512, oSets_x = oB_x + KS8 * DB * 512;
+    static constexpr int IMGX = KS8 * 512;
     // per-step bias vectors (time column folded in), T-layout order [block][q][r]
     static constexpr int v1 = 0, v2 = v1 + HB * 16, v3 = v2 + HB * 16, vec_floats = v3 + DB * 16;
     // region: [dt A][B][sets ...][vectors of step 0 .. N-1]
@@ -64,7 +72,7 @@ struct DGeo {
     }
     // LDS (floats): problem vectors, reduction scratch, two images per wave (X_n and the increment panel v)
     static constexpr int vdr = 0, vrun = vdr + DB * 16, vterm = vrun + DB * 16, fRed = vterm + DB * 16,
-                         fImg = fRed + 64, IMG = KP * 64, lds_floats = fImg + 4 * 2 * IMG;
+                         fImg = fRed + 64, IMG = KP * 64, lds_floats = fImg + 4 * 2 * IMG, lds_floats_x3 = fImg + 4 * 2 * IMGX;
     // image block of one (step, 16-trajectory tile) for the backward kernel: X_n, relu(z1), relu(z2), xi image
     static constexpr int pX = 0, pR1 = pX + KP * 64, pR2 = pR1 + 4 * HB * 64, pXi = pR2 + 4 * HB * 64, PBI = pXi + KP * 64;
     // padded gradient layout of one work item (instance sizes, no time rows): W1 (D x H), b1, W2 ((D+H) x H), b2, W3 ((D+2H) x D), b3
@@ -94,6 +102,64 @@ __global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a, int 
     const long long oW1 = 0, ob1 = (long long)di * hh, oW2 = ob1 + hh, ob2 = oW2 + (long long)(di + hh) * hh,
                     oW3 = ob2 + hh, ob3 = oW3 + (long long)(di + 2 * hh) * d;
     float* T = a.tbl;
+    if (adjoint == 2) {                                // split-product forward tables (same sources as the fp32 forward set below)
+        auto fill = [&](float* dstf, int MB, int NS, auto src) { table_fill_x3(dstf, MB, NS, gtid, gs, src); };
+        if (h.drift_kind == DRIFT_DENSE) {
+            const float dt = h.dt;
+            const float* __restrict__ A = h.drift;
+            fill(T + W::oA_x, W::DB, W::KS8, [&](int row, int col) { return (row < D && col < D) ? dt * A[row * D + col] : 0.f; });
+        }
+        if (h.sigma_kind == SIGMA_DENSE) {
+            const float* __restrict__ B = h.sigma;
+            fill(T + W::oB_x, W::DB, W::KS8, [&](int row, int col) { return (row < D && col < D) ? B[row * D + col] : 0.f; });
+        }
+        const int nsets = a.per_step ? h.N : 1;
+        for (int s = 0; s < nsets; ++s) {
+            const float* __restrict__ Pp = h.params + (long long)s * P;
+            float* Ts = T + W::oSets_x + (long long)s * W::set_floats_x3;
+            fill(Ts + W::xW12, 2 * W::HB, W::KS8, [&](int row, int col) {      // rows: [W1 outputs | W2 outputs]
+                const int o = row < 16 * W::HB ? row : row - 16 * W::HB;
+                if (o >= hh || col >= d) return 0.f;
+                return row < 16 * W::HB ? Pp[oW1 + (long long)(to + col) * hh + o] : Pp[oW2 + (long long)(to + col) * hh + o]; });
+            fill(Ts + W::xW2h, W::HB, W::KH8, [&](int row, int col) {
+                return (row < hh && col < hh) ? Pp[oW2 + (long long)(di + col) * hh + row] : 0.f; });
+            fill(Ts + W::xW3x, W::DB, W::KS8, [&](int row, int col) {
+                return (row < d && col < d) ? Pp[oW3 + (long long)(to + col) * d + row] : 0.f; });
+            fill(Ts + W::xW3h1, W::DB, W::KH8, [&](int row, int col) {
+                return (row < d && col < hh) ? Pp[oW3 + (long long)(di + col) * d + row] : 0.f; });
+            fill(Ts + W::xW3h2, W::DB, W::KH8, [&](int row, int col) {
+                return (row < d && col < hh) ? Pp[oW3 + (long long)(di + hh + col) * d + row] : 0.f; });
+            if (W::MERGE) {
+                const bool denseA = h.drift_kind == DRIFT_DENSE;
+                const float dt = h.dt;
+                const float* __restrict__ A = h.drift;
+                fill(Ts + W::xXall, W::NXB, W::KS8, [&](int row, int col) {
+                    const int blk = row >> 4, o = row & 15;
+                    if (blk < W::HB) { const int u = 16 * blk + o; return (u < hh && col < d) ? Pp[oW1 + (long long)(to + col) * hh + u] : 0.f; }
+                    if (blk < 2 * W::HB) { const int u = 16 * (blk - W::HB) + o; return (u < hh && col < d) ? Pp[oW2 + (long long)(to + col) * hh + u] : 0.f; }
+                    if (blk < 2 * W::HB + W::DB) { const int f = 16 * (blk - 2 * W::HB) + o; return (f < d && col < d) ? Pp[oW3 + (long long)(to + col) * d + f] : 0.f; }
+                    const int f = 16 * (blk - 2 * W::HB - W::DB) + o;
+                    return (denseA && f < D && col < D) ? dt * A[f * D + col] : 0.f; });
+            }
+        }
+        // per-step bias vectors behind the sets, as in the fp32 layout
+        float* V = T + W::oSets_x + (long long)nsets * W::set_floats_x3;
+        const long long nv = (long long)h.N * W::vec_floats;
+        for (long long idx = gtid; idx < nv; idx += gs) {
+            const int n = (int)(idx / W::vec_floats), e = (int)(idx % W::vec_floats);
+            const float* __restrict__ Pp = h.params + (long long)(a.per_step ? n : 0) * P;
+            const float tn = h.tfeat ? h.tfeat[n] : (float)n * h.dt;
+            const int which = e < W::v2 ? 0 : (e < W::v3 ? 1 : 2);
+            const int loc = e - (which == 0 ? W::v1 : (which == 1 ? W::v2 : W::v3));
+            const int f = 16 * (loc >> 4) + 4 * (loc & 3) + ((loc >> 2) & 3);
+            float v = 0.f;
+            if (which == 0 && f < hh) v = Pp[ob1 + f] + (to ? tn * Pp[oW1 + f] : 0.f);
+            if (which == 1 && f < hh) v = Pp[ob2 + f] + (to ? tn * Pp[oW2 + f] : 0.f);
+            if (which == 2 && f < d) v = Pp[ob3 + f] + (to ? tn * Pp[oW3 + f] : 0.f);
+            V[idx] = v;
+        }
+        return;
+    }
     if (adjoint) {
         if (h.drift_kind == DRIFT_DENSE) {
             const float dt = h.dt;
@@ -183,10 +249,14 @@ __global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a, int 
     }
 }
 
-template <int D, int H>
+// X3 (psp_hjb_config.mlp_dtype = PSP_MLP_F16X3): every product as split f16 products (gemm_img_x3 / gemm_regs_x3, hjbw_kernels.h) on
+// the tables of hjbd_tables_kernel(.., 2); the two images of a wave hold hi / lo packs
+template <int D, int H, bool X3 = false>
 __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const DnetArgs da) {   // d <= 128: two workgroups per CU
     using W = DGeo<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
+    constexpr int oSets = X3 ? W::oSets_x : W::oSets, SETF = X3 ? W::set_floats_x3 : W::set_floats, IMGF = X3 ? W::IMGX : W::IMG;
+    [[maybe_unused]] const f32x4 zero4x = {0.f, 0.f, 0.f, 0.f};
     const HjbArgs& a = da.h;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -209,15 +279,17 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
     const bool kvalid = wave_valid && k < a.K_local;
     const uint32_t kglob = (uint32_t)(a.k_offset + k);
     const float dt = a.dt, sqdt = a.sqdt;
-    float* imgX = lds + W::fImg + wave * 2 * W::IMG;  // this wave's image of X_n   [KP][64]
-    float* imgV = imgX + W::IMG;                      // ... and of the increment panel v (dense sigma)
+    float* imgX = lds + W::fImg + wave * 2 * IMGF;    // this wave's image of X_n   [KP][64] (X3: hi / lo packs)
+    float* imgV = imgX + IMGF;                        // ... and of the increment panel v (dense sigma)
+    [[maybe_unused]] f16x8* imgX8 = reinterpret_cast<f16x8*>(imgX) + lane;
+    [[maybe_unused]] f16x8* imgV8 = reinterpret_cast<f16x8*>(imgV) + lane;
     const bool store = a.store_path && kvalid;
     // image in the xi slot: c_xi xi + c_z Z.  store_path 1: xi, or xi + sqrt(dt) Z for a non-adaptive process; 2: xi - sqrt(dt) Z
     // and 3: Z for the adjoint sweep (attached forward process / relative entropy), as in hjb_fwd_kernel
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;
     const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
     const int nsets_m1 = da.per_step ? a.N - 1 : 0;
-    const float* Vbase = T + W::oSets + (long long)(nsets_m1 + 1) * W::set_floats;
+    const float* Vbase = T + oSets + (long long)(nsets_m1 + 1) * SETF;
 
     double sD = 0.0, sD2 = 0.0;
     {
@@ -241,12 +313,21 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
             const int qn = opaque_i(q);
             const f32x4* vdr = vecs + W::vdr / 4;
             const f32x4* vrun = vecs + W::vrun / 4;
-            const float* Ts = T + W::oSets + (long long)(da.per_step ? n : 0) * W::set_floats;     // this step's weight set
+            const float* Ts = T + oSets + (long long)(da.per_step ? n : 0) * SETF;     // this step's weight set
             const f32x4* Vn = reinterpret_cast<const f32x4*>(Vbase + (long long)n * W::vec_floats) + qn;
             const size_t row = ((size_t)n * a.K_local + (kvalid ? k : 0));
             // ---- X_n: LDS image (B operand of every product over x) and the row-major store for the backward pass
+            if constexpr (X3) {
 #pragma unroll
-            for (int ks = 0; ks < KP; ++ks) imgX[ks * 64 + lane] = X[ks >> 2][ks & 3];
+                for (int S = 0; S < W::KS8; ++S) {
+                    f16x8 ph, pl;
+                    split_pack(X[2 * S], (2 * S + 1 < DB) ? X[(2 * S + 1 < DB) ? 2 * S + 1 : 0] : zero4x, ph, pl);
+                    imgX8[(2 * S) * 64] = ph; imgX8[(2 * S + 1) * 64] = pl;
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KP; ++ks) imgX[ks * 64 + lane] = X[ks >> 2][ks & 3];
+            }
             float* iblk = da.pimg ? da.pimg + ((size_t)n * a.ntile16 + t16) * (size_t)W::PBI + lane : nullptr;
             const bool store_img = a.store_path && wave_valid && da.pimg != nullptr;
             if (store_img) {
@@ -273,8 +354,14 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 for (int m = 0; m < HB; ++m) { xa[m] = Vn[(W::v1 / 16 + m) * 4]; xa[HB + m] = Vn[(W::v2 / 16 + m) * 4]; }
 #pragma unroll
                 for (int b = 0; b < DB; ++b) { xa[2 * HB + b] = Vn[(W::v3 / 16 + b) * 4]; xa[2 * HB + DB + b] = X[b]; }
-                if (a.drift_kind == DRIFT_DENSE) gemm_img<W::NXB, KP, W::NXB>(xa, Ts + W::tXall, imgX, lane);
-                else gemm_img<2 * HB + DB, KP, W::NXB>(reinterpret_cast<f32x4 (&)[2 * HB + DB]>(xa), Ts + W::tXall, imgX, lane);
+                if constexpr (X3) {
+                    // (output blocks in groups of at most 8: a correction chain of 24 registers under the 256-register cap)
+                    if (a.drift_kind == DRIFT_DENSE) gemm_img_x3<W::NXB, W::KS8, W::NXB, 8>(xa, Ts + W::xXall, imgX, lane);
+                    else gemm_img_x3<2 * HB + DB, W::KS8, W::NXB, 8>(reinterpret_cast<f32x4 (&)[2 * HB + DB]>(xa), Ts + W::xXall, imgX, lane);
+                } else {
+                    if (a.drift_kind == DRIFT_DENSE) gemm_img<W::NXB, KP, W::NXB>(xa, Ts + W::tXall, imgX, lane);
+                    else gemm_img<2 * HB + DB, KP, W::NXB>(reinterpret_cast<f32x4 (&)[2 * HB + DB]>(xa), Ts + W::tXall, imgX, lane);
+                }
 #pragma unroll
                 for (int m = 0; m < 2 * HB; ++m) z12[m] = xa[m];
 #pragma unroll
@@ -282,10 +369,14 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
             } else {
 #pragma unroll
                 for (int m = 0; m < HB; ++m) { z12[m] = Vn[(W::v1 / 16 + m) * 4]; z12[HB + m] = Vn[(W::v2 / 16 + m) * 4]; }
-                gemm_img<2 * HB, KP>(z12, Ts + W::tW12, imgX, lane);
+                if constexpr (X3) gemm_img_x3<2 * HB, W::KS8>(z12, Ts + W::xW12, imgX, lane);
+                else gemm_img<2 * HB, KP>(z12, Ts + W::tW12, imgX, lane);
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Xn[b] = X[b];
-                if (a.drift_kind == DRIFT_DENSE) gemm_img<DB, KP>(Xn, T + W::oA, imgX, lane);
+                if (a.drift_kind == DRIFT_DENSE) {
+                    if constexpr (X3) gemm_img_x3<DB, W::KS8>(Xn, T + W::oA_x, imgX, lane);
+                    else gemm_img<DB, KP>(Xn, T + W::oA, imgX, lane);
+                }
             }
             // ---- drift part of X_{n+1} (solver.py:471): the dense product is done above
             if (a.drift_kind == DRIFT_DENSE) {
@@ -321,7 +412,8 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 f32x4 z2[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) z2[m] = z12[HB + m];
-                gemm_regs<HB, 4 * HB, HB>(z2, Ts + W::tW2h, h1, lane);
+                if constexpr (X3) gemm_regs_x3<HB, HB>(z2, Ts + W::xW2h, h1, lane);
+                else gemm_regs<HB, 4 * HB, HB>(z2, Ts + W::tW2h, h1, lane);
 #pragma unroll
                 for (int m = 0; m < HB; ++m) {
                     const f32x4 r = relu4d(z2[m]);
@@ -344,10 +436,17 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 } else {
 #pragma unroll
                     for (int m = 0; m < NB; ++m) Zg[m] = Vn[(W::v3 / 16 + 4 * g + m) * 4];
-                    gemm_img<NB, KP, DB>(Zg, Ts + W::tW3x + 4 * g * 64, imgX, lane);
+                    if constexpr (X3) gemm_img_x3<NB, W::KS8, DB>(Zg, Ts + W::xW3x + 4 * g * 512, imgX, lane);
+                    else gemm_img<NB, KP, DB>(Zg, Ts + W::tW3x + 4 * g * 64, imgX, lane);
                 }
-                gemm_regs<NB, 4 * HB, HB, DB>(Zg, Ts + W::tW3h1 + 4 * g * 64, h1, lane);
-                gemm_regs<NB, 4 * HB, HB, DB>(Zg, Ts + W::tW3h2 + 4 * g * 64, h2, lane);
+                if constexpr (X3) {
+                    gemm_regs_x3<NB, HB, DB>(Zg, Ts + W::xW3h1 + 4 * g * 512, h1, lane);
+                    gemm_regs_x3<NB, HB, DB>(Zg, Ts + W::xW3h2 + 4 * g * 512, h2, lane);
+                } else {
+                    gemm_regs<NB, 4 * HB, HB, DB>(Zg, Ts + W::tW3h1 + 4 * g * 64, h1, lane);
+                    gemm_regs<NB, 4 * HB, HB, DB>(Zg, Ts + W::tW3h2 + 4 * g * 64, h2, lane);
+                }
+                [[maybe_unused]] f32x4 vg[4] = {zero4x, zero4x, zero4x, zero4x};
 #pragma unroll
                 for (int m = 0; m < NB; ++m) {
                     const int b = 4 * g + m;
@@ -384,12 +483,25 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                     }
                     const f32x4 v = a.adaptive ? (sqdt * xi - dt * Zg[m]) : (sqdt * xi);
                     if (a.sigma_kind == SIGMA_DENSE) {
+                        if constexpr (X3) vg[m] = v;
+                        else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) imgV[(4 * b + r) * 64 + lane] = v[r];
+                            for (int r = 0; r < 4; ++r) imgV[(4 * b + r) * 64 + lane] = v[r];
+                        }
                     } else if (a.sigma_kind == SIGMA_SCALE) {
                         Xn[b] += a.sigma_scale * v;
                     } else {
                         Xn[b] += v;
+                    }
+                }
+                if constexpr (X3) {                    // increment panel of this group as hi / lo packs (two S-steps per group)
+                    if (a.sigma_kind == SIGMA_DENSE) {
+#pragma unroll
+                        for (int s2 = 0; s2 < (NB + 1) / 2; ++s2) {
+                            f16x8 ph, pl;
+                            split_pack(vg[2 * s2], vg[2 * s2 + 1], ph, pl);
+                            imgV8[(2 * (2 * g + s2)) * 64] = ph; imgV8[(2 * (2 * g + s2) + 1) * 64] = pl;
+                        }
                     }
                 }
             };
@@ -398,7 +510,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
             if constexpr (DB % 4 != 0) z_group(std::integral_constant<int, DB % 4>{}, DB / 4);
             S = qsum(S);
             Pz = qsum(Pz);
-            if (a.sigma_kind == SIGMA_DENSE) gemm_img<DB, KP>(Xn, T + W::oB, imgV, lane);    // X += B v
+            if (a.sigma_kind == SIGMA_DENSE) {                                                // X += B v
+                if constexpr (X3) gemm_img_x3<DB, W::KS8>(Xn, T + W::oB_x, imgV, lane);
+                else gemm_img<DB, KP>(Xn, T + W::oB, imgV, lane);
+            }
 #pragma unroll
             for (int b = 0; b < DB; ++b) X[b] = Xn[b];
             // ---- running cost f(X_{n+1}) and Y update (solver.py:477-478)
@@ -856,6 +971,8 @@ struct DnetInstance {
                                // registers) or 0 (not covered: the library-GEMM formulation is used instead)
     hipError_t (*launch_bwd)(const DnetArgs&, int grid, hipStream_t);
     hipError_t (*launch_adj)(const DnetArgs&, int grid, hipStream_t);      // adjoint sweep (transposed tables + hjbd_adj_kernel)
+    int lds_bytes_x3;                                                      // split-product forward (PSP_MLP_F16X3)
+    hipError_t (*launch_fwd_x3)(const DnetArgs&, int grid, hipStream_t);
 };
 
 template <int D, int H>
@@ -883,6 +1000,17 @@ struct DnetLaunch {
         hipLaunchKernelGGL((hjbd_fwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
         return hipGetLastError();
     }
+    static hipError_t fwd_x3(const DnetArgs& a, int grid, hipStream_t s) {
+        hipLaunchKernelGGL((hjbd_tables_kernel<D, H>), dim3(512), dim3(256), 0, s, a, 2);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const int bytes = W::lds_floats_x3 * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_fwd_kernel<D, H, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbd_fwd_kernel<D, H, true>), dim3(grid), dim3(256), bytes, s, a);
+        return hipGetLastError();
+    }
     static constexpr int NALL = W::DB + 2 * W::HB;
     static constexpr int kTiles0 = cdiv(NALL, 4) * NALL;                                      // accumulator tiles per wave, one launch
     static constexpr int kTiles1 = cdiv(NALL, 4) * W::DB, kTiles2 = cdiv(W::DB + W::HB, 4) * 2 * W::HB;   // ... split by columns
@@ -908,8 +1036,10 @@ struct DnetLaunch {
         }
     }
     static DnetInstance instance() {
-        return DnetInstance{D, H, W::lds_floats * 4, W::set_floats, W::vec_floats, W::oSets, &fwd,
-                            W::PBI, W::PP, W::bwd_lds_floats * 4, kPasses, &bwd, &adj};
+        // (set / shared table sizes: the larger of the fp32 and the split layouts -- the caller allocates one region for both)
+        return DnetInstance{D, H, W::lds_floats * 4, W::set_floats > W::set_floats_x3 ? W::set_floats : W::set_floats_x3, W::vec_floats,
+                            W::oSets > W::oSets_x ? W::oSets : W::oSets_x, &fwd,
+                            W::PBI, W::PP, W::bwd_lds_floats * 4, kPasses, &bwd, &adj, W::lds_floats_x3 * 4, &fwd_x3};
     }
 };
 

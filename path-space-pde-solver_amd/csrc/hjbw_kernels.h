@@ -74,6 +74,30 @@ __device__ __forceinline__ void table_fill(float* dst, int MB, int KS, long long
     }
 }
 
+// split-product table (hjb_kernels.h gemm_Tx): S-step-major hi / lo f16x8 images, element ((S * MB + mb) * 2 + hi/lo) * 64 + lane;
+// k = 8 g + e of S-step S <-> column 32 S + (e < 4 ? 4 e : 16 + 4 (e - 4)) + g
+template <class F>
+__device__ __forceinline__ void table_fill_x3(float* dstf, int MB, int NS, long long gtid, long long gstride, F src) {
+    f16x8* dst = reinterpret_cast<f16x8*>(dstf);
+    const long long total = (long long)NS * MB * 64;
+    for (long long idx = gtid; idx < total; idx += gstride) {
+        const int lane = (int)(idx & 63);
+        const int t = (int)(idx >> 6);
+        const int mb = t % MB, S = t / MB;
+        const int i = lane & 15, g = lane >> 4;
+        const int row = 16 * mb + 4 * (i & 3) + (i >> 2);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 h, l;
+            split_f16(src(row, 32 * S + (e < 4 ? 4 * e : 16 + 4 * (e - 4)) + g), h, l);
+            hi[e] = h; lo[e] = l;
+        }
+        dst[((long long)t * 2) * 64 + lane] = hi;
+        dst[((long long)t * 2 + 1) * 64 + lane] = lo;
+    }
+}
+
 template <int D, int H>
 __global__ __launch_bounds__(256) void hjbw_tables_kernel(const HjbArgs a, int backward) {
     using G = Geo<D, H>;
@@ -87,26 +111,7 @@ __global__ __launch_bounds__(256) void hjbw_tables_kernel(const HjbArgs a, int b
         return;
     }
     if (backward == 3) {                               // split-product forward tables (hi / lo f16 images)
-        auto fill = [&](float* dstf, int MB, int NS, auto src) {
-            f16x8* dst = reinterpret_cast<f16x8*>(dstf);
-            const long long total = (long long)NS * MB * 64;
-            for (long long idx = gtid; idx < total; idx += gs) {
-                const int lane = (int)(idx & 63);
-                const int t = (int)(idx >> 6);
-                const int mb = t % MB, S = t / MB;
-                const int i = lane & 15, g = lane >> 4;
-                const int row = 16 * mb + 4 * (i & 3) + (i >> 2);
-                f16x8 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    _Float16 h, l;
-                    split_f16(src(row, 32 * S + (e < 4 ? 4 * e : 16 + 4 * (e - 4)) + g), h, l);
-                    hi[e] = h; lo[e] = l;
-                }
-                dst[((long long)t * 2) * 64 + lane] = hi;
-                dst[((long long)t * 2 + 1) * 64 + lane] = lo;
-            }
-        };
+        auto fill = [&](float* dstf, int MB, int NS, auto src) { table_fill_x3(dstf, MB, NS, gtid, gs, src); };
         fill(T + W::xW1, W::HB, W::KS8, [&](int row, int col) {
             return (row < H && col < D) ? P[G::oW1 + row * (D + 1) + 1 + col] : 0.f; });
         fill(T + W::xW2, W::HB, 2, [&](int row, int col) {
@@ -291,12 +296,12 @@ __device__ __forceinline__ void split_pack(const f32x4& u0, const f32x4& u1, f16
 }
 // acc[MB] += T . img over KS8 S-steps; img: this wave's LDS image of hi / lo packs.  Rolled over S; within an S-step the output
 // blocks run in chunks of CH with the operands of the next chunk (or of the next S-step's first chunk) requested one chunk ahead.
-template <int MB, int KS8, int LD = MB>
+template <int MB, int KS8, int LD = MB, int GMAX = 16>
 __device__ __forceinline__ void gemm_img_x3(f32x4 (&acc)[MB], const float* __restrict__ tbl, const float* img, int lane) {
     constexpr int CH = MB >= 4 ? 4 : MB;                                // (8 spills at d = 500 and under the 256-register cap of d <= 256)
     // output blocks in groups of at most 16: the correction chain of a group is 64 registers instead of 4 MB (d = 500: 128, which
     // spilled 45 dwords per step); every (S, block) operand is still read once, only the input packs are re-read from LDS per group
-    constexpr int NG = cdiv(MB, 16), GB = cdiv(MB, NG);
+    constexpr int NG = cdiv(MB, GMAX), GB = cdiv(MB, NG);
     const unsigned ul = (unsigned)lane;
     tbl = opaque_base(tbl);
     const f16x8* imgp = reinterpret_cast<const f16x8*>(img) + lane;

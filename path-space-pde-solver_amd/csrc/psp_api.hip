@@ -488,6 +488,8 @@ int make_dnet_plan(const psp_dnet_config* c, DnetPlan* p) {
         b.store_path < 0 || b.store_path > 3 || b.loss_kind < 0 || b.loss_kind > 3)
         return fail(-1, "config enum out of range");
     if (p->inst.lds_bytes > kMaxLds) return fail(-3, "DenseNet-control kernel images do not fit the 160 KiB LDS");
+    if (b.mlp_dtype == PSP_MLP_F16X3 && (!p->inst.launch_fwd_x3 || p->inst.lds_bytes_x3 > kMaxLds))
+        return fail(-3, "split-product forward images do not fit the 160 KiB LDS for this (d,H)");
     p->ntile16 = (b.K_local + 15) / 16;
     p->grid = (p->ntile16 + 3) / 4;
     p->table_floats = (long long)p->inst.shared_floats + (long long)(c->per_step ? b.N : 1) * p->inst.set_floats +
@@ -617,7 +619,9 @@ extern "C" int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* par
     if ((cfg->r1_out == nullptr) != (cfg->r2_out == nullptr)) return fail(-1, "r1_out and r2_out go together");
     a.pr1 = cfg->r1_out; a.pr2 = cfg->r2_out; a.pimg = cfg->images_out;
     a.d_real = cfg->d_real; a.h_real = cfg->H_real; a.time_input = cfg->time_input ? 1 : 0; a.per_step = cfg->per_step ? 1 : 0;
-    hipError_t e = p.inst.launch_fwd(a, p.grid, (hipStream_t)stream);
+    const bool x3 = b->mlp_dtype == PSP_MLP_F16X3 && p.inst.launch_fwd_x3 && p.inst.lds_bytes_x3 <= kMaxLds;
+    if (b->mlp_dtype == PSP_MLP_F16X3 && !x3) return fail(-3, "split-product forward images do not fit the 160 KiB LDS for this (d,H)");
+    hipError_t e = x3 ? p.inst.launch_fwd_x3(a, p.grid, (hipStream_t)stream) : p.inst.launch_fwd(a, p.grid, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjbd_fwd_kernel launch");
     return 0;
 }

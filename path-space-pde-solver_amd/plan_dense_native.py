@@ -146,6 +146,17 @@ class DenseNativePlan:
         cfg.time_input, cfg.per_step = (0 if self.outer else 1), (1 if self.outer else 0)
         self.cfg = cfg
         sizes = nat.DnetSizes()
+        # matrix products of the forward rollout: 'f16x3' = fp32-grade split products on the f16 matrix pipe (csrc/hjbd_kernels.h
+        # hjbd_fwd_kernel<.., X3>; same parity bounds); 'auto' (the default) takes it where its images fit the LDS
+        want = getattr(s, 'mlp_dtype', 'auto')
+        if want == 'bf16':
+            raise PlanUnsupported("mlp_dtype='bf16' exists for MySequential controls only")
+        b.mlp_dtype = nat.MLP_F16X3 if want in ('auto', 'f16x3') else nat.MLP_FP32
+        if self.lib.psp_dnet_query(C.byref(cfg), C.byref(sizes)) != 0:
+            if want == 'f16x3':
+                nat.check(self.lib.psp_dnet_query(C.byref(cfg), C.byref(sizes)), 'psp_dnet_query')
+            b.mlp_dtype = nat.MLP_FP32
+        self.matrix_mode = 'f16x3' if b.mlp_dtype == nat.MLP_F16X3 else 'fp32'
         nat.check(self.lib.psp_dnet_query(C.byref(cfg), C.byref(sizes)), 'psp_dnet_query')
         assert sizes.n_params_per_set == self.Pset, (sizes.n_params_per_set, self.Pset)
         f32 = torch.float32
