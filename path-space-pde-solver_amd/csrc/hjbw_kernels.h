@@ -49,6 +49,10 @@ struct GeoW {
     static constexpr int KS8 = cdiv(DB, 2);
     static constexpr int xW1 = 0, xW2 = xW1 + KS8 * HB * 512, xW3 = xW2 + 2 * HB * 512, xA = xW3 + 2 * DB * 512,
                          xB = xA + KS8 * DB * 512, fwd_x3_table_floats = xB + KS8 * DB * 512;
+    // ... and the adjoint sweep's transposed tables in split form (same total as the forward set)
+    static constexpr int xaBT = 0, xaAT = xaBT + KS8 * DB * 512, xaW3T = xaAT + KS8 * DB * 512, xaW2T = xaW3T + KS8 * HB * 512,
+                         xaW1T = xaW2T + 2 * HB * 512, adj_x3_table_floats = xaW1T + 2 * DB * 512;
+    static_assert(adj_x3_table_floats == fwd_x3_table_floats, "the split sweep reuses the split forward's table region");
     static constexpr int IMGX = KS8 * 512, fStage = fImg + 4 * IMGX;
     // the shared table stream (gemm_img_x3s) where TWO workgroups fit a CU with the stage (d <= 256 runs two per CU and they cover
     // each other's barriers); with one wave per SIMD (d > 256) the lock-step costs more than the L2 stream saves (d = 500: 24.7 ->
@@ -129,6 +133,22 @@ __global__ __launch_bounds__(256) void hjbw_tables_kernel(const HjbArgs a, int b
             fill(T + W::xB, W::DB, W::KS8, [&](int row, int col) {
                 return (row < D && col < D) ? B[row * D + col] : 0.f; });
         }
+        return;
+    }
+    if (backward == 4) {                               // adjoint sweep, split-product tables: B^T, (dt A)^T, W3^T, W2^T, W1x^T
+        auto fill = [&](float* dstf, int MB, int NS, auto src) { table_fill_x3(dstf, MB, NS, gtid, gs, src); };
+        if (a.sigma_kind == SIGMA_DENSE) {
+            const float* __restrict__ B = a.sigma;
+            fill(T + W::xaBT, W::DB, W::KS8, [&](int row, int col) { return (row < D && col < D) ? B[col * D + row] : 0.f; });
+        }
+        if (a.drift_kind == DRIFT_DENSE) {
+            const float dt = a.dt;
+            const float* __restrict__ A = a.drift;
+            fill(T + W::xaAT, W::DB, W::KS8, [&](int row, int col) { return (row < D && col < D) ? dt * A[col * D + row] : 0.f; });
+        }
+        fill(T + W::xaW3T, W::HB, W::KS8, [&](int row, int col) { return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+        fill(T + W::xaW2T, W::HB, 2, [&](int row, int col) { return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
+        fill(T + W::xaW1T, W::DB, 2, [&](int row, int col) { return (row < D && col < H) ? P[G::oW1 + col * (D + 1) + 1 + row] : 0.f; });
         return;
     }
     if (backward == 2) {                               // adjoint sweep: B^T, (dt A)^T, W3^T, W2^T, W1x^T
@@ -1082,11 +1102,14 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
 // (dt A)^T lambda' are rolled k-loops over it (the second accumulates into lambda in place), gZ replaces the image,
 // W3^T gZ is the third rolled product, W2^T and W1x^T are short unrolled ones.
 // =======================================================================================
-template <int D, int H>
+// X3: the five products as split f16 products (tables of hjbw_tables_kernel(.., 4), image as hi / lo packs); the trajectory weights
+// (mu, nu, wT ~ 1 / K) are scaled per wave by a power of two and the image written back is scaled back, as in hjb_adj_kernel<.., X3>
+template <int D, int H, bool X3 = false>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const HjbArgs a) {
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
+    [[maybe_unused]] const f32x4 zero4x = {0.f, 0.f, 0.f, 0.f};
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
@@ -1105,13 +1128,28 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const
     const int t16 = t16raw;
     const int k = t16 * 16 + j;
     const bool kvalid = k < a.K_local;
-    const float dt = a.dt, sqdt = a.sqdt, rsq = 1.0f / a.sqdt;
-    const float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
-    const float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    const float dt = a.dt, sqdt = a.sqdt;
+    float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
+    float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    float wT_in = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);
+    float ginv = 1.0f;
+    if constexpr (X3) {
+        float am = fmaxf(fmaxf(fabsf(mu), fabsf(nu)), fabsf(wT_in));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+        const unsigned e = (__float_as_uint(am) >> 23) & 0xFFu;
+        if (e >= 1u && e <= 253u) {
+            const float gsc = __uint_as_float((254u - e) << 23);
+            ginv = __uint_as_float(e << 23);
+            mu *= gsc; nu *= gsc; wT_in *= gsc;
+        }
+    }
+    const float rsq = ginv / a.sqdt;
     const float coefW = (a.store_path == 3) ? nu * dt : mu * sqdt;
     const float wf = (mu + nu) * dt;
-    const float wT = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);      // weight of grad g(X_N) in lambda_N
-    float* img = lds + W::fImg + wave * W::IMG;
+    const float wT = wT_in;                                                     // weight of grad g(X_N) in lambda_N
+    float* img = lds + W::fImg + wave * (X3 ? W::IMGX : W::IMG);       // this wave's image (X3: hi / lo packs)
+    [[maybe_unused]] f16x8* img8 = reinterpret_cast<f16x8*>(img) + lane;
     const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds) + q;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -1162,14 +1200,24 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const
                 lam[b] += (2.0f * wf) * (vrun[b * 4] * x);
             }
         }
+        if constexpr (X3) {
 #pragma unroll
-        for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = lam[ks >> 2][ks & 3];
+            for (int S = 0; S < W::KS8; ++S) {
+                f16x8 ph, pl;
+                split_pack(lam[2 * S], (2 * S + 1 < DB) ? lam[(2 * S + 1 < DB) ? 2 * S + 1 : 0] : zero4x, ph, pl);
+                img8[(2 * S) * 64] = ph; img8[(2 * S + 1) * 64] = pl;
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = lam[ks >> 2][ks & 3];
+        }
         // q = B^T lambda'
         f32x4 qv[DB];
         if (a.sigma_kind == SIGMA_DENSE) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) qv[b] = zero4;
-            gemm_img<DB, KP>(qv, T + W::aBT, img, lane);
+            if constexpr (X3) gemm_img_x3<DB, W::KS8>(qv, T + W::xaBT, img, lane);
+            else gemm_img<DB, KP>(qv, T + W::aBT, img, lane);
         } else if (a.sigma_kind == SIGMA_SCALE) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) qv[b] = a.sigma_scale * lam[b];
@@ -1179,7 +1227,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const
         }
         // lambda += dt b'(X_n)^T lambda'   (in place; the image still holds lambda')
         if (a.drift_kind == DRIFT_DENSE) {
-            gemm_img<DB, KP>(lam, T + W::aAT, img, lane);
+            if constexpr (X3) gemm_img_x3<DB, W::KS8>(lam, T + W::xaAT, img, lane);
+            else gemm_img<DB, KP>(lam, T + W::aAT, img, lane);
         } else if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) lam[b] += dt * (vdr[b * 4] * lam[b]);
@@ -1194,6 +1243,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const
             }
         }
         // gZ_n: back into the xi slot (as gZ / sqrt(dt)) and into the image (B operand of the W3^T product)
+        [[maybe_unused]] f32x4 gzp = zero4x;           // X3: gZ of the even block of a pair, until its odd partner is formed
 #pragma unroll
         for (int b = 0; b < DB; ++b) {
             gwptr_t pw = pbase(n, G::pXi + b * 256);
@@ -1202,9 +1252,18 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const
             for (int r = 0; r < 4; ++r) w[r] = pw[r * 64 + ul];
             const f32x4 gz = coefW * w - dt * qv[b];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pw[r * 64 + ul] = rsq * gz[r];
-                img[(4 * b + r) * 64 + lane] = gz[r];
+            for (int r = 0; r < 4; ++r) pw[r * 64 + ul] = rsq * gz[r];
+            if constexpr (X3) {
+                if ((b & 1) == 0 && b + 1 < DB) gzp = gz;
+                else {
+                    f16x8 ph, pl;
+                    if (b & 1) split_pack(gzp, gz, ph, pl);
+                    else split_pack(gz, zero4x, ph, pl);          // odd block count: the last step's upper half stays zero
+                    img8[(2 * (b >> 1)) * 64] = ph; img8[(2 * (b >> 1) + 1) * 64] = pl;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) img[(4 * b + r) * 64 + lane] = gz[r];
             }
         }
         f32x4 dz2[HB], dz1[HB];
@@ -1216,7 +1275,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const
                 for (int r = 0; r < 4; ++r) h2[m][r] = pbase(n, G::pH2)[(4 * m + r) * 64 + ul];
 #pragma unroll
             for (int m = 0; m < HB; ++m) dz2[m] = zero4;
-            gemm_img<HB, KP>(dz2, T + W::aW3T, img, lane);
+            if constexpr (X3) gemm_img_x3<HB, W::KS8>(dz2, T + W::xaW3T, img, lane);
+            else gemm_img<HB, KP>(dz2, T + W::aW3T, img, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (1.0f - h2[m] * h2[m]);
         }
@@ -1228,11 +1288,13 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const
                 for (int r = 0; r < 4; ++r) h1[m][r] = pbase(n, G::pH1)[(4 * m + r) * 64 + ul];
 #pragma unroll
             for (int m = 0; m < HB; ++m) dz1[m] = zero4;
-            gemm_regs<HB, 16, HB>(dz1, T + W::aW2T, dz2, lane);
+            if constexpr (X3) gemm_regs_x3<HB, HB>(dz1, T + W::xaW2T, dz2, lane);
+            else gemm_regs<HB, 16, HB>(dz1, T + W::aW2T, dz2, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (1.0f - h1[m] * h1[m]);
         }
-        gemm_regs<DB, 16, HB>(lam, T + W::aW1T, dz1, lane);               // lambda_n += W1x^T dz1
+        if constexpr (X3) gemm_regs_x3<DB, HB>(lam, T + W::xaW1T, dz1, lane);
+        else gemm_regs<DB, 16, HB>(lam, T + W::aW1T, dz1, lane);           // lambda_n += W1x^T dz1
     }
 }
 
@@ -1612,9 +1674,20 @@ struct HjbwLaunch {
         hipLaunchKernelGGL((hjbw_adj_kernel<D, H>), dim3(grid), dim3(block), bytes, s, a);
         return hipGetLastError();
     }
+    static hipError_t adj_x3(const HjbArgs& a, int grid, int block, hipStream_t s) {
+        hipError_t e = tables(a, 4, s);
+        if (e != hipSuccess) return e;
+        const int bytes = W::fwd_x3_lds_floats * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_adj_kernel<D, H, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbw_adj_kernel<D, H, true>), dim3(grid), dim3(block), bytes, s, a);
+        return hipGetLastError();
+    }
     static HjbInstance instance() {
         HjbInstance r{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::PB, &bwd2_lds, &bwd2};
         r.launch_adj = &adj;
+        r.launch_adj_x3 = &adj_x3;
         r.wide = 1;
         r.bwd2_one_per_cu = kRoles ? 1 : 0;
         r.fwd_table_floats = W::fwd_table_floats > W::fwd_x3_table_floats ? W::fwd_table_floats : W::fwd_x3_table_floats;

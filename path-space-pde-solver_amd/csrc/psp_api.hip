@@ -880,7 +880,7 @@ int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float*
     if (fw < 1) fw = 1;
     if (fw > (p.inst.wide ? 4 : 8)) fw = p.inst.wide ? 4 : 8;
     const int grid = (p.ntile16 + fw - 1) / fw;
-    const bool adj_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && !p.inst.wide && p.inst.launch_adj_x3;    // (make_plan checked the LDS fit)
+    const bool adj_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.inst.launch_adj_x3;    // (make_plan checked the LDS fit of the forward carve)
     hipError_t e = adj_x3 ? p.inst.launch_adj_x3(a, grid, fw * 64, (hipStream_t)stream)
                           : p.inst.launch_adj(a, grid, fw * 64, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_adj_kernel launch");
