@@ -160,6 +160,36 @@ __global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a, int 
         }
         return;
     }
+    if (adjoint == 3) {                                // adjoint sweep, split-product tables (the orientations of adjoint == 1 below)
+        auto fill = [&](float* dstf, int MB, int NS, auto src) { table_fill_x3(dstf, MB, NS, gtid, gs, src); };
+        if (h.drift_kind == DRIFT_DENSE) {
+            const float dt = h.dt;
+            const float* __restrict__ A = h.drift;
+            fill(T + W::oA_x, W::DB, W::KS8, [&](int row, int col) { return (row < D && col < D) ? dt * A[col * D + row] : 0.f; });
+        }
+        if (h.sigma_kind == SIGMA_DENSE) {
+            const float* __restrict__ B = h.sigma;
+            fill(T + W::oB_x, W::DB, W::KS8, [&](int row, int col) { return (row < D && col < D) ? B[col * D + row] : 0.f; });
+        }
+        const int nsets = a.per_step ? h.N : 1;
+        for (int s = 0; s < nsets; ++s) {
+            const float* __restrict__ Pp = h.params + (long long)s * P;
+            float* Ts = T + W::oSets_x + (long long)s * W::set_floats_x3;
+            fill(Ts + W::xW12, 2 * W::HB, W::KS8, [&](int row, int col) {     // rows: [h2 units | h1 units]
+                const int u = row < 16 * W::HB ? row : row - 16 * W::HB;
+                if (u >= hh || col >= d) return 0.f;
+                return row < 16 * W::HB ? Pp[oW3 + (long long)(di + hh + u) * d + col] : Pp[oW3 + (long long)(di + u) * d + col]; });
+            fill(Ts + W::xW2h, W::HB, W::KH8, [&](int row, int col) {
+                return (row < hh && col < hh) ? Pp[oW2 + (long long)(di + row) * hh + col] : 0.f; });
+            fill(Ts + W::xW3x, W::DB, W::KS8, [&](int row, int col) {
+                return (row < d && col < d) ? Pp[oW3 + (long long)(to + row) * d + col] : 0.f; });
+            fill(Ts + W::xW3h1, W::DB, W::KH8, [&](int row, int col) {
+                return (row < d && col < hh) ? Pp[oW2 + (long long)(to + row) * hh + col] : 0.f; });
+            fill(Ts + W::xW3h2, W::DB, W::KH8, [&](int row, int col) {
+                return (row < d && col < hh) ? Pp[oW1 + (long long)(to + row) * hh + col] : 0.f; });
+        }
+        return;
+    }
     if (adjoint) {
         if (h.drift_kind == DRIFT_DENSE) {
             const float dt = h.dt;
@@ -590,7 +620,9 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
 // weights.  One wave per 16-trajectory tile like the forward; the step's TRANSPOSED tables come from hjbd_tables_kernel
 // (adjoint = 1) in the forward's table region.
 // =======================================================================================
-template <int D, int H>
+// X3: split f16 products on the transposed split sets of hjbd_tables_kernel(.., 3); images as hi / lo packs; trajectory weights scaled
+// per wave by a power of two and the image written back scaled back (hjb_adj_kernel<.., X3>)
+template <int D, int H, bool X3 = false>
 __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const DnetArgs da) {
     using W = DGeo<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
@@ -612,13 +644,30 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
     if (t16 >= a.ntile16) return;                      // no workgroup barriers below
     const int k = t16 * 16 + j;
     const bool kvalid = k < a.K_local;
-    const float dt = a.dt, sqdt = a.sqdt, rsq = 1.0f / a.sqdt;
-    const float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
-    const float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    const float dt = a.dt, sqdt = a.sqdt;
+    float mu = (kvalid && a.adj_mu) ? a.adj_mu[k] : 0.f;
+    float nu = (kvalid && a.adj_nu) ? a.adj_nu[k] : 0.f;
+    float wT_in = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);
+    float ginv = 1.0f;
+    if constexpr (X3) {
+        float am = fmaxf(fmaxf(fabsf(mu), fabsf(nu)), fabsf(wT_in));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+        const unsigned e = (__float_as_uint(am) >> 23) & 0xFFu;
+        if (e >= 1u && e <= 253u) {
+            const float gsc = __uint_as_float((254u - e) << 23);
+            ginv = __uint_as_float(e << 23);
+            mu *= gsc; nu *= gsc; wT_in *= gsc;
+        }
+    }
+    const float rsq = ginv / a.sqdt;
+    [[maybe_unused]] const f32x4 zero4x = {0.f, 0.f, 0.f, 0.f};
+    constexpr int oSets = X3 ? W::oSets_x : W::oSets, SETF = X3 ? W::set_floats_x3 : W::set_floats;
     const float coefW = (a.store_path == 3) ? nu * dt : mu * sqdt;
     const float wf = (mu + nu) * dt;
-    const float wT = a.adj_wT ? (kvalid ? a.adj_wT[k] : 0.f) : (nu - mu);      // weight of grad g(X_N) in lambda_N
-    float* img = lds + W::fImg + wave * 2 * W::IMG;
+    const float wT = wT_in;                                                     // weight of grad g(X_N) in lambda_N
+    float* img = lds + W::fImg + wave * 2 * (X3 ? W::IMGX : W::IMG);
+    [[maybe_unused]] f16x8* img8 = reinterpret_cast<f16x8*>(img) + lane;
     const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds) + q;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const unsigned ul = (unsigned)lane;
@@ -648,7 +697,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
         const f32x4* vecs = opaque(vecs0);
         const f32x4* vdr = vecs + W::vdr / 4;
         const f32x4* vrun = vecs + W::vrun / 4;
-        const float* Ts = T + W::oSets + (long long)(da.per_step ? n : 0) * W::set_floats;     // this step's transposed set
+        const float* Ts = T + oSets + (long long)(da.per_step ? n : 0) * SETF;     // this step's transposed set
         auto pbase = [&](int nn, int ofs) __attribute__((always_inline)) {
             return (gwptr_t)sgpr_block_addr(da.pimg, (unsigned long long)nn * a.ntile16 + t16, (unsigned)W::PBI, (unsigned)ofs);
         };
@@ -669,14 +718,24 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
                 lam[b] += (2.0f * wf) * (vrun[b * 4] * x);
             }
         }
+        if constexpr (X3) {
 #pragma unroll
-        for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = lam[ks >> 2][ks & 3];
+            for (int S = 0; S < W::KS8; ++S) {
+                f16x8 ph, pl;
+                split_pack(lam[2 * S], (2 * S + 1 < DB) ? lam[(2 * S + 1 < DB) ? 2 * S + 1 : 0] : zero4x, ph, pl);
+                img8[(2 * S) * 64] = ph; img8[(2 * S + 1) * 64] = pl;
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KP; ++ks) img[ks * 64 + lane] = lam[ks >> 2][ks & 3];
+        }
         // q = B^T lambda'
         f32x4 qv[DB];
         if (a.sigma_kind == SIGMA_DENSE) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) qv[b] = zero4;
-            gemm_img<DB, KP>(qv, T + W::oB, img, lane);
+            if constexpr (X3) gemm_img_x3<DB, W::KS8>(qv, T + W::oB_x, img, lane);
+            else gemm_img<DB, KP>(qv, T + W::oB, img, lane);
         } else if (a.sigma_kind == SIGMA_SCALE) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) qv[b] = a.sigma_scale * lam[b];
@@ -686,7 +745,8 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
         }
         // lambda += dt b'(X_n)^T lambda'   (in place; the image still holds lambda')
         if (a.drift_kind == DRIFT_DENSE) {
-            gemm_img<DB, KP>(lam, T + W::oA, img, lane);
+            if constexpr (X3) gemm_img_x3<DB, W::KS8>(lam, T + W::oA_x, img, lane);
+            else gemm_img<DB, KP>(lam, T + W::oA, img, lane);
         } else if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) lam[b] += dt * (vdr[b * 4] * lam[b]);
@@ -701,6 +761,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
             }
         }
         // gZ_n: back into the xi slot (as gZ / sqrt(dt)) and into the image (B operand of the transposed products)
+        [[maybe_unused]] f32x4 gzp = zero4x;           // X3: gZ of the even block of a pair, until its odd partner is formed
 #pragma unroll
         for (int b = 0; b < DB; ++b) {
             gwptr_t pw = pbase(n, W::pXi + b * 256);
@@ -709,16 +770,26 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
             for (int r = 0; r < 4; ++r) w[r] = pw[r * 64 + ul];
             const f32x4 gz = coefW * w - dt * qv[b];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pw[r * 64 + ul] = rsq * gz[r];
-                img[(4 * b + r) * 64 + lane] = gz[r];
+            for (int r = 0; r < 4; ++r) pw[r * 64 + ul] = rsq * gz[r];
+            if constexpr (X3) {
+                if ((b & 1) == 0 && b + 1 < DB) gzp = gz;
+                else {
+                    f16x8 ph, pl;
+                    if (b & 1) split_pack(gzp, gz, ph, pl);
+                    else split_pack(gz, zero4x, ph, pl);          // odd block count: the last step's upper half stays zero
+                    img8[(2 * (b >> 1)) * 64] = ph; img8[(2 * (b >> 1) + 1) * 64] = pl;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) img[(4 * b + r) * 64 + lane] = gz[r];
             }
         }
         // adjoints of the hidden layers
         f32x4 u[2 * HB], dz2[HB], dz1[HB];
 #pragma unroll
         for (int m = 0; m < 2 * HB; ++m) u[m] = zero4;
-        gemm_img<2 * HB, KP>(u, Ts + W::tW12, img, lane);                 // [W3h2^T gZ | W3h1^T gZ]
+        if constexpr (X3) gemm_img_x3<2 * HB, W::KS8>(u, Ts + W::xW12, img, lane);
+        else gemm_img<2 * HB, KP>(u, Ts + W::tW12, img, lane);            // [W3h2^T gZ | W3h1^T gZ]
 #pragma unroll
         for (int m = 0; m < HB; ++m) {
             f32x4 r2;
@@ -727,7 +798,8 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
             dz2[m] = u[m] * (2.0f * r2);
             dz1[m] = u[HB + m];
         }
-        gemm_regs<HB, 4 * HB, HB>(dz1, Ts + W::tW2h, dz2, lane);           // + W2h^T dz2
+        if constexpr (X3) gemm_regs_x3<HB, HB>(dz1, Ts + W::xW2h, dz2, lane);
+        else gemm_regs<HB, 4 * HB, HB>(dz1, Ts + W::tW2h, dz2, lane);      // + W2h^T dz2
 #pragma unroll
         for (int m = 0; m < HB; ++m) {
             f32x4 r1;
@@ -736,9 +808,15 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
             dz1[m] = dz1[m] * (2.0f * r1);
         }
         // lambda_n += J_n^T gZ_n
-        gemm_img<DB, KP>(lam, Ts + W::tW3x, img, lane);                   // W3x^T gZ
-        gemm_regs<DB, 4 * HB, HB>(lam, Ts + W::tW3h1, dz2, lane);         // W2x^T dz2
-        gemm_regs<DB, 4 * HB, HB>(lam, Ts + W::tW3h2, dz1, lane);         // W1^T dz1
+        if constexpr (X3) {
+            gemm_img_x3<DB, W::KS8>(lam, Ts + W::xW3x, img, lane);
+            gemm_regs_x3<DB, HB>(lam, Ts + W::xW3h1, dz2, lane);
+            gemm_regs_x3<DB, HB>(lam, Ts + W::xW3h2, dz1, lane);
+        } else {
+            gemm_img<DB, KP>(lam, Ts + W::tW3x, img, lane);               // W3x^T gZ
+            gemm_regs<DB, 4 * HB, HB>(lam, Ts + W::tW3h1, dz2, lane);     // W2x^T dz2
+            gemm_regs<DB, 4 * HB, HB>(lam, Ts + W::tW3h2, dz1, lane);     // W1^T dz1
+        }
     }
 }
 
@@ -973,6 +1051,7 @@ struct DnetInstance {
     hipError_t (*launch_adj)(const DnetArgs&, int grid, hipStream_t);      // adjoint sweep (transposed tables + hjbd_adj_kernel)
     int lds_bytes_x3;                                                      // split-product forward (PSP_MLP_F16X3)
     hipError_t (*launch_fwd_x3)(const DnetArgs&, int grid, hipStream_t);
+    hipError_t (*launch_adj_x3)(const DnetArgs&, int grid, hipStream_t);
 };
 
 template <int D, int H>
@@ -987,6 +1066,17 @@ struct DnetLaunch {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((hjbd_adj_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
+        return hipGetLastError();
+    }
+    static hipError_t adj_x3(const DnetArgs& a, int grid, hipStream_t s) {
+        hipLaunchKernelGGL((hjbd_tables_kernel<D, H>), dim3(512), dim3(256), 0, s, a, 3);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const int bytes = W::lds_floats_x3 * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_adj_kernel<D, H, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbd_adj_kernel<D, H, true>), dim3(grid), dim3(256), bytes, s, a);
         return hipGetLastError();
     }
     static hipError_t fwd(const DnetArgs& a, int grid, hipStream_t s) {
@@ -1039,7 +1129,7 @@ struct DnetLaunch {
         // (set / shared table sizes: the larger of the fp32 and the split layouts -- the caller allocates one region for both)
         return DnetInstance{D, H, W::lds_floats * 4, W::set_floats > W::set_floats_x3 ? W::set_floats : W::set_floats_x3, W::vec_floats,
                             W::oSets > W::oSets_x ? W::oSets : W::oSets_x, &fwd,
-                            W::PBI, W::PP, W::bwd_lds_floats * 4, kPasses, &bwd, &adj, W::lds_floats_x3 * 4, &fwd_x3};
+                            W::PBI, W::PP, W::bwd_lds_floats * 4, kPasses, &bwd, &adj, W::lds_floats_x3 * 4, &fwd_x3, &adj_x3};
     }
 };
 

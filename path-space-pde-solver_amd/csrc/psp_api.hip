@@ -583,7 +583,8 @@ extern "C" int psp_dnet_adjoint_sweep(const psp_dnet_config* cfg, const float* p
     h.params = params; h.XN = const_cast<float*>(XN); h.adj_mu = mu; h.adj_nu = nu; h.adj_wT = wT;
     a.tbl = tables; a.pimg = images;
     a.d_real = cfg->d_real; a.h_real = cfg->H_real; a.time_input = cfg->time_input ? 1 : 0; a.per_step = cfg->per_step ? 1 : 0;
-    hipError_t e = p.inst.launch_adj(a, p.grid, (hipStream_t)stream);
+    const bool x3 = b->mlp_dtype == PSP_MLP_F16X3 && p.inst.launch_adj_x3 && p.inst.lds_bytes_x3 <= kMaxLds;
+    hipError_t e = x3 ? p.inst.launch_adj_x3(a, p.grid, (hipStream_t)stream) : p.inst.launch_adj(a, p.grid, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjbd_adj_kernel launch");
     return 0;
 }
