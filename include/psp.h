@@ -96,9 +96,12 @@ typedef struct psp_hjb_config {
                            * PSP_MLP_F16X3: fp32-GRADE split products on the f16 matrix pipe -- every operand x = hi + lo / 2048 as
                            * two f16 numbers, a.b = hi.hi + (hi.lo + lo.hi) / 2048 as three v_mfma_f32_16x16x32_f16 (16x the
                            * fp32 matrix rate); same parity bounds as PSP_MLP_FP32 (D within 2e-5, gradient 2e-4, loss 1e-4 of the
-                           * reference; observed 1e-6), operands must stay below 65504 in magnitude.  Forward (hjb_fwd_kernel mode 2)
-                           * and backward (hjb_bwd3_kernel) of the narrow family, tile-per-wave forward only; -3 where the instance
-                           * does not have it or its tables do not fit the LDS.
+                           * reference; observed 1e-6), operands must stay below 65504 in magnitude.  Narrow family: forward
+                           * (hjb_fwd_kernel mode 2, tile-per-wave kernel only), adjoint sweep and backward (hjb_bwd3_kernel); wide
+                           * family: forward and adjoint sweep (its backward kernels run fp32 MFMA on the same path store); DenseNet
+                           * controls (psp_dnet_*): forward and adjoint sweep; -3 where an instance does not have the mode or its
+                           * tables do not fit the LDS.  The weight-carrying operands of the backward passes (~1 / K) are scaled by
+                           * a power of two inside the kernels and the results scaled back (exact).
                            * PSP_MLP_BF16_FWD: the three products of the control net in the FORWARD rollout on
                            * v_mfma_f32_16x16x32_bf16 (bf16 operands: its OWN tolerance, not the 1e-4 bar); drift / sigma
                            * products, state, sums and the backward pass stay fp32.  Narrow kernel family only (-3 otherwise) */
@@ -315,7 +318,11 @@ typedef struct psp_gen_config {
                            * adjoint products and the weight-gradient outer products of the backward kernel.  State, Y,
                            * accumulators and every element-wise step stay fp32 (BASELINE.json configs[2]); with PSP_MLP_BF16 the
                            * path store holds the six images as bf16 pairs (960 instead of 1 920 bytes per sample:
-                           * psp_gen_query reports the size), with PSP_MLP_BF16_FWD it stays fp32                           */
+                           * psp_gen_query reports the size), with PSP_MLP_BF16_FWD it stays fp32.
+                           * PSP_MLP_F16X3: fp32-GRADE split products (psp_hjb_config.mlp_dtype) in the forward rollout and -- with
+                           * shared trajectory weights -- in the backward kernel (per_sample_weights keeps fp32 MFMA there); fp32
+                           * path store, the 1e-4 bounds of PSP_MLP_FP32; the network factors multiplying the scaled weights in
+                           * the backward pass (w3 phi', W2 products) must stay below 256 in magnitude                        */
     /* Solver.train with approx_method='value_function' (solver.py:93-97, 334-339, 438-440: Z = sigma grad_x Y_n(X), loss +
      * mean_k sum_{n>=1} (Y_n(X_n) - Y)^2) runs on these kernels too (plan_value_native.py):                              */
     float* v_steps_out;   /* optional (N, 16*ceil(K_local/16)): V(X_n, t_n) at every step, written by psp_gen_rollout_fwd       */
