@@ -45,11 +45,12 @@ def _draw(i):
                 net=dict(kind="tanh_mlp", widths=[H, H], seed=123))
 
 
+@pytest.mark.parametrize("mode", ["fp32", "f16x3"])          # fp32-MFMA kernels / split-product kernels: same bars
 @pytest.mark.parametrize("i", range(28))
-def test_random_configuration_matches_oracle(i):
+def test_random_configuration_matches_oracle(i, mode):
     case = _draw(i)
     s = case["solver"]
-    model = make_pkg_solver(case, torch.device("cuda:0"), backend="native", L=1)
+    model = make_pkg_solver(case, torch.device("cuda:0"), backend="native", L=1, mlp_dtype=mode)
     oprob, ocfg, omodels = make_oracle(case, L=1)
     assert torch.equal(flat_params(model.z_n), flat_params(omodels[0]))
     model.train()
@@ -130,13 +131,14 @@ def _draw_general(i):
     return case
 
 
+@pytest.mark.parametrize("mode", ["fp32", "f16x3"])
 @pytest.mark.parametrize("i", range(24))
-def test_random_general_configuration_matches_oracle(i):
+def test_random_general_configuration_matches_oracle(i, mode):
     """GeneralSolver / EllipticSolver on unbounded, sphere and box domains: native first iteration against the oracle."""
     from test_general_composite_golden import build as build_pkg
     from test_gpu_bounded_elliptic import oracle_run
     case = _draw_general(i)
-    prob, model = build_pkg(case, device=torch.device("cuda:0"), backend="native", L=1)
+    prob, model = build_pkg(case, device=torch.device("cuda:0"), backend="native", L=1, mlp_dtype=mode)
     model.train()
     assert model.plan_name == "native", case
     ref = oracle_run(case, 1)
