@@ -24,6 +24,7 @@ would not fit in HBM; the reference holds the whole autograd graph instead).
 """
 import json
 import os
+import math
 import time
 import warnings
 from copy import deepcopy
@@ -353,6 +354,12 @@ class Solver:
             watch = ul2 is not None and self.early_stopping_time is not None and l > self.early_stopping_time
             if (self.verbose and l % self.print_every == 0) or l == self.L - 1 or watch:
                 vals = losses[done:l + 1].cpu().tolist()          # one sync per block
+                if getattr(plan, 'matrix_mode', 'fp32') == 'f16x3' and not getattr(self, '_warned_range', False) \
+                        and not all(math.isfinite(v) for v in vals):
+                    import warnings
+                    self._warned_range = True
+                    warnings.warn("non-finite loss on the split-product kernels: their operands must stay below 65504 in magnitude "
+                                  "(f16 range); if Solver(mlp_dtype='fp32') stays finite on this problem, use it")
                 now = time.time()
                 per = (now - t_block) / max(1, l + 1 - done)
                 self.loss_log += vals
