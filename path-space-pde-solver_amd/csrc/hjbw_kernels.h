@@ -135,6 +135,11 @@ __global__ __launch_bounds__(256) void hjbw_tables_kernel(const HjbArgs a, int b
         }
         return;
     }
+    if (backward == 5) {                               // hjbw_bwd_x3_kernel: W3^T as split S-step-major images
+        table_fill_x3(T, W::HB, W::KS8, gtid, gs, [&](int row, int col) {
+            return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
+        return;
+    }
     if (backward == 4) {                               // adjoint sweep, split-product tables: B^T, (dt A)^T, W3^T, W2^T, W1x^T
         auto fill = [&](float* dstf, int MB, int NS, auto src) { table_fill_x3(dstf, MB, NS, gtid, gs, src); };
         if (a.sigma_kind == SIGMA_DENSE) {
@@ -1586,6 +1591,323 @@ __global__ __launch_bounds__(512) void hjbw_bwd2_kernel(const HjbArgs a) {
     }
 }
 
+// =======================================================================================
+// hjbw_bwd_x3_kernel: split-product version of hjbw_bwd_kernel for d > 256 (one wave per SIMD, 512 registers).  Same phases:
+//   phase A  wave w, block 4 round + w:  dz2 = (W3^T G)(1 - h2^2) with G = w sqrt(dt) xi split on the fly per 32-feature step
+//            (8 image dwords per lane) against the split W3^T table (hjbw_tables_kernel(.., 5)): 12 f16 MFMAs per step instead
+//            of 32 fp32 ones; two accumulator chains (the table carries the scaled lo of table_fill_x3);
+//   phase B  wave w owns hidden block ib = w; the four blocks of a round as TWO PAIRS: every weight-gradient tile contracts
+//            the pair's 32 samples in three f16 MFMAs on ONE accumulator (operands split with unscaled residuals, as in
+//            gen_bwd2_kernel<.., X3>): A operands G = w xi / dz2 / dz1, B operands h2 / h1 / X tiles of both blocks.
+// The trajectory weights are scaled by a power of two that maps the largest |w_k| sqrt(dt) (one scan of D per workgroup) to
+// [2^7, 2^8); the partial gradient is scaled back when it is written.  Gradient layout and bias sums as in hjbw_bwd_kernel.
+// =======================================================================================
+template <int D, int H>
+__global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
+    using G = Geo<D, H>;
+    using W = GeoW<D, H>;
+    constexpr int DB = W::DB, HB = W::HB, EXB = W::EXB, KS8 = W::KS8;
+    constexpr int OBW = cdiv(DB, 4);                  // state blocks per wave for the db3 sums
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    const float* __restrict__ P = a.params;
+    const float* __restrict__ T = a.tables;           // W3^T, split S-step-major images
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned lofsU = (unsigned)image_lane_offset_F(lane);
+    const unsigned ul = (unsigned)lane;
+
+    const double invK = 1.0 / (double)a.K_global;
+    const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
+    const float coef = (float)(2.0 * invK);
+    const float sqdt = a.sqdt, dt = a.dt;
+    const long long nblk = (long long)a.N * a.ntile16;
+    const long long nround = (nblk + 3) / 4;
+    auto weight_of = [&](int kk) __attribute__((always_inline)) {      // w_k sqrt(dt), unscaled
+        const float dk = a.D[kk < a.K_local ? kk : 0];
+        return (kk < a.K_local) ? (a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)) * sqdt : 0.f;
+    };
+    // power-of-two scale: largest |w_k| sqrt(dt) -> [2^7, 2^8)
+    float gs = 1.0f, ginv = 1.0f;
+    {
+        float am = 0.f;
+        for (int k0 = tid; k0 < a.K_local; k0 += 256) am = fmaxf(am, fabsf(weight_of(k0)));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
+        if (lane == 0) lds[wave] = am;
+        __syncthreads();
+        am = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+        const unsigned e = (__float_as_uint(am) >> 23) & 0xFFu;
+        if (e >= 8u && e <= 249u) { gs = __uint_as_float((261u - e) << 23); ginv = __uint_as_float((e - 7u) << 23); }
+        __syncthreads();
+    }
+    auto split2u = [&](const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                     // hi = f16(x), lo = f16(x - hi): the unscaled residual
+            _Float16 h = (_Float16)u0[e];
+            hi[e] = h; lo[e] = (_Float16)(u0[e] - (float)h);
+            h = (_Float16)u1[e];
+            hi[4 + e] = h; lo[4 + e] = (_Float16)(u1[e] - (float)h);
+        }
+    };
+    auto fma3 = [&](f32x4& acc, const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl) __attribute__((always_inline)) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    };
+
+    // persistent accumulators: dW3 / dW1 tiles of the state blocks ob = wave + 4 o against ALL hidden blocks; dW2[:, ib = wave]
+    f32x4 acc3[OBW][HB], acc1[OBW][HB], acc2[HB];
+#pragma unroll
+    for (int o = 0; o < OBW; ++o)
+#pragma unroll
+        for (int m = 0; m < HB; ++m) { acc3[o][m] = zero4; acc1[o][m] = zero4; }
+#pragma unroll
+    for (int m = 0; m < HB; ++m) acc2[m] = zero4;
+    f32x4 bs1 = zero4, bt1 = zero4;
+    float bs3[OBW], bs2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < OBW; ++i) bs3[i] = 0.f;
+
+    int par = 0;
+#pragma unroll 1
+    for (long long round = blockIdx.x; round < nround; round += gridDim.x, par ^= 1) {
+        float* exch = lds + par * 4 * EXB;
+        // ------------------------------------------------------------------ phase A: own block
+        {
+            const long long blk0 = round * 4 + wave;
+            const bool bvalid = blk0 < nblk;
+            const long long blk = bvalid ? blk0 : nblk - 1;
+            const int t16 = (int)(blk % a.ntile16);
+            const int k = t16 * 16 + j;
+            const float wks = (bvalid ? weight_of(k) : 0.f) * gs;
+            const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
+            f32x4 h2[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
+            f32x4 dz2[HB], dzc[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) { dz2[m] = zero4; dzc[m] = zero4; }
+            const float* xip = pb + G::pXi;
+            constexpr int NSTG = 3;
+            float xb[NSTG][8];
+            f16x8 ah[NSTG][HB], al[NSTG][HB];
+            auto load = [&](int st, int S) __attribute__((always_inline)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int b = 2 * S + (e >> 2);            // block 2 S (e < 4) or 2 S + 1; past the last block: re-read it (zeroed below)
+                    xb[st][e] = xip[(size_t)(4 * (b < DB ? b : DB - 1) + (e & 3)) * 64];
+                }
+#pragma unroll
+                for (int m = 0; m < HB; m += 2) {
+                    gptr8_t tp = sgpr_ptr8(T + ((size_t)S * HB + m) * 512);
+                    ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
+                    if (m + 1 < HB) { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul]; }
+                }
+            };
+            auto fma_stage = [&](int st, int S) __attribute__((always_inline)) {
+                f16x8 bh, bl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool inb = (2 * S + (e >> 2)) < DB;
+                    _Float16 h, l;
+                    split_f16(inb ? wks * xb[st][e] : 0.f, h, l);
+                    bh[e] = h; bl[e] = l;
+                }
+#pragma unroll
+                for (int m = 0; m < HB; ++m) {
+                    dz2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[st][m], bh, dz2[m], 0, 0, 0);
+                    dzc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[st][m], bl, dzc[m], 0, 0, 0);
+                    dzc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[st][m], bh, dzc[m], 0, 0, 0);
+                }
+            };
+            load(0, 0);
+            if (KS8 > 1) load(1, 1);
+#pragma unroll
+            for (int S = 0; S < KS8; ++S) {
+                if (S + NSTG - 1 < KS8) load((S + NSTG - 1) % NSTG, S + NSTG - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                fma_stage(S % NSTG, S);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float* ex = exch + wave * EXB + lane;
+#pragma unroll
+            for (int m = 0; m < HB; ++m) {
+                dz2[m] = (dz2[m] + kSplitInv * dzc[m]) * (1.0f - h2[m] * h2[m]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ex[(4 * m + r) * 64] = dz2[m][r];
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------------ phase B1: wave = hidden block ib -- dz1 tiles, dW2
+        float* a1x = lds + 2 * 4 * EXB + 4 * 16 * DB;                   // [4 blocks][HB] dz1 tiles (f32x4 per lane), shared below
+#pragma unroll 1
+        for (int pr = 0; pr < 2; ++pr) {
+            const long long c0 = round * 4 + 2 * pr;
+            if (c0 >= nblk) break;                                    // wave-uniform
+            const bool v1 = c0 + 1 < nblk;                            // second block of the pair exists (else: zero weights)
+            const int cb0 = __builtin_amdgcn_readfirstlane((int)c0), cb1 = __builtin_amdgcn_readfirstlane((int)(v1 ? c0 + 1 : c0));
+            const int n0 = cb0 / a.ntile16, n1 = cb1 / a.ntile16;
+            const float* bp0 = a.path + (size_t)cb0 * (size_t)G::PB;
+            const float* bp1 = a.path + (size_t)cb1 * (size_t)G::PB;
+            const float* ex0 = exch + (2 * pr) * EXB;
+            const float* ex1 = ex0 + EXB;
+            const f32x4 h1t0 = *reinterpret_cast<const f32x4*>(bp0 + G::pH1 + wave * 256 + lofsU);
+            const f32x4 h1t1 = *reinterpret_cast<const f32x4*>(bp1 + G::pH1 + wave * 256 + lofsU);
+            // dz1 tiles of hidden block ib for both blocks: (dz2^T W2[:, ib]) (1 - h1^2)   (fp32 MFMA: 16 per block)
+            f32x4 dzt0 = zero4, dzt1 = zero4;
+            {
+                float w2b[16];
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int o = 4 * ks + q, i = 16 * wave + j;
+                    w2b[ks] = (o < H && i < H) ? P[G::oW2 + opaque_i(0) + o * H + i] : 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    dzt0 = mfma16(ex0[ks * 64 + lane], w2b[ks], dzt0);
+                    dzt1 = mfma16(v1 ? ex1[ks * 64 + lane] : 0.f, w2b[ks], dzt1);
+                }
+            }
+            // dW2[:, ib] += dz2^T h1
+            {
+                f16x8 bh, bl;
+                split2u(h1t0, h1t1, bh, bl);
+#pragma unroll
+                for (int m = 0; m < HB; ++m) {
+                    const f32x4 a20 = tile_get(ex0 + m * 256, lane);
+                    const f32x4 a21 = v1 ? tile_get(ex1 + m * 256, lane) : zero4;
+                    if (m == wave) bs2 += hsum4(a20) + hsum4(a21);
+                    f16x8 ahp, alp;
+                    split2u(a20, a21, ahp, alp);
+                    fma3(acc2[m], ahp, alp, bh, bl);
+                }
+            }
+            const f32x4 a10 = dzt0 * (1.0f - h1t0 * h1t0);
+            const f32x4 a11 = dzt1 * (1.0f - h1t1 * h1t1);
+            bs1 += a10 + a11;
+            bt1 += ((float)n0 * dt) * a10 + ((float)n1 * dt) * a11;
+            reinterpret_cast<f32x4*>(a1x)[((2 * pr) * HB + wave) * 64 + lane] = a10;
+            reinterpret_cast<f32x4*>(a1x)[((2 * pr + 1) * HB + wave) * 64 + lane] = a11;
+        }
+        __syncthreads();
+        // ------------------------------------------------------------------ phase B2: wave owns the state blocks ob = wave + 4 o and ALL
+        // hidden blocks: each xi / X tile of the pair is loaded and split by ONE wave (a quarter of the loads and of the VALU work
+        // of a per-hidden-block stream), the h2 tiles and the dz1 tiles (LDS) of the four hidden blocks are its B / A operands
+#pragma unroll 1
+        for (int pr = 0; pr < 2; ++pr) {
+            const long long c0 = round * 4 + 2 * pr;
+            if (c0 >= nblk) break;                                    // wave-uniform
+            const bool v1 = c0 + 1 < nblk;
+            const int cb0 = __builtin_amdgcn_readfirstlane((int)c0), cb1 = __builtin_amdgcn_readfirstlane((int)(v1 ? c0 + 1 : c0));
+            const int t0 = cb0 % a.ntile16, t1 = cb1 % a.ntile16;
+            const float* bp0 = a.path + (size_t)cb0 * (size_t)G::PB;
+            const float* bp1 = a.path + (size_t)cb1 * (size_t)G::PB;
+            f32x4 w40, w41;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                w40[r] = gs * weight_of(t0 * 16 + 4 * q + r);
+                w41[r] = v1 ? gs * weight_of(t1 * 16 + 4 * q + r) : 0.f;
+            }
+            f16x8 B3h[HB], B3l[HB], A1h[HB], A1l[HB];
+#pragma unroll
+            for (int m = 0; m < HB; ++m) {
+                const f32x4 h2t0 = *reinterpret_cast<const f32x4*>(bp0 + G::pH2 + m * 256 + lofsU);
+                const f32x4 h2t1 = *reinterpret_cast<const f32x4*>(bp1 + G::pH2 + m * 256 + lofsU);
+                split2u(h2t0, h2t1, B3h[m], B3l[m]);
+                const f32x4 a10 = reinterpret_cast<const f32x4*>(a1x)[((2 * pr) * HB + m) * 64 + lane];
+                const f32x4 a11 = reinterpret_cast<const f32x4*>(a1x)[((2 * pr + 1) * HB + m) * 64 + lane];
+                split2u(a10, a11, A1h[m], A1l[m]);
+            }
+            const float* xib0 = bp0 + G::pXi + lofsU + wave * 256;
+            const float* xib1 = bp1 + G::pXi + lofsU + wave * 256;
+            const float* xb0 = bp0 + G::pX + lofsU + wave * 256;
+            const float* xb1 = bp1 + G::pX + lofsU + wave * 256;
+            constexpr int RD = 3;                                     // own blocks are 4 apart: RD - 1 of them (24 MFMAs each) in flight
+            f32x4 xit0[RD], xit1[RD], xt0[RD], xt1[RD];
+#pragma unroll
+            for (int i = 0; i < RD - 1; ++i) {
+                if (i < OBW) {
+                    xit0[i] = *reinterpret_cast<const f32x4*>(xib0 + i * 1024); xit1[i] = *reinterpret_cast<const f32x4*>(xib1 + i * 1024);
+                    xt0[i] = *reinterpret_cast<const f32x4*>(xb0 + i * 1024); xt1[i] = *reinterpret_cast<const f32x4*>(xb1 + i * 1024);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < OBW; ++o) {
+                if (o + RD - 1 < OBW) {
+                    const int s = (o + RD - 1) % RD, of = (o + RD - 1) * 1024;
+                    xit0[s] = *reinterpret_cast<const f32x4*>(xib0 + of); xit1[s] = *reinterpret_cast<const f32x4*>(xib1 + of);
+                    xt0[s] = *reinterpret_cast<const f32x4*>(xb0 + of); xt1[s] = *reinterpret_cast<const f32x4*>(xb1 + of);
+                }
+                __builtin_amdgcn_sched_barrier(0);            // (a fence that lets VMEM cross lets the scheduler sink the prefetch to its use)
+                const bool ovalid = wave + 4 * o < DB;            // wave-uniform (DB not a multiple of 4: the last slot of some waves is empty)
+                const f32x4 g0 = ovalid ? xit0[o % RD] * w40 : zero4, g1 = ovalid ? xit1[o % RD] * w41 : zero4;
+                bs3[o] += hsum4(g0) + hsum4(g1);
+                f16x8 gh, gl, xh, xl;
+                split2u(g0, g1, gh, gl);
+                split2u(xt0[o % RD], xt1[o % RD], xh, xl);
+#pragma unroll
+                for (int m = 0; m < HB; ++m) {                      // (chains of different tiles interleaved: a split product is three dependent MFMAs)
+                    acc3[o][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, B3h[m], acc3[o][m], 0, 0, 0);
+                    acc1[o][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1h[m], xh, acc1[o][m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < HB; ++m) {
+                    acc3[o][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, B3l[m], acc3[o][m], 0, 0, 0);
+                    acc1[o][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1h[m], xl, acc1[o][m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < HB; ++m) {
+                    acc3[o][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, B3h[m], acc3[o][m], 0, 0, 0);
+                    acc1[o][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1l[m], xh, acc1[o][m], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- write-out (layout of hjbw_bwd_kernel), scaled back by the weights' power of two
+    float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
+    const int col = lane & 15, qq = lane >> 4, ib = wave;
+#pragma unroll
+    for (int o = 0; o < OBW; ++o) {
+        const int ob = wave + 4 * o;
+#pragma unroll
+        for (int m = 0; m < HB; ++m)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int o3 = 16 * ob + 4 * qq + rr, i3 = 16 * m + col;
+                if (ob < DB && o3 < D && i3 < H) gp[G::oW3 + o3 * H + i3] = ginv * acc3[o][m][rr];
+                const int o1 = 16 * m + 4 * qq + rr, i1 = 16 * ob + col;
+                if (ob < DB && o1 < H && i1 < D) gp[G::oW1 + o1 * (D + 1) + 1 + i1] = ginv * acc1[o][m][rr];
+            }
+        const float v = ginv * qsum(bs3[o]);
+        const int f = 16 * ob + col;
+        if (qq == 0 && ob < DB && f < D) gp[G::ob3 + f] = v;
+    }
+#pragma unroll
+    for (int m = 0; m < HB; ++m)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int o2 = 16 * m + 4 * qq + rr, i2 = 16 * ib + col;
+            if (o2 < H && i2 < H) gp[G::oW2 + o2 * H + i2] = ginv * acc2[m][rr];
+        }
+    {
+        const float v1 = ginv * qsum(hsum4(bs1)), vt = ginv * qsum(hsum4(bt1));
+        const int f = 16 * ib + col;
+        if (qq == 0 && f < H) { gp[G::ob1 + f] = v1; gp[G::oW1 + f * (D + 1)] = vt; }
+    }
+    {
+        const float v2 = ginv * qsum(bs2);
+        const int f = 16 * ib + col;
+        if (qq == 0 && f < H) gp[G::ob2 + f] = v2;
+    }
+}
+
 template <int D, int H>
 struct HjbwLaunch {
     using G = Geo<D, H>;
@@ -1664,6 +1986,21 @@ struct HjbwLaunch {
         hipLaunchKernelGGL((hjbw_bwd_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
         return hipGetLastError();
     }
+    // split-product backward for the instances that run hjbw_bwd_kernel (d > 256: one wave per SIMD)
+    static hipError_t bwd2_x3(const HjbArgs& a, int grid, hipStream_t s) {
+        if constexpr (kRoles || D <= 256) {
+            return bwd2(a, grid, s);
+        } else {
+            hipError_t e = tables(a, 5, s);
+            if (e != hipSuccess) return e;
+            const int bytes = (W::bwd_lds_floats + 4 * W::HB * 256) * 4;      // + the shared dz1 tiles of a round
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_bwd_x3_kernel<D, H>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((hjbw_bwd_x3_kernel<D, H>), dim3(grid), dim3(256), bytes, s, a);
+            return hipGetLastError();
+        }
+    }
     static hipError_t adj(const HjbArgs& a, int grid, int block, hipStream_t s) {
         hipError_t e = tables(a, 2, s);
         if (e != hipSuccess) return e;
@@ -1688,12 +2025,13 @@ struct HjbwLaunch {
         HjbInstance r{D, H, G::P, &fwd_lds, &bwd_lds, &fwd, &bwd, G::PB, &bwd2_lds, &bwd2};
         r.launch_adj = &adj;
         r.launch_adj_x3 = &adj_x3;
+        r.launch_bwd2_x3 = &bwd2_x3;
         r.wide = 1;
         r.bwd2_one_per_cu = kRoles ? 1 : 0;
         r.fwd_table_floats = W::fwd_table_floats > W::fwd_x3_table_floats ? W::fwd_table_floats : W::fwd_x3_table_floats;
         r.fwd_x3_lds_bytes = &fwd_x3_lds;
         r.launch_fwd_x3 = &fwd_x3;
-        r.bwd_table_floats = W::bwd_table_floats;
+        r.bwd_table_floats = W::bwd_table_floats > W::KS8 * W::HB * 512 ? W::bwd_table_floats : W::KS8 * W::HB * 512;
         return r;
     }
 };

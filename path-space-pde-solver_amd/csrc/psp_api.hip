@@ -812,8 +812,8 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
     a.tables = reinterpret_cast<float*>(reinterpret_cast<char*>(grad_partial) + grad_rows_bytes(p));
     if (a.dbg) a.dbg += (size_t)p.fwd_grid * 8 * 8;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    const bool bwd_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.bwd_specialised && !p.inst.wide && p.inst.launch_bwd2_x3 &&
-                        p.inst.bwd2_x3_lds_bytes() <= kMaxLds;        // (else the fp32 backward: same results, same store)
+    const bool bwd_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.bwd_specialised && p.inst.launch_bwd2_x3 &&
+                        (p.inst.wide || p.inst.bwd2_x3_lds_bytes() <= kMaxLds);   // (else the fp32 backward: same results, same store)
     hipError_t e = bwd_x3 ? p.inst.launch_bwd2_x3(a, p.bwd_grid, (hipStream_t)stream)
                    : p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
                                        : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
@@ -840,8 +840,8 @@ int psp_hjb_rollout_bwd_step(const psp_hjb_config* cfg, float* params, const flo
     a.sums = sums; a.grad_partial = grad_partial;
     a.tables = reinterpret_cast<float*>(reinterpret_cast<char*>(grad_partial) + grad_rows_bytes(p));
     if (a.dbg) a.dbg += (size_t)p.fwd_grid * 8 * 8;
-    const bool bwd_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.bwd_specialised && !p.inst.wide && p.inst.launch_bwd2_x3 &&
-                        p.inst.bwd2_x3_lds_bytes() <= kMaxLds;        // (else the fp32 backward: same results, same store)
+    const bool bwd_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.bwd_specialised && p.inst.launch_bwd2_x3 &&
+                        (p.inst.wide || p.inst.bwd2_x3_lds_bytes() <= kMaxLds);   // (else the fp32 backward: same results, same store)
     hipError_t e = bwd_x3 ? p.inst.launch_bwd2_x3(a, p.bwd_grid, (hipStream_t)stream)
                    : p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
                                        : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
