@@ -568,6 +568,8 @@ def main():
         if x3:
             if plan.family != 2:
                 bwd_name = "hjb_bwd3_kernel"
+            elif plan.d_pad > 256:
+                bwd_name = "hjbw_bwd_x3_kernel"
             issued_x3 = issued_mfma_x3(plan.d_pad, plan.H_pad, dense, plan.family)
         if quad:
             issued = (issued_mfma_quad_kernel(plan.d_pad, plan.H_pad, dense), 0, issued[2])
@@ -628,8 +630,8 @@ def main():
                                        "a.b = hi.hi + (hi.lo + lo.hi)/2048 as three v_mfma_f32_16x16x32_f16 with fp32 accumulation "
                                        "(product error 1.07x that of v_mfma_f32_16x16x4_f32; same parity bounds, "
                                        "tests/test_gpu_split_product.py); state, sums and the path store are fp32"
-                                       + ("; forward kernel only (the wide family's backward runs v_mfma_f32_16x16x4_f32)"
-                                          if getattr(plan, "family", 1) == 2 else "")) if x3 else
+                                       + ("; forward kernel only (hjbw_bwd2_kernel, d <= 256, runs v_mfma_f32_16x16x4_f32)"
+                                          if (getattr(plan, "family", 1) == 2 and plan.d_pad <= 256) else "")) if x3 else
                                       ("v_mfma_f32_16x16x32_bf16 for the control net, v_mfma_f32_16x16x4_f32 elsewhere" if bf16_mlp
                                        else "v_mfma_f32_16x16x4_f32"),
                    "launch": "hipGraph replay of the captured iteration" if graph else "eager launches",
