@@ -1822,23 +1822,26 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
                 const f32x4 a11 = reinterpret_cast<const f32x4*>(a1x)[((2 * pr + 1) * HB + m) * 64 + lane];
                 split2u(a10, a11, A1h[m], A1l[m]);
             }
-            const float* xib0 = bp0 + G::pXi + lofsU + wave * 256;
-            const float* xib1 = bp1 + G::pXi + lofsU + wave * 256;
-            const float* xb0 = bp0 + G::pX + lofsU + wave * 256;
-            const float* xb1 = bp1 + G::pX + lofsU + wave * 256;
+            const float* xib0 = bp0 + G::pXi + lofsU;
+            const float* xib1 = bp1 + G::pXi + lofsU;
+            const float* xb0 = bp0 + G::pX + lofsU;
+            const float* xb1 = bp1 + G::pX + lofsU;
+            // tile offset of this wave's o-th state block, clamped into the image (DB not a multiple of 4: the empty last slot of
+            // some waves re-reads the last block; its products are discarded at the write-out)
+            auto tofs = [&](int o) __attribute__((always_inline)) { const int ob = wave + 4 * o; return (ob < DB ? ob : DB - 1) * 256; };
             constexpr int RD = 3;                                     // own blocks are 4 apart: RD - 1 of them (24 MFMAs each) in flight
             f32x4 xit0[RD], xit1[RD], xt0[RD], xt1[RD];
 #pragma unroll
             for (int i = 0; i < RD - 1; ++i) {
                 if (i < OBW) {
-                    xit0[i] = *reinterpret_cast<const f32x4*>(xib0 + i * 1024); xit1[i] = *reinterpret_cast<const f32x4*>(xib1 + i * 1024);
-                    xt0[i] = *reinterpret_cast<const f32x4*>(xb0 + i * 1024); xt1[i] = *reinterpret_cast<const f32x4*>(xb1 + i * 1024);
+                    xit0[i] = *reinterpret_cast<const f32x4*>(xib0 + tofs(i)); xit1[i] = *reinterpret_cast<const f32x4*>(xib1 + tofs(i));
+                    xt0[i] = *reinterpret_cast<const f32x4*>(xb0 + tofs(i)); xt1[i] = *reinterpret_cast<const f32x4*>(xb1 + tofs(i));
                 }
             }
 #pragma unroll
             for (int o = 0; o < OBW; ++o) {
                 if (o + RD - 1 < OBW) {
-                    const int s = (o + RD - 1) % RD, of = (o + RD - 1) * 1024;
+                    const int s = (o + RD - 1) % RD, of = tofs(o + RD - 1);
                     xit0[s] = *reinterpret_cast<const f32x4*>(xib0 + of); xit1[s] = *reinterpret_cast<const f32x4*>(xib1 + of);
                     xt0[s] = *reinterpret_cast<const f32x4*>(xb0 + of); xt1[s] = *reinterpret_cast<const f32x4*>(xb1 + of);
                 }
