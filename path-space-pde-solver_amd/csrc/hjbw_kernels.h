@@ -1670,6 +1670,7 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
 #pragma unroll
     for (int i = 0; i < OBW; ++i) bs3[i] = 0.f;
 
+    float* wts = lds + 2 * 4 * EXB + 4 * 16 * DB + 4 * HB * 256;        // [2 rounds][4 blocks][16] scaled trajectory weights
     int par = 0;
 #pragma unroll 1
     for (long long round = blockIdx.x; round < nround; round += gridDim.x, par ^= 1) {
@@ -1733,6 +1734,7 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
                 fma_stage(S % NSTG, S);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (q == 0) wts[par * 64 + wave * 16 + j] = wks;      // the block's 16 scaled weights, for phase B2 (no loads of D there)
             float* ex = exch + wave * EXB + lane;
 #pragma unroll
             for (int m = 0; m < HB; ++m) {
@@ -1803,15 +1805,11 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
             if (c0 >= nblk) break;                                    // wave-uniform
             const bool v1 = c0 + 1 < nblk;
             const int cb0 = __builtin_amdgcn_readfirstlane((int)c0), cb1 = __builtin_amdgcn_readfirstlane((int)(v1 ? c0 + 1 : c0));
-            const int t0 = cb0 % a.ntile16, t1 = cb1 % a.ntile16;
             const float* bp0 = a.path + (size_t)cb0 * (size_t)G::PB;
             const float* bp1 = a.path + (size_t)cb1 * (size_t)G::PB;
-            f32x4 w40, w41;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                w40[r] = gs * weight_of(t0 * 16 + 4 * q + r);
-                w41[r] = v1 ? gs * weight_of(t1 * 16 + 4 * q + r) : 0.f;
-            }
+            // weights of the lane's samples 4 q .. 4 q + 3 of both blocks (written by phase A; an invalid block's are zero)
+            const f32x4 w40 = *reinterpret_cast<const f32x4*>(wts + par * 64 + (2 * pr) * 16 + 4 * q);
+            const f32x4 w41 = *reinterpret_cast<const f32x4*>(wts + par * 64 + (2 * pr + 1) * 16 + 4 * q);
             f16x8 B3h[HB], B3l[HB], A1h[HB], A1l[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) {
@@ -1996,7 +1994,7 @@ struct HjbwLaunch {
         } else {
             hipError_t e = tables(a, 5, s);
             if (e != hipSuccess) return e;
-            const int bytes = (W::bwd_lds_floats + 4 * W::HB * 256) * 4;      // + the shared dz1 tiles of a round
+            const int bytes = (W::bwd_lds_floats + 4 * W::HB * 256 + 128) * 4;   // + the shared dz1 tiles and the weights of a round
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_bwd_x3_kernel<D, H>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;
