@@ -1671,6 +1671,12 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
     for (int i = 0; i < OBW; ++i) bs3[i] = 0.f;
 
     float* wts = lds + 2 * 4 * EXB + 4 * 16 * DB + 4 * HB * 256;        // [2 rounds][4 blocks][16] scaled trajectory weights
+    float w2b[16];                                                      // B operands of the dz1 products: W2[4 ks + q][16 ib + j]
+#pragma unroll                                                          // (512 registers here: kept for the whole kernel)
+    for (int ks = 0; ks < 16; ++ks) {
+        const int o = 4 * ks + q, i = 16 * wave + j;
+        w2b[ks] = (o < H && i < H) ? P[G::oW2 + o * H + i] : 0.f;
+    }
     int par = 0;
 #pragma unroll 1
     for (long long round = blockIdx.x; round < nround; round += gridDim.x, par ^= 1) {
@@ -1761,18 +1767,10 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
             const f32x4 h1t1 = *reinterpret_cast<const f32x4*>(bp1 + G::pH1 + wave * 256 + lofsU);
             // dz1 tiles of hidden block ib for both blocks: (dz2^T W2[:, ib]) (1 - h1^2)   (fp32 MFMA: 16 per block)
             f32x4 dzt0 = zero4, dzt1 = zero4;
-            {
-                float w2b[16];
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    const int o = 4 * ks + q, i = 16 * wave + j;
-                    w2b[ks] = (o < H && i < H) ? P[G::oW2 + opaque_i(0) + o * H + i] : 0.f;
-                }
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    dzt0 = mfma16(ex0[ks * 64 + lane], w2b[ks], dzt0);
-                    dzt1 = mfma16(v1 ? ex1[ks * 64 + lane] : 0.f, w2b[ks], dzt1);
-                }
+            for (int ks = 0; ks < 16; ++ks) {
+                dzt0 = mfma16(ex0[ks * 64 + lane], w2b[ks], dzt0);
+                dzt1 = mfma16(v1 ? ex1[ks * 64 + lane] : 0.f, w2b[ks], dzt1);
             }
             // dW2[:, ib] += dz2^T h1
             {
