@@ -93,6 +93,21 @@ def native_eligibility(solver):
     return None
 
 
+def chunk_scratch_sizes(cfg, chunk_Ks):
+    """psp_hjb_sizes that serve EVERY chunk size in `chunk_Ks`: the field-wise maximum of the per-size queries."""
+    sizes = None
+    for k in sorted(set(int(k) for k in chunk_Ks)):
+        probe = nat.HjbConfig.from_buffer_copy(cfg)
+        probe.K_local = k
+        q = nat.query(probe)
+        if sizes is None:
+            sizes = q
+        else:
+            for f in ('path_bytes', 'fwd_partial_bytes', 'grad_partial_bytes', 'fwd_workgroups', 'bwd_workgroups'):
+                setattr(sizes, f, max(getattr(sizes, f), getattr(q, f)))
+    return sizes
+
+
 class HjbNativePlan:
     def __init__(self, solver, noise='reference'):
         reason = native_eligibility(solver)
@@ -261,12 +276,21 @@ class HjbNativePlan:
         return nat.stream_ptr(self.dev)
 
     # ---- K-chunking (module docstring) -------------------------------------------------------------------------------
-    DEFAULT_PATH_BUDGET = 96 * 2 ** 30          # a third of the 288 GB of HBM3E: chunk only when the store would not fit beside the rest
+    DEFAULT_PATH_BUDGET = 96 * 2 ** 30          # a third of the 288 GB of HBM3E when the device cannot be asked
+
+    def _default_budget(self):
+        """A third of THIS device's memory, and never more than 80 % of what is free right now (other tensors, other ranks on
+        the same card): the plan chunks instead of failing in torch.empty(path_bytes)."""
+        try:
+            free, total = torch.cuda.mem_get_info(self.dev)
+            return max(1 << 28, min(int(total) // 3, int(free) * 4 // 5))
+        except Exception:                                # size queries on a machine without a GPU
+            return self.DEFAULT_PATH_BUDGET
 
     def _setup_chunks(self, solver, cfg, sizes):
         """Decides the number of trajectory chunks from the path-store budget and re-queries the scratch sizes for one
         chunk.  Sets self.n_chunks, self.chunk_K (trajectories per chunk, a multiple of 16), self.sizes, self.chunk_mode."""
-        budget = getattr(solver, 'path_budget_bytes', None) or self.DEFAULT_PATH_BUDGET
+        budget = getattr(solver, 'path_budget_bytes', None) or self._default_budget()
         forced = getattr(solver, 'path_chunks', None)
         n = int(forced) if forced else max(1, -(-int(sizes.path_bytes) // int(budget)))
         n = min(n, max(1, (self.K_local + 15) // 16))
@@ -293,9 +317,11 @@ class HjbNativePlan:
         n = -(-self.K_local // Kc)
         if n <= 1:
             return
-        probe = nat.HjbConfig.from_buffer_copy(cfg)
-        probe.K_local = Kc
-        self.sizes = nat.query(probe)                    # the largest chunk sizes every scratch buffer
+        # every DISTINCT chunk size is queried and each scratch buffer takes the maximum: the forward grid (hence the
+        # fp64 partials, and in the wide family the operand tables behind them) is not monotone in K_local -- a ragged
+        # last chunk can pick another forward kernel with a LARGER grid than the full chunks (K_local = 2064 in two
+        # chunks: 65 tiles -> feature-split kernel, grid 65; 64 tiles -> quad kernel, grid 256)
+        self.sizes = chunk_scratch_sizes(cfg, {Kc, self.K_local - (n - 1) * Kc})
         self.n_chunks, self.chunk_K = n, Kc
         mode = getattr(solver, 'chunk_mode', 'auto')
         simple = (not self.attached and not self.relent and not self.generic_loss)      # log-variance / moment, detached

@@ -28,6 +28,8 @@ def dev():
 CASES = [("llgc_d100_h64_logvar", ("two_gradient", "recompute")),
          ("lqgc_d2_logvar_noul2", ("two_gradient", "recompute")),
          ("llgc_d200_h64_logvar", ("two_gradient", "recompute")),          # wide family
+         ("llgc_d300_h40_logvar", ("two_gradient", "recompute")),          # wide family, d > 256: hjbw_bwd_x3_kernel under
+         ("llgc_d500_h64_logvar", ("two_gradient", "recompute")),          #   PSP_LOSS_WEIGHTS (the path configs[4] takes)
          ("lqgc_d33_h50_logvar", ("two_gradient", "recompute")),           # padded instance
          ("lqgc_d2_moment", ("two_gradient", "recompute")),                # learn_Y_0
          ("lqgc_d4_randx0", ("two_gradient", "recompute")),
@@ -111,6 +113,27 @@ def test_budget_selects_the_chunk_count():
     assert math.isclose(m.loss_log[0], full.loss_log[0], rel_tol=1e-6)
     err = float((plan.grad - fplan.grad).abs().max()) / float(fplan.grad.abs().max())
     assert err <= 5e-6, err
+
+
+def test_ragged_last_chunk_on_another_forward_kernel():
+    """the forward grid is not monotone in K_local.  K = 2064 in two chunks on 256 CUs: chunk 0 has 65 tiles
+    (feature-split kernel, grid 65), chunk 1 has 64 tiles (quad kernel, grid 256) -- the shared scratch must be sized for
+    the larger of the two, per buffer.  fp32 products: the small-K kernels exist in that mode only."""
+    case = load_golden("llgc_d100_h64_logvar")["case"]
+    K = 2064
+    base, bplan = _run(case, 1, "philox", K=K, mlp_dtype="fp32")
+    for mode in ("two_gradient", "recompute"):
+        m, plan = _run(case, 1, "philox", K=K, mlp_dtype="fp32", path_chunks=2, chunk_mode=mode)
+        assert plan.n_chunks == 2 and plan.chunk_K == 1040, (plan.n_chunks, plan.chunk_K)
+        from path_space_pde_solver_amd import native as nat
+        for off, k, c, c0, cw in plan.chunks:
+            q = nat.query(c)
+            assert q.fwd_partial_bytes <= plan.fp_stride * 8 and q.grad_partial_bytes <= plan.grad_partial.numel() * 4
+            assert q.path_bytes <= plan.path.numel() * 4
+        assert float((plan.D - bplan.D).abs().max()) <= 2e-6 * max(1.0, float(bplan.D.abs().max()))
+        assert math.isclose(m.loss_log[0], base.loss_log[0], rel_tol=1e-6), (m.loss_log, base.loss_log)
+        err = float((plan.grad - bplan.grad).abs().max()) / float(bplan.grad.abs().max())
+        assert err <= 5e-6, (mode, err)
 
 
 def test_two_gradient_is_shift_invariant_under_a_large_mean():

@@ -97,3 +97,24 @@ def test_padded_value_net_equals_real_value_net():
     assert cands and cands[0] == (32, 32)
     assert shapes.gen_candidates(100, 64)[0] == (100, 64)
     assert shapes.gen_candidates(101, 64) == []
+
+
+def test_chunk_scratch_covers_every_chunk_size():
+    """the forward grid of psp_hjb_query is not monotone in K_local (K = 1040: feature-split kernel, 65
+    workgroups; K = 1024: quad kernel, 256 workgroups on a 256-CU device), so the scratch shared by the chunks of a K-chunked
+    plan is the field-wise maximum over the distinct chunk sizes (plan_native.chunk_scratch_sizes)."""
+    from path_space_pde_solver_amd import plan_native
+    cfg = nat.HjbConfig()
+    cfg.d, cfg.H, cfg.K_local, cfg.N, cfg.K_global = 100, 64, 1040, 10, 2064
+    cfg.drift_kind, cfg.sigma_kind, cfg.term_kind = nat.DRIFT_DENSE, nat.SIGMA_DENSE, nat.TERM_LINEAR
+    cfg.adaptive, cfg.store_path, cfg.noise_mode = 1, 1, nat.NOISE_PHILOX
+    big = nat.query(cfg)
+    cfg.K_local = 1024
+    small = nat.query(cfg)
+    if small.fwd_partial_bytes <= big.fwd_partial_bytes:        # (a device with another CU count: the premise does not hold)
+        return
+    cfg.K_local = 1040
+    both = plan_native.chunk_scratch_sizes(cfg, {1040, 1024})
+    assert both.fwd_partial_bytes == small.fwd_partial_bytes > big.fwd_partial_bytes
+    assert both.path_bytes == big.path_bytes >= small.path_bytes
+    assert both.grad_partial_bytes == max(big.grad_partial_bytes, small.grad_partial_bytes)
