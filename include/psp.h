@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PSP_VERSION 201 /* 0.2.1 */
+#define PSP_VERSION 300 /* 0.3.0: range_flag in psp_hjb_config / psp_gen_config (guarded split-product mode) */
 
 /* drift b(x): reference problems.py:36-37,154-155 (dense), :311-315 (double well) */
 enum { PSP_DRIFT_ZERO = 0, PSP_DRIFT_DENSE = 1, PSP_DRIFT_DIAG = 2, PSP_DRIFT_DOUBLE_WELL = 3 };
@@ -109,6 +109,20 @@ typedef struct psp_hjb_config {
     const uint32_t* iter_dev; /* optional DEVICE-resident iteration counter (the `iter` member of a psp_iter_state): when set, the
                            * forward kernels key Philox with *iter_dev instead of the `iter` argument, so that a captured
                            * hipGraph of the iteration can be replayed without per-iteration host arguments.  NULL: `iter` */
+    int32_t* range_flag;  /* optional DEVICE int32[4] (8-byte aligned; [2..3] are scratch of the library), read only with mlp_dtype == PSP_MLP_F16X3: the RANGE GUARD of the split-product
+                           * mode.  The reference computes in fp32 (solver.py:39-40); an f16x3 operand beyond 65504 has hi = +inf and
+                           * lo = -inf, so main and correction chains of every product it enters meet as inf - inf: every output of
+                           * that trajectory is NaN from that step on and D_k is NaN -- an overflow can never go unnoticed, and it
+                           * costs nothing to detect.  With range_flag set,
+                           *   psp_hjb_rollout_fwd / psp_dnet_rollout_fwd run the split kernel, set range_flag[0] = 1 iff a per-workgroup
+                           *     partial of (sum D, sum D^2) is non-finite (else 0; range_flag[1] counts the 1s), and enqueue the
+                           *     fp32-MFMA kernel of the same launch PREDICATED on range_flag[0] (its workgroups return at once when it
+                           *     is 0; when it runs it overwrites D, the partials and the path store, whose format the two share);
+                           *   psp_hjb_adjoint_sweep, psp_hjb_rollout_bwd(_step), psp_dnet_adjoint_sweep enqueue the split kernel
+                           *     predicated on range_flag[0] == 0 and its fp32-MFMA twin predicated on range_flag[0] == 1.
+                           * A guarded iteration therefore returns the fp32-MFMA result wherever the split kernels left their range
+                           * (and the same non-finite loss as the reference when fp32 itself overflows), with no host sync.
+                           * NULL: unguarded split kernels.                                                                       */
 } psp_hjb_config;
 
 /* Sizes of the caller-owned scratch buffers for a config. */
@@ -331,6 +345,9 @@ typedef struct psp_gen_config {
                            * sample (0 in slot N) and `ahat` holds the coefficient of grad_theta V of every sample itself
                            * (wV is ignored): losses with a term at every step.  0: per-trajectory wY, wV as described below     */
     int32_t reserved;
+    int32_t* range_flag;  /* optional DEVICE int32[4]: range guard of PSP_MLP_F16X3 as in psp_hjb_config.range_flag -- the forward sets
+                           * range_flag[0] iff V(X_N) or Y_N of any trajectory is non-finite and enqueues the fp32-MFMA forward
+                           * predicated on it; psp_gen_rollout_bwd enqueues both backward kernels, predicated.  NULL: unguarded    */
 } psp_gen_config;
 
 typedef struct psp_gen_sizes {

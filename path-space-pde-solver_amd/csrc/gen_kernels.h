@@ -48,6 +48,8 @@ struct GenArgs {
     float dom_a, dom_b;   // sphere radius / box bounds X_l, X_r
     float h_par[4];       // GH_EXPBALL_*: alpha, d (real dimension), coefficient of the extra -y, 1 if the exponent carries 2 t
     uint32_t seed_lo, seed_hi, iter;
+    const int* cond;      // launch predicate of the guarded split-product mode (hjb_kernels.h PSP_COND_EXIT)
+    int cond_want;
 };
 
 template <int D, int H>
@@ -163,6 +165,7 @@ __device__ __forceinline__ f32x4 image_get_T(const float* base, int o32, int o16
 // X3 (psp_gen_config.mlp_dtype = PSP_MLP_F16X3): the nine value-net products per step as split f16 products, fp32-grade
 template <int D, int H, bool BF16 = false, bool PHILOX = false, bool X3 = false>
 __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
+    PSP_COND_EXIT(a);
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, KSI = G::KSI, HB = G::HB, KSH = G::KSH;
     constexpr int MODE = X3 ? 2 : (BF16 ? 1 : 0);
@@ -543,6 +546,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
 // =======================================================================================
 template <int D, int H>
 __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
+    PSP_COND_EXIT(a);
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, HB = G::HB, KSH = G::KSH;
     constexpr int WH = G::WH, WD = G::WD, NIB = G::NIB, NRX = G::NRX, NRH = G::NRH;
@@ -884,6 +888,7 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
 //  packs + their landing registers do not fit 256 registers: 57 spilled dwords in the consumer loop, 5.3 ms against 4.47.)
 template <int D, int H, bool BF16 = false, bool X3 = false>
 __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
+    PSP_COND_EXIT(a);
     static_assert(!(BF16 && X3), "one matrix-product mode");
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, HB = G::HB, KSH = G::KSH, EXT = G::EXT;

@@ -49,6 +49,8 @@ struct HjbArgs {
     const float* adj_nu;       //                                  dL/dZsum_N per trajectory (relative entropy), may be null
     const float* adj_wT;       //   weight of grad g(X_N) in lambda_N per trajectory; null: nu - mu (losses of Y_N - g(X_N))
     const uint32_t* iter_dev;  // optional device-resident iteration counter (hipGraph replay); null: `iter` below
+    const int* cond;           // optional launch predicate (range guard of the split-product mode, include/psp.h): the grid
+    int cond_want;             //   returns at once unless (*cond != 0) == (cond_want != 0)
     long long k_offset;
     long long K_global;
     int x0_stride;
@@ -59,6 +61,11 @@ struct HjbArgs {
     int drift_kind, sigma_kind, runcost_kind, term_kind, adaptive, loss_kind, noise_mode, store_path;
     uint32_t seed_lo, seed_hi, iter;
 };
+
+// Predicated launch: the guarded split-product mode enqueues the f16x3 kernel AND its fp32-MFMA twin; a device flag written
+// between the two (non-finite partial sums = an operand left the f16 range) decides which of them does the work.  The test is
+// one scalar load per workgroup, uniform, and stands before any barrier.
+#define PSP_COND_EXIT(args) do { if ((args).cond != nullptr && ((*(args).cond != 0) != ((args).cond_want != 0))) return; } while (0)
 
 // ---- enums mirrored from include/psp.h (kept numeric here to avoid including C header in device code)
 enum { DRIFT_ZERO = 0, DRIFT_DENSE = 1, DRIFT_DIAG = 2, DRIFT_DWELL = 3 };
@@ -553,6 +560,7 @@ struct Geo {
 // are short; the larger part of the path store's cost stays (finding 7).
 template <int D, int H, int MODE = 0, bool FAST = false>
 __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
@@ -914,6 +922,7 @@ __device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] +
 
 template <int D, int H>
 __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
     constexpr int WH = G::WH, WD = G::WD, NIB = G::NIB, NOBD = G::NOBD, NOBH = G::NOBH;
@@ -1249,6 +1258,7 @@ __global__ __launch_bounds__(256, 2) void hjb_bwd_kernel(const HjbArgs a) {
 // =======================================================================================
 template <int D, int H>
 __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH, EXB = G::EXB;
     constexpr int WH = G::WH, WD = G::WD, NIB = G::NIB, NOBD = G::NOBD, NOBH = G::NOBH;

@@ -27,6 +27,7 @@ namespace psp {
 // the image it writes back -- exact.
 template <int D, int H, bool X3 = false>
 __global__ __launch_bounds__(512) void hjb_adj_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
     constexpr int VSH = X3 ? G::xVec - G::fVec : 0;    // the vectors and the d x d tables follow the (larger) split tables

@@ -94,6 +94,7 @@ struct DGeo {
 // oB <- B^T.  (The forward tables are dead once the rollout has finished; the backward kernel stages its own from the parameters.)
 template <int D, int H>
 __global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a, int adjoint) {
+    PSP_COND_EXIT(a.h);
     using W = DGeo<D, H>;
     const HjbArgs& h = a.h;
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gs = (long long)gridDim.x * blockDim.x;
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a, int 
 // the tables of hjbd_tables_kernel(.., 2); the two images of a wave hold hi / lo packs
 template <int D, int H, bool X3 = false>
 __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const DnetArgs da) {   // d <= 128: two workgroups per CU
+    PSP_COND_EXIT(da.h);
     using W = DGeo<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
     constexpr int oSets = X3 ? W::oSets_x : W::oSets, SETF = X3 ? W::set_floats_x3 : W::set_floats, IMGF = X3 ? W::IMGX : W::IMG;
@@ -624,6 +626,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
 // per wave by a power of two and the image written back scaled back (hjb_adj_kernel<.., X3>)
 template <int D, int H, bool X3 = false>
 __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const DnetArgs da) {
+    PSP_COND_EXIT(da.h);
     using W = DGeo<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
     const HjbArgs& a = da.h;

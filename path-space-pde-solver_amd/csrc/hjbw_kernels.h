@@ -104,6 +104,7 @@ __device__ __forceinline__ void table_fill_x3(float* dstf, int MB, int NS, long 
 
 template <int D, int H>
 __global__ __launch_bounds__(256) void hjbw_tables_kernel(const HjbArgs a, int backward) {
+    PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gs = (long long)gridDim.x * blockDim.x;
@@ -546,6 +547,7 @@ __device__ __forceinline__ void gemm_regs_x3(f32x4 (&acc)[MB], const float* __re
 // X3: every product as split f16 products (psp_hjb_config.mlp_dtype = PSP_MLP_F16X3; tables built by hjbw_tables_kernel(.., 3))
 template <int D, int H, bool LOGU = false, bool FAST = false, bool X3 = false>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
@@ -873,6 +875,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
 // =======================================================================================
 template <int D, int H>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP, EXB = W::EXB;
@@ -1111,6 +1114,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_bwd_kernel(const
 // (mu, nu, wT ~ 1 / K) are scaled per wave by a power of two and the image written back is scaled back, as in hjb_adj_kernel<.., X3>
 template <int D, int H, bool X3 = false>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_adj_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP;
@@ -1334,6 +1338,7 @@ struct GeoB2 {
 
 template <int D, int H>
 __global__ __launch_bounds__(512) void hjbw_bwd2_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     using B2 = GeoB2<D, H>;
     constexpr int DB = B2::DB, HB = B2::HB, KSD = B2::KSD, KSH = B2::KSH, EXQ = B2::EXQ, RD = B2::RD, RS = B2::RS;
@@ -1604,6 +1609,7 @@ __global__ __launch_bounds__(512) void hjbw_bwd2_kernel(const HjbArgs a) {
 // =======================================================================================
 template <int D, int H>
 __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     constexpr int DB = W::DB, HB = W::HB, EXB = W::EXB, KS8 = W::KS8;

@@ -16,8 +16,14 @@
 //     operand is a tanh output (|h| <= 1), so 2048 hi_h is exact in f16 and main and correction terms share ONE accumulator
 //     (2048 a.b = hi_a (2048 hi_b) + hi_a lo_b + lo_a hi_b); dW1 keeps two.
 // Magnitudes: G (and with it dz2, dz1) carries the trajectory weights w_k ~ 1 / K -- far below the f16 normal range, where the
-// hi part would lose its bits.  Each workgroup scales G by a power of two taken from the largest |G| of its first round
-// (exact; the gradient is linear in G) and scales its partial gradient back when it is written.
+// hi part would lose its bits.  Each workgroup scales G by a power of two (exact; the gradient is linear in G) and scales its
+// partial gradient back when it is written.  The scale maps  max_k |w_k| * sqrt(dt) * I  into [1, 2): max_k |w_k| from a scan of
+// ALL of this rank's weights by every workgroup (K_local floats, L2-resident; round 3 -- a first-round estimate failed silently
+// when the first tiles carried zero weights, and overflowed on a weight 3e4 x the first round's), and I = 8 when the stored image
+// is the Brownian increment itself (adaptive forward process, store_path 1: |xi| < 6 from Box-Muller on 24-bit uniforms), else
+// the largest |image| of the workgroup's first round (non-adaptive / attached images carry Z or the adjoint gZ; the stated
+// range condition there: no later image entry above 3e4 x that maximum).  Below the scale the split keeps its accuracy down to
+// 2^-36 of the maximum (hi subnormal, lo still exact), i.e. weights 1e5 x smaller than the largest lose nothing that matters.
 // One barrier per round swaps the two exchange buffers, as in hjb_bwd2_kernel.  LDS: W3^T and W2^T split tables, 2 x 2 pairs
 // of (2 D + 4 * 16 HB) * 64 bytes (d = 100, H = 64: 158 736 bytes).  Reference lines: solver.py:468-472 (what carries a
 // gradient), function_space.py:190-195 (the net).
@@ -39,8 +45,8 @@ struct GeoX {
     static constexpr int NX = cdiv(DB, 4);                             // X blocks per consumer wave
     static constexpr int NT = DB + 2 * HB;                             // A tiles per pair: G, dz2, dz1
     static_assert(4 * RS <= 4 * (PAIRH / 2), "bias sums reuse the exchange area");
-    static constexpr int GS = EX + 4 * (PAIRH / 2);                    // 4 floats: the producers' largest |G| of round 0
-    static int lds_floats() { return GS + 4; }
+    static constexpr int GS = EX + 4 * (PAIRH / 2);                    // 4 floats: the producers' largest |image| of round 0,
+    static int lds_floats() { return GS + 12; }                        // 8 floats: per-wave largest |w_k| of the weight scan
 };
 
 template <int NB>
@@ -123,6 +129,7 @@ __device__ __forceinline__ void gemm_Txp(f32x4 (&acc)[MB], const float* wlds, co
 
 template <int D, int H>
 __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
+    PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     using X = GeoX<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH, NX = X::NX, RS = X::RS, PAIRH = X::PAIRH, NT = X::NT;
@@ -134,26 +141,40 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
     const int sub = wave & 3;                         // producer: block within the round; consumer: tile column
     const float* __restrict__ P = a.params;
 
+    const double invK = 1.0 / (double)a.K_global;
+    const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
+    const float coef = (float)(2.0 * invK);
+    {   // largest |w_k| of this rank (header comment); NaN entries drop out of fmaxf
+        float wm = 0.f;
+        for (int k = tid; k < a.K_local; k += nthr) {
+            const float dk = a.D[k];
+            wm = fmaxf(wm, fabsf(a.loss_kind == LOSS_WEIGHTS ? dk : coef * (dk - meanD)));
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+        if (lane == 0) lds[X::GS + 4 + wave] = wm;
+    }
     stage_aop_x3<KSD, DB>(lds + X::T3, HB, tid, nthr, [&](int row, int col) {      // W3^T and W2^T (producers)
         return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
     stage_aop_x3<KSH, HB>(lds + X::T2, HB, tid, nthr, [&](int row, int col) {
         return (row < H && col < H) ? P[G::oW2 + col * H + row] : 0.f; });
     __syncthreads();
     _Float16* exh = reinterpret_cast<_Float16*>(lds + X::EX);           // [2 buffers][2 pairs][PAIRH] halves
-    // power-of-two scale of G from the four producers' largest |G| of round 0 (written before the first barrier)
+    // power-of-two scale of G (header comment): max |w| of the scan x sqrt(dt) x image bound
+    const bool xi_image = a.adaptive != 0 && a.store_path == 1;
     auto g_scale = [&](float& gs, float& ginv) __attribute__((always_inline)) {
         const float* slot = lds + X::GS;
-        const float amax = fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3]));
+        float imax = fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3]));
+        if (xi_image || !(imax >= 1.1754944e-38f)) imax = xi_image ? 8.0f : 1.0f;
+        const float wmax = fmaxf(fmaxf(fmaxf(slot[4], slot[5]), fmaxf(slot[6], slot[7])),
+                                 fmaxf(fmaxf(slot[8], slot[9]), fmaxf(slot[10], slot[11])));
+        const float amax = wmax * a.sqdt * imax;
         const unsigned e = (__float_as_uint(amax) >> 23) & 0xFFu;
         const bool ok = e >= 1u && e <= 253u;                             // zero / subnormal / non-finite: no scaling
         gs = ok ? __uint_as_float((254u - e) << 23) : 1.0f;
         ginv = ok ? __uint_as_float(e << 23) : 1.0f;
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    const double invK = 1.0 / (double)a.K_global;
-    const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
-    const float coef = (float)(2.0 * invK);
     const float sqdt = a.sqdt, dt = a.dt;
     const long long nblk = (long long)a.N * a.ntile16;
     const long long nround = (nblk + 3) / 4;
@@ -196,12 +217,11 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
             const long long b0 = own_block(0);
             const int k0 = (int)((b0 >= 0 ? b0 : nblk - 1) % a.ntile16) * 16 + j;
             const bool kv = b0 >= 0 && k0 < a.K_local;
-            const float w0 = kv ? (a.loss_kind == LOSS_WEIGHTS ? dkn : coef * (dkn - meanD)) * sqdt : 0.f;
             float am = 0.f;
 #pragma unroll
             for (int b = 0; b < DB; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(w0 * xin[b][r]));
+                for (int r = 0; r < 4; ++r) am = fmaxf(am, kv ? fabsf(xin[b][r]) : 0.f);
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) am = fmaxf(am, __shfl_xor(am, o));
             if (lane == 0) lds[X::GS + sub] = am;

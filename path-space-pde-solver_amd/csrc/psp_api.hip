@@ -136,6 +136,8 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
         if (!p->inst.launch_fwd_x3) return fail(-3, "the split-product mode (PSP_MLP_F16X3) is not built for this kernel family");
         if (p->inst.fwd_x3_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
             return fail(-3, "split-product forward tables do not fit the 160 KiB LDS for this (d,H,drift,sigma)");
+        if (c->range_flag && p->inst.fwd_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
+            return fail(-3, "range guard: the fp32-MFMA forward tables do not fit the 160 KiB LDS for this (d,H,drift,sigma)");
     } else if (p->inst.fwd_lds_bytes(c->drift_kind, c->sigma_kind) > kMaxLds)
         return fail(-3, "forward kernel weights do not fit the 160 KiB LDS for this (d,H,drift,sigma)");
     p->ntile16 = (c->K_local + 15) / 16;
@@ -307,6 +309,41 @@ __global__ void reduce_partials_loss_kernel(const double* __restrict__ part, int
             if (loss_kind == PSP_LOSS_REL_ENTROPY) loss = -m;         // D = -(Zsum + g) (:179-180)
             loss_log[index_dev ? *index_dev : 0u] = (float)loss;
         }
+    }
+}
+
+// Range guard of the split-product mode (include/psp.h: range_flag).  flag[0] = 1 iff any of the n doubles is non-finite
+// (a per-workgroup partial of (sum D, sum D^2): an f16x3 operand beyond 65504 makes D_k NaN), flag[1] counts the 1s.
+__global__ void range_flag_partials_kernel(const double* __restrict__ part, int n, int* __restrict__ flag) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = part[i];
+        mine |= !(fabs(v) <= 1.7976931348623157e308);            // NaN and +-inf
+    }
+    if (mine) bad = 1;                                           // benign race: every writer stores 1
+    __syncthreads();
+    if (threadIdx.x == 0) { flag[0] = bad; flag[1] += bad; }
+}
+__global__ void snapshot_u64_kernel(const unsigned long long* src, unsigned long long* dst) { *dst = *src; }
+// the same from two fp32 arrays of n entries (GeneralSolver: V(X_N) and Y_N per trajectory)
+__global__ void range_flag_arrays_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, int* __restrict__ flag,
+                                         unsigned long long* counter, const unsigned long long* counter_before) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        mine |= !(fabsf(a[i]) <= 3.402823466e38f);
+        mine |= !(fabsf(b[i]) <= 3.402823466e38f);
+    }
+    if (mine) bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        flag[0] = bad; flag[1] += bad;
+        if (bad && counter) *counter = *counter_before;          // the predicated fp32 kernel counts the active steps afresh
     }
 }
 
@@ -584,7 +621,13 @@ extern "C" int psp_dnet_adjoint_sweep(const psp_dnet_config* cfg, const float* p
     a.tbl = tables; a.pimg = images;
     a.d_real = cfg->d_real; a.h_real = cfg->H_real; a.time_input = cfg->time_input ? 1 : 0; a.per_step = cfg->per_step ? 1 : 0;
     const bool x3 = b->mlp_dtype == PSP_MLP_F16X3 && p.inst.launch_adj_x3 && p.inst.lds_bytes_x3 <= kMaxLds;
+    const bool guard = x3 && b->range_flag != nullptr;       // range guard (psp_hjb_config.range_flag): both sweeps, predicated
+    if (guard) { h.cond = b->range_flag; h.cond_want = 0; }
     hipError_t e = x3 ? p.inst.launch_adj_x3(a, p.grid, (hipStream_t)stream) : p.inst.launch_adj(a, p.grid, (hipStream_t)stream);
+    if (e == hipSuccess && guard) {
+        h.cond_want = 1;
+        e = p.inst.launch_adj(a, p.grid, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail_hip(e, "hjbd_adj_kernel launch");
     return 0;
 }
@@ -623,6 +666,14 @@ extern "C" int psp_dnet_rollout_fwd(const psp_dnet_config* cfg, const float* par
     const bool x3 = b->mlp_dtype == PSP_MLP_F16X3 && p.inst.launch_fwd_x3 && p.inst.lds_bytes_x3 <= kMaxLds;
     if (b->mlp_dtype == PSP_MLP_F16X3 && !x3) return fail(-3, "split-product forward images do not fit the 160 KiB LDS for this (d,H)");
     hipError_t e = x3 ? p.inst.launch_fwd_x3(a, p.grid, (hipStream_t)stream) : p.inst.launch_fwd(a, p.grid, (hipStream_t)stream);
+    if (e == hipSuccess && x3 && b->range_flag) {
+        // range guard (psp_hjb_config.range_flag): non-finite partials -> flag -> the fp32-MFMA rollout, predicated
+        hipLaunchKernelGGL(range_flag_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fwd_partial, 2 * p.grid,
+                           b->range_flag);
+        if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "range_flag_partials_kernel launch");
+        h.cond = b->range_flag; h.cond_want = 1;
+        e = p.inst.launch_fwd(a, p.grid, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail_hip(e, "hjbd_fwd_kernel launch");
     return 0;
 }
@@ -705,6 +756,15 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
         e = p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);      // make_plan kept the tile-per-wave forward
     } else if (cfg->mlp_dtype == PSP_MLP_F16X3) {
         e = p.inst.launch_fwd_x3(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+        if (e == hipSuccess && cfg->range_flag) {
+            // range guard: non-finite partials -> flag -> the fp32-MFMA forward of the same launch, predicated on the flag
+            // (same grid, same partials / D / path-store layout; it overwrites what the split kernel left)
+            hipLaunchKernelGGL(range_flag_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fwd_partial,
+                               2 * p.fwd_grid, cfg->range_flag);
+            if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "range_flag_partials_kernel launch");
+            a.cond = cfg->range_flag; a.cond_want = 1;
+            e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+        }
     } else if (cfg->mlp_dtype != PSP_MLP_FP32) {
         return fail(-1, "mlp_dtype out of range for the HJB rollout (fp32, bf16_fwd or f16x3)");
     } else {
@@ -796,6 +856,27 @@ int psp_adam_step_dev(float* params, const float* grad, float* exp_avg, float* e
     return 0;
 }
 
+namespace {
+// the backward kernel(s) of a config: the split-product kernel where it exists, guarded by its fp32-MFMA twin when
+// cfg->range_flag is set (both enqueued, predicated on range_flag[0] == 0 / == 1; same grid and partial-gradient layout)
+hipError_t launch_hjb_bwd(const psp_hjb_config* cfg, const Plan& p, psp::HjbArgs& a, hipStream_t st) {
+    const bool bwd_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.bwd_specialised && p.inst.launch_bwd2_x3 &&
+                        (p.inst.wide || p.inst.bwd2_x3_lds_bytes() <= kMaxLds);   // (else the fp32 backward: same results, same store)
+    auto fp32 = [&]() {
+        return p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, st) : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, st);
+    };
+    if (!bwd_x3) return fp32();
+    const bool guard = cfg->range_flag != nullptr;
+    if (guard) { a.cond = cfg->range_flag; a.cond_want = 0; }
+    hipError_t e = p.inst.launch_bwd2_x3(a, p.bwd_grid, st);
+    if (e != hipSuccess || !guard) return e;
+    a.cond_want = 1;
+    e = fp32();
+    a.cond = nullptr; a.cond_want = 0;
+    return e;
+}
+}  // namespace
+
 int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const float* xi, uint64_t seed,
                         uint32_t iter, const float* path, const float* D, const double* sums,
                         float* grad_partial, float* grad_out, void* stream) {
@@ -812,11 +893,7 @@ int psp_hjb_rollout_bwd(const psp_hjb_config* cfg, const float* params, const fl
     a.tables = reinterpret_cast<float*>(reinterpret_cast<char*>(grad_partial) + grad_rows_bytes(p));
     if (a.dbg) a.dbg += (size_t)p.fwd_grid * 8 * 8;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.iter = iter;
-    const bool bwd_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.bwd_specialised && p.inst.launch_bwd2_x3 &&
-                        (p.inst.wide || p.inst.bwd2_x3_lds_bytes() <= kMaxLds);   // (else the fp32 backward: same results, same store)
-    hipError_t e = bwd_x3 ? p.inst.launch_bwd2_x3(a, p.bwd_grid, (hipStream_t)stream)
-                   : p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
-                                       : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
+    hipError_t e = launch_hjb_bwd(cfg, p, a, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");
     const int P = p.inst.n_params;
     hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 31) / 32), dim3(256), 0, (hipStream_t)stream,
@@ -840,11 +917,7 @@ int psp_hjb_rollout_bwd_step(const psp_hjb_config* cfg, float* params, const flo
     a.sums = sums; a.grad_partial = grad_partial;
     a.tables = reinterpret_cast<float*>(reinterpret_cast<char*>(grad_partial) + grad_rows_bytes(p));
     if (a.dbg) a.dbg += (size_t)p.fwd_grid * 8 * 8;
-    const bool bwd_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.bwd_specialised && p.inst.launch_bwd2_x3 &&
-                        (p.inst.wide || p.inst.bwd2_x3_lds_bytes() <= kMaxLds);   // (else the fp32 backward: same results, same store)
-    hipError_t e = bwd_x3 ? p.inst.launch_bwd2_x3(a, p.bwd_grid, (hipStream_t)stream)
-                   : p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
-                                       : p.inst.launch_bwd(a, p.bwd_grid, p.bwd_waves * 64, (hipStream_t)stream);
+    hipError_t e = launch_hjb_bwd(cfg, p, a, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hjb_bwd_kernel launch");
     const int P = p.inst.n_params;
     hipLaunchKernelGGL(reduce_grad_adam_advance_kernel, dim3((P + 31) / 32), dim3(256), 0, (hipStream_t)stream, grad_partial,
@@ -882,8 +955,14 @@ int psp_hjb_adjoint_sweep(const psp_hjb_config* cfg, const float* params, float*
     if (fw > (p.inst.wide ? 4 : 8)) fw = p.inst.wide ? 4 : 8;
     const int grid = (p.ntile16 + fw - 1) / fw;
     const bool adj_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.inst.launch_adj_x3;    // (make_plan checked the LDS fit of the forward carve)
+    const bool guard = adj_x3 && cfg->range_flag != nullptr;                         // range guard: both sweeps, predicated
+    if (guard) { a.cond = cfg->range_flag; a.cond_want = 0; }
     hipError_t e = adj_x3 ? p.inst.launch_adj_x3(a, grid, fw * 64, (hipStream_t)stream)
                           : p.inst.launch_adj(a, grid, fw * 64, (hipStream_t)stream);
+    if (e == hipSuccess && guard) {
+        a.cond_want = 1;
+        e = p.inst.launch_adj(a, grid, fw * 64, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail_hip(e, "hjb_adj_kernel launch");
     return 0;
 }
@@ -936,9 +1015,24 @@ int psp_gen_rollout_fwd(const psp_gen_config* cfg, const float* params, const fl
     if (cfg->mlp_dtype < PSP_MLP_FP32 || cfg->mlp_dtype > PSP_MLP_F16X3) return fail(-1, "mlp_dtype out of range");
     if (cfg->mlp_dtype == PSP_MLP_F16X3 && (!p.inst.launch_fwd_x3 || p.inst.fwd_x3_lds_bytes() > kMaxLds))
         return fail(-3, "split-product forward tables do not fit the 160 KiB LDS for this (d,H)");
+    if (cfg->mlp_dtype == PSP_MLP_F16X3 && cfg->range_flag) {
+        hipLaunchKernelGGL(snapshot_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, kcount,
+                           reinterpret_cast<unsigned long long*>(cfg->range_flag + 2));
+        hipError_t es = hipGetLastError();
+        if (es != hipSuccess) return fail_hip(es, "snapshot_u64_kernel launch");
+    }
     hipError_t e = cfg->mlp_dtype == PSP_MLP_F16X3 ? p.inst.launch_fwd_x3(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream)
                    : cfg->mlp_dtype != PSP_MLP_FP32 ? p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream)
                                                     : p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    if (e == hipSuccess && cfg->mlp_dtype == PSP_MLP_F16X3 && cfg->range_flag) {
+        // range guard (psp_gen_config.range_flag): a non-finite V(X_N) / Y_N -> flag -> the fp32-MFMA forward, predicated.
+        // kcount accumulates (atomicAdd): the flag kernel takes back what the split kernel added when it raises the flag
+        hipLaunchKernelGGL(range_flag_arrays_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, VN, YN, cfg->K_local,
+                           cfg->range_flag, kcount, reinterpret_cast<const unsigned long long*>(cfg->range_flag + 2));
+        if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "range_flag_arrays_kernel launch");
+        a.cond = cfg->range_flag; a.cond_want = 1;
+        e = p.inst.launch_fwd(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail_hip(e, "gen_fwd_kernel launch");
     return 0;
 }
@@ -959,10 +1053,16 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
         return fail(-3, "the bf16 backward exists for the role-specialised kernel only (LDS budget / PSP_BWD_VARIANT)");
     // (PSP_MLP_F16X3 with shared trajectory weights: the split-product consumers; per-sample weights keep the fp32 kernel)
     const bool bwd_x3 = cfg->mlp_dtype == PSP_MLP_F16X3 && p.bwd_specialised && !cfg->per_sample_weights && p.inst.launch_bwd2_x3;
+    const bool guard = bwd_x3 && cfg->range_flag != nullptr;     // range guard: split and fp32-MFMA backward, predicated
+    if (guard) { a.cond = cfg->range_flag; a.cond_want = 0; }
     hipError_t e = cfg->mlp_dtype == PSP_MLP_BF16 ? p.inst.launch_bwd2_bf16(a, p.bwd_grid, (hipStream_t)stream)
                    : bwd_x3 ? p.inst.launch_bwd2_x3(a, p.bwd_grid, (hipStream_t)stream)
                    : p.bwd_specialised ? p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream)
                                        : p.inst.launch_bwd(a, p.bwd_grid, 256, (hipStream_t)stream);
+    if (e == hipSuccess && guard) {
+        a.cond_want = 1;
+        e = p.inst.launch_bwd2(a, p.bwd_grid, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail_hip(e, "gen_bwd_kernel launch");
     const int P = p.inst.n_params;
     hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 31) / 32), dim3(256), 0, (hipStream_t)stream,

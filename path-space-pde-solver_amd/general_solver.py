@@ -84,8 +84,11 @@ class GeneralSolver:
                  verbose=True, approx_method='Y', sample_center=False, loss_method='diffusion',
                  loss_with_stopped=False, K_test_log=None, PINN_log_variance=False, log_loss_parts=False,
                  boundary_loss=True, full_hessian=False, uniform_square=False, solve_linear_L2_projection=False,
-                 device=None, backend='auto', noise='reference', mlp_dtype='auto'):
+                 device=None, backend='auto', noise='reference', mlp_dtype='auto', range_guard=True):
         self.problem, self.name = problem, name
+        # split-product kernels ('auto' / 'f16x3'): redo an iteration on the fp32-MFMA kernels when an operand left the f16 range
+        # (include/psp.h: psp_gen_config.range_flag); self.range_fallback_iterations counts them after train()
+        self.range_guard, self.range_fallback_iterations = bool(range_guard), 0
         if mlp_dtype not in ('auto', 'fp32', 'f16x3', 'bf16', 'bf16_fwd'):
             raise ValueError("mlp_dtype must be 'auto', 'fp32', 'f16x3', 'bf16' or 'bf16_fwd'")
         self.mlp_dtype = mlp_dtype      # 'bf16': the matrix products of the native kernels on bf16 MFMA with fp32 accumulation
@@ -183,7 +186,7 @@ class GeneralSolver:
         `model.V = DenseNet(...)` after a first train() must rebuild the plan, Allen-Cahn.ipynb:72)."""
         return (id(self.V), self.K, self.N, self.K_boundary, float(self.delta_t_np), self.loss_method, tuple(self.alpha),
                 bool(self.adaptive_forward_process), bool(self.detach_forward), getattr(self, 'noise', None),
-                getattr(self, 'mlp_dtype', None), bool(getattr(self, 'uniform_square', False)), id(self.problem))
+                getattr(self, 'mlp_dtype', None), bool(getattr(self, 'range_guard', True)), bool(getattr(self, 'uniform_square', False)), id(self.problem))
 
     def _choose_plan(self):
         if self.backend == 'torch':
@@ -297,7 +300,7 @@ class EllipticSolver(GeneralSolver):
                  approx_method='Y', sample_center=False, loss_method='diffusion', loss_with_stopped=False,
                  K_test_log=None, PINN_log_variance=False, log_loss_parts=False, boundary_loss=True,
                  boundary_type='Dirichlet', variance_moment_split=False, full_hessian=False, uniform_square=False,
-                 device=None, backend='auto', noise='reference', mlp_dtype='auto', v_l2_error_flag=True):
+                 device=None, backend='auto', noise='reference', mlp_dtype='auto', v_l2_error_flag=True, range_guard=True):
         self.v_l2_error_flag = v_l2_error_flag   # False: skip the V_L2 diagnostic of solver.py:738 on the native plan (timed runs)
         super().__init__(problem, name, seed=seed, delta_t=delta_t, N=N, lr=lr, L=L, K=K, K_boundary=K_boundary,
                          alpha=alpha, adaptive_forward_process=adaptive_forward_process, detach_forward=detach_forward,
@@ -305,7 +308,7 @@ class EllipticSolver(GeneralSolver):
                          loss_method=loss_method, loss_with_stopped=loss_with_stopped, K_test_log=K_test_log,
                          PINN_log_variance=PINN_log_variance, log_loss_parts=log_loss_parts, boundary_loss=boundary_loss,
                          full_hessian=full_hessian, uniform_square=uniform_square, device=device, backend=backend,
-                         noise=noise, mlp_dtype=mlp_dtype)
+                         noise=noise, mlp_dtype=mlp_dtype, range_guard=range_guard)
         self.approx_method = approx_method
         self.boundary_type = boundary_type
         self.variance_moment_split = variance_moment_split

@@ -49,6 +49,7 @@ class HjbConfig(C.Structure):
         ("u_ref", C.c_void_p), ("u_l2_out", C.c_void_p),
         ("mlp_dtype", C.c_int32), ("reserved2", C.c_int32),
         ("iter_dev", C.c_void_p),
+        ("range_flag", C.c_void_p),
     ]
 
 
@@ -76,6 +77,7 @@ class GenConfig(C.Structure):
         ("d_real", C.c_int32), ("mlp_dtype", C.c_int32),
         ("v_steps_out", C.c_void_p), ("y_steps_out", C.c_void_p),
         ("per_sample_weights", C.c_int32), ("reserved", C.c_int32),
+        ("range_flag", C.c_void_p),
     ]
 
 

@@ -157,6 +157,11 @@ class DenseNativePlan:
                 nat.check(self.lib.psp_dnet_query(C.byref(cfg), C.byref(sizes)), 'psp_dnet_query')
             b.mlp_dtype = nat.MLP_FP32
         self.matrix_mode = 'f16x3' if b.mlp_dtype == nat.MLP_F16X3 else 'fp32'
+        # range guard of the split-product rollout (include/psp.h: psp_hjb_config.range_flag)
+        self.range_flag = None
+        if b.mlp_dtype == nat.MLP_F16X3 and getattr(s, 'range_guard', True):
+            self.range_flag = torch.zeros(4, dtype=torch.int32, device=dev)
+            b.range_flag = nat.ptr(self.range_flag)
         nat.check(self.lib.psp_dnet_query(C.byref(cfg), C.byref(sizes)), 'psp_dnet_query')
         assert sizes.n_params_per_set == self.Pset, (sizes.n_params_per_set, self.Pset)
         f32 = torch.float32
@@ -396,6 +401,10 @@ class DenseNativePlan:
                                         nat.ptr(self.y0_v), 1, self.step, ylr, yb1, yb2, yeps, st),
                       'psp_adam_step(Y_0)')
         return loss
+
+    def range_fallbacks(self):
+        """Iterations the range guard sent to the fp32-MFMA rollout so far; one device read."""
+        return int(self.range_flag[1].item()) if self.range_flag is not None else 0
 
     def _adam_hyper(self, nets):
         """lr / betas / eps of the nets' OWN optimisers (function_space.py:131; solver.py:198-200 steps every Phi's Adam).  One

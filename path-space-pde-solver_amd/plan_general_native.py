@@ -126,6 +126,12 @@ class GeneralNativePlan:
             else:
                 cfg.mlp_dtype = nat.MLP_FP32
         self.matrix_mode = {nat.MLP_FP32: 'fp32', nat.MLP_F16X3: 'f16x3', nat.MLP_BF16_FWD: 'bf16_fwd', nat.MLP_BF16: 'bf16'}[cfg.mlp_dtype]
+        # range guard of the split-product mode (include/psp.h: psp_gen_config.range_flag): a non-finite V(X_N) / Y_N raises a
+        # device flag and the fp32-MFMA kernels, enqueued behind the split ones and predicated on it, redo the iteration
+        self.range_flag = None
+        if cfg.mlp_dtype == nat.MLP_F16X3 and getattr(s, 'range_guard', True):
+            self.range_flag = torch.zeros(4, dtype=torch.int32, device=self.dev)
+            cfg.range_flag = nat.ptr(self.range_flag)
         self.pad = shapes.GenParamPad(s.d, self.H, self.d_pad, self.H_pad, self.dev, time_input=not self.elliptic)
         if spec['drift'][1] is not None:
             t = self.pad.vec(spec['drift'][1].detach().to(device=self.dev, dtype=torch.float32)).contiguous()
@@ -333,6 +339,10 @@ class GeneralNativePlan:
         sharding.allreduce_sum_(kc)
         return loss, kc
 
+    def range_fallbacks(self):
+        """Iterations the range guard sent to the fp32-MFMA kernels so far; one device read."""
+        return int(self.range_flag[1].item()) if self.range_flag is not None else 0
+
     def _adam_hyper(self):
         """lr / betas / eps of V's OWN optimiser (function_space.py:131; solver.py:1188 steps V.optim)."""
         opt = getattr(self.net, 'optim', None)
@@ -393,3 +403,4 @@ class GeneralNativePlan:
                 if s.verbose and l % s.print_every == 0:
                     print('%d - loss = %.4e, v L2 error = %.4e, %.4f s/iter' % (l, s.loss_log[-1], s.V_L2_log[-1], s.times[-1]))
                 losses, counts, vl2 = [], [], []
+        s.range_fallback_iterations = self.range_fallbacks()

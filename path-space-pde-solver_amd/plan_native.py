@@ -181,6 +181,15 @@ class HjbNativePlan:
                 else:
                     cfg.mlp_dtype = nat.MLP_FP32
         self.matrix_mode = {nat.MLP_FP32: 'fp32', nat.MLP_BF16_FWD: 'bf16', nat.MLP_F16X3: 'f16x3'}[cfg.mlp_dtype]
+        # range guard of the split-product mode (include/psp.h: psp_hjb_config.range_flag): the reference is fp32 end to end
+        # (solver.py:39-40); an f16x3 operand beyond 65504 turns D_k into NaN, the forward call raises a device flag and the
+        # fp32-MFMA kernels -- enqueued behind the split ones, predicated on that flag -- redo the iteration.  No host sync.
+        self.range_flag = None
+        if cfg.mlp_dtype == nat.MLP_F16X3 and getattr(solver, 'range_guard', True):
+            self.range_flag = torch.zeros(4, dtype=torch.int32, device=dev)
+            cfg.range_flag = nat.ptr(self.range_flag)
+            if nat.query_rc(cfg)[0] != 0:                # (the fp32-MFMA tables of this instance do not fit the LDS: unguarded)
+                cfg.range_flag, self.range_flag = None, None
         self.pad = shapes.ParamPad(solver.d, self.H, self.d_pad, self.H_pad, dev)
         pad = self.pad
         cfg.drift = nat.ptr(dev_f32(pad.drift_or_sigma(spec['drift'][1]))) if spec['drift'][1] is not None else None
@@ -651,6 +660,10 @@ class HjbNativePlan:
             nat.check(lib.psp_adam_step(nat.ptr(self.y0_param), nat.ptr(self.y0_grad), nat.ptr(self.y0_m),
                                         nat.ptr(self.y0_v), 1, self.step, ylr, yb1, yb2, yeps, st),
                       'psp_adam_step(Y_0)')
+
+    def range_fallbacks(self):
+        """Iterations (chunk launches) the range guard sent to the fp32-MFMA kernels so far; one device read."""
+        return int(self.range_flag[1].item()) if self.range_flag is not None else 0
 
     def export_optimizer_state(self):
         """Called by Solver._train_native when training returns: the nets' own optimisers see the moments this plan kept."""

@@ -65,7 +65,7 @@ class Solver:
                  plot_trajectories=None, seed=42, save_results=False, u_l2_error_flag=True,
                  log_gradient=False, burgers_drift=False, verbose=True,
                  device=None, backend='auto', noise='reference', widths=(30, 30), mlp_dtype='auto',
-                 path_budget_bytes=None, path_chunks=None, chunk_mode='auto', use_graph='auto'):
+                 path_budget_bytes=None, path_chunks=None, chunk_mode='auto', use_graph='auto', range_guard=True):
         self.problem, self.name = problem, name
         self.date = date.today().strftime('%Y-%m-%d')
         self.d, self.T = problem.d, problem.T
@@ -84,6 +84,12 @@ class Solver:
         # same parity bounds, ~1.8x faster at large K), 'auto' (f16x3 where it exists and pays, plan_native.py); 'bf16': control-net
         # products of the forward rollout on bf16 MFMA (opt-in, own tolerance)
         self.mlp_dtype = mlp_dtype
+        # split-product kernels: operands must stay below 65504 (f16 range).  range_guard=True (default) lets the library redo an
+        # iteration on the fp32-MFMA kernels when an operand left that range (device-side flag + predicated launches, no host
+        # sync; include/psp.h: range_flag), so that 'auto' / 'f16x3' never return a non-finite loss where 'fp32' is finite.
+        # self.range_fallback_iterations counts them after train()
+        self.range_guard = bool(range_guard)
+        self.range_fallback_iterations = 0
         # native plan: HBM budget of the path store kept for the backward pass (None: a third of the HBM); a larger store is
         # processed in K-chunks (plan_native.py).  path_chunks forces a chunk count; chunk_mode 'auto' | 'two_gradient' | 'recompute'
         self.path_budget_bytes, self.path_chunks, self.chunk_mode = path_budget_bytes, path_chunks, chunk_mode
@@ -269,7 +275,7 @@ class Solver:
         nets = nets + tuple(id(v) for v in getattr(self, 'y_n', []))
         return (nets, self.noise, self.K, self.N, float(self.delta_t_np), self.loss_method, self.approx_method,
                 self.time_approx, bool(self.learn_Y_0), bool(self.adaptive_forward_process), bool(self.detach_forward),
-                bool(self.random_X_0), bool(self.u_l2_error_flag), self.mlp_dtype, self.path_budget_bytes, self.path_chunks,
+                bool(self.random_X_0), bool(self.u_l2_error_flag), self.mlp_dtype, getattr(self, 'range_guard', True), self.path_budget_bytes, self.path_chunks,
                 self.chunk_mode, id(self.problem), id(self.y_0) if hasattr(self, 'y_0') else None)
 
     def _choose_plan(self):
@@ -354,12 +360,12 @@ class Solver:
             watch = ul2 is not None and self.early_stopping_time is not None and l > self.early_stopping_time
             if (self.verbose and l % self.print_every == 0) or l == self.L - 1 or watch:
                 vals = losses[done:l + 1].cpu().tolist()          # one sync per block
-                if getattr(plan, 'matrix_mode', 'fp32') == 'f16x3' and not getattr(self, '_warned_range', False) \
-                        and not all(math.isfinite(v) for v in vals):
+                if getattr(plan, 'matrix_mode', 'fp32') == 'f16x3' and getattr(plan, 'range_flag', None) is None \
+                        and not getattr(self, '_warned_range', False) and not all(math.isfinite(v) for v in vals):
                     import warnings
                     self._warned_range = True
-                    warnings.warn("non-finite loss on the split-product kernels: their operands must stay below 65504 in magnitude "
-                                  "(f16 range); if Solver(mlp_dtype='fp32') stays finite on this problem, use it")
+                    warnings.warn("non-finite loss on the UNGUARDED split-product kernels (range_guard=False): their operands must "
+                                  "stay below 65504 in magnitude (f16 range); use range_guard=True or mlp_dtype='fp32'")
                 now = time.time()
                 per = (now - t_block) / max(1, l + 1 - done)
                 self.loss_log += vals
@@ -377,6 +383,8 @@ class Solver:
                     recent = self.u_L2_loss[-self.early_stopping_time:]
                     if np.std(recent) / self.u_L2_loss[-1] < 0.02:
                         break
+        if hasattr(plan, 'range_fallbacks'):
+            self.range_fallback_iterations = plan.range_fallbacks()
         if hasattr(plan, 'export_optimizer_state'):
             plan.export_optimizer_state()       # phi.optim carries the Adam state, as in the reference (function_space.py:185)
 

@@ -130,10 +130,12 @@ def test_ragged_last_chunk_on_another_forward_kernel():
             q = nat.query(c)
             assert q.fwd_partial_bytes <= plan.fp_stride * 8 and q.grad_partial_bytes <= plan.grad_partial.numel() * 4
             assert q.path_bytes <= plan.path.numel() * 4
-        assert float((plan.D - bplan.D).abs().max()) <= 2e-6 * max(1.0, float(bplan.D.abs().max()))
-        assert math.isclose(m.loss_log[0], base.loss_log[0], rel_tol=1e-6), (m.loss_log, base.loss_log)
+        # chunk 0 runs the kernel of the resident launch (bit-identical), chunk 1 another one: equal to summation order
+        assert torch.equal(plan.D[:1040], bplan.D[:1040])
+        assert float((plan.D - bplan.D).abs().max()) <= 5e-6 * max(1.0, float(bplan.D.abs().max()))
+        assert math.isclose(m.loss_log[0], base.loss_log[0], rel_tol=2e-6), (m.loss_log, base.loss_log)
         err = float((plan.grad - bplan.grad).abs().max()) / float(bplan.grad.abs().max())
-        assert err <= 5e-6, (mode, err)
+        assert err <= 2e-5, (mode, err)
 
 
 def test_two_gradient_is_shift_invariant_under_a_large_mean():
