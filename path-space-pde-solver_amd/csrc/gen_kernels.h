@@ -118,6 +118,11 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     o[0] = fmaxf(v[0], 0.f); o[1] = fmaxf(v[1], 0.f); o[2] = fmaxf(v[2], 0.f); o[3] = fmaxf(v[3], 0.f);
     return o;
 }
+template <int MODE>
+__device__ __forceinline__ f32x4 relu4m(f32x4 v) {
+    if constexpr (MODE == 2) return relu4n(v);
+    else return relu4(v);
+}
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
     acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc);
     acc = fmaf(a[2], b[2], acc); acc = fmaf(a[3], b[3], acc);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             for (int m = 0; m < HB; ++m) r1[m] = vb1[m * 4];
             gen_gemm<MODE, HB, KSI, DBI>(r1, lds + oW1f, X, lane);
 #pragma unroll
-            for (int m = 0; m < HB; ++m) r1[m] = relu4(r1[m]);
+            for (int m = 0; m < HB; ++m) r1[m] = relu4m<MODE>(r1[m]);
             f32x4 h1[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = r1[m] * r1[m];
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             gen_gemm<MODE, HB, KSI, DBI>(r2, lds + oW2xf, X, lane);
             gen_gemm<MODE, HB, KSH, HB>(r2, lds + oW2hf, h1, lane);
 #pragma unroll
-            for (int m = 0; m < HB; ++m) r2[m] = relu4(r2[m]);
+            for (int m = 0; m < HB; ++m) r2[m] = relu4m<MODE>(r2[m]);
             float v = 0.f;
 #pragma unroll
             for (int b = 0; b < DBI; ++b) v = dot4(vw3x[b * 4], X[b], v);

@@ -494,6 +494,15 @@ __device__ __forceinline__ f32x4 tanh4(f32x4 v) {
     return o;
 }
 
+// NaN-propagating relu for the split-product instances: v_max_f32 returns the non-NaN operand, which would turn the NaN of an
+// operand beyond the f16 range (inf - inf between the main and the correction chain) into a clean 0 and hide the overflow from
+// the range guard (include/psp.h: range_flag).  One compare + select instead of one max.
+__device__ __forceinline__ f32x4 relu4n(f32x4 v) {
+    f32x4 o;
+    o[0] = v[0] < 0.f ? 0.f : v[0]; o[1] = v[1] < 0.f ? 0.f : v[1]; o[2] = v[2] < 0.f ? 0.f : v[2]; o[3] = v[3] < 0.f ? 0.f : v[3];
+    return o;
+}
+
 // Geometry of one (D, H) instantiation
 template <int D, int H>
 struct Geo {

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
             };
 #pragma unroll
             for (int m = 0; m < HB; ++m) {
-                const f32x4 r = relu4d(z12[m]);
+                const f32x4 r = X3 ? relu4n(z12[m]) : relu4d(z12[m]);       // (X3: NaN-propagating, gen_kernels.h)
                 h1[m] = r * r;
                 if (store_r) put_r(da.pr1, m, r);
                 if (store_img) {
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 else gemm_regs<HB, 4 * HB, HB>(z2, Ts + W::tW2h, h1, lane);
 #pragma unroll
                 for (int m = 0; m < HB; ++m) {
-                    const f32x4 r = relu4d(z2[m]);
+                    const f32x4 r = X3 ? relu4n(z2[m]) : relu4d(z2[m]);
                     h2[m] = r * r;
                     if (store_r) put_r(da.pr2, m, r);
                     if (store_img) {
