@@ -16,16 +16,27 @@ Weak-scaling workloads keep the per-GPU trajectory count, strong-scaling ones (K
 workload) split a fixed global batch; `value` is always the whole-job aggregate.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- dominant kernel, from HIP events recorded on the launch stream inside the timed
-                  region.  `frac` = max(MFMA term, HBM term).  MFMA term = MINIMAL algorithmic flops
-                  (m = 2 dense d x d products per step: A x and B (c dt + xi sqrt dt) -- the
-                  reference's separate B c and B xi products are one product algebraically) over
-                  the kernel time against the fp32 MFMA peak (157.3 TFLOP/s); `frac_issued` counts
-                  the MFMA instructions the kernel really issues (incl. zero padding to 16-blocks);
-                  `frac_survey_m3` is SURVEY 8d's convention (m = 3), kept as a labelled extra.
-                  bf16 workloads are priced against the flop-weighted blend of the bf16 and fp32
-                  peaks, so no line can exceed 1.
-  collectives  -- N > 1: mean HIP-event time of the two all-reduces per iteration.
+  roofline     -- dominant kernel (the longer of the two rollout kernels), timed with HIP events recorded on the launch
+                  stream inside the timed region.  Two terms, both from SURVEY.md 8(d)'s ALGORITHMIC work per
+                  trajectory-timestep x the units one launch processes / the kernel's mean duration:
+                    hbm_term   frac_alg_bytes = (8 d + 8) B per unit against 8 TB/s (the state streamed once per step);
+                               next to it frac_path_store prices the bytes this design really moves (the path store the
+                               forward writes and the backward reads) -- arithmetically right, but those bytes are the
+                               design's own, not the algorithm's;
+                    mfma_term  minimal algorithmic flops (m = 2 dense d x d products per step) against the peak of the
+                               pipe the kernel computes on: 157.3 TFLOP/s for v_mfma_f32_16x16x4_f32 kernels, 2500 / 3 =
+                               833 TFLOP/s for the split-product kernels (three f16 flops per algorithmic fp32 flop), a
+                               flop-weighted blend for bf16 workloads; frac_issued prices the instructions really issued.
+                  `bound` / `achieved` / `peak` / `frac` are those of the LARGER term ("hbm" -> the algorithmic-bytes
+                  term).  `binder` names what the kernel actually waits on when neither term exceeds 0.5 (e.g. "valu":
+                  SQ_INSTS_VALU per tile-step from the committed PMC passes, profiles/r3_counters.json); `traffic` = HBM
+                  bytes per launch from the same passes (2 x FETCH_SIZE + WRITE_SIZE, calibrated for gfx950).
+  also_sustained -- the same iteration run back to back for >= 3 s after the timed region (the timed region of the
+                  default run is only steps x 4 ms): steady-state rate, clocks and power settled.
+  collectives  -- N > 1: HIP-event time of the two all-reduces per iteration and their share of the step.
+  parity_vs_1rank -- N > 1: before timing, iteration 0 of a 16384-trajectories-per-rank batch on the N ranks against the
+                  same global batch on rank 0 alone (Philox noise is indexed by the global trajectory: equal to summation
+                  order); rccl_ranks_seen = what a SUM all-reduce of ones returns.
   cpu_baseline -- the CPU oracle (a port of the reference algorithm, oracle/) timed on the host
                   cores of this box on bounded samples (configs[0], configs[1] and a K = 4096 cut
                   of the workload; all cores and 1 thread).  Rank 0, N = 1 only.
@@ -323,6 +334,50 @@ def check_c_abi_allreduce(psp, dist, rank, world, dev, rehearsal):
         return {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
 
 
+def parity_vs_one_rank(psp, sharding, dist, rank, world, dev, w, outer):
+    """N > 1, before anything is timed: iteration 0 of a batch of 16384 trajectories per rank on the N ranks (sharded plan, both
+    collectives) against the SAME global batch on rank 0 alone.  Philox noise is indexed by the global trajectory id, so D is
+    the same per trajectory and loss / gradient agree to summation order.  Also returns what a SUM all-reduce of ones
+    returns on this backend (`rccl_ranks_seen`)."""
+    if outer:
+        return None
+    Kc = 16384 * world
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+
+    def run(single):
+        sharding.force_single = single
+        try:
+            prob = psp.LLGC(d=w["d"], off_diag=w["off_diag"], T=w["T"], seed=42, device=dev)
+            m = psp.Solver("bench-parity-%d" % single, prob, lr=1e-3, L=1, K=Kc, delta_t=w["dt"], loss_method="log-variance",
+                           time_approx="inner", adaptive_forward_process=True, detach_forward=True, u_l2_error_flag=False,
+                           verbose=False, seed=42, device=dev, backend="native", noise="philox", widths=(w["H"], w["H"]),
+                           mlp_dtype=w.get("mlp", "auto"))
+            pl = m._choose_plan()
+            out = torch.zeros(1, dtype=torch.float32, device=dev)
+            pl.iteration(0, out)
+            torch.cuda.synchronize()
+            return pl.D.clone(), float(out[0].item()), pl.grad.clone()
+        finally:
+            sharding.force_single = False
+
+    D_s, loss_s, g_s = run(False)
+    parts = [torch.empty_like(D_s) for _ in range(world)]
+    dist.all_gather(parts, D_s)
+    res = None
+    if rank == 0:
+        D_1, loss_1, g_1 = run(True)
+        D_all = torch.cat(parts)
+        res = {"K_global": Kc, "ranks": world, "rccl_ranks_seen": int(round(float(ones.item()))),
+               "D_max_abs_diff": float((D_all - D_1).abs().max()), "D_max_abs": float(D_1.abs().max()),
+               "loss_rel_diff": abs(loss_s - loss_1) / abs(loss_1),
+               "grad_max_rel_diff": float((g_s - g_1).abs().max()) / float(g_1.abs().max()),
+               "tolerance": "summation order: loss 1e-6, gradient 1e-5 x max|g|"}
+        res["ok"] = bool(res["loss_rel_diff"] <= 1e-6 and res["grad_max_rel_diff"] <= 1e-5 and res["rccl_ranks_seen"] == world)
+    dist.barrier()
+    return res
+
+
 def collective_summary(sharding, steps):
     """Mean HIP-event time per iteration of the all-reduces recorded by sharding.allreduce_sum_ (N > 1 only)."""
     evs = sharding.coll_events or []
@@ -452,9 +507,52 @@ def mfma_roofline(fl2, fl3, issued, units, tiles_steps, ms, bf16_mlp, which):
                 frac_survey_m3=(fl3[which] * units / t / 1e12) / peak)
 
 
+def load_counters(workload, kernel):
+    """Committed PMC means per launch of `kernel` in `workload` (profiles/r3_counters.json, written by
+    tools/r3/make_counters_json.py from the separate --pmc passes of tools/pmc_passes.sh), or {}."""
+    cpath = os.path.join(ROOT, "profiles", "r3_counters.json")
+    if not os.path.exists(cpath):
+        return {}
+    return json.load(open(cpath)).get(workload, {}).get(kernel, {}) or {}
+
+
+def binder_of(mf_frac, hbm_alg_frac, hbm_store_frac, counters, tiles_steps):
+    """What the dominant kernel waits on.  A term above 0.5 names itself; otherwise the committed counters decide: the share
+    of wave cycles spent issuing / waiting on a busy pipe against waiting on memory, and the VALU instruction count per
+    tile-step next to the MFMA count."""
+    out = {"name": None}
+    if counters:
+        valu, mfma = counters.get("SQ_INSTS_VALU"), counters.get("SQ_INSTS_MFMA")
+        wc = counters.get("SQ_WAVE_CYCLES")
+        if valu and tiles_steps:
+            out["valu_insts_per_tile_step"] = valu / tiles_steps
+        if mfma and tiles_steps:
+            out["mfma_insts_per_tile_step"] = mfma / tiles_steps
+        if wc:
+            for k_, n_ in (("SQ_ACTIVE_INST_ANY", "issuing"), ("SQ_WAIT_INST_ANY", "waiting_on_busy_pipe"), ("SQ_WAIT_ANY", "waiting_on_memory_or_barrier")):
+                if counters.get(k_) is not None:
+                    out["wave_cycles_" + n_] = counters[k_] / wc
+        bc = counters.get("SQ_BUSY_CYCLES")
+        if counters.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and counters.get("GRBM_GUI_ACTIVE"):
+            out["matrix_pipe_busy"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"] / (counters["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    if max(mf_frac, hbm_alg_frac) >= 0.5:
+        out["name"] = "mfma" if mf_frac >= hbm_alg_frac else "hbm"
+    elif hbm_store_frac >= 0.5:
+        out["name"] = "hbm (path store: the design's own bytes, 1.7x the algorithmic ones)"
+    elif out.get("valu_insts_per_tile_step") and out.get("mfma_insts_per_tile_step") and \
+            out["valu_insts_per_tile_step"] > 3.0 * out["mfma_insts_per_tile_step"]:
+        out["name"] = "valu"
+    else:
+        out["name"] = "latency / issue (no single unit above half of its peak)"
+    return out
+
+
 def load_traffic(workload, kernel):
     """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: FETCH_SIZE already carries the gfx950
     correction for the stream widths this kernel uses, as calibrated by tools/fetch_calibrate)."""
+    c = load_counters(workload, kernel)
+    if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None:
+        return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None
@@ -473,6 +571,8 @@ def main():
                     choices=sorted(WORKLOADS) + sorted(GENERAL_WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] side measurement")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 3 s steady-state leg")
+    ap.add_argument("--sustain-s", type=float, default=3.0)
     args = ap.parse_args()
     spawn_ranks_if_needed(args)                          # N > 1 without a launcher: children do the work
 
@@ -509,6 +609,7 @@ def main():
         model.update_Phis()
     plan = model._choose_plan()
     assert model.plan_name == "native"
+    parity = parity_vs_one_rank(psp, sharding, dist, rank, world, dev, w, outer) if world > 1 else None
     N_t = model.N
     n_eager = 6                                          # eager iterations after the timed region (graph workloads only)
     losses = torch.zeros(total + n_eager, dtype=torch.float32, device=dev)
@@ -591,20 +692,31 @@ def main():
     # store: state stays on chip, the forward writes / the backward reads one block of register images per unit)
     path_B_unit = float(plan.sizes.path_bytes) / max(1, units_launch) if hasattr(plan, "sizes") else None
     step_s = elapsed / args.steps
-    hbm = {"bytes_per_unit_survey": 8 * w["d"] + 8, "bytes_per_unit_path_store": path_B_unit,
-           "kernel_GBps_path_store": (path_B_unit * units_launch / (dom_ms * 1e-3) / 1e9) if path_B_unit else None,
-           "peak_GBps": PEAK_HBM_GBS}
-    hbm["frac"] = (hbm["kernel_GBps_path_store"] or 0.0) / PEAK_HBM_GBS
-    bound = "mfma" if mf["frac"] >= hbm["frac"] else "hbm"
+    dom_s = dom_ms * 1e-3
+    alg_B_unit = 8 * w["d"] + 8
+    hbm = {"bytes_per_unit_alg": alg_B_unit, "achieved_GBps_alg": alg_B_unit * units_launch / dom_s / 1e9,
+           "bytes_per_unit_path_store": path_B_unit,
+           "achieved_GBps_path_store": (path_B_unit * units_launch / dom_s / 1e9) if path_B_unit else None,
+           "peak_GBps": PEAK_HBM_GBS, "achievable_GBps": 6300.0}
+    hbm["frac_alg_bytes"] = hbm["achieved_GBps_alg"] / PEAK_HBM_GBS
+    hbm["frac_path_store"] = (hbm["achieved_GBps_path_store"] or 0.0) / PEAK_HBM_GBS
+    hbm["frac"] = hbm["frac_alg_bytes"]
+    bound = "mfma" if mf["frac"] >= hbm["frac_alg_bytes"] else "hbm"
     value = K_global * N_t * args.steps / elapsed
     whole_tf = fl2["total"] * K_local * N_t / step_s / 1e12
+    counters = load_counters(args.workload, dom)
     roof = {"bound": bound, "kernel": dom,
-            "achieved": mf["achieved"] if bound == "mfma" else hbm["kernel_GBps_path_store"],
+            "achieved": mf["achieved"] if bound == "mfma" else hbm["achieved_GBps_alg"],
             "peak": mf["peak"] if bound == "mfma" else PEAK_HBM_GBS,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-            "frac": max(mf["frac"], hbm["frac"]),
+            "frac": max(mf["frac"], hbm["frac_alg_bytes"]),
             "traffic": load_traffic(args.workload, dom),
-            "convention": "minimal algorithmic flops (m = 2 dense d x d products per step) / HIP-event kernel time / peak",
+            "binder": binder_of(mf["frac"], hbm["frac_alg_bytes"], hbm["frac_path_store"], counters, tiles_steps),
+            "convention": ("SURVEY 8d algorithmic work per trajectory-timestep x units per launch / HIP-event kernel time / peak: "
+                           "bytes 8d+8 against 8 TB/s, minimal flops (m = 2 dense d x d products) against the peak of the pipe the "
+                           "kernel computes on (%s); frac = the larger of the two; hbm_term.frac_path_store prices the bytes the "
+                           "design really moves" % ("2500/3 TFLOP/s: split products, three f16 flops per fp32 flop" if x3 else
+                                                    ("bf16 / fp32 blend" if bf16_mlp else "157.3 TFLOP/s fp32 MFMA"))),
             "mfma_term": mf, "hbm_term": hbm,
             "alg_flops_per_traj_step": {k: fl2[k] for k in ("fwd_kernel", "bwd_kernel", "total")},
             "alg_flops_per_traj_step_survey_m3": {k: fl3[k] for k in ("fwd_kernel", "bwd_kernel", "total")},
@@ -614,12 +726,22 @@ def main():
             "units_per_launch": units_launch, "launches_per_step": n_chunks,
             "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
             "whole_step_tflops": whole_tf, "whole_step_frac_of_fp32_peak": whole_tf / PEAK_FP32_MFMA_TFLOPS}
+    # the other rollout kernel, same two terms (the iteration is the pair)
+    oth, oth_ms, oth_which = (fwd_name, fwd_ms, "fwd_kernel") if bwd_dominant else (bwd_name, bwd_ms, "bwd_kernel")
+    if oth_ms > 0:
+        oth_peak = mf["peak"] if not (x3 and oth_which == "bwd_kernel" and issued_x3 and issued_x3[1] is None) else PEAK_FP32_MFMA_TFLOPS
+        roof["other_kernel"] = {"kernel": oth, "ms": oth_ms,
+                                "frac_alg_bytes": alg_B_unit * units_launch / (oth_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                "frac_path_store": ((path_B_unit or 0.0) * units_launch / (oth_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
+                                "frac_mfma": fl2[oth_which] * units_launch / (oth_ms * 1e-3) / 1e12 / oth_peak,
+                                "traffic": load_traffic(args.workload, oth)}
     out = {
         "metric": "trajectory-timesteps/sec (K*N/s), d=%d HJB log-variance training iteration" % w["d"],
         "value": value, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * step_s, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "bf16 control-net products in the forward rollout, f32 elsewhere" if bf16_mlp else "f32",
+        "dtype": ("bf16 control-net products in the forward rollout, f32 elsewhere" if bf16_mlp else
+                  ("f32 (f16x3 split products: every matrix product as three f16 MFMAs, fp32 accumulate; state / sums fp32)" if x3 else "f32")),
         "data": "synthetic",
         "config": {"workload": args.workload, "problem": "LLGC", "d": w["d"], "K_per_gpu": K_local,
                    "K_global": K_global, "N": N_t,
@@ -653,7 +775,28 @@ def main():
                                     "recompute: pass 1 re-runs the forward rollout without the path store to obtain the global "
                                     "(sum D, sum D^2)") + "; value counts each trajectory-timestep once"}
     if coll is not None:
+        coll["fraction_of_step"] = coll["per_step_ms"] / (1e3 * step_s)
         out["collectives"] = coll
+    if parity is not None:
+        out["parity_vs_1rank"] = parity
+        out["rccl_ranks_seen"] = parity.get("rccl_ranks_seen")
+    if getattr(plan, "range_flag", None) is not None:
+        out["config"]["range_guard"] = ("on: device flag + predicated fp32-MFMA twins of the split kernels (include/psp.h range_flag); "
+                                        "fallback iterations in this run: %d" % plan.range_fallbacks())
+    if world == 1 and not args.no_sustained and not graph:
+        # >= 3 s of back-to-back iterations (the timed region above is steps x ms_per_step, i.e. under 0.1 s by default)
+        n_s, t_s = 0, 0.0
+        plan.events = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while t_s < args.sustain_s:
+            for l in range(total + n_s, total + n_s + 50):
+                plan.iteration(l % losses.numel(), losses)
+            n_s += 50
+            torch.cuda.synchronize()
+            t_s = time.perf_counter() - t0
+        out["also_sustained"] = {"value": K_global * N_t * n_s / t_s, "unit": "trajectory-timesteps/s", "ms_per_step": 1e3 * t_s / n_s,
+                                 "steps": n_s, "seconds": t_s, "note": "same plan, iterations back to back after the timed region"}
     if world == 1 and args.workload == "hjb_llgc_d100_K65536_N100_h64" and not args.no_secondary:
         # BASELINE.json configs[1] (d=100, K=1024, N=50) measured in the same process, for readers who take
         # that as the quoted configuration (64 16-trajectory tiles: runs on the feature-split forward kernel)
@@ -675,12 +818,18 @@ def main():
 def finish_ranks(psp, dist, rank, world, dev, rehearsal):
     """N > 1, AFTER rank 0 has printed the JSON line: cross-check of the C-ABI collective (psp_comm_* / psp_allreduce) against
     torch.distributed's all-reduce on every rank, reported as one line on rank 0's stderr.  A watchdog ends the process if the
-    second RCCL communicator does not come up within a minute -- the measurement is already out by then."""
+    second RCCL communicator does not come up within a minute (exit status 3 and a line on stderr: a hung check must not
+    read as success) -- the measurement is already out by then."""
     if dist is None:
         return
     if not rehearsal and os.environ.get("PSP_BENCH_CABI_CHECK", "1") == "1":
         import threading
-        dog = threading.Timer(60.0, lambda: os._exit(0))
+        def bark():
+            sys.stderr.write("bench.py: the C-ABI RCCL cross-check (second communicator) did not finish within 60 s on rank %d; "
+                             "the JSON line above is complete, exiting with status 3\n" % rank)
+            sys.stderr.flush()
+            os._exit(3)
+        dog = threading.Timer(60.0, bark)
         dog.daemon = True
         dog.start()
         res = check_c_abi_allreduce(psp, dist, rank, world, dev, rehearsal)
@@ -741,34 +890,59 @@ def main_general(args, psp, sharding):
     achieved = dom_fl * units / (dom_ms * 1e-3) / 1e12
     path_B = float(plan.sizes.path_bytes) / ((w["N"] + 1) * w["K"]) if hasattr(plan, "sizes") else None
     hbm_gbps = (float(plan.sizes.path_bytes) / (dom_ms * 1e-3) / 1e9) if hasattr(plan, "sizes") else 0.0
-    mf_frac, hbm_frac = achieved / peak, hbm_gbps / PEAK_HBM_GBS
+    alg_B = 8 * w["d"] + 8                                       # state streamed once per step
+    hbm_alg_gbps = alg_B * units / (dom_ms * 1e-3) / 1e9
+    mf_frac, hbm_frac, hbm_store_frac = achieved / peak, hbm_alg_gbps / PEAK_HBM_GBS, hbm_gbps / PEAK_HBM_GBS
     bound = "mfma" if mf_frac >= hbm_frac else "hbm"
+    counters = load_counters(args.workload, dom)
     if rank == 0:
         out = {"metric": "active trajectory-timesteps/sec, d=100 %s loss training iteration" % w["loss"],
                "value": active / elapsed, "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
                "dtype": {"bf16": "bf16 MFMA operands in both rollout kernels, f32 state / accumulate / element-wise",
-                         "bf16_fwd": "bf16 MFMA operands in the forward rollout, f32 state / accumulate / backward"}.get(mlp, "f32"),
+                         "bf16_fwd": "bf16 MFMA operands in the forward rollout, f32 state / accumulate / backward"}.get(
+                             mlp, "f32 (f16x3 split products: every matrix product as three f16 MFMAs, fp32 accumulate)" if x3 else "f32"),
                "data": "synthetic",
                "config": {"workload": args.workload, "problem": "DoubleWell_multidim_for_general_solver",
                           "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%d-%d-1" % (w["d"] + 1, w["H"], w["H"]),
                           "loss": w["loss"], "active_fraction": active / (w["K"] * world * w["N"] * args.steps)},
                "roofline": {"bound": bound, "kernel": dom,
-                            "achieved": achieved if bound == "mfma" else hbm_gbps,
+                            "achieved": achieved if bound == "mfma" else hbm_alg_gbps,
                             "peak": peak if bound == "mfma" else PEAK_HBM_GBS,
                             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                             "frac": max(mf_frac, hbm_frac),
                             "traffic": load_traffic(args.workload, dom),
+                            "binder": binder_of(mf_frac, hbm_frac, hbm_store_frac, counters, (w["K"] // 16) * (w["N"] + 1)),
+                            "convention": "algorithmic work per launched trajectory-timestep x units per launch / HIP-event kernel time / "
+                                          "peak of the pipe the kernel computes on (%s); hbm_term.frac_path_store prices the design's own bytes"
+                                          % ("2500/3 TFLOP/s split products" if x3 else ("2500 TFLOP/s bf16" if on_bf16 else "157.3 TFLOP/s fp32 MFMA")),
                             "mfma_term": {"achieved": achieved, "peak": peak, "frac": mf_frac},
-                            "hbm_term": {"bytes_per_sample_slot_path_store": path_B, "kernel_GBps_path_store": hbm_gbps,
-                                         "peak_GBps": PEAK_HBM_GBS, "frac": hbm_frac},
+                            "hbm_term": {"bytes_per_unit_alg": alg_B, "achieved_GBps_alg": hbm_alg_gbps, "frac_alg_bytes": hbm_frac,
+                                         "bytes_per_sample_slot_path_store": path_B, "achieved_GBps_path_store": hbm_gbps,
+                                         "frac_path_store": hbm_store_frac, "peak_GBps": PEAK_HBM_GBS, "frac": hbm_frac},
                             "alg_flops_per_launched_unit": {"value_net_F": F, "fwd_kernel": 3 * F, "bwd_kernel": 3 * F},
                             "units_per_launch": units, "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms},
                "launched_units_per_s": w["K"] * world * w["N"] * args.steps / elapsed,
                "loss_first_last": [float(losses[0]), float(losses[-1])]}
         if coll is not None:
+            coll["fraction_of_step"] = coll["per_step_ms"] / (1e3 * elapsed / args.steps)
             out["collectives"] = coll
+        if getattr(plan, "range_flag", None) is not None:
+            out["config"]["range_guard"] = "on (include/psp.h range_flag); fallback iterations in this run: %d" % plan.range_fallbacks()
+        if world == 1 and not args.no_sustained:
+            n_s, t_s, c_s = 0, 0.0, []
+            plan.events = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            while t_s < args.sustain_s:
+                for l in range(total + n_s, total + n_s + 20):
+                    c_s.append(plan.iteration(l)[1])
+                n_s += 20
+                torch.cuda.synchronize()
+                t_s = time.perf_counter() - t0
+            out["also_sustained"] = {"value": float(torch.stack(c_s).sum().item()) / t_s, "unit": "trajectory-timesteps/s",
+                                     "ms_per_step": 1e3 * t_s / n_s, "steps": n_s, "seconds": t_s}
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

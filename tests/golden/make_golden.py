@@ -530,6 +530,13 @@ CASES = [
     dict(name="box_d2_upper_elliptic_diffusion", family="elliptic",
          problem=dict(kind="QuadraticOnBox", kwargs=dict(d=2, X_l=-1.0, X_r=0.6, one_boundary=True, parabolic=False, quad_h=False)),
          solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=64, K_boundary=20, loss_method="diffusion")),
+    # round 3: the d = 100 instance BASELINE configs[2] names (gen_*<100,64>: fp32, split-product and bf16 modes under pytest)
+    dict(name="dwgen_d100_h64_diffusion", family="general",
+         problem=dict(kind="DoubleWell_multidim_for_general_solver",
+                      kwargs=dict(d=100, d_1=50, d_2=50, T=0.3, eta=1, kappa=1, modus="HJB")),
+         solver=dict(seed=42, delta_t=0.01, N=5, lr=0.001, L=3, K=64, K_boundary=16,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
+         net=dict(arch=[64, 64], seed=42)),
     dict(name="heat_d6_diffusion", family="general",
          problem=dict(kind="HeatEquation", kwargs=dict(d=6, T=0.5, seed=42)),
          solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=72, K_boundary=16,
@@ -555,9 +562,13 @@ def main():
             json.dump(rec, fh, indent=1)
         index["cases"].append(case["name"])
         print("   loss_log", res["loss_log"])
-    if not only:
-        with open(os.path.join(OUT, "index.json"), "w") as fh:
-            json.dump(index, fh, indent=1)
+    if only:                                  # a partial run: keep the index, add what is new
+        with open(os.path.join(OUT, "index.json")) as fh:
+            old = json.load(fh)
+        old["cases"] += [c for c in index["cases"] if c not in old["cases"]]
+        index = old
+    with open(os.path.join(OUT, "index.json"), "w") as fh:
+        json.dump(index, fh, indent=1)
 
 
 if __name__ == "__main__":

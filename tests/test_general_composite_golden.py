@@ -9,7 +9,8 @@ from conftest import load_golden
 from util_cases import psp
 
 CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
-         "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde"]
+         "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde",
+         "dwgen_d100_h64_diffusion"]   # the exact (100, 64) instance of BASELINE configs[2]
 
 
 BOUNDED = ["expsphere_d4_diffusion_dirichlet", "expsphere_d12_h40_bsde_dirichlet", "expsphere_d3_diffusion_neumann",

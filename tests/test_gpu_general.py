@@ -11,7 +11,8 @@ from util_cases import orc, psp
 
 pytestmark = pytest.mark.gpu
 CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
-         "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde"]
+         "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde",
+         "dwgen_d100_h64_diffusion"]   # the exact (100, 64) instance of BASELINE configs[2]
 
 
 def dev():

@@ -59,7 +59,8 @@ def test_bf16_forward_products_track_the_fp32_kernels():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_golden
     from test_gpu_general import build
-    for name in ("dwgen_d10_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde", "heat_d6_diffusion"):
+    for name in ("dwgen_d10_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde", "heat_d6_diffusion",
+                 "dwgen_d100_h64_diffusion"):           # gen_*<100, 64, bf16>: the instances BASELINE configs[2] names
         rec = load_golden(name)
         res = {}
         for dt in ("fp32", "bf16_fwd", "bf16"):

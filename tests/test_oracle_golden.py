@@ -23,7 +23,8 @@ SOLVER_CASES = ["lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "ll
                 "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive", "lqgc_d2_outer",
                 "lqgc_d2_variance", "lqgc_d2_variance_learn_y0", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
 GENERAL_CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
-                 "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde"]
+                 "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde",
+         "dwgen_d100_h64_diffusion"]   # the exact (100, 64) instance of BASELINE configs[2]
 
 
 def _same_build(rec):

@@ -16,7 +16,7 @@ for C in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ
     i=$((i + 1))
     rm -rf /tmp/pmc_${W}_$i
     (cd /tmp && rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_${W}_$i -o run --output-format csv -- \
-        python3 "$ROOT/bench.py" --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/${W}_pass$i.err") || exit 1
+        python3 "$ROOT/bench.py" --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-sustained > /dev/null 2> "$OUT/${W}_pass$i.err") || exit 1
     F=$(find /tmp/pmc_${W}_$i -name "*counter_collection.csv" | head -1)
     python3 - "$F" >> "$OUT/${W}_summary.txt" <<'PY'
 import csv, sys, collections

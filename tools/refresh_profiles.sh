@@ -24,7 +24,7 @@ for W in $WL; do
     rm -rf /tmp/prof_$W
     PSTEPS=$STEPS; [ $PSTEPS -gt 40 ] && PSTEPS=40
     (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$W -o run --output-format csv -- \
-        python3 "$ROOT/bench.py" --workload $W --steps $PSTEPS --warmup $WARM --no-cpu-baseline --no-secondary > /dev/null 2> "$OUT/${W}_prof.err") || { echo "profile $W failed"; tail -3 "$OUT/${W}_prof.err"; exit 1; }
+        python3 "$ROOT/bench.py" --workload $W --steps $PSTEPS --warmup $WARM --no-cpu-baseline --no-secondary --no-sustained > /dev/null 2> "$OUT/${W}_prof.err") || { echo "profile $W failed"; tail -3 "$OUT/${W}_prof.err"; exit 1; }
     F=$(find /tmp/prof_$W -name "*kernel_stats.csv" | head -1)
     [ -n "$F" ] && cp "$F" "$OUT/${W}_kernel_stats.csv" && echo "profile $W: $(head -3 "$OUT/${W}_kernel_stats.csv" | tail -2 | cut -c1-160)"
 done
