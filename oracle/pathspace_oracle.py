@@ -219,7 +219,22 @@ def problem_quadratic_on_box(d=2, T=0.5, X_l=-1.0, X_r=1.0, one_boundary=False, 
                                     boundary_type="Dirichlet", v_true=v_true))
 
 
+def problem_committor(d=2, alpha=1.0) -> OracleProblem:
+    """Committor between two concentric spheres (problems.py:1546-1579): b = 0, sigma = I, h = 0, boundary data 1 on the outer
+    and 0 on the inner sphere, radii a = 1 and c = 2."""
+    a, c = 1.0, 2.0                                                  # :1549-1550
+    B = torch.eye(d)                                                 # :1552
+    r = lambda x: torch.sqrt(torch.sum(x ** 2, 1))
+    v_true = lambda x: ((a ** 2 - r(x) ** (2 - d) * a ** d) / (a ** 2 - c ** (2 - d) * a ** d))     # :1577-1579
+    return OracleProblem(kind="Committor", d=d, T=None, X_0=torch.zeros(d), B=B, b=lambda x: torch.zeros(x.shape),
+                         sigma=lambda x: B, h=lambda x, y, z: torch.zeros(x.shape[0]),                # :1571-1572
+                         f=lambda x, t=None: torch.zeros(x.shape[0]), g=lambda x: (r(x) > a).float(),  # :1565-1569
+                         extra=dict(boundary="two_spheres", boundary_distance_1=a, boundary_distance_2=c,
+                                    boundary_type="Dirichlet", v_true=v_true))
+
+
 PROBLEMS = {
+    "Committor": problem_committor,
     "ExponentialOnSphere": problem_exp_sphere, "ExponentialOnBallNonlinear": problem_exp_ball_nonlinear,
     "ExponentialOnBallNonlinearSin": problem_exp_ball_nonlinear_sin,
     "ExponentialOnSphereNonlinearParabolic": problem_exp_sphere_nonlinear_parabolic,
@@ -230,8 +245,21 @@ PROBLEMS = {
 }
 
 
+_DOMAIN_ATTRS = ("boundary", "boundary_distance", "boundary_distance_1", "boundary_distance_2", "X_corner", "X_l", "X_r")
+
+
 def make_problem(kind: str, **kwargs) -> OracleProblem:
-    return PROBLEMS[kind](**kwargs)
+    """Domain attributes a caller sets on the problem INSTANCE (problem.boundary = 'two_spheres', ...) are accepted as
+    keywords next to the constructor's own and land in `extra`."""
+    over = {k: kwargs.pop(k) for k in list(kwargs) if k in _DOMAIN_ATTRS and k not in _ctor_args(PROBLEMS[kind])}
+    pb = PROBLEMS[kind](**kwargs)
+    pb.extra.update(over)
+    return pb
+
+
+def _ctor_args(fn):
+    import inspect
+    return set(inspect.signature(fn).parameters)
 
 
 # --------------------------------------------------------------------------------------
@@ -505,13 +533,23 @@ def sample_boundary(problem: OracleProblem, Kb: int):
     if ex["boundary"] == "sphere":
         Xb = torch.randn(Kb, d)                                      # :1021
         return ex["boundary_distance"] * Xb / torch.sqrt(torch.sum(Xb ** 2, 1)).unsqueeze(1)    # :1022
-    assert ex["boundary"] == "square"
     half = int(Kb / 2)
+    if ex["boundary"] == "two_spheres":
+        Xb = torch.randn(Kb, d)                                      # :1024 == :654
+        radii = torch.tensor([ex["boundary_distance_1"]] * half + [ex["boundary_distance_2"]] * half).unsqueeze(1)   # :1025-1026
+        return radii * Xb / torch.sqrt(torch.sum(Xb ** 2, 1)).unsqueeze(1)                        # :1027
+    assert ex["boundary"] in ("square", "square-corner")
     sel = np.concatenate([np.ones(half)[:, np.newaxis], np.zeros([half, d - 1])], 1)     # :1029
     np.apply_along_axis(np.random.shuffle, 1, sel)                   # :1030
     a = np.concatenate([sel, np.zeros([half, d])]).astype(bool)      # :1031
     b = np.concatenate([np.zeros([half, d]), sel]).astype(bool)      # :1032
     X_l, X_r = ex["X_l"], ex["X_r"]
+    if ex["boundary"] == "square-corner":
+        Xc = ex["X_corner"]
+        Xb = (X_r - Xc) * torch.rand(Kb, d) + Xc                     # :671
+        Xb[torch.tensor(a.astype(float)).bool()] = Xc                # :672
+        Xb[torch.tensor(b.astype(float)).bool()] = Xc                # :673
+        return Xb
     Xb = (X_r - X_l) * torch.rand(Kb, d) + X_l                       # :1033
     Xb[torch.tensor(a.astype(float)).bool()] = X_l                   # :1034
     Xb[torch.tensor(b.astype(float)).bool()] = X_r                   # :1035
@@ -531,6 +569,11 @@ def exit_test(problem: OracleProblem, X, X_prop, elliptic: bool):
             le = X_prop <= ex["X_r"]
             return torch.all(le, 1) if elliptic else torch.any(le, 1)            # :764 vs :1127
         return torch.all((X_prop >= ex["X_l"]) & (X_prop <= ex["X_r"]), 1)       # :1129
+    if ex["boundary"] == "two_spheres":                                         # :1122-1123 == :752-753 (X, not the proposal)
+        r = torch.sqrt(torch.sum(X ** 2, 1))
+        return (r > ex["boundary_distance_1"]) & (r < ex["boundary_distance_2"])
+    if ex["boundary"] == "square-corner":
+        return torch.any(X_prop <= ex["X_r"], 1)                                 # :759-760
     return torch.ones(X.shape[0]).bool()
 
 
@@ -545,7 +588,7 @@ def neumann_residual(V, Xb_in, g_val, d):
 
 def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=False):
     """Restates GeneralSolver.train for loss_method in {'diffusion','BSDE'} on
-    boundary in {'unbounded','unbounded_square','sphere','square'} (solver.py:1001-1206)."""
+    boundary in {'unbounded','unbounded_square','sphere','two_spheres','square'} (solver.py:1001-1206)."""
     if V is None:
         V = general_build(problem, cfg)
     dt32 = torch.tensor(cfg.delta_t)                                 # :950
@@ -569,6 +612,13 @@ def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=Fals
                 X = torch.randn(K, d)                                # :1045
                 X = problem.extra["boundary_distance"] * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) \
                     * (torch.rand(K).unsqueeze(1) ** (1 / d))        # :1046
+        elif bnd == "two_spheres":
+            X = torch.randn(cfg.K, d)                                # :1048 (K_original draws)
+            X = problem.extra["boundary_distance_2"] * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) \
+                * (torch.rand(cfg.K).unsqueeze(1) ** (1 / d))        # :1049
+            selection = torch.sqrt(torch.sum(X ** 2, 1)) > problem.extra["boundary_distance_1"]      # :1050
+            X = X[selection, :]                                      # :1051
+            K = int(torch.sum(selection))                            # :1052: the batch size follows the rejection step
         else:
             X_l, X_r = problem.extra["X_l"], problem.extra["X_r"]
             X = (X_r - X_l) * torch.rand(K, d) + X_l                 # :1056
@@ -628,8 +678,12 @@ def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=Fals
                 loss = loss + torch.mean((Y - problem.f(X)) ** 2)    # :1174
             elif btype == "Dirichlet":
                 loss = loss + torch.mean((Y - problem.g(X, t_n.squeeze())) ** 2)     # :1176
-            else:
-                raise NotImplementedError("BSDE loss with a Neumann boundary (solver.py:1177-1183) is not restated")
+            else:                                                    # 'Neumann', :1177-1183
+                T_selection = (t_n > (T - dt32)).squeeze()           # :1178
+                if torch.sum(T_selection) > 0:
+                    loss = loss + torch.mean((Y[T_selection] - problem.f(X[T_selection, :])) ** 2)   # :1181
+                if torch.sum(T_selection) < K:                       # :1182-1183: grad_V of the LAST executed step, final X, all K
+                    loss = loss + torch.mean((torch.sum(grad_V * X, 1) - torch.sum(problem.g(X, t_n.squeeze()) * X, 1)) ** 2)
         loss.backward()                                              # :1187
         if trace:
             tr["grads"] = [p.grad.detach().clone() for p in V.parameters()]
@@ -669,7 +723,8 @@ def elliptic_build(problem: OracleProblem, cfg: EllipticConfig, arch=None):
 
 
 def elliptic_train(problem: OracleProblem, cfg: EllipticConfig, V=None, trace=False):
-    """Restates EllipticSolver.train for loss_method in {'diffusion','BSDE'} on boundary in {'sphere','square'}."""
+    """Restates EllipticSolver.train for loss_method in {'diffusion','BSDE'} on boundary in {'sphere','two_spheres','square',
+    'square-corner'}."""
     if V is None:
         V = elliptic_build(problem, cfg)
     dt32 = torch.tensor(cfg.delta_t)                                 # :576
@@ -694,8 +749,23 @@ def elliptic_train(problem: OracleProblem, cfg: EllipticConfig, V=None, trace=Fa
                 X = torch.randn(K, d)                                # :700
                 X = ex["boundary_distance"] * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) \
                     * (torch.rand(K).unsqueeze(1) ** (1 / d))        # :701
+        elif ex["boundary"] == "two_spheres":
+            if cfg.uniform_square:
+                X = torch.rand(K, d) * 2 - 1                         # :703
+                X = X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * (
+                    torch.rand(K, d) * (ex["boundary_distance_2"] - ex["boundary_distance_1"]) + ex["boundary_distance_1"])   # :704
+            else:
+                X = torch.randn(cfg.K, d)                            # :706 (K_original draws)
+                X = ex["boundary_distance_2"] * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) \
+                    * (torch.rand(cfg.K).unsqueeze(1) ** (1 / d))    # :707
+                selection = torch.sqrt(torch.sum(X ** 2, 1)) > ex["boundary_distance_1"]     # :708
+                X = X[selection, :]                                  # :709
+                K = int(torch.sum(selection))                        # :710
         else:
-            X = (ex["X_r"] - ex["X_l"]) * torch.rand(K, d) + ex["X_l"]       # :713
+            X = (ex["X_r"] - ex["X_l"]) * torch.rand(K, d) + ex["X_l"]       # :713 / :707 ('square-corner')
+            if ex["boundary"] == "square-corner":
+                corner = torch.all(X > ex["X_corner"], 1)
+                X[corner, :] = -X[corner, :]                         # :708
         X = X.clone().requires_grad_(True)                           # :718
         Y = V(X).squeeze()                                           # :721
         stopped = torch.zeros(K).bool()                              # :724

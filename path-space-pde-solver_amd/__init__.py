@@ -13,7 +13,7 @@ from .function_space import (Affine, Constant, DenseNet, DenseNet_tanh, Linear, 
 from .problems import (LLGC, LQGC, AllenCahn, DoubleWell_multidim,  # noqa: F401
                        DoubleWell_multidim_for_general_solver, HeatEquation, ExponentialOnSphere,
                        ExponentialOnBallNonlinear, ExponentialOnBallNonlinearSin,
-                       ExponentialOnSphereNonlinearParabolic, QuadraticOnBox)
+                       ExponentialOnSphereNonlinearParabolic, QuadraticOnBox, Committor)
 from .solver import Solver  # noqa: F401
 from .general_solver import GeneralSolver, EllipticSolver  # noqa: F401
 from .plan_native import PlanUnsupported  # noqa: F401
@@ -23,6 +23,6 @@ from . import plan_native, plan_dense_native, plan_general_native, plan_value_na
 from .utilities import do_importance_sampling_me  # noqa: F401
 
 __all__ = ['Solver', 'GeneralSolver', 'EllipticSolver', 'ExponentialOnSphere', 'ExponentialOnBallNonlinear',
-           'ExponentialOnBallNonlinearSin', 'ExponentialOnSphereNonlinearParabolic', 'QuadraticOnBox', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
+           'ExponentialOnBallNonlinearSin', 'ExponentialOnSphereNonlinearParabolic', 'QuadraticOnBox', 'Committor', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
            'AllenCahn', 'HeatEquation', 'MySequential', 'DenseNet', 'DenseNet_tanh', 'SingleParam',
            'Constant', 'Linear', 'Affine', 'PlanUnsupported', 'native']

@@ -1,7 +1,7 @@
 """GeneralSolver / EllipticSolver: diffusion / BSDE loss for parabolic terminal-value problems and for elliptic
 exit-time problems -- API mirrors of the reference's ``solver.GeneralSolver`` (reference solver.py:934-1206) and
 ``solver.EllipticSolver`` (:560-826) for the hot-path part: ``loss_method in {'diffusion', 'BSDE'}`` on
-``boundary in {'unbounded', 'unbounded_square', 'sphere', 'square'}``.
+``boundary in {'unbounded', 'unbounded_square', 'sphere', 'two_spheres', 'square'}`` (+ 'square-corner' for the elliptic solver).
 
 One iteration (reference solver.py:1009-1201):
   sample X uniformly in the domain and t ~ U(0, T); Y = V(X, t);
@@ -17,8 +17,9 @@ Execution plans, resolved once in ``train()``:
   * native (plan_general_native, hand-written HIP): V is a DenseNet(d+1 -> 1) with two hidden
     layers, problem in the native catalogue, device is a GPU;
   * composite (this file): the reference op sequence with torch autograd on ``self.device``.
-The 'two_spheres' / 'square-corner' domains, PINN and the BSDE-2/3/4 variants are outside the scope of this
-build and raise NotImplementedError.
+The 'two_spheres' (committor problem: the batch size changes from iteration to iteration) and 'square-corner' domains, the
+BSDE loss with a Neumann boundary, ``loss_with_stopped``, ``sample_center`` and the ``K_test_log`` diagnostic run on the
+composite plan (never an error: SURVEY.md 8b); PINN and the BSDE-2/3/4 variants are outside the scope of this build.
 """
 import time
 import warnings
@@ -43,10 +44,19 @@ def sample_boundary(pb, Kb, d, dev):
         Xb = torch.randn(Kb, d).to(dev)
         return pb.boundary_distance * Xb / torch.sqrt(torch.sum(Xb ** 2, 1)).unsqueeze(1)
     half = int(Kb / 2)
+    if pb.boundary == 'two_spheres':                              # solver.py:1023-1027 == :653-657: inner half, outer half
+        Xb = torch.randn(Kb, d).to(dev)
+        radii = torch.tensor([pb.boundary_distance_1] * half + [pb.boundary_distance_2] * half).unsqueeze(1).to(dev)
+        return radii * Xb / torch.sqrt(torch.sum(Xb ** 2, 1)).unsqueeze(1)
     pick = np.concatenate([np.ones(half)[:, np.newaxis], np.zeros([half, d - 1])], 1)
     np.apply_along_axis(np.random.shuffle, 1, pick)
     lower = torch.tensor(np.concatenate([pick, np.zeros([half, d])]).astype(float)).bool()
     upper = torch.tensor(np.concatenate([np.zeros([half, d]), pick]).astype(float)).bool()
+    if pb.boundary == 'square-corner':                            # solver.py:666-673: one coordinate on the corner planes
+        Xb = (pb.X_r - pb.X_corner) * torch.rand(Kb, d).to(dev) + pb.X_corner
+        Xb[lower] = pb.X_corner
+        Xb[upper] = pb.X_corner
+        return Xb
     Xb = (pb.X_r - pb.X_l) * torch.rand(Kb, d).to(dev) + pb.X_l
     Xb[lower] = pb.X_r if pb.one_boundary else pb.X_l
     Xb[upper] = pb.X_r
@@ -62,6 +72,11 @@ def exit_test(pb, X, X_prop, elliptic):
             le = X_prop <= pb.X_r
             return torch.all(le, 1) if elliptic else torch.any(le, 1)
         return torch.all((X_prop >= pb.X_l) & (X_prop <= pb.X_r), 1)
+    if pb.boundary == 'two_spheres':                              # solver.py:1122-1123 == :752-753, the state BEFORE the move
+        r = torch.sqrt(torch.sum(X ** 2, 1))
+        return (r > pb.boundary_distance_1) & (r < pb.boundary_distance_2)
+    if pb.boundary == 'square-corner':                            # solver.py:759-760
+        return torch.any(X_prop <= pb.X_r, 1)
     return torch.ones(X.shape[0], dtype=torch.bool, device=X.device)
 
 
@@ -73,7 +88,7 @@ def neumann_residual(V, Xb_in, g_val, d):
     return torch.mean((torch.sum(grad_V[:, :d] * xb, 1) - torch.sum(g_val * xb, 1)) ** 2)
 
 
-_DOMAINS = ('unbounded', 'unbounded_square', 'sphere', 'square')
+_DOMAINS = ('unbounded', 'unbounded_square', 'sphere', 'two_spheres', 'square')
 
 
 class GeneralSolver:
@@ -139,13 +154,29 @@ class GeneralSolver:
             raise NotImplementedError("approx_method='Z' is outside this build's scope")
         if self.loss_method not in ('diffusion', 'BSDE'):
             raise NotImplementedError("loss_method %r: only 'diffusion' and 'BSDE' are built" % self.loss_method)
-        if self.problem.boundary not in _DOMAINS:
-            raise NotImplementedError("boundary %r is not built (sphere / square / unbounded are)" % self.problem.boundary)
-        if self.bounded and self.loss_method == 'BSDE' and getattr(self.problem, 'boundary_type', None) != 'Dirichlet' \
-                and not self.elliptic:
-            raise NotImplementedError('BSDE loss with a Neumann boundary (solver.py:1177-1183) is not built')
-        if self.sample_center or self.loss_with_stopped or self.solve_linear_L2_projection or self.K_test_log:
-            raise NotImplementedError('sample_center / loss_with_stopped / L2 projection / test logging are not built')
+        if self.problem.boundary not in _DOMAINS and not (self.elliptic and self.problem.boundary == 'square-corner'):
+            raise NotImplementedError("boundary %r is not built (sphere / two_spheres / square / unbounded are)" % self.problem.boundary)
+        if self.solve_linear_L2_projection:
+            raise NotImplementedError('solve_linear_L2_projection is not built')
+
+    def composite_only_reason(self):
+        """Why this configuration runs on the composite torch plan whatever the net / problem (None: the native plan may take
+        it).  These are the reference features the HIP kernels do not cover; none of them raises."""
+        pb = self.problem
+        if pb.boundary == 'two_spheres':
+            return "boundary 'two_spheres': the batch size changes every iteration (solver.py:1048-1052, :705-710)"
+        if pb.boundary == 'square-corner':
+            return "boundary 'square-corner' (solver.py:706-708, :759-760)"
+        btype = self.boundary_type if self.elliptic else getattr(pb, 'boundary_type', None)
+        if self.bounded and self.loss_method == 'BSDE' and btype == 'Neumann' and not self.elliptic:
+            return 'BSDE loss with a Neumann boundary (solver.py:1177-1183)'
+        if self.sample_center:
+            return 'sample_center (solver.py:1015-1017)'
+        if self.loss_with_stopped:
+            return 'loss_with_stopped (solver.py:1185-1186)'
+        if self.K_test_log:
+            return 'K_test_log: compute_test_error draws from the CPU generator every iteration (solver.py:1193-1197)'
+        return None
 
     @property
     def bounded(self):
@@ -162,7 +193,24 @@ class GeneralSolver:
                 X = torch.randn(K, d).to(dev)
                 radial = (torch.rand(K).unsqueeze(1) ** (1 / d)).to(dev)
             return pb.boundary_distance * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * radial
-        return (pb.X_r - pb.X_l) * torch.rand(K, d).to(dev) + pb.X_l
+        if pb.boundary == 'two_spheres':
+            if self.elliptic and self.uniform_square:               # solver.py:702-704 (a radius per COMPONENT, as written there)
+                X = torch.rand(K, d).to(dev) * 2 - 1
+                return X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * (
+                    torch.rand(K, d).to(dev) * (pb.boundary_distance_2 - pb.boundary_distance_1) + pb.boundary_distance_1)
+            # rejection from the outer ball: K_original draws, the points outside the inner ball stay and K follows
+            # (solver.py:1048-1052 == :706-710)
+            X = torch.randn(self.K_original, d).to(dev)
+            X = pb.boundary_distance_2 * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * (
+                torch.rand(self.K_original).unsqueeze(1) ** (1 / d)).to(dev)
+            keep = torch.sqrt(torch.sum(X ** 2, 1)) > pb.boundary_distance_1
+            self.K = int(torch.sum(keep))
+            return X[keep, :]
+        X = (pb.X_r - pb.X_l) * torch.rand(K, d).to(dev) + pb.X_l
+        if pb.boundary == 'square-corner':                          # solver.py:708: points of the cut-out corner are mirrored
+            corner = torch.all(X > pb.X_corner, 1)
+            X[corner, :] = -X[corner, :]
+        return X
 
     def boundary_residual(self, X_in_b, X_b, t_b):
         """Dirichlet / Neumann residual on the boundary batch (solver.py:1066-1074)."""
@@ -199,7 +247,9 @@ class GeneralSolver:
                 import plan_general_native as pgn
         except ImportError:
             pgn = None
-        reason = 'the native diffusion-loss plan is not built yet' if pgn is None else pgn.native_eligibility(self)
+        reason = self.composite_only_reason()
+        if reason is None:
+            reason = 'the native diffusion-loss plan is not built yet' if pgn is None else pgn.native_eligibility(self)
         if reason is None:
             self.plan_name = 'native'
             plan = getattr(self, '_gen_plan', None)
@@ -216,17 +266,32 @@ class GeneralSolver:
         self.plan_name, self.plan_reason = 'torch', reason
         return None
 
+    def _log_test_error(self, modus):
+        """K_test_log (solver.py:1193-1197 / :821-825): Monte-Carlo error of V on fresh points after the update."""
+        try:
+            from .utilities import compute_test_error
+        except ImportError:
+            from utilities import compute_test_error
+        l2, mae, mre = compute_test_error(self, self.problem, self.K_test_log, self.device, modus)
+        self.V_test_L2.append(l2)
+        self.V_test_abs.append(mae)
+        self.V_test_rel_abs.append(mre)
+
     def _train_composite(self):
         pb, dev, dt, sq = self.problem, self.device, self.delta_t, self.sq_delta_t
-        K, d, T = self.K, self.d, pb.T
+        d, T = self.d, pb.T
         a0, a1 = self.alpha[0], self.alpha[1]
         bounded = self.bounded
         for l in range(self.L):
             t_0 = time.time()
             loss = 0
+            if self.sample_center:                               # solver.py:1015-1017 (a one-dimensional probe point, as written there)
+                X_center = torch.zeros(1, 1).to(dev)
+                loss = loss + torch.mean((self.V(X_center).squeeze() - pb.v_true(X_center).squeeze()) ** 2)
             if bounded:
                 X_b = sample_boundary(pb, self.K_boundary, d, dev)
             X = self.sample_domain()
+            K = self.K                                            # 'two_spheres': the rejection step sets it every iteration
             if bounded:
                 t_b = torch.rand(self.K_boundary, 1).to(dev) * T
                 X_t_b = torch.cat([X_b, t_b], 1)
@@ -277,11 +342,28 @@ class GeneralSolver:
             if self.loss_method == 'BSDE':
                 if int(torch.sum(stopped)) != K:
                     print('Not all trajectories stopped.')
-                loss = loss + torch.mean((Y - (pb.g(X, t_n.squeeze()) if bounded else pb.f(X))) ** 2)
+                if not bounded:
+                    loss = loss + torch.mean((Y - pb.f(X)) ** 2)
+                elif pb.boundary_type == 'Dirichlet':
+                    loss = loss + torch.mean((Y - pb.g(X, t_n.squeeze())) ** 2)
+                elif pb.boundary_type == 'Neumann':
+                    # solver.py:1177-1183: trajectories that ran out of time are matched with f; the Neumann residual takes grad V of
+                    # the LAST executed step (the state before its move) against the final X, over ALL trajectories, as written there
+                    late = (t_n > (T - dt)).squeeze()
+                    if int(torch.sum(late)) > 0:
+                        loss = loss + torch.mean((Y[late] - pb.f(X[late, :])) ** 2)
+                    if int(torch.sum(late)) < K:
+                        loss = loss + torch.mean((torch.sum(grad_V * X, 1) - torch.sum(pb.g(X, t_n.squeeze()) * X, 1)) ** 2)
+                else:
+                    raise NotImplementedError('boundary_type %r' % pb.boundary_type)
+            if self.loss_with_stopped:                            # solver.py:1185-1186
+                loss = loss + torch.mean((Y[stopped] - pb.f(X[stopped, :])) ** 2)
             loss.backward()
             self.V.optim.step()
             self.loss_log.append(loss.item())
             self.V_L2_log.append(0.0)
+            if self.K_test_log is not None:
+                self._log_test_error('parabolic')
             self.times.append(time.time() - t_0)
             if self.verbose and l % self.print_every == 0:
                 print('%d - loss = %.4e, v L2 error = %.4e, n = %d, active: %d/%d, %.2f'
@@ -320,8 +402,8 @@ class EllipticSolver(GeneralSolver):
             self.Z = DenseNet(d_in=self.d, d_out=self.d, lr=lr, seed=seed).to(self.device)
 
     def _check_scope(self):
-        if self.problem.boundary not in ('sphere', 'square'):
-            raise NotImplementedError("boundary %r is not built for EllipticSolver (sphere / square are)" % self.problem.boundary)
+        if self.problem.boundary not in ('sphere', 'two_spheres', 'square', 'square-corner'):
+            raise NotImplementedError("boundary %r is not built for EllipticSolver" % self.problem.boundary)
         if self.variance_moment_split or self.full_hessian:
             raise NotImplementedError('variance_moment_split / full_hessian are not built')
         super()._check_scope()
@@ -345,14 +427,18 @@ class EllipticSolver(GeneralSolver):
 
     def _train_composite(self):
         pb, dev, dt, sq = self.problem, self.device, self.delta_t, self.sq_delta_t
-        K, d = self.K, self.d
+        d = self.d
         for l in range(self.L):
             t_0 = time.time()
             loss = 0
+            if self.sample_center:                               # solver.py:643-645
+                X_center = torch.zeros(1, 1).to(dev)
+                loss = loss + torch.mean((self.V(X_center).squeeze() - pb.v_true(X_center).squeeze()) ** 2)
             X_b = sample_boundary(pb, self.K_boundary, d, dev)
             if self.loss_method != 'BSDE' and self.boundary_loss:
                 loss = loss + self.alpha[1] * self.boundary_residual(X_b)
             X = self.sample_domain().clone().requires_grad_(True)
+            K = self.K                                            # 'two_spheres': set by the rejection step of this iteration
             Y = self.V(X).squeeze()
             stopped = torch.zeros(K).bool().to(dev)
             V_L2 = torch.zeros(K)
@@ -391,11 +477,15 @@ class EllipticSolver(GeneralSolver):
                 if int(torch.sum(stopped)) != K:
                     print('Not all trajectories stopped.')
                 loss = loss + torch.mean((pb.g(X) - Y) ** 2)
+            if self.loss_with_stopped:                            # solver.py:803-804
+                loss = loss + torch.mean((pb.g(X[stopped, :]) - Y[stopped]) ** 2)
             self.V.zero_grad()
             loss.backward()
             self.V.optim.step()
             self.loss_log.append(loss.item())
             self.V_L2_log.append(torch.mean(V_L2).item())
+            if self.K_test_log is not None:
+                self._log_test_error('elliptic')
             self.times.append(time.time() - t_0)
             if self.verbose and l % self.print_every == 0:
                 print('%d - loss = %.4e, v L2 error = %.4e, n = %d, active: %d/%d, %.2f'

@@ -442,6 +442,44 @@ class ExponentialOnSphereNonlinearParabolic(_ExpBall):
         return torch.exp(self.alpha * self._r2(x) + t)
 
 
+class Committor:
+    """Committor function between two concentric spheres of radius a = 1 and c = 2 (reference problems.py:1546-1579): b = 0,
+    sigma = I, h = 0, boundary data 0 on the inner and 1 on the outer sphere; ``boundary = 'two_spheres'`` (EllipticSolver:
+    the batch size changes with the rejection step of every iteration, so this runs on the composite plan)."""
+
+    def __init__(self, name='Committor', d=2, alpha=1.0, device=None):
+        self.device = _resolve(device)
+        self.name, self.d = name, d
+        self.a, self.c = 1.0, 2.0
+        self.B = torch.eye(d).to(self.device)
+        self.X_0 = torch.zeros(d).to(self.device)
+        self.Y_0 = torch.zeros(1).to(self.device)
+        self.boundary = 'two_spheres'
+        self.boundary_distance_1, self.boundary_distance_2 = self.a, self.c
+
+    def b(self, x):
+        return torch.zeros(x.shape).to(x.device)
+
+    def sigma(self, x):
+        return self.B
+
+    def f(self, x):
+        return torch.zeros(x.shape[0]).to(x.device)
+
+    def g(self, x):
+        return (torch.sqrt(torch.sum(x ** 2, 1)) > self.a).float()
+
+    def h(self, x, y, z):
+        return torch.zeros(x.shape[0]).to(x.device)
+
+    def u_true(self, x):
+        return torch.zeros(x.shape)
+
+    def v_true(self, x):
+        r = torch.sqrt(torch.sum(x ** 2, 1))
+        return (self.a ** 2 - r ** (2 - self.d) * self.a ** self.d) / (self.a ** 2 - self.c ** (2 - self.d) * self.a ** self.d)
+
+
 class QuadraticOnBox:
     """NOT a reference class: b = 0, sigma = scale I, h = -|z|^2/2 (or 0) with data |x|^2 on the box [X_l, X_r]^d.
     It exercises the 'square' exit tests of the solvers (reference solver.py:1125-1129, :762-767) with coefficients

@@ -241,3 +241,30 @@ def do_importance_sampling_me(problem, model, K, control='approx', simulate_naiv
     if verbose:
         print('IS mean: %.4e, IS variance: %.4e, IS RE %.4e' % out)
     return out
+
+
+def compute_test_error(model, problem, K, device=None, modus='elliptic'):
+    """Monte-Carlo error of the value net against ``problem.v_true`` on K fresh points of the domain -- the ``K_test_log``
+    diagnostic of EllipticSolver / GeneralSolver (reference utilities.py:440-472; draws from the CPU generator in that order:
+    randn(K, d) and rand(K) for the ball-shaped domains, rand(K, d) for the boxes, then rand(K, 1) for the times).
+    Returns (L2 error, mean absolute error, mean relative error)."""
+    device = torch.device(device) if device is not None else model.device
+    d = problem.d
+    if problem.boundary in ('sphere', 'unbounded', 'two_spheres'):
+        R = problem.boundary_distance_2 if problem.boundary == 'two_spheres' else problem.boundary_distance
+        X = torch.randn(K, d).to(device)
+        X = R * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * (torch.rand(K).unsqueeze(1) ** (1 / d)).to(device)
+        if problem.boundary == 'two_spheres':
+            X = X[torch.sqrt(torch.sum(X ** 2, 1)) > problem.boundary_distance_1, :]
+    else:
+        X = (problem.X_r - problem.X_l) * torch.rand(K, d).to(device) + problem.X_l
+    with torch.no_grad():
+        if modus == 'parabolic':
+            t_n = torch.rand(K, 1).to(device) * problem.T
+            v_true = np.asarray(torch.as_tensor(problem.v_true(X.detach().cpu(), t_n.cpu().squeeze())).squeeze())
+            v_est = model.V(torch.cat([X, t_n], 1)).squeeze().cpu().numpy()
+        else:
+            v_true = np.asarray(torch.as_tensor(problem.v_true(X.detach().cpu())).squeeze())
+            v_est = model.V(X).squeeze().cpu().numpy()
+    diff = v_true - v_est
+    return float(np.mean(diff ** 2)), float(np.mean(np.abs(diff))), float(np.mean(np.abs(diff) / v_true))

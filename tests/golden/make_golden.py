@@ -229,6 +229,7 @@ def run_elliptic_case(case):
         "loss_log": [float(v_) for v_ in model.loss_log],
         "K_log": [int(v_) for v_ in model.K_log],
         "V_L2_log": [float(v_) for v_ in model.V_L2_log],
+        "V_test_L2": [float(v_) for v_ in model.V_test_L2], "V_test_abs": [float(v_) for v_ in model.V_test_abs],
         "init_params": init_fp, "final_params": param_fingerprint(model.V),
         "probe_x": f32list(xp), "probe_V": f32list(v),
     }
@@ -530,6 +531,33 @@ CASES = [
     dict(name="box_d2_upper_elliptic_diffusion", family="elliptic",
          problem=dict(kind="QuadraticOnBox", kwargs=dict(d=2, X_l=-1.0, X_r=0.6, one_boundary=True, parabolic=False, quad_h=False)),
          solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=64, K_boundary=20, loss_method="diffusion")),
+    # round 3: the remaining domains / boundary terms of the diffusion-loss solvers (solver.py:647-708, 750-760, 1023-1027,
+    # 1048-1052, 1122-1123, 1177-1183): composite plan, never an error
+    dict(name="committor_d3_elliptic_diffusion", family="elliptic",
+         problem=dict(kind="Committor", kwargs=dict(d=3)),
+         solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=90, K_boundary=20, loss_method="diffusion")),
+    dict(name="committor_d4_elliptic_bsde", family="elliptic",
+         problem=dict(kind="Committor", kwargs=dict(d=4)),
+         solver=dict(seed=42, delta_t=0.02, N=150, lr=0.001, L=3, K=64, K_boundary=20, loss_method="BSDE"),
+         net=dict(arch=[24, 24], seed=42)),
+    dict(name="committor_d3_elliptic_testlog", family="elliptic",                # K_test_log + loss_with_stopped (the committor notebook's flags)
+         problem=dict(kind="Committor", kwargs=dict(d=3)),
+         solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=90, K_boundary=20, loss_method="diffusion",
+                     K_test_log=200, loss_with_stopped=True, alpha=[10.0, 1.0])),
+    dict(name="expsphere_d3_two_spheres_diffusion", family="general_bounded",
+         problem=dict(kind="ExponentialOnSphereNonlinearParabolic", kwargs=dict(d=3, T=0.5, alpha=0.5),
+                      attrs=dict(boundary="two_spheres", boundary_distance_1=0.4, boundary_distance_2=1.0)),
+         solver=dict(seed=42, delta_t=0.01, N=25, lr=0.001, L=3, K=96, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion")),
+    dict(name="corner_d3_elliptic_diffusion", family="elliptic",
+         problem=dict(kind="QuadraticOnBox", kwargs=dict(d=3, X_l=-1.0, X_r=1.0, parabolic=False),
+                      attrs=dict(boundary="square-corner", X_corner=0.2)),
+         solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=96, K_boundary=20, loss_method="diffusion")),
+    dict(name="expsphere_d3_bsde_neumann", family="general_bounded",
+         problem=dict(kind="ExponentialOnSphereNonlinearParabolic", kwargs=dict(d=3, T=0.3, alpha=0.5),
+                      attrs=dict(boundary_type="Neumann")),
+         solver=dict(seed=42, delta_t=0.01, N=40, lr=0.001, L=3, K=64, K_boundary=18,
+                     alpha=[1.0, 1.0, 1.0], loss_method="BSDE")),
     # round 3: the d = 100 instance BASELINE configs[2] names (gen_*<100,64>: fp32, split-product and bf16 modes under pytest)
     dict(name="dwgen_d100_h64_diffusion", family="general",
          problem=dict(kind="DoubleWell_multidim_for_general_solver",

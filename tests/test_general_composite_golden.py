@@ -17,6 +17,11 @@ BOUNDED = ["expsphere_d4_diffusion_dirichlet", "expsphere_d12_h40_bsde_dirichlet
            "box_d5_diffusion", "box_d3_upper_bsde"]
 ELLIPTIC = ["expball_sin_d5_elliptic_diffusion", "expball_sq_d3_elliptic_bsde", "expsphere_lin_d10_elliptic_diffusion",
             "expball_sin_d4_elliptic_neumann", "box_d4_elliptic_diffusion", "box_d2_upper_elliptic_diffusion"]
+# round 3: what the reference has beyond the native kernels' catalogue runs on the composite plan on every device, never an
+# error: 'two_spheres' (the batch size changes per iteration), 'square-corner', BSDE loss with a Neumann boundary
+# (solver.py:1177-1183), K_test_log / loss_with_stopped
+COMPOSITE_ONLY = ["expsphere_d3_two_spheres_diffusion", "expsphere_d3_bsde_neumann", "committor_d3_elliptic_diffusion",
+                  "committor_d4_elliptic_bsde", "corner_d3_elliptic_diffusion", "committor_d3_elliptic_testlog"]
 
 
 def build(case, device="cpu", backend="auto", **over):
@@ -58,7 +63,7 @@ def test_general_composite_matches_reference(name):
     assert torch.allclose(v, want, rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC)
+@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC + COMPOSITE_ONLY)
 def test_bounded_and_elliptic_composite_matches_reference(name):
     """Sphere / square domains (exit tests, Dirichlet / Neumann terms, BSDE with boundary data) and EllipticSolver."""
     rec = load_golden(name)
@@ -75,6 +80,10 @@ def test_bounded_and_elliptic_composite_matches_reference(name):
     if rec["case"]["family"] == "elliptic":
         for got, want in zip(model.V_L2_log, exp["V_L2_log"]):
             assert math.isclose(got, want, rel_tol=1e-5)
+        if exp.get("V_test_L2"):                              # K_test_log: compute_test_error after every update
+            assert len(model.V_test_L2) == len(exp["V_test_L2"])
+            for got, want in zip(model.V_test_L2 + model.V_test_abs, exp["V_test_L2"] + exp["V_test_abs"]):
+                assert math.isclose(got, want, rel_tol=1e-5)
     else:
         xp = torch.cat([xp, torch.full((xp.shape[0], 1), exp["probe_t"])], 1)
     with torch.no_grad():

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from test_general_composite_golden import BOUNDED, ELLIPTIC, build as build_pkg
+from test_general_composite_golden import BOUNDED, COMPOSITE_ONLY, ELLIPTIC, build as build_pkg
 from util_cases import orc, psp
 
 pytestmark = pytest.mark.gpu
@@ -170,3 +170,21 @@ def test_edge_shapes_match_oracle(case):
     g = model._gen_plan.grad.cpu()
     err = float((g - g_ref).abs().max())
     assert err <= 5e-4 * float(g_ref.abs().max()), (err, float(g_ref.abs().max()))
+
+
+@pytest.mark.parametrize("name", COMPOSITE_ONLY)
+def test_composite_only_configurations_run_on_the_gpu(name):
+    """'two_spheres', 'square-corner', BSDE + Neumann, K_test_log / loss_with_stopped: outside the kernels' catalogue, so
+    backend='auto' resolves to the composite torch plan on the GPU -- with the reference's loss log, never an error."""
+    rec = load_golden(name)
+    with pytest.warns(UserWarning, match="composite torch plan"):
+        prob, model = build_pkg(rec["case"], device=dev(), backend="auto")
+        model.train()
+    assert model.plan_name == "torch" and model.plan_reason
+    exp = rec["expected"]
+    assert model.K_log == exp["K_log"]
+    for got, want in zip(model.loss_log, exp["loss_log"]):
+        assert math.isclose(got, want, rel_tol=1e-4), (name, model.loss_log, exp["loss_log"])
+    with pytest.raises(NotImplementedError):
+        prob, model = build_pkg(rec["case"], device=dev(), backend="native")
+        model.train()

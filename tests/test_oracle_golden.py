@@ -123,9 +123,13 @@ def test_general_oracle_matches_reference(name):
 
 
 BOUNDED_CASES = ["expsphere_d4_diffusion_dirichlet", "expsphere_d12_h40_bsde_dirichlet", "expsphere_d3_diffusion_neumann",
-                 "box_d5_diffusion", "box_d3_upper_bsde"]
+                 "box_d5_diffusion", "box_d3_upper_bsde",
+                 # round 3: 'two_spheres' (variable batch size) and the BSDE loss with a Neumann boundary (solver.py:1177-1183)
+                 "expsphere_d3_two_spheres_diffusion", "expsphere_d3_bsde_neumann"]
 ELLIPTIC_CASES = ["expball_sin_d5_elliptic_diffusion", "expball_sq_d3_elliptic_bsde", "expsphere_lin_d10_elliptic_diffusion",
-                  "expball_sin_d4_elliptic_neumann", "box_d4_elliptic_diffusion", "box_d2_upper_elliptic_diffusion"]
+                  "expball_sin_d4_elliptic_neumann", "box_d4_elliptic_diffusion", "box_d2_upper_elliptic_diffusion",
+                  # round 3: the committor problem between two spheres, and the 'square-corner' domain (solver.py:666-673, 706-708, 759-760)
+                  "committor_d3_elliptic_diffusion", "committor_d4_elliptic_bsde", "corner_d3_elliptic_diffusion"]
 
 
 def _bounded_problem(case):
