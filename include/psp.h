@@ -141,6 +141,8 @@ const char* psp_last_error(void);
 /* sizeof() of the six structs above / below, in declaration order (psp_hjb_config, psp_hjb_sizes, psp_gen_config,
  * psp_gen_sizes, psp_dnet_config, psp_dnet_sizes): lets a binding check its own struct declarations at load time. */
 int psp_abi_struct_sizes(int32_t out[6]);
+/* ... and of psp_genl_config, psp_genl_sizes (added in 0.3.0). */
+int psp_abi_struct_sizes2(int32_t out[2]);
 
 /* 1 if a compiled kernel instantiation exists for (d, H), else 0. */
 int psp_hjb_supported(int32_t d, int32_t H);
@@ -378,6 +380,53 @@ int psp_gen_rollout_fwd(const psp_gen_config* cfg, const float* params, const fl
  * VN, YN (diffusion: wV = 2 a0 (VN - YN)/K = -wY ; BSDE: wV = 0, wY = 2 (YN - f(XN))/K). */
 int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const float* path, const float* ahat,
                         const float* wY, const float* wV, float* grad_partial, float* grad_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GeneralSolver / EllipticSolver with a value net of ANY depth: V = DenseNet(d [+ 1] -> 1, arch = [H_1 .. H_L]), 1 <= L <= 4,
+ * H_i <= 128, d + 1 <= 112 (reference function_space.py:116-140; the nets the diffusion-loss notebooks swap into model.V:
+ * Allen-Cahn.ipynb:72 arch = [110, 110, 50], [30, 30, 30, 30], ...).  Shapes are run-time arguments: activations in per-wave
+ * LDS images, weights as A-operand tables in global memory (csrc/genl_kernels.h).  The step is the one of psp_gen_rollout_fwd
+ * (same noise counters, exit tests, h kinds, outputs); the parameter gradient is formed by
+ *   psp_genl_adjoints  per sample: activations a, their tangent a' along s u^, and the adjoints zbar_i, zbar_i' of every
+ *                      layer's pre-activation, written as T-layout images (block of 16 samples after block), and by the CALLER's
+ *   library GEMMs      dW_i = A[:, :in_i]^T Zbar_i + A'[:, :in_i]^T Zbar_i',  db_i = column sums of Zbar_i,
+ *                      dw_out = A^T a + A'^T w,  db_out = sum a      (plain GEMMs over the sample axis).
+ */
+typedef struct psp_genl_config {
+    psp_gen_config base;      /* d = state dimension; H, mlp_dtype, d_real, v_steps_out, y_steps_out, per_sample_weights, range_flag unused */
+    int32_t has_time;         /* 1: network input [x, t] (GeneralSolver), 0: [x] (EllipticSolver; base.T = +inf)                 */
+    int32_t n_hidden;         /* L                                                                                              */
+    int32_t widths[4];        /* H_1 .. H_L                                                                                     */
+} psp_genl_config;
+
+typedef struct psp_genl_sizes {
+    int64_t table_bytes;      /* scratch for the operand tables (rebuilt by every call that takes `tables`)                     */
+    int64_t path_bytes;       /* (N + 1) x ceil(K/16) blocks of x and s u^ images                                               */
+    int64_t ahat_bytes;       /* (N + 1) x 16 ceil(K/16) floats                                                                 */
+    int64_t n_params;         /* DenseNet registration order W_1, b_1, .., W_out, b_out; weights (in, out)                       */
+    int32_t act_floats_per_block;   /* 256 x TB: one 16-sample block of the A / A' outputs (TB padded 16-feature blocks)        */
+    int32_t zbar_floats_per_block;  /* 256 x sum_i ceil(H_i / 16): one block of the Zbar / Zbar' outputs                        */
+    int32_t n_blocks;         /* (N + 1) x ceil(K/16) sample blocks                                                              */
+    int32_t fwd_workgroups;
+    int32_t seg_block_offset[5];    /* first padded 16-feature block of segment s (0: input, s: h_s); [L] + ceil(H_L/16) = TB    */
+    int32_t reserved;
+} psp_genl_sizes;
+
+/* <0: shape outside the limits above, or the per-wave LDS images exceed 160 KiB. */
+int psp_genl_query(const psp_genl_config* cfg, psp_genl_sizes* out);
+/* Forward rollout; arguments as psp_gen_rollout_fwd plus the table scratch. */
+int psp_genl_rollout_fwd(const psp_genl_config* cfg, const float* params, const float* x0, const float* t0, const float* xi,
+                         uint64_t seed, uint32_t iter, float* tables, float* path, float* ahat, float* VN, float* YN,
+                         float* XN, float* tN, unsigned long long* kcount, void* stream);
+/* Adjoint pass over the sample blocks [blk0, blk1) of the path store (block = n * ceil(K/16) + tile; a caller with a memory
+ * budget walks the store in slabs).  wY, wV: per-trajectory loss weights as for psp_gen_rollout_bwd (zero padded to
+ * 16 ceil(K/16)).  out_A, out_Ad: (blk1 - blk0) x act_floats_per_block; out_Zb, out_Zdb: (blk1 - blk0) x
+ * zbar_floats_per_block (layer i at block offset sum_{j<i} ceil(H_j/16)); out_av, out_wy: (blk1 - blk0) x 16 sample
+ * coefficients (a of V, w of the tangent part).  Image element (ks, lane = j + 16 q) = feature 4 ks + q of sample j.
+ * `tables` must hold the tables of the SAME parameters (psp_genl_rollout_fwd leaves them there). */
+int psp_genl_adjoints(const psp_genl_config* cfg, const float* params, const float* tables, const float* path, const float* ahat,
+                      const float* wY, const float* wV, int64_t blk0, int64_t blk1, float* out_A, float* out_Ad,
+                      float* out_Zb, float* out_Zdb, float* out_av, float* out_wy, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Solver.train with a DenseNet control (function_space.py:116-140: dense-concat layers, relu^2, weights (in, out)):

@@ -85,7 +85,7 @@ def _build(force, jobs, verbose, only):
     dhdr = os.path.join(CSRC, "hjbd_kernels.h")
     ddef = os.path.join(CSRC, "dense_instances.def")
     dinst_src = os.path.join(CSRC, "hjbd_instance.hip")
-    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, ghdr, whdr, dhdr, inc, idef, gdef, wdef, ddef])]
+    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, ghdr, whdr, dhdr, os.path.join(CSRC, "genl_kernels.h"), inc, idef, gdef, wdef, ddef])]
     for d, H in instances("dense_instances.def"):
         tasks.append((dinst_src, os.path.join(OBJ, "dnet_inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [dinst_src, dhdr, whdr, hdr]))

@@ -13,6 +13,7 @@
 #include "gen_kernels.h"
 #include "hjbw_kernels.h"
 #include "hjbd_kernels.h"
+#include "genl_kernels.h"
 
 #define X(D_, H_) PSP_DECLARE_DNET_INSTANCE(D_, H_)
 #include "dense_instances.def"
@@ -503,6 +504,11 @@ int psp_abi_struct_sizes(int32_t out[6]) {
     out[0] = (int32_t)sizeof(psp_hjb_config); out[1] = (int32_t)sizeof(psp_hjb_sizes);
     out[2] = (int32_t)sizeof(psp_gen_config); out[3] = (int32_t)sizeof(psp_gen_sizes);
     out[4] = (int32_t)sizeof(psp_dnet_config); out[5] = (int32_t)sizeof(psp_dnet_sizes);
+    return 0;
+}
+int psp_abi_struct_sizes2(int32_t out[2]) {
+    if (!out) return fail(-1, "null output");
+    out[0] = (int32_t)sizeof(psp_genl_config); out[1] = (int32_t)sizeof(psp_genl_sizes);
     return 0;
 }
 const char* psp_last_error(void) { return g_err; }
@@ -1069,6 +1075,139 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
                        grad_partial, p.bwd_grid, P, grad_out);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "reduce_grad_kernel launch");
+    return 0;
+}
+
+
+// ---- value nets of any depth (genl_kernels.h) ----------------------------------------------------------------------------
+namespace {
+struct GenlPlan { psp::GenlArgs a; int ntile16; long long table_floats; long long n_params; int fwd_lds, adj_lds; };
+int make_genl_plan(const psp_genl_config* c, GenlPlan* p) {
+    if (!c) return fail(-1, "null config");
+    const psp_gen_config& b = c->base;
+    if (b.d <= 0 || b.K_local <= 0 || b.N <= 0) return fail(-1, "non-positive d/K/N");
+    const int L = c->n_hidden;
+    if (L < 1 || L > psp::GENL_MAXL) return fail(-2, "value net: 1 to 4 hidden layers");
+    const int D0 = b.d + (c->has_time ? 1 : 0);
+    if (D0 > 16 * psp::GENL_MAXDB) return fail(-2, "value net: input width above 112");
+    if ((b.drift_kind != PSP_DRIFT_ZERO && b.drift_kind != PSP_DRIFT_DOUBLE_WELL && b.drift_kind != PSP_DRIFT_DIAG) || b.h_kind < 0 ||
+        b.h_kind > PSP_GH_EXPBALL_SIN || b.noise_mode < 0 || b.noise_mode > 1 || b.domain_kind < 0 || b.domain_kind > PSP_DOM_BOX_UPPER_ANY)
+        return fail(-1, "config enum out of range");
+    if (b.domain_kind == PSP_DOM_SPHERE && !(b.dom_a > 0.f)) return fail(-1, "sphere radius must be positive");
+    if (b.domain_kind == PSP_DOM_BOX && !(b.dom_a < b.dom_b)) return fail(-1, "box bounds must satisfy X_l < X_r");
+    if (b.drift_kind != PSP_DRIFT_ZERO && !b.drift) return fail(-1, "drift vector missing (double-well kappa / diagonal of A)");
+    psp::GenlArgs& a = p->a;
+    memset(&a, 0, sizeof(a));
+    a.d = b.d; a.D0 = D0; a.has_time = c->has_time ? 1 : 0; a.L = L;
+    a.DB0 = (D0 + 15) / 16;
+    a.off[0] = 0; a.roff[0] = 0;
+    int blocks = a.DB0, real = D0, hbsum = 0;
+    long long pofs = 0, tofs = 0;
+    for (int i = 0; i < L; ++i) {
+        const int Hi = c->widths[i];
+        if (Hi < 1 || Hi > 16 * psp::GENL_MAXHB) return fail(-2, "value net: hidden widths between 1 and 128");
+        a.H[i] = Hi; a.HB[i] = (Hi + 15) / 16;
+        a.off[i + 1] = blocks; a.roff[i + 1] = real;
+        a.oW[i] = (int)pofs; pofs += (long long)real * Hi;
+        a.ob[i] = (int)pofs; pofs += Hi;
+        a.tF[i] = tofs; tofs += (long long)a.HB[i] * 4 * blocks * 64;           // [HB_i][4 * input blocks][64]
+        a.tR[i] = tofs; tofs += (long long)blocks * 4 * a.HB[i] * 64;           // [input blocks][4 HB_i][64]
+        a.vB[i] = tofs; tofs += (long long)a.HB[i] * 16;
+        blocks += a.HB[i]; real += Hi; hbsum += a.HB[i];
+    }
+    a.oW[L] = (int)pofs; pofs += real;
+    a.ob[L] = (int)pofs; pofs += 1;
+    a.TB = blocks; a.HBsum = hbsum;
+    a.vW = tofs; tofs += (long long)blocks * 16;
+    p->table_floats = tofs; p->n_params = pofs;
+    p->ntile16 = (b.K_local + 15) / 16;
+    p->fwd_lds = psp::genl_fwd_lds_bytes(a.TB); p->adj_lds = psp::genl_adj_lds_bytes(a.TB);
+    if (p->fwd_lds > kMaxLds || p->adj_lds > kMaxLds)
+        return fail(-3, "value net: the per-wave activation images exceed the 160 KiB LDS (sum of the padded widths too large)");
+    if ((long long)(b.N + 1) * p->ntile16 >= (1LL << 31)) return fail(-1, "(N + 1) * ceil(K/16) must stay below 2^31");
+    // the GenArgs part: as fill_gen_args
+    psp::GenArgs& g = a.g;
+    g.drift = b.drift; g.k_offset = b.k_offset; g.K_local = b.K_local; g.N = b.N; g.ntile16 = p->ntile16;
+    g.dt = b.dt; g.sqdt = b.sqrt_dt; g.T = b.T; g.sigma_scale = b.sigma_scale;
+    g.drift_kind = b.drift_kind; g.h_kind = b.h_kind; g.adaptive = b.adaptive;
+    g.noise_mode = b.noise_mode; g.store_path = b.store_path;
+    g.domain_kind = b.domain_kind; g.dom_a = b.dom_a; g.dom_b = b.dom_b; g.d_real = b.d;
+    for (int i = 0; i < 4; ++i) g.h_par[i] = b.h_par[i];
+    return 0;
+}
+}  // namespace
+
+int psp_genl_query(const psp_genl_config* cfg, psp_genl_sizes* out) {
+    GenlPlan p;
+    int rc = make_genl_plan(cfg, &p);
+    if (rc) return rc;
+    if (!out) return fail(-1, "null output");
+    memset(out, 0, sizeof(*out));
+    const int64_t nblk = (int64_t)(cfg->base.N + 1) * p.ntile16;
+    out->table_bytes = p.table_floats * 4;
+    out->path_bytes = cfg->base.store_path ? nblk * 2 * p.a.DB0 * 256 * 4 : 0;
+    out->ahat_bytes = nblk * 16 * 4;
+    out->n_params = p.n_params;
+    out->act_floats_per_block = p.a.TB * 256;
+    out->zbar_floats_per_block = p.a.HBsum * 256;
+    out->n_blocks = (int32_t)nblk;
+    out->fwd_workgroups = p.ntile16;
+    for (int i = 0; i <= p.a.L; ++i) out->seg_block_offset[i] = p.a.off[i];
+    return 0;
+}
+
+int psp_genl_rollout_fwd(const psp_genl_config* cfg, const float* params, const float* x0, const float* t0,
+                                    const float* xi, uint64_t seed, uint32_t iter, float* tables, float* path, float* ahat,
+                                    float* VN, float* YN, float* XN, float* tN, unsigned long long* kcount, void* stream) {
+    GenlPlan p;
+    int rc = make_genl_plan(cfg, &p);
+    if (rc) return rc;
+    if (!params || !x0 || !tables || !VN || !YN || !XN || !tN || !kcount) return fail(-1, "null buffer passed to psp_genl_rollout_fwd");
+    if (cfg->has_time && !t0) return fail(-1, "t0 missing");
+    if (cfg->base.noise_mode == PSP_NOISE_SUPPLIED && !xi) return fail(-1, "supplied-noise mode needs xi");
+    if (cfg->base.store_path && (!path || !ahat)) return fail(-1, "store_path set but path / ahat buffer is null");
+    psp::GenlArgs& a = p.a;
+    a.tables = tables; a.tables_w = tables;
+    psp::GenArgs& g = a.g;
+    g.params = params; g.x0 = x0; g.t0 = t0; g.xi = xi; g.path = path; g.ahat = ahat;
+    g.VN = VN; g.YN = YN; g.XN = XN; g.tN = tN; g.kcount = kcount;
+    g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32); g.iter = iter;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(psp::genl_tables_kernel, dim3(128), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "genl_tables_kernel launch");
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&psp::genl_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, p.fwd_lds);
+    if (e != hipSuccess) return fail_hip(e, "genl_fwd_kernel attribute");
+    hipLaunchKernelGGL(psp::genl_fwd_kernel, dim3(p.ntile16), dim3(64), p.fwd_lds, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "genl_fwd_kernel launch");
+    return 0;
+}
+
+int psp_genl_adjoints(const psp_genl_config* cfg, const float* params, const float* tables, const float* path,
+                                 const float* ahat, const float* wY, const float* wV, int64_t blk0, int64_t blk1, float* out_A,
+                                 float* out_Ad, float* out_Zb, float* out_Zdb, float* out_av, float* out_wy, void* stream) {
+    GenlPlan p;
+    int rc = make_genl_plan(cfg, &p);
+    if (rc) return rc;
+    if (!params || !tables || !path || !ahat || !wY || !wV || !out_A || !out_Ad || !out_Zb || !out_Zdb || !out_av || !out_wy)
+        return fail(-1, "null buffer passed to psp_genl_adjoints");
+    const int64_t nblk = (int64_t)(cfg->base.N + 1) * p.ntile16;
+    if (blk0 < 0 || blk1 > nblk || blk0 >= blk1) return fail(-1, "psp_genl_adjoints: block range outside [0, (N + 1) ceil(K/16))");
+    psp::GenlArgs& a = p.a;
+    a.tables = tables;
+    psp::GenArgs& g = a.g;
+    g.params = params; g.path = const_cast<float*>(path); g.ahat = const_cast<float*>(ahat); g.wY = wY; g.wV = wV;
+    a.outA = out_A; a.outAd = out_Ad; a.outZb = out_Zb; a.outZdb = out_Zdb; a.out_av = out_av; a.out_wy = out_wy;
+    a.blk0 = blk0; a.blk1 = blk1;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&psp::genl_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, p.adj_lds);
+    if (e != hipSuccess) return fail_hip(e, "genl_adj_kernel attribute");
+    long long grid = blk1 - blk0;
+    const long long gmax = 8LL * n_cus();
+    if (grid > gmax) grid = gmax;
+    hipLaunchKernelGGL(psp::genl_adj_kernel, dim3((unsigned)grid), dim3(64), p.adj_lds, (hipStream_t)stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "genl_adj_kernel launch");
     return 0;
 }
 

@@ -248,14 +248,23 @@ class GeneralSolver:
         except ImportError:
             pgn = None
         reason = self.composite_only_reason()
+        deep = False
         if reason is None:
             reason = 'the native diffusion-loss plan is not built yet' if pgn is None else pgn.native_eligibility(self)
+            if reason is not None and pgn is not None and getattr(self, 'mlp_dtype', 'auto') in ('auto', 'fp32'):
+                # value nets of other depths / widths (the notebooks' nets): the run-time-shaped kernels of csrc/genl_kernels.h
+                try:
+                    from . import plan_general_deep as pgd
+                except ImportError:
+                    import plan_general_deep as pgd
+                if pgd.deep_eligibility(self) is None and pgn.native_eligibility(self, deep=True) is None:
+                    reason, deep = None, True
         if reason is None:
             self.plan_name = 'native'
             plan = getattr(self, '_gen_plan', None)
             key = self._plan_key()
             if plan is None or plan.net is not self.V or plan.key != key:
-                plan = pgn.GeneralNativePlan(self)              # owns the flat parameters and Adam moments
+                plan = pgd.GeneralDeepPlan(self) if deep else pgn.GeneralNativePlan(self)   # owns the flat parameters and Adam moments
                 plan.key = key
                 self._gen_plan = plan
             return plan

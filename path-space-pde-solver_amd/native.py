@@ -101,11 +101,27 @@ class GenSizes(C.Structure):
     ]
 
 
+class GenlConfig(C.Structure):
+    _fields_ = [("base", GenConfig), ("has_time", C.c_int32), ("n_hidden", C.c_int32), ("widths", C.c_int32 * 4)]
+
+
+class GenlSizes(C.Structure):
+    _fields_ = [("table_bytes", C.c_int64), ("path_bytes", C.c_int64), ("ahat_bytes", C.c_int64), ("n_params", C.c_int64),
+                ("act_floats_per_block", C.c_int32), ("zbar_floats_per_block", C.c_int32), ("n_blocks", C.c_int32),
+                ("fwd_workgroups", C.c_int32), ("seg_block_offset", C.c_int32 * 5), ("reserved", C.c_int32)]
+
+
 _P = C.c_void_p
 SIGNATURES = {
     "psp_version": (C.c_int, []),
     "psp_abi_struct_sizes": (C.c_int, [C.POINTER(C.c_int32 * 6)]),
+    "psp_abi_struct_sizes2": (C.c_int, [C.POINTER(C.c_int32 * 2)]),
     "psp_last_error": (C.c_char_p, []),
+    "psp_genl_query": (C.c_int, [C.POINTER(GenlConfig), C.POINTER(GenlSizes)]),
+    "psp_genl_rollout_fwd": (C.c_int, [C.POINTER(GenlConfig), _P, _P, _P, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P, _P,
+                                       _P, _P]),
+    "psp_genl_adjoints": (C.c_int, [C.POINTER(GenlConfig), _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P,
+                                    _P]),
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_family": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_adjoint_sweep": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -178,6 +194,12 @@ def load():
     if list(sizes) != mine:          # a stale build or a drifted struct declaration would corrupt kernel arguments silently
         raise NativeLibraryError("%s was built for other struct layouts (library %s, binding %s): rebuild it"
                                  % (LIB_PATH, list(sizes), mine))
+    sizes2 = (C.c_int32 * 2)()
+    lib.psp_abi_struct_sizes2(C.byref(sizes2))
+    mine2 = [C.sizeof(GenlConfig), C.sizeof(GenlSizes)]
+    if list(sizes2) != mine2:
+        raise NativeLibraryError("%s was built for other struct layouts (library %s, binding %s): rebuild it"
+                                 % (LIB_PATH, list(sizes2), mine2))
     _lib = lib
     return lib
 

@@ -36,7 +36,9 @@ except ImportError:
     import general_solver as gs
 
 
-def native_eligibility(solver):
+def native_eligibility(solver, deep=False):
+    """None if the (d, H)-templated value-net kernels take this solver, else a reason.  deep=True: the checks that do not
+    concern the net's shape (plan_general_deep.py has its own shape test)."""
     if solver.device.type != 'cuda':
         return 'device is %s (the HIP rollout needs a GPU)' % solver.device
     if solver.approx_method != 'Y' or solver.loss_method not in ('diffusion', 'BSDE'):
@@ -48,8 +50,8 @@ def native_eligibility(solver):
     V = solver.V
     dims = getattr(V, 'nn_dims', None)
     d_in = solver.d + (0 if solver.elliptic else 1)
-    if not isinstance(V, DenseNet) or dims is None or len(dims) != 4 or dims[1] != dims[2] or dims[3] != 1 \
-            or dims[0] != d_in:
+    if not deep and (not isinstance(V, DenseNet) or dims is None or len(dims) != 4 or dims[1] != dims[2] or dims[3] != 1
+                     or dims[0] != d_in):
         return 'V is not a DenseNet(%d -> 1) with two equal hidden widths' % d_in
     spec_fn = getattr(solver.problem, 'general_native_spec', None)
     if spec_fn is None:
@@ -63,7 +65,7 @@ def native_eligibility(solver):
         return 'problem.%s is not the catalogue implementation general_native_spec() describes' % over
     if not nat.is_built():
         raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
-    if not shapes.gen_candidates(solver.d, dims[1]):
+    if not deep and not shapes.gen_candidates(solver.d, dims[1]):
         return 'no compiled kernel instance covers d=%d, H=%d (see csrc/gen_instances.def)' % (solver.d, dims[1])
     return None
 
@@ -281,10 +283,7 @@ class GeneralNativePlan:
         if self.events is not None:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
-        nat.check(lib.psp_gen_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(x0), nat.ptr(t0), nat.ptr(xi),
-                                          int(s.seed) & 0xFFFFFFFFFFFFFFFF, l, nat.ptr(self.path),
-                                          nat.ptr(self.ahat), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN_k),
-                                          nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_gen_rollout_fwd')
+        self._launch_fwd(flat_k, x0, t0, xi, l, st)
         if ev is not None:
             ev[1].record()
         if rng_state is not None:                                # rewind, then consume what the reference consumes
@@ -319,9 +318,7 @@ class GeneralNativePlan:
         self.wV[:self.K_local].copy_(wV)
         if ev is not None:
             ev[2].record()
-        nat.check(lib.psp_gen_rollout_bwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.path), nat.ptr(self.ahat),
-                                          nat.ptr(self.wY), nat.ptr(self.wV), nat.ptr(self.grad_partial), nat.ptr(self.grad_k),
-                                          st), 'psp_gen_rollout_bwd')
+        self._launch_bwd(flat_k, st)
         self.pad.gather_grad(self.grad_k, self.grad)
         if ev is not None:
             ev[3].record()
@@ -338,6 +335,22 @@ class GeneralNativePlan:
         kc = self.kcount.clone()
         sharding.allreduce_sum_(kc)
         return loss, kc
+
+    # ---- the two kernel launches of an iteration (plan_general_deep.py overrides them for value nets of other depths)
+    def _launch_fwd(self, flat_k, x0, t0, xi, l, st):
+        nat.check(self.lib.psp_gen_rollout_fwd(C.byref(self.cfg), nat.ptr(flat_k), nat.ptr(x0), nat.ptr(t0), nat.ptr(xi),
+                                               int(self.s.seed) & 0xFFFFFFFFFFFFFFFF, l, nat.ptr(self.path),
+                                               nat.ptr(self.ahat), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN_k),
+                                               nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_gen_rollout_fwd')
+
+    def _launch_bwd(self, flat_k, st):
+        nat.check(self.lib.psp_gen_rollout_bwd(C.byref(self.cfg), nat.ptr(flat_k), nat.ptr(self.path), nat.ptr(self.ahat),
+                                               nat.ptr(self.wY), nat.ptr(self.wV), nat.ptr(self.grad_partial), nat.ptr(self.grad_k),
+                                               st), 'psp_gen_rollout_bwd')
+
+    def _x_image_floats(self):
+        """Floats of the X_n register image at the head of a path block (the network input incl. the time row)."""
+        return 4 * ((self.d_pad + 1 + 15) // 16) * 64
 
     def range_fallbacks(self):
         """Iterations the range guard sent to the fp32-MFMA kernels so far; one device read."""
@@ -369,7 +382,7 @@ class GeneralNativePlan:
         s, cfg = self.s, self.cfg
         N, nt = s.N, (self.K_local + 15) // 16
         PB = self.sizes.path_bytes // 4 // ((N + 1) * nt)
-        nx = 4 * ((self.d_pad + 1 + 15) // 16) * 64
+        nx = self._x_image_floats()
         img = self.path.view(N + 1, nt, PB)[:N, :, :nx].reshape(N, nt, nx // 64, 4, 16)
         X = img.permute(0, 1, 4, 2, 3).reshape(N, nt * 16, nx // 16)[:, :self.K_local, :s.d]
         m = torch.round(self.tN / cfg.dt)                                            # active steps per trajectory

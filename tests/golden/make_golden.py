@@ -558,6 +558,38 @@ CASES = [
                       attrs=dict(boundary_type="Neumann")),
          solver=dict(seed=42, delta_t=0.01, N=40, lr=0.001, L=3, K=64, K_boundary=18,
                      alpha=[1.0, 1.0, 1.0], loss_method="BSDE")),
+    # round 3: value nets of other depths / widths -- the nets the diffusion-loss notebooks swap into model.V (function_space.py:116-140)
+    dict(name="allencahn_d10_arch3_diffusion", family="general",
+         problem=dict(kind="AllenCahn", kwargs=dict(d=10, T=0.3, seed=42, modus="pt")),
+         solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=80, K_boundary=16,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
+         net=dict(arch=[24, 24, 12], seed=42)),
+    dict(name="dwgen_d10_arch4_bsde", family="general",
+         problem=dict(kind="DoubleWell_multidim_for_general_solver",
+                      kwargs=dict(d=10, d_1=5, d_2=5, T=0.1, eta=0.1, kappa=1, modus="HJB")),
+         solver=dict(seed=42, delta_t=0.01, N=12, lr=0.001, L=3, K=64, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="BSDE"),
+         net=dict(arch=[30, 30, 30, 30], seed=42)),
+    dict(name="heat_d6_arch1_diffusion", family="general",
+         problem=dict(kind="HeatEquation", kwargs=dict(d=6, T=0.5, seed=42)),
+         solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=72, K_boundary=16,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
+         net=dict(arch=[40], seed=42)),
+    dict(name="expsphere_d4_arch3_diffusion_dirichlet", family="general_bounded",
+         problem=dict(kind="ExponentialOnSphereNonlinearParabolic", kwargs=dict(d=4, T=0.6, alpha=0.5)),
+         solver=dict(seed=42, delta_t=0.01, N=30, lr=0.001, L=3, K=96, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
+         net=dict(arch=[20, 16, 12], seed=42)),
+    dict(name="expball_sin_d5_arch3_elliptic_diffusion", family="elliptic",
+         problem=dict(kind="ExponentialOnBallNonlinearSin", kwargs=dict(d=5, alpha=0.5)),
+         solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=96, K_boundary=20, loss_method="diffusion"),
+         net=dict(arch=[24, 24, 12], seed=42)),
+    # ... and the one configuration the reference publishes a timing for (Allen-Cahn.ipynb:46-72, 86: 0.31 s per iteration)
+    dict(name="allencahn_d100_notebook_a110", family="general",
+         problem=dict(kind="AllenCahn", kwargs=dict(d=100, T=0.3, seed=42, modus="pt"), attrs=dict(boundary_distance=7.0)),
+         solver=dict(seed=42, delta_t=0.001, N=25, lr=0.001, L=3, K=200, K_boundary=50,
+                     alpha=[10.0, 1.0, 1.0], loss_method="diffusion", uniform_square=True),
+         net=dict(arch=[110, 110, 50], seed=42)),
     # round 3: the d = 100 instance BASELINE configs[2] names (gen_*<100,64>: fp32, split-product and bf16 modes under pytest)
     dict(name="dwgen_d100_h64_diffusion", family="general",
          problem=dict(kind="DoubleWell_multidim_for_general_solver",

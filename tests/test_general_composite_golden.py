@@ -11,6 +11,10 @@ from util_cases import psp
 CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
          "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde",
          "dwgen_d100_h64_diffusion"]   # the exact (100, 64) instance of BASELINE configs[2]
+# round 3: value nets of other depths / widths (native on the run-time-shaped kernels of csrc/genl_kernels.h)
+DEEP = ["allencahn_d10_arch3_diffusion", "dwgen_d10_arch4_bsde", "heat_d6_arch1_diffusion", "allencahn_d100_notebook_a110"]
+DEEP_BOUNDED = ["expsphere_d4_arch3_diffusion_dirichlet"]
+DEEP_ELLIPTIC = ["expball_sin_d5_arch3_elliptic_diffusion"]
 
 
 BOUNDED = ["expsphere_d4_diffusion_dirichlet", "expsphere_d12_h40_bsde_dirichlet", "expsphere_d3_diffusion_neumann",
@@ -43,7 +47,7 @@ def build(case, device="cpu", backend="auto", **over):
     return prob, model
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + DEEP)
 def test_general_composite_matches_reference(name):
     rec = load_golden(name)
     exact = rec["torch"] == torch.__version__
@@ -63,7 +67,7 @@ def test_general_composite_matches_reference(name):
     assert torch.allclose(v, want, rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC + COMPOSITE_ONLY)
+@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC + COMPOSITE_ONLY + DEEP_BOUNDED + DEEP_ELLIPTIC)
 def test_bounded_and_elliptic_composite_matches_reference(name):
     """Sphere / square domains (exit tests, Dirichlet / Neumann terms, BSDE with boundary data) and EllipticSolver."""
     rec = load_golden(name)

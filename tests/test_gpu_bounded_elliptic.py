@@ -27,7 +27,8 @@ def oracle_run(case, L):
     if "numpy_seed" in case:
         np.random.seed(case["numpy_seed"])
     common = dict(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=L, seed=s["seed"], K_boundary=s["K_boundary"],
-                  loss_method=s["loss_method"], adaptive_forward_process=s.get("adaptive_forward_process", False))
+                  loss_method=s["loss_method"], adaptive_forward_process=s.get("adaptive_forward_process", False),
+                  uniform_square=s.get("uniform_square", False))
     arch = case["net"]["arch"] if "net" in case else None
     if case["family"] == "elliptic":
         cfg = orc.EllipticConfig(alpha=tuple(s.get("alpha", (1.0, 1.0))), boundary_type=s.get("boundary_type", "Dirichlet"),

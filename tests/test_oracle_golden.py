@@ -24,7 +24,9 @@ SOLVER_CASES = ["lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "ll
                 "lqgc_d2_variance", "lqgc_d2_variance_learn_y0", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
 GENERAL_CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
                  "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde",
-         "dwgen_d100_h64_diffusion"]   # the exact (100, 64) instance of BASELINE configs[2]
+         "dwgen_d100_h64_diffusion",   # the exact (100, 64) instance of BASELINE configs[2]
+         # round 3: value nets of other depths (the notebooks' nets; csrc/genl_kernels.h)
+         "allencahn_d10_arch3_diffusion", "dwgen_d10_arch4_bsde", "heat_d6_arch1_diffusion", "allencahn_d100_notebook_a110"]
 
 
 def _same_build(rec):
@@ -110,10 +112,11 @@ def test_general_oracle_matches_reference(name):
     exact = _same_build(rec)
     case = rec["case"]
     torch.set_num_threads(1)
-    prob = orc.make_problem(case["problem"]["kind"], **case["problem"]["kwargs"])
+    prob = orc.make_problem(case["problem"]["kind"], **dict(case["problem"]["kwargs"], **case["problem"].get("attrs", {})))
     s = case["solver"]
     cfg = orc.GeneralConfig(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=s["L"], seed=s["seed"],
-                            K_boundary=s["K_boundary"], alpha=tuple(s["alpha"]), loss_method=s["loss_method"])
+                            K_boundary=s["K_boundary"], alpha=tuple(s["alpha"]), loss_method=s["loss_method"],
+                            uniform_square=s.get("uniform_square", False))
     V = orc.general_build(prob, cfg, arch=case["net"]["arch"] if "net" in case else None)
     out = orc.general_train(prob, cfg, V=V)
     exp = rec["expected"]
@@ -125,11 +128,12 @@ def test_general_oracle_matches_reference(name):
 BOUNDED_CASES = ["expsphere_d4_diffusion_dirichlet", "expsphere_d12_h40_bsde_dirichlet", "expsphere_d3_diffusion_neumann",
                  "box_d5_diffusion", "box_d3_upper_bsde",
                  # round 3: 'two_spheres' (variable batch size) and the BSDE loss with a Neumann boundary (solver.py:1177-1183)
-                 "expsphere_d3_two_spheres_diffusion", "expsphere_d3_bsde_neumann"]
+                 "expsphere_d3_two_spheres_diffusion", "expsphere_d3_bsde_neumann", "expsphere_d4_arch3_diffusion_dirichlet"]
 ELLIPTIC_CASES = ["expball_sin_d5_elliptic_diffusion", "expball_sq_d3_elliptic_bsde", "expsphere_lin_d10_elliptic_diffusion",
                   "expball_sin_d4_elliptic_neumann", "box_d4_elliptic_diffusion", "box_d2_upper_elliptic_diffusion",
                   # round 3: the committor problem between two spheres, and the 'square-corner' domain (solver.py:666-673, 706-708, 759-760)
-                  "committor_d3_elliptic_diffusion", "committor_d4_elliptic_bsde", "corner_d3_elliptic_diffusion"]
+                  "committor_d3_elliptic_diffusion", "committor_d4_elliptic_bsde", "corner_d3_elliptic_diffusion",
+                  "expball_sin_d5_arch3_elliptic_diffusion"]
 
 
 def _bounded_problem(case):
