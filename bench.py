@@ -100,6 +100,17 @@ GENERAL_WORKLOADS = {
     # BASELINE.json configs[2] as written: value-net products of the forward rollout on bf16 MFMA (fp32 state / accumulate)
     "diffusion_dw_d100_K65536_N100_h64_bf16": dict(d=100, H=64, K=65536, N=100, T=0.3, dt=0.001, loss="diffusion", mlp="bf16"),
     "diffusion_dw_d100_K65536_N100_h64_bf16fwd": dict(d=100, H=64, K=65536, N=100, T=0.3, dt=0.001, loss="diffusion", mlp="bf16_fwd"),
+    # the ONE configuration the reference publishes a timing for (Allen-Cahn.ipynb:46-72, 86, 115: 0.31-0.35 s per iteration on an
+    # unnamed CUDA GPU): AllenCahn d=100, T=0.3, K=200, N=25, dt=1e-3, V = DenseNet(101 -> 1, [110, 110, 50]),
+    # alpha = [10, 1, 1], uniform_square -- the run-time-shaped value-net kernels (csrc/genl_kernels.h)
+    "diffusion_allencahn_d100_K200_N25_a110": dict(d=100, arch=[110, 110, 50], K=200, N=25, T=0.3, dt=0.001, loss="diffusion",
+                                                   problem="AllenCahn", alpha=[10.0, 1.0, 1.0], uniform_square=True,
+                                                   boundary_distance=7.0, published_s_per_iter=(0.31, 0.35),
+                                                   published_units_per_s=1.4e4),
+    # the same net at a batch that fills the chip
+    "diffusion_allencahn_d100_K16384_N25_a110": dict(d=100, arch=[110, 110, 50], K=16384, N=25, T=0.3, dt=0.001, loss="diffusion",
+                                                     problem="AllenCahn", alpha=[10.0, 1.0, 1.0], uniform_square=True,
+                                                     boundary_distance=7.0),
 }
 # MI355X_MICROARCH.md, chip-level parameters
 PEAK_FP32_MFMA_TFLOPS = 157.3
@@ -840,20 +851,59 @@ def finish_ranks(psp, dist, rank, world, dev, rehearsal):
     dist.destroy_process_group()
 
 
+def general_composite_leg(psp, dev, w, arch, iters=6):
+    """The same configuration on the package's composite torch plan (the reference's op sequence with autograd) on this GPU."""
+    prob = psp.AllenCahn(d=w["d"], T=w["T"], seed=42, modus="pt", device=dev)
+    prob.boundary_distance = w.get("boundary_distance", 1.0)
+    m = psp.GeneralSolver(problem=prob, name="bench-composite", seed=42, delta_t=w["dt"], N=w["N"], lr=1e-3, L=iters, K=w["K"],
+                          K_boundary=50, alpha=w.get("alpha", [1.0, 1.0, 1.0]), loss_method=w["loss"], verbose=False, device=dev,
+                          backend="torch", uniform_square=bool(w.get("uniform_square", False)))
+    m.V = psp.DenseNet(d_in=w["d"] + 1, d_out=1, lr=1e-3, arch=arch, seed=42).to(dev)
+    m.train()
+    per = sorted(m.times[1:])[len(m.times[1:]) // 2]
+    return {"s_per_iteration": per, "value": (sum(m.K_log[1:]) / max(1, len(m.K_log) - 1)) / per, "unit": "trajectory-timesteps/s",
+            "iterations": iters, "plan": "composite (torch autograd, eager)"}
+
+
+def general_cpu_baseline(w, arch, iters=8):
+    """The CPU oracle (oracle/pathspace_oracle.py general_train: a port of GeneralSolver.train) on this box's host cores."""
+    from oracle import pathspace_oracle as orc
+    allc = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(allc)
+    prob = orc.make_problem("AllenCahn", d=w["d"], T=w["T"], seed=42, modus="pt", boundary_distance=w.get("boundary_distance", 1.0))
+    cfg = orc.GeneralConfig(K=w["K"], N=w["N"], delta_t=w["dt"], lr=1e-3, L=1, seed=42, K_boundary=50, alpha=tuple(w.get("alpha", (1.0, 1.0, 1.0))),
+                            loss_method=w["loss"], uniform_square=bool(w.get("uniform_square", False)))
+    V = orc.general_build(prob, cfg, arch=arch)
+    orc.general_train(prob, cfg, V=V)
+    t0, act = time.time(), 0
+    for _ in range(iters):
+        act += orc.general_train(prob, cfg, V=V)["K_log"][0]
+    el = time.time() - t0
+    return {"value": act / el, "unit": "trajectory-timesteps/s", "cores": allc, "kind": "port", "s_per_iteration": el / iters,
+            "sample": "oracle general_train, the whole workload (K=%d, N=%d), %d iterations, %.1f s, torch %s" % (w["K"], w["N"], iters, el, torch.__version__)}
+
+
 def main_general(args, psp, sharding):
     """GeneralSolver (diffusion / BSDE loss) workloads: metric counts ACTIVE trajectory-timesteps
     (K_log, reference solver.py:1152), as SURVEY.md 8d prescribes."""
     w = GENERAL_WORKLOADS[args.workload]
     dist, rank, world, dev, rehearsal = init_ranks(args)
-    prob = psp.DoubleWell_multidim_for_general_solver(d=w["d"], d_1=w["d"] // 2, d_2=w["d"] - w["d"] // 2, T=w["T"],
-                                                      eta=1, kappa=1, modus="HJB", device=dev)
+    if w.get("problem") == "AllenCahn":
+        prob = psp.AllenCahn(d=w["d"], T=w["T"], seed=42, modus="pt", device=dev)
+        prob.boundary_distance = w.get("boundary_distance", 1.0)
+    else:
+        prob = psp.DoubleWell_multidim_for_general_solver(d=w["d"], d_1=w["d"] // 2, d_2=w["d"] - w["d"] // 2, T=w["T"],
+                                                          eta=1, kappa=1, modus="HJB", device=dev)
     total = args.warmup + args.steps
+    arch = w.get("arch") or [w["H"], w["H"]]
     model = psp.GeneralSolver(problem=prob, name="bench", seed=42, delta_t=w["dt"], N=w["N"], lr=1e-3, L=total,
-                              K=w["K"] * world, K_boundary=50, alpha=[1.0, 1.0, 1.0], loss_method=w["loss"],
-                              verbose=False, device=dev, backend="native", noise="philox", mlp_dtype=w.get("mlp", "auto"))
-    model.V = psp.DenseNet(d_in=w["d"] + 1, d_out=1, lr=1e-3, arch=[w["H"], w["H"]], seed=42).to(dev)
+                              K=w["K"] * world, K_boundary=50, alpha=w.get("alpha", [1.0, 1.0, 1.0]), loss_method=w["loss"],
+                              verbose=False, device=dev, backend="native", noise="philox", mlp_dtype=w.get("mlp", "auto"),
+                              uniform_square=bool(w.get("uniform_square", False)))
+    model.V = psp.DenseNet(d_in=w["d"] + 1, d_out=1, lr=1e-3, arch=arch, seed=42).to(dev)
     plan = model._choose_plan()
     assert model.plan_name == "native"
+    deep = type(plan).__name__ == "GeneralDeepPlan"
     for l in range(args.warmup):
         plan.iteration(l)
     plan.events = []
@@ -874,11 +924,19 @@ def main_general(args, psp, sharding):
     # algorithmic flops per LAUNCHED trajectory-timestep: value net F = 2[(d+1)H + (d+1+H)H + (d+1+2H)],
     # its input gradient ~ F (reverse sweep), and the double-backward of both ~ 2 x that: forward kernel
     # 2F (+ F for the tangent part it pre-computes), backward kernel 3F  -> 6F per unit in total
-    F = 2 * ((w["d"] + 1) * w["H"] + (w["d"] + 1 + w["H"]) * w["H"] + (w["d"] + 1 + 2 * w["H"]))
+    n_in, F = w["d"] + 1, 0
+    for h_ in arch:                                              # dense-concat layers: in_i = d + 1 + sum of the earlier widths
+        F += 2 * n_in * h_
+        n_in += h_
+    F += 2 * n_in
     units = w["K"] * w["N"]
     mlp = w.get("mlp")
     bwd_dom = bwd_ms >= fwd_ms
     dom, dom_ms, dom_fl = ("gen_bwd2_kernel", bwd_ms, 3 * F) if bwd_dom else ("gen_fwd_kernel", fwd_ms, 3 * F)
+    if deep:
+        # run-time-shaped family: forward = value + reverse sweep (2 F); backward = adjoint kernel (recompute value and tangent 2 F,
+        # adjoints 2 F) + the weight-gradient GEMMs (2 F), timed together as the backward leg
+        dom, dom_fl = ("genl_adj_kernel + weight-gradient GEMMs", 6 * F) if bwd_dom else ("genl_fwd_kernel", 2 * F)
     # every product of these kernels is a value-net product: on bf16 workloads the whole kernel is priced at the bf16 MFMA
     # peak (forward always; backward only with mlp == 'bf16')
     on_bf16 = (mlp in ("bf16", "bf16_fwd") and not bwd_dom) or (mlp == "bf16" and bwd_dom)
@@ -905,7 +963,7 @@ def main_general(args, psp, sharding):
                              mlp, "f32 (f16x3 split products: every matrix product as three f16 MFMAs, fp32 accumulate)" if x3 else "f32"),
                "data": "synthetic",
                "config": {"workload": args.workload, "problem": "DoubleWell_multidim_for_general_solver",
-                          "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%d-%d-1" % (w["d"] + 1, w["H"], w["H"]),
+                          "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%s-1" % (w["d"] + 1, "-".join(str(h_) for h_ in arch)),
                           "loss": w["loss"], "active_fraction": active / (w["K"] * world * w["N"] * args.steps)},
                "roofline": {"bound": bound, "kernel": dom,
                             "achieved": achieved if bound == "mfma" else hbm_alg_gbps,
@@ -924,12 +982,21 @@ def main_general(args, psp, sharding):
                             "alg_flops_per_launched_unit": {"value_net_F": F, "fwd_kernel": 3 * F, "bwd_kernel": 3 * F},
                             "units_per_launch": units, "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms},
                "launched_units_per_s": w["K"] * world * w["N"] * args.steps / elapsed,
+               "s_per_iteration": elapsed / args.steps,
                "loss_first_last": [float(losses[0]), float(losses[-1])]}
         if coll is not None:
             coll["fraction_of_step"] = coll["per_step_ms"] / (1e3 * elapsed / args.steps)
             out["collectives"] = coll
         if getattr(plan, "range_flag", None) is not None:
             out["config"]["range_guard"] = "on (include/psp.h range_flag); fallback iterations in this run: %d" % plan.range_fallbacks()
+        if w.get("published_s_per_iter"):
+            out["vs_baseline"] = out["value"] / w["published_units_per_s"]
+            out["reference_published"] = {"s_per_iteration": list(w["published_s_per_iter"]), "units_per_s": w["published_units_per_s"],
+                                          "hardware": "unnamed CUDA GPU", "source": "experiments/diffusion-loss/Allen-Cahn.ipynb:86,115 (BASELINE.md section 1)"}
+            if world == 1 and not args.no_secondary:
+                out["also_composite_torch_plan_same_gpu"] = general_composite_leg(psp, dev, w, arch)
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = general_cpu_baseline(w, arch)
         if world == 1 and not args.no_sustained:
             n_s, t_s, c_s = 0, 0.0, []
             plan.events = None

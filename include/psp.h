@@ -388,7 +388,7 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
  * LDS images, weights as A-operand tables in global memory (csrc/genl_kernels.h).  The step is the one of psp_gen_rollout_fwd
  * (same noise counters, exit tests, h kinds, outputs); the parameter gradient is formed by
  *   psp_genl_adjoints  per sample: activations a, their tangent a' along s u^, and the adjoints zbar_i, zbar_i' of every
- *                      layer's pre-activation, written as T-layout images (block of 16 samples after block), and by the CALLER's
+ *                      layer's pre-activation, written as row-major (sample, padded feature) matrices, and by the CALLER's
  *   library GEMMs      dW_i = A[:, :in_i]^T Zbar_i + A'[:, :in_i]^T Zbar_i',  db_i = column sums of Zbar_i,
  *                      dw_out = A^T a + A'^T w,  db_out = sum a      (plain GEMMs over the sample axis).
  */
@@ -420,9 +420,9 @@ int psp_genl_rollout_fwd(const psp_genl_config* cfg, const float* params, const 
                          float* XN, float* tN, unsigned long long* kcount, void* stream);
 /* Adjoint pass over the sample blocks [blk0, blk1) of the path store (block = n * ceil(K/16) + tile; a caller with a memory
  * budget walks the store in slabs).  wY, wV: per-trajectory loss weights as for psp_gen_rollout_bwd (zero padded to
- * 16 ceil(K/16)).  out_A, out_Ad: (blk1 - blk0) x act_floats_per_block; out_Zb, out_Zdb: (blk1 - blk0) x
- * zbar_floats_per_block (layer i at block offset sum_{j<i} ceil(H_j/16)); out_av, out_wy: (blk1 - blk0) x 16 sample
- * coefficients (a of V, w of the tangent part).  Image element (ks, lane = j + 16 q) = feature 4 ks + q of sample j.
+ * 16 ceil(K/16)).  out_A, out_Ad: row-major (16 (blk1 - blk0) samples) x (act_floats_per_block / 16 padded features: segment s
+ * of the concatenation starts at column 16 seg_block_offset[s]); out_Zb, out_Zdb: (samples) x (zbar_floats_per_block / 16), layer i
+ * at column 16 sum_{j<i} ceil(H_j/16); out_av, out_wy: (samples) coefficients (a of V, w of the tangent part).
  * `tables` must hold the tables of the SAME parameters (psp_genl_rollout_fwd leaves them there). */
 int psp_genl_adjoints(const psp_genl_config* cfg, const float* params, const float* tables, const float* path, const float* ahat,
                       const float* wY, const float* wV, int64_t blk0, int64_t blk1, float* out_A, float* out_Ad,

@@ -46,7 +46,7 @@ struct GenlArgs {
     int TB, DB0;
     long long tF[GENL_MAXL], tR[GENL_MAXL];      // float offsets of the forward / reverse tables
     long long vB[GENL_MAXL], vW;                 // float offsets of the staged bias vectors / output-layer vector
-    // adjoint kernel: image-layout outputs, one block of 16 samples after the other
+    // adjoint kernel: ROW-MAJOR outputs (sample, padded feature), one block of 16 samples after the other
     float* outA; float* outAd; float* outZb; float* outZdb;
     float* out_av;                  // (16 per block) coefficient a of V, (16 per block) weight w of the tangent part
     float* out_wy;
@@ -109,39 +109,33 @@ __global__ __launch_bounds__(256) void genl_tables_kernel(const GenlArgs a) {
     }
 }
 
-// acc[m] (m < nb <= 4 output blocks starting at table block mb0) += Table . image over KS k-steps
-__device__ __forceinline__ void genl_gemm4(f32x4 (&acc)[4], const float* __restrict__ tbl, int KS, int nb, const float* img, int lane) {
+// Work split inside the workgroup: GENL_NW waves share the tile's LDS images; every product is cut by OUTPUT block -- wave w takes
+// the pairs of blocks {2 w, 2 w + 1}, {2 (w + NW), ..}, .. -- and a barrier stands between a layer and the next.  The rolled
+// k-loops are unrolled eight deep so that sixteen table operands (L2 latency ~1 us) are in flight per wave.
+constexpr int GENL_NW = 4;
+// acc[m] (m < nb <= 2 output blocks starting at the table pointer) += Table . image over KS k-steps
+__device__ __forceinline__ void genl_gemm2(f32x4 (&acc)[2], const float* __restrict__ tbl, int KS, int nb, const float* img, int lane) {
     const float* t0 = tbl + lane;
-    const size_t stride = (size_t)KS * 64;
-#pragma unroll 4
+    const float* t1 = t0 + (nb > 1 ? (size_t)KS * 64 : 0);
+#pragma unroll 8
     for (int ks = 0; ks < KS; ++ks) {
         const float b = img[ks * 64 + lane];
-        const float a0 = t0[(size_t)ks * 64];
-        const float a1 = nb > 1 ? t0[stride + (size_t)ks * 64] : 0.f;
-        const float a2 = nb > 2 ? t0[2 * stride + (size_t)ks * 64] : 0.f;
-        const float a3 = nb > 3 ? t0[3 * stride + (size_t)ks * 64] : 0.f;
+        const float a0 = t0[(size_t)ks * 64], a1 = t1[(size_t)ks * 64];
         acc[0] = mfma16(a0, b, acc[0]);
-        if (nb > 1) acc[1] = mfma16(a1, b, acc[1]);
-        if (nb > 2) acc[2] = mfma16(a2, b, acc[2]);
-        if (nb > 3) acc[3] = mfma16(a3, b, acc[3]);
+        acc[1] = mfma16(a1, b, acc[1]);            // (nb == 1: a second copy of block 0, discarded by the caller)
     }
 }
-// the same with two images sharing the table operands (value and tangent passes)
-__device__ __forceinline__ void genl_gemm4x2(f32x4 (&acc)[4], f32x4 (&acd)[4], const float* __restrict__ tbl, int KS, int nb,
+// the same with two images sharing the table operands (value and tangent passes, adjoint and tangent-adjoint passes)
+__device__ __forceinline__ void genl_gemm2x2(f32x4 (&acc)[2], f32x4 (&acd)[2], const float* __restrict__ tbl, int KS, int nb,
                                              const float* img, const float* imgd, int lane) {
     const float* t0 = tbl + lane;
-    const size_t stride = (size_t)KS * 64;
-#pragma unroll 2
+    const float* t1 = t0 + (nb > 1 ? (size_t)KS * 64 : 0);
+#pragma unroll 4
     for (int ks = 0; ks < KS; ++ks) {
         const float b = img[ks * 64 + lane], bd = imgd[ks * 64 + lane];
-        const float a0 = t0[(size_t)ks * 64];
-        const float a1 = nb > 1 ? t0[stride + (size_t)ks * 64] : 0.f;
-        const float a2 = nb > 2 ? t0[2 * stride + (size_t)ks * 64] : 0.f;
-        const float a3 = nb > 3 ? t0[3 * stride + (size_t)ks * 64] : 0.f;
+        const float a0 = t0[(size_t)ks * 64], a1 = t1[(size_t)ks * 64];
         acc[0] = mfma16(a0, b, acc[0]); acd[0] = mfma16(a0, bd, acd[0]);
-        if (nb > 1) { acc[1] = mfma16(a1, b, acc[1]); acd[1] = mfma16(a1, bd, acd[1]); }
-        if (nb > 2) { acc[2] = mfma16(a2, b, acc[2]); acd[2] = mfma16(a2, bd, acd[2]); }
-        if (nb > 3) { acc[3] = mfma16(a3, b, acc[3]); acd[3] = mfma16(a3, bd, acd[3]); }
+        acc[1] = mfma16(a1, b, acc[1]); acd[1] = mfma16(a1, bd, acd[1]);
     }
 }
 __device__ __forceinline__ void img_put(float* img, int blk, const f32x4& v, int lane) {     // T-layout block -> k-steps 4 blk .. 4 blk + 3
@@ -157,25 +151,24 @@ __device__ __forceinline__ f32x4 img_get(const float* img, int blk, int lane) {
 __device__ __forceinline__ f32x4 vec_get(const float* __restrict__ vec, int blk, int q) {   // staged vector: [(b * 4 + q) * 4 + r]
     return *reinterpret_cast<const f32x4*>(vec + (blk * 4 + q) * 4);
 }
-// one wave, one workgroup: LDS traffic of the wave is ordered by the barrier (a single-wave s_barrier costs nothing)
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }      // the workgroup's waves share the LDS images
 
 // ---- value net at the point held in image A (blocks 0 .. DB0 - 1 filled): fills the hidden segments of A (h_i) and R (relu(z_i));
 // returns V.  Padded rows / features carry zero weights and biases, so they stay exactly zero.
-__device__ __forceinline__ float genl_value(const GenlArgs& a, float* A, float* R, int lane, int q) {
+__device__ __forceinline__ float genl_value(const GenlArgs& a, float* A, float* R, int lane, int q, int wave) {
     const float* __restrict__ T = a.tables;
     for (int i = 0; i < a.L; ++i) {
         const int HBi = a.HB[i];
-        const int seg = a.off[i] + (i == 0 ? a.DB0 : a.HB[i - 1]);   // first block of this layer's output segment = its input blocks
+        const int seg = a.off[i + 1];                                // first block of this layer's output segment = its input blocks
         const int KSin = 4 * seg;
-        for (int mb0 = 0; mb0 < HBi; mb0 += 4) {
-            const int nb = (HBi - mb0) < 4 ? (HBi - mb0) : 4;
-            f32x4 acc[4];
+        for (int mb0 = 2 * wave; mb0 < HBi; mb0 += 2 * GENL_NW) {
+            const int nb = (HBi - mb0) < 2 ? 1 : 2;
+            f32x4 acc[2];
+            acc[0] = vec_get(T + a.vB[i], mb0, q);
+            acc[1] = vec_get(T + a.vB[i], mb0 + nb - 1, q);
+            genl_gemm2(acc, T + a.tF[i] + (size_t)mb0 * KSin * 64, KSin, nb, A, lane);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = m < nb ? vec_get(T + a.vB[i], mb0 + m, q) : f32x4{0.f, 0.f, 0.f, 0.f};
-            genl_gemm4(acc, T + a.tF[i] + (size_t)mb0 * KSin * 64, KSin, nb, A, lane);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 2; ++m)
                 if (m < nb) {
                     const f32x4 r = relu4(acc[m]);
                     img_put(R, seg + mb0 + m, r, lane);
@@ -184,30 +177,30 @@ __device__ __forceinline__ float genl_value(const GenlArgs& a, float* A, float* 
         }
         wave_sync();                                                 // the next layer reads what this one wrote
     }
-    float v = 0.f;
+    float v = 0.f;                                                   // (every wave forms the same sum)
     for (int b = 0; b < a.TB; ++b) v = dot4(vec_get(T + a.vW, b, q), img_get(A, b, lane), v);
     return qsum(v) + a.g.params[a.ob[a.L]];
 }
 
 // ---- grad of V w.r.t. the input segment by the reverse sweep: G (TB blocks) <- w; for i = L..1: gz = G_h * 2 relu(z),
 // G[0 .. seg) += W_i gz.  On return blocks 0 .. DB0 - 1 of G hold grad_{[x, t]} V.
-__device__ __forceinline__ void genl_input_gradient(const GenlArgs& a, const float* R, float* G, float* GZ, int lane, int q) {
+__device__ __forceinline__ void genl_input_gradient(const GenlArgs& a, const float* R, float* G, float* GZ, int lane, int q, int wave) {
     const float* __restrict__ T = a.tables;
-    for (int b = 0; b < a.TB; ++b) img_put(G, b, vec_get(T + a.vW, b, q), lane);
+    for (int b = wave; b < a.TB; b += GENL_NW) img_put(G, b, vec_get(T + a.vW, b, q), lane);
     wave_sync();
     for (int i = a.L - 1; i >= 0; --i) {
-        const int seg = a.off[i] + (i == 0 ? a.DB0 : a.HB[i - 1]);   // first block of h_i; also the number of input blocks of layer i
+        const int seg = a.off[i + 1];                                // first block of h_i; also the number of input blocks of layer i
         const int HBi = a.HB[i], KSh = 4 * HBi;
-        for (int m = 0; m < HBi; ++m) img_put(GZ, m, img_get(G, seg + m, lane) * (2.0f * img_get(R, seg + m, lane)), lane);
+        for (int m = wave; m < HBi; m += GENL_NW) img_put(GZ, m, img_get(G, seg + m, lane) * (2.0f * img_get(R, seg + m, lane)), lane);
         wave_sync();
-        for (int ob0 = 0; ob0 < seg; ob0 += 4) {
-            const int nb = (seg - ob0) < 4 ? (seg - ob0) : 4;
-            f32x4 acc[4];
+        for (int ob0 = 2 * wave; ob0 < seg; ob0 += 2 * GENL_NW) {
+            const int nb = (seg - ob0) < 2 ? 1 : 2;
+            f32x4 acc[2];
+            acc[0] = img_get(G, ob0, lane);
+            acc[1] = img_get(G, ob0 + nb - 1, lane);
+            genl_gemm2(acc, T + a.tR[i] + (size_t)ob0 * KSh * 64, KSh, nb, GZ, lane);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = m < nb ? img_get(G, ob0 + m, lane) : f32x4{0.f, 0.f, 0.f, 0.f};
-            genl_gemm4(acc, T + a.tR[i] + (size_t)ob0 * KSh * 64, KSh, nb, GZ, lane);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) if (m < nb) img_put(G, ob0 + m, acc[m], lane);
+            for (int m = 0; m < 2; ++m) if (m < nb) img_put(G, ob0 + m, acc[m], lane);
         }
         wave_sync();
     }
@@ -216,7 +209,7 @@ __device__ __forceinline__ void genl_input_gradient(const GenlArgs& a, const flo
 // LDS: A, R, G (TB blocks each) + GZ (GENL_MAXHB blocks), 1 KiB per block
 __host__ __device__ inline int genl_fwd_lds_bytes(int TB) { return (3 * TB + GENL_MAXHB) * 1024; }
 
-__global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
+__global__ __launch_bounds__(64 * GENL_NW) void genl_fwd_kernel(const GenlArgs ga) {
     PSP_COND_EXIT(ga.g);
     const GenArgs& a = ga.g;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -225,6 +218,8 @@ __global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
     float* G = R + ga.TB * 256;
     float* GZ = G + ga.TB * 256;
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool w0 = wave == 0;                                       // every wave carries the tile's state; wave 0 writes the outputs
     const int D = ga.d, DB0 = ga.DB0;
     const int t16 = blockIdx.x;
     const int k = t16 * 16 + j;
@@ -233,7 +228,7 @@ __global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
     const float dt = a.dt, sqdt = a.sqdt, sig = a.sigma_scale, Tend = a.T;
     const int TBq = D >> 4, TRq = (D & 15) >> 2, TQq = D & 3;        // position of the time input (feature index D) in the T layout
     unsigned long long nact = 0;
-    for (int i = lane; i < (3 * ga.TB + GENL_MAXHB) * 256; i += 64) lds[i] = 0.f;
+    for (int i = threadIdx.x; i < (3 * ga.TB + GENL_MAXHB) * 256; i += 64 * GENL_NW) lds[i] = 0.f;
     wave_sync();
 
     f32x4 X[GENL_MAXDB];
@@ -258,8 +253,10 @@ __global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
         }
     };
     auto put_state = [&]() {
+        if (w0) {
 #pragma unroll
-        for (int b = 0; b < GENL_MAXDB; ++b) if (b < DB0) img_put(A, b, X[b], lane);
+            for (int b = 0; b < GENL_MAXDB; ++b) if (b < DB0) img_put(A, b, X[b], lane);
+        }
         wave_sync();
     };
     put_time(t);
@@ -268,9 +265,9 @@ __global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
 
     for (int n = 0; n < a.N; ++n) {
         put_state();
-        const float Vnow = genl_value(ga, A, R, lane, q);
+        const float Vnow = genl_value(ga, A, R, lane, q, wave);
         if (n == 0) Y = Vnow;                                        // solver.py:1081 / :721
-        genl_input_gradient(ga, R, G, GZ, lane, q);
+        genl_input_gradient(ga, R, G, GZ, lane, q, wave);
         const float alivef = stopped ? 0.f : 1.f;
         auto noise_block = [&](int b) __attribute__((always_inline)) {
             f32x4 xi;
@@ -352,7 +349,7 @@ __global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
                 if (a.h_kind == GH_QUAD) u += dt * Z;
                 const f32x4 U = (actf * sig) * u;
                 const f32x4 step = move_block(b, Z, xi);
-                if (a.store_path) {                                  // the sample point is the state BEFORE the move
+                if (a.store_path && w0) {                            // the sample point is the state BEFORE the move
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         pblk[(4 * b + r) * 64] = X[b][r];
@@ -383,16 +380,17 @@ __global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
         }
         const float zc = a.adaptive ? -S : 0.f;
         Y = Y + ((minus_h + zc) * dt + Pz * sqdt) * actf;
-        if (a.store_path && q == 0) a.ahat[(size_t)n * (a.ntile16 * 16) + k] = (n == 0 ? 1.f : 0.f) - hy * dt * actf;
+        if (a.store_path && w0 && q == 0) a.ahat[(size_t)n * (a.ntile16 * 16) + k] = (n == 0 ? 1.f : 0.f) - hy * dt * actf;
         t = t + dt * actf;
         put_time(t);
         if (act && q == 0) ++nact;
         stopped = stopped || !in_time;
+        wave_sync();                                                 // the G image is read above and rewritten by the next step
     }
     // final point: V(X_N, t_N) (solver.py:1163 / :799) as an extra value-only sample
     put_state();
-    const float VN = genl_value(ga, A, R, lane, q);
-    if (a.store_path) {
+    const float VN = genl_value(ga, A, R, lane, q, wave);
+    if (a.store_path && w0) {
         float* pblk = a.path + ((size_t)a.N * a.ntile16 + t16) * PBL + lane;
 #pragma unroll
         for (int b = 0; b < GENL_MAXDB; ++b)
@@ -402,8 +400,8 @@ __global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
             }
         if (q == 0) a.ahat[(size_t)a.N * (a.ntile16 * 16) + k] = 1.f;
     }
-    if (kvalid && q == 0) { a.VN[k] = VN; a.YN[k] = Y; a.tN[k] = t; }
-    if (kvalid) {
+    if (kvalid && w0 && q == 0) { a.VN[k] = VN; a.YN[k] = Y; a.tN[k] = t; }
+    if (kvalid && w0) {
 #pragma unroll
         for (int b = 0; b < GENL_MAXDB; ++b)
 #pragma unroll
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
             }
     }
     for (int o = 1; o < 64; o <<= 1) nact += __shfl_xor(nact, o);
-    if (lane == 0 && nact) atomicAdd(a.kcount, nact);
+    if (w0 && lane == 0 && nact) atomicAdd(a.kcount, nact);
 }
 
 // =======================================================================================
@@ -422,7 +420,7 @@ __global__ __launch_bounds__(64) void genl_fwd_kernel(const GenlArgs ga) {
 // =======================================================================================
 __host__ __device__ inline int genl_adj_lds_bytes(int TB) { return (4 * TB + 2 * GENL_MAXHB) * 1024; }
 
-__global__ __launch_bounds__(64) void genl_adj_kernel(const GenlArgs ga) {
+__global__ __launch_bounds__(64 * GENL_NW) void genl_adj_kernel(const GenlArgs ga) {
     PSP_COND_EXIT(ga.g);
     const GenArgs& a = ga.g;
     const float* __restrict__ T = ga.tables;
@@ -435,6 +433,7 @@ __global__ __launch_bounds__(64) void genl_adj_kernel(const GenlArgs ga) {
     float* S1 = Zd + TB * 256;        // staging: zbar_i
     float* S2 = S1 + GENL_MAXHB * 256;  // staging: zbar_i'
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int Kpad = a.ntile16 * 16;
     const size_t PBL = (size_t)2 * DB0 * 256;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -447,21 +446,23 @@ __global__ __launch_bounds__(64) void genl_adj_kernel(const GenlArgs ga) {
         const float av = sval ? (fin ? wv : wy * ah) : 0.f;          // coefficient of grad_theta V
         const float ws = (sval && !fin) ? wy : 0.f;                  // weight of the tangent part
         const float* pb = a.path + (size_t)blk * PBL + lane;
-        for (int b = 0; b < TB; ++b) { img_put(A, b, zero4, lane); img_put(Ad, b, zero4, lane); img_put(R, b, zero4, lane); img_put(Zd, b, zero4, lane); }
-        for (int ks = 0; ks < 4 * DB0; ++ks) { A[ks * 64 + lane] = pb[ks * 64]; Ad[ks * 64 + lane] = pb[(size_t)DB0 * 256 + ks * 64]; }
+        const size_t ob = (size_t)(blk - ga.blk0);
+        wave_sync();                                                 // the previous block's sweep has finished with the images
+        for (int b = DB0 + wave; b < TB; b += GENL_NW) { img_put(R, b, zero4, lane); img_put(Zd, b, zero4, lane); }
+        for (int ks = wave; ks < 4 * DB0; ks += GENL_NW) { A[ks * 64 + lane] = pb[ks * 64]; Ad[ks * 64 + lane] = pb[(size_t)DB0 * 256 + ks * 64]; }
         wave_sync();
         // ---- recompute: z_i, z_i' (shared table operands), h_i = r^2, h_i' = 2 r z_i'
         for (int i = 0; i < ga.L; ++i) {
-            const int seg = ga.off[i] + (i == 0 ? DB0 : ga.HB[i - 1]);
+            const int seg = ga.off[i + 1];
             const int KSin = 4 * seg, HBi = ga.HB[i];
-            for (int mb0 = 0; mb0 < HBi; mb0 += 4) {
-                const int nb = (HBi - mb0) < 4 ? (HBi - mb0) : 4;
-                f32x4 acc[4], acd[4];
+            for (int mb0 = 2 * wave; mb0 < HBi; mb0 += 2 * GENL_NW) {
+                const int nb = (HBi - mb0) < 2 ? 1 : 2;
+                f32x4 acc[2], acd[2];
+                acc[0] = vec_get(T + ga.vB[i], mb0, q); acc[1] = vec_get(T + ga.vB[i], mb0 + nb - 1, q);
+                acd[0] = zero4; acd[1] = zero4;
+                genl_gemm2x2(acc, acd, T + ga.tF[i] + (size_t)mb0 * KSin * 64, KSin, nb, A, Ad, lane);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { acc[m] = m < nb ? vec_get(T + ga.vB[i], mb0 + m, q) : zero4; acd[m] = zero4; }
-                genl_gemm4x2(acc, acd, T + ga.tF[i] + (size_t)mb0 * KSin * 64, KSin, nb, A, Ad, lane);
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 2; ++m)
                     if (m < nb) {
                         const f32x4 r = relu4(acc[m]);
                         img_put(R, seg + mb0 + m, r, lane);
@@ -472,17 +473,26 @@ __global__ __launch_bounds__(64) void genl_adj_kernel(const GenlArgs ga) {
             }
             wave_sync();
         }
-        // ---- the activations leave for the weight-gradient GEMMs (image layout, block after block)
+        // ---- the activations leave for the weight-gradient GEMMs: ROW-MAJOR (sample, padded feature), 16 rows of 16 TB floats per
+        // block.  Wave w writes the rows j = w, w + NW, ..: lane l carries the four features of k-step l (and l + 64) of that
+        // sample -- four LDS reads 16 lanes apart -- as one 16-byte store: a row leaves as contiguous 1 KiB pieces.
         {
-            const size_t ob = (size_t)(blk - ga.blk0);
-            float* oA = ga.outA + ob * (size_t)TB * 256 + lane;
-            float* oD = ga.outAd + ob * (size_t)TB * 256 + lane;
-            for (int ks = 0; ks < 4 * TB; ++ks) { oA[ks * 64] = A[ks * 64 + lane]; oD[ks * 64] = Ad[ks * 64 + lane]; }
-            if (q == 0) { ga.out_av[ob * 16 + j] = av; ga.out_wy[ob * 16 + j] = ws; }
+            const int KSa = 4 * TB;
+            for (int jr = wave; jr < 16; jr += GENL_NW) {
+                float* rowA = ga.outA + (ob * 16 + jr) * (size_t)(16 * TB);
+                float* rowD = ga.outAd + (ob * 16 + jr) * (size_t)(16 * TB);
+                for (int ks = lane; ks < KSa; ks += 64) {
+                    const float* pa = A + ks * 64 + jr;
+                    const float* pd = Ad + ks * 64 + jr;
+                    *reinterpret_cast<f32x4*>(rowA + 4 * ks) = f32x4{pa[0], pa[16], pa[32], pa[48]};
+                    *reinterpret_cast<f32x4*>(rowD + 4 * ks) = f32x4{pd[0], pd[16], pd[32], pd[48]};
+                }
+            }
+            if (wave == 0 && q == 0) { ga.out_av[ob * 16 + j] = av; ga.out_wy[ob * 16 + j] = ws; }
         }
         wave_sync();
         // ---- adjoint sweep: abar = a w_out, abar' = w w_out over the whole concatenation
-        for (int b = 0; b < TB; ++b) {
+        for (int b = wave; b < TB; b += GENL_NW) {
             const f32x4 w = vec_get(T + ga.vW, b, q);
             img_put(A, b, av * w, lane);
             img_put(Ad, b, ws * w, lane);
@@ -490,46 +500,38 @@ __global__ __launch_bounds__(64) void genl_adj_kernel(const GenlArgs ga) {
         wave_sync();
         int zoff = ga.HBsum;                                           // block offset of layer i inside the Zbar images
         for (int i = ga.L - 1; i >= 0; --i) {
-            const int seg = ga.off[i] + (i == 0 ? DB0 : ga.HB[i - 1]);
+            const int seg = ga.off[i + 1];
             const int HBi = ga.HB[i], KSh = 4 * HBi;
             zoff -= HBi;
-            float* oZ = ga.outZb + ((size_t)(blk - ga.blk0) * ga.HBsum + zoff) * 256 + lane;
-            float* oZd = ga.outZdb + ((size_t)(blk - ga.blk0) * ga.HBsum + zoff) * 256 + lane;
-            for (int m = 0; m < HBi; ++m) {
+            for (int m = wave; m < HBi; m += GENL_NW) {
                 const f32x4 r = img_get(R, seg + m, lane), zd = img_get(Zd, seg + m, lane);
                 const f32x4 gh = img_get(A, seg + m, lane), ghd = img_get(Ad, seg + m, lane);
                 const f32x4 zbd = ghd * (2.0f * r);
                 const f32x4 zb = gh * (2.0f * r) + ghd * (step2(r) * zd);
                 img_put(S1, m, zb, lane); img_put(S2, m, zbd, lane);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { oZ[(4 * m + e) * 64] = zb[e]; oZd[(4 * m + e) * 64] = zbd[e]; }
             }
             wave_sync();
+            // zbar_i, zbar_i' of the block, row-major at column 16 zoff of the (sample, 16 HBsum) matrices
+            for (int jr = wave; jr < 16; jr += GENL_NW) {
+                float* rowZ = ga.outZb + (ob * 16 + jr) * (size_t)(16 * ga.HBsum) + 16 * zoff;
+                float* rowZd = ga.outZdb + (ob * 16 + jr) * (size_t)(16 * ga.HBsum) + 16 * zoff;
+                if (lane < KSh) {
+                    const float* p1 = S1 + lane * 64 + jr;
+                    const float* p2 = S2 + lane * 64 + jr;
+                    *reinterpret_cast<f32x4*>(rowZ + 4 * lane) = f32x4{p1[0], p1[16], p1[32], p1[48]};
+                    *reinterpret_cast<f32x4*>(rowZd + 4 * lane) = f32x4{p2[0], p2[16], p2[32], p2[48]};
+                }
+            }
             if (i > 0) {                                             // (the input segment's adjoint is not needed: no input gradient)
-                for (int ob0 = DB0; ob0 < seg; ob0 += 4) {           // hidden segments below layer i only
-                    const int nb = (seg - ob0) < 4 ? (seg - ob0) : 4;
-                    f32x4 acc[4], acd[4];
+                // hidden segments below layer i only; two products with the same reverse table: abar += W zbar, abar' += W zbar'
+                for (int ob0 = DB0 + 2 * wave; ob0 < seg; ob0 += 2 * GENL_NW) {
+                    const int nb = (seg - ob0) < 2 ? 1 : 2;
+                    f32x4 acc[2], acd[2];
+                    acc[0] = img_get(A, ob0, lane); acc[1] = img_get(A, ob0 + nb - 1, lane);
+                    acd[0] = img_get(Ad, ob0, lane); acd[1] = img_get(Ad, ob0 + nb - 1, lane);
+                    genl_gemm2x2(acc, acd, T + ga.tR[i] + (size_t)ob0 * KSh * 64, KSh, nb, S1, S2, lane);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        acc[m] = m < nb ? img_get(A, ob0 + m, lane) : zero4;
-                        acd[m] = m < nb ? img_get(Ad, ob0 + m, lane) : zero4;
-                    }
-                    // two products with the same reverse table: abar += W zbar, abar' += W zbar'
-                    const float* tb = T + ga.tR[i] + (size_t)ob0 * KSh * 64 + lane;
-                    const size_t stride = (size_t)KSh * 64;
-#pragma unroll 2
-                    for (int ks = 0; ks < KSh; ++ks) {
-                        const float b1 = S1[ks * 64 + lane], b2 = S2[ks * 64 + lane];
-#pragma unroll
-                        for (int m = 0; m < 4; ++m)
-                            if (m < nb) {
-                                const float aop = tb[m * stride + (size_t)ks * 64];
-                                acc[m] = mfma16(aop, b1, acc[m]);
-                                acd[m] = mfma16(aop, b2, acd[m]);
-                            }
-                    }
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) if (m < nb) { img_put(A, ob0 + m, acc[m], lane); img_put(Ad, ob0 + m, acd[m], lane); }
+                    for (int m = 0; m < 2; ++m) if (m < nb) { img_put(A, ob0 + m, acc[m], lane); img_put(Ad, ob0 + m, acd[m], lane); }
                 }
                 wave_sync();
             }

@@ -1178,7 +1178,7 @@ int psp_genl_rollout_fwd(const psp_genl_config* cfg, const float* params, const 
     if (e != hipSuccess) return fail_hip(e, "genl_tables_kernel launch");
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&psp::genl_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, p.fwd_lds);
     if (e != hipSuccess) return fail_hip(e, "genl_fwd_kernel attribute");
-    hipLaunchKernelGGL(psp::genl_fwd_kernel, dim3(p.ntile16), dim3(64), p.fwd_lds, st, a);
+    hipLaunchKernelGGL(psp::genl_fwd_kernel, dim3(p.ntile16), dim3(64 * psp::GENL_NW), p.fwd_lds, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "genl_fwd_kernel launch");
     return 0;
@@ -1203,9 +1203,9 @@ int psp_genl_adjoints(const psp_genl_config* cfg, const float* params, const flo
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&psp::genl_adj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, p.adj_lds);
     if (e != hipSuccess) return fail_hip(e, "genl_adj_kernel attribute");
     long long grid = blk1 - blk0;
-    const long long gmax = 8LL * n_cus();
+    const long long gmax = 4LL * n_cus();
     if (grid > gmax) grid = gmax;
-    hipLaunchKernelGGL(psp::genl_adj_kernel, dim3((unsigned)grid), dim3(64), p.adj_lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(psp::genl_adj_kernel, dim3((unsigned)grid), dim3(64 * psp::GENL_NW), p.adj_lds, (hipStream_t)stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "genl_adj_kernel launch");
     return 0;

@@ -6,7 +6,7 @@ Same iteration as plan_general_native.GeneralNativePlan (host RNG in the referen
 K_boundary-sized terms by autograd, Adam through psp_adam_step); what differs are the two device steps:
     psp_genl_rollout_fwd   the rollout (csrc/genl_kernels.h: activations in per-wave LDS images, weight tables in L2,
                            rolled fp32-MFMA products; shapes are run-time arguments, nothing is padded on the host)
-    psp_genl_adjoints      per sample: activations a, tangents a', adjoints zbar_i, zbar_i' as T-layout images,
+    psp_genl_adjoints      per sample: activations a, tangents a', adjoints zbar_i, zbar_i' as row-major matrices,
     + library GEMMs        dW_i = A[:, :in_i]^T Zbar_i + A'[:, :in_i]^T Zbar_i' (torch.matmul = hipBLASLt: plain GEMMs over the
                            sample axis), walked over the path store in slabs of a fixed memory budget.
 The (d, H)-templated kernels of gen_kernels.h stay the fast path for arch = [H, H], H <= 64.
@@ -167,10 +167,11 @@ class GeneralDeepPlan(GeneralNativePlan):
         for sgm, w in enumerate(widths):
             pad_of_real += [16 * seg[sgm] + c for c in range(w)]
         self.pad_of_real = torch.tensor(pad_of_real, dtype=torch.long, device=dev)             # (D0 + sum H)
-        self.zcols = []                                                                       # per layer: padded zbar columns of the real units
+        self.zcol0, self.in_pad = [], []                   # per layer: first zbar column of its units; padded width of its input
         zoff = 0
         for i in range(self.L):
-            self.zcols.append(torch.arange(16 * zoff, 16 * zoff + self.dims[1 + i], device=dev))
+            self.zcol0.append(16 * zoff)
+            self.in_pad.append(16 * seg[i + 1])
             zoff += (self.dims[1 + i] + 15) // 16
         # flat-gradient offsets in registration order W_1, b_1, .., W_out, b_out
         self.goff, o, n_in = [], 0, D0
@@ -190,33 +191,30 @@ class GeneralDeepPlan(GeneralNativePlan):
                                                 nat.ptr(self.ahat), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN_k),
                                                 nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_genl_rollout_fwd')
 
-    def _rows(self, buf, nb, width):
-        """Image-layout block buffer -> (16 nb samples) x (padded features): element (ks, lane = j + 16 q) = feature 4 ks + q."""
-        return buf[:nb * width * 16].view(nb, width // 4, 4, 16).permute(0, 3, 1, 2).reshape(nb * 16, width)
-
     def _launch_bwd(self, flat_k, st):
         sz, g = self.sizes, self.grad
         g.zero_()
         n_blocks = int(sz.n_blocks)
+        TBf, HBf = self.TBf, self.HBf
         for b0 in range(0, n_blocks, self.slab_blocks):
             b1 = min(n_blocks, b0 + self.slab_blocks)
-            nb = b1 - b0
+            ns = 16 * (b1 - b0)
             nat.check(self.lib.psp_genl_adjoints(C.byref(self.gcfg), nat.ptr(self.flat), nat.ptr(self.tables), nat.ptr(self.path),
                                                  nat.ptr(self.ahat), nat.ptr(self.wY), nat.ptr(self.wV), b0, b1, nat.ptr(self.bA),
                                                  nat.ptr(self.bAd), nat.ptr(self.bZ), nat.ptr(self.bZd), nat.ptr(self.bav),
                                                  nat.ptr(self.bwy), st), 'psp_genl_adjoints')
-            A = self._rows(self.bA, nb, self.TBf)[:, self.pad_of_real]           # (samples, D0 + sum H): real features only
-            Ad = self._rows(self.bAd, nb, self.TBf)[:, self.pad_of_real]
-            Zb = self._rows(self.bZ, nb, self.HBf)
-            Zd = self._rows(self.bZd, nb, self.HBf)
+            # row-major (sample, padded feature) matrices straight from the kernel: the GEMMs run on the padded layout (padding
+            # rows / columns are exactly zero) and only the small results are cut down to the real rows / columns
+            A, Ad = self.bA[:ns * TBf].view(ns, TBf), self.bAd[:ns * TBf].view(ns, TBf)
+            Zb, Zd = self.bZ[:ns * HBf].view(ns, HBf), self.bZd[:ns * HBf].view(ns, HBf)
             for i in range(self.L):
                 oW, ob, n_in, Hi = self.goff[i]
-                zb, zd = Zb[:, self.zcols[i]], Zd[:, self.zcols[i]]
-                dW = A[:, :n_in].t() @ zb
-                dW.addmm_(Ad[:, :n_in].t(), zd)
-                g[oW:ob].add_(dW.reshape(-1))
-                g[ob:ob + Hi].add_(zb.sum(0))
+                c0, in_pad = self.zcol0[i], self.in_pad[i]
+                dW = A[:, :in_pad].t() @ Zb[:, c0:c0 + Hi]
+                dW.addmm_(Ad[:, :in_pad].t(), Zd[:, c0:c0 + Hi])
+                g[oW:ob].add_(dW[self.pad_of_real[:n_in]].reshape(-1))
+                g[ob:ob + Hi].add_(Zb[:, c0:c0 + Hi].sum(0))
             oW, ob, n_in = self.goff_out
-            av, wy = self.bav[:nb * 16], self.bwy[:nb * 16]
-            g[oW:ob].add_(A.t() @ av + Ad.t() @ wy)
+            av, wy = self.bav[:ns], self.bwy[:ns]
+            g[oW:ob].add_((A.t() @ av + Ad.t() @ wy)[self.pad_of_real])
             g[ob:ob + 1].add_(av.sum())
