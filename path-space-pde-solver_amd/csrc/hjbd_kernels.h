@@ -841,8 +841,19 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
 // PASS 0: everything in one launch.  Wider instances split the COLUMNS over two launches so that a wave's accumulators fit
 // its registers: PASS 1 = the G columns (dW3 and db3; needs no adjoint panels), PASS 2 = the dz2 / dz1 columns (dW2, dW1,
 // db2, db1; x and h1 rows only).  Both read the same images and write disjoint parts of partial[item].
-template <int D, int H, int PASS = 0>
+// X3 (round 3; psp_hjb_config.mlp_dtype = PSP_MLP_F16X3 on a detached adaptive run, i.e. the stored image is the Brownian increment):
+// the weight-gradient outer products of phase (2) -- three quarters of the kernel's fp32 MFMAs -- contract PAIRS of sample blocks
+// on v_mfma_f32_16x16x32_f16 (k = 8 g + e: e < 4 block 2 p, e >= 4 block 2 p + 1, sample 4 g + (e & 3)): three instructions per
+// (row item, column tile, pair) instead of eight fp32 ones.  Operands are split as x = hi + lo with the UNSCALED residual
+// lo = f16(x - hi) on ONE accumulator (a.b = hi.hi + hi.lo + lo.hi): the weight-carrying column tiles (G, dz2, dz1 ~ 1 / K) are
+// scaled by a power of two that maps  max_k |w_k| sqrt(dt) 8  (a scan of all weights; |xi| < 6) into [2^6, 2^7), where their
+// residuals are normal f16 numbers; the unweighted row operands (x, h = r^2) are O(1), where a subnormal residual costs at
+// most 3e-8 absolute, fp32's own epsilon.  Stated range: the network factors between G and dz2 / dz1 stay below 256 and
+// h = r^2 below 65504.  The partial gradient is scaled back when it is written (exact).  Phase (1) runs its three adjoint
+// products through gemm_Tx on split tables of the same size as the fp32 ones.
+template <int D, int H, int PASS = 0, bool X3 = false>
 __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
+    PSP_COND_EXIT(da.h);
     using W = DGeo<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP, EXT = W::EXT;
     constexpr bool PH1 = PASS != 1;                                 // adjoint panels needed
@@ -862,7 +873,23 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
     const long long oW2 = (long long)di * hh + hh, oW3 = oW2 + (long long)(di + hh) * hh + hh;
     float* bufs = lds + W::bEx;
     const int S = da.slices, n_items = a.N * S;
-    const float gs = a.sqdt;
+    float gs = a.sqdt;
+    float ginv = 1.0f;
+    if constexpr (X3) {
+        float wm = 0.f;
+        const int Kpad = a.ntile16 * 16;
+        for (int k = tid; k < Kpad; k += nthr) wm = fmaxf(wm, fabsf(da.wts[k]));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+        if (lane == 0) bufs[sub] = wm;
+        __syncthreads();
+        const float amax = fmaxf(fmaxf(bufs[0], bufs[1]), fmaxf(bufs[2], bufs[3])) * a.sqdt * 8.0f;
+        const unsigned e = (__float_as_uint(amax) >> 23) & 0xFFu;
+        const bool ok = e >= 7u && e <= 253u;                     // zero / tiny / non-finite weights: no scaling
+        const float sc = ok ? __uint_as_float((260u - e) << 23) : 1.0f;
+        ginv = ok ? __uint_as_float((e - 6u) << 23) : 1.0f;
+        gs = a.sqdt * sc;
+    }
     typedef const __attribute__((address_space(1))) float* gptr_t;
 
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -873,12 +900,19 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
         const float* __restrict__ P = a.params + (long long)(da.per_step ? n : 0) * Pset;
         __syncthreads();                                  // the previous item's readers are done with tables and exchange
         if constexpr (PH1) {
-        stage_aop(lds + W::bW3h2, HB, KP, tid, nthr, [&](int row, int c2) {
-            return (row < hh && c2 < d) ? P[oW3 + (long long)(di + hh + row) * d + c2] : 0.f; });
-        stage_aop(lds + W::bW3h1, HB, KP, tid, nthr, [&](int row, int c2) {
-            return (row < hh && c2 < d) ? P[oW3 + (long long)(di + row) * d + c2] : 0.f; });
-        stage_aop(lds + W::bW2h, HB, 4 * HB, tid, nthr, [&](int row, int c2) {
-            return (row < hh && c2 < hh) ? P[oW2 + (long long)(di + row) * hh + c2] : 0.f; });
+        auto w3h2 = [&](int row, int c2) { return (row < hh && c2 < d) ? P[oW3 + (long long)(di + hh + row) * d + c2] : 0.f; };
+        auto w3h1 = [&](int row, int c2) { return (row < hh && c2 < d) ? P[oW3 + (long long)(di + row) * d + c2] : 0.f; };
+        auto w2h = [&](int row, int c2) { return (row < hh && c2 < hh) ? P[oW2 + (long long)(di + row) * hh + c2] : 0.f; };
+        if constexpr (X3) {                               // split tables: the same bytes as the fp32 ones (SplitGeo, hjb_kernels.h)
+            static_assert(SplitGeo<KP, DB>::floats(HB) == HB * KP * 64 && SplitGeo<4 * HB, HB>::floats(HB) == HB * 4 * HB * 64, "split tables keep the fp32 carve");
+            stage_aop_x3<KP, DB>(lds + W::bW3h2, HB, tid, nthr, w3h2);
+            stage_aop_x3<KP, DB>(lds + W::bW3h1, HB, tid, nthr, w3h1);
+            stage_aop_x3<4 * HB, HB>(lds + W::bW2h, HB, tid, nthr, w2h);
+        } else {
+            stage_aop(lds + W::bW3h2, HB, KP, tid, nthr, w3h2);
+            stage_aop(lds + W::bW3h1, HB, KP, tid, nthr, w3h1);
+            stage_aop(lds + W::bW2h, HB, 4 * HB, tid, nthr, w2h);
+        }
         }
         __syncthreads();
         const float* img_n = da.pimg + (size_t)n * a.ntile16 * (size_t)W::PBI;
@@ -927,11 +961,17 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
                 f32x4 dz2[HB], dz1[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) { dz2[m] = zero4; dz1[m] = zero4; }
-                gemm_T<HB, KP, DB>(dz2, lds + W::bW3h2, G, lane);                 // dh2 = W3h2 G
+                if constexpr (X3) gemm_Tx<HB, KP, DB, 1>(dz2, lds + W::bW3h2, G, lane);
+                else gemm_T<HB, KP, DB>(dz2, lds + W::bW3h2, G, lane);            // dh2 = W3h2 G
 #pragma unroll
                 for (int m = 0; m < HB; ++m) dz2[m] = dz2[m] * (2.0f * pR2[m]);
-                gemm_T<HB, KP, DB>(dz1, lds + W::bW3h1, G, lane);                 // dh1 = W3h1 G + W2h dz2
-                gemm_T<HB, 4 * HB, HB>(dz1, lds + W::bW2h, dz2, lane);
+                if constexpr (X3) {
+                    gemm_Tx<HB, KP, DB, 1>(dz1, lds + W::bW3h1, G, lane);
+                    gemm_Tx<HB, 4 * HB, HB, 1>(dz1, lds + W::bW2h, dz2, lane);
+                } else {
+                    gemm_T<HB, KP, DB>(dz1, lds + W::bW3h1, G, lane);             // dh1 = W3h1 G + W2h dz2
+                    gemm_T<HB, 4 * HB, HB>(dz1, lds + W::bW2h, dz2, lane);
+                }
 #pragma unroll
                 for (int m = 0; m < HB; ++m) dz1[m] = dz1[m] * (2.0f * pR1[m]);
                 float* my_ex = exch + sub * (EXT * 256);
@@ -944,6 +984,102 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
             __syncthreads();                              // (the buffer written two rounds ago is free: every wave has passed
                                                           //  the previous round's barrier after reading it)
             request1(it + 1 < R ? it + 1 : it);
+            if constexpr (X3) {
+                // ---- (2, split products) pairs of sample blocks.  ONE set of raw-operand registers: the operands of a pair are split
+                // into f16 packs first, then the next pair is requested into the same registers and the MFMAs of this pair issue
+                f32x4 gx[2][GCOL ? DB : 1], ax[2][NR], wv[2];
+                auto requestp = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int hh2 = 0; hh2 < 2; ++hh2) {
+                        const int t0 = t_lo + 4 * it + 2 * p + hh2;
+                        const bool bvalid = t0 < t_hi;
+                        const int t16 = __builtin_amdgcn_readfirstlane(bvalid ? t0 : t_hi - 1);
+                        f32x4 w4 = *reinterpret_cast<const f32x4*>(da.wts + t16 * 16 + 4 * qq);
+                        wv[hh2] = bvalid ? w4 * gs : zero4;
+                        if constexpr (GCOL) {
+#pragma unroll
+                            for (int b = 0; b < DB; ++b) gx[hh2][b] = get_F(t16, W::pXi + b * 256);
+                        }
+#pragma unroll
+                        for (int li = 0; li < NR; ++li) {
+                            const int i0 = sub + 4 * li, i = i0 < NRI ? i0 : NRI - 1;
+                            const int ofs = (i < DB) ? W::pX + i * 256
+                                          : ((i < DB + HB) ? W::pR1 + (i - DB) * 256 : W::pR2 + (i - DB - HB) * 256);
+                            ax[hh2][li] = get_F(t16, ofs);
+                        }
+                    }
+                };
+                auto pack_split = [&](const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const _Float16 h0 = (_Float16)u0[e], h1 = (_Float16)u1[e];
+                        hi[e] = h0; hi[4 + e] = h1;
+                        lo[e] = (_Float16)(u0[e] - (float)h0); lo[4 + e] = (_Float16)(u1[e] - (float)h1);
+                    }
+                };
+                requestp(0);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const float* ex0 = exch + (2 * p) * (EXT * 256);
+                    const float* ex1 = exch + (2 * p + 1) * (EXT * 256);
+                    // (a block beyond the slice: its weights are zero, its exchange tiles hold zeros -- phase (1) wrote them with
+                    //  weight zero --, and the clamped row operands it re-reads meet those zero columns only)
+                    // row packs first (they meet both column groups), then the G columns, then -- after the next pair's raw operands
+                    // have been requested into the registers the G columns came from -- the exchanged dz2 / dz1 columns: at most
+                    // DB + NR pack pairs are live at once (all NC + NR of them spilled 130 registers)
+                    f16x8 Ah[NR], Al[NR];
+#pragma unroll
+                    for (int li = 0; li < NR; ++li) {
+                        const int i = sub + 4 * li;
+                        if (i < DB) pack_split(ax[0][li], ax[1][li], Ah[li], Al[li]);
+                        else pack_split(ax[0][li] * ax[0][li], ax[1][li] * ax[1][li], Ah[li], Al[li]);      // h = r^2
+                    }
+                    auto products = [&](auto c0c, auto ncc, const auto& Bh, const auto& Bl) __attribute__((always_inline)) {
+                        constexpr int CB = decltype(c0c)::value, NB = decltype(ncc)::value;      // local columns CB .. CB + NB - 1
+#pragma unroll
+                        for (int li = 0; li < NR; ++li) {
+                            const int i = sub + 4 * li;        // row item (wave-uniform): x block, h1 block or h2 block
+                            if (i < NRI) {
+                                const int ncol = (i < DB) ? DB + 2 * HB : ((i < DB + HB) ? DB + HB : DB);
+#pragma unroll
+                                for (int c = 0; c < NB; ++c)
+                                    if (C0 + CB + c < ncol) {
+                                        acc[li][CB + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[li], Bh[c], acc[li][CB + c], 0, 0, 0);
+                                        acc[li][CB + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[li], Bl[c], acc[li][CB + c], 0, 0, 0);
+                                        acc[li][CB + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[li], Bh[c], acc[li][CB + c], 0, 0, 0);
+                                    }
+                            }
+                        }
+                    };
+                    if constexpr (GCOL) {
+                        f16x8 Bh[DB], Bl[DB];
+#pragma unroll
+                        for (int b = 0; b < DB; ++b) {
+                            const f32x4 c0 = wv[0] * gx[0][b], c1 = wv[1] * gx[1][b];
+                            if (sub == 0) bs[b] += hsum4(c0) + hsum4(c1);
+                            pack_split(c0, c1, Bh[b], Bl[b]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (p < 1) requestp(p + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        products(std::integral_constant<int, 0>{}, std::integral_constant<int, DB>{}, Bh, Bl);
+                    } else {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (p < 1) requestp(p + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (PH1) {
+                        f16x8 Bh[2 * HB], Bl[2 * HB];
+#pragma unroll
+                        for (int m = 0; m < 2 * HB; ++m) {
+                            const f32x4 c0 = tile_get(ex0 + m * 256, lane), c1 = tile_get(ex1 + m * 256, lane);
+                            if (sub == 0) bs[DB - C0 + m] += hsum4(c0) + hsum4(c1);
+                            pack_split(c0, c1, Bh[m], Bl[m]);
+                        }
+                        products(std::integral_constant<int, DB - C0>{}, std::integral_constant<int, 2 * HB>{}, Bh, Bl);
+                    }
+                }
+            } else {
             // ---- (2) weight-gradient outer products, feature on lane.  One wave per SIMD: nothing else hides the latency of the
             //      image reads, so the raw operands of block sb + 1 are requested before the MFMAs of block sb issue
             f32x4 gx[2][GCOL ? DB : 1], ax[2][NR], wv[2];
@@ -1001,6 +1137,7 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
                     }
                 }
             }
+            }
         }
         // ---- flush the item: tile (row item i, column tile c): lane (col, qq), reg rr <-> dW[16 rb + 4 qq + rr][16 cb + col]
         float* gp = da.partial + (size_t)item * (size_t)W::PP;
@@ -1017,9 +1154,10 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const int row = rbase + 4 * qq + rr;
-                            if (c < DB) gp[W::gW3 + row * D + 16 * c + col] = acc[li][cl][rr];                          // . G
-                            else if (c < DB + HB) gp[W::gW2 + row * H + 16 * (c - DB) + col] = acc[li][cl][rr];          // . dz2
-                            else gp[W::gW1 + row * H + 16 * (c - DB - HB) + col] = acc[li][cl][rr];                      // . dz1 (x rows only)
+                            const float v = ginv * acc[li][cl][rr];      // (X3: the power-of-two scale of the column tiles, taken back)
+                            if (c < DB) gp[W::gW3 + row * D + 16 * c + col] = v;                          // . G
+                            else if (c < DB + HB) gp[W::gW2 + row * H + 16 * (c - DB) + col] = v;          // . dz2
+                            else gp[W::gW1 + row * H + 16 * (c - DB - HB) + col] = v;                      // . dz1 (x rows only)
                         }
                     }
                 }
@@ -1029,7 +1167,7 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
 #pragma unroll
             for (int cl = 0; cl < NC; ++cl) {
                 const int c = C0 + cl;
-                float v = bs[cl];
+                float v = ginv * bs[cl];
                 v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
                 if (qq == 0) {
                     if (c < DB) gp[W::gb3 + 16 * c + col] = v;
@@ -1055,6 +1193,7 @@ struct DnetInstance {
     int lds_bytes_x3;                                                      // split-product forward (PSP_MLP_F16X3)
     hipError_t (*launch_fwd_x3)(const DnetArgs&, int grid, hipStream_t);
     hipError_t (*launch_adj_x3)(const DnetArgs&, int grid, hipStream_t);
+    hipError_t (*launch_bwd_x3)(const DnetArgs&, int grid, hipStream_t);   // split-product weight-gradient outer products
 };
 
 template <int D, int H>
@@ -1128,11 +1267,30 @@ struct DnetLaunch {
             return hipErrorNotSupported;
         }
     }
+    template <int PASS>
+    static hipError_t bwd_pass_x3(const DnetArgs& a, int grid, hipStream_t s) {
+        const int bytes = W::bwd_lds_floats * 4;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_bwd_kernel<D, H, PASS, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbd_bwd_kernel<D, H, PASS, true>), dim3(grid), dim3(256), bytes, s, a);
+        return hipGetLastError();
+    }
+    static hipError_t bwd_x3(const DnetArgs& a, int grid, hipStream_t s) {       // split-product outer products (detached adaptive runs)
+        if constexpr (kPasses == 1) {
+            return bwd_pass_x3<0>(a, grid, s);
+        } else if constexpr (kPasses == 2) {
+            hipError_t e = bwd_pass_x3<1>(a, grid, s);
+            return e != hipSuccess ? e : bwd_pass_x3<2>(a, grid, s);
+        } else {
+            return hipErrorNotSupported;
+        }
+    }
     static DnetInstance instance() {
         // (set / shared table sizes: the larger of the fp32 and the split layouts -- the caller allocates one region for both)
         return DnetInstance{D, H, W::lds_floats * 4, W::set_floats > W::set_floats_x3 ? W::set_floats : W::set_floats_x3, W::vec_floats,
                             W::oSets > W::oSets_x ? W::oSets : W::oSets_x, &fwd,
-                            W::PBI, W::PP, W::bwd_lds_floats * 4, kPasses, &bwd, &adj, W::lds_floats_x3 * 4, &fwd_x3, &adj_x3};
+                            W::PBI, W::PP, W::bwd_lds_floats * 4, kPasses, &bwd, &adj, W::lds_floats_x3 * 4, &fwd_x3, &adj_x3, &bwd_x3};
     }
 };
 

@@ -601,7 +601,16 @@ extern "C" int psp_dnet_rollout_bwd(const psp_dnet_config* cfg, const float* par
     a.h.params = params; a.h.K_local = b->K_local; a.h.N = b->N; a.h.ntile16 = p.ntile16; a.h.sqdt = b->sqrt_dt; a.h.dt = b->dt;
     a.pimg = const_cast<float*>(images); a.wts = w; a.partial = partial; a.slices = p.slices;
     a.d_real = cfg->d_real; a.h_real = cfg->H_real; a.time_input = cfg->time_input ? 1 : 0; a.per_step = cfg->per_step ? 1 : 0;
-    hipError_t e = p.inst.launch_bwd(a, p.bwd_grid, (hipStream_t)stream);
+    // split-product outer products where the stored image is the Brownian increment itself (detached adaptive run: the power-of-two
+    // scale of the weight-carrying tiles then needs nothing but the weights); guarded by the fp32 kernel like the other split kernels
+    const bool x3 = b->mlp_dtype == PSP_MLP_F16X3 && b->adaptive && b->store_path == 1 && p.inst.launch_bwd_x3;
+    const bool guard = x3 && b->range_flag != nullptr;
+    if (guard) { a.h.cond = b->range_flag; a.h.cond_want = 0; }
+    hipError_t e = x3 ? p.inst.launch_bwd_x3(a, p.bwd_grid, (hipStream_t)stream) : p.inst.launch_bwd(a, p.bwd_grid, (hipStream_t)stream);
+    if (e == hipSuccess && guard) {
+        a.h.cond_want = 1;
+        e = p.inst.launch_bwd(a, p.bwd_grid, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return fail_hip(e, "hjbd_bwd_kernel launch");
     return 0;
 }
