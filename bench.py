@@ -376,16 +376,21 @@ def parity_vs_one_rank(psp, sharding, dist, rank, world, dev, w, outer):
     parts = [torch.empty_like(D_s) for _ in range(world)]
     dist.all_gather(parts, D_s)
     res = None
-    if rank == 0:
-        D_1, loss_1, g_1 = run(True)
-        D_all = torch.cat(parts)
-        res = {"K_global": Kc, "ranks": world, "rccl_ranks_seen": int(round(float(ones.item()))),
-               "D_max_abs_diff": float((D_all - D_1).abs().max()), "D_max_abs": float(D_1.abs().max()),
-               "loss_rel_diff": abs(loss_s - loss_1) / abs(loss_1),
-               "grad_max_rel_diff": float((g_s - g_1).abs().max()) / float(g_1.abs().max()),
-               "tolerance": "summation order: loss 1e-6, gradient 1e-5 x max|g|"}
-        res["ok"] = bool(res["loss_rel_diff"] <= 1e-6 and res["grad_max_rel_diff"] <= 1e-5 and res["rccl_ranks_seen"] == world)
-    dist.barrier()
+    try:
+        if rank == 0:
+            D_1, loss_1, g_1 = run(True)
+            D_all = torch.cat(parts)
+            res = {"K_global": Kc, "ranks": world, "rccl_ranks_seen": int(round(float(ones.item()))),
+                   "D_max_abs_diff": float((D_all - D_1).abs().max()), "D_max_abs": float(D_1.abs().max()),
+                   "loss_rel_diff": abs(loss_s - loss_1) / abs(loss_1),
+                   "grad_max_rel_diff": float((g_s - g_1).abs().max()) / float(g_1.abs().max()),
+                   "tolerance": "summation order: loss 1e-6, gradient 1e-5 x max|g|"}
+            res["ok"] = bool(res["loss_rel_diff"] <= 1e-6 and res["grad_max_rel_diff"] <= 1e-5 and res["rccl_ranks_seen"] == world)
+    except Exception as e:                                   # noqa: BLE001 -- a self-check must not take the measurement down
+        res = {"ok": False, "error": "%s: %s" % (type(e).__name__, e), "rccl_ranks_seen": int(round(float(ones.item())))}
+    finally:
+        sharding.force_single = False
+        dist.barrier()
     return res
 
 

@@ -279,6 +279,22 @@ class Solver:
                 self.chunk_mode, id(self.problem), id(self.y_0) if hasattr(self, 'y_0') else None)
 
     def _choose_plan(self):
+        """The execution plan of train(): a native plan object, or None for the composite torch plan.  A native plan that turns
+        out not to cover the configuration while it is being built (PlanUnsupported from a constructor: e.g. mlp_dtype='bf16'
+        with a DenseNet control, an Adam with weight decay) falls back to the composite plan under backend='auto' like every
+        other out-of-catalogue combination (never an error); backend='native' raises."""
+        try:
+            return self._choose_plan_checked()
+        except PlanUnsupported as e:
+            if self.backend == 'native':
+                raise
+            if self.device.type == 'cuda':
+                warnings.warn('path-space solver: running the composite torch plan (%s)' % e)
+            self.plan_name, self.plan_reason = 'torch', str(e)
+            self._native_plan = None
+            return None
+
+    def _choose_plan_checked(self):
         if self.backend == 'torch':
             self.plan_name, self.plan_reason = 'torch', "backend='torch' requested"
             return None

@@ -253,3 +253,22 @@ def test_outer_default_nets_at_d100_match_oracle():
     ref = orc.hjb_train(oprob, ocfg, step_models=omodels)
     for got, want in zip(model.loss_log, ref["loss_log"]):
         assert math.isclose(got, want, rel_tol=1e-4), (model.loss_log, ref["loss_log"])
+
+
+def test_unsupported_matrix_mode_falls_back_under_auto():
+    """mlp_dtype='bf16' exists for MySequential controls only; with a DenseNet control the plan constructor raises
+    PlanUnsupported -- backend='auto' then runs the composite torch plan like every other out-of-catalogue combination (never an
+    error), backend='native' raises."""
+    import warnings
+    from path_space_pde_solver_amd.plan_native import PlanUnsupported
+    rec = load_golden("lqgc_d2_outer")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model = make_pkg_solver(rec["case"], torch.device("cuda:0"), backend="auto", mlp_dtype="bf16")
+        model.train()
+    assert model.plan_name == "torch" and "bf16" in model.plan_reason
+    assert any("composite torch plan" in str(x.message) for x in w)
+    for got, want in zip(model.loss_log, rec["expected"]["loss_log"]):
+        assert math.isclose(got, want, rel_tol=1e-4)
+    with pytest.raises(PlanUnsupported):
+        make_pkg_solver(rec["case"], torch.device("cuda:0"), backend="native", mlp_dtype="bf16").train()
