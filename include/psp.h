@@ -404,8 +404,10 @@ typedef struct psp_genl_sizes {
     int64_t path_bytes;       /* (N + 1) x ceil(K/16) blocks of x and s u^ images                                               */
     int64_t ahat_bytes;       /* (N + 1) x 16 ceil(K/16) floats                                                                 */
     int64_t n_params;         /* DenseNet registration order W_1, b_1, .., W_out, b_out; weights (in, out)                       */
-    int32_t act_floats_per_block;   /* 256 x TB: one 16-sample block of the A / A' outputs (TB padded 16-feature blocks)        */
-    int32_t zbar_floats_per_block;  /* 256 x sum_i ceil(H_i / 16): one block of the Zbar / Zbar' outputs                        */
+    int32_t act_floats_per_block;   /* 256 x (TB + 1): one 16-sample block of the A / A' outputs (TB padded 16-feature blocks
+                                       and one trailing block: (1, 0, .., 0) in A, zeros in A')                                  */
+    int32_t zbar_floats_per_block;  /* 256 x (sum_i ceil(H_i / 16) + 1): one block of the Zbar / Zbar' outputs; the trailing
+                                       16-float block of a row is (a, 0, .., 0) in Zbar and (w, 0, .., 0) in Zbar'               */
     int32_t n_blocks;         /* (N + 1) x ceil(K/16) sample blocks                                                              */
     int32_t fwd_workgroups;
     int32_t seg_block_offset[5];    /* first padded 16-feature block of segment s (0: input, s: h_s); [L] + ceil(H_L/16) = TB    */
@@ -422,7 +424,9 @@ int psp_genl_rollout_fwd(const psp_genl_config* cfg, const float* params, const 
  * budget walks the store in slabs).  wY, wV: per-trajectory loss weights as for psp_gen_rollout_bwd (zero padded to
  * 16 ceil(K/16)).  out_A, out_Ad: row-major (16 (blk1 - blk0) samples) x (act_floats_per_block / 16 padded features: segment s
  * of the concatenation starts at column 16 seg_block_offset[s]); out_Zb, out_Zdb: (samples) x (zbar_floats_per_block / 16), layer i
- * at column 16 sum_{j<i} ceil(H_j/16); out_av, out_wy: (samples) coefficients (a of V, w of the tangent part).
+ * at column 16 sum_{j<i} ceil(H_j/16); out_av, out_wy: (samples) coefficients (a of V, w of the tangent part), also found in
+ * the trailing block of the Zbar / Zbar' rows.  With the trailing blocks M = A^T Zbar + A'^T Zbar' holds every gradient: the
+ * weight blocks, the bias gradients in row 16 TB (ones column of A) and the output layer in column 16 sum_i ceil(H_i/16).
  * `tables` must hold the tables of the SAME parameters (psp_genl_rollout_fwd leaves them there). */
 int psp_genl_adjoints(const psp_genl_config* cfg, const float* params, const float* tables, const float* path, const float* ahat,
                       const float* wY, const float* wV, int64_t blk0, int64_t blk1, float* out_A, float* out_Ad,

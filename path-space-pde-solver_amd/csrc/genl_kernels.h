@@ -9,8 +9,8 @@
 //     sample j, hjb_kernels.h), every segment of the dense concatenation padded to whole 16-feature blocks;
 //   * weights live in global memory (L2-resident: <= 1 MB) as pre-permuted A-operand tables built per call by
 //     genl_tables_kernel, forward orientation (out^T = W^T in^T) and reverse orientation (g_in = W g_out) per layer;
-//   * every product is a rolled loop of v_mfma_f32_16x16x4_f32 over the k-steps of the input image, four output blocks at a
-//     time (one table operand per MFMA straight from L2, one LDS read per k-step shared by the four).
+//   * every product is a rolled loop of v_mfma_f32_16x16x4_f32 over the k-steps of the input image, two output blocks at a
+//     time (tables are k-quad-major: one 16-byte load per lane straight from L2 feeds four MFMAs).
 // One wave owns a 16-trajectory tile for all N steps (the time axis is sequential); the workgroup is that one wave, so a
 // small batch (K = 200: 13 tiles) still spreads over 13 CUs and nothing needs a barrier beyond wave-level LDS ordering.
 //   genl_fwd_kernel   per step: V(X, t), grad_x V by the reverse sweep, masked Euler-Maruyama step, Y update (h sees V(X, t) and
@@ -75,21 +75,22 @@ __global__ __launch_bounds__(256) void genl_tables_kernel(const GenlArgs a) {
         const int Hi = a.H[i], HBi = a.HB[i];
         const int inb = a.off[i] + (i == 0 ? a.DB0 : a.HB[i - 1]);      // input blocks of layer i = off[i + 1]
         const int KSin = 4 * inb, KSh = 4 * HBi;
-        // forward: [mb][ks][lane], row = 16 mb + rowmap(lane & 15) (an output unit), k = 4 ks + q (a padded input feature)
+        // forward: [mb][ks / 4][lane][ks & 3] (one 16-byte load per lane = the A operands of four consecutive k-steps),
+        // row = 16 mb + rowmap(lane & 15) (an output unit), k = 4 ks + q (a padded input feature)
         for (long long idx = gtid; idx < (long long)HBi * KSin * 64; idx += gn) {
-            const int lane = (int)(idx & 63);
-            const long long t = idx >> 6;
-            const int ks = (int)(t % KSin), mb = (int)(t / KSin);
+            const int lane = (int)((idx >> 2) & 63);
+            const long long t = idx >> 8;                           // (mb, ks / 4)
+            const int ks = 4 * (int)(t % (KSin / 4)) + (int)(idx & 3), mb = (int)(t / (KSin / 4));
             const int ii = lane & 15, q = lane >> 4;
             const int row = 16 * mb + 4 * (ii & 3) + (ii >> 2);
             const int rf = genl_real_feature(a, 4 * ks + q);
             T[a.tF[i] + idx] = (row < Hi && rf >= 0) ? P[a.oW[i] + rf * Hi + row] : 0.f;
         }
-        // reverse: [ob][ks][lane], row = 16 ob + rowmap (a padded input feature), k = 4 ks + q (an output unit)
+        // reverse: [ob][ks / 4][lane][ks & 3], row = 16 ob + rowmap (a padded input feature), k = 4 ks + q (an output unit)
         for (long long idx = gtid; idx < (long long)inb * KSh * 64; idx += gn) {
-            const int lane = (int)(idx & 63);
-            const long long t = idx >> 6;
-            const int ks = (int)(t % KSh), ob = (int)(t / KSh);
+            const int lane = (int)((idx >> 2) & 63);
+            const long long t = idx >> 8;
+            const int ks = 4 * (int)(t % (KSh / 4)) + (int)(idx & 3), ob = (int)(t / (KSh / 4));
             const int ii = lane & 15, q = lane >> 4;
             const int rf = genl_real_feature(a, 16 * ob + 4 * (ii & 3) + (ii >> 2));
             const int col = 4 * ks + q;
@@ -113,29 +114,37 @@ __global__ __launch_bounds__(256) void genl_tables_kernel(const GenlArgs a) {
 // the pairs of blocks {2 w, 2 w + 1}, {2 (w + NW), ..}, .. -- and a barrier stands between a layer and the next.  The rolled
 // k-loops are unrolled eight deep so that sixteen table operands (L2 latency ~1 us) are in flight per wave.
 constexpr int GENL_NW = 4;
-// acc[m] (m < nb <= 2 output blocks starting at the table pointer) += Table . image over KS k-steps
+// acc[m] (m < nb <= 2 output blocks starting at the table pointer) += Table . image over KS k-steps (KS a multiple of 4: whole
+// 16-feature blocks).  One 16-byte table load per lane feeds four MFMAs; four quads are requested per trip, i.e. 8 KiB of
+// operands in flight per wave and block -- the products are bound by the L2 latency of these loads, not by the matrix pipe
 __device__ __forceinline__ void genl_gemm2(f32x4 (&acc)[2], const float* __restrict__ tbl, int KS, int nb, const float* img, int lane) {
-    const float* t0 = tbl + lane;
-    const float* t1 = t0 + (nb > 1 ? (size_t)KS * 64 : 0);
-#pragma unroll 8
-    for (int ks = 0; ks < KS; ++ks) {
-        const float b = img[ks * 64 + lane];
-        const float a0 = t0[(size_t)ks * 64], a1 = t1[(size_t)ks * 64];
-        acc[0] = mfma16(a0, b, acc[0]);
-        acc[1] = mfma16(a1, b, acc[1]);            // (nb == 1: a second copy of block 0, discarded by the caller)
+    const f32x4* t0 = reinterpret_cast<const f32x4*>(tbl) + lane;
+    const f32x4* t1 = t0 + (nb > 1 ? (size_t)(KS / 4) * 64 : 0);
+#pragma unroll 4
+    for (int k4 = 0; k4 < KS / 4; ++k4) {
+        const f32x4 a0 = t0[(size_t)k4 * 64], a1 = t1[(size_t)k4 * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float b = img[(4 * k4 + r) * 64 + lane];
+            acc[0] = mfma16(a0[r], b, acc[0]);
+            acc[1] = mfma16(a1[r], b, acc[1]);        // (nb == 1: a second copy of block 0, discarded by the caller)
+        }
     }
 }
 // the same with two images sharing the table operands (value and tangent passes, adjoint and tangent-adjoint passes)
 __device__ __forceinline__ void genl_gemm2x2(f32x4 (&acc)[2], f32x4 (&acd)[2], const float* __restrict__ tbl, int KS, int nb,
                                              const float* img, const float* imgd, int lane) {
-    const float* t0 = tbl + lane;
-    const float* t1 = t0 + (nb > 1 ? (size_t)KS * 64 : 0);
+    const f32x4* t0 = reinterpret_cast<const f32x4*>(tbl) + lane;
+    const f32x4* t1 = t0 + (nb > 1 ? (size_t)(KS / 4) * 64 : 0);
 #pragma unroll 4
-    for (int ks = 0; ks < KS; ++ks) {
-        const float b = img[ks * 64 + lane], bd = imgd[ks * 64 + lane];
-        const float a0 = t0[(size_t)ks * 64], a1 = t1[(size_t)ks * 64];
-        acc[0] = mfma16(a0, b, acc[0]); acd[0] = mfma16(a0, bd, acd[0]);
-        acc[1] = mfma16(a1, b, acc[1]); acd[1] = mfma16(a1, bd, acd[1]);
+    for (int k4 = 0; k4 < KS / 4; ++k4) {
+        const f32x4 a0 = t0[(size_t)k4 * 64], a1 = t1[(size_t)k4 * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float b = img[(4 * k4 + r) * 64 + lane], bd = imgd[(4 * k4 + r) * 64 + lane];
+            acc[0] = mfma16(a0[r], b, acc[0]); acd[0] = mfma16(a0[r], bd, acd[0]);
+            acc[1] = mfma16(a1[r], b, acc[1]); acd[1] = mfma16(a1[r], bd, acd[1]);
+        }
     }
 }
 __device__ __forceinline__ void img_put(float* img, int blk, const f32x4& v, int lane) {     // T-layout block -> k-steps 4 blk .. 4 blk + 3
@@ -478,17 +487,29 @@ __global__ __launch_bounds__(64 * GENL_NW) void genl_adj_kernel(const GenlArgs g
         // sample -- four LDS reads 16 lanes apart -- as one 16-byte store: a row leaves as contiguous 1 KiB pieces.
         {
             const int KSa = 4 * TB;
+            // Every row carries one more 16-float block: (1, 0, ..) behind a, zeros behind a' -- the ones column makes the
+            // bias gradients (column sums of zbar) a row of the same GEMM that forms the weight gradients.
             for (int jr = wave; jr < 16; jr += GENL_NW) {
-                float* rowA = ga.outA + (ob * 16 + jr) * (size_t)(16 * TB);
-                float* rowD = ga.outAd + (ob * 16 + jr) * (size_t)(16 * TB);
+                float* rowA = ga.outA + (ob * 16 + jr) * (size_t)(16 * TB + 16);
+                float* rowD = ga.outAd + (ob * 16 + jr) * (size_t)(16 * TB + 16);
                 for (int ks = lane; ks < KSa; ks += 64) {
                     const float* pa = A + ks * 64 + jr;
                     const float* pd = Ad + ks * 64 + jr;
                     *reinterpret_cast<f32x4*>(rowA + 4 * ks) = f32x4{pa[0], pa[16], pa[32], pa[48]};
                     *reinterpret_cast<f32x4*>(rowD + 4 * ks) = f32x4{pd[0], pd[16], pd[32], pd[48]};
                 }
+                if (lane < 4) {
+                    *reinterpret_cast<f32x4*>(rowA + 16 * TB + 4 * lane) = f32x4{lane == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(rowD + 16 * TB + 4 * lane) = zero4;
+                }
             }
-            if (wave == 0 && q == 0) { ga.out_av[ob * 16 + j] = av; ga.out_wy[ob * 16 + j] = ws; }
+            if (wave == 0) {                                         // last block of the zbar rows: (a, 0, ..) and (w, 0, ..)
+                float* zr = ga.outZb + (ob * 16 + j) * (size_t)(16 * ga.HBsum + 16) + 16 * ga.HBsum + 4 * q;
+                float* zd = ga.outZdb + (ob * 16 + j) * (size_t)(16 * ga.HBsum + 16) + 16 * ga.HBsum + 4 * q;
+                *reinterpret_cast<f32x4*>(zr) = f32x4{q == 0 ? av : 0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(zd) = f32x4{q == 0 ? ws : 0.f, 0.f, 0.f, 0.f};
+                if (q == 0) { ga.out_av[ob * 16 + j] = av; ga.out_wy[ob * 16 + j] = ws; }
+            }
         }
         wave_sync();
         // ---- adjoint sweep: abar = a w_out, abar' = w w_out over the whole concatenation
@@ -513,8 +534,8 @@ __global__ __launch_bounds__(64 * GENL_NW) void genl_adj_kernel(const GenlArgs g
             wave_sync();
             // zbar_i, zbar_i' of the block, row-major at column 16 zoff of the (sample, 16 HBsum) matrices
             for (int jr = wave; jr < 16; jr += GENL_NW) {
-                float* rowZ = ga.outZb + (ob * 16 + jr) * (size_t)(16 * ga.HBsum) + 16 * zoff;
-                float* rowZd = ga.outZdb + (ob * 16 + jr) * (size_t)(16 * ga.HBsum) + 16 * zoff;
+                float* rowZ = ga.outZb + (ob * 16 + jr) * (size_t)(16 * ga.HBsum + 16) + 16 * zoff;
+                float* rowZd = ga.outZdb + (ob * 16 + jr) * (size_t)(16 * ga.HBsum + 16) + 16 * zoff;
                 if (lane < KSh) {
                     const float* p1 = S1 + lane * 64 + jr;
                     const float* p2 = S2 + lane * 64 + jr;

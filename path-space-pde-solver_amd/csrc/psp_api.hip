@@ -1157,8 +1157,8 @@ int psp_genl_query(const psp_genl_config* cfg, psp_genl_sizes* out) {
     out->path_bytes = cfg->base.store_path ? nblk * 2 * p.a.DB0 * 256 * 4 : 0;
     out->ahat_bytes = nblk * 16 * 4;
     out->n_params = p.n_params;
-    out->act_floats_per_block = p.a.TB * 256;
-    out->zbar_floats_per_block = p.a.HBsum * 256;
+    out->act_floats_per_block = (p.a.TB + 1) * 256;              // rows of 16 TB + 16 floats (the ones block)
+    out->zbar_floats_per_block = (p.a.HBsum + 1) * 256;          // rows of 16 HBsum + 16 floats (the a / w block)
     out->n_blocks = (int32_t)nblk;
     out->fwd_workgroups = p.ntile16;
     for (int i = 0; i <= p.a.L; ++i) out->seg_block_offset[i] = p.a.off[i];

@@ -149,7 +149,8 @@ class GeneralDeepPlan(GeneralNativePlan):
         self.last_v_l2 = None
         self.events = None
         # ---- slab buffers of the adjoint pass and the index maps from padded features to real parameter rows / columns
-        self.TBf, self.HBf = sz.act_floats_per_block // 16, sz.zbar_floats_per_block // 16      # padded widths of a / zbar rows
+        # padded widths of the a / zbar rows, without their trailing block (ones | a, w)
+        self.TBf, self.HBf = sz.act_floats_per_block // 16 - 16, sz.zbar_floats_per_block // 16 - 16
         per_block = 4 * (2 * sz.act_floats_per_block + 2 * sz.zbar_floats_per_block + 32)
         self.slab_blocks = max(1, min(int(sz.n_blocks), self.ADJ_BUDGET_BYTES // per_block))
         nb = self.slab_blocks
@@ -191,11 +192,30 @@ class GeneralDeepPlan(GeneralNativePlan):
                                                 nat.ptr(self.ahat), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN_k),
                                                 nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_genl_rollout_fwd')
 
+    MAX_BATCHES = 32             # split-K factor of the weight-gradient products
+    MIN_ROWS = 2048              # ... and the fewest samples a batch is worth
+
+    @classmethod
+    def _atb(cls, A, B):
+        """A^T B for tall operands (samples x features): the sample axis is cut into up to MAX_BATCHES equal batches so that
+        the product is a batched GEMM with many workgroups (one plain GEMM has in x H / tile^2 ~ 60 output tiles for a
+        contraction over up to millions of samples and runs on 60 CUs), then summed over the batches."""
+        n = A.shape[0]
+        nb = max(1, min(cls.MAX_BATCHES, n // cls.MIN_ROWS))
+        if nb == 1:
+            return A.t() @ B
+        R = n // nb
+        out = torch.bmm(A[:nb * R].view(nb, R, A.shape[1]).transpose(1, 2), B[:nb * R].view(nb, R, B.shape[1])).sum(0)
+        if nb * R < n:
+            out = out + A[nb * R:].t() @ B[nb * R:]
+        return out
+
     def _launch_bwd(self, flat_k, st):
         sz, g = self.sizes, self.grad
         g.zero_()
         n_blocks = int(sz.n_blocks)
         TBf, HBf = self.TBf, self.HBf
+        WA, WZ = TBf + 16, HBf + 16
         for b0 in range(0, n_blocks, self.slab_blocks):
             b1 = min(n_blocks, b0 + self.slab_blocks)
             ns = 16 * (b1 - b0)
@@ -203,18 +223,18 @@ class GeneralDeepPlan(GeneralNativePlan):
                                                  nat.ptr(self.ahat), nat.ptr(self.wY), nat.ptr(self.wV), b0, b1, nat.ptr(self.bA),
                                                  nat.ptr(self.bAd), nat.ptr(self.bZ), nat.ptr(self.bZd), nat.ptr(self.bav),
                                                  nat.ptr(self.bwy), st), 'psp_genl_adjoints')
-            # row-major (sample, padded feature) matrices straight from the kernel: the GEMMs run on the padded layout (padding
-            # rows / columns are exactly zero) and only the small results are cut down to the real rows / columns
-            A, Ad = self.bA[:ns * TBf].view(ns, TBf), self.bAd[:ns * TBf].view(ns, TBf)
-            Zb, Zd = self.bZ[:ns * HBf].view(ns, HBf), self.bZd[:ns * HBf].view(ns, HBf)
+            # row-major (sample, padded feature) matrices straight from the kernel, each row with one trailing block: ones
+            # behind a, (a | w) behind zbar.  ONE pair of batched GEMMs forms M = A^T Zbar + A'^T Zbar' on the padded layout:
+            # weight blocks, bias gradients (row TBf: the ones column) and the output layer (column HBf) at once.  Padding rows /
+            # columns are exactly zero; the blocks of M no layer needs are the price of two launches instead of 2 L + 2.
+            A, Ad = self.bA[:ns * WA].view(ns, WA), self.bAd[:ns * WA].view(ns, WA)
+            Zb, Zd = self.bZ[:ns * WZ].view(ns, WZ), self.bZd[:ns * WZ].view(ns, WZ)
+            M = self._atb(A, Zb) + self._atb(Ad, Zd)                       # (TBf + 16, HBf + 16)
             for i in range(self.L):
                 oW, ob, n_in, Hi = self.goff[i]
-                c0, in_pad = self.zcol0[i], self.in_pad[i]
-                dW = A[:, :in_pad].t() @ Zb[:, c0:c0 + Hi]
-                dW.addmm_(Ad[:, :in_pad].t(), Zd[:, c0:c0 + Hi])
-                g[oW:ob].add_(dW[self.pad_of_real[:n_in]].reshape(-1))
-                g[ob:ob + Hi].add_(Zb[:, c0:c0 + Hi].sum(0))
+                c0 = self.zcol0[i]
+                g[oW:ob].add_(M[self.pad_of_real[:n_in], c0:c0 + Hi].reshape(-1))
+                g[ob:ob + Hi].add_(M[TBf, c0:c0 + Hi])
             oW, ob, n_in = self.goff_out
-            av, wy = self.bav[:ns], self.bwy[:ns]
-            g[oW:ob].add_((A.t() @ av + Ad.t() @ wy)[self.pad_of_real])
-            g[ob:ob + 1].add_(av.sum())
+            g[oW:ob].add_(M[self.pad_of_real, HBf])
+            g[ob:ob + 1].add_(M[TBf, HBf:HBf + 1])
