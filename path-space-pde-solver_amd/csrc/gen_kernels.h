@@ -1152,13 +1152,7 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     if constexpr (X3) {
         // split f16 outer products over pairs of sample blocks (the structure of the bf16 consumers below; fp32 path store)
         auto split2 = [&](const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) __attribute__((always_inline)) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {                 // hi = f16(x), lo = f16(x - hi): the unscaled residual (header comment)
-                _Float16 h = (_Float16)u0[e];
-                hi[e] = h; lo[e] = (_Float16)(u0[e] - (float)h);
-                h = (_Float16)u1[e];
-                hi[4 + e] = h; lo[4 + e] = (_Float16)(u1[e] - (float)h);
-            }
+            split8u(u0, u1, hi, lo);                      // hi = f16(x), lo = f16(x - hi): the unscaled residual (header comment)
         };
         auto weights_of = [&](long long c0, f32x4& w4, f32x4& a4) __attribute__((always_inline)) {
             const bool sval = c0 < nblk;

@@ -153,7 +153,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        // three-input xor in one instruction (v_bitop3_b32, truth table 0x96; gfx9 has no v_xor3_b32)
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -162,11 +163,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // two Box-Muller pairs -> four N(0,1) values
 __device__ __forceinline__ f32x4 normal4(const uint32_t (&r)[4]) {
-    const float s24 = 1.0f / 16777216.0f;
-    const float u0 = ((float)(r[0] >> 8) + 0.5f) * s24;
-    const float u1 = ((float)(r[1] >> 8) + 0.5f) * s24;
-    const float u2 = ((float)(r[2] >> 8) + 0.5f) * s24;
-    const float u3 = ((float)(r[3] >> 8) + 0.5f) * s24;
+    // u = (m + 1/2) 2^-24, m = the upper 24 bits: as ONE fma (m 2^-24 + 2^-25 rounds once; (m + 0.5) 2^-24 rounds the sum and
+    // scales it exactly by a power of two -- the same value)
+    const float s24 = 1.0f / 16777216.0f, h24 = 0.5f / 16777216.0f;
+    const float u0 = __builtin_fmaf((float)(r[0] >> 8), s24, h24);
+    const float u1 = __builtin_fmaf((float)(r[1] >> 8), s24, h24);
+    const float u2 = __builtin_fmaf((float)(r[2] >> 8), s24, h24);
+    const float u3 = __builtin_fmaf((float)(r[3] >> 8), s24, h24);
     // -2 ln u = -2 ln2 * log2 u ; sin/cos hardware ops take revolutions
     const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
     const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
@@ -333,7 +336,42 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
     lo = (_Float16)((v - (float)hi) * kSplitScale);
 }
-// dst: per 16-row block mb [S][hi | lo][lane] f16x8, then the trailing block ([lane] fp32 or [hi | lo][lane] f16x4)
+// Packs of four / eight values (two 16-feature blocks of the T layout side by side).  Plain C on purpose.  Round 3 tried the
+// split as inline asm -- v_cvt_pk_f16_f32, one packed multiply and v_fma_mixlo/hi_f16 (lo = f16(fma(hi, -2048, 2048 x)), bit-identical,
+// two instructions per value instead of the compiler's three) -- and took it out again: the hazard recogniser does not look into
+// inline asm, and on this chip (a) an MFMA result read by a VALU instruction, (b) a half-register write followed directly by an
+// MFMA read, and (c) a VALU write to the dead SrcC of an MFMA still in flight (v[a:b] = mfma(.., v[c:d]) is not in place) all need
+// software wait states that the compiler inserts only for its own instructions.  (a) gave a 2e-4 gradient error and NaN at
+// d > 256, (c) run-to-run different gradients (499 entries, 6e-5) in gen_bwd2_kernel<.., X3>; the variant that avoids all three
+// needs extra moves and saves half an instruction per value (1 - 2 % of a kernel) -- not worth an unprovable rule set.
+__device__ __forceinline__ void split4(const f32x4& u, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split_f16(u[e], h, l);
+        hi[e] = h; lo[e] = l;
+    }
+}
+__device__ __forceinline__ void split8(const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split_f16(u0[e], h, l);
+        hi[e] = h; lo[e] = l;
+        split_f16(u1[e], h, l);
+        hi[4 + e] = h; lo[4 + e] = l;
+    }
+}
+// ... with the UNSCALED residual lo = f16(x - hi) (the weight-gradient outer products: one accumulator for all three terms)
+__device__ __forceinline__ void split8u(const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h = (_Float16)u0[e];
+        hi[e] = h; lo[e] = (_Float16)(u0[e] - (float)h);
+        h = (_Float16)u1[e];
+        hi[4 + e] = h; lo[4 + e] = (_Float16)(u1[e] - (float)h);
+    }
+}
 template <int KS, int INB, class F>
 __device__ __forceinline__ void stage_aop_x3(float* dstf, int MB, int tid, int nthr, F src) {
     using SG = SplitGeo<KS, INB>;
@@ -375,10 +413,15 @@ __device__ __forceinline__ void stage_aop_x3(float* dstf, int MB, int tid, int n
         }
     }
 }
-// out^T (MB blocks) += W . in^T with fp32-grade products on the f16 pipe; A operands prefetched one chunk of units ahead
-// (CU: units (16-row block x 32-deep step) fetched per chunk -- 2 hides the LDS latency better, 1 costs 16 registers less)
-template <int MB, int KS, int INB, int CU = 2>
-__device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane) {
+// out^T (MB blocks) += W . in^T with fp32-grade products on the f16 pipe; A operands prefetched through a ring of 2 CU slots
+// (unit = 16-row block x 32-deep step; CU = 2: four slots, reads three units ahead; CU = 1: two slots, 16 registers less)
+struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
+// `between(u)` runs after the products of unit u (u = S * MB + mb): the forward kernels hand their path stores over in
+// portions so that they stand BETWEEN the MFMAs (the scheduler clusters them into bursts of 28 - 32 otherwise, and a burst
+// blocks the in-order wave while the store path drains at 16 B/clk per CU); fences with a functor do not let VMEM cross.
+template <int MB, int KS, int INB, int CU = 2, class BT = NoBetween>
+__device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane, BT between = BT()) {
+    constexpr int kFence = std::is_same<BT, NoBetween>::value ? kFenceMask : (0x1 | 0x2 | 0x4);
     using SG = SplitGeo<KS, INB>;
     constexpr int NS = SG::NS;
     static_assert(MB * SG::per_mb * 4 <= 65536, "table exceeds the 16-bit ds_read immediate offset");
@@ -387,49 +430,33 @@ __device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, con
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) corr[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (NS > 0) {
+        // units u = S * MB + mb in a ring of R = 2 CU operand slots, each unit's pair of 16-byte reads issued R - 1 units
+        // (3 (R - 1) MFMAs) before its products: with CU = 2 that is 9 MFMAs of distance for the 32 registers a double-buffered
+        // chunk of two gave 6 for (the forward's waves spent a quarter of their cycles in s_waitcnt on these reads)
         const f16x8* tbl = reinterpret_cast<const f16x8*>(wlds) + lane;
-        constexpr int NU = NS * MB, NCH = cdiv(NU, CU);
-        f16x8 ah[2][CU], al[2][CU];
+        constexpr int NU = NS * MB, R = 2 * CU, PF = R - 1;
+        f16x8 ah[R], al[R];
 #pragma unroll
-        for (int kk = 0; kk < CU; ++kk)
-            if (kk < NU) {
-                ah[0][kk] = tbl[((kk % MB) * SG::per_mb + (kk / MB) * 512) / 4];
-                al[0][kk] = tbl[((kk % MB) * SG::per_mb + (kk / MB) * 512) / 4 + 64];
+        for (int u = 0; u < PF; ++u)
+            if (u < NU) {
+                ah[u % R] = tbl[((u % MB) * SG::per_mb + (u / MB) * 512) / 4];
+                al[u % R] = tbl[((u % MB) * SG::per_mb + (u / MB) * 512) / 4 + 64];
             }
         f16x8 bh, bl;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) {
-#pragma unroll
-                for (int kk = 0; kk < CU; ++kk) {
-                    const int u = (c + 1) * CU + kk;
-                    if (u < NU) {
-                        ah[(c + 1) & 1][kk] = tbl[((u % MB) * SG::per_mb + (u / MB) * 512) / 4];
-                        al[(c + 1) & 1][kk] = tbl[((u % MB) * SG::per_mb + (u / MB) * 512) / 4 + 64];
-                    }
-                }
+        for (int u = 0; u < NU; ++u) {
+            if (u + PF < NU) {
+                const int v = u + PF;
+                ah[v % R] = tbl[((v % MB) * SG::per_mb + (v / MB) * 512) / 4];
+                al[v % R] = tbl[((v % MB) * SG::per_mb + (v / MB) * 512) / 4 + 64];
             }
-#pragma unroll
-            for (int kk = 0; kk < CU; ++kk) {
-                const int u = c * CU + kk;
-                if (u < NU) {
-                    const int S = u / MB, mb = u % MB;
-                    if (mb == 0) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            _Float16 h, l;
-                            split_f16(in[2 * S][e], h, l);
-                            bh[e] = h; bl[e] = l;
-                            split_f16(in[2 * S + 1][e], h, l);
-                            bh[4 + e] = h; bl[4 + e] = l;
-                        }
-                    }
-                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c & 1][kk], bh, acc[mb], 0, 0, 0);
-                    corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c & 1][kk], bl, corr[mb], 0, 0, 0);
-                    corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c & 1][kk], bh, corr[mb], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(kFenceMask);
+            const int S = u / MB, mb = u % MB;
+            if (mb == 0) split8(in[2 * S], in[2 * S + 1], bh, bl);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u % R], bh, acc[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u % R], bl, corr[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u % R], bh, corr[mb], 0, 0, 0);
+            between(u);
+            __builtin_amdgcn_sched_barrier(kFence);
         }
     }
     if constexpr (SG::ODD_F32) {
@@ -439,12 +466,7 @@ __device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, con
     }
     if constexpr (SG::ODD_H16) {
         f16x4 bh, bl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 h, l;
-            split_f16(in[INB - 1][e], h, l);
-            bh[e] = h; bl[e] = l;
-        }
+        split4(in[INB - 1], bh, bl);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const f16x4* p = reinterpret_cast<const f16x4*>(wlds + mb * SG::per_mb + NS * 512) + lane;
@@ -452,6 +474,69 @@ __device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, con
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_hi, bh, acc[mb], 0, 0, 0);
             corr[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_hi, bl, corr[mb], 0, 0, 0);
             corr[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_lo, bh, corr[mb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = acc[mb] + kSplitInv * corr[mb];
+}
+
+// gemm_Tx for an input panel that feeds TWO products (the state: W1 x and (dt A) x of the same step): the panel is split once
+// by split_panel8 and both products read the packs.
+template <int INB>
+__device__ __forceinline__ void split_panel8(const f32x4 (&in)[INB], f16x8 (&bh)[INB / 2 > 0 ? INB / 2 : 1], f16x8 (&bl)[INB / 2 > 0 ? INB / 2 : 1]) {
+#pragma unroll
+    for (int S = 0; S < INB / 2; ++S) split8(in[2 * S], in[2 * S + 1], bh[S], bl[S]);
+}
+template <int MB, int KS, int INB, int CU = 2, class BT = NoBetween>
+__device__ __forceinline__ void gemm_Txs(f32x4 (&acc)[MB], const float* wlds, const f16x8 (&bh)[INB / 2 > 0 ? INB / 2 : 1],
+                                         const f16x8 (&bl)[INB / 2 > 0 ? INB / 2 : 1], const f32x4& last, int lane, BT between = BT()) {
+    constexpr int kFence = std::is_same<BT, NoBetween>::value ? kFenceMask : (0x1 | 0x2 | 0x4);
+    using SG = SplitGeo<KS, INB>;
+    constexpr int NS = SG::NS;
+    lane = opaque_i(lane);
+    f32x4 corr[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) corr[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NS > 0) {
+        const f16x8* tbl = reinterpret_cast<const f16x8*>(wlds) + lane;
+        constexpr int NU = NS * MB, R = 2 * CU, PF = R - 1;
+        f16x8 ah[R], al[R];
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (u < NU) {
+                ah[u % R] = tbl[((u % MB) * SG::per_mb + (u / MB) * 512) / 4];
+                al[u % R] = tbl[((u % MB) * SG::per_mb + (u / MB) * 512) / 4 + 64];
+            }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + PF < NU) {
+                const int v = u + PF;
+                ah[v % R] = tbl[((v % MB) * SG::per_mb + (v / MB) * 512) / 4];
+                al[v % R] = tbl[((v % MB) * SG::per_mb + (v / MB) * 512) / 4 + 64];
+            }
+            const int S = u / MB, mb = u % MB;
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u % R], bh[S], acc[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u % R], bl[S], corr[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u % R], bh[S], corr[mb], 0, 0, 0);
+            between(u);
+            __builtin_amdgcn_sched_barrier(kFence);
+        }
+    }
+    if constexpr (SG::ODD_F32) {
+        const float bop = last[0];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma16(wlds[mb * SG::per_mb + NS * 512 + lane], bop, acc[mb]);
+    }
+    if constexpr (SG::ODD_H16) {
+        f16x4 b4h, b4l;
+        split4(last, b4h, b4l);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const f16x4* p = reinterpret_cast<const f16x4*>(wlds + mb * SG::per_mb + NS * 512) + lane;
+            const f16x4 a_hi = p[0], a_lo = p[64];
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_hi, b4h, acc[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_hi, b4l, corr[mb], 0, 0, 0);
+            corr[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_lo, b4h, corr[mb], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -636,6 +721,9 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
     const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
+    // FAST instances always keep the path (the launcher sends store_path = 0 to the general instance): without the
+    // wave-uniform branch the stores share a scheduling region with the products instead of standing as bursts of 28 - 32
+    const bool do_store = FAST ? true : (a.store_path != 0);
     double sD = 0.0, sD2 = 0.0;
     if (wave_valid) {
         // per-lane-q views of the staged vectors
@@ -672,7 +760,16 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             const f32x4* vdr = vecs + (G::vdr - G::fVec) / 4;
             const f32x4* vrun = vecs + (G::vrun - G::fVec) / 4;
             float* pblk = a.path + ((size_t)n * a.ntile16 + t16) * (size_t)G::PB + lane;
-            if (a.store_path) {
+            // portion [u n / NU, (u + 1) n / NU) of n stores behind unit u of NU (split-product instances: see gemm_Tx)
+            auto x_store = [&](int u, int NU) __attribute__((always_inline)) {
+                if (do_store) {
+#pragma unroll
+                    for (int ks = 0; ks < 4 * DB; ++ks)
+                        if (ks >= u * (4 * DB) / NU && ks < (u + 1) * (4 * DB) / NU)
+                            PSP_PATH_STORE(pblk + (G::pX / 64 + ks) * 64, X[ks >> 2][ks & 3]);
+                }
+            };
+            if (!X3 && do_store) {
 #pragma unroll
                 for (int ks = 0; ks < 4 * DB; ++ks) PSP_PATH_STORE(pblk + (G::pX / 64 + ks) * 64, X[ks >> 2][ks & 3]);
             }
@@ -680,7 +777,26 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 h1[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h1[m] = vb1[m * 4] + tn * vw1t[m * 4];
-            if constexpr (X3) gemm_Tx<HB, KSD, DB>(h1, lds + oW1, X, lane);
+            // split products with a dense drift: the state panel is split ONCE for W1 x and (dt A) x (Tn = X + dt A X is formed
+            // here, next to the first layer, instead of after the control)
+            f32x4 Tn[DB];
+            const bool early_drift = X3 && a.drift_kind == DRIFT_DENSE;
+            if constexpr (X3) {
+                if (a.drift_kind == DRIFT_DENSE) {
+                    f16x8 xh[DB / 2 > 0 ? DB / 2 : 1], xl[DB / 2 > 0 ? DB / 2 : 1];
+                    constexpr int NU1 = (DB / 2) * HB, NU2 = (DB / 2) * DB;
+                    split_panel8<DB>(X, xh, xl);
+                    gemm_Txs<HB, KSD, DB, 2>(h1, lds + oW1, xh, xl, X[DB - 1], lane, [&](int u) __attribute__((always_inline)) { x_store(u, NU1 + NU2); });
+#pragma unroll
+                    for (int b = 0; b < DB; ++b) Tn[b] = X[b];
+                    gemm_Txs<DB, KSD, DB, 2>(Tn, ldsA, xh, xl, X[DB - 1], lane, [&](int u) __attribute__((always_inline)) { x_store(NU1 + u, NU1 + NU2); });
+                    if constexpr (NU1 + NU2 == 0) x_store(0, 1);
+                } else {
+                    constexpr int NU1 = (DB / 2) * HB;
+                    gemm_Tx<HB, KSD, DB, 2>(h1, lds + oW1, X, lane, [&](int u) __attribute__((always_inline)) { x_store(u, NU1); });
+                    if constexpr (NU1 == 0) x_store(0, 1);
+                }
+            }
             else if constexpr (BF16) gemm_Tb<HB, DB>(h1, lds + oW1, X, lane);
             else gemm_T<HB, KSD, DB>(h1, lds + oW1, X, lane);
             PSP_STAMP(fs1);
@@ -690,12 +806,26 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 h2[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
-            if constexpr (X3) gemm_Tx<HB, KSH, HB>(h2, lds + oW2, h1, lane);
+            // hidden activations for the backward pass (no recompute); split-product instances: h1 between the units of the
+            // W2 product, h2 between those of the W3 product
+            auto h_store = [&](const f32x4 (&h)[HB], int slot, int u, int NU) __attribute__((always_inline)) {
+                if (do_store) {
+#pragma unroll
+                    for (int ks = 0; ks < 4 * HB; ++ks)
+                        if (ks >= u * (4 * HB) / NU && ks < (u + 1) * (4 * HB) / NU)
+                            PSP_PATH_STORE(pblk + (slot / 64 + ks) * 64, h[ks >> 2][ks & 3]);
+                }
+            };
+            constexpr int NUH2 = (HB / 2) * HB, NUH3 = (HB / 2) * DB;
+            if constexpr (X3) {
+                gemm_Tx<HB, KSH, HB, 2>(h2, lds + oW2, h1, lane, [&](int u) __attribute__((always_inline)) { h_store(h1, G::pH1, u, NUH2); });
+                if constexpr (NUH2 == 0) h_store(h1, G::pH1, 0, 1);
+            }
             else if constexpr (BF16) gemm_Tb<HB, HB>(h2, lds + oW2, h1, lane);
             else gemm_T<HB, KSH, HB>(h2, lds + oW2, h1, lane);
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = tanh4(h2[m]);
-            if (a.store_path) {                        // hidden activations for the backward pass (no recompute)
+            if (!X3 && do_store) {
 #pragma unroll
                 for (int ks = 0; ks < 4 * HB; ++ks) {
                     PSP_PATH_STORE(pblk + (G::pH1 / 64 + ks) * 64, h1[ks >> 2][ks & 3]);
@@ -705,7 +835,10 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 Z[DB];
 #pragma unroll
             for (int m = 0; m < DB; ++m) Z[m] = vb3[m * 4];
-            if constexpr (X3) gemm_Tx<DB, KSH, HB>(Z, lds + oW3, h2, lane);
+            if constexpr (X3) {
+                gemm_Tx<DB, KSH, HB, 2>(Z, lds + oW3, h2, lane, [&](int u) __attribute__((always_inline)) { h_store(h2, G::pH2, u, NUH3); });
+                if constexpr (NUH3 == 0) h_store(h2, G::pH2, 0, 1);
+            }
             else if constexpr (BF16) gemm_Tb<DB, HB>(Z, lds + oW3, h2, lane);
             else gemm_T<DB, KSH, HB>(Z, lds + oW3, h2, lane);
             PSP_STAMP(fs3);
@@ -731,7 +864,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
                 }
-                if (a.store_path) {
+                if (do_store) {
                     // 1: xi, or xi + sqrt(dt) Z when the forward process is NOT adaptive (then dL/dZ_n = w (Z dt + xi sqrt(dt))
                     //    = w sqrt(dt) * image, the same expression the backward kernels evaluate); attached process (hjba_kernels.h):
                     // 2: xi - sqrt(dt) Z, 3: Z  -- the adjoint sweep replaces it by dL/dZ_n / sqrt(dt)
@@ -764,12 +897,12 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             PSP_STAMP(fs4);
 
             // ---- X_{n+1} = X + b(X) dt + sigma v      (solver.py:471-472)
-            f32x4 Tn[DB];
+            if (!early_drift) {
 #pragma unroll
-            for (int b = 0; b < DB; ++b) Tn[b] = X[b];
+                for (int b = 0; b < DB; ++b) Tn[b] = X[b];
+            }
             if (a.drift_kind == DRIFT_DENSE) {
-                if constexpr (X3) gemm_Tx<DB, KSD, DB>(Tn, ldsA, X, lane);
-                else gemm_T<DB, KSD, DB>(Tn, ldsA, X, lane);     // + (dt A) X
+                if constexpr (!X3) gemm_T<DB, KSD, DB>(Tn, ldsA, X, lane);     // + (dt A) X
             } else if (a.drift_kind == DRIFT_DIAG) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Tn[b] += dt * (vdr[b * 4] * X[b]);
@@ -1684,7 +1817,7 @@ struct HjbLaunch {
         return hipGetLastError();
     }
     // FAST (no vector-memory load in the time loop): Philox noise, no u_L2 log, no time-feature table -- every training launch
-    static bool fast(const HjbArgs& a) { return a.noise_mode == NOISE_PHILOX && a.uref == nullptr && a.tfeat == nullptr; }
+    static bool fast(const HjbArgs& a) { return a.noise_mode == NOISE_PHILOX && a.uref == nullptr && a.tfeat == nullptr && a.store_path != 0; }
     static hipError_t fwd(const HjbArgs& a, int grid, int block, hipStream_t s) {
         return fast(a) ? fwd_as<0, true>(a, grid, block, s) : fwd_as<0, false>(a, grid, block, s);
     }

@@ -1010,12 +1010,7 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
                     }
                 };
                 auto pack_split = [&](const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const _Float16 h0 = (_Float16)u0[e], h1 = (_Float16)u1[e];
-                        hi[e] = h0; hi[4 + e] = h1;
-                        lo[e] = (_Float16)(u0[e] - (float)h0); lo[4 + e] = (_Float16)(u1[e] - (float)h1);
-                    }
+                    split8u(u0, u1, hi, lo);
                 };
                 requestp(0);
 #pragma unroll

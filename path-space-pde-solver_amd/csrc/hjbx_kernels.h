@@ -53,12 +53,7 @@ template <int NB>
 __device__ __forceinline__ void split_panel(const f32x4 (&v)[NB], f16x4 (&hi)[NB], f16x4 (&lo)[NB]) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            _Float16 h, l;
-            split_f16(v[b][r], h, l);
-            hi[b][r] = h; lo[b][r] = l;
-        }
+        split4(v[b], hi[b], lo[b]);
 }
 
 // gemm_Tx with the input panel already split (hi / lo per 16-feature block; `last` = the fp32 value in[INB-1][0] for the exact
@@ -377,14 +372,7 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
         }
     };
     auto pack = [&](const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 h, l;
-            split_f16(u0[e], h, l);
-            hi[e] = h; lo[e] = l;
-            split_f16(u1[e], h, l);
-            hi[4 + e] = h; lo[4 + e] = l;
-        }
+        split8(u0, u1, hi, lo);
     };
     // A operand of tile t of the pair (0 .. DB-1: G, then dz2, then dz1): lane (i, g) = feature 16 tile + i, samples 4 g .. 4 g + 3
     // of block c0, then of block c1 -- one 16-byte read each for hi and lo

@@ -6,7 +6,7 @@ OUT=gpurun_out/ab_bench; mkdir -p $OUT
 A=$1; B=$2; shift 2
 for w in "$@"; do
   for L in $A $B $A $B; do
-    PSP_LIB_PATH=$PWD/$L timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --no-secondary > $OUT/line.json 2>$OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }
+    PSP_LIB_PATH=$PWD/$L timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --no-secondary --no-sustained > $OUT/line.json 2>$OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }
     python - "$w" "$L" <<'PY' | tee -a $OUT/ab.txt
 import json, sys
 j = json.loads(open("gpurun_out/ab_bench/line.json").read().strip().splitlines()[-1])
