@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PSP_VERSION 300 /* 0.3.0: range_flag in psp_hjb_config / psp_gen_config (guarded split-product mode) */
+#define PSP_VERSION 301 /* 0.3.0: range_flag in psp_hjb_config / psp_gen_config (guarded split-product mode); 0.3.1: store_path 4 */
 
 /* drift b(x): reference problems.py:36-37,154-155 (dense), :311-315 (double well) */
 enum { PSP_DRIFT_ZERO = 0, PSP_DRIFT_DENSE = 1, PSP_DRIFT_DIAG = 2, PSP_DRIFT_DOUBLE_WELL = 3 };
@@ -80,7 +80,11 @@ typedef struct psp_hjb_config {
     int32_t loss_kind;
     int32_t noise_mode;
     int32_t store_path;   /* 0: forward only; 1: keep X_n, h1, h2, xi for the backward pass;
-                           * 2 / 3: same with xi - sqrt(dt) Z / Z in the xi slot, for psp_hjb_adjoint_sweep */
+                           * 2 / 3: same with xi - sqrt(dt) Z / Z in the xi slot, for psp_hjb_adjoint_sweep;
+                           * 4: keep X_n, h1, h2 only -- psp_hjb_rollout_bwd regenerates xi from the Philox counters
+                           *    (seed, iter of the call = those of the forward call).  Narrow family, PSP_NOISE_PHILOX,
+                           *    adaptive = 1 (the image of mode 1 is then xi itself); the block layout is that of mode 1
+                           *    with the xi slot unused (same path_bytes).  Not for psp_hjb_rollout_bwd_step.        */
     float sigma_scale;    /* PSP_SIGMA_SCALED_IDENTITY                            */
     int32_t reserved;
     const float* drift;   /* DENSE: A (d*d row-major); DIAG: a (d); DOUBLE_WELL: kappa (d) */

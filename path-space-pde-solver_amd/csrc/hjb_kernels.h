@@ -190,6 +190,26 @@ __device__ __forceinline__ f32x4 philox_block(uint32_t kglob, uint32_t step, uin
     return normal4(r);
 }
 
+// The xi image of sample block (step n, 16-trajectory tile) from the counters the forward kernel used -- store_path 4: the
+// forward keeps X_n, h1, h2 only (960 instead of 1408 B per unit at d = 100, H = 64) and the backward producers pay seven
+// Philox calls per block instead of 28 loads.  Padded features are zero, as in the forward.
+template <int D, int DB>
+__device__ __forceinline__ void regen_xi(f32x4 (&xin)[DB], uint32_t kglob, uint32_t n, int q, uint32_t iter,
+                                         uint32_t seed_lo, uint32_t seed_hi) {
+#pragma unroll
+    for (int b = 0; b < DB; ++b) {
+#ifdef PSP_ABL_REGEN
+        xin[b] = f32x4{1e-3f * (float)(kglob & 255u), 0.5f, -0.25f * (float)(n & 7u), 0.125f * (float)b};   // timing ablation only
+#else
+        xin[b] = philox_block(kglob, n, (uint32_t)(4 * b + q), iter, seed_lo, seed_hi);
+#endif
+        if (16 * b + 16 > D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xin[b][r] = 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // LDS staging of pre-permuted A operands and per-feature vectors
 // ---------------------------------------------------------------------------------------
@@ -864,7 +884,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
                 }
-                if (do_store) {
+                if (do_store && a.store_path != 4) {   // (4: the backward regenerates xi from the Philox counters)
                     // 1: xi, or xi + sqrt(dt) Z when the forward process is NOT adaptive (then dL/dZ_n = w (Z dt + xi sqrt(dt))
                     //    = w sqrt(dt) * image, the same expression the backward kernels evaluate); attached process (hjba_kernels.h):
                     // 2: xi - sqrt(dt) Z, 3: Z  -- the adjoint sweep replaces it by dL/dZ_n / sqrt(dt)
@@ -1425,6 +1445,8 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
     const double invK = 1.0 / (double)a.K_global;
     const float meanD = (a.loss_kind == LOSS_LOGVAR) ? (float)(a.sums[0] * invK) : 0.f;
     const float coef = (float)(2.0 * invK);
+    const bool regen = a.store_path == 4;                       // xi from the Philox counters instead of the path store
+    const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;
     const float sqdt = a.sqdt, dt = a.dt;
     const long long nblk = (long long)a.N * a.ntile16;
     const long long nround = (nblk + 3) / 4;
@@ -1458,10 +1480,14 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
             const float* pb = a.path + (size_t)blk * (size_t)G::PB + lane;
             const int k0 = (int)(blk % a.ntile16) * 16 + j;
             dkn = a.D[k0 < a.K_local ? k0 : 0];
+            if (regen) {
+                regen_xi<D, DB>(xin, (uint32_t)(a.k_offset + k0), (uint32_t)(blk / a.ntile16), q, iter_now, a.seed_lo, a.seed_hi);
+            } else {
 #pragma unroll
-            for (int b = 0; b < DB; ++b)
+                for (int b = 0; b < DB; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xin[b][r] = pb[G::pXi + (4 * b + r) * 64];
+                    for (int r = 0; r < 4; ++r) xin[b][r] = pb[G::pXi + (4 * b + r) * 64];
+            }
         }
         for (int it = 0; it <= R; ++it) {
             PSP_STAMP(tp0);
@@ -1495,10 +1521,14 @@ __global__ __launch_bounds__(512) void hjb_bwd2_kernel(const HjbArgs a) {
                     const float* pn = a.path + (size_t)nblk1 * (size_t)G::PB + lane;
                     const int k1 = (int)(nblk1 % a.ntile16) * 16 + j;
                     dkn = a.D[k1 < a.K_local ? k1 : 0];
+                    if (regen) {
+                        regen_xi<D, DB>(xin, (uint32_t)(a.k_offset + k1), (uint32_t)(nblk1 / a.ntile16), q, iter_now, a.seed_lo, a.seed_hi);
+                    } else {
 #pragma unroll
-                    for (int b = 0; b < DB; ++b)
+                        for (int b = 0; b < DB; ++b)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) xin[b][r] = pn[G::pXi + (4 * b + r) * 64];
+                            for (int r = 0; r < 4; ++r) xin[b][r] = pn[G::pXi + (4 * b + r) * 64];
+                    }
                 }
                 PSP_STAMP(tp1);
                 PSP_ACC(0, tp1, tp0);                 // weights -> G, issue of this block's h2 loads and next round's xi

@@ -365,7 +365,7 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
             }
         }
         Z = fvalid ? Z : 0.f;
-        if (storing && gvalid) pblk[offXi] = store_cxi * xi + store_cz * Z;     // 1: xi, 2: xi - sqrt(dt) Z, 3: Z (hjb_fwd_kernel)
+        if (storing && a.store_path != 4 && gvalid) pblk[offXi] = store_cxi * xi + store_cz * Z;     // 1: xi, 2: xi - sqrt(dt) Z, 3: Z (hjb_fwd_kernel)
         float UL = 0.f;
         if (has_uref) {                                  // u_L2 logging: |-Z_n - u*(t_n)|^2 (solver.py:491-494)
             const float e = fvalid ? Z + a.uref[(size_t)n * D + fc] : 0.f;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (16 * sb + 4 * r + q >= D) xi[r] = 0.f;
-                if (a.store_path) {                    // 1: xi, 2: xi - sqrt(dt) Z, 3: Z (see hjb_fwd_kernel)
+                if (a.store_path && a.store_path != 4) {   // 1: xi, 2: xi - sqrt(dt) Z, 3: Z, 4: no image (see hjb_fwd_kernel)
                     const f32x4 wv = store_cxi * xi + store_cz * Z[io];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pblk[(G::pXi / 64 + 4 * sb + r) * 64] = wv[r];

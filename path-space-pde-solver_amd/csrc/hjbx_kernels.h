@@ -38,7 +38,7 @@ struct GeoX {
     static constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
     static constexpr int T3 = 0, T2 = T3 + SplitGeo<KSD, DB>::floats(HB), EX = T2 + SplitGeo<KSH, HB>::floats(HB);   // floats
     // exchange area of one PAIR of sample blocks, in halves: G (hi, lo: D features), dz2, dz1 (hi, lo: 16 HB features); element
-    // (feature f, block c of the pair, sample s) at f * 32 + (s >> 2) * 8 + c * 4 + (s & 3)
+    // (feature f, block c of the pair, sample s) at f * 32 + ((s >> 2) ^ ((f >> 2) & 3)) * 8 + c * 4 + (s & 3)  (chunk swizzle: see the producers)
     static constexpr int hG = 0, hGl = hG + D * 32, hZ2 = hGl + D * 32, hZ2l = hZ2 + HB * 512, hZ1 = hZ2l + HB * 512,
                          hZ1l = hZ1 + HB * 512, PAIRH = hZ1l + HB * 512;
     static constexpr int RS = 16 * DB + 3 * 16 * HB;                   // bias-sum slots per producer (G | dz2 | dz1 | t dz1)
@@ -122,7 +122,9 @@ __device__ __forceinline__ void gemm_Txp(f32x4 (&acc)[MB], const float* wlds, co
     for (int mb = 0; mb < MB; ++mb) acc[mb] = acc[mb] + kSplitInv * corr[mb];
 }
 
-template <int D, int H>
+// REGEN: the xi image is regenerated from the Philox counters (psp_hjb_config.store_path 4) -- its own instance, so that the
+// landing registers of the stored image and the deeper h2 / h1 lead of the regenerating schedule do not add up in one allocation
+template <int D, int H, bool REGEN = false>
 __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
     PSP_COND_EXIT(a);
     using G = Geo<D, H>;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
     __syncthreads();
     _Float16* exh = reinterpret_cast<_Float16*>(lds + X::EX);           // [2 buffers][2 pairs][PAIRH] halves
     // power-of-two scale of G (header comment): max |w| of the scan x sqrt(dt) x image bound
-    const bool xi_image = a.adaptive != 0 && a.store_path == 1;
+    const bool xi_image = a.adaptive != 0 && (a.store_path == 1 || a.store_path == 4);
     auto g_scale = [&](float& gs, float& ginv) __attribute__((always_inline)) {
         const float* slot = lds + X::GS;
         float imax = fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3]));
@@ -171,12 +173,16 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const float sqdt = a.sqdt, dt = a.dt;
+    constexpr bool regen = REGEN;                               // xi from the Philox counters instead of the path store
+    const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;
     const long long nblk = (long long)a.N * a.ntile16;
     const long long nround = (nblk + 3) / 4;
     const int R = (int)((nround - blockIdx.x + gridDim.x - 1) / gridDim.x);   // rounds of this workgroup (>= 1)
 
     if (producer) {
         // ================================================================================ producers
+        // (the producers' chain sets the pace of a round -- stamps: the consumers idle 15 - 40 % at the barrier; s_setprio 3 for
+        // the producers, which share each SIMD with one consumer wave, measured 1.4 % slower: not kept)
         f32x4 sG[DB], sZ2[HB], sZ1[HB], sT1[HB];
 #pragma unroll
         for (int b = 0; b < DB; ++b) sG[b] = zero4;
@@ -190,10 +196,8 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
             const long long b0 = own_block(it2);
             return a.path + (size_t)(b0 >= 0 ? b0 : nblk - 1) * (size_t)G::PB + lane;
         };
-        // h2 of the current block is requested at the top of the iteration (used behind the first product); h1 (used behind the
-        // second product) and then the xi image and the trajectory weight of the NEXT round behind the first product, when the
-        // split G panel is dead -- the register budget (256, with 76 registers of bias sums) has no room for more lead, and a
-        // spilled register's reload would wait behind every load in flight (vmcnt is in order)
+        // (the register budget -- 256, with 76 registers of bias sums -- has no room for a second set of landing registers, and a
+        // spilled register's reload would wait behind every load in flight)
         f32x4 xin[DB], h2n[HB], h1n[HB];
         float dkn;
         {
@@ -202,10 +206,34 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
             const float* pb = path_of(0);
             const int k0 = (int)(blk % a.ntile16) * 16 + j;
             dkn = a.D[k0 < a.K_local ? k0 : 0];
+            // Stored xi (REGEN = false): h2 of the current block is requested at the top of its round (used behind the first
+            // product); h1 (used behind the second product) and the xi image and weight of the NEXT round behind the first product,
+            // when the split G panel is dead.  The stamped producer spends ~3 000 of its 9 300 cycles per round waiting for h2 / h1
+            // and sets the pace of the kernel (the consumers idle 28 % at the barrier), but a whole round of lead for them next to
+            // the xi landing registers spills inside the loop (tried in round 3: 6 - 19 dwords).
+            // store_path 4 (REGEN): xi comes from the Philox counters at the top of each round (no landing registers, no latency)
+            // and every panel is requested a whole round ahead -- the loads for the NEXT block stand right where the current
+            // block's registers are consumed (h2 behind the first tanh', h1 behind the second): same registers, issue order =
+            // consumption order (vmcnt is in order).
+            if constexpr (regen) {
 #pragma unroll
-            for (int b = 0; b < DB; ++b)
+                for (int b = 0; b < DB; ++b) xin[b] = zero4;
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xin[b][r] = pb[G::pXi + (4 * b + r) * 64];
+                for (int b = 0; b < DB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xin[b][r] = pb[G::pXi + (4 * b + r) * 64];
+            }
+            if constexpr (regen) {
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h2n[m][r] = pb[G::pH2 + (4 * m + r) * 64];
+#pragma unroll
+                for (int m = 0; m < HB; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h1n[m][r] = pb[G::pH1 + (4 * m + r) * 64];
+            }
         }
         float gs, ginv;
         {
@@ -223,7 +251,11 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
             __syncthreads();                              // (A) pairs with the consumers' barrier behind their first loads
             g_scale(gs, ginv);
         }
+#ifdef PSP_STAMPS
+        unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         for (int it = 0; it <= R; ++it) {
+            PSP_STAMP(tp0);
             if (it < R) {
                 const long long blk0 = own_block(it);
                 const bool bvalid = blk0 >= 0;
@@ -232,21 +264,55 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
                 const int k = t16 * 16 + j;
                 const bool kvalid = bvalid && k < a.K_local;
                 const float tn = (float)(blk / a.ntile16) * dt;
-                _Float16* ex = exh + ((it & 1) * 2 + (sub >> 1)) * PAIRH + (j >> 2) * 8 + (sub & 1) * 4 + (j & 3);
+                // exchange image: element (feature f, block c of the pair, sample s) at f * 32 + (((s >> 2) ^ ((f >> 2) & 3)) * 8
+                // + c * 4 + (s & 3): the 16-byte chunk of a sample quad is XOR-swizzled with the feature row, so that the consumers'
+                // ds_read_b128 of rows i, i + 4, i + 8, i + 12 (64 bytes apart: the same 16 banks) fall on four different bank
+                // groups (round 3: the unswizzled reads cost the kernel 27 % LDS bank-conflict cycles).  (f >> 2) & 3 = r here.
+                _Float16* ex0 = exh + ((it & 1) * 2 + (sub >> 1)) * PAIRH + (sub & 1) * 4 + (j & 3);
+                _Float16* exr[4] = {ex0 + (((j >> 2) ^ 0) * 8), ex0 + (((j >> 2) ^ 1) * 8), ex0 + (((j >> 2) ^ 2) * 8), ex0 + (((j >> 2) ^ 3) * 8)};
                 const float* pn = path_of(it + 1);
                 const float* pc = path_of(it);
+                const float dkc = dkn;
+                if constexpr (!regen) {
 #pragma unroll
-                for (int m = 0; m < HB; ++m)
+                    for (int m = 0; m < HB; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h2n[m][r] = pc[G::pH2 + (4 * m + r) * 64];
-                // LOSS_WEIGHTS: the caller supplies w_k = dLoss/dY_k directly in the D argument
-                const float wk = kvalid ? (a.loss_kind == LOSS_WEIGHTS ? dkn : coef * (dkn - meanD)) : 0.f;
-                f32x4 Gt[DB];
-#pragma unroll
-                for (int b = 0; b < DB; ++b) {
-                    Gt[b] = (wk * sqdt * gs) * xin[b];              // adaptive: the (Z + c) dt term cancels
-                    sG[b] += Gt[b];
+                        for (int r = 0; r < 4; ++r) h2n[m][r] = pc[G::pH2 + (4 * m + r) * 64];
                 }
+                // LOSS_WEIGHTS: the caller supplies w_k = dLoss/dY_k directly in the D argument
+                const float wk = kvalid ? (a.loss_kind == LOSS_WEIGHTS ? dkc : coef * (dkc - meanD)) : 0.f;
+                f32x4 Gt[DB];
+                if constexpr (regen) {
+                    const uint32_t kg = (uint32_t)(a.k_offset + k), nstep = (uint32_t)(blk / a.ntile16);
+                    // (q through an opaque copy: the first Philox round of the call index 4 b + q is loop-invariant, and seven
+                    // hoisted products per lane were spilled and reloaded every round -- behind every path load in flight)
+                    const int qo = opaque_i(q);
+#pragma unroll
+                    for (int b = 0; b < DB; ++b) {                  // one Philox call at a time (their temporaries do not pile up)
+                        f32x4 xi = philox_block(kg, nstep, (uint32_t)(4 * b + qo), iter_now, a.seed_lo, a.seed_hi);
+                        if (16 * b + 16 > D) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
+                        }
+                        {
+#pragma clang fp contract(off)
+                            Gt[b] = (wk * sqdt * gs) * xi;
+                            sG[b] += Gt[b];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    {
+#pragma clang fp contract(off)
+#pragma unroll
+                        for (int b = 0; b < DB; ++b) {
+                            Gt[b] = (wk * sqdt * gs) * xin[b];      // adaptive: the (Z + c) dt term cancels
+                            sG[b] += Gt[b];
+                        }
+                    }
+                }
+                PSP_STAMP(tp1);
+                PSP_ACC(0, tp1, tp0);                 // h2 loads issued, weights -> G
                 f16x4 Gh[DB], Gl[DB];
                 split_panel<DB>(Gt, Gh, Gl);
 #pragma unroll
@@ -255,21 +321,34 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const int f = 16 * b + 4 * r + q;
                         if (16 * b + 16 <= D || f < D) {
-                            ex[X::hG + f * 32] = Gh[b][r];
-                            ex[X::hGl + f * 32] = Gl[b][r];
+                            exr[r][X::hG + f * 32] = Gh[b][r];
+                            exr[r][X::hGl + f * 32] = Gl[b][r];
                         }
                     }
+                PSP_STAMP(tp2);
+                PSP_ACC(1, tp2, tp1);                 // G split + image write
                 f32x4 dz2[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) dz2[m] = zero4;
                 gemm_Txp<HB, KSD, DB>(dz2, lds + X::T3, Gh, Gl, Gt[DB - 1][0], lane);
-#pragma unroll
-                for (int m = 0; m < HB; ++m) { dz2[m] = dz2[m] * (1.0f - h2n[m] * h2n[m]); sZ2[m] += dz2[m]; }
-#pragma unroll
-                for (int m = 0; m < HB; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h1n[m][r] = pc[G::pH1 + (4 * m + r) * 64];
                 {
+                    // (no contraction here: the two instances of this kernel must round dz2 and the bias sums alike -- one of them
+                    // had folded the product into the sum, 1 ulp in db2)
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) { dz2[m] = dz2[m] * (1.0f - h2n[m] * h2n[m]); sZ2[m] += dz2[m]; }
+                }
+                if constexpr (regen) {
+                    __builtin_amdgcn_sched_barrier(0);              // (the loads below overwrite h2n: not before it is consumed)
+#pragma unroll
+                    for (int m = 0; m < HB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h2n[m][r] = pn[G::pH2 + (4 * m + r) * 64];
+                } else {
+#pragma unroll
+                    for (int m = 0; m < HB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h1n[m][r] = pc[G::pH1 + (4 * m + r) * 64];
                     const long long n0 = own_block(it + 1);
                     const long long nb1 = n0 >= 0 ? n0 : nblk - 1;
                     const int k1 = (int)(nb1 % a.ntile16) * 16 + j;
@@ -279,36 +358,63 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xin[b][r] = pn[G::pXi + (4 * b + r) * 64];
                 }
+                PSP_STAMP(tp3);
+                PSP_ACC(2, tp3, tp2);                 // W3^T G, tanh', h1 loads, next xi (loads or Philox)
                 f16x4 Zh[HB], Zl[HB];
                 split_panel<HB>(dz2, Zh, Zl);
 #pragma unroll
                 for (int m = 0; m < HB; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        ex[X::hZ2 + (16 * m + 4 * r + q) * 32] = Zh[m][r];
-                        ex[X::hZ2l + (16 * m + 4 * r + q) * 32] = Zl[m][r];
+                        exr[r][X::hZ2 + (16 * m + 4 * r + q) * 32] = Zh[m][r];
+                        exr[r][X::hZ2l + (16 * m + 4 * r + q) * 32] = Zl[m][r];
                     }
                 f32x4 dz1[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) dz1[m] = zero4;
                 gemm_Txp<HB, KSH, HB>(dz1, lds + X::T2, Zh, Zl, dz2[HB - 1][0], lane);
+                {
+#pragma clang fp contract(off)
 #pragma unroll
-                for (int m = 0; m < HB; ++m) {
-                    dz1[m] = dz1[m] * (1.0f - h1n[m] * h1n[m]);
-                    sZ1[m] += dz1[m];
-                    sT1[m] += tn * dz1[m];
+                    for (int m = 0; m < HB; ++m) {
+                        dz1[m] = dz1[m] * (1.0f - h1n[m] * h1n[m]);
+                        sZ1[m] += dz1[m];
+                        sT1[m] += tn * dz1[m];
+                    }
+                }
+                if constexpr (regen) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const long long n0 = own_block(it + 1);
+                    const long long nb1 = n0 >= 0 ? n0 : nblk - 1;
+                    const int k1 = (int)(nb1 % a.ntile16) * 16 + j;
+                    dkn = a.D[k1 < a.K_local ? k1 : 0];
+#pragma unroll
+                    for (int m = 0; m < HB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h1n[m][r] = pn[G::pH1 + (4 * m + r) * 64];
                 }
                 split_panel<HB>(dz1, Zh, Zl);
 #pragma unroll
                 for (int m = 0; m < HB; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        ex[X::hZ1 + (16 * m + 4 * r + q) * 32] = Zh[m][r];
-                        ex[X::hZ1l + (16 * m + 4 * r + q) * 32] = Zl[m][r];
+                        exr[r][X::hZ1 + (16 * m + 4 * r + q) * 32] = Zh[m][r];
+                        exr[r][X::hZ1l + (16 * m + 4 * r + q) * 32] = Zl[m][r];
                     }
             }
+            PSP_STAMP(tp4);
+            PSP_ACC(3, tp4, tp0);                     // whole produce phase
             __syncthreads();                              // swap the exchange buffers (pairs with the consumer loop)
+            PSP_STAMP(tp5);
+            PSP_ACC(4, tp5, tp4);                     // barrier wait
+            PSP_ACC(6, tp5, tp0);
         }
+#ifdef PSP_STAMPS
+        if (a.dbg && lane == 0) {
+            stamps[7] = (unsigned long long)R;
+            for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+        }
+#endif
         // per-wave bias sums -> LDS (the exchange area is free after the last barrier); lane (j = 0, q), component r of block b
         // holds feature 16 b + 4 r + q
         float* red = lds + X::EX + sub * RS;
@@ -376,7 +482,7 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
     };
     // A operand of tile t of the pair (0 .. DB-1: G, then dz2, then dz1): lane (i, g) = feature 16 tile + i, samples 4 g .. 4 g + 3
     // of block c0, then of block c1 -- one 16-byte read each for hi and lo
-    const int aofs = opaque_i((lane & 15) * 32 + (lane >> 4) * 8);
+    const int aofs = opaque_i((lane & 15) * 32 + (((lane >> 4) ^ ((lane >> 2) & 3)) * 8));   // (the producers' chunk swizzle)
     auto a_load = [&](const _Float16* e, int t, f16x8& Ah, f16x8& Al) __attribute__((always_inline)) {
         const int hi = t < DB ? X::hG + t * 512 : (t < DB + HB ? X::hZ2 + (t - DB) * 512 : X::hZ1 + (t - DB - HB) * 512);
         const int lo = t < DB ? X::hGl + t * 512 : (t < DB + HB ? X::hZ2l + (t - DB) * 512 : X::hZ1l + (t - DB - HB) * 512);
@@ -431,14 +537,31 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
     }
     __syncthreads();                                      // (A) the producers' scale slots are written
     __syncthreads();                                      // pairs with producer iteration 0
+#ifdef PSP_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int it = 1; it <= R; ++it) {
+        PSP_STAMP(tc0);
         const long long rb = ((long long)blockIdx.x + (long long)(it - 1) * gridDim.x) * 4;
         const _Float16* exr = exh + ((it - 1) & 1) * 2 * PAIRH;
         const long long rn = rb + 4LL * gridDim.x;        // first block of this workgroup's next round
         pair_phase(exr, blk_at(rb + 2), blk_at(rb + 3));
+        PSP_STAMP(tc1);
         pair_phase(exr + PAIRH, blk_at(rn), blk_at(rn + 1));
+        PSP_STAMP(tc2);
+        PSP_ACC(0, tc2, tc0);                         // both pairs
+        PSP_ACC(1, tc1, tc0);                         // first pair
         __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
+        PSP_STAMP(tc3);
+        PSP_ACC(4, tc3, tc2);                         // barrier wait
+        PSP_ACC(6, tc3, tc0);
     }
+#ifdef PSP_STAMPS
+    if (a.dbg && lane == 0) {
+        stamps[7] = (unsigned long long)R;
+        for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+    }
+#endif
     float gs, ginv;
     g_scale(gs, ginv);
     const float inv1 = ginv, inv2 = ginv * kSplitInv;     // un-scale: G's power of two, and the 2048 of the one-chain tiles
@@ -502,10 +625,17 @@ struct HjbxLaunch {
     static int lds_bytes() { return X::lds_floats() * 4; }
     static hipError_t bwd(const HjbArgs& a, int grid, hipStream_t s) {
         const int bytes = lds_bytes();
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_bwd3_kernel<D, H>),
+        if (a.store_path == 4) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_bwd3_kernel<D, H, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((hjb_bwd3_kernel<D, H, true>), dim3(grid), dim3(512), bytes, s, a);
+            return hipGetLastError();
+        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_bwd3_kernel<D, H, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjb_bwd3_kernel<D, H>), dim3(grid), dim3(512), bytes, s, a);
+        hipLaunchKernelGGL((hjb_bwd3_kernel<D, H, false>), dim3(grid), dim3(512), bytes, s, a);
         return hipGetLastError();
     }
 };

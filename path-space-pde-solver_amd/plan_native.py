@@ -190,6 +190,20 @@ class HjbNativePlan:
             cfg.range_flag = nat.ptr(self.range_flag)
             if nat.query_rc(cfg)[0] != 0:                # (the fp32-MFMA tables of this instance do not fit the LDS: unguarded)
                 cfg.range_flag, self.range_flag = None, None
+        # store_path 4 (include/psp.h): the forward keeps X_n, h1, h2 only and the backward producers regenerate xi from the
+        # Philox counters -- where the stored image would be xi itself (detached adaptive process, on-device noise), in the
+        # narrow kernel family, on the eager iteration (psp_hjb_rollout_bwd_step of the hipGraph replay takes no seed; that
+        # regime -- at most two tiles per CU -- is launch-bound, not store-bound).  Solver(path_noise='store') keeps xi.
+        self.regen_xi = False
+        if (getattr(solver, 'path_noise', 'auto') != 'store' and cfg.store_path == 1 and cfg.noise_mode == nat.NOISE_PHILOX
+                and cfg.adaptive and self.family == 1 and torch.device(dev).type == 'cuda'
+                and getattr(solver, 'use_graph', 'auto') is not True
+                and (self.K_local + 15) // 16 > 2 * torch.cuda.get_device_properties(dev).multi_processor_count):
+            cfg.store_path = 4
+            if nat.query_rc(cfg)[0] == 0:
+                self.regen_xi = True
+            else:
+                cfg.store_path = 1
         self.pad = shapes.ParamPad(solver.d, self.H, self.d_pad, self.H_pad, dev)
         pad = self.pad
         cfg.drift = nat.ptr(dev_f32(pad.drift_or_sigma(spec['drift'][1]))) if spec['drift'][1] is not None else None

@@ -65,7 +65,8 @@ class Solver:
                  plot_trajectories=None, seed=42, save_results=False, u_l2_error_flag=True,
                  log_gradient=False, burgers_drift=False, verbose=True,
                  device=None, backend='auto', noise='reference', widths=(30, 30), mlp_dtype='auto',
-                 path_budget_bytes=None, path_chunks=None, chunk_mode='auto', use_graph='auto', range_guard=True):
+                 path_budget_bytes=None, path_chunks=None, chunk_mode='auto', use_graph='auto', range_guard=True,
+                 path_noise='auto'):
         self.problem, self.name = problem, name
         self.date = date.today().strftime('%Y-%m-%d')
         self.d, self.T = problem.d, problem.T
@@ -90,6 +91,12 @@ class Solver:
         # self.range_fallback_iterations counts them after train()
         self.range_guard = bool(range_guard)
         self.range_fallback_iterations = 0
+        # path store of the native plan: 'auto' lets the backward regenerate the Brownian increments from the Philox counters
+        # where that is exact (detached adaptive process, on-device noise, narrow kernel family: 960 instead of 1408 B per
+        # trajectory-timestep at d = 100); 'store' always keeps them (psp_hjb_config.store_path 1 instead of 4)
+        if path_noise not in ('auto', 'store'):
+            raise ValueError("path_noise must be 'auto' or 'store'")
+        self.path_noise = path_noise
         # native plan: HBM budget of the path store kept for the backward pass (None: a third of the HBM); a larger store is
         # processed in K-chunks (plan_native.py).  path_chunks forces a chunk count; chunk_mode 'auto' | 'two_gradient' | 'recompute'
         self.path_budget_bytes, self.path_chunks, self.chunk_mode = path_budget_bytes, path_chunks, chunk_mode
@@ -275,7 +282,7 @@ class Solver:
         nets = nets + tuple(id(v) for v in getattr(self, 'y_n', []))
         return (nets, self.noise, self.K, self.N, float(self.delta_t_np), self.loss_method, self.approx_method,
                 self.time_approx, bool(self.learn_Y_0), bool(self.adaptive_forward_process), bool(self.detach_forward),
-                bool(self.random_X_0), bool(self.u_l2_error_flag), self.mlp_dtype, getattr(self, 'range_guard', True), self.path_budget_bytes, self.path_chunks,
+                bool(self.random_X_0), bool(self.u_l2_error_flag), self.mlp_dtype, getattr(self, 'range_guard', True), getattr(self, 'path_noise', 'auto'), self.path_budget_bytes, self.path_chunks,
                 self.chunk_mode, id(self.problem), id(self.y_0) if hasattr(self, 'y_0') else None)
 
     def _choose_plan(self):

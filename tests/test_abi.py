@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_support_table(lib):
-    assert lib.psp_version() == 300
+    assert lib.psp_version() == 301
     assert nat.supported(100, 64) and nat.supported(2, 30)
     assert not nat.supported(3, 7)
 

@@ -28,7 +28,7 @@ prob = psp.LLGC(d=100, off_diag=0.01, T=1.0, seed=42, device=dev)
 model = psp.Solver("diag", prob, lr=1e-3, L=4, K=65536, delta_t=0.01, loss_method="log-variance",
                    time_approx="inner", adaptive_forward_process=True, detach_forward=True,
                    u_l2_error_flag=False, verbose=False, seed=42, device=dev, backend="native",
-                   noise="philox", widths=(64, 64))
+                   noise="philox", widths=(64, 64), path_noise=os.environ.get("PSP_PATH_NOISE", "auto"))
 plan = model._choose_plan()
 nat = psp.native
 nwg = plan.sizes.bwd_workgroups
@@ -56,12 +56,16 @@ if os.environ.get("PSP_BWD_VARIANT", "") != "1":
     pr, co = s[:, :4, :], s[:, 4:, :]
     R = pr[:, :, 7].clamp(min=1)
     print("backward (role-specialised): workgroups %d, rounds per workgroup %.1f" % (nwg, R.mean()))
-    for nm, i in [("xi -> G, issue h2 / next-xi loads", 0), ("G store, GEMM W3^T G, tanh'", 1),
-                  ("dz2 store", 3), ("barrier wait", 4), ("whole round", 6)]:
+    x3 = model._native_plan.matrix_mode == 'f16x3' if hasattr(model, '_native_plan') and model._native_plan is not None else plan.matrix_mode == 'f16x3'
+    prod = ([("h2 loads issued, weights -> G", 0), ("G split + image write", 1), ("W3^T G, tanh', h1 loads, next xi", 2),
+             ("whole produce phase", 3), ("barrier wait", 4), ("whole round", 6)] if x3 else
+            [("xi -> G, issue h2 / next-xi loads", 0), ("G store, GEMM W3^T G, tanh'", 1), ("dz2 store", 3), ("barrier wait", 4), ("whole round", 6)])
+    for nm, i in prod:
         v = pr[:, :, i] / R
         print("  producer  %-40s mean %8.0f   min %8.0f  max %8.0f" % (nm, v.mean(), v.min(), v.max()))
     Rc = co[:, :, 7].clamp(min=1)
-    for nm, i in [("eight phases (352 MFMA)", 0), ("barrier wait", 4), ("whole round", 6)]:
+    for nm, i in ([("both pairs", 0), ("first pair", 1), ("barrier wait", 4), ("whole round", 6)] if x3 else
+                  [("eight phases (352 MFMA)", 0), ("barrier wait", 4), ("whole round", 6)]):
         v = co[:, :, i] / Rc
         print("  consumer  %-40s mean %8.0f   min %8.0f  max %8.0f" % (nm, v.mean(), v.min(), v.max()))
     sys.exit(0)
