@@ -707,6 +707,10 @@ def main():
     # HBM term: SURVEY 8d's algorithmic bytes (state streamed once per step, 8d + 8) and this design's real ones (the path
     # store: state stays on chip, the forward writes / the backward reads one block of register images per unit)
     path_B_unit = float(plan.sizes.path_bytes) / max(1, units_launch) if hasattr(plan, "sizes") else None
+    if path_B_unit and getattr(plan, "regen_xi", False):
+        # store_path 4 (include/psp.h): the xi slot of a block is neither written nor read (the backward regenerates the
+        # increments from the Philox counters); the allocation keeps the slot, the traffic does not
+        path_B_unit -= 4.0 * 16 * ((plan.d_pad + 15) // 16)
     step_s = elapsed / args.steps
     dom_s = dom_ms * 1e-3
     alg_B_unit = 8 * w["d"] + 8
@@ -796,6 +800,9 @@ def main():
     if parity is not None:
         out["parity_vs_1rank"] = parity
         out["rccl_ranks_seen"] = parity.get("rccl_ranks_seen")
+    if hasattr(plan, "regen_xi"):
+        out["config"]["path_store"] = ("store_path 4: X_n, h1, h2 kept, xi regenerated by the backward from the Philox counters"
+                                       if plan.regen_xi else "store_path %d" % int(plan.cfg.store_path))
     if getattr(plan, "range_flag", None) is not None:
         out["config"]["range_guard"] = ("on: device flag + predicated fp32-MFMA twins of the split kernels (include/psp.h range_flag); "
                                         "fallback iterations in this run: %d" % plan.range_fallbacks())
