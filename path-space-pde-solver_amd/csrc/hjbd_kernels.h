@@ -73,6 +73,10 @@ struct DGeo {
     // LDS (floats): problem vectors, reduction scratch, two images per wave (X_n and the increment panel v)
     static constexpr int vdr = 0, vrun = vdr + DB * 16, vterm = vrun + DB * 16, fRed = vterm + DB * 16,
                          fImg = fRed + 64, IMG = KP * 64, lds_floats = fImg + 4 * 2 * IMG, lds_floats_x3 = fImg + 4 * 2 * IMGX;
+    // (Round 3 tried the wide family's shared table stream -- gemm_img_x3s: each 8 KiB chunk of a step's table fetched once per
+    //  workgroup -- for the two long products of the split forward at d <= 128, with the increment image aliased onto the X image
+    //  so that two workgroups and their stages still fit a CU: correct on all 44 dense-control tests, but the stage's operand
+    //  ring spills 45 instead of 22 dwords under the 256-register cap and the forward went 3.11 -> 3.31 ms.  Not kept.)
     // image block of one (step, 16-trajectory tile) for the backward kernel: X_n, relu(z1), relu(z2), xi image
     static constexpr int pX = 0, pR1 = pX + KP * 64, pR2 = pR1 + 4 * HB * 64, pXi = pR2 + 4 * HB * 64, PBI = pXi + KP * 64;
     // padded gradient layout of one work item (instance sizes, no time rows): W1 (D x H), b1, W2 ((D+H) x H), b2, W3 ((D+2H) x D), b3
