@@ -223,7 +223,9 @@ class GeneralNativePlan:
         return min(s.N, m + (2 if self.elliptic else 1))
 
     def _boundary_terms(self, X, X_b, t_b):
-        """The K_boundary-sized loss terms, differentiated by autograd into p.grad (solver.py:1062-1074, :683-693)."""
+        """The K_boundary-sized loss terms, differentiated by autograd into p.grad (solver.py:1062-1074, :683-693).
+        (Round 3 measured them behind the rollout launch and on a side stream beside it -- same-box A/B, d=100 K=65536 and the
+        K=200 notebook shape: both slower than here in front of the rollout, 8.65 vs 8.75 / 8.9 ms and 1.2 vs 1.33 / 1.5 ms.)"""
         s, dev = self.s, self.dev
         if s.loss_method == 'BSDE' or not s.boundary_loss:
             return None
