@@ -27,7 +27,7 @@ def run(path_noise, mlp, K=16384 + 48, d=20, L=3, x0_scale=None, **kw):
     return model, plan
 
 
-@pytest.mark.parametrize("mlp", ["fp32", "f16x3"])
+@pytest.mark.parametrize("mlp", ["fp32", "f16x3", "bf16"])
 def test_regenerated_increments_give_the_stored_ones_result(mlp):
     a, pa = run("store", mlp)
     b, pb = run("auto", mlp)
