@@ -74,3 +74,33 @@ def test_where_the_increments_stay_in_the_store():
         model = psp.Solver("pn", pbm, **args)
         model.train()
         assert not model._native_plan.regen_xi and model._native_plan.cfg.store_path in (1, 2), kw
+
+
+def test_store_path_4_is_refused_where_the_image_is_not_the_increment():
+    """The C ABI's own checks (include/psp.h): wide family, supplied noise, non-adaptive process, and the fused
+    backward + Adam entry point (which takes no Philox seed)."""
+    import ctypes as C
+    nat = psp.native
+    m, p = run("auto", "fp32", L=1)
+    assert p.cfg.store_path == 4
+    for field, value, code in (("noise_mode", nat.NOISE_SUPPLIED, -1), ("adaptive", 0, -1)):
+        cfg = nat.HjbConfig.from_buffer_copy(p.cfg)
+        setattr(cfg, field, value)
+        rc, _, msg = nat.query_rc(cfg)
+        assert rc == code and "store_path 4" in msg, (field, rc, msg)
+    wide = psp.Solver("w", psp.LLGC(d=200, off_diag=0.01, T=0.1, seed=42, device=dev()), lr=1e-3, L=1, K=16384 + 16, delta_t=0.01,
+                      loss_method="log-variance", time_approx="inner", adaptive_forward_process=True, detach_forward=True,
+                      u_l2_error_flag=False, verbose=False, seed=42, device=dev(), backend="native", noise="philox", widths=(64, 64))
+    wide.train()
+    wp = wide._native_plan
+    assert wp.family == 2 and not wp.regen_xi and wp.cfg.store_path == 1
+    cfg = nat.HjbConfig.from_buffer_copy(wp.cfg)
+    cfg.store_path = 4
+    rc, _, msg = nat.query_rc(cfg)
+    assert rc == -2 and "narrow kernel family" in msg, (rc, msg)
+    # psp_hjb_rollout_bwd_step: arguments are checked before anything is launched
+    z = torch.zeros(8, device=dev())
+    rc = nat.load().psp_hjb_rollout_bwd_step(C.byref(p.cfg), nat.ptr(p.flat), nat.ptr(p.path), nat.ptr(p.D), nat.ptr(p.sums),
+                                             nat.ptr(p.grad_partial), nat.ptr(p.grad), nat.ptr(p.m), nat.ptr(p.v), nat.ptr(z),
+                                             nat.ptr(z), 1e-3, 0.9, 0.999, 1e-8, None)
+    assert rc == -1 and "store_path 4" in nat.load().psp_last_error().decode()
