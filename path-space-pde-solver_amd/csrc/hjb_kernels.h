@@ -161,6 +161,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// one round of the above with the keys of round r handed in (k0 + r W0, k1 + r W1): the forward kernels of the split-product mode
+// run the ten rounds of a call as separate slices between the MFMAs of their products (hjb_fwd_kernel: philox_slice)
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * (unsigned long long)c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+}
+
 // two Box-Muller pairs -> four N(0,1) values
 __device__ __forceinline__ f32x4 normal4(const uint32_t (&r)[4]) {
     // u = (m + 1/2) 2^-24, m = the upper 24 bits: as ONE fma (m 2^-24 + 2^-25 rounds once; (m + 0.5) 2^-24 rounds the sum and
@@ -438,10 +449,11 @@ __device__ __forceinline__ void stage_aop_x3(float* dstf, int MB, int tid, int n
 struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
 // `between(u)` runs after the products of unit u (u = S * MB + mb): the forward kernels hand their path stores over in
 // portions so that they stand BETWEEN the MFMAs (the scheduler clusters them into bursts of 28 - 32 otherwise, and a burst
-// blocks the in-order wave while the store path drains at 16 B/clk per CU); fences with a functor do not let VMEM cross.
+// blocks the in-order wave while the store path drains at 16 B/clk per CU), and the slices of their Philox calls so that they
+// run in the MFMAs' shadow; fences with a functor let nothing cross.
 template <int MB, int KS, int INB, int CU = 2, class BT = NoBetween>
 __device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, const f32x4 (&in)[INB], int lane, BT between = BT()) {
-    constexpr int kFence = std::is_same<BT, NoBetween>::value ? kFenceMask : (0x1 | 0x2 | 0x4);
+    constexpr int kFence = std::is_same<BT, NoBetween>::value ? kFenceMask : 0;      // (with a functor: nothing crosses a unit's fence)
     using SG = SplitGeo<KS, INB>;
     constexpr int NS = SG::NS;
     static_assert(MB * SG::per_mb * 4 <= 65536, "table exceeds the 16-bit ds_read immediate offset");
@@ -510,7 +522,7 @@ __device__ __forceinline__ void split_panel8(const f32x4 (&in)[INB], f16x8 (&bh)
 template <int MB, int KS, int INB, int CU = 2, class BT = NoBetween>
 __device__ __forceinline__ void gemm_Txs(f32x4 (&acc)[MB], const float* wlds, const f16x8 (&bh)[INB / 2 > 0 ? INB / 2 : 1],
                                          const f16x8 (&bl)[INB / 2 > 0 ? INB / 2 : 1], const f32x4& last, int lane, BT between = BT()) {
-    constexpr int kFence = std::is_same<BT, NoBetween>::value ? kFenceMask : (0x1 | 0x2 | 0x4);
+    constexpr int kFence = std::is_same<BT, NoBetween>::value ? kFenceMask : 0;      // (with a functor: nothing crosses a unit's fence)
     using SG = SplitGeo<KS, INB>;
     constexpr int NS = SG::NS;
     lane = opaque_i(lane);
@@ -826,6 +838,40 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             f32x4 h2[HB];
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
+            // Split-product FAST instances: the Brownian increments of this step are generated IN the W2 and W3 products --
+            // the 11 DB slices of the step's Philox calls (ten rounds and the Box-Muller finish per call) are dealt out over the
+            // products' units and stand between their MFMAs.  An f16 MFMA stream hides three VALU instructions per MFMA
+            // completely, even within one wave (tools/r3/ubench/mfma_valu_overlap.hip: 1 MFMA + 3 VALU 11.9 ns against 14.8 ns for
+            // the MFMA alone); the noise was 22 % of the step standing by itself.  Bit-identical to philox_block.
+            constexpr int NUH2 = (HB / 2) * HB, NUH3 = (HB / 2) * DB;
+            constexpr bool PREGEN = X3 && FAST && (NUH2 + NUH3 > 0);
+            [[maybe_unused]] f32x4 xig[PREGEN ? DB : 1];
+            [[maybe_unused]] uint32_t pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0;
+            auto philox_slice = [&](int sidx) __attribute__((always_inline)) {
+                const int b = sidx / 11, sub = sidx % 11;
+                if (sub == 0) { pc0 = kglob; pc1 = (uint32_t)n; pc2 = (uint32_t)(4 * b + q); pc3 = iter_now; }
+                if (sub < 10) {
+                    philox_round(pc0, pc1, pc2, pc3, a.seed_lo + (uint32_t)sub * 0x9E3779B9u, a.seed_hi + (uint32_t)sub * 0xBB67AE85u);
+                    // (pins the round to this unit: pure arithmetic is otherwise sunk to its use in the noise phase, past the fences)
+                    asm volatile("" : "+v"(pc0), "+v"(pc1), "+v"(pc2), "+v"(pc3));
+                } else {
+                    const uint32_t rr[4] = {pc0, pc1, pc2, pc3};
+                    f32x4 xi = normal4(rr);
+                    if (16 * b + 16 > D) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
+                    }
+                    asm volatile("" : "+v"(xi));
+                    xig[b < DB ? b : 0] = xi;
+                }
+            };
+            auto philox_portion = [&](int u) __attribute__((always_inline)) {      // slices of unit u of the NUH2 + NUH3 units
+                if constexpr (PREGEN) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 11 * DB; ++sidx)
+                        if (sidx >= u * (11 * DB) / (NUH2 + NUH3) && sidx < (u + 1) * (11 * DB) / (NUH2 + NUH3)) philox_slice(sidx);
+                }
+            };
             // hidden activations for the backward pass (no recompute); split-product instances: h1 between the units of the
             // W2 product, h2 between those of the W3 product
             auto h_store = [&](const f32x4 (&h)[HB], int slot, int u, int NU) __attribute__((always_inline)) {
@@ -836,9 +882,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
                             PSP_PATH_STORE(pblk + (slot / 64 + ks) * 64, h[ks >> 2][ks & 3]);
                 }
             };
-            constexpr int NUH2 = (HB / 2) * HB, NUH3 = (HB / 2) * DB;
             if constexpr (X3) {
-                gemm_Tx<HB, KSH, HB, 2>(h2, lds + oW2, h1, lane, [&](int u) __attribute__((always_inline)) { h_store(h1, G::pH1, u, NUH2); });
+                gemm_Tx<HB, KSH, HB, 2>(h2, lds + oW2, h1, lane, [&](int u) __attribute__((always_inline)) { h_store(h1, G::pH1, u, NUH2); philox_portion(u); });
                 if constexpr (NUH2 == 0) h_store(h1, G::pH1, 0, 1);
             }
             else if constexpr (BF16) gemm_Tb<HB, HB>(h2, lds + oW2, h1, lane);
@@ -856,7 +901,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
             for (int m = 0; m < DB; ++m) Z[m] = vb3[m * 4];
             if constexpr (X3) {
-                gemm_Tx<DB, KSH, HB, 2>(Z, lds + oW3, h2, lane, [&](int u) __attribute__((always_inline)) { h_store(h2, G::pH2, u, NUH3); });
+                gemm_Tx<DB, KSH, HB, 2>(Z, lds + oW3, h2, lane, [&](int u) __attribute__((always_inline)) { h_store(h2, G::pH2, u, NUH3); philox_portion(NUH2 + u); });
                 if constexpr (NUH3 == 0) h_store(h2, G::pH2, 0, 1);
             }
             else if constexpr (BF16) gemm_Tb<DB, HB>(Z, lds + oW3, h2, lane);
@@ -868,7 +913,9 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
             for (int b = 0; b < DB; ++b) {
                 f32x4 xi;
-                if (FAST || a.noise_mode == NOISE_PHILOX) {
+                if constexpr (PREGEN) {
+                    xi = xig[b];
+                } else if (FAST || a.noise_mode == NOISE_PHILOX) {
                     xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + q), iter_now, a.seed_lo, a.seed_hi);
                 } else {
                     // unconditional clamped loads + select: no per-element branch around the load
