@@ -497,8 +497,14 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                             xi[r] = xrow[f < D ? f : D - 1];
                         }
                     }
+                    // padding carries no noise.  (Only blocks that CONTAIN padding are masked, behind a wave-uniform test: the 4 DB
+                    // per-lane masks of the unconditional form were hoisted out of the time loop as 2 x 4 DB SGPRs, spilled to VGPR
+                    // lanes, and the VGPRs that made room for them were reloaded from scratch in every step)
+                    if (16 * b + 16 > dr) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= dr || !kvalid) xi[r] = 0.f;   // padding carries no noise
+                        for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= dr) xi[r] = 0.f;
+                    }
+                    if (!kvalid) xi = zero4x;
                     if (store_img) {
                         const f32x4 wv = store_cxi * xi + store_cz * Zg[m];
 #pragma unroll
