@@ -104,3 +104,23 @@ def test_store_path_4_is_refused_where_the_image_is_not_the_increment():
                                              nat.ptr(p.grad_partial), nat.ptr(p.grad), nat.ptr(p.m), nat.ptr(p.v), nat.ptr(z),
                                              nat.ptr(z), 1e-3, 0.9, 0.999, 1e-8, None)
     assert rc == -1 and "store_path 4" in nat.load().psp_last_error().decode()
+
+
+def test_headline_shape_regenerated_equals_stored():
+    """BASELINE.json's headline shape (d=100, H=64, K=65536, N=100, split products): two iterations with the increments kept in the
+    path store and with them regenerated by the backward agree bit for bit in D, loss, gradient and parameters."""
+    pb = psp.LLGC(d=100, off_diag=0.01, T=1.0, seed=42, device=dev())
+
+    def go(path_noise):
+        m = psp.Solver("hl", pb, lr=1e-3, L=2, K=65536, delta_t=0.01, loss_method="log-variance", time_approx="inner",
+                       adaptive_forward_process=True, detach_forward=True, u_l2_error_flag=False, verbose=False, seed=42, device=dev(),
+                       backend="native", noise="philox", widths=(64, 64), path_noise=path_noise)
+        m.train()
+        return m, m._native_plan
+
+    a, pa = go("store")
+    b, pb2 = go("auto")
+    assert pa.cfg.store_path == 1 and pb2.cfg.store_path == 4 and pb2.matrix_mode == "f16x3"
+    assert a.loss_log == b.loss_log and all(v == v for v in a.loss_log)
+    assert torch.equal(pa.D, pb2.D) and torch.equal(pa.grad, pb2.grad) and torch.equal(pa.flat, pb2.flat)
+    assert b.range_fallback_iterations == 0
