@@ -40,7 +40,9 @@
 extern "C" {
 #endif
 
-#define PSP_VERSION 301 /* 0.3.0: range_flag in psp_hjb_config / psp_gen_config (guarded split-product mode); 0.3.1: store_path 4 */
+#define PSP_VERSION 400 /* 0.3.0: range_flag in psp_hjb_config / psp_gen_config (guarded split-product mode); 0.3.1: store_path 4;
+                         * 0.4.0: PSP_DOM_ANNULUS; psp_genl_config.activation / linear_layout, psp_genl_rollout_bwd replaces
+                         *        psp_genl_adjoints (hand-written weight gradient), psp_genl_sizes re-laid out */
 
 /* drift b(x): reference problems.py:36-37,154-155 (dense), :311-315 (double well) */
 enum { PSP_DRIFT_ZERO = 0, PSP_DRIFT_DENSE = 1, PSP_DRIFT_DIAG = 2, PSP_DRIFT_DOUBLE_WELL = 3 };
@@ -313,8 +315,11 @@ enum { PSP_GH_ZERO = 0, PSP_GH_QUAD = 1, PSP_GH_ALLEN_CAHN = 2, PSP_GH_EXPBALL_L
  *   SPHERE        |X_n| < dom_a               (the state BEFORE the move, as the reference tests it)
  *   BOX           dom_a <= X_proposal <= dom_b in every coordinate
  *   BOX_UPPER_ALL X_proposal <= dom_b in every coordinate   (EllipticSolver, one_boundary)
- *   BOX_UPPER_ANY X_proposal <= dom_b in some coordinate    (GeneralSolver, one_boundary) */
-enum { PSP_DOM_NONE = 0, PSP_DOM_SPHERE = 1, PSP_DOM_BOX = 2, PSP_DOM_BOX_UPPER_ALL = 3, PSP_DOM_BOX_UPPER_ANY = 4 };
+ *   BOX_UPPER_ANY X_proposal <= dom_b in some coordinate    (GeneralSolver, one_boundary; also the exit test of
+ *                                                            'square-corner', solver.py:759-760)
+ *   ANNULUS       dom_a < |X_n| < dom_b       ('two_spheres', solver.py:1122-1123, :752-753; the state before the move) */
+enum { PSP_DOM_NONE = 0, PSP_DOM_SPHERE = 1, PSP_DOM_BOX = 2, PSP_DOM_BOX_UPPER_ALL = 3, PSP_DOM_BOX_UPPER_ANY = 4,
+       PSP_DOM_ANNULUS = 5 };
 
 typedef struct psp_gen_config {
     int32_t d, H, K_local, N;
@@ -329,7 +334,7 @@ typedef struct psp_gen_config {
     int32_t store_path;   /* 1: keep what the backward pass needs                            */
     int32_t domain_kind;  /* PSP_DOM_*                                                         */
     const float* drift;   /* DOUBLE_WELL: kappa (d); DIAG: a (d); else NULL                  */
-    float dom_a, dom_b;   /* sphere radius (dom_a) or box bounds X_l, X_r                     */
+    float dom_a, dom_b;   /* sphere radius (dom_a), box bounds X_l, X_r, or annulus radii r_1, r_2 */
     float h_par[4];       /* PSP_GH_EXPBALL_*: al, d (the REAL dimension, not a padded one), e, tau */
     int32_t d_real;       /* components the exit test and |x|^2 read when d is a zero-padded instance (0: all d);
                            * the padding carries device noise, which nothing else ever reads                */
@@ -386,55 +391,54 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
                         const float* wY, const float* wV, float* grad_partial, float* grad_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * GeneralSolver / EllipticSolver with a value net of ANY depth: V = DenseNet(d [+ 1] -> 1, arch = [H_1 .. H_L]), 1 <= L <= 4,
- * H_i <= 128, d + 1 <= 112 (reference function_space.py:116-140; the nets the diffusion-loss notebooks swap into model.V:
- * Allen-Cahn.ipynb:72 arch = [110, 110, 50], [30, 30, 30, 30], ...).  Shapes are run-time arguments: activations in per-wave
- * LDS images, weights as A-operand tables in global memory (csrc/genl_kernels.h).  The step is the one of psp_gen_rollout_fwd
- * (same noise counters, exit tests, h kinds, outputs); the parameter gradient is formed by
- *   psp_genl_adjoints  per sample: activations a, their tangent a' along s u^, and the adjoints zbar_i, zbar_i' of every
- *                      layer's pre-activation, written as row-major (sample, padded feature) matrices, and by the CALLER's
- *   library GEMMs      dW_i = A[:, :in_i]^T Zbar_i + A'[:, :in_i]^T Zbar_i',  db_i = column sums of Zbar_i,
- *                      dw_out = A^T a + A'^T w,  db_out = sum a      (plain GEMMs over the sample axis).
+ * GeneralSolver / EllipticSolver with a value net of ANY depth: V = dense-concat net (d [+ 1] -> 1, arch = [H_1 .. H_L]),
+ * 1 <= L <= 4, H_i <= 128, d + 1 <= 112 (reference function_space.py:116-140 DenseNet, relu^2; :143-158 DenseNet_tanh, tanh with
+ * nn.Linear weights; the nets the diffusion-loss notebooks swap into model.V: Allen-Cahn.ipynb:72 arch = [110, 110, 50],
+ * [30, 30, 30, 30], `Committor function.ipynb` cell 1: [d + 10, d, d, d] with tanh^2).  Shapes and activation are run-time
+ * arguments: activations in per-tile LDS images, weights as A-operand tables in global memory (csrc/genl_kernels.h).  The
+ * step is the one of psp_gen_rollout_fwd (same noise counters, exit tests, h kinds, outputs); a tile whose trajectories have
+ * all stopped leaves the time loop early (solver.py:1093-1097 / :742-744) and the backward pass skips what it did not execute.
  */
+enum { PSP_ACT_RELU2 = 0,   /* h = relu(z)^2   (function_space.py:138)                       */
+       PSP_ACT_TANH2 = 1,   /* h = tanh(z)^2   (Committor function.ipynb, DenseNet_tanh_2)    */
+       PSP_ACT_TANH = 2 };  /* h = tanh(z)     (function_space.py:157)                        */
+
 typedef struct psp_genl_config {
     psp_gen_config base;      /* d = state dimension; H, mlp_dtype, d_real, v_steps_out, y_steps_out, per_sample_weights, range_flag unused */
     int32_t has_time;         /* 1: network input [x, t] (GeneralSolver), 0: [x] (EllipticSolver; base.T = +inf)                 */
     int32_t n_hidden;         /* L                                                                                              */
     int32_t widths[4];        /* H_1 .. H_L                                                                                     */
+    int32_t activation;       /* PSP_ACT_*                                                                                      */
+    int32_t linear_layout;    /* 0: weights stored (in, out) (DenseNet); 1: (out, in) (nn.Linear, DenseNet_tanh)                */
 } psp_genl_config;
 
 typedef struct psp_genl_sizes {
-    int64_t table_bytes;      /* scratch for the operand tables (rebuilt by every call that takes `tables`)                     */
+    int64_t table_bytes;      /* scratch for the operand tables (rebuilt by every forward call)                                 */
     int64_t path_bytes;       /* (N + 1) x ceil(K/16) blocks of x and s u^ images                                               */
-    int64_t ahat_bytes;       /* (N + 1) x 16 ceil(K/16) floats                                                                 */
-    int64_t n_params;         /* DenseNet registration order W_1, b_1, .., W_out, b_out; weights (in, out)                       */
-    int32_t act_floats_per_block;   /* 256 x (TB + 1): one 16-sample block of the A / A' outputs (TB padded 16-feature blocks
-                                       and one trailing block: (1, 0, .., 0) in A, zeros in A')                                  */
-    int32_t zbar_floats_per_block;  /* 256 x (sum_i ceil(H_i / 16) + 1): one block of the Zbar / Zbar' outputs; the trailing
-                                       16-float block of a row is (a, 0, .., 0) in Zbar and (w, 0, .., 0) in Zbar'               */
+    int64_t ahat_bytes;       /* (N + 1) x 16 ceil(K/16) floats, then ceil(K/16) int32: the step count of every tile            */
+    int64_t n_params;         /* registration order W_1, b_1, .., W_out, b_out                                                  */
+    int64_t grad_partial_bytes;     /* per-workgroup partial gradients of psp_genl_rollout_bwd                                  */
     int32_t n_blocks;         /* (N + 1) x ceil(K/16) sample blocks                                                              */
-    int32_t fwd_workgroups;
+    int32_t fwd_workgroups, bwd_workgroups;
+    int32_t waves_per_tile;   /* 1 (small nets, no barriers) or 8                                                               */
     int32_t seg_block_offset[5];    /* first padded 16-feature block of segment s (0: input, s: h_s); [L] + ceil(H_L/16) = TB    */
     int32_t reserved;
 } psp_genl_sizes;
 
-/* <0: shape outside the limits above, or the per-wave LDS images exceed 160 KiB. */
+/* <0: shape outside the limits above, or the activation images exceed 160 KiB. */
 int psp_genl_query(const psp_genl_config* cfg, psp_genl_sizes* out);
-/* Forward rollout; arguments as psp_gen_rollout_fwd plus the table scratch. */
+/* Forward rollout; arguments as psp_gen_rollout_fwd plus the table scratch.  `ahat` is required (it carries the tiles' step
+ * counts behind the coefficients). */
 int psp_genl_rollout_fwd(const psp_genl_config* cfg, const float* params, const float* x0, const float* t0, const float* xi,
                          uint64_t seed, uint32_t iter, float* tables, float* path, float* ahat, float* VN, float* YN,
                          float* XN, float* tN, unsigned long long* kcount, void* stream);
-/* Adjoint pass over the sample blocks [blk0, blk1) of the path store (block = n * ceil(K/16) + tile; a caller with a memory
- * budget walks the store in slabs).  wY, wV: per-trajectory loss weights as for psp_gen_rollout_bwd (zero padded to
- * 16 ceil(K/16)).  out_A, out_Ad: row-major (16 (blk1 - blk0) samples) x (act_floats_per_block / 16 padded features: segment s
- * of the concatenation starts at column 16 seg_block_offset[s]); out_Zb, out_Zdb: (samples) x (zbar_floats_per_block / 16), layer i
- * at column 16 sum_{j<i} ceil(H_j/16); out_av, out_wy: (samples) coefficients (a of V, w of the tangent part), also found in
- * the trailing block of the Zbar / Zbar' rows.  With the trailing blocks M = A^T Zbar + A'^T Zbar' holds every gradient: the
- * weight blocks, the bias gradients in row 16 TB (ones column of A) and the output layer in column 16 sum_i ceil(H_i/16).
+/* Backward pass (replaces loss.backward() of solver.py:1187 / :814 for the domain part of the loss), arguments as
+ * psp_gen_rollout_bwd: wY, wV per-trajectory loss weights zero padded to 16 ceil(K/16).  One kernel recomputes the activations
+ * of every executed sample block, runs the adjoint sweep and accumulates all parameter gradients (weight tiles as MFMA outer
+ * products over the samples of the block); grad_partial (psp_genl_sizes.grad_partial_bytes) is summed in a fixed order.
  * `tables` must hold the tables of the SAME parameters (psp_genl_rollout_fwd leaves them there). */
-int psp_genl_adjoints(const psp_genl_config* cfg, const float* params, const float* tables, const float* path, const float* ahat,
-                      const float* wY, const float* wV, int64_t blk0, int64_t blk1, float* out_A, float* out_Ad,
-                      float* out_Zb, float* out_Zdb, float* out_av, float* out_wy, void* stream);
+int psp_genl_rollout_bwd(const psp_genl_config* cfg, const float* params, const float* tables, const float* path,
+                         const float* ahat, const float* wY, const float* wV, float* grad_partial, float* grad_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Solver.train with a DenseNet control (function_space.py:116-140: dense-concat layers, relu^2, weights (in, out)):

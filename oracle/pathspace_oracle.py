@@ -295,10 +295,13 @@ class TanhMLP(torch.nn.Module):
 
 
 class DenseNetOracle(torch.nn.Module):
-    """function_space.py:116-140: dense-concat net, relu(.)**2, weights randn*0.1, zero bias."""
+    """function_space.py:116-140: dense-concat net, relu(.)**2, weights randn*0.1, zero bias.  ``activation='tanh2'`` is the
+    variant `Committor function.ipynb` (cell 1, DenseNet_tanh_2) defines for itself and swaps into model.V: the same
+    constructor, tanh(.)**2 in the forward."""
 
-    def __init__(self, d_in, d_out, lr, arch=(30, 30), seed=42):
+    def __init__(self, d_in, d_out, lr, arch=(30, 30), seed=42, activation="relu2"):
         super().__init__()
+        self.activation = activation
         torch.manual_seed(seed)                                      # :119
         dims = [d_in] + list(arch) + [d_out]
         self.dims = dims
@@ -317,9 +320,46 @@ class DenseNetOracle(torch.nn.Module):
             lin = torch.matmul(x, self.W[2 * i]) + self.W[2 * i + 1]
             if i == nl - 1:
                 x = lin
+            elif self.activation == "tanh2":
+                x = torch.cat([x, torch.tanh(lin) ** 2], dim=1)      # Committor function.ipynb cell 1
             else:
                 x = torch.cat([x, torch.nn.functional.relu(lin) ** 2], dim=1)
         return x
+
+
+class DenseNetTanhOracle(torch.nn.Module):
+    """function_space.py:143-158 (DenseNet_tanh): dense-concat net of nn.Linear layers with tanh."""
+
+    def __init__(self, d_in, d_out, lr, arch=(30, 30), seed=42):
+        super().__init__()
+        torch.manual_seed(seed)                                      # :146
+        dims = [d_in] + list(arch) + [d_out]
+        self.dims = dims
+        self.layers = torch.nn.ModuleList([torch.nn.Linear(sum(dims[:i + 1]), dims[i + 1])
+                                           for i in range(len(dims) - 1)])     # :148-149
+        self.optim = torch.optim.Adam(self.parameters(), lr=lr)      # :150
+
+    def forward(self, x):                                            # :152-158
+        nl = len(self.dims) - 1
+        for i in range(nl):
+            if i == nl - 1:
+                x = self.layers[i](x)
+            else:
+                x = torch.cat([x, torch.tanh(self.layers[i](x))], dim=1)
+        return x
+
+
+def value_net(d_in, lr, seed, net=None, arch=None):
+    """The value net of a golden case: ``net`` = dict(kind, arch, seed) ('densenet' / absent kind: DenseNet; 'user_tanh2': the
+    committor notebook's own class; 'densenet_tanh': DenseNet_tanh), or just ``arch`` for a DenseNet with the solver's seed."""
+    if net is None:
+        kw = {} if arch is None else dict(arch=arch)
+        return DenseNetOracle(d_in, 1, lr, seed=seed, **kw)
+    kind = net.get("kind", "densenet")
+    if kind == "densenet_tanh":
+        return DenseNetTanhOracle(d_in, 1, lr, arch=net["arch"], seed=net["seed"])
+    return DenseNetOracle(d_in, 1, lr, arch=net["arch"], seed=net["seed"],
+                          activation="tanh2" if kind == "user_tanh2" else "relu2")
 
 
 class ScalarY0(torch.nn.Module):
@@ -518,12 +558,37 @@ class GeneralConfig:
     adaptive_forward_process: bool = False
     detach_forward: bool = True
     uniform_square: bool = False
+    loss_with_stopped: bool = False
+    K_test_log: Optional[int] = None
+    sample_center: bool = False
 
 
-def general_build(problem: OracleProblem, cfg: GeneralConfig, arch=None):
+def general_build(problem: OracleProblem, cfg: GeneralConfig, arch=None, net=None):
     torch.manual_seed(cfg.seed)                                      # :978
-    kw = {} if arch is None else dict(arch=arch)
-    return DenseNetOracle(problem.d + 1, 1, cfg.lr, seed=cfg.seed, **kw)    # :980
+    return value_net(problem.d + 1, cfg.lr, cfg.seed, net=net, arch=arch)    # :980 (or the net the caller swaps in)
+
+
+def compute_test_error(V, problem: OracleProblem, K: int, modus: str):
+    """utilities.py:441-472: Monte-Carlo error of V on K fresh points of the domain (CPU generator)."""
+    ex, d = problem.extra, problem.d
+    if ex["boundary"] in ("sphere", "unbounded"):
+        X = torch.randn(K, d)                                        # :446
+        X = ex["boundary_distance"] * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * (torch.rand(K).unsqueeze(1) ** (1 / d))
+    elif ex["boundary"] == "two_spheres":
+        X = torch.randn(K, d)                                        # :449
+        X = ex["boundary_distance_2"] * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * (torch.rand(K).unsqueeze(1) ** (1 / d))
+        X = X[torch.sqrt(torch.sum(X ** 2, 1)) > ex["boundary_distance_1"], :]      # :451-452
+    else:
+        X = (ex["X_r"] - ex["X_l"]) * torch.rand(K, d) + ex["X_l"]   # :456
+    if modus == "parabolic":
+        t_n = torch.rand(K, 1) * problem.T                           # :459
+        v_true = np.array(ex["v_true"](X.detach(), t_n.squeeze()).squeeze())
+        v_est = V(torch.cat([X, t_n], 1)).squeeze().detach().numpy()
+    else:
+        v_true = np.array(ex["v_true"](X.detach()).squeeze())        # :467
+        v_est = V(X).squeeze().detach().numpy()
+    return float(np.mean((v_true - v_est) ** 2)), float(np.mean(np.abs(v_true - v_est))), \
+        float(np.mean(np.abs(v_true - v_est) / v_true))
 
 
 def sample_boundary(problem: OracleProblem, Kb: int):
@@ -597,10 +662,13 @@ def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=Fals
     bnd = problem.extra["boundary"]
     bounded = "unbounded" not in bnd
     btype = problem.extra.get("boundary_type")
-    out = dict(loss_log=[], K_log=[], traces=[])
+    out = dict(loss_log=[], K_log=[], traces=[], V_test_L2=[])
     torch.manual_seed(cfg.seed)                                      # :1003
     for l in range(cfg.L):
         loss = 0
+        if cfg.sample_center:                                        # :1015-1017
+            X_center = torch.zeros(1, 1)
+            loss = loss + torch.mean((V(X_center).squeeze() - problem.extra["v_true"](X_center).squeeze()) ** 2)
         if bounded:
             X_boundary = sample_boundary(problem, cfg.K_boundary)    # :1020-1038
         if bnd in ("unbounded", "sphere"):                           # :1040
@@ -684,12 +752,16 @@ def general_train(problem: OracleProblem, cfg: GeneralConfig, V=None, trace=Fals
                     loss = loss + torch.mean((Y[T_selection] - problem.f(X[T_selection, :])) ** 2)   # :1181
                 if torch.sum(T_selection) < K:                       # :1182-1183: grad_V of the LAST executed step, final X, all K
                     loss = loss + torch.mean((torch.sum(grad_V * X, 1) - torch.sum(problem.g(X, t_n.squeeze()) * X, 1)) ** 2)
+        if cfg.loss_with_stopped:                                    # :1185-1186
+            loss = loss + torch.mean((Y[stopped] - problem.f(X[stopped, :])) ** 2)
         loss.backward()                                              # :1187
         if trace:
             tr["grads"] = [p.grad.detach().clone() for p in V.parameters()]
             tr["VN_minus_Y"] = None
         V.optim.step()                                               # :1188
         out["loss_log"].append(loss.item())                          # :1192
+        if cfg.K_test_log is not None:                               # :1193-1197
+            out["V_test_L2"].append(compute_test_error(V, problem, cfg.K_test_log, "parabolic")[0])
         if trace:
             out["traces"].append(tr)
     out["V"] = V
@@ -714,12 +786,14 @@ class EllipticConfig:
     detach_forward: bool = True
     boundary_type: str = "Dirichlet"
     uniform_square: bool = False
+    loss_with_stopped: bool = False
+    K_test_log: Optional[int] = None
+    sample_center: bool = False
 
 
-def elliptic_build(problem: OracleProblem, cfg: EllipticConfig, arch=None):
+def elliptic_build(problem: OracleProblem, cfg: EllipticConfig, arch=None, net=None):
     torch.manual_seed(cfg.seed)                                      # :604
-    kw = {} if arch is None else dict(arch=arch)
-    return DenseNetOracle(problem.d, 1, cfg.lr, seed=cfg.seed, **kw)     # :606
+    return value_net(problem.d, cfg.lr, cfg.seed, net=net, arch=arch)    # :606 (or the net the caller swaps in)
 
 
 def elliptic_train(problem: OracleProblem, cfg: EllipticConfig, V=None, trace=False):
@@ -730,11 +804,14 @@ def elliptic_train(problem: OracleProblem, cfg: EllipticConfig, V=None, trace=Fa
     dt32 = torch.tensor(cfg.delta_t)                                 # :576
     sq_dt32 = torch.sqrt(dt32)                                       # :577
     K, d, ex = cfg.K, problem.d, problem.extra
-    out = dict(loss_log=[], K_log=[], V_L2_log=[], traces=[])
+    out = dict(loss_log=[], K_log=[], V_L2_log=[], traces=[], V_test_L2=[])
     torch.manual_seed(cfg.seed)                                      # :630
     np.random.seed(cfg.seed)                                         # :631
     for l in range(cfg.L):
         loss = 0
+        if cfg.sample_center:                                        # :643-645
+            X_center = torch.zeros(1, 1)
+            loss = loss + torch.mean((V(X_center).squeeze() - ex["v_true"](X_center).squeeze()) ** 2)
         X_boundary = sample_boundary(problem, cfg.K_boundary)        # :650-680
         if cfg.loss_method != "BSDE":                                # :683 (boundary_loss=True)
             if cfg.boundary_type == "Dirichlet":
@@ -806,6 +883,8 @@ def elliptic_train(problem: OracleProblem, cfg: EllipticConfig, V=None, trace=Fa
         out["K_log"].append(int(K_count))                            # :803
         if cfg.loss_method == "BSDE":
             loss = loss + torch.mean((problem.g(X) - Y) ** 2)        # :808
+        if cfg.loss_with_stopped:                                    # :803-804
+            loss = loss + torch.mean((problem.g(X[stopped, :]) - Y[stopped]) ** 2)
         V.zero_grad()                                                # :813
         loss.backward()                                              # :814
         if trace:
@@ -813,6 +892,8 @@ def elliptic_train(problem: OracleProblem, cfg: EllipticConfig, V=None, trace=Fa
         V.optim.step()                                               # :815
         out["loss_log"].append(loss.item())                          # :819
         out["V_L2_log"].append(torch.mean(V_L2).item())              # :820
+        if cfg.K_test_log is not None:                               # :821-825
+            out["V_test_L2"].append(compute_test_error(V, problem, cfg.K_test_log, "elliptic")[0])
         if trace:
             out["traces"].append(tr)
     out["V"] = V

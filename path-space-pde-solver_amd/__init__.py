@@ -8,7 +8,7 @@ The directory can be used in two ways:
     ``from solver import Solver``; ``from problems import LLGC`` -- the module names the
     reference's notebooks import.
 """
-from .function_space import (Affine, Constant, DenseNet, DenseNet_tanh, Linear, MySequential,  # noqa: F401
+from .function_space import (Affine, Constant, DenseNet, DenseNet_tanh, DenseNet_tanh_2, Linear, MySequential,  # noqa: F401
                              SingleParam)
 from .problems import (LLGC, LQGC, AllenCahn, DoubleWell_multidim,  # noqa: F401
                        DoubleWell_multidim_for_general_solver, HeatEquation, ExponentialOnSphere,
@@ -24,5 +24,5 @@ from .utilities import do_importance_sampling_me  # noqa: F401
 
 __all__ = ['Solver', 'GeneralSolver', 'EllipticSolver', 'ExponentialOnSphere', 'ExponentialOnBallNonlinear',
            'ExponentialOnBallNonlinearSin', 'ExponentialOnSphereNonlinearParabolic', 'QuadraticOnBox', 'Committor', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
-           'AllenCahn', 'HeatEquation', 'MySequential', 'DenseNet', 'DenseNet_tanh', 'SingleParam',
+           'AllenCahn', 'HeatEquation', 'MySequential', 'DenseNet', 'DenseNet_tanh', 'DenseNet_tanh_2', 'SingleParam',
            'Constant', 'Linear', 'Affine', 'PlanUnsupported', 'native']

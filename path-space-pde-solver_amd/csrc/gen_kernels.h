@@ -16,8 +16,10 @@
 namespace psp {
 
 enum { GH_ZERO = 0, GH_QUAD = 1, GH_ALLEN_CAHN = 2, GH_EXPBALL_LIN = 3, GH_EXPBALL_SQ = 4, GH_EXPBALL_SIN = 5 };
-// exit test of a bounded domain (solver.py:1119-1129, :758-767): sphere |X_n| < a (the state BEFORE the move), boxes on the proposal
-enum { DOM_NONE = 0, DOM_SPHERE = 1, DOM_BOX = 2, DOM_BOX_UPPER_ALL = 3, DOM_BOX_UPPER_ANY = 4 };
+// exit test of a bounded domain (solver.py:1119-1129, :758-767): sphere |X_n| < a (the state BEFORE the move), boxes on the proposal,
+// annulus a < |X_n| < b ('two_spheres', :1122-1123 / :752-753; the state before the move).  'square-corner' (:759-760) tests
+// any(X_proposal <= X_r): that is DOM_BOX_UPPER_ANY
+enum { DOM_NONE = 0, DOM_SPHERE = 1, DOM_BOX = 2, DOM_BOX_UPPER_ALL = 3, DOM_BOX_UPPER_ANY = 4, DOM_ANNULUS = 5 };
 
 struct GenArgs {
     const float* params;
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
         float t = kvalid ? a.t0[k] : 0.f;
         bool stopped = !kvalid;
         float Y = 0.f;
+        int msteps = 0;                                             // active steps of this trajectory (exact)
 
         // one network evaluation at the current (X, t): fills r1, r2 (relu(z)), returns V
         auto net_value = [&](const f32x4* vecs, f32x4 (&r1)[HB], f32x4 (&r2)[HB]) {
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             };
             // ---- exit test of a bounded domain (solver.py:1119-1129; EllipticSolver :758-767) and |x|^2 for the x-dependent h
             float rr = 0.f;
-            if (a.domain_kind == DOM_SPHERE || a.h_kind >= GH_EXPBALL_LIN) {
+            if (a.domain_kind == DOM_SPHERE || a.domain_kind == DOM_ANNULUS || a.h_kind >= GH_EXPBALL_LIN) {
 #pragma unroll
                 for (int b = 0; b < DBI; ++b)
 #pragma unroll
@@ -354,6 +357,9 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             bool inside = true;
             if (a.domain_kind == DOM_SPHERE) {
                 inside = sqrtf(rr) < a.dom_a;                        // the state BEFORE the move (:1121)
+            } else if (a.domain_kind == DOM_ANNULUS) {
+                const float rad = sqrtf(rr);                         // :1122-1123 / :752-753, the state before the move
+                inside = rad > a.dom_a && rad < a.dom_b;
             } else if (a.domain_kind >= DOM_BOX) {
                 // the boxes test the PROPOSAL (:1126-1129): one extra pass over the blocks (noise regenerated: the
                 // move itself needs the verdict, and keeping both images would cost the unbounded case registers)
@@ -480,6 +486,7 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             t = t + dt * actf;
             put_time(t);
             if (act && q == 0) ++nact;
+            msteps += act ? 1 : 0;
             stopped = stopped || !in_time;
         }
         // ---- final point: V(X_N, t_N) (solver.py:1163) as an extra value-only sample
@@ -519,7 +526,9 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 }
                 if (q == 0) a.ahat[(size_t)a.N * (a.ntile16 * 16) + k] = 1.f;
             }
-            if (kvalid && q == 0) { a.VN[k] = VN; a.YN[k] = Y; a.tN[k] = t; }
+            // (EllipticSolver: T = +inf and no time input; t_N then only counts the active steps -- as m dt with ONE rounding, so that
+            //  round(t_N / dt) is exact however long the trajectory ran: the committor notebook runs N = 5000)
+            if (kvalid && q == 0) { a.VN[k] = VN; a.YN[k] = Y; a.tN[k] = (Tend == __builtin_inff()) ? (float)msteps * dt : t; }
             if (kvalid) {
 #pragma unroll
                 for (int b = 0; b < DBI; ++b)

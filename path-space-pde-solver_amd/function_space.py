@@ -88,10 +88,17 @@ class DenseNet(nn.Module):
 
     Layer i sees the concatenation of the input and all previous hidden outputs; weights are
     stored (in, out) and drawn as randn * 0.1 with zero biases, in layer order (:121-125).
+    ``activation`` (not a reference argument; default = the reference's relu(.)**2) selects the
+    hidden nonlinearity: 'relu2', 'tanh2' (tanh(.)**2, the net `Committor function.ipynb` defines
+    in its first cell) or 'tanh'.  The parameter draws do not depend on it.
     """
+    ACTIVATIONS = ('relu2', 'tanh2', 'tanh')
 
-    def __init__(self, d_in, d_out, lr, arch=[30, 30], seed=42):
+    def __init__(self, d_in, d_out, lr, arch=[30, 30], seed=42, activation='relu2'):
         super().__init__()
+        if activation not in self.ACTIVATIONS:
+            raise ValueError('activation must be one of %s' % (self.ACTIVATIONS,))
+        self.activation = activation
         torch.manual_seed(seed)
         self.nn_dims = [d_in] + list(arch) + [d_out]
         self.W = []
@@ -104,12 +111,25 @@ class DenseNet(nn.Module):
             self.register_parameter('param %d' % i, w)
         _own_adam(self, lr)
 
+    def _hidden(self, z):
+        if self.activation == 'relu2':
+            return torch.relu(z) ** 2
+        return torch.tanh(z) ** 2 if self.activation == 'tanh2' else torch.tanh(z)
+
     def forward(self, x):
         depth = len(self.nn_dims) - 1
         for i in range(depth - 1):
-            hidden = torch.relu(torch.matmul(x, self.W[2 * i]) + self.W[2 * i + 1]) ** 2
+            hidden = self._hidden(torch.matmul(x, self.W[2 * i]) + self.W[2 * i + 1])
             x = torch.cat([x, hidden], dim=1)
         return torch.matmul(x, self.W[2 * depth - 2]) + self.W[2 * depth - 1]
+
+
+class DenseNet_tanh_2(DenseNet):
+    """Dense-concat net with tanh(.)**2: the class the reference's `Committor function.ipynb` defines in its first cell and
+    swaps into ``model.V`` (same parameter draws as DenseNet)."""
+
+    def __init__(self, d_in, d_out, lr, arch=[30, 30], seed=42):
+        super().__init__(d_in, d_out, lr, arch=arch, seed=seed, activation='tanh2')
 
 
 class DenseNet_tanh(nn.Module):

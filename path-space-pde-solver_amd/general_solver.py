@@ -14,12 +14,14 @@ One iteration (reference solver.py:1009-1201):
   / mean((Y - g(X_N, t_N))^2) ('BSDE');  Adam on V.  EllipticSolver is the same step without the time input.
 
 Execution plans, resolved once in ``train()``:
-  * native (plan_general_native, hand-written HIP): V is a DenseNet(d+1 -> 1) with two hidden
-    layers, problem in the native catalogue, device is a GPU;
-  * composite (this file): the reference op sequence with torch autograd on ``self.device``.
-The 'two_spheres' (committor problem: the batch size changes from iteration to iteration) and 'square-corner' domains, the
-BSDE loss with a Neumann boundary, ``loss_with_stopped``, ``sample_center`` and the ``K_test_log`` diagnostic run on the
-composite plan (never an error: SURVEY.md 8b); PINN and the BSDE-2/3/4 variants are outside the scope of this build.
+  * native (plan_general_native / plan_general_deep, hand-written HIP): V is a dense-concat net (d [+ 1] -> 1) of one to four
+    hidden layers (DenseNet relu^2, DenseNet_tanh, the committor notebook's tanh^2 net, or any module of that structure),
+    problem in the native catalogue, device is a GPU -- on every domain: 'two_spheres' (the committor problem: the batch size
+    changes from iteration to iteration), 'square-corner', the BSDE loss with a Neumann boundary, ``loss_with_stopped``,
+    ``sample_center`` and the ``K_test_log`` diagnostic included;
+  * composite (this file): the reference op sequence with torch autograd on ``self.device`` (CPU runs, user-defined
+    coefficients or nets: never an error).
+PINN and the BSDE-2/3/4 variants are outside the scope of this build.
 """
 import time
 import warnings
@@ -161,21 +163,9 @@ class GeneralSolver:
 
     def composite_only_reason(self):
         """Why this configuration runs on the composite torch plan whatever the net / problem (None: the native plan may take
-        it).  These are the reference features the HIP kernels do not cover; none of them raises."""
-        pb = self.problem
-        if pb.boundary == 'two_spheres':
-            return "boundary 'two_spheres': the batch size changes every iteration (solver.py:1048-1052, :705-710)"
-        if pb.boundary == 'square-corner':
-            return "boundary 'square-corner' (solver.py:706-708, :759-760)"
-        btype = self.boundary_type if self.elliptic else getattr(pb, 'boundary_type', None)
-        if self.bounded and self.loss_method == 'BSDE' and btype == 'Neumann' and not self.elliptic:
-            return 'BSDE loss with a Neumann boundary (solver.py:1177-1183)'
-        if self.sample_center:
-            return 'sample_center (solver.py:1015-1017)'
-        if self.loss_with_stopped:
-            return 'loss_with_stopped (solver.py:1185-1186)'
-        if self.K_test_log:
-            return 'K_test_log: compute_test_error draws from the CPU generator every iteration (solver.py:1193-1197)'
+        it).  Round 4: 'two_spheres', 'square-corner', the BSDE loss with a Neumann boundary, ``sample_center``,
+        ``loss_with_stopped`` and ``K_test_log`` all run on the HIP kernels (plan_general_native.py); nothing of the hot path is
+        left here."""
         return None
 
     @property

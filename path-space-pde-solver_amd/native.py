@@ -25,7 +25,8 @@ GH_ZERO, GH_QUAD, GH_ALLEN_CAHN, GH_EXPBALL_LIN, GH_EXPBALL_SQ, GH_EXPBALL_SIN =
 MLP_FP32, MLP_BF16_FWD, MLP_BF16, MLP_F16X3 = 0, 1, 2, 3
 DT_F32, DT_F64 = 0, 1
 COMM_ID_BYTES = 128
-DOM_NONE, DOM_SPHERE, DOM_BOX, DOM_BOX_UPPER_ALL, DOM_BOX_UPPER_ANY = 0, 1, 2, 3, 4
+DOM_NONE, DOM_SPHERE, DOM_BOX, DOM_BOX_UPPER_ALL, DOM_BOX_UPPER_ANY, DOM_ANNULUS = 0, 1, 2, 3, 4, 5
+ACT_RELU2, ACT_TANH2, ACT_TANH = 0, 1, 2
 
 
 class NativeLibraryError(RuntimeError):
@@ -102,13 +103,15 @@ class GenSizes(C.Structure):
 
 
 class GenlConfig(C.Structure):
-    _fields_ = [("base", GenConfig), ("has_time", C.c_int32), ("n_hidden", C.c_int32), ("widths", C.c_int32 * 4)]
+    _fields_ = [("base", GenConfig), ("has_time", C.c_int32), ("n_hidden", C.c_int32), ("widths", C.c_int32 * 4),
+                ("activation", C.c_int32), ("linear_layout", C.c_int32)]
 
 
 class GenlSizes(C.Structure):
     _fields_ = [("table_bytes", C.c_int64), ("path_bytes", C.c_int64), ("ahat_bytes", C.c_int64), ("n_params", C.c_int64),
-                ("act_floats_per_block", C.c_int32), ("zbar_floats_per_block", C.c_int32), ("n_blocks", C.c_int32),
-                ("fwd_workgroups", C.c_int32), ("seg_block_offset", C.c_int32 * 5), ("reserved", C.c_int32)]
+                ("grad_partial_bytes", C.c_int64), ("n_blocks", C.c_int32), ("fwd_workgroups", C.c_int32),
+                ("bwd_workgroups", C.c_int32), ("waves_per_tile", C.c_int32), ("seg_block_offset", C.c_int32 * 5),
+                ("reserved", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -120,8 +123,7 @@ SIGNATURES = {
     "psp_genl_query": (C.c_int, [C.POINTER(GenlConfig), C.POINTER(GenlSizes)]),
     "psp_genl_rollout_fwd": (C.c_int, [C.POINTER(GenlConfig), _P, _P, _P, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P, _P,
                                        _P, _P]),
-    "psp_genl_adjoints": (C.c_int, [C.POINTER(GenlConfig), _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P,
-                                    _P]),
+    "psp_genl_rollout_bwd": (C.c_int, [C.POINTER(GenlConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "psp_hjb_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_family": (C.c_int, [C.c_int32, C.c_int32]),
     "psp_hjb_adjoint_sweep": (C.c_int, [C.POINTER(HjbConfig), _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -1,15 +1,21 @@
-"""Native plan of GeneralSolver / EllipticSolver for value nets of ANY depth: V = DenseNet(d [+ 1] -> 1, arch = [H_1 .. H_L]),
-1 <= L <= 4, H_i <= 128 -- the nets the reference's diffusion-loss notebooks train (Allen-Cahn.ipynb:72 arch = [110, 110, 50],
-the only configuration with a published timing; [30, 30, 30, 30], [15, 15, 15, 15], ...; reference function_space.py:116-140).
+"""Native plan of GeneralSolver / EllipticSolver for value nets of ANY depth: V = dense-concat net (d [+ 1] -> 1,
+arch = [H_1 .. H_L]), 1 <= L <= 4, H_i <= 128 -- the nets the reference's diffusion-loss notebooks train (Allen-Cahn.ipynb:72
+arch = [110, 110, 50], the only Allen-Cahn configuration with a published timing; [30, 30, 30, 30]; `Committor function.ipynb`:
+[d + 10, d, d, d] with tanh(.)**2; reference function_space.py:116-140 DenseNet, :143-158 DenseNet_tanh).
 
 Same iteration as plan_general_native.GeneralNativePlan (host RNG in the reference's order, K-vector loss weights, the
 K_boundary-sized terms by autograd, Adam through psp_adam_step); what differs are the two device steps:
-    psp_genl_rollout_fwd   the rollout (csrc/genl_kernels.h: activations in per-wave LDS images, weight tables in L2,
-                           rolled fp32-MFMA products; shapes are run-time arguments, nothing is padded on the host)
-    psp_genl_adjoints      per sample: activations a, tangents a', adjoints zbar_i, zbar_i' as row-major matrices,
-    + library GEMMs        dW_i = A[:, :in_i]^T Zbar_i + A'[:, :in_i]^T Zbar_i' (torch.matmul = hipBLASLt: plain GEMMs over the
-                           sample axis), walked over the path store in slabs of a fixed memory budget.
-The (d, H)-templated kernels of gen_kernels.h stay the fast path for arch = [H, H], H <= 64.
+    psp_genl_rollout_fwd   the rollout (csrc/genl_kernels.h: activations in per-tile LDS images, weight tables in L2,
+                           rolled fp32-MFMA products; shapes and activation are run-time arguments, nothing is padded on the
+                           host; a tile whose trajectories have all stopped leaves the time loop)
+    psp_genl_rollout_bwd   ONE hand-written kernel over the executed sample blocks: activations and tangents recomputed, adjoint
+                           sweep, every weight gradient as MFMA outer products over the samples of the block (no library GEMM)
+The (d, H)-templated kernels of gen_kernels.h stay the fast path for DenseNet arch = [H, H], H <= 64.
+
+Which nets: ``value_net_spec`` recognises the package's DenseNet (any ``activation``), DenseNet_tanh (nn.Linear weights) and --
+by structure plus a numerical probe of its forward -- any module that carries ``nn_dims`` and a list ``W`` of (in, out) weights
+and biases in the dense-concat layout with one of the three activations: the class a notebook defines for itself
+(`Committor function.ipynb` cell 1) runs on the kernels without the package knowing its name.
 """
 import ctypes as C
 
@@ -18,13 +24,15 @@ import torch
 try:
     from . import native as nat
     from . import sharding
-    from .function_space import DenseNet
-    from .plan_general_native import GeneralNativePlan
+    from .function_space import DenseNet, DenseNet_tanh
+    from .plan_general_native import GeneralNativePlan, set_domain
 except ImportError:
     import native as nat
     import sharding
-    from function_space import DenseNet
-    from plan_general_native import GeneralNativePlan
+    from function_space import DenseNet, DenseNet_tanh
+    from plan_general_native import GeneralNativePlan, set_domain
+
+_ACT = {'relu2': nat.ACT_RELU2, 'tanh2': nat.ACT_TANH2, 'tanh': nat.ACT_TANH}
 
 
 class _IdentityPad:
@@ -47,13 +55,64 @@ class _IdentityPad:
         return out
 
 
-def deep_eligibility(solver):
-    """None if the value net is a DenseNet the genl kernels take (and the two-hidden-layer kernels do not), else a reason."""
-    V = solver.V
+def _dense_concat_forward(x, params, act):
+    """The dense-concat forward on (in, out) weights: the formula the kernels implement."""
+    n = len(params) // 2
+    for i in range(n - 1):
+        z = torch.matmul(x, params[2 * i]) + params[2 * i + 1]
+        h = torch.relu(z) ** 2 if act == 'relu2' else (torch.tanh(z) ** 2 if act == 'tanh2' else torch.tanh(z))
+        x = torch.cat([x, h], 1)
+    return torch.matmul(x, params[2 * n - 2]) + params[2 * n - 1]
+
+
+def value_net_spec(V, d_in):
+    """dict(dims, act, linear, params) if V is a dense-concat net (d_in -> 1) the genl kernels implement, else a reason string."""
     dims = getattr(V, 'nn_dims', None)
+    if dims is None or len(dims) < 3 or dims[0] != d_in or dims[-1] != 1:
+        return 'V is not a dense-concat net (%d -> 1) (no matching nn_dims)' % d_in
+    dims = [int(v) for v in dims]
+    if isinstance(V, DenseNet):
+        return dict(dims=dims, act=getattr(V, 'activation', 'relu2'), linear=False, params=list(V.W))
+    if isinstance(V, DenseNet_tanh):
+        params = []
+        for layer in V.layers:
+            params += [layer.weight, layer.bias]
+        return dict(dims=dims, act='tanh', linear=True, params=params)
+    # a user-defined module of the same structure (the notebooks define their own variants): W = [W_1, b_1, .., W_out, b_out] with
+    # (in, out) weights over the growing concatenation, registered in that order and nothing else -- and a forward that IS one
+    # of the three formulas, checked on a probe batch (a private generator: the global RNG stream is the reference's)
+    W = getattr(V, 'W', None)
+    if not isinstance(W, (list, tuple)) or len(W) != 2 * (len(dims) - 1):
+        return 'V carries no dense-concat parameter list W'
+    fan = 0
+    for i in range(len(dims) - 1):
+        fan += dims[i]
+        if tuple(W[2 * i].shape) != (fan, dims[i + 1]) or tuple(W[2 * i + 1].shape) != (dims[i + 1],):
+            return 'V.W does not have the dense-concat shapes'
+    regs = list(V.parameters())
+    if len(regs) != len(W) or any(a is not b for a, b in zip(regs, W)):
+        return 'V has parameters besides V.W'
+    g = torch.Generator().manual_seed(1234)
+    probe = torch.randn(16, d_in, generator=g).to(W[0].device)
+    with torch.no_grad():
+        try:
+            want = V(probe)
+        except Exception as e:                                   # pragma: no cover
+            return 'V could not be evaluated on a probe batch (%s)' % e
+        for act in ('relu2', 'tanh2', 'tanh'):
+            got = _dense_concat_forward(probe, W, act)
+            if want.shape == got.shape and torch.allclose(want, got, rtol=1e-5, atol=1e-6):
+                return dict(dims=dims, act=act, linear=False, params=list(W))
+    return "V's forward is none of the dense-concat formulas the kernels implement (relu^2, tanh^2, tanh)"
+
+
+def deep_eligibility(solver):
+    """None if the value net is one the genl kernels take, else a reason."""
     d_in = solver.d + (0 if solver.elliptic else 1)
-    if not isinstance(V, DenseNet) or dims is None or dims[0] != d_in or dims[-1] != 1:
-        return 'V is not a DenseNet(%d -> 1)' % d_in
+    spec = value_net_spec(solver.V, d_in)
+    if isinstance(spec, str):
+        return spec
+    dims = spec['dims']
     L = len(dims) - 2
     if L < 1 or L > 4:
         return 'V has %d hidden layers (the native value-net kernels take 1 to 4)' % L
@@ -72,38 +131,32 @@ def deep_eligibility(solver):
 
 
 class GeneralDeepPlan(GeneralNativePlan):
-    ADJ_BUDGET_BYTES = 2 << 30        # activations + adjoints of one slab of samples (the GEMM operands)
-
     def __init__(self, solver):
         s = solver
         self.s = s
         self.lib = nat.load()
         self.dev = s.device
-        self.dist, self.rank, self.world = sharding.dist_info()
-        lo, hi = sharding.shard_bounds(s.K, self.rank, self.world)
-        self.lo, self.hi, self.K_local = lo, hi, hi - lo
+        self._shard(s.K_original)
+        self.K_cap = self.K_local
         self.net = s.V
         self.key = None
-        self.dims = list(s.V.nn_dims)
+        self.elliptic = bool(s.elliptic)
+        net = value_net_spec(s.V, s.d + (0 if self.elliptic else 1))
+        assert not isinstance(net, str), net
+        self.net_spec = net
+        self.dims = list(net['dims'])
         self.L = len(self.dims) - 2
         self.H = self.dims[1]
-        self._flatten(s.V)
+        self._flatten(net['params'])
         spec = s.problem.general_native_spec()
         self._keep = []
         gcfg = nat.GenlConfig()
         cfg = gcfg.base
         cfg.d = s.d
-        cfg.K_local, cfg.N, cfg.k_offset = self.K_local, s.N, lo
+        cfg.K_local, cfg.N, cfg.k_offset = self.K_local, s.N, self.lo
         cfg.dt, cfg.sqrt_dt = float(s.delta_t.item()), float(s.sq_delta_t.item())
-        self.elliptic = bool(s.elliptic)
         cfg.T = float('inf') if self.elliptic else float(torch.tensor(s.problem.T, dtype=torch.float32).item())
-        pb = s.problem
-        if pb.boundary == 'sphere':
-            cfg.domain_kind, cfg.dom_a = nat.DOM_SPHERE, float(pb.boundary_distance)
-        elif pb.boundary == 'square':
-            cfg.dom_a, cfg.dom_b = float(pb.X_l), float(pb.X_r)
-            cfg.domain_kind = nat.DOM_BOX if not pb.one_boundary else \
-                (nat.DOM_BOX_UPPER_ALL if self.elliptic else nat.DOM_BOX_UPPER_ANY)
+        set_domain(cfg, s.problem, self.elliptic)
         cfg.d_real = s.d
         for i, v in enumerate(spec.get('h_par', ())):
             cfg.h_par[i] = float(v)
@@ -119,6 +172,8 @@ class GeneralDeepPlan(GeneralNativePlan):
         gcfg.has_time, gcfg.n_hidden = (0 if self.elliptic else 1), self.L
         for i, h in enumerate(self.dims[1:-1]):
             gcfg.widths[i] = int(h)
+        gcfg.activation = _ACT[net['act']]
+        gcfg.linear_layout = 1 if net['linear'] else 0
         self.gcfg, self.cfg = gcfg, cfg
         sz = nat.GenlSizes()
         nat.check(self.lib.psp_genl_query(C.byref(gcfg), C.byref(sz)), 'psp_genl_query')
@@ -131,60 +186,35 @@ class GeneralDeepPlan(GeneralNativePlan):
         dev, f32 = self.dev, torch.float32
         self.tables = torch.empty(sz.table_bytes // 4, dtype=f32, device=dev)
         self.path = torch.empty(sz.path_bytes // 4, dtype=f32, device=dev)
-        self.ahat = torch.zeros(sz.ahat_bytes // 4, dtype=f32, device=dev)
-        self.VN = torch.empty(self.K_local, dtype=f32, device=dev)
-        self.YN = torch.empty(self.K_local, dtype=f32, device=dev)
-        self.tN = torch.zeros(self.K_local, dtype=f32, device=dev)
-        self.XN_k = torch.empty(self.K_local, s.d, dtype=f32, device=dev)
-        self.XN = self.XN_k
-        self.kcount = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.grad = torch.empty(self.P, dtype=f32, device=dev)
+        self.ahat = torch.zeros((sz.ahat_bytes + 3) // 4, dtype=f32, device=dev)
+        self.grad_partial = torch.empty(sz.grad_partial_bytes // 4, dtype=f32, device=dev)
         self.grad_k = self.grad
-        self.m = torch.zeros(self.P, dtype=f32, device=dev)
-        self.v = torch.zeros(self.P, dtype=f32, device=dev)
-        self.Kpad = 16 * ((self.K_local + 15) // 16)
-        self.wY = torch.zeros(self.Kpad, dtype=f32, device=dev)
-        self.wV = torch.zeros(self.Kpad, dtype=f32, device=dev)
-        self.step = 0
-        self.last_v_l2 = None
-        self.events = None
-        # ---- slab buffers of the adjoint pass and the index maps from padded features to real parameter rows / columns
-        # padded widths of the a / zbar rows, without their trailing block (ones | a, w)
-        self.TBf, self.HBf = sz.act_floats_per_block // 16 - 16, sz.zbar_floats_per_block // 16 - 16
-        per_block = 4 * (2 * sz.act_floats_per_block + 2 * sz.zbar_floats_per_block + 32)
-        self.slab_blocks = max(1, min(int(sz.n_blocks), self.ADJ_BUDGET_BYTES // per_block))
-        nb = self.slab_blocks
-        self.bA = torch.empty(nb * sz.act_floats_per_block, dtype=f32, device=dev)
-        self.bAd = torch.empty(nb * sz.act_floats_per_block, dtype=f32, device=dev)
-        self.bZ = torch.empty(nb * sz.zbar_floats_per_block, dtype=f32, device=dev)
-        self.bZd = torch.empty(nb * sz.zbar_floats_per_block, dtype=f32, device=dev)
-        self.bav = torch.empty(nb * 16, dtype=f32, device=dev)
-        self.bwy = torch.empty(nb * 16, dtype=f32, device=dev)
-        seg = [int(sz.seg_block_offset[i]) for i in range(self.L + 1)]
-        D0 = self.dims[0]
-        widths = [D0] + self.dims[1:-1]
-        # real feature r of the concatenation a_L  <->  padded feature 16 * seg[s] + c
-        pad_of_real = []
-        for sgm, w in enumerate(widths):
-            pad_of_real += [16 * seg[sgm] + c for c in range(w)]
-        self.pad_of_real = torch.tensor(pad_of_real, dtype=torch.long, device=dev)             # (D0 + sum H)
-        self.zcol0, self.in_pad = [], []                   # per layer: first zbar column of its units; padded width of its input
-        zoff = 0
-        for i in range(self.L):
-            self.zcol0.append(16 * zoff)
-            self.in_pad.append(16 * seg[i + 1])
-            zoff += (self.dims[1 + i] + 15) // 16
-        # flat-gradient offsets in registration order W_1, b_1, .., W_out, b_out
-        self.goff, o, n_in = [], 0, D0
-        for i in range(self.L):
-            Hi = self.dims[1 + i]
-            self.goff.append((o, o + n_in * Hi, n_in, Hi))
-            o += n_in * Hi + Hi
-            n_in += Hi
-        self.goff_out = (o, o + n_in, n_in)
+        self._common_buffers(s.d)
+
+    def _check_sizes(self):
+        sz = nat.GenlSizes()
+        nat.check(self.lib.psp_genl_query(C.byref(self.gcfg), C.byref(sz)), 'psp_genl_query')
+        assert sz.path_bytes <= self.path.numel() * 4 and sz.ahat_bytes <= self.ahat.numel() * 4
+        if sz.grad_partial_bytes > self.grad_partial.numel() * 4:
+            self.grad_partial = torch.empty(sz.grad_partial_bytes // 4, dtype=torch.float32, device=self.dev)
+        self.sizes = sz
 
     def _x_image_floats(self):
         return 4 * ((self.dims[0] + 15) // 16) * 64
+
+    def _tile_steps(self):
+        """Loop steps every tile of this rank executed (int32 view of the tail of `ahat`, include/psp.h)."""
+        nt = (self.K_local + 15) // 16
+        return self.ahat[(self.s.N + 1) * nt * 16:(self.s.N + 1) * nt * 16 + nt].view(torch.int32)
+
+    def _loop_steps(self, t0):
+        """The kernels count the executed steps of every tile themselves: the loop of the reference runs as long as the
+        longest-running tile."""
+        m = self._tile_steps().max().reshape(1)
+        dist, _, world = sharding.dist_info()
+        if world > 1:
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        return int(m.item())
 
     def _launch_fwd(self, flat_k, x0, t0, xi, l, st):
         nat.check(self.lib.psp_genl_rollout_fwd(C.byref(self.gcfg), nat.ptr(self.flat), nat.ptr(x0), nat.ptr(t0), nat.ptr(xi),
@@ -192,49 +222,7 @@ class GeneralDeepPlan(GeneralNativePlan):
                                                 nat.ptr(self.ahat), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN_k),
                                                 nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_genl_rollout_fwd')
 
-    MAX_BATCHES = 32             # split-K factor of the weight-gradient products
-    MIN_ROWS = 2048              # ... and the fewest samples a batch is worth
-
-    @classmethod
-    def _atb(cls, A, B):
-        """A^T B for tall operands (samples x features): the sample axis is cut into up to MAX_BATCHES equal batches so that
-        the product is a batched GEMM with many workgroups (one plain GEMM has in x H / tile^2 ~ 60 output tiles for a
-        contraction over up to millions of samples and runs on 60 CUs), then summed over the batches."""
-        n = A.shape[0]
-        nb = max(1, min(cls.MAX_BATCHES, n // cls.MIN_ROWS))
-        if nb == 1:
-            return A.t() @ B
-        R = n // nb
-        out = torch.bmm(A[:nb * R].view(nb, R, A.shape[1]).transpose(1, 2), B[:nb * R].view(nb, R, B.shape[1])).sum(0)
-        if nb * R < n:
-            out = out + A[nb * R:].t() @ B[nb * R:]
-        return out
-
     def _launch_bwd(self, flat_k, st):
-        sz, g = self.sizes, self.grad
-        g.zero_()
-        n_blocks = int(sz.n_blocks)
-        TBf, HBf = self.TBf, self.HBf
-        WA, WZ = TBf + 16, HBf + 16
-        for b0 in range(0, n_blocks, self.slab_blocks):
-            b1 = min(n_blocks, b0 + self.slab_blocks)
-            ns = 16 * (b1 - b0)
-            nat.check(self.lib.psp_genl_adjoints(C.byref(self.gcfg), nat.ptr(self.flat), nat.ptr(self.tables), nat.ptr(self.path),
-                                                 nat.ptr(self.ahat), nat.ptr(self.wY), nat.ptr(self.wV), b0, b1, nat.ptr(self.bA),
-                                                 nat.ptr(self.bAd), nat.ptr(self.bZ), nat.ptr(self.bZd), nat.ptr(self.bav),
-                                                 nat.ptr(self.bwy), st), 'psp_genl_adjoints')
-            # row-major (sample, padded feature) matrices straight from the kernel, each row with one trailing block: ones
-            # behind a, (a | w) behind zbar.  ONE pair of batched GEMMs forms M = A^T Zbar + A'^T Zbar' on the padded layout:
-            # weight blocks, bias gradients (row TBf: the ones column) and the output layer (column HBf) at once.  Padding rows /
-            # columns are exactly zero; the blocks of M no layer needs are the price of two launches instead of 2 L + 2.
-            A, Ad = self.bA[:ns * WA].view(ns, WA), self.bAd[:ns * WA].view(ns, WA)
-            Zb, Zd = self.bZ[:ns * WZ].view(ns, WZ), self.bZd[:ns * WZ].view(ns, WZ)
-            M = self._atb(A, Zb) + self._atb(Ad, Zd)                       # (TBf + 16, HBf + 16)
-            for i in range(self.L):
-                oW, ob, n_in, Hi = self.goff[i]
-                c0 = self.zcol0[i]
-                g[oW:ob].add_(M[self.pad_of_real[:n_in], c0:c0 + Hi].reshape(-1))
-                g[ob:ob + Hi].add_(M[TBf, c0:c0 + Hi])
-            oW, ob, n_in = self.goff_out
-            g[oW:ob].add_(M[self.pad_of_real, HBf])
-            g[ob:ob + 1].add_(M[TBf, HBf:HBf + 1])
+        nat.check(self.lib.psp_genl_rollout_bwd(C.byref(self.gcfg), nat.ptr(self.flat), nat.ptr(self.tables), nat.ptr(self.path),
+                                                nat.ptr(self.ahat), nat.ptr(self.wY), nat.ptr(self.wV), nat.ptr(self.grad_partial),
+                                                nat.ptr(self.grad), st), 'psp_genl_rollout_bwd')

@@ -1,5 +1,5 @@
 """Native (HIP) execution plan for GeneralSolver.train and EllipticSolver.train (diffusion / BSDE loss on unbounded,
-sphere and box domains).
+sphere, annulus ('two_spheres'), box and cut-corner ('square-corner') domains).
 
 Per iteration (reference solver.py:1009-1201):
     host RNG in the reference's order (domain sample, t ~ U(0,T), per-step xi)      [noise='reference']
@@ -7,16 +7,19 @@ Per iteration (reference solver.py:1009-1201):
     per-trajectory loss weights (K-vectors) and the small terminal-condition term in torch
     psp_gen_rollout_bwd   -> flat gradient of the domain part of the loss
     [all-reduce gradient] -> psp_adam_step
-The terminal term a1 mean((V(X[:Kb],T) - f(X[:Kb]))^2) and the Dirichlet / Neumann residual on the boundary batch
-involve K_boundary (~50) points and are differentiated by torch autograd on the same parameters (views of the flat
-buffer); they are O(K_boundary) work against O(K N) in the kernels.
+The terminal term a1 mean((V(X[:Kb],T) - f(X[:Kb]))^2), the Dirichlet / Neumann residual on the boundary batch and the
+`sample_center` probe involve K_boundary (~50) points and are differentiated by torch autograd on the same parameters (views
+of the flat buffer); they are O(K_boundary) work against O(K N) in the kernels.  So is the Neumann residual of the BSDE loss
+(solver.py:1177-1183): grad_x V at the K sample points of the LAST executed step, read back from the path store.
 
-Bounded domains (reference solver.py:1119-1129, :758-767): the exit test runs inside the forward kernel
+Bounded domains (reference solver.py:1119-1129, :750-767): the exit test runs inside the forward kernel
 (psp_gen_config.domain_kind).  EllipticSolver (V = DenseNet(d -> 1), no time input) runs through the same kernels
 with T = +inf and a parameter index map that leaves the kernels' time row zero (native_shapes.GenParamPad).
+'two_spheres' (the committor problem) draws its batch by rejection, so the batch size K changes from iteration to iteration
+(solver.py:1048-1052, :706-710): every buffer is sized for K_original and each launch takes that iteration's K.
 With noise='reference' the host must consume exactly as many randn(K,d) draws as the reference loop executes before
-its all-stopped break; on a bounded domain that count depends on the paths, so it is read back from t_N after the
-forward kernel and the CPU generator is rewound and advanced by that many draws.
+its all-stopped break; on a bounded domain that count depends on the paths, so it is read back after the forward kernel
+and the CPU generator is rewound and advanced by that many draws.
 """
 import ctypes as C
 
@@ -51,8 +54,8 @@ def native_eligibility(solver, deep=False):
     dims = getattr(V, 'nn_dims', None)
     d_in = solver.d + (0 if solver.elliptic else 1)
     if not deep and (not isinstance(V, DenseNet) or dims is None or len(dims) != 4 or dims[1] != dims[2] or dims[3] != 1
-                     or dims[0] != d_in):
-        return 'V is not a DenseNet(%d -> 1) with two equal hidden widths' % d_in
+                     or dims[0] != d_in or getattr(V, 'activation', 'relu2') != 'relu2'):
+        return 'V is not a DenseNet(%d -> 1) with two equal hidden widths and relu^2' % d_in
     spec_fn = getattr(solver.problem, 'general_native_spec', None)
     if spec_fn is None:
         return 'problem has no general_native_spec() (coefficients outside the native catalogue)'
@@ -70,34 +73,42 @@ def native_eligibility(solver, deep=False):
     return None
 
 
+def set_domain(cfg, pb, elliptic):
+    """psp_gen_config.domain_kind / dom_a / dom_b from the problem's ``boundary`` (include/psp.h PSP_DOM_*)."""
+    if pb.boundary == 'sphere':
+        cfg.domain_kind, cfg.dom_a = nat.DOM_SPHERE, float(pb.boundary_distance)
+    elif pb.boundary == 'two_spheres':                            # solver.py:1122-1123 / :752-753
+        cfg.domain_kind, cfg.dom_a, cfg.dom_b = nat.DOM_ANNULUS, float(pb.boundary_distance_1), float(pb.boundary_distance_2)
+    elif pb.boundary == 'square':
+        cfg.dom_a, cfg.dom_b = float(pb.X_l), float(pb.X_r)
+        cfg.domain_kind = nat.DOM_BOX if not pb.one_boundary else \
+            (nat.DOM_BOX_UPPER_ALL if elliptic else nat.DOM_BOX_UPPER_ANY)
+    elif pb.boundary == 'square-corner':                          # solver.py:759-760: any(X_proposal <= X_r)
+        cfg.domain_kind, cfg.dom_a, cfg.dom_b = nat.DOM_BOX_UPPER_ANY, float(pb.X_l), float(pb.X_r)
+
+
 class GeneralNativePlan:
     def __init__(self, solver):
         s = solver
         self.s = s
         self.lib = nat.load()
         self.dev = s.device
-        self.dist, self.rank, self.world = sharding.dist_info()
-        lo, hi = sharding.shard_bounds(s.K, self.rank, self.world)
-        self.lo, self.hi, self.K_local = lo, hi, hi - lo
+        self._shard(s.K_original)                # capacity: the largest batch an iteration can see
+        self.K_cap = self.K_local
         self.net = s.V                           # the plan is rebuilt when the caller swaps model.V (general_solver._choose_plan)
         self.key = None
         self.H = s.V.nn_dims[1]
-        self._flatten(s.V)
+        self._flatten(list(s.V.W))               # registration order W1,b1,W2,b2,W3,b3 (include/psp.h)
         spec = s.problem.general_native_spec()
         self._keep = []
         cfg = nat.GenConfig()
         cfg.K_local, cfg.N = self.K_local, s.N
-        cfg.k_offset = lo
+        cfg.k_offset = self.lo
         cfg.dt, cfg.sqrt_dt = float(s.delta_t.item()), float(s.sq_delta_t.item())
         self.elliptic = bool(s.elliptic)
         cfg.T = float('inf') if self.elliptic else float(torch.tensor(s.problem.T, dtype=torch.float32).item())
         pb = s.problem
-        if pb.boundary == 'sphere':
-            cfg.domain_kind, cfg.dom_a = nat.DOM_SPHERE, float(pb.boundary_distance)
-        elif pb.boundary == 'square':
-            cfg.dom_a, cfg.dom_b = float(pb.X_l), float(pb.X_r)
-            cfg.domain_kind = nat.DOM_BOX if not pb.one_boundary else \
-                (nat.DOM_BOX_UPPER_ALL if self.elliptic else nat.DOM_BOX_UPPER_ANY)
+        set_domain(cfg, pb, self.elliptic)
         cfg.d_real = s.d
         # 'f16x3': fp32-grade split products on the f16 matrix pipe in the forward rollout (csrc/hjb_kernels.h gemm_Tx; same parity
         # bounds as 'fp32'); 'auto' (the default): 'f16x3' where the instance has it and its tables fit the LDS (decided below)
@@ -147,25 +158,68 @@ class GeneralNativePlan:
         self.path = torch.empty(sz.path_bytes // 4, dtype=f32, device=dev)
         self.ahat = torch.zeros(sz.ahat_bytes // 4, dtype=f32, device=dev)
         self.grad_partial = torch.empty(sz.grad_partial_bytes // 4, dtype=f32, device=dev)
-        self.VN = torch.empty(self.K_local, dtype=f32, device=dev)
-        self.YN = torch.empty(self.K_local, dtype=f32, device=dev)
-        self.tN = torch.empty(self.K_local, dtype=f32, device=dev)
-        self.XN_k = torch.empty(self.K_local, self.d_pad, dtype=f32, device=dev)
-        self.XN = self.XN_k[:, :s.d]
-        self.kcount = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.grad = torch.empty(self.P, dtype=f32, device=dev)
         self.grad_k = self.grad if self.pad.identity else torch.empty(self.pad.Pp, dtype=f32, device=dev)
+        self._common_buffers(self.d_pad)
+
+    # ---- pieces shared with plan_general_deep.GeneralDeepPlan ---------------------------------------------------------
+    def _shard(self, K):
+        """This rank's contiguous block of a batch of K trajectories."""
+        self.dist, self.rank, self.world = sharding.dist_info()
+        lo, hi = sharding.shard_bounds_ragged(K, self.rank, self.world)
+        self.lo, self.hi, self.K_local = lo, hi, hi - lo
+
+    def _common_buffers(self, d_store):
+        dev, f32, cap = self.dev, torch.float32, self.K_cap
+        self._VN = torch.empty(cap, dtype=f32, device=dev)
+        self._YN = torch.empty(cap, dtype=f32, device=dev)
+        self._tN = torch.zeros(cap, dtype=f32, device=dev)
+        self._XN = torch.empty(cap * d_store, dtype=f32, device=dev)
+        self.d_store = d_store
+        self.kcount = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.grad = getattr(self, 'grad', None)
+        if self.grad is None:
+            self.grad = torch.empty(self.P, dtype=f32, device=dev)
         self.m = torch.zeros(self.P, dtype=f32, device=dev)
         self.v = torch.zeros(self.P, dtype=f32, device=dev)
-        self.Kpad = 16 * ((self.K_local + 15) // 16)
-        self.wY = torch.zeros(self.Kpad, dtype=f32, device=dev)     # zero-padded (include/psp.h)
-        self.wV = torch.zeros(self.Kpad, dtype=f32, device=dev)
+        cap_pad = 16 * ((cap + 15) // 16)
+        self.wY = torch.zeros(cap_pad, dtype=f32, device=dev)     # zero-padded (include/psp.h)
+        self.wV = torch.zeros(cap_pad, dtype=f32, device=dev)
         self.step = 0
         self.last_v_l2 = None
+        self._extra_grad = None
         self.events = None   # bench.py: HIP-event pairs around the two rollout kernels
+        self._batch_views()
 
-    def _flatten(self, V):
-        params = list(V.W)                      # registration order W1,b1,W2,b2,W3,b3 (include/psp.h)
+    def _batch_views(self):
+        """Output views for this iteration's batch (K_local <= K_cap)."""
+        Kl = self.K_local
+        self.VN, self.YN, self.tN = self._VN[:Kl], self._YN[:Kl], self._tN[:Kl]
+        self.XN_k = self._XN[:Kl * self.d_store].view(Kl, self.d_store)
+        self.XN = self.XN_k[:, :self.s.d]
+        self.Kpad = 16 * ((Kl + 15) // 16)
+
+    def _set_batch(self, K):
+        """A new batch size (the 'two_spheres' rejection step): shard it, point the kernels' config at it."""
+        if K == getattr(self, '_K_now', None):
+            return
+        self._K_now = K
+        self._shard(K)
+        if self.K_local > self.K_cap or self.K_local <= 0:
+            raise RuntimeError('batch of %d trajectories outside the plan capacity %d' % (self.K_local, self.K_cap))
+        self.cfg.K_local, self.cfg.k_offset = self.K_local, self.lo
+        self._batch_views()
+        self.wY.zero_()
+        self.wV.zero_()
+        self._check_sizes()
+
+    def _check_sizes(self):
+        sz = nat.gen_query(self.cfg)
+        assert sz.path_bytes <= self.path.numel() * 4 and sz.ahat_bytes <= self.ahat.numel() * 4
+        if sz.grad_partial_bytes > self.grad_partial.numel() * 4:
+            self.grad_partial = torch.empty(sz.grad_partial_bytes // 4, dtype=torch.float32, device=self.dev)
+        self.sizes = sz
+
+    def _flatten(self, params):
         self.params = params
         self.P = sum(p.numel() for p in params)
         flat = torch.empty(self.P, dtype=torch.float32, device=self.dev)
@@ -176,23 +230,40 @@ class GeneralNativePlan:
             p.data = flat[off:off + n].view(p.shape)
             off += n
         self.flat = flat
+        self.grad = torch.empty(self.P, dtype=torch.float32, device=self.dev)
 
     def _sample_domain_device(self, l):
-        """Domain sample of solver.py:1040-1056 drawn with a device generator (noise='philox')."""
+        """Domain sample of solver.py:1040-1056 / :695-708 drawn with a device generator (noise='philox')."""
         s, dev, pb = self.s, self.dev, self.s.problem
         if not hasattr(self, '_gen'):
             self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(int(s.seed) * 1000003 + l)
-        K, d = s.K, s.d
+        K, d, g = s.K, s.d, self._gen
         if pb.boundary in ('unbounded', 'sphere'):
             if s.uniform_square:                                 # solver.py:1042-1043
-                X = torch.rand(K, d, generator=self._gen, device=dev) * 2 - 1
-                radial = torch.rand(K, generator=self._gen, device=dev).unsqueeze(1)
+                X = torch.rand(K, d, generator=g, device=dev) * 2 - 1
+                radial = torch.rand(K, generator=g, device=dev).unsqueeze(1)
             else:
-                X = torch.randn(K, d, generator=self._gen, device=dev)
-                radial = torch.rand(K, generator=self._gen, device=dev).unsqueeze(1) ** (1 / d)
+                X = torch.randn(K, d, generator=g, device=dev)
+                radial = torch.rand(K, generator=g, device=dev).unsqueeze(1) ** (1 / d)
             return pb.boundary_distance * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * radial
-        return (pb.X_r - pb.X_l) * torch.rand(K, d, generator=self._gen, device=dev) + pb.X_l
+        if pb.boundary == 'two_spheres':
+            if self.elliptic and s.uniform_square:               # solver.py:702-704
+                X = torch.rand(K, d, generator=g, device=dev) * 2 - 1
+                return X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * (
+                    torch.rand(K, d, generator=g, device=dev) * (pb.boundary_distance_2 - pb.boundary_distance_1) + pb.boundary_distance_1)
+            Ko = s.K_original                                     # rejection from the outer ball (solver.py:1048-1052 == :706-710)
+            X = torch.randn(Ko, d, generator=g, device=dev)
+            X = pb.boundary_distance_2 * X / torch.sqrt(torch.sum(X ** 2, 1)).unsqueeze(1) * (
+                torch.rand(Ko, generator=g, device=dev).unsqueeze(1) ** (1 / d))
+            keep = torch.sqrt(torch.sum(X ** 2, 1)) > pb.boundary_distance_1
+            s.K = int(torch.sum(keep))                            # (one host read: the launch geometry follows the batch size)
+            return X[keep, :]
+        X = (pb.X_r - pb.X_l) * torch.rand(K, d, generator=g, device=dev) + pb.X_l
+        if pb.boundary == 'square-corner':                        # solver.py:708
+            corner = torch.all(X > pb.X_corner, 1)
+            X[corner, :] = -X[corner, :]
+        return X
 
     def _executed_steps(self, t0_cpu):
         """Steps the reference executes before its early break (solver.py:1093-1097): it stops drawing
@@ -210,41 +281,70 @@ class GeneralNativePlan:
             stopped = stopped | ~in_time
         return s.N
 
-    def _draws_executed(self, t0):
-        """randn(K,d) draws the reference loop makes on a bounded domain: it leaves at the first step that finds every
-        trajectory stopped (solver.py:1093-1097; EllipticSolver draws xi before that test, :739-744).  A trajectory is
-        active for round((t_N - t_0)/dt) steps and stopped by the step after."""
-        s = self.s
-        m = torch.round((self.tN - t0) / self.cfg.dt).max().reshape(1)
+    def _active_steps(self, t0):
+        """Active steps per trajectory: round((t_N - t_0)/dt) (EllipticSolver: the kernels write t_N = m dt with one rounding)."""
+        return torch.round((self.tN - t0) / self.cfg.dt)
+
+    def _loop_steps(self, t0):
+        """Steps of the time loop the reference executes before every trajectory has stopped (solver.py:1093-1097): a trajectory
+        with m active steps is found stopped by the step after, so the loop runs max m + 1 steps, at most N."""
+        m = self._active_steps(t0).max().reshape(1)
         dist, _, world = sharding.dist_info()
         if world > 1:
             dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        m = int(m.item())
-        return min(s.N, m + (2 if self.elliptic else 1))
+        return min(self.s.N, int(m.item()) + 1)
+
+    def _draws_executed(self, t0):
+        """randn(K,d) draws the reference loop makes on a bounded domain: it leaves at the first step that finds every
+        trajectory stopped (solver.py:1093-1097); EllipticSolver draws xi before that test (:739-744)."""
+        return min(self.s.N, self._loop_steps(t0) + (1 if self.elliptic else 0))
 
     def _boundary_terms(self, X, X_b, t_b):
-        """The K_boundary-sized loss terms, differentiated by autograd into p.grad (solver.py:1062-1074, :683-693).
-        (Round 3 measured them behind the rollout launch and on a side stream beside it -- same-box A/B, d=100 K=65536 and the
-        K=200 notebook shape: both slower than here in front of the rollout, 8.65 vs 8.75 / 8.9 ms and 1.2 vs 1.33 / 1.5 ms.)"""
+        """The K_boundary-sized loss terms, differentiated by autograd into p.grad (solver.py:1015-1017, :1062-1074, :643-645,
+        :683-693).  (Round 3 measured them behind the rollout launch and on a side stream beside it -- same-box A/B, d=100 K=65536
+        and the K=200 notebook shape: both slower than here in front of the rollout, 8.65 vs 8.75 / 8.9 ms and 1.2 vs 1.33 / 1.5 ms.)"""
         s, dev = self.s, self.dev
-        if s.loss_method == 'BSDE' or not s.boundary_loss:
-            return None
-        if self.elliptic:
-            loss_b = s.alpha[1] * s.boundary_residual(X_b)
-        else:
-            Kb, T = s.K_boundary, s.problem.T
-            X_T = torch.cat([X[:Kb, :], T * torch.ones(Kb, device=dev).unsqueeze(1)], 1)
-            loss_b = s.alpha[1] * torch.mean((s.V(X_T).squeeze() - s.problem.f(X[:Kb, :])) ** 2)
-            if s.bounded:
-                loss_b = loss_b + s.alpha[2] * s.boundary_residual(torch.cat([X_b, t_b], 1), X_b, t_b)
-        loss_b.backward()                                       # K_boundary points only
+        loss_b = None
+        if s.sample_center:                                      # a one-dimensional probe point, as written there
+            X_center = torch.zeros(1, 1, device=dev)
+            loss_b = torch.mean((s.V(X_center).squeeze() - s.problem.v_true(X_center).squeeze()) ** 2)
+        if s.loss_method != 'BSDE' and s.boundary_loss:
+            if self.elliptic:
+                term = s.alpha[1] * s.boundary_residual(X_b)
+            else:
+                Kb, T = s.K_boundary, s.problem.T
+                X_T = torch.cat([X[:Kb, :], T * torch.ones(Kb, device=dev).unsqueeze(1)], 1)
+                term = s.alpha[1] * torch.mean((s.V(X_T).squeeze() - s.problem.f(X[:Kb, :])) ** 2)
+                if s.bounded:
+                    term = term + s.alpha[2] * s.boundary_residual(torch.cat([X_b, t_b], 1), X_b, t_b)
+            loss_b = term if loss_b is None else loss_b + term
+        if loss_b is not None:
+            loss_b.backward()                                    # K_boundary points only
         return loss_b
+
+    def _mean_sq_masked(self, r, mask, K_global):
+        """(sum over the masked entries of r^2 / count, dLoss/dr) with the count taken over ALL ranks; zero when the mask is empty."""
+        cnt = mask.sum().double().reshape(1)
+        sq = torch.sum(torch.where(mask, r, torch.zeros_like(r)).double() ** 2).reshape(1)
+        sharding.allreduce_sum_(cnt)
+        sharding.allreduce_sum_(sq)
+        c = torch.clamp(cnt, min=1.0)
+        w = torch.where(mask, (2.0 / c.float()) * r, torch.zeros_like(r))
+        return (sq[0] / c[0]).float(), w, cnt
+
+    def _last_step_points(self, n_last):
+        """The network inputs [x, t] of loop step n_last for every trajectory of this rank, from the path store."""
+        s = self.s
+        nt = (self.K_local + 15) // 16
+        PB = self._path_block_floats()
+        nx = self._x_image_floats()
+        img = self.path[:(s.N + 1) * nt * PB].view(s.N + 1, nt, PB)[n_last, :, :nx].reshape(nt, nx // 64, 4, 16)
+        return img.permute(0, 3, 1, 2).reshape(nt * 16, nx // 16)[:self.K_local]
 
     def iteration(self, l):
         s, lib, cfg, dev = self.s, self.lib, self.cfg, self.dev
         st = nat.stream_ptr(dev)
-        K, d, pb = s.K, s.d, s.problem
-        lo, hi = self.lo, self.hi
+        d, pb = s.d, s.problem
         diffusion = s.loss_method == 'diffusion'
         bounded, ell = s.bounded, self.elliptic
         reference_noise = s.noise == 'reference'
@@ -255,6 +355,9 @@ class GeneralNativePlan:
         if ell:
             loss_T = self._boundary_terms(None, X_b, None)      # no RNG inside: order as in the reference
         X = s.sample_domain() if reference_noise else self._sample_domain_device(l)
+        K = s.K                                                  # 'two_spheres': the rejection step has just set it
+        self._set_batch(K)
+        lo, hi = self.lo, self.hi
         t_b = None
         if bounded and not ell:
             t_b = torch.rand(s.K_boundary, 1).to(dev) * pb.T
@@ -294,6 +397,7 @@ class GeneralNativePlan:
             for _ in range(draws):
                 torch.randn(K, d)
         # ---- per-trajectory loss weights (K-vectors)
+        wV = None
         if diffusion:
             r = self.VN - self.YN
             sq = torch.sum(r.double() ** 2).reshape(1)
@@ -301,23 +405,33 @@ class GeneralNativePlan:
             loss = s.alpha[0] * (sq[0] / K).float()
             wV = (2.0 * s.alpha[0] / K) * r
             wY = -wV
-            if loss_T is not None:
-                loss = loss + loss_T.detach()
         else:
-            if ell:
-                target = pb.g(self.XN)                            # solver.py:808
-            elif bounded:
-                target = pb.g(self.XN, self.tN)                   # :1176
+            btype = None if ell else getattr(pb, 'boundary_type', None)
+            if bounded and not ell and btype == 'Neumann':
+                loss, wY = self._bsde_neumann(t0, K)             # solver.py:1177-1183
             else:
-                target = pb.f(self.XN)                            # :1174
-            r = self.YN - target
-            sq = torch.sum(r.double() ** 2).reshape(1)
-            sharding.allreduce_sum_(sq)
-            loss = (sq[0] / K).float()
-            wY = (2.0 / K) * r
-            wV = torch.zeros_like(r)
+                if ell:
+                    target = pb.g(self.XN)                        # solver.py:808
+                elif bounded:
+                    target = pb.g(self.XN, self.tN)               # :1176
+                else:
+                    target = pb.f(self.XN)                        # :1174
+                r = self.YN - target
+                sq = torch.sum(r.double() ** 2).reshape(1)
+                sharding.allreduce_sum_(sq)
+                loss = (sq[0] / K).float()
+                wY = (2.0 / K) * r
+        if s.loss_with_stopped:                                  # solver.py:1185-1186 / :803-804: Y against the data at the exit points
+            stopped = self._active_steps(t0) < float(s.N)
+            target = pb.g(self.XN) if ell else pb.f(self.XN)
+            l_st, w_st, _ = self._mean_sq_masked(self.YN - target, stopped, K)
+            loss = loss + l_st
+            wY = wY + w_st
+        if loss_T is not None:
+            loss = loss + loss_T.detach()
         self.wY[:self.K_local].copy_(wY)
-        self.wV[:self.K_local].copy_(wV)
+        if wV is not None:
+            self.wV[:self.K_local].copy_(wV)
         if ev is not None:
             ev[2].record()
         self._launch_bwd(flat_k, st)
@@ -326,9 +440,12 @@ class GeneralNativePlan:
             ev[3].record()
             self.events.append(ev)
         sharding.allreduce_sum_(self.grad)
-        if loss_T is not None:                                   # identical on every rank: add after the reduce
+        if any(p.grad is not None for p in self.params):         # identical on every rank: add after the reduce
             self.grad += torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                                     for p in self.params])       # (a pure Neumann residual never touches b3)
+        if self._extra_grad is not None:                         # the BSDE Neumann residual (already summed over the ranks)
+            self.grad += self._extra_grad
+            self._extra_grad = None
         self.last_v_l2 = self._v_l2_from_path() if self.log_v_l2 else None     # before the update, as the reference logs it
         self.step += 1
         lr, b1, b2, eps = self._adam_hyper()
@@ -336,7 +453,35 @@ class GeneralNativePlan:
                                     self.P, self.step, lr, b1, b2, eps, st), 'psp_adam_step')
         kc = self.kcount.clone()
         sharding.allreduce_sum_(kc)
+        if s.K_test_log is not None:                             # solver.py:1193-1197 / :821-825: after the update, CPU generator
+            s._log_test_error('elliptic' if ell else 'parabolic')
         return loss, kc
+
+    def _bsde_neumann(self, t0, K):
+        """BSDE loss with a Neumann boundary (solver.py:1177-1183): trajectories that ran out of time are matched with f; the
+        Neumann residual takes grad_x V of the LAST executed loop step (the state before its move) against the final X, over ALL
+        trajectories, as written there.  Returns (loss, dLoss/dY_N); the residual's parameter gradient goes into p.grad."""
+        s, pb = self.s, self.s.problem
+        T, dt = pb.T, s.delta_t
+        late = self.tN > (T - dt)                                # :1178 (fp32 tensor arithmetic, as there)
+        loss_l, wY, n_late = self._mean_sq_masked(self.YN - pb.f(self.XN), late, K)
+        loss = loss_l
+        if int(n_late.item()) < K:
+            n_last = self._loop_steps(t0) - 1
+            img = self._last_step_points(n_last)               # [x (d_pad), t]: a zero-padded instance keeps the time behind the padding
+            pts = torch.cat([img[:, :s.d], img[:, self.d_pad:self.d_pad + 1]], 1).clone().requires_grad_(True)
+            grad_V, = torch.autograd.grad(s.V(pts).squeeze().sum(), pts, create_graph=True)
+            XN = self.XN.detach()
+            res = torch.sum(grad_V[:, :s.d] * XN, 1) - torch.sum(pb.g(XN, self.tN) * XN, 1)
+            term = torch.sum(res ** 2) / K                       # mean over all K trajectories (every rank adds its share)
+            gs_ = torch.autograd.grad(term, self.params, allow_unused=True)
+            extra = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs_, self.params)])
+            tot = term.detach().double().reshape(1)
+            sharding.allreduce_sum_(tot)
+            sharding.allreduce_sum_(extra)
+            self._extra_grad = extra
+            loss = loss + tot[0].float()
+        return loss, wY
 
     # ---- the two kernel launches of an iteration (plan_general_deep.py overrides them for value nets of other depths)
     def _launch_fwd(self, flat_k, x0, t0, xi, l, st):
@@ -353,6 +498,11 @@ class GeneralNativePlan:
     def _x_image_floats(self):
         """Floats of the X_n register image at the head of a path block (the network input incl. the time row)."""
         return 4 * ((self.d_pad + 1 + 15) // 16) * 64
+
+    def _path_block_floats(self):
+        """Floats of one (step, tile) block of the path store for the CURRENT batch."""
+        nt = (self.K_local + 15) // 16
+        return self.sizes.path_bytes // 4 // ((self.s.N + 1) * nt)
 
     def range_fallbacks(self):
         """Iterations the range guard sent to the fp32-MFMA kernels so far; one device read."""
@@ -379,32 +529,36 @@ class GeneralNativePlan:
         """EllipticSolver's V_L2 log (solver.py:718, 738, 813): mean_k sum_{n alive} (V(X_n) - v_true(X_n))^2 dt, from the X_n
         register images the forward kernel left in the path store (slot n = the state BEFORE the move of step n; image
         float ks * 64 + 16 q + j holds feature 4 ks + q of sample j).  A trajectory with m active steps is alive at steps
-        0..m (the step that finds it outside still counts it, :736-738), capped by the N steps of the loop.  Diagnostics:
-        K N small-net evaluations in torch, off the timed path (v_l2_error_flag=False skips it)."""
+        0..m (the step that finds it outside still counts it, :736-738), capped by the N steps of the loop; slots a tile did
+        not execute (it left the loop early) are masked, never read as numbers.  Diagnostics: K N small-net evaluations in
+        torch, off the timed path (v_l2_error_flag=False skips it)."""
         s, cfg = self.s, self.cfg
         N, nt = s.N, (self.K_local + 15) // 16
-        PB = self.sizes.path_bytes // 4 // ((N + 1) * nt)
+        PB = self._path_block_floats()
         nx = self._x_image_floats()
-        img = self.path.view(N + 1, nt, PB)[:N, :, :nx].reshape(N, nt, nx // 64, 4, 16)
-        X = img.permute(0, 1, 4, 2, 3).reshape(N, nt * 16, nx // 16)[:, :self.K_local, :s.d]
         m = torch.round(self.tN / cfg.dt)                                            # active steps per trajectory
-        alive = (torch.arange(N, device=self.dev).unsqueeze(1) <= m.unsqueeze(0)).float()
+        n_used = min(N, int(m.max().item()) + 1)
+        img = self.path[:(N + 1) * nt * PB].view(N + 1, nt, PB)[:n_used, :, :nx].reshape(n_used, nt, nx // 64, 4, 16)
+        X = img.permute(0, 1, 4, 2, 3).reshape(n_used, nt * 16, nx // 16)[:, :self.K_local, :s.d]
+        alive = torch.arange(n_used, device=self.dev).unsqueeze(1) <= m.unsqueeze(0)
         with torch.no_grad():
-            Xf = X.reshape(-1, s.d)
+            Xf = torch.where(alive.unsqueeze(2), X, torch.zeros_like(X)).reshape(-1, s.d)
+            Xf = torch.where(alive.reshape(-1, 1), Xf, self.XN[:1].expand_as(Xf))     # (v_true may be singular at the origin)
             err = (s.V(Xf).squeeze() - torch.as_tensor(s.problem.v_true(Xf)).float().to(self.dev).squeeze()) ** 2
-        tot = (err.reshape(N, self.K_local) * alive).sum().reshape(1) * s.delta_t_np
+        tot = torch.where(alive, err.reshape(n_used, self.K_local), torch.zeros((), device=self.dev)).sum().reshape(1) * s.delta_t_np
         sharding.allreduce_sum_(tot)
         return tot[0] / float(s.K)
 
     def train(self):
         import time
         s = self.s
-        losses, counts, vl2 = [], [], []
+        losses, counts, vl2, Ks = [], [], [], []
         t_block = time.time()
         for l in range(s.L):
             loss, kc = self.iteration(l)
             losses.append(loss)
             counts.append(kc)
+            Ks.append(s.K)
             if self.last_v_l2 is not None:
                 vl2.append(self.last_v_l2)
             if (s.verbose and l % s.print_every == 0) or l == s.L - 1:
@@ -417,5 +571,5 @@ class GeneralNativePlan:
                 t_block = now
                 if s.verbose and l % s.print_every == 0:
                     print('%d - loss = %.4e, v L2 error = %.4e, %.4f s/iter' % (l, s.loss_log[-1], s.V_L2_log[-1], s.times[-1]))
-                losses, counts, vl2 = [], [], []
+                losses, counts, vl2, Ks = [], [], [], []
         s.range_fallback_iterations = self.range_fallbacks()

@@ -445,7 +445,7 @@ class ExponentialOnSphereNonlinearParabolic(_ExpBall):
 class Committor:
     """Committor function between two concentric spheres of radius a = 1 and c = 2 (reference problems.py:1546-1579): b = 0,
     sigma = I, h = 0, boundary data 0 on the inner and 1 on the outer sphere; ``boundary = 'two_spheres'`` (EllipticSolver:
-    the batch size changes with the rejection step of every iteration, so this runs on the composite plan)."""
+    the batch size changes with the rejection step of every iteration; native: PSP_DOM_ANNULUS)."""
 
     def __init__(self, name='Committor', d=2, alpha=1.0, device=None):
         self.device = _resolve(device)
@@ -478,6 +478,9 @@ class Committor:
     def v_true(self, x):
         r = torch.sqrt(torch.sum(x ** 2, 1))
         return (self.a ** 2 - r ** (2 - self.d) * self.a ** self.d) / (self.a ** 2 - self.c ** (2 - self.d) * self.a ** self.d)
+
+    def general_native_spec(self):
+        return {'drift': (_nat.DRIFT_ZERO, None), 'sigma_scale': 1.0, 'h': _nat.GH_ZERO}
 
 
 class QuadraticOnBox:

@@ -36,6 +36,12 @@ def shard_bounds(K, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def shard_bounds_ragged(K, rank, world):
+    """The same split for a batch size the world size need not divide (the 'two_spheres' rejection sampler of the diffusion-loss
+    solvers changes K every iteration, reference solver.py:1048-1052): equal to shard_bounds when it does."""
+    return (K * rank) // world, (K * (rank + 1)) // world
+
+
 # bench.py sets this to a list to collect (start_event, end_event, bytes) of every device all-reduce: HIP events on the
 # launch stream, which waits for the collective (torch's synchronous all_reduce makes the current stream wait on RCCL's)
 coll_events = None

@@ -122,6 +122,26 @@ class QuadraticOnBox:
         return torch.sum(x ** 2, 1)
 
 
+class UserTanh2Net(ref_fs.DenseNet):
+    """NOT a reference class: a user-defined value net handed to the REFERENCE solvers through the `model.V = ...` extension
+    point, as `Committor function.ipynb` does with the tanh(.)**2 variant of DenseNet it defines for itself.
+    The reference constructor draws the parameters; only the hidden nonlinearity differs."""
+
+    def forward(self, x):
+        n = len(self.nn_dims) - 1
+        for i in range(n - 1):
+            x = torch.cat([x, torch.tanh(torch.matmul(x, self.W[2 * i]) + self.W[2 * i + 1]) ** 2], dim=1)
+        return torch.matmul(x, self.W[2 * n - 2]) + self.W[2 * n - 1]
+
+
+def make_value_net(net, d_in, lr):
+    kind = net.get("kind", "densenet")
+    if kind == "densenet_tanh":
+        return ref_fs.DenseNet_tanh(d_in=d_in, d_out=1, lr=lr, arch=net["arch"], seed=net["seed"])
+    cls = UserTanh2Net if kind == "user_tanh2" else ref_fs.DenseNet
+    return cls(d_in=d_in, d_out=1, lr=lr, arch=net["arch"], seed=net["seed"])
+
+
 def make_problem(spec):
     kind = spec["kind"]
     kw = dict(spec["kwargs"])
@@ -192,8 +212,7 @@ def run_general_case(case):
     model = ref_sv.GeneralSolver(problem=problem, name=case["name"], verbose=False, **skw)
     net = case.get("net")
     if net is not None:
-        model.V = ref_fs.DenseNet(d_in=problem.d + 1, d_out=1, lr=skw["lr"], arch=net["arch"],
-                                  seed=net["seed"])
+        model.V = make_value_net(net, problem.d + 1, skw["lr"])
     init_fp = param_fingerprint(model.V)
     model.train()
     xp = probe_points(problem.d)
@@ -203,6 +222,7 @@ def run_general_case(case):
     return {
         "loss_log": [float(v_) for v_ in model.loss_log],
         "K_log": [int(v_) for v_ in model.K_log],
+        "V_test_L2": [float(v_) for v_ in model.V_test_L2],
         "init_params": init_fp, "final_params": param_fingerprint(model.V),
         "probe_x": f32list(xp), "probe_t": 0.5 * problem.T, "probe_V": f32list(v),
     }
@@ -219,7 +239,7 @@ def run_elliptic_case(case):
     model = ref_sv.EllipticSolver(problem=problem, name=case["name"], verbose=False, **skw)
     net = case.get("net")
     if net is not None:
-        model.V = ref_fs.DenseNet(d_in=problem.d, d_out=1, lr=skw["lr"], arch=net["arch"], seed=net["seed"])
+        model.V = make_value_net(net, problem.d, skw["lr"])
     init_fp = param_fingerprint(model.V)
     model.train()
     xp = 0.4 * probe_points(problem.d)
@@ -601,6 +621,41 @@ CASES = [
          problem=dict(kind="HeatEquation", kwargs=dict(d=6, T=0.5, seed=42)),
          solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=72, K_boundary=16,
                      alpha=[1.0, 1.0, 1.0], loss_method="diffusion")),
+    # round 4: the committor notebook (`Committor function.ipynb`): EllipticSolver on 'two_spheres' with the tanh(.)**2 net the
+    # notebook defines for itself, arch = [d + 10, d, d, d]; its BSDE run (cell 15: N = 5000, every trajectory runs until it leaves
+    # the annulus) is the reference's second published timing (14-28 s per iteration at d = 10, K = 200)
+    dict(name="committor_d4_tanh2_elliptic_bsde", family="elliptic",
+         problem=dict(kind="Committor", kwargs=dict(d=4)),
+         solver=dict(seed=42, delta_t=0.004, N=1500, lr=0.001, L=3, K=48, K_boundary=20, loss_method="BSDE",
+                     alpha=[0.01, 1.0]),
+         net=dict(kind="user_tanh2", arch=[14, 4, 4, 4], seed=42)),
+    dict(name="committor_d10_tanh2_notebook_diffusion", family="elliptic",     # cell 3: K = 200, N = 50, dt = 1e-3, alpha = [10, 1]
+         problem=dict(kind="Committor", kwargs=dict(d=10)),
+         solver=dict(seed=42, delta_t=0.001, N=50, lr=0.001, L=3, K=200, K_boundary=50, loss_method="diffusion",
+                     alpha=[10.0, 1.0], K_test_log=300),
+         net=dict(kind="user_tanh2", arch=[20, 10, 10, 10], seed=42)),
+    # DenseNet_tanh (function_space.py:143-158: nn.Linear layers, tanh) as the value net
+    dict(name="allencahn_d10_densenet_tanh_diffusion", family="general",
+         problem=dict(kind="AllenCahn", kwargs=dict(d=10, T=0.3, seed=42, modus="pt")),
+         solver=dict(seed=42, delta_t=0.01, N=10, lr=0.001, L=3, K=80, K_boundary=16,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion"),
+         net=dict(kind="densenet_tanh", arch=[24, 24, 12], seed=42)),
+    # BASELINE configs[2] says "diffusion-loss (BSDE)": the BSDE loss on the exact (100, 64) instance
+    dict(name="dwgen_d100_h64_bsde", family="general",
+         problem=dict(kind="DoubleWell_multidim_for_general_solver",
+                      kwargs=dict(d=100, d_1=50, d_2=50, T=0.05, eta=1, kappa=1, modus="HJB")),
+         solver=dict(seed=42, delta_t=0.01, N=5, lr=0.001, L=3, K=64, K_boundary=16,
+                     alpha=[1.0, 1.0, 1.0], loss_method="BSDE"),
+         net=dict(arch=[64, 64], seed=42)),
+    # loss_with_stopped on a parabolic sphere problem (solver.py:1185-1186), sample_center on a one-dimensional elliptic one (:643-645)
+    dict(name="expsphere_d4_stopped_diffusion", family="general_bounded",
+         problem=dict(kind="ExponentialOnSphereNonlinearParabolic", kwargs=dict(d=4, T=0.6, alpha=0.5)),
+         solver=dict(seed=42, delta_t=0.01, N=30, lr=0.001, L=3, K=96, K_boundary=20,
+                     alpha=[1.0, 1.0, 1.0], loss_method="diffusion", loss_with_stopped=True)),
+    dict(name="expsphere_lin_d1_elliptic_center", family="elliptic",
+         problem=dict(kind="ExponentialOnSphere", kwargs=dict(d=1, alpha=0.3)),
+         solver=dict(seed=42, delta_t=0.01, N=20, lr=0.001, L=3, K=64, K_boundary=20, loss_method="diffusion",
+                     sample_center=True)),
 ]
 
 

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_support_table(lib):
-    assert lib.psp_version() == 301
+    assert lib.psp_version() == 400
     assert nat.supported(100, 64) and nat.supported(2, 30)
     assert not nat.supported(3, 7)
 
@@ -102,3 +102,35 @@ def test_collective_entry_points_validate_arguments(lib):
     ident = (C.c_ubyte * nat.COMM_ID_BYTES)()
     assert lib.psp_comm_init(C.byref(comm), 2, 5, ident) != 0
     assert lib.psp_comm_destroy(None) == 0
+
+
+def test_genl_query_without_gpu(lib):
+    """Value nets of any depth (include/psp.h 0.4.0): sizes, activation / layout switches and limits -- queries only."""
+    def cfg(d, dims, has_time=1, act=nat.ACT_RELU2, K=200, N=25):
+        c = nat.GenlConfig()
+        c.base.d, c.base.K_local, c.base.N, c.base.store_path = d, K, N, 1
+        c.has_time, c.n_hidden, c.activation = has_time, len(dims), act
+        for i, h in enumerate(dims):
+            c.widths[i] = h
+        return c
+    sz = nat.GenlSizes()
+    c = cfg(100, [110, 110, 50])                                 # Allen-Cahn.ipynb:72
+    assert lib.psp_genl_query(C.byref(c), C.byref(sz)) == 0
+    assert sz.n_params == 101 * 110 + 110 + 211 * 110 + 110 + 321 * 50 + 50 + 371 + 1
+    nt = (200 + 15) // 16
+    assert sz.n_blocks == 26 * nt and sz.path_bytes == 26 * nt * 2 * 7 * 256 * 4
+    assert sz.ahat_bytes == 26 * nt * 16 * 4 + nt * 4             # coefficients, then one step count per tile
+    assert sz.waves_per_tile == 8 and sz.grad_partial_bytes % (sz.n_params * 4) == 0
+    assert list(sz.seg_block_offset)[:4] == [0, 7, 14, 21]
+    c = cfg(10, [20, 10, 10, 10], has_time=0, act=nat.ACT_TANH2, N=5000)     # Committor function.ipynb: tanh^2, N = 5000
+    assert lib.psp_genl_query(C.byref(c), C.byref(sz)) == 0 and sz.waves_per_tile == 1
+    assert sz.n_params == 10 * 20 + 20 + 30 * 10 + 10 + 40 * 10 + 10 + 50 * 10 + 10 + 60 + 1
+    c = cfg(10, [20, 10], act=7)
+    assert lib.psp_genl_query(C.byref(c), C.byref(sz)) != 0 and "activation" in nat.last_error()
+    c = cfg(10, [200])
+    assert lib.psp_genl_query(C.byref(c), C.byref(sz)) != 0
+    c = cfg(10, [20, 10])
+    c.base.domain_kind, c.base.dom_a, c.base.dom_b = nat.DOM_ANNULUS, 2.0, 1.0
+    assert lib.psp_genl_query(C.byref(c), C.byref(sz)) != 0 and "annulus" in nat.last_error()
+    rc = lib.psp_genl_rollout_bwd(C.byref(cfg(10, [20, 10])), None, None, None, None, None, None, None, None, None)
+    assert rc != 0 and "null" in nat.last_error()

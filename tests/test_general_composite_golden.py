@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from util_cases import psp
+from util_cases import make_pkg_value_net, psp
 
 CASES = ["dwgen_d10_diffusion", "dwgen_d10_bsde", "allencahn_d10_diffusion", "heat_d6_diffusion",
          "dwgen_d7_h20_diffusion", "allencahn_d20_default_diffusion", "dwgen_d40_h50_bsde",
@@ -26,6 +26,13 @@ ELLIPTIC = ["expball_sin_d5_elliptic_diffusion", "expball_sq_d3_elliptic_bsde", 
 # (solver.py:1177-1183), K_test_log / loss_with_stopped
 COMPOSITE_ONLY = ["expsphere_d3_two_spheres_diffusion", "expsphere_d3_bsde_neumann", "committor_d3_elliptic_diffusion",
                   "committor_d4_elliptic_bsde", "corner_d3_elliptic_diffusion", "committor_d3_elliptic_testlog"]
+# round 4: all of the above run on the HIP kernels on a GPU (tests/test_gpu_bounded_elliptic.py); here the composite plan on CPU.
+# New goldens: the committor notebook's tanh^2 net (BSDE with N = 1500 and exits after a few hundred steps; the notebook's diffusion
+# configuration with K_test_log), DenseNet_tanh, the BSDE loss on the (100, 64) instance, loss_with_stopped on a parabolic problem,
+# sample_center
+R4_GENERAL = ["allencahn_d10_densenet_tanh_diffusion", "dwgen_d100_h64_bsde"]
+R4_BOUNDED = ["expsphere_d4_stopped_diffusion"]
+R4_ELLIPTIC = ["committor_d4_tanh2_elliptic_bsde", "committor_d10_tanh2_notebook_diffusion", "expsphere_lin_d1_elliptic_center"]
 
 
 def build(case, device="cpu", backend="auto", **over):
@@ -40,14 +47,13 @@ def build(case, device="cpu", backend="auto", **over):
     kw.update(over)
     model = cls(problem=prob, name=case["name"], verbose=False, device=device, backend=backend, **kw)
     if "net" in case:
-        model.V = psp.DenseNet(d_in=prob.d + (0 if elliptic else 1), d_out=1, lr=case["solver"]["lr"],
-                               arch=case["net"]["arch"], seed=case["net"]["seed"]).to(device)
+        model.V = make_pkg_value_net(case["net"], prob.d + (0 if elliptic else 1), case["solver"]["lr"], device)
     if "numpy_seed" in case:
         np.random.seed(case["numpy_seed"])         # GeneralSolver.train leaves numpy unseeded (square boundary shuffle)
     return prob, model
 
 
-@pytest.mark.parametrize("name", CASES + DEEP)
+@pytest.mark.parametrize("name", CASES + DEEP + R4_GENERAL)
 def test_general_composite_matches_reference(name):
     rec = load_golden(name)
     exact = rec["torch"] == torch.__version__
@@ -67,7 +73,7 @@ def test_general_composite_matches_reference(name):
     assert torch.allclose(v, want, rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC + COMPOSITE_ONLY + DEEP_BOUNDED + DEEP_ELLIPTIC)
+@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC + COMPOSITE_ONLY + DEEP_BOUNDED + DEEP_ELLIPTIC + R4_BOUNDED + R4_ELLIPTIC)
 def test_bounded_and_elliptic_composite_matches_reference(name):
     """Sphere / square domains (exit tests, Dirichlet / Neumann terms, BSDE with boundary data) and EllipticSolver."""
     rec = load_golden(name)

@@ -9,8 +9,8 @@ import pytest
 import torch
 
 from conftest import load_golden
-from test_general_composite_golden import BOUNDED, COMPOSITE_ONLY, ELLIPTIC, build as build_pkg
-from util_cases import orc, psp
+from test_general_composite_golden import BOUNDED, COMPOSITE_ONLY, ELLIPTIC, R4_BOUNDED, R4_ELLIPTIC, build as build_pkg
+from util_cases import general_oracle_run, orc, psp
 
 pytestmark = pytest.mark.gpu
 
@@ -20,25 +20,16 @@ def dev():
 
 
 def oracle_run(case, L):
-    kw = dict(case["problem"]["kwargs"])
-    kw.update(case["problem"].get("attrs", {}))
-    prob = orc.make_problem(case["problem"]["kind"], **kw)
-    s = case["solver"]
-    if "numpy_seed" in case:
-        np.random.seed(case["numpy_seed"])
-    common = dict(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=L, seed=s["seed"], K_boundary=s["K_boundary"],
-                  loss_method=s["loss_method"], adaptive_forward_process=s.get("adaptive_forward_process", False),
-                  uniform_square=s.get("uniform_square", False))
-    arch = case["net"]["arch"] if "net" in case else None
-    if case["family"] == "elliptic":
-        cfg = orc.EllipticConfig(alpha=tuple(s.get("alpha", (1.0, 1.0))), boundary_type=s.get("boundary_type", "Dirichlet"),
-                                 **common)
-        return orc.elliptic_train(prob, cfg, V=orc.elliptic_build(prob, cfg, arch=arch), trace=True)
-    cfg = orc.GeneralConfig(alpha=tuple(s["alpha"]), **common)
-    return orc.general_train(prob, cfg, V=orc.general_build(prob, cfg, arch=arch), trace=True)
+    return general_oracle_run(case, L=L, trace=True)[1]
 
 
-@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC)
+# round 4: 'two_spheres' (annulus exit test, a batch size that changes every iteration), 'square-corner', the BSDE loss with a
+# Neumann boundary, loss_with_stopped / K_test_log / sample_center, the committor notebook's tanh^2 net (BSDE with N = 1500:
+# the tiles leave the time loop after a few hundred steps) -- all on the HIP kernels
+NATIVE_R4 = COMPOSITE_ONLY + R4_BOUNDED + R4_ELLIPTIC
+
+
+@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC + NATIVE_R4)
 def test_first_iteration_gradient_matches_oracle(name):
     case = load_golden(name)["case"]
     prob, model = build_pkg(case, device=dev(), backend="native", L=1)
@@ -54,7 +45,7 @@ def test_first_iteration_gradient_matches_oracle(name):
     assert err <= 5e-4 * float(g_ref.abs().max()), (err, float(g_ref.abs().max()))
 
 
-@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC)
+@pytest.mark.parametrize("name", BOUNDED + ELLIPTIC + NATIVE_R4)
 def test_loss_log_matches_reference_golden(name):
     """Several iterations: also checks that the host consumed exactly the reference's number of noise draws
     (the all-stopped break of solver.py:1093-1097 / :742-744), otherwise iteration 2 would see other noise."""
@@ -73,6 +64,10 @@ def test_loss_log_matches_reference_golden(name):
         assert len(model.V_L2_log) == len(exp["V_L2_log"])
         for got, want in zip(model.V_L2_log, exp["V_L2_log"]):
             assert math.isclose(got, want, rel_tol=1e-4, abs_tol=1e-9), (model.V_L2_log, exp["V_L2_log"])
+    if exp.get("V_test_L2"):                                  # K_test_log: the same fresh points after every update
+        assert len(model.V_test_L2) == len(exp["V_test_L2"])
+        for got, want in zip(model.V_test_L2, exp["V_test_L2"]):
+            assert math.isclose(got, want, rel_tol=1e-4), (model.V_test_L2, exp["V_test_L2"])
     xp = torch.tensor(exp["probe_x"]).reshape(-1, prob.d).to(dev())
     if rec["case"]["family"] != "elliptic":
         xp = torch.cat([xp, torch.full((xp.shape[0], 1), exp["probe_t"], device=dev())], 1)
@@ -173,19 +168,46 @@ def test_edge_shapes_match_oracle(case):
     assert err <= 5e-4 * float(g_ref.abs().max()), (err, float(g_ref.abs().max()))
 
 
-@pytest.mark.parametrize("name", COMPOSITE_ONLY)
-def test_composite_only_configurations_run_on_the_gpu(name):
-    """'two_spheres', 'square-corner', BSDE + Neumann, K_test_log / loss_with_stopped: outside the kernels' catalogue, so
-    backend='auto' resolves to the composite torch plan on the GPU -- with the reference's loss log, never an error."""
-    rec = load_golden(name)
+def test_annulus_philox_large():
+    """'two_spheres' with device noise at K_original = 2^16 (the rejection step keeps ~ 1 - (r_1 / r_2)^d of it): bitwise
+    determinism, the batch size follows the sampler, every early exit sits outside the annulus, counts consistent."""
+    d, N = 6, 80
+    prob = psp.Committor(d=d, device=dev())
+
+    def make():
+        m = psp.EllipticSolver(problem=prob, name="big", seed=42, delta_t=0.002, N=N, lr=1e-3, L=2, K=1 << 16, K_boundary=50,
+                               alpha=[1.0, 1.0], loss_method="diffusion", verbose=False, device=dev(), backend="native",
+                               noise="philox", v_l2_error_flag=False)
+        m.V = psp.DenseNet_tanh_2(d_in=d, d_out=1, lr=1e-3, arch=[d + 10, d, d, d], seed=42).to(dev())
+        return m
+
+    a, b = make(), make()
+    a.train()
+    b.train()
+    pa, pb = a._gen_plan, b._gen_plan
+    assert type(pa).__name__ == "GeneralDeepPlan"
+    assert a.loss_log == b.loss_log and all(math.isfinite(v) for v in a.loss_log) and a.K_log == b.K_log
+    assert torch.equal(pa.grad, pb.grad) and torch.equal(pa.YN, pb.YN) and bool(torch.isfinite(pa.grad).all())
+    assert a.K < a.K_original and a.K > 0.9 * a.K_original and pa.YN.numel() == a.K
+    steps = torch.round(pa.tN / pa.cfg.dt)
+    assert int(steps.sum().item()) == a.K_log[-1] and 0 < a.K_log[-1] < a.K * N
+    r = pa.XN.norm(dim=1)
+    early = steps < N
+    assert int(early.sum()) > 0
+    assert bool(((r[early] <= prob.boundary_distance_1) | (r[early] >= prob.boundary_distance_2)).all())
+    assert bool(((r[~early] < 3.0)).all())
+
+
+def test_user_coefficients_keep_the_composite_plan():
+    """A problem whose coefficient was replaced on the instance is outside the kernels' catalogue: backend='auto' takes the
+    composite torch plan with a warning, backend='native' raises."""
+    rec = load_golden("committor_d3_elliptic_diffusion")
+    prob, model = build_pkg(rec["case"], device=dev(), backend="auto", L=1)
+    prob.h = lambda x, y, z: 0.1 * y
     with pytest.warns(UserWarning, match="composite torch plan"):
-        prob, model = build_pkg(rec["case"], device=dev(), backend="auto")
         model.train()
     assert model.plan_name == "torch" and model.plan_reason
-    exp = rec["expected"]
-    assert model.K_log == exp["K_log"]
-    for got, want in zip(model.loss_log, exp["loss_log"]):
-        assert math.isclose(got, want, rel_tol=1e-4), (name, model.loss_log, exp["loss_log"])
+    prob, model = build_pkg(rec["case"], device=dev(), backend="native", L=1)
+    prob.h = lambda x, y, z: 0.1 * y
     with pytest.raises(NotImplementedError):
-        prob, model = build_pkg(rec["case"], device=dev(), backend="native")
         model.train()

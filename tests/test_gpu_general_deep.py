@@ -10,12 +10,12 @@ import pytest
 import torch
 
 from conftest import load_golden
-from test_general_composite_golden import DEEP, DEEP_BOUNDED, DEEP_ELLIPTIC, build as build_pkg
+from test_general_composite_golden import DEEP, DEEP_BOUNDED, DEEP_ELLIPTIC, R4_GENERAL, build as build_pkg
 from test_gpu_bounded_elliptic import oracle_run
 from util_cases import psp
 
 pytestmark = pytest.mark.gpu
-ALL = DEEP + DEEP_BOUNDED + DEEP_ELLIPTIC
+ALL = DEEP + DEEP_BOUNDED + DEEP_ELLIPTIC + ["allencahn_d10_densenet_tanh_diffusion"]     # (DenseNet_tanh: nn.Linear weights)
 
 
 def dev():
@@ -59,25 +59,85 @@ def test_loss_log_matches_reference_golden(name):
     assert float((v - want).abs().max()) <= 1e-4 * max(1e-2, float(want.abs().max()))
 
 
-def test_slabs_of_the_adjoint_pass_add_up():
-    """The adjoint pass walks the path store in slabs of a memory budget: one slab and many slabs give the same gradient."""
-    case = load_golden("allencahn_d10_arch3_diffusion")["case"]
-    from path_space_pde_solver_amd import plan_general_deep as pgd
+def test_wave_split_and_launch_groups_agree():
+    """The same net through the one-wave and the eight-wave kernels (PSP_GENL_NW), and a net whose weight-gradient tiles need
+    several launch groups against the oracle: the work split never changes the result beyond summation order."""
+    import os
+    case = load_golden("dwgen_d10_arch4_bsde")["case"]            # [30, 30, 30, 30]: small enough for one wave per tile
     grads = {}
-    keep = pgd.GeneralDeepPlan.ADJ_BUDGET_BYTES
+    keep = os.environ.get("PSP_GENL_NW")
     try:
-        for budget in (keep, 300 * 1024):
-            pgd.GeneralDeepPlan.ADJ_BUDGET_BYTES = budget
-            prob, model = build_pkg(case, device=dev(), backend="native", L=1, noise="philox", K=1000)
+        for nw in ("1", "8"):
+            os.environ["PSP_GENL_NW"] = nw
+            prob, model = build_pkg(case, device=dev(), backend="native", L=1)
             model.train()
-            plan = model._gen_plan
-            grads[budget] = (plan.grad.clone(), plan.slab_blocks, int(plan.sizes.n_blocks), model.loss_log[0], model.K_log[0])
+            assert int(model._gen_plan.sizes.waves_per_tile) == int(nw)
+            grads[nw] = (model._gen_plan.grad.clone(), model.loss_log[0], model.K_log[0])
     finally:
-        pgd.GeneralDeepPlan.ADJ_BUDGET_BYTES = keep
-    (g1, s1, nb, l1, k1), (g2, s2, _, l2, k2) = grads[keep], grads[300 * 1024]
-    assert s1 >= nb and s2 < nb // 3, (s1, s2, nb)
-    assert l1 == l2 and k1 == k2
-    assert float((g1 - g2).abs().max()) <= 2e-6 * float(g1.abs().max())
+        if keep is None:
+            os.environ.pop("PSP_GENL_NW", None)
+        else:
+            os.environ["PSP_GENL_NW"] = keep
+    (g1, l1, k1), (g8, l8, k8) = grads["1"], grads["8"]
+    assert k1 == k8 and math.isclose(l1, l8, rel_tol=2e-6)
+    assert float((g1 - g8).abs().max()) <= 2e-5 * float(g1.abs().max())
+    # 4 x 128 hidden units at d = 20: 2 + 8 .. blocks per layer -> (2 + 10 + 18 + 26) * 8 + 34 = 482 tiles = two launch groups
+    wide = dict(case, net=dict(arch=[128, 128, 128, 128], seed=42),
+                problem=dict(kind="DoubleWell_multidim_for_general_solver",
+                             kwargs=dict(d=20, d_1=10, d_2=10, T=0.1, eta=0.1, kappa=1, modus="HJB")))
+    prob, model = build_pkg(wide, device=dev(), backend="native", L=1)
+    model.train()
+    assert int(model._gen_plan.sizes.bwd_workgroups) > int(model._gen_plan.grad_partial.numel() // model._gen_plan.P)   # > 1 group
+    ref = oracle_run(wide, 1)
+    assert model.K_log == ref["K_log"] and math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=5e-5)
+    g_ref = torch.cat([g.reshape(-1) for g in ref["traces"][0]["grads"]])
+    err = float((model._gen_plan.grad.cpu() - g_ref).abs().max()) / float(g_ref.abs().max())
+    print("4 x 128 net: gradient rel err %.2e" % err)
+    assert err <= 5e-4
+
+
+class NotebookTanh2(torch.nn.Module):
+    """A value net as a notebook would define it for itself (`Committor function.ipynb` cell 1 does): not a class of the
+    package -- dense-concat layout, (in, out) weights in a list W, tanh(.)**2.  The plan recognises it by structure and by a
+    probe of its forward (plan_general_deep.value_net_spec)."""
+
+    def __init__(self, d_in, arch, lr, seed, power=2):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.nn_dims = [d_in] + list(arch) + [1]
+        self.power = power
+        self.W = []
+        for i in range(len(self.nn_dims) - 1):
+            self.W.append(torch.nn.Parameter(torch.randn(sum(self.nn_dims[:i + 1]), self.nn_dims[i + 1]) * 0.1))
+            self.W.append(torch.nn.Parameter(torch.zeros(self.nn_dims[i + 1])))
+        for i, w in enumerate(self.W):
+            self.register_parameter("p%d" % i, w)
+        self.optim = torch.optim.Adam(self.parameters(), lr=lr)
+
+    def forward(self, x):
+        n = len(self.nn_dims) - 1
+        for i in range(n - 1):
+            x = torch.cat([x, torch.tanh(x @ self.W[2 * i] + self.W[2 * i + 1]) ** self.power], 1)
+        return x @ self.W[2 * n - 2] + self.W[2 * n - 1]
+
+
+def test_user_defined_dense_concat_net_runs_on_the_kernels():
+    rec = load_golden("committor_d10_tanh2_notebook_diffusion")
+    case = rec["case"]
+    prob, model = build_pkg(case, device=dev(), backend="native")
+    model.V = NotebookTanh2(prob.d, case["net"]["arch"], case["solver"]["lr"], case["net"]["seed"]).to(dev())
+    model.train()
+    assert type(model._gen_plan).__name__ == "GeneralDeepPlan" and model._gen_plan.net_spec["act"] == "tanh2"
+    exp = rec["expected"]
+    assert model.K_log == exp["K_log"]
+    errs = [abs(a - b) / abs(b) for a, b in zip(model.loss_log, exp["loss_log"])]
+    assert max(errs) <= 1e-4, (model.loss_log, exp["loss_log"])
+    # a forward the kernels do not implement (tanh cubed) is NOT taken for one they do: composite plan, with a warning
+    prob, other = build_pkg(case, device=dev(), backend="auto", L=1)
+    other.V = NotebookTanh2(prob.d, case["net"]["arch"], case["solver"]["lr"], case["net"]["seed"], power=3).to(dev())
+    with pytest.warns(UserWarning, match="composite torch plan"):
+        other.train()
+    assert other.plan_name == "torch" and "none of the dense-concat formulas" in other.plan_reason
 
 
 def test_philox_rollout_is_deterministic_and_shard_independent():

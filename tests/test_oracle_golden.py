@@ -10,6 +10,7 @@ import torch
 
 from conftest import load_golden
 from oracle import pathspace_oracle as orc
+from util_cases import general_oracle_run
 
 SOLVER_CASES = ["lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "llgc_d12_outer_relative_entropy_detached", "dw_d20_densenet_attached_moment", "lqgc_d6_densenet_attached_cross_entropy",
                 "llgc_d12_outer_moment", "dw_d20_densenet_nonadaptive", "lqgc_d6_densenet_variance", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_logvar", "llgc_d200_h64_logvar",
@@ -106,19 +107,20 @@ def test_ul2_flag_does_not_change_loss():
     assert a == b
 
 
-@pytest.mark.parametrize("name", GENERAL_CASES)
+# round 4: value nets that are not the relu^2 DenseNet (the committor notebook's tanh^2 net, DenseNet_tanh), the BSDE loss on the
+# (100, 64) instance, loss_with_stopped / K_test_log / sample_center
+GENERAL_R4 = ["allencahn_d10_densenet_tanh_diffusion", "dwgen_d100_h64_bsde"]
+BOUNDED_R4 = ["expsphere_d4_stopped_diffusion"]
+ELLIPTIC_R4 = ["committor_d4_tanh2_elliptic_bsde", "committor_d10_tanh2_notebook_diffusion", "expsphere_lin_d1_elliptic_center",
+               "committor_d3_elliptic_testlog"]
+
+
+@pytest.mark.parametrize("name", GENERAL_CASES + GENERAL_R4)
 def test_general_oracle_matches_reference(name):
     rec = load_golden(name)
     exact = _same_build(rec)
-    case = rec["case"]
     torch.set_num_threads(1)
-    prob = orc.make_problem(case["problem"]["kind"], **dict(case["problem"]["kwargs"], **case["problem"].get("attrs", {})))
-    s = case["solver"]
-    cfg = orc.GeneralConfig(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=s["L"], seed=s["seed"],
-                            K_boundary=s["K_boundary"], alpha=tuple(s["alpha"]), loss_method=s["loss_method"],
-                            uniform_square=s.get("uniform_square", False))
-    V = orc.general_build(prob, cfg, arch=case["net"]["arch"] if "net" in case else None)
-    out = orc.general_train(prob, cfg, V=V)
+    prob, out = general_oracle_run(rec["case"])
     exp = rec["expected"]
     _check_series(out["loss_log"], exp["loss_log"], exact)
     assert out["K_log"] == exp["K_log"]
@@ -136,53 +138,31 @@ ELLIPTIC_CASES = ["expball_sin_d5_elliptic_diffusion", "expball_sq_d3_elliptic_b
                   "expball_sin_d5_arch3_elliptic_diffusion"]
 
 
-def _bounded_problem(case):
-    import numpy as np
-    kw = dict(case["problem"]["kwargs"])
-    kw.update(case["problem"].get("attrs", {}))          # boundary_type set on the instance -> oracle keyword
-    if "numpy_seed" in case:
-        np.random.seed(case["numpy_seed"])
-    return orc.make_problem(case["problem"]["kind"], **kw)
-
-
-@pytest.mark.parametrize("name", BOUNDED_CASES)
+@pytest.mark.parametrize("name", BOUNDED_CASES + BOUNDED_R4)
 def test_general_bounded_oracle_matches_reference(name):
     """GeneralSolver on sphere / square domains: exit tests, Dirichlet / Neumann terms, BSDE with boundary data."""
     rec = load_golden(name)
     exact = _same_build(rec)
-    case = rec["case"]
     torch.set_num_threads(1)
-    prob = _bounded_problem(case)
-    s = case["solver"]
-    cfg = orc.GeneralConfig(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=s["L"], seed=s["seed"],
-                            K_boundary=s["K_boundary"], alpha=tuple(s["alpha"]), loss_method=s["loss_method"],
-                            adaptive_forward_process=s.get("adaptive_forward_process", False))
-    V = orc.general_build(prob, cfg, arch=case["net"]["arch"] if "net" in case else None)
-    out = orc.general_train(prob, cfg, V=V)
+    prob, out = general_oracle_run(rec["case"])
     exp = rec["expected"]
     _check_series(out["loss_log"], exp["loss_log"], exact)
     assert out["K_log"] == exp["K_log"]
     _check_fp(orc.fingerprint(out["V"]), exp["final_params"], exact)
 
 
-@pytest.mark.parametrize("name", ELLIPTIC_CASES)
+@pytest.mark.parametrize("name", ELLIPTIC_CASES + ELLIPTIC_R4)
 def test_elliptic_oracle_matches_reference(name):
     rec = load_golden(name)
     exact = _same_build(rec)
-    case = rec["case"]
     torch.set_num_threads(1)
-    prob = _bounded_problem(case)
-    s = case["solver"]
-    cfg = orc.EllipticConfig(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=s["L"], seed=s["seed"],
-                             K_boundary=s["K_boundary"], alpha=tuple(s.get("alpha", (1.0, 1.0))),
-                             loss_method=s["loss_method"], boundary_type=s.get("boundary_type", "Dirichlet"),
-                             adaptive_forward_process=s.get("adaptive_forward_process", False))
-    V = orc.elliptic_build(prob, cfg, arch=case["net"]["arch"] if "net" in case else None)
-    out = orc.elliptic_train(prob, cfg, V=V)
+    prob, out = general_oracle_run(rec["case"])
     exp = rec["expected"]
     _check_series(out["loss_log"], exp["loss_log"], exact)
     assert out["K_log"] == exp["K_log"]
     _check_series(out["V_L2_log"], exp["V_L2_log"], False)
+    if exp.get("V_test_L2"):
+        _check_series(out["V_test_L2"], exp["V_test_L2"], False)
     _check_fp(orc.fingerprint(out["V"]), exp["final_params"], exact)
 
 

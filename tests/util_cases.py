@@ -54,3 +54,36 @@ def make_oracle(case, L=None):
 
 def flat_params(module):
     return torch.cat([p.detach().reshape(-1).cpu() for p in module.parameters()])
+
+
+def general_oracle_run(case, L=None, trace=False):
+    """Oracle run of a GeneralSolver / EllipticSolver golden case (families 'general', 'general_bounded', 'elliptic'): every
+    solver switch of the case and its value net (kind 'densenet' | 'user_tanh2' | 'densenet_tanh').  Returns (problem, out)."""
+    import numpy as np
+    kw = dict(case["problem"]["kwargs"])
+    kw.update(case["problem"].get("attrs", {}))          # attributes set on the instance -> oracle keywords
+    if "numpy_seed" in case:
+        np.random.seed(case["numpy_seed"])
+    prob = orc.make_problem(case["problem"]["kind"], **kw)
+    s = case["solver"]
+    common = dict(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=s["L"] if L is None else L, seed=s["seed"],
+                  K_boundary=s["K_boundary"], loss_method=s["loss_method"],
+                  adaptive_forward_process=s.get("adaptive_forward_process", False),
+                  uniform_square=s.get("uniform_square", False), loss_with_stopped=s.get("loss_with_stopped", False),
+                  K_test_log=s.get("K_test_log"), sample_center=s.get("sample_center", False))
+    net = case.get("net")
+    if case["family"] == "elliptic":
+        cfg = orc.EllipticConfig(alpha=tuple(s.get("alpha", (1.0, 1.0))), boundary_type=s.get("boundary_type", "Dirichlet"),
+                                 **common)
+        return prob, orc.elliptic_train(prob, cfg, V=orc.elliptic_build(prob, cfg, net=net), trace=trace)
+    cfg = orc.GeneralConfig(alpha=tuple(s["alpha"]), **common)
+    return prob, orc.general_train(prob, cfg, V=orc.general_build(prob, cfg, net=net), trace=trace)
+
+
+def make_pkg_value_net(net, d_in, lr, device):
+    """The package-side value net of a golden case (kinds as in tests/golden/make_golden.py)."""
+    kind = net.get("kind", "densenet")
+    if kind == "densenet_tanh":
+        return psp.DenseNet_tanh(d_in=d_in, d_out=1, lr=lr, arch=net["arch"], seed=net["seed"]).to(device)
+    cls = psp.DenseNet_tanh_2 if kind == "user_tanh2" else psp.DenseNet
+    return cls(d_in=d_in, d_out=1, lr=lr, arch=net["arch"], seed=net["seed"]).to(device)
