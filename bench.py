@@ -111,6 +111,16 @@ GENERAL_WORKLOADS = {
     "diffusion_allencahn_d100_K16384_N25_a110": dict(d=100, arch=[110, 110, 50], K=16384, N=25, T=0.3, dt=0.001, loss="diffusion",
                                                      problem="AllenCahn", alpha=[10.0, 1.0, 1.0], uniform_square=True,
                                                      boundary_distance=7.0),
+    # the reference's OTHER published timing: EllipticSolver, BSDE loss, committor function between two
+    # spheres at d = 10, K = 200, N = 5000, dt = 1e-3, the notebook's own tanh(.)**2 net arch = [d + 10, d, d, d] -- 14.07 .. 28.46 s
+    # per iteration (`Committor function.ipynb` cell 15-16: every trajectory runs until it leaves the annulus, 450 .. 1700 steps)
+    "elliptic_committor_d10_K200": dict(d=10, arch=[20, 10, 10, 10], act="tanh2", K=200, N=5000, dt=0.001, loss="BSDE",
+                                        problem="Committor", solver="elliptic", alpha=[0.01, 1.0],
+                                        published_s_per_iter=(14.07, 28.46),
+                                        published_source="experiments/diffusion-loss/Committor function.ipynb:375,686 (BASELINE.md section 1)"),
+    # the same problem at a batch that fills the chip
+    "elliptic_committor_d10_K65536": dict(d=10, arch=[20, 10, 10, 10], act="tanh2", K=65536, N=5000, dt=0.001, loss="BSDE",
+                                          problem="Committor", solver="elliptic", alpha=[0.01, 1.0]),
 }
 # MI355X_MICROARCH.md, chip-level parameters
 PEAK_FP32_MFMA_TFLOPS = 157.3
@@ -863,14 +873,33 @@ def finish_ranks(psp, dist, rank, world, dev, rehearsal):
     dist.destroy_process_group()
 
 
+def make_general_model(psp, w, dev, arch, K, L, backend, noise, mlp="auto", name="bench"):
+    """Problem + solver + value net of a GENERAL_WORKLOADS entry (GeneralSolver, or EllipticSolver for solver='elliptic')."""
+    if w.get("problem") == "AllenCahn":
+        prob = psp.AllenCahn(d=w["d"], T=w["T"], seed=42, modus="pt", device=dev)
+        prob.boundary_distance = w.get("boundary_distance", 1.0)
+    elif w.get("problem") == "Committor":
+        prob = psp.Committor(d=w["d"], device=dev)
+    else:
+        prob = psp.DoubleWell_multidim_for_general_solver(d=w["d"], d_1=w["d"] // 2, d_2=w["d"] - w["d"] // 2, T=w["T"],
+                                                          eta=1, kappa=1, modus="HJB", device=dev)
+    elliptic = w.get("solver") == "elliptic"
+    if elliptic:
+        model = psp.EllipticSolver(problem=prob, name=name, seed=42, delta_t=w["dt"], N=w["N"], lr=1e-3, L=L, K=K, K_boundary=50,
+                                   alpha=w.get("alpha", [1.0, 1.0]), loss_method=w["loss"], verbose=False, device=dev,
+                                   backend=backend, noise=noise, v_l2_error_flag=False)
+    else:
+        model = psp.GeneralSolver(problem=prob, name=name, seed=42, delta_t=w["dt"], N=w["N"], lr=1e-3, L=L, K=K, K_boundary=50,
+                                  alpha=w.get("alpha", [1.0, 1.0, 1.0]), loss_method=w["loss"], verbose=False, device=dev,
+                                  backend=backend, noise=noise, mlp_dtype=mlp, uniform_square=bool(w.get("uniform_square", False)))
+    model.V = psp.DenseNet(d_in=w["d"] + (0 if elliptic else 1), d_out=1, lr=1e-3, arch=arch, seed=42,
+                           activation=w.get("act", "relu2")).to(dev)
+    return prob, model
+
+
 def general_composite_leg(psp, dev, w, arch, iters=6):
     """The same configuration on the package's composite torch plan (the reference's op sequence with autograd) on this GPU."""
-    prob = psp.AllenCahn(d=w["d"], T=w["T"], seed=42, modus="pt", device=dev)
-    prob.boundary_distance = w.get("boundary_distance", 1.0)
-    m = psp.GeneralSolver(problem=prob, name="bench-composite", seed=42, delta_t=w["dt"], N=w["N"], lr=1e-3, L=iters, K=w["K"],
-                          K_boundary=50, alpha=w.get("alpha", [1.0, 1.0, 1.0]), loss_method=w["loss"], verbose=False, device=dev,
-                          backend="torch", uniform_square=bool(w.get("uniform_square", False)))
-    m.V = psp.DenseNet(d_in=w["d"] + 1, d_out=1, lr=1e-3, arch=arch, seed=42).to(dev)
+    prob, m = make_general_model(psp, w, dev, arch, w["K"], iters, "torch", "reference", name="bench-composite")
     m.train()
     per = sorted(m.times[1:])[len(m.times[1:]) // 2]
     return {"s_per_iteration": per, "value": (sum(m.K_log[1:]) / max(1, len(m.K_log) - 1)) / per, "unit": "trajectory-timesteps/s",
@@ -878,21 +907,30 @@ def general_composite_leg(psp, dev, w, arch, iters=6):
 
 
 def general_cpu_baseline(w, arch, iters=8):
-    """The CPU oracle (oracle/pathspace_oracle.py general_train: a port of GeneralSolver.train) on this box's host cores."""
+    """The CPU oracle (oracle/pathspace_oracle.py general_train / elliptic_train: ports of GeneralSolver.train and
+    EllipticSolver.train) on this box's host cores."""
     from oracle import pathspace_oracle as orc
     allc = min(16, os.cpu_count() or 1)
     torch.set_num_threads(allc)
-    prob = orc.make_problem("AllenCahn", d=w["d"], T=w["T"], seed=42, modus="pt", boundary_distance=w.get("boundary_distance", 1.0))
-    cfg = orc.GeneralConfig(K=w["K"], N=w["N"], delta_t=w["dt"], lr=1e-3, L=1, seed=42, K_boundary=50, alpha=tuple(w.get("alpha", (1.0, 1.0, 1.0))),
-                            loss_method=w["loss"], uniform_square=bool(w.get("uniform_square", False)))
-    V = orc.general_build(prob, cfg, arch=arch)
-    orc.general_train(prob, cfg, V=V)
+    net = dict(kind="user_tanh2" if w.get("act") == "tanh2" else "densenet", arch=arch, seed=42)
+    if w.get("solver") == "elliptic":
+        prob = orc.make_problem(w["problem"], d=w["d"])
+        cfg = orc.EllipticConfig(K=w["K"], N=w["N"], delta_t=w["dt"], lr=1e-3, L=1, seed=42, K_boundary=50,
+                                 alpha=tuple(w.get("alpha", (1.0, 1.0))), loss_method=w["loss"])
+        V, train = orc.elliptic_build(prob, cfg, net=net), orc.elliptic_train
+    else:
+        prob = orc.make_problem("AllenCahn", d=w["d"], T=w["T"], seed=42, modus="pt", boundary_distance=w.get("boundary_distance", 1.0))
+        cfg = orc.GeneralConfig(K=w["K"], N=w["N"], delta_t=w["dt"], lr=1e-3, L=1, seed=42, K_boundary=50, alpha=tuple(w.get("alpha", (1.0, 1.0, 1.0))),
+                                loss_method=w["loss"], uniform_square=bool(w.get("uniform_square", False)))
+        V, train = orc.general_build(prob, cfg, net=net), orc.general_train
+    train(prob, cfg, V=V)
     t0, act = time.time(), 0
     for _ in range(iters):
-        act += orc.general_train(prob, cfg, V=V)["K_log"][0]
+        act += train(prob, cfg, V=V)["K_log"][0]
     el = time.time() - t0
     return {"value": act / el, "unit": "trajectory-timesteps/s", "cores": allc, "kind": "port", "s_per_iteration": el / iters,
-            "sample": "oracle general_train, the whole workload (K=%d, N=%d), %d iterations, %.1f s, torch %s" % (w["K"], w["N"], iters, el, torch.__version__)}
+            "sample": "oracle %s, the whole workload (K=%d, N=%d), %d iterations, %.1f s, torch %s"
+                      % (train.__name__, w["K"], w["N"], iters, el, torch.__version__)}
 
 
 def main_general(args, psp, sharding):
@@ -900,19 +938,9 @@ def main_general(args, psp, sharding):
     (K_log, reference solver.py:1152), as SURVEY.md 8d prescribes."""
     w = GENERAL_WORKLOADS[args.workload]
     dist, rank, world, dev, rehearsal = init_ranks(args)
-    if w.get("problem") == "AllenCahn":
-        prob = psp.AllenCahn(d=w["d"], T=w["T"], seed=42, modus="pt", device=dev)
-        prob.boundary_distance = w.get("boundary_distance", 1.0)
-    else:
-        prob = psp.DoubleWell_multidim_for_general_solver(d=w["d"], d_1=w["d"] // 2, d_2=w["d"] - w["d"] // 2, T=w["T"],
-                                                          eta=1, kappa=1, modus="HJB", device=dev)
     total = args.warmup + args.steps
     arch = w.get("arch") or [w["H"], w["H"]]
-    model = psp.GeneralSolver(problem=prob, name="bench", seed=42, delta_t=w["dt"], N=w["N"], lr=1e-3, L=total,
-                              K=w["K"] * world, K_boundary=50, alpha=w.get("alpha", [1.0, 1.0, 1.0]), loss_method=w["loss"],
-                              verbose=False, device=dev, backend="native", noise="philox", mlp_dtype=w.get("mlp", "auto"),
-                              uniform_square=bool(w.get("uniform_square", False)))
-    model.V = psp.DenseNet(d_in=w["d"] + 1, d_out=1, lr=1e-3, arch=arch, seed=42).to(dev)
+    prob, model = make_general_model(psp, w, dev, arch, w["K"] * world, total, "native", "philox", mlp=w.get("mlp", "auto"))
     plan = model._choose_plan()
     assert model.plan_name == "native"
     deep = type(plan).__name__ == "GeneralDeepPlan"
@@ -936,7 +964,7 @@ def main_general(args, psp, sharding):
     # algorithmic flops per LAUNCHED trajectory-timestep: value net F = 2[(d+1)H + (d+1+H)H + (d+1+2H)],
     # its input gradient ~ F (reverse sweep), and the double-backward of both ~ 2 x that: forward kernel
     # 2F (+ F for the tangent part it pre-computes), backward kernel 3F  -> 6F per unit in total
-    n_in, F = w["d"] + 1, 0
+    n_in, F = w["d"] + (0 if w.get("solver") == "elliptic" else 1), 0
     for h_ in arch:                                              # dense-concat layers: in_i = d + 1 + sum of the earlier widths
         F += 2 * n_in * h_
         n_in += h_
@@ -946,9 +974,13 @@ def main_general(args, psp, sharding):
     bwd_dom = bwd_ms >= fwd_ms
     dom, dom_ms, dom_fl = ("gen_bwd2_kernel", bwd_ms, 3 * F) if bwd_dom else ("gen_fwd_kernel", fwd_ms, 3 * F)
     if deep:
-        # run-time-shaped family: forward = value + reverse sweep (2 F); backward = adjoint kernel (recompute value and tangent 2 F,
-        # adjoints 2 F) + the weight-gradient GEMMs (2 F), timed together as the backward leg
-        dom, dom_fl = ("genl_adj_kernel + weight-gradient GEMMs", 6 * F) if bwd_dom else ("genl_fwd_kernel", 2 * F)
+        # run-time-shaped family: forward = value + reverse sweep (2 F); backward = ONE kernel: recompute value and tangent (2 F),
+        # adjoints (2 F), weight-gradient outer products (2 F)
+        dom, dom_fl = ("genl_bwd_kernel", 6 * F) if bwd_dom else ("genl_fwd_kernel", 2 * F)
+    if w.get("solver") == "elliptic":
+        # exit-time problem: a tile leaves the time loop once all of its trajectories have left the domain -- the launched units are
+        # the executed steps, measured (not K x N)
+        units = active / args.steps
     # every product of these kernels is a value-net product: on bf16 workloads the whole kernel is priced at the bf16 MFMA
     # peak (forward always; backward only with mlp == 'bf16')
     on_bf16 = (mlp in ("bf16", "bf16_fwd") and not bwd_dom) or (mlp == "bf16" and bwd_dom)
@@ -974,8 +1006,10 @@ def main_general(args, psp, sharding):
                          "bf16_fwd": "bf16 MFMA operands in the forward rollout, f32 state / accumulate / backward"}.get(
                              mlp, "f32 (f16x3 split products: every matrix product as three f16 MFMAs, fp32 accumulate)" if x3 else "f32"),
                "data": "synthetic",
-               "config": {"workload": args.workload, "problem": "DoubleWell_multidim_for_general_solver",
-                          "d": w["d"], "K_per_gpu": w["K"], "N": w["N"], "V": "DenseNet %d-%s-1" % (w["d"] + 1, "-".join(str(h_) for h_ in arch)),
+               "config": {"workload": args.workload, "problem": w.get("problem", "DoubleWell_multidim_for_general_solver"),
+                          "solver": "EllipticSolver" if w.get("solver") == "elliptic" else "GeneralSolver",
+                          "d": w["d"], "K_per_gpu": w["K"], "N": w["N"],
+                          "V": "dense-concat %s net %d-%s-1" % (w.get("act", "relu2"), w["d"] + (0 if w.get("solver") == "elliptic" else 1), "-".join(str(h_) for h_ in arch)),
                           "loss": w["loss"], "active_fraction": active / (w["K"] * world * w["N"] * args.steps)},
                "roofline": {"bound": bound, "kernel": dom,
                             "achieved": achieved if bound == "mfma" else hbm_alg_gbps,
@@ -996,15 +1030,31 @@ def main_general(args, psp, sharding):
                "launched_units_per_s": w["K"] * world * w["N"] * args.steps / elapsed,
                "s_per_iteration": elapsed / args.steps,
                "loss_first_last": [float(losses[0]), float(losses[-1])]}
+        if w.get("solver") == "elliptic":
+            out["config"]["last_batch_size"] = model.K
+            out["config"]["mean_active_steps_per_iteration"] = active / args.steps
+            out["config"]["waves_per_tile"] = int(plan.sizes.waves_per_tile) if deep else None
         if coll is not None:
             coll["fraction_of_step"] = coll["per_step_ms"] / (1e3 * elapsed / args.steps)
             out["collectives"] = coll
         if getattr(plan, "range_flag", None) is not None:
             out["config"]["range_guard"] = "on (include/psp.h range_flag); fallback iterations in this run: %d" % plan.range_fallbacks()
         if w.get("published_s_per_iter"):
-            out["vs_baseline"] = out["value"] / w["published_units_per_s"]
-            out["reference_published"] = {"s_per_iteration": list(w["published_s_per_iter"]), "units_per_s": w["published_units_per_s"],
-                                          "hardware": "unnamed CUDA GPU", "source": "experiments/diffusion-loss/Allen-Cahn.ipynb:86,115 (BASELINE.md section 1)"}
+            lo_s, hi_s = w["published_s_per_iter"]
+            out["reference_published"] = {"s_per_iteration": [lo_s, hi_s], "units_per_s": w.get("published_units_per_s"),
+                                          "hardware": "unnamed CUDA GPU",
+                                          "source": w.get("published_source", "experiments/diffusion-loss/Allen-Cahn.ipynb:86,115 (BASELINE.md section 1)"),
+                                          "iteration_time_ratio": [lo_s / (elapsed / args.steps), hi_s / (elapsed / args.steps)]}
+            if w.get("published_units_per_s"):
+                out["vs_baseline"] = out["value"] / w["published_units_per_s"]
+            else:
+                # the notebook prints seconds per iteration, not the number of active steps; the same sampler and net give the same
+                # distribution of exit times, so the published rate is this run's active steps per iteration over the published time
+                mid = 0.5 * (lo_s + hi_s)
+                out["reference_published"]["units_per_s_derived"] = (active / args.steps) / mid
+                out["reference_published"]["note"] = ("units/s derived from this run's mean active steps per iteration and the midpoint of the "
+                                                      "published seconds per iteration (the notebook logs no step counts)")
+                out["vs_baseline"] = mid / (elapsed / args.steps)
             if world == 1 and not args.no_secondary:
                 out["also_composite_torch_plan_same_gpu"] = general_composite_leg(psp, dev, w, arch)
             if world == 1 and not args.no_cpu_baseline:

@@ -903,6 +903,7 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
 template <int D, int H, bool BF16 = false, bool X3 = false>
 __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
     PSP_COND_EXIT(a);
+    GradCheck<X3> gchk;                                      // backward side of the range guard (hjb_kernels.h)
     static_assert(!(BF16 && X3), "one matrix-product mode");
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, HB = G::HB, KSH = G::KSH, EXT = G::EXT;
@@ -1475,8 +1476,8 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
             for (int rr = 0; rr < 4; ++rr) {
                 const int i = 16 * rbk + 4 * qq + rr, jo = 16 * cbk + col;
                 if (rbk < DBI && cbk < HB && i < DI && jo < H) {
-                    gp[G::oW2 + i * H + jo] = osc * acc2x[s][t][rr];
-                    gp[G::oW1 + i * H + jo] = osc * acc1[s][t][rr];
+                    { const float gv_ = osc * acc2x[s][t][rr]; gp[G::oW2 + i * H + jo] = gv_; gchk.see(gv_); }
+                    { const float gv_ = osc * acc1[s][t][rr]; gp[G::oW1 + i * H + jo] = gv_; gchk.see(gv_); }
                 }
             }
         }
@@ -1488,14 +1489,14 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int i = 16 * rbk + 4 * qq + rr, jo = 16 * cbk + col;
-                if (rbk < HB && cbk < HB && i < H && jo < H) gp[G::oW2 + (DI + i) * H + jo] = osc * acc2h[s][t][rr];
+                if (rbk < HB && cbk < HB && i < H && jo < H) { const float gv_ = osc * acc2h[s][t][rr]; gp[G::oW2 + (DI + i) * H + jo] = gv_; gchk.see(gv_); }
             }
         }
 #pragma unroll
     for (int t = 0; t < NIB; ++t) {
         const float v2 = ginv * qsum(bs2[t]), v1 = ginv * qsum(bs1[t]);
         const int f = 16 * (wh + WHc * t) + col;
-        if (wd == 0 && qq == 0 && (wh + WHc * t) < HB && f < H) { gp[G::ob2 + f] = v2; gp[G::ob1 + f] = v1; }
+        if (wd == 0 && qq == 0 && (wh + WHc * t) < HB && f < H) { { const float gv_ = v2; gp[G::ob2 + f] = gv_; gchk.see(gv_); } { const float gv_ = v1; gp[G::ob1 + f] = gv_; gchk.see(gv_); } }
     }
     // dW3, x and h1 rows: lane = feature; row item i belongs to the wave with i % WHc == wh
 #pragma unroll
@@ -1504,10 +1505,10 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
         if (i % WHc == wh && qq == 0) {
             if (i < NRX) {
                 const int f = 16 * (wd + WDc * i) + col;
-                if ((wd + WDc * i) < DBI && f < DI) gp[G::oW3 + f] = v;
+                if ((wd + WDc * i) < DBI && f < DI) { const float gv_ = v; gp[G::oW3 + f] = gv_; gchk.see(gv_); }
             } else {
                 const int f = 16 * (wd + WDc * (i - NRX)) + col;
-                if ((wd + WDc * (i - NRX)) < HB && f < H) gp[G::oW3 + DI + f] = v;
+                if ((wd + WDc * (i - NRX)) < HB && f < H) { const float gv_ = v; gp[G::oW3 + DI + f] = gv_; gchk.see(gv_); }
             }
         }
     }
@@ -1516,10 +1517,11 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
         const float* red = bufs;
         for (int f = tid - 256; f < HB * 16 + 1; f += 256) {
             const float v = (red[f] + red[(HB * 16 + 1) + f]) + (red[2 * (HB * 16 + 1) + f] + red[3 * (HB * 16 + 1) + f]);
-            if (f < H) gp[G::oW3 + DI + H + f] = v;
-            else if (f == HB * 16) gp[G::ob3] = v;
+            if (f < H) { const float gv_ = v; gp[G::oW3 + DI + H + f] = gv_; gchk.see(gv_); }
+            else if (f == HB * 16) { const float gv_ = v; gp[G::ob3] = gv_; gchk.see(gv_); }
         }
     }
+    gchk.raise(a.cond);
 }
 
 struct GenInstance {

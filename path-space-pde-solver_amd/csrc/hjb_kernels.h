@@ -67,6 +67,27 @@ struct HjbArgs {
 // one scalar load per workgroup, uniform, and stands before any barrier.
 #define PSP_COND_EXIT(args) do { if ((args).cond != nullptr && ((*(args).cond != 0) != ((args).cond_want != 0))) return; } while (0)
 
+// Range guard, backward side (include/psp.h: range_flag): a split-product BACKWARD kernel can leave the f16 range where the forward
+// did not (e.g. relu^2 pre-activations r in 128 .. 255: h = r^2 < 65504 is a finite forward operand, but the adjoint (W3 G) 2 r is
+// not a finite backward one), and a non-finite gradient would reach Adam -- the parameters would be NaN for good.  Every value a
+// split-product backward kernel writes into its partial gradient passes through see(): v * 0 is NaN exactly for NaN / inf.
+// raise() at the end of the kernel sets range_flag[0] (and counts the iteration in range_flag[1]) -- BEFORE the fp32-MFMA twin of
+// the same launch, which is enqueued behind every guarded split kernel predicated on that flag, reads it: the twin then redoes
+// the pass and overwrites the partial gradients.  Costs one fma per stored value; nothing when the guard is off.
+template <bool ON>
+struct GradCheck {
+    float chk = 0.f;
+    __device__ __forceinline__ void see(float v) { if constexpr (ON) chk = fmaf(v, 0.f, chk); }
+    __device__ __forceinline__ void raise(const int* cond) {
+        if constexpr (ON) {
+            if (cond != nullptr && chk != chk) {
+                int* f = const_cast<int*>(cond);
+                if (atomicCAS(f, 0, 1) == 0) atomicAdd(f + 1, 1);
+            }
+        }
+    }
+};
+
 // ---- enums mirrored from include/psp.h (kept numeric here to avoid including C header in device code)
 enum { DRIFT_ZERO = 0, DRIFT_DENSE = 1, DRIFT_DIAG = 2, DRIFT_DWELL = 3 };
 enum { SIGMA_IDENT = 0, SIGMA_DENSE = 1, SIGMA_SCALE = 2 };

@@ -864,6 +864,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_adj_kernel(const
 template <int D, int H, int PASS = 0, bool X3 = false>
 __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
     PSP_COND_EXIT(da.h);
+    GradCheck<X3> gchk;                                      // backward side of the range guard (hjb_kernels.h)
     using W = DGeo<D, H>;
     constexpr int DB = W::DB, HB = W::HB, KP = W::KP, EXT = W::EXT;
     constexpr bool PH1 = PASS != 1;                                 // adjoint panels needed
@@ -1160,9 +1161,9 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
                         for (int rr = 0; rr < 4; ++rr) {
                             const int row = rbase + 4 * qq + rr;
                             const float v = ginv * acc[li][cl][rr];      // (X3: the power-of-two scale of the column tiles, taken back)
-                            if (c < DB) gp[W::gW3 + row * D + 16 * c + col] = v;                          // . G
-                            else if (c < DB + HB) gp[W::gW2 + row * H + 16 * (c - DB) + col] = v;          // . dz2
-                            else gp[W::gW1 + row * H + 16 * (c - DB - HB) + col] = v;                      // . dz1 (x rows only)
+                            if (c < DB) { const float gv_ = v; gp[W::gW3 + row * D + 16 * c + col] = gv_; gchk.see(gv_); }                          // . G
+                            else if (c < DB + HB) { const float gv_ = v; gp[W::gW2 + row * H + 16 * (c - DB) + col] = gv_; gchk.see(gv_); }          // . dz2
+                            else { const float gv_ = v; gp[W::gW1 + row * H + 16 * (c - DB - HB) + col] = gv_; gchk.see(gv_); }                      // . dz1 (x rows only)
                         }
                     }
                 }
@@ -1175,13 +1176,14 @@ __global__ __launch_bounds__(256) void hjbd_bwd_kernel(const DnetArgs da) {
                 float v = ginv * bs[cl];
                 v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
                 if (qq == 0) {
-                    if (c < DB) gp[W::gb3 + 16 * c + col] = v;
-                    else if (c < DB + HB) gp[W::gb2 + 16 * (c - DB) + col] = v;
-                    else gp[W::gb1 + 16 * (c - DB - HB) + col] = v;
+                    if (c < DB) { const float gv_ = v; gp[W::gb3 + 16 * c + col] = gv_; gchk.see(gv_); }
+                    else if (c < DB + HB) { const float gv_ = v; gp[W::gb2 + 16 * (c - DB) + col] = gv_; gchk.see(gv_); }
+                    else { const float gv_ = v; gp[W::gb1 + 16 * (c - DB - HB) + col] = gv_; gchk.see(gv_); }
                 }
             }
         }
     }
+    gchk.raise(da.h.cond);
 }
 
 // host-side launch table entry of this family

@@ -1612,6 +1612,7 @@ __global__ __launch_bounds__(512) void hjbw_bwd2_kernel(const HjbArgs a) {
 template <int D, int H>
 __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
     PSP_COND_EXIT(a);
+    GradCheck<true> gchk;                                      // backward side of the range guard (hjb_kernels.h)
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     constexpr int DB = W::DB, HB = W::HB, EXB = W::EXB, KS8 = W::KS8;
@@ -1888,31 +1889,32 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int o3 = 16 * ob + 4 * qq + rr, i3 = 16 * m + col;
-                if (ob < DB && o3 < D && i3 < H) gp[G::oW3 + o3 * H + i3] = ginv * acc3[o][m][rr];
+                if (ob < DB && o3 < D && i3 < H) { const float gv_ = ginv * acc3[o][m][rr]; gp[G::oW3 + o3 * H + i3] = gv_; gchk.see(gv_); }
                 const int o1 = 16 * m + 4 * qq + rr, i1 = 16 * ob + col;
-                if (ob < DB && o1 < H && i1 < D) gp[G::oW1 + o1 * (D + 1) + 1 + i1] = ginv * acc1[o][m][rr];
+                if (ob < DB && o1 < H && i1 < D) { const float gv_ = ginv * acc1[o][m][rr]; gp[G::oW1 + o1 * (D + 1) + 1 + i1] = gv_; gchk.see(gv_); }
             }
         const float v = ginv * qsum(bs3[o]);
         const int f = 16 * ob + col;
-        if (qq == 0 && ob < DB && f < D) gp[G::ob3 + f] = v;
+        if (qq == 0 && ob < DB && f < D) { const float gv_ = v; gp[G::ob3 + f] = gv_; gchk.see(gv_); }
     }
 #pragma unroll
     for (int m = 0; m < HB; ++m)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int o2 = 16 * m + 4 * qq + rr, i2 = 16 * ib + col;
-            if (o2 < H && i2 < H) gp[G::oW2 + o2 * H + i2] = ginv * acc2[m][rr];
+            if (o2 < H && i2 < H) { const float gv_ = ginv * acc2[m][rr]; gp[G::oW2 + o2 * H + i2] = gv_; gchk.see(gv_); }
         }
     {
         const float v1 = ginv * qsum(hsum4(bs1)), vt = ginv * qsum(hsum4(bt1));
         const int f = 16 * ib + col;
-        if (qq == 0 && f < H) { gp[G::ob1 + f] = v1; gp[G::oW1 + f * (D + 1)] = vt; }
+        if (qq == 0 && f < H) { { const float gv_ = v1; gp[G::ob1 + f] = gv_; gchk.see(gv_); } { const float gv_ = vt; gp[G::oW1 + f * (D + 1)] = gv_; gchk.see(gv_); } }
     }
     {
         const float v2 = ginv * qsum(bs2);
         const int f = 16 * ib + col;
-        if (qq == 0 && f < H) gp[G::ob2 + f] = v2;
+        if (qq == 0 && f < H) { const float gv_ = v2; gp[G::ob2 + f] = gv_; gchk.see(gv_); }
     }
+    gchk.raise(a.cond);
 }
 
 template <int D, int H>

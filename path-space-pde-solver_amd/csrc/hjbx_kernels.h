@@ -127,6 +127,7 @@ __device__ __forceinline__ void gemm_Txp(f32x4 (&acc)[MB], const float* wlds, co
 template <int D, int H, bool REGEN = false>
 __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
     PSP_COND_EXIT(a);
+    GradCheck<true> gchk;                                      // backward side of the range guard (hjb_kernels.h)
     using G = Geo<D, H>;
     using X = GeoX<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH, NX = X::NX, RS = X::RS, PAIRH = X::PAIRH, NT = X::NT;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int o3 = 16 * b + 4 * qq + rr, i3 = 16 * sub + col;
-                if (o3 < D && i3 < H) gp[G::oW3 + o3 * H + i3] = v[rr];
+                if (o3 < D && i3 < H) { const float gv_ = v[rr]; gp[G::oW3 + o3 * H + i3] = gv_; gchk.see(gv_); }
             }
         }
 #pragma unroll
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int o2 = 16 * m + 4 * qq + rr, i2 = 16 * sub + col;
-                if (o2 < H && i2 < H) gp[G::oW2 + o2 * H + i2] = v[rr];
+                if (o2 < H && i2 < H) { const float gv_ = v[rr]; gp[G::oW2 + o2 * H + i2] = gv_; gchk.see(gv_); }
             }
         }
     }
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int o1 = 16 * m + 4 * qq + rr, i1 = 16 * ob + col;
-                if (ob < DB && o1 < H && i1 < D) gp[G::oW1 + o1 * (D + 1) + 1 + i1] = v[rr];
+                if (ob < DB && o1 < H && i1 < D) { const float gv_ = v[rr]; gp[G::oW1 + o1 * (D + 1) + 1 + i1] = gv_; gchk.see(gv_); }
             }
         }
     // bias gradients and the time column of dW1: fixed-order sum of the four producers' partial sums (LDS)
@@ -607,16 +608,17 @@ __global__ __launch_bounds__(512) void hjb_bwd3_kernel(const HjbArgs a) {
         const float* red = lds + X::EX;
         const int ct = tid - 256;
         for (int f = ct; f < D; f += 256)
-            gp[G::ob3 + f] = (red[f] + red[RS + f]) + (red[2 * RS + f] + red[3 * RS + f]);
+            { const float gv_ = (red[f] + red[RS + f]) + (red[2 * RS + f] + red[3 * RS + f]); gp[G::ob3 + f] = gv_; gchk.see(gv_); }
         for (int f = ct; f < H; f += 256) {
             const float* r2 = red + 16 * DB + f;
-            gp[G::ob2 + f] = (r2[0] + r2[RS]) + (r2[2 * RS] + r2[3 * RS]);
+            { const float gv_ = (r2[0] + r2[RS]) + (r2[2 * RS] + r2[3 * RS]); gp[G::ob2 + f] = gv_; gchk.see(gv_); }
             const float* r1 = r2 + 16 * HB;
-            gp[G::ob1 + f] = (r1[0] + r1[RS]) + (r1[2 * RS] + r1[3 * RS]);
+            { const float gv_ = (r1[0] + r1[RS]) + (r1[2 * RS] + r1[3 * RS]); gp[G::ob1 + f] = gv_; gchk.see(gv_); }
             const float* rt = r1 + 16 * HB;
-            gp[G::oW1 + f * (D + 1)] = (rt[0] + rt[RS]) + (rt[2 * RS] + rt[3 * RS]);
+            { const float gv_ = (rt[0] + rt[RS]) + (rt[2 * RS] + rt[3 * RS]); gp[G::oW1 + f * (D + 1)] = gv_; gchk.see(gv_); }
         }
     }
+    gchk.raise(a.cond);
 }
 
 template <int D, int H>

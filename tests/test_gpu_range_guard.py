@@ -232,3 +232,68 @@ def test_bwd3_gradient_scale_comes_from_all_weights(kind):
     assert float(rel.max()) <= 1e-4, (int(rel.argmax()), float(rel.max()))
     g_ref = _oracle_weighted_gradient(case, K, model, w).to(dev())
     assert float((g3 - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
+
+
+# ---- backward side of the guard (round 4): the forward stays finite, the split-product BACKWARD does not ------------
+def test_backward_overflow_with_a_finite_forward_is_caught():
+    """relu^2 pre-activations around 200: h = r^2 = 4e4 is a finite f16 forward operand, so the forward raises no flag -- but the
+    adjoint dz2 = (W3 G) 2 r of hjbd_bwd_kernel<.., X3> (G scaled to a top magnitude in [64, 128), |W3| ~ 1) leaves the f16
+    range.  Every split-product backward kernel checks what it writes into its partial gradient and raises the same flag; the
+    fp32-MFMA twin behind it redoes the pass BEFORE the optimiser step: finite gradient (that of the fp32 kernels on the same
+    path store), finite parameters, one fallback counted.  Unguarded, the same run leaves NaN parameters behind."""
+    rec = load_golden("llgc_d12_outer_moment")
+
+    def run(mlp, **kw):
+        # one time step (dt = T): the state stays at X_0 = 0 inside the net, only the biases set the pre-activations
+        model = make_pkg_solver(rec["case"], dev(), backend="native", mlp_dtype=mlp, L=1, delta_t=0.2, **kw)
+        assert model.N == 1
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for net in model.z_n:
+                W1, b1, W2, b2, W3, b3 = list(net.W)
+                b2.fill_(200.0)
+                W3.copy_(torch.randn(W3.shape, generator=g).to(W3.device))
+        model.train()
+        assert model.plan_name == "native"
+        return model
+
+    ref, got = run("fp32"), run("f16x3")
+    g_ref, g = ref._native_plan.grad, got._native_plan.grad
+    assert math.isfinite(ref.loss_log[0]) and bool(torch.isfinite(g_ref).all())
+    assert got._native_plan.matrix_mode == "f16x3"
+    assert math.isfinite(got.loss_log[0]) and math.isclose(got.loss_log[0], ref.loss_log[0], rel_tol=1e-4)
+    assert bool(torch.isfinite(g).all()), "non-finite gradient reached the optimiser"
+    assert got.range_fallback_iterations == 1
+    assert float((g - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
+    for net in got.z_n:
+        assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+    raw = run("f16x3", range_guard=False)                          # the test means something: unguarded, the backward overflows
+    assert math.isfinite(raw.loss_log[0]) and not bool(torch.isfinite(raw._native_plan.grad).all())
+
+
+def test_backward_overflow_general_solver():
+    """The same window for gen_bwd2_kernel<.., X3>: second-layer bias at 200, an O(1) output layer; one rollout step."""
+    rec = load_golden("heat_d6_diffusion")
+    case = rec["case"]
+
+    def run(mlp, **kw):
+        prob = getattr(psp, case["problem"]["kind"])(device=dev(), **case["problem"]["kwargs"])
+        s = dict(case["solver"])
+        s.update(L=1, N=1, mlp_dtype=mlp, **kw)
+        model = psp.GeneralSolver(problem=prob, name=case["name"], verbose=False, device=dev(), backend="native", **s)
+        g = torch.Generator().manual_seed(6)
+        with torch.no_grad():
+            W1, b1, W2, b2, W3, b3 = list(model.V.W)
+            b2.fill_(200.0)
+            W3.copy_(torch.randn(W3.shape, generator=g).to(W3.device))
+        model.train()
+        assert model.plan_name == "native"
+        return model
+
+    ref, got = run("fp32"), run("f16x3")
+    g_ref, g = ref._gen_plan.grad, got._gen_plan.grad
+    assert math.isfinite(ref.loss_log[0]) and bool(torch.isfinite(g_ref).all())
+    assert got._gen_plan.matrix_mode == "f16x3" and math.isfinite(got.loss_log[0])
+    assert bool(torch.isfinite(g).all()), "non-finite gradient reached the optimiser"
+    assert float((g - g_ref).abs().max()) <= 5e-4 * float(g_ref.abs().max())
+    assert all(bool(torch.isfinite(p).all()) for p in got.V.parameters())
