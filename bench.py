@@ -818,13 +818,16 @@ def main():
                                         "fallback iterations in this run: %d" % plan.range_fallbacks())
     if world == 1 and not args.no_sustained and not graph:
         # >= 3 s of back-to-back iterations (the timed region above is steps x ms_per_step, i.e. under 0.1 s by default)
+        # (a continuation of the SAME training run: the iteration index keeps counting -- it is the Philox `iter` counter -- and the
+        #  losses go to a log of their own; nothing of the timed region is replayed or overwritten)
         n_s, t_s = 0, 0.0
         plan.events = None
+        scratch = torch.zeros(1 << 20, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        while t_s < args.sustain_s:
+        while t_s < args.sustain_s and total + n_s + 50 <= scratch.numel():
             for l in range(total + n_s, total + n_s + 50):
-                plan.iteration(l % losses.numel(), losses)
+                plan.iteration(l, scratch)
             n_s += 50
             torch.cuda.synchronize()
             t_s = time.perf_counter() - t0

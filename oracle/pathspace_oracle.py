@@ -394,6 +394,7 @@ class HJBConfig:
     random_X_0: bool = False
     IS_variance_K: int = 0
     IS_variance_iter: int = 1
+    approx_method: str = "control"       # or 'value_function' (solver.py:93-97, 334-339, 438-440; time_approx='inner')
 
 
 def hjb_build(problem: OracleProblem, cfg: HJBConfig, net: Optional[torch.nn.Module] = None):
@@ -401,7 +402,10 @@ def hjb_build(problem: OracleProblem, cfg: HJBConfig, net: Optional[torch.nn.Mod
     torch.manual_seed(cfg.seed)                                      # :84
     y0 = ScalarY0(lr=cfg.lr)                                         # :86 (re-seeds with 42)
     N = int(np.floor(problem.T / cfg.delta_t))                       # :41 (float64)
-    if cfg.time_approx == "inner":
+    if cfg.approx_method == "value_function":
+        assert cfg.time_approx == "inner"
+        z = DenseNetOracle(problem.d + 1, 1, cfg.lr, seed=cfg.seed)  # :97 (y_n = [DenseNet(d + 1 -> 1)]; no y_0 in this ansatz)
+    elif cfg.time_approx == "inner":
         z = TanhMLP(problem.d + 1, problem.d, cfg.lr, seed=123)      # :91
     else:
         z = [DenseNetOracle(problem.d, problem.d, cfg.lr, seed=cfg.seed) for _ in range(N)]   # :88
@@ -416,6 +420,20 @@ def control_eval(z, X, n, dt32, N, time_approx="inner"):
         return z[max(0, min(n, N - 1))](X)                           # :352-353
     t_X = torch.cat([torch.ones([X.shape[0], 1]) * n * dt32, X], 1)  # :355
     return z(t_X)                                                    # :356
+
+
+def value_eval(y_n, X, t):
+    """solver.py:334-339 (Y_n, 'inner'): the time feature is the ARGUMENT t as passed -- the training loop passes the step
+    index n, not n * delta_t (:439, :328)."""
+    t_X = torch.cat([torch.ones([X.shape[0], 1]) * t, X], 1)          # :338
+    return y_n(t_X)                                                  # :339
+
+
+def value_gradient(y_n, X, n, problem):
+    """solver.py:326-332 (compute_grad_Y): Z = sigma(X) grad_x Y_n(X, n), differentiable (create_graph)."""
+    Y_eval = value_eval(y_n, X, n).squeeze(1).sum()                  # :327
+    Zg, = torch.autograd.grad(Y_eval, X, create_graph=True)          # :329 (the .backward of :328 only fills .grad, cleared at :194)
+    return torch.mm(problem.sigma(X), Zg.t()).t()                    # :330
 
 
 def hjb_loss(kind, D, Y, gX, Z_sum=None, adaptive=True):
@@ -460,14 +478,21 @@ def hjb_train(problem: OracleProblem, cfg: HJBConfig, net=None, noise: Optional[
         if cfg.learn_Y_0:
             Y = y0(X)                                                # :373 (shape (1,), broadcasts)
             out["Y_0_log"].append(Y[0].item())                       # :374
+        vf = cfg.approx_method == "value_function"
+        if vf:
+            X = X.clone().requires_grad_(True)                       # :370
+            Y = value_eval(z, X, 0)[:, 0]                            # :371
         xi = torch.randn(K, d, N + 1) if noise is None else noise[l]     # :381
-        tr = dict(X=[X.clone()], Y=[]) if trace else None
+        tr = dict(X=[X.detach().clone()], Y=[]) if trace else None
         Z_sum = torch.zeros(K)                                       # :376
+        additional_loss = torch.zeros(K)                             # :434
         for n in range(N):
-            Z = control_eval(z, X, n, dt32, N, cfg.time_approx)      # :449
+            if vf and n > 0:
+                additional_loss = additional_loss + (value_eval(z, X, n)[:, 0] - Y).pow(2)    # :438-440
+            Z = value_gradient(z, X, n, problem) if vf else control_eval(z, X, n, dt32, N, cfg.time_approx)      # :449
             c = torch.zeros(d, K)                                    # :451
             if cfg.adaptive_forward_process:
-                c = -control_eval(z, X, n, dt32, N, cfg.time_approx).t()     # :456 (2nd forward)
+                c = -(value_gradient(z, X, n, problem) if vf else control_eval(z, X, n, dt32, N, cfg.time_approx)).t()     # :456 (2nd forward)
             if cfg.detach_forward:
                 c = c.detach()                                       # :468-469
             sig = problem.sigma(X)
@@ -484,7 +509,7 @@ def hjb_train(problem: OracleProblem, cfg: HJBConfig, net=None, noise: Optional[
             p_.optim.zero_grad()                                     # :194-196
         gX = problem.g(X)
         D = Y - gX
-        loss = hjb_loss(cfg.loss_method, D, Y, gX, Z_sum=Z_sum, adaptive=cfg.adaptive_forward_process) + torch.zeros(K).mean()   # :220, :434, :499
+        loss = hjb_loss(cfg.loss_method, D, Y, gX, Z_sum=Z_sum, adaptive=cfg.adaptive_forward_process) + additional_loss.mean()   # :220, :434, :499
         loss.backward()                                              # :221
         if trace:
             tr["D"] = D.detach().clone()

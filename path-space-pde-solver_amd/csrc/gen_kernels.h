@@ -297,6 +297,23 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
             f32x4 gz2[HB], gz1[HB], gx[DBI];
 #pragma unroll
             for (int m = 0; m < HB; ++m) gz2[m] = vw3h2[m * 4] * (2.0f * r2[m]);
+            // the d2 = 2 relu(z2) image leaves for the path store HERE: nothing below reads r2 again, and holding its 4 HB registers
+            // across the reverse sweep, the Euler step and the tangent products is what pushed this kernel over its 256 registers
+            // (26 spilled dwords inside the time loop of the split-product instance, reloaded behind the path stores)
+            if (a.store_path) {
+                if (p16) {
+                    gwptr_t p2 = pbase16(n, G::qD2);
+#pragma unroll
+                    for (int m = 0; m < HB; ++m)
+#pragma unroll
+                        for (int rp = 0; rp < 2; ++rp)
+                            p2[(unsigned)(2 * m + rp) * 64 + ul] = pk_bf16(2.0f * r2[m][rp], 2.0f * r2[m][rp + 2]);
+                } else {
+                    gwptr_t p2 = pbase(n, G::pD2);
+#pragma unroll
+                    for (int ks = 0; ks < 4 * HB; ++ks) p2[ks * 64 + ul] = 2.0f * r2[ks >> 2][ks & 3];
+                }
+            }
 #pragma unroll
             for (int m = 0; m < HB; ++m) gz1[m] = vw3h1[m * 4];
             gen_gemm<MODE, HB, KSH, HB>(gz1, lds + oW2hr, gz2, lane);     // g_h1 = w3h1 + W2h g_z2
@@ -455,29 +472,37 @@ __global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
                 f32x4 h1d[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) h1d[m] = (2.0f * r1[m]) * z1h[m];
-                gen_gemm<MODE, HB, KSI, DBI>(z2h, lds + oW2xf, U, lane);
-                gen_gemm<MODE, HB, KSH, HB>(z2h, lds + oW2hf, h1d, lane);
+                // d1 = 2 relu(z1) and z1^ leave as soon as h1' is formed: r1 and z1^ are dead during the two z2^ products
                 if (p16) {
-                    gwptr_t p1 = pbase16(n, G::qD1), p2 = pbase16(n, G::qD2), p3 = pbase16(n, G::qZ1), p4 = pbase16(n, G::qZ2);
+                    gwptr_t p1 = pbase16(n, G::qD1), p3 = pbase16(n, G::qZ1);
 #pragma unroll
                     for (int m = 0; m < HB; ++m)
 #pragma unroll
                         for (int rp = 0; rp < 2; ++rp) {
                             const unsigned o = (unsigned)(2 * m + rp) * 64 + ul;
                             p1[o] = pk_bf16(2.0f * r1[m][rp], 2.0f * r1[m][rp + 2]);
-                            p2[o] = pk_bf16(2.0f * r2[m][rp], 2.0f * r2[m][rp + 2]);
                             p3[o] = pk_bf16(z1h[m][rp], z1h[m][rp + 2]);
-                            p4[o] = pk_bf16(z2h[m][rp], z2h[m][rp + 2]);
                         }
                 } else {
-                    gwptr_t p1 = pbase(n, G::pD1), p2 = pbase(n, G::pD2), p3 = pbase(n, G::pZ1), p4 = pbase(n, G::pZ2);
+                    gwptr_t p1 = pbase(n, G::pD1), p3 = pbase(n, G::pZ1);
 #pragma unroll
                     for (int ks = 0; ks < 4 * HB; ++ks) {
                         p1[ks * 64 + ul] = 2.0f * r1[ks >> 2][ks & 3];
-                        p2[ks * 64 + ul] = 2.0f * r2[ks >> 2][ks & 3];
                         p3[ks * 64 + ul] = z1h[ks >> 2][ks & 3];
-                        p4[ks * 64 + ul] = z2h[ks >> 2][ks & 3];
                     }
+                }
+                gen_gemm<MODE, HB, KSI, DBI>(z2h, lds + oW2xf, U, lane);
+                gen_gemm<MODE, HB, KSH, HB>(z2h, lds + oW2hf, h1d, lane);
+                if (p16) {
+                    gwptr_t p4 = pbase16(n, G::qZ2);
+#pragma unroll
+                    for (int m = 0; m < HB; ++m)
+#pragma unroll
+                        for (int rp = 0; rp < 2; ++rp) p4[(unsigned)(2 * m + rp) * 64 + ul] = pk_bf16(z2h[m][rp], z2h[m][rp + 2]);
+                } else {
+                    gwptr_t p4 = pbase(n, G::pZ2);
+#pragma unroll
+                    for (int ks = 0; ks < 4 * HB; ++ks) p4[ks * 64 + ul] = z2h[ks >> 2][ks & 3];
                 }
                 // coefficient of grad_theta V at this sample: -h_y dt act, plus 1 for V(X_0,t_0) at n = 0
                 if (q == 0) a.ahat[(size_t)n * (a.ntile16 * 16) + k] = (n == 0 ? 1.f : 0.f) - hy * dt * actf;

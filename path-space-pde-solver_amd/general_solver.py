@@ -39,30 +39,36 @@ def _default_device():
     return torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
 
-def sample_boundary(pb, Kb, d, dev):
-    """Uniform points on the boundary, drawn in the reference's order (solver.py:1020-1038 == :650-668); the square
-    variant shuffles with numpy's global generator like the reference."""
+def sample_boundary_host(pb, Kb, d):
+    """Uniform points on the boundary, drawn AND formed on the host in the reference's order (solver.py:1020-1038 == :650-668);
+    the square variants shuffle with numpy's global generator like the reference.  Host arithmetic on purpose: the batch is
+    then the reference's CPU batch bit for bit on every device -- the 'two_spheres' data g = [|x| > a] is evaluated exactly ON
+    the inner sphere, where the last bit of the normalisation decides (GeneralSolver._g_on_boundary)."""
     if pb.boundary == 'sphere':
-        Xb = torch.randn(Kb, d).to(dev)
+        Xb = torch.randn(Kb, d)
         return pb.boundary_distance * Xb / torch.sqrt(torch.sum(Xb ** 2, 1)).unsqueeze(1)
     half = int(Kb / 2)
     if pb.boundary == 'two_spheres':                              # solver.py:1023-1027 == :653-657: inner half, outer half
-        Xb = torch.randn(Kb, d).to(dev)
-        radii = torch.tensor([pb.boundary_distance_1] * half + [pb.boundary_distance_2] * half).unsqueeze(1).to(dev)
+        Xb = torch.randn(Kb, d)
+        radii = torch.tensor([pb.boundary_distance_1] * half + [pb.boundary_distance_2] * half).unsqueeze(1)
         return radii * Xb / torch.sqrt(torch.sum(Xb ** 2, 1)).unsqueeze(1)
     pick = np.concatenate([np.ones(half)[:, np.newaxis], np.zeros([half, d - 1])], 1)
     np.apply_along_axis(np.random.shuffle, 1, pick)
     lower = torch.tensor(np.concatenate([pick, np.zeros([half, d])]).astype(float)).bool()
     upper = torch.tensor(np.concatenate([np.zeros([half, d]), pick]).astype(float)).bool()
     if pb.boundary == 'square-corner':                            # solver.py:666-673: one coordinate on the corner planes
-        Xb = (pb.X_r - pb.X_corner) * torch.rand(Kb, d).to(dev) + pb.X_corner
+        Xb = (pb.X_r - pb.X_corner) * torch.rand(Kb, d) + pb.X_corner
         Xb[lower] = pb.X_corner
         Xb[upper] = pb.X_corner
         return Xb
-    Xb = (pb.X_r - pb.X_l) * torch.rand(Kb, d).to(dev) + pb.X_l
+    Xb = (pb.X_r - pb.X_l) * torch.rand(Kb, d) + pb.X_l
     Xb[lower] = pb.X_r if pb.one_boundary else pb.X_l
     Xb[upper] = pb.X_r
     return Xb
+
+
+def sample_boundary(pb, Kb, d, dev):
+    return sample_boundary_host(pb, Kb, d).to(dev)
 
 
 def exit_test(pb, X, X_prop, elliptic):
@@ -202,13 +208,31 @@ class GeneralSolver:
             X[corner, :] = -X[corner, :]
         return X
 
+    def _sample_boundary(self):
+        """The boundary batch on ``self.device``; the host copy stays for _g_on_boundary."""
+        self._Xb_host = sample_boundary_host(self.problem, self.K_boundary, self.d)
+        return self._Xb_host.to(self.device)
+
+    def _g_on_boundary(self, X_b, *t):
+        """problem.g on the boundary batch.  On 'two_spheres' the data is discontinuous exactly on the sampled inner sphere
+        (Committor.g = [|x| > a] at |x| = a up to rounding, problems.py:1569-1570): its value there hangs on the last bit of a
+        norm, i.e. on the device's summation order.  Evaluated on the host copy of the batch it is the reference's CPU value
+        on every device (the loss moves by 1 / K_boundary per flipped point otherwise).  Other domains: on the device."""
+        host = getattr(self, '_Xb_host', None)
+        if self.problem.boundary == 'two_spheres' and host is not None and host.shape == X_b.shape:
+            try:
+                return self.problem.g(host, *[ti.cpu() for ti in t]).to(X_b.device)
+            except Exception:                                     # a user g tied to device tensors: evaluate it where they live
+                pass
+        return self.problem.g(X_b, *t)
+
     def boundary_residual(self, X_in_b, X_b, t_b):
         """Dirichlet / Neumann residual on the boundary batch (solver.py:1066-1074)."""
         pb = self.problem
         if pb.boundary_type == 'Dirichlet':
-            return torch.mean((self.V(X_in_b).squeeze() - pb.g(X_b, t_b.squeeze())) ** 2)
+            return torch.mean((self.V(X_in_b).squeeze() - self._g_on_boundary(X_b, t_b.squeeze())) ** 2)
         if pb.boundary_type == 'Neumann':
-            return neumann_residual(self.V, X_in_b, pb.g(X_b, t_b.squeeze()), self.d)
+            return neumann_residual(self.V, X_in_b, self._g_on_boundary(X_b, t_b.squeeze()), self.d)
         raise NotImplementedError('boundary_type %r' % pb.boundary_type)
 
     def train(self):
@@ -288,7 +312,7 @@ class GeneralSolver:
                 X_center = torch.zeros(1, 1).to(dev)
                 loss = loss + torch.mean((self.V(X_center).squeeze() - pb.v_true(X_center).squeeze()) ** 2)
             if bounded:
-                X_b = sample_boundary(pb, self.K_boundary, d, dev)
+                X_b = self._sample_boundary()
             X = self.sample_domain()
             K = self.K                                            # 'two_spheres': the rejection step sets it every iteration
             if bounded:
@@ -410,9 +434,9 @@ class EllipticSolver(GeneralSolver):
     def boundary_residual(self, X_b):
         """Dirichlet / Neumann residual on the boundary batch (solver.py:683-693); the type is the SOLVER's argument."""
         if self.boundary_type == 'Dirichlet':
-            return torch.mean((self.V(X_b).squeeze() - self.problem.g(X_b)) ** 2)
+            return torch.mean((self.V(X_b).squeeze() - self._g_on_boundary(X_b)) ** 2)
         if self.boundary_type == 'Neumann':
-            return neumann_residual(self.V, X_b, self.problem.g(X_b), self.d)
+            return neumann_residual(self.V, X_b, self._g_on_boundary(X_b), self.d)
         raise NotImplementedError('boundary_type %r' % self.boundary_type)
 
     def train(self):
@@ -433,7 +457,7 @@ class EllipticSolver(GeneralSolver):
             if self.sample_center:                               # solver.py:643-645
                 X_center = torch.zeros(1, 1).to(dev)
                 loss = loss + torch.mean((self.V(X_center).squeeze() - pb.v_true(X_center).squeeze()) ** 2)
-            X_b = sample_boundary(pb, self.K_boundary, d, dev)
+            X_b = self._sample_boundary()
             if self.loss_method != 'BSDE' and self.boundary_loss:
                 loss = loss + self.alpha[1] * self.boundary_residual(X_b)
             X = self.sample_domain().clone().requires_grad_(True)

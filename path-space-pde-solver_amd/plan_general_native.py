@@ -351,7 +351,7 @@ class GeneralNativePlan:
         for p in self.params:
             p.grad = None
         # ---- host RNG in the reference's order (solver.py:1020-1060, :1078, :1106; EllipticSolver :650-739)
-        X_b = gs.sample_boundary(pb, s.K_boundary, d, dev) if bounded else None
+        X_b = s._sample_boundary() if bounded else None
         if ell:
             loss_T = self._boundary_terms(None, X_b, None)      # no RNG inside: order as in the reference
         X = s.sample_domain() if reference_noise else self._sample_domain_device(l)

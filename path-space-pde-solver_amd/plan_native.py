@@ -213,6 +213,7 @@ class HjbNativePlan:
         self.cfg = cfg
         assert sizes.n_params == pad.Pp, (sizes.n_params, pad.Pp)
         self._setup_chunks(solver, cfg, sizes)
+        solver.path_plan = dict(n_chunks=self.n_chunks, chunk_mode=self.chunk_mode, chunk_K=self.chunk_K)   # what the budget chose
         sizes = self.sizes
         # kernel-side (padded) parameter and gradient vectors; identical to the real ones when nothing is padded
         self.flat_k = self.flat if pad.identity else pad.new_padded_params()
@@ -302,11 +303,13 @@ class HjbNativePlan:
     DEFAULT_PATH_BUDGET = 96 * 2 ** 30          # a third of the 288 GB of HBM3E when the device cannot be asked
 
     def _default_budget(self):
-        """A third of THIS device's memory, and never more than 80 % of what is free right now (other tensors, other ranks on
-        the same card): the plan chunks instead of failing in torch.empty(path_bytes)."""
+        """A third of THIS device's TOTAL memory -- a function of the device alone, so the same seed and configuration give the
+        same chunk count (hence the same summation order of the partial sums and gradients) from run to run and on every rank of
+        a job, whatever else occupies the card at the moment.  (Round 3 also capped it at 80 % of the memory free right now;
+        a store that then does not fit fails in its allocation and says so -- Solver(path_budget_bytes=...) / path_chunks pick
+        another split.)  The chosen n_chunks / chunk_mode are recorded on the solver (solver.path_plan) and in bench.py's line."""
         try:
-            free, total = torch.cuda.mem_get_info(self.dev)
-            return max(1 << 28, min(int(total) // 3, int(free) * 4 // 5))
+            return max(1 << 28, int(torch.cuda.get_device_properties(self.dev).total_memory) // 3)
         except Exception:                                # size queries on a machine without a GPU
             return self.DEFAULT_PATH_BUDGET
 

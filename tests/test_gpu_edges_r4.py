@@ -1,0 +1,197 @@
+"""Edges the round-3 review found untested ("What's weak" 1-2):
+  (a) the SMALL-magnitude side of the split-product (f16x3) mode: a sweep over the initial state, the step size and the weight
+      scale across ten orders of magnitude, both matrix modes against the CPU oracle at the usual bounds;
+  (b) BASELINE configs[4] at its per-GPU share (d = 500, N = 200, K = 131072): the K-chunked plan -- determinism, shard
+      independence through k_offset, chunked D = resident D on a K = 16384 slice;
+  (c) BASELINE configs[2] as written (bf16 MFMA value net) at K = 65536: determinism and its own 2 % tolerance against the fp32
+      kernels on the same Philox stream;
+  (d) the BSDE loss on the exact (100, 64) instance against the reference's golden run.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from util_cases import flat_params, make_oracle, make_pkg_solver, orc, psp
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+# ---- (a) scale sweep ------------------------------------------------------------------------------------------------------------
+def _sweep_case(kind, d, H, dt, N=4, K=48, loss="log-variance"):
+    if kind == "LLGC":
+        prob = dict(kind="LLGC", kwargs=dict(d=d, off_diag=0.01, T=N * dt, seed=42))
+    else:
+        prob = dict(kind="DoubleWell_multidim", kwargs=dict(d=d, d_1=d // 2, d_2=d - d // 2, T=N * dt, eta=0.05, kappa=0.5))
+    solver = dict(loss_method=loss, time_approx="inner", adaptive_forward_process=True, detach_forward=True,
+                  early_stopping_time=None, L=1, lr=0.001, seed=42, delta_t=dt, K=K, u_l2_error_flag=False)
+    return dict(name="sweep", family="solver", problem=prob, solver=solver, net=dict(kind="tanh_mlp", widths=[H, H], seed=123))
+
+
+SWEEP = [(x0, dt, ws) for x0 in (1e-6, 1e-3, 1.0, 1e3) for dt in (1e-6, 1e-2, 0.05) for ws in (1e-4, 1.0)]
+
+
+@pytest.mark.parametrize("loss", ["moment", "log-variance"])      # moment: weights (2/K) D_k, no mean subtraction -- the strict bar
+@pytest.mark.parametrize("kind", ["LLGC", "DoubleWell_multidim"])
+@pytest.mark.parametrize("mode", ["fp32", "f16x3"])
+def test_scale_sweep_matches_oracle(kind, mode, loss):
+    """X_0 in {1e-6 .. 1e3} x 1, dt in {1e-6, 1e-2, 0.05}, network weights x {1e-4, 1}: D_k, loss and gradient of the first
+    iteration against the oracle.  An f16x3 operand below 6.1e-5 is an f16 subnormal in its hi part; the residual keeps the
+    product error at 2^-22 of the operand magnitudes, i.e. ABSOLUTELY small where the operands are small -- which is the bar
+    the fp32 kernels are held to as well (D: 2e-5 max(1, |D|), gradient: 2e-4 max|g|)."""
+    worst = (0.0, 0.0, None)
+    for x0, dt, ws in SWEEP:
+        if kind == "DoubleWell_multidim" and x0 >= 1e3:
+            continue                                         # explicit Euler on x^3 from |x| = 1000 overflows in the reference too
+        case = _sweep_case(kind, 100, 64, dt, loss=loss)
+        model = make_pkg_solver(case, dev(), backend="native", L=1, mlp_dtype=mode)
+        oprob, ocfg, omodels = make_oracle(case, L=1)
+        with torch.no_grad():
+            for p, q in zip(model.z_n.parameters(), omodels[0].parameters()):
+                p.mul_(ws)
+                q.mul_(ws)
+        model.X_0 = torch.full((100,), x0, device=dev())
+        oprob.X_0 = torch.full((100,), x0)
+        assert torch.equal(flat_params(model.z_n), flat_params(omodels[0]))
+        model.train()
+        assert model.plan_name == "native" and model._native_plan.matrix_mode == mode
+        if mode == "f16x3":
+            assert model.range_fallback_iterations == 0, (x0, dt, ws)      # in range: the split kernels did the work
+        ref = orc.hjb_train(oprob, ocfg, step_models=omodels, trace=True)
+        tr = ref["traces"][0]
+        D, D_ref = model._native_plan.D.cpu(), tr["D"]
+        assert bool(torch.isfinite(D).all()) and bool(torch.isfinite(D_ref).all()), (x0, dt, ws)
+        eD = float((D - D_ref).abs().max()) / max(1.0, float(D_ref.abs().max()))
+        g, g_ref = model._native_plan.grad.cpu(), torch.cat([x.reshape(-1) for x in tr["grads"]])
+        eg = float((g - g_ref).abs().max()) / max(float(g_ref.abs().max()), 1e-30)
+        if max(eD / 2e-5, eg / 2e-4) > max(worst[0] / 2e-5, worst[1] / 2e-4):
+            worst = (eD, eg, (x0, dt, ws))
+        assert eD <= 2e-5, (kind, mode, x0, dt, ws, eD)
+        # log-variance weights are (2/K)(D_k - mean D): where the spread of D is small against |D| (a tiny step size next to an
+        # O(1) terminal value) the permitted error of D is amplified by |D| / std(D) in every weight -- in ANY fp32 implementation
+        eD_abs = float((D - D_ref).abs().max())
+        tol_g = 2e-4 + (2.0 * math.sqrt(D.numel()) * eD_abs / max(float(D_ref.std()), 1e-30) if loss == "log-variance" else 0.0)
+        assert eg <= tol_g, (kind, mode, x0, dt, ws, eg, tol_g, float(g_ref.abs().max()))
+        lref = ref["loss_log"][0]
+        cond = float((D_ref.double() ** 2).mean()) / max(abs(lref), 1e-30)
+        assert math.isclose(model.loss_log[0], lref, rel_tol=min(1e-3, max(2e-5, 4 * 6e-8 * cond)), abs_tol=1e-9), (x0, dt, ws)
+    print("%s %s %s: worst D err %.1e, worst gradient err %.1e at (X0, dt, weight scale) = %s" % (kind, mode, loss, worst[0], worst[1], worst[2]))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "f16x3"])
+def test_scale_sweep_general_solver(mode):
+    """The same for the value-net kernels on the (100, 64) instance: initial points scaled to a ball of radius 1e-3 .. 1e2,
+    dt in {1e-6, 1e-3}, value net x {1e-3, 1}."""
+    from test_general_composite_golden import build as build_pkg
+    from test_gpu_bounded_elliptic import oracle_run
+    case0 = load_golden("dwgen_d100_h64_diffusion")["case"]
+    for dt in (1e-6, 1e-3):
+        for ws in (1e-3, 1.0):
+            case = dict(case0, solver=dict(case0["solver"], delta_t=dt, L=1))
+            case["problem"] = dict(case0["problem"], kwargs=dict(case0["problem"]["kwargs"], T=5 * dt))
+            prob, model = build_pkg(case, device=dev(), backend="native", L=1, mlp_dtype=mode)
+            with torch.no_grad():
+                for p in model.V.parameters():
+                    p.mul_(ws)
+            model.train()
+            assert model.plan_name == "native"
+            from util_cases import general_oracle_run          # the oracle's net gets the same scaling through a hook: rebuild
+            import numpy as np
+            kw = dict(case["problem"]["kwargs"])
+            oprob = orc.make_problem(case["problem"]["kind"], **kw)
+            s = case["solver"]
+            cfg = orc.GeneralConfig(K=s["K"], N=s["N"], delta_t=s["delta_t"], lr=s["lr"], L=1, seed=s["seed"],
+                                    K_boundary=s["K_boundary"], alpha=tuple(s["alpha"]), loss_method=s["loss_method"])
+            V = orc.general_build(oprob, cfg, net=case["net"])
+            with torch.no_grad():
+                for p in V.parameters():
+                    p.mul_(ws)
+            ref = orc.general_train(oprob, cfg, V=V, trace=True)
+            assert model.K_log == ref["K_log"], (dt, ws)
+            assert math.isclose(model.loss_log[0], ref["loss_log"][0], rel_tol=1e-4, abs_tol=1e-9), (dt, ws, model.loss_log, ref["loss_log"])
+            g_ref = torch.cat([g.reshape(-1) for g in ref["traces"][0]["grads"]])
+            err = float((model._gen_plan.grad.cpu() - g_ref).abs().max()) / float(g_ref.abs().max())
+            assert err <= 5e-4, (mode, dt, ws, err)
+
+
+# ---- (b) configs[4] at its per-GPU share ------------------------------------------------------------------------------------------
+def test_config5_per_gpu_share_chunked():
+    """d = 500, N = 200, K = 131072 (1048576 / 8) under a 32 GiB path budget: four chunks of 32768 on the 'two_gradient' plan."""
+    d, K, T = 500, 131072, 2.0
+    prob = psp.LLGC(d=d, off_diag=0.1 / d ** 0.5, T=T, seed=42, device=dev())
+    kw = dict(lr=1e-3, L=1, K=K, delta_t=0.01, loss_method="log-variance", time_approx="inner", adaptive_forward_process=True,
+              detach_forward=True, u_l2_error_flag=False, verbose=False, seed=42, device=dev(), backend="native",
+              noise="philox", widths=(64, 64))
+
+    def run(**over):
+        m = psp.Solver("c5", prob, **dict(kw, **over))
+        m.path_budget_bytes = 32 << 30
+        m.train()
+        return m
+
+    a = run()
+    pa = a._native_plan
+    assert a.N == 200 and pa.n_chunks == 4 and pa.chunk_mode == "two_gradient"
+    assert math.isfinite(a.loss_log[0]) and bool(torch.isfinite(pa.grad).all()) and float(pa.grad.abs().max()) > 0
+    Da, ga = pa.D.clone(), pa.grad.clone()
+    b = run()
+    assert b.loss_log == a.loss_log and torch.equal(b._native_plan.D, Da) and torch.equal(b._native_plan.grad, ga)   # determinism
+    del b
+    # a K = 16384 slice in the middle of the batch, resident store, k_offset pointing at it: the same trajectories bit for bit
+    lo = 3 * 16384 + 32768
+    half = psp.Solver("slice", prob, **dict(kw, K=16384))
+    plan = psp.plan_native.HjbNativePlan(half, noise="philox")
+    assert plan.n_chunks == 1
+    plan.cfg.k_offset = lo
+    losses = torch.zeros(1, device=dev())
+    plan.iteration(0, losses)
+    torch.cuda.synchronize()
+    assert torch.equal(plan.D, Da[lo:lo + 16384])
+    # fp64 sums of the chunked run against a plain sum of its D
+    tot = Da.double().sum()
+    assert abs(float(pa.sums[0] - tot)) <= 1e-9 * float(Da.double().abs().sum()) + 1e-9
+
+
+# ---- (c) configs[2] as written: bf16 value net at K = 65536 ----------------------------------------------------------------------
+def test_config3_bf16_full_size():
+    d, K, N = 100, 65536, 100
+    prob = psp.DoubleWell_multidim_for_general_solver(d=d, d_1=50, d_2=50, T=0.3, eta=1, kappa=1, modus="HJB", device=dev())
+    res = {}
+    for mlp in ("fp32", "bf16", "bf16"):
+        m = psp.GeneralSolver(problem=prob, name="c3", seed=42, delta_t=0.001, N=N, lr=1e-3, L=2, K=K, K_boundary=50,
+                              alpha=[1.0, 1.0, 1.0], loss_method="diffusion", verbose=False, device=dev(), backend="native",
+                              noise="philox", mlp_dtype=mlp)
+        m.V = psp.DenseNet(d_in=d + 1, d_out=1, lr=1e-3, arch=[64, 64], seed=42).to(dev())
+        m.train()
+        assert m.plan_name == "native" and m._gen_plan.matrix_mode == mlp
+        res.setdefault(mlp, []).append((m.loss_log, m.K_log, m._gen_plan.grad.double().cpu()))
+    (l32, k32, g32), = res["fp32"]
+    (la, ka, ga), (lb, kb, gb) = res["bf16"]
+    assert la == lb and ka == kb and torch.equal(ga, gb)                     # determinism of the bf16 mode
+    assert ka == k32                                                         # the same trajectories stay active
+    for a, b in zip(la, l32):
+        assert math.isfinite(a) and math.isclose(a, b, rel_tol=2e-2), (la, l32)
+    cos = float(torch.dot(g32, ga) / (g32.norm() * ga.norm()))
+    assert cos >= 0.999, cos
+    assert 0.5 * K * N < ka[0] < K * N                                        # (~2/3 of the steps are active: t_0 ~ U(0, T))
+
+
+# ---- (d) BSDE on the exact (100, 64) instance -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["fp32", "f16x3", "bf16"])
+def test_bsde_d100_h64_matches_reference_golden(mode):
+    from test_general_composite_golden import build as build_pkg
+    rec = load_golden("dwgen_d100_h64_bsde")
+    prob, model = build_pkg(rec["case"], device=dev(), backend="native", mlp_dtype=mode)
+    model.train()
+    assert model.plan_name == "native" and type(model._gen_plan).__name__ == "GeneralNativePlan"
+    exp = rec["expected"]
+    assert model.K_log == exp["K_log"]
+    tol = 2e-2 if mode == "bf16" else 1e-4
+    errs = [abs(a - b) / abs(b) for a, b in zip(model.loss_log, exp["loss_log"])]
+    print("dwgen_d100_h64_bsde %s: loss rel err per iteration %s" % (mode, ["%.1e" % e for e in errs]))
+    assert max(errs) <= tol, (model.loss_log, exp["loss_log"])

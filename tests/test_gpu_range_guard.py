@@ -268,7 +268,7 @@ def test_backward_overflow_with_a_finite_forward_is_caught():
     for net in got.z_n:
         assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
     raw = run("f16x3", range_guard=False)                          # the test means something: unguarded, the backward overflows
-    assert math.isfinite(raw.loss_log[0]) and not bool(torch.isfinite(raw._native_plan.grad).all())
+    assert not (math.isfinite(raw.loss_log[0]) and bool(torch.isfinite(raw._native_plan.grad).all()))
 
 
 def test_backward_overflow_general_solver():

@@ -12,7 +12,10 @@ from conftest import load_golden
 from oracle import pathspace_oracle as orc
 from util_cases import general_oracle_run
 
-SOLVER_CASES = ["lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "llgc_d12_outer_relative_entropy_detached", "dw_d20_densenet_attached_moment", "lqgc_d6_densenet_attached_cross_entropy",
+# approx_method='value_function' (solver.py:93-97, 334-339, 438-440): Z = sigma grad_x Y_n, extra loss sum_n (Y_n(X_n) - Y)^2
+VALUE_FUNCTION_CASES = ["lqgc_d3_value_function", "dw_d10_value_function", "llgc_d8_diag_value_function_moment",
+                        "dw_d20_value_function_randx0"]
+SOLVER_CASES = VALUE_FUNCTION_CASES + ["lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "llgc_d12_outer_relative_entropy_detached", "dw_d20_densenet_attached_moment", "lqgc_d6_densenet_attached_cross_entropy",
                 "llgc_d12_outer_moment", "dw_d20_densenet_nonadaptive", "lqgc_d6_densenet_variance", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_logvar", "llgc_d200_h64_logvar",
                 "llgc_d500_h64_logvar",
                 "llgc_d7_default_logvar", "lqgc_d33_h50_logvar", "dw_d70_h64_logvar", "llgc_d105_h64_logvar",
@@ -62,7 +65,8 @@ def run_solver_case(rec):
                         loss_method=s["loss_method"], time_approx=s["time_approx"],
                         learn_Y_0=s.get("learn_Y_0", False),
                         adaptive_forward_process=s["adaptive_forward_process"],
-                        detach_forward=s["detach_forward"], random_X_0=s.get("random_X_0", False))
+                        detach_forward=s["detach_forward"], random_X_0=s.get("random_X_0", False),
+                        approx_method=s.get("approx_method", "control"))
     models = orc.hjb_build(prob, cfg)
     net = case.get("net")
     if net is not None:
@@ -81,9 +85,18 @@ def test_solver_oracle_matches_reference(name):
     prob, cfg, out, models = run_solver_case(rec)
     exp = rec["expected"]
     assert out["N"] == exp["N"]
-    _check_series(out["loss_log"], exp["loss_log"], exact)
+    vf = rec["case"]["solver"].get("approx_method") == "value_function"
+    # (value_function: a double-backward graph whose gradient accumulation order is not pinned by the op sequence -- the first
+    #  iterations agree bit for bit, later ones to the rounding of the parameter updates: 2e-7)
+    _check_series(out["loss_log"], exp["loss_log"], exact and not vf)
     _check_series(out["Y_0_log"], exp["Y_0_log"], exact)
     z = out["z"]
+    if vf:
+        assert out["loss_log"][0] == exp["loss_log"][0] or not exact
+        # every parameter but the output bias: the losses of this ansatz do not depend on a constant offset of the value net (Y and
+        # Y_n(X_n) both carry it), so its gradient is rounding noise -- which Adam normalises to steps of +-lr in BOTH implementations
+        _check_fp(orc.fingerprint(z)[:-1], exp["final_params"][:-1], False)
+        return
     if exp["final_params"] is not None:
         # with gradients through the state path the backward graph sums contributions in an order that depends on
         # how the graph was built: losses agree bit-for-bit, final parameters to ~1e-7 relative

@@ -40,7 +40,8 @@ def make_oracle(case, L=None):
                         loss_method=s["loss_method"], time_approx=s["time_approx"],
                         learn_Y_0=s.get("learn_Y_0", False),
                         adaptive_forward_process=s["adaptive_forward_process"],
-                        detach_forward=s["detach_forward"], random_X_0=s.get("random_X_0", False))
+                        detach_forward=s["detach_forward"], random_X_0=s.get("random_X_0", False),
+                        approx_method=s.get("approx_method", "control"))
     models = orc.hjb_build(prob, cfg)
     net = case.get("net")
     if net is not None:

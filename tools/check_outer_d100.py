@@ -1,5 +1,7 @@
 import sys, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import path_space_pde_solver_amd as psp
 from oracle import pathspace_oracle as orc
 dev = torch.device('cuda:0')

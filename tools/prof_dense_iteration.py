@@ -1,5 +1,7 @@
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
 import path_space_pde_solver_amd as psp
 dev = torch.device('cuda:0')
 d, K, N, H = 100, 65536, 100, 30

@@ -1,7 +1,9 @@
 """Small-K GeneralSolver: the (d, H)-templated kernels (gen_*: one wave per 16-trajectory tile, tables in LDS) against the
 run-time-shaped ones (genl_*: four waves per tile, tables in L2) on the SAME two-hidden-layer net.  Run on an MI355X."""
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT)
 import torch
 import path_space_pde_solver_amd as psp
 from path_space_pde_solver_amd import plan_general_deep as pgd, plan_general_native as pgn

@@ -1,5 +1,7 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
 import torch
 import path_space_pde_solver_amd as psp
 dev = torch.device("cuda:0")
