@@ -271,8 +271,11 @@ class GeneralSolver:
                     from . import plan_general_deep as pgd
                 except ImportError:
                     import plan_general_deep as pgd
-                if pgd.deep_eligibility(self) is None and pgn.native_eligibility(self, deep=True) is None:
+                deep_reason = pgd.deep_eligibility(self) or pgn.native_eligibility(self, deep=True)
+                if deep_reason is None:
                     reason, deep = None, True
+                else:
+                    reason = deep_reason                          # (why NEITHER kernel family takes it)
         if reason is None:
             self.plan_name = 'native'
             plan = getattr(self, '_gen_plan', None)

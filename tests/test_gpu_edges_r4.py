@@ -77,9 +77,16 @@ def test_scale_sweep_matches_oracle(kind, mode, loss):
         eD_abs = float((D - D_ref).abs().max())
         tol_g = 2e-4 + (2.0 * math.sqrt(D.numel()) * eD_abs / max(float(D_ref.std()), 1e-30) if loss == "log-variance" else 0.0)
         assert eg <= tol_g, (kind, mode, x0, dt, ws, eg, tol_g, float(g_ref.abs().max()))
+        # the loss: against the fp64 value of the kernel's own D (the kernels reduce in fp64), and against the reference's fp32
+        # value wherever THAT is meaningful -- mean(D^2) - mean(D)^2 in fp32 loses everything once mean(D^2) / var(D) passes 1e6
+        # (X_0 = 1, dt = 1e-6: the reference logs 0.0048828125 = 5 * 2^-10 for a variance of 2.98e-4)
+        Dd = D.double()
+        l64 = float((Dd ** 2).mean() - Dd.mean() ** 2) if loss == "log-variance" else float((Dd ** 2).mean())
+        assert math.isclose(model.loss_log[0], l64, rel_tol=1e-5, abs_tol=1e-12), (x0, dt, ws, model.loss_log[0], l64)
         lref = ref["loss_log"][0]
         cond = float((D_ref.double() ** 2).mean()) / max(abs(lref), 1e-30)
-        assert math.isclose(model.loss_log[0], lref, rel_tol=min(1e-3, max(2e-5, 4 * 6e-8 * cond)), abs_tol=1e-9), (x0, dt, ws)
+        if 4 * 6e-8 * cond <= 1e-3:
+            assert math.isclose(model.loss_log[0], lref, rel_tol=max(2e-5, 4 * 6e-8 * cond), abs_tol=1e-9), (x0, dt, ws)
     print("%s %s %s: worst D err %.1e, worst gradient err %.1e at (X0, dt, weight scale) = %s" % (kind, mode, loss, worst[0], worst[1], worst[2]))
 
 

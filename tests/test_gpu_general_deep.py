@@ -130,8 +130,11 @@ def test_user_defined_dense_concat_net_runs_on_the_kernels():
     assert type(model._gen_plan).__name__ == "GeneralDeepPlan" and model._gen_plan.net_spec["act"] == "tanh2"
     exp = rec["expected"]
     assert model.K_log == exp["K_log"]
-    errs = [abs(a - b) / abs(b) for a, b in zip(model.loss_log, exp["loss_log"])]
-    assert max(errs) <= 1e-4, (model.loss_log, exp["loss_log"])
+    # (two_spheres boundary data hangs on the last bit of a host reduction: the log is compared with the oracle run on THIS machine,
+    #  tests/test_gpu_bounded_elliptic.py::test_loss_log_matches_reference_golden)
+    want = oracle_run(case, len(exp["loss_log"]))["loss_log"]
+    errs = [abs(a - b) / abs(b) for a, b in zip(model.loss_log, want)]
+    assert max(errs) <= 1e-4, (model.loss_log, want, exp["loss_log"])
     # a forward the kernels do not implement (tanh cubed) is NOT taken for one they do: composite plan, with a warning
     prob, other = build_pkg(case, device=dev(), backend="auto", L=1)
     other.V = NotebookTanh2(prob.d, case["net"]["arch"], case["solver"]["lr"], case["net"]["seed"], power=3).to(dev())
