@@ -171,6 +171,7 @@ class DenseNativePlan:
         # library-GEMM formulation on row-major stores (PSP_DENSE_BWD=gemm forces the latter: cross-check / timing)
         import os
         self.kernel_bwd = bool(sizes.bwd_supported) and os.environ.get('PSP_DENSE_BWD', 'kernel') != 'gemm'
+        self._gidx = None                                        # padded -> real gather index of a parameter set ('outer')
         if (self.attached or self.relent) and not self.kernel_bwd:
             raise PlanUnsupported('the adjoint sweep of a DenseNet control works on the register images of the hand-written '
                                   'backward, which does not cover the (%d, %d) instance' % (self.d_pad, self.H_pad))
@@ -259,6 +260,13 @@ class DenseNativePlan:
         nat.check(self.lib.psp_dnet_rollout_bwd(C.byref(self.cfg), nat.ptr(self.flat), nat.ptr(self.images), nat.ptr(self.wpad),
                                                 nat.ptr(self.partial), nat.stream_ptr(self.dev)), 'psp_dnet_rollout_bwd')
         g = self.partial.view(N, self.slices, self.PP).sum(1)          # (N, PP): one padded gradient per time step
+        if self.outer:
+            # one parameter set per time step: the real rows / columns of every set are ONE gather through an index built once
+            # (round 3 cut them out with a dozen strided slices and three torch.cat per iteration -- 35 device copies)
+            if self._gidx is None:
+                self._gidx = self._gather_index()
+            torch.index_select(g, 1, self._gidx, out=self.grad.view(N, self.Pset))
+            return self.grad
         o = 0
         W1 = g[:, o:o + D * Hp].view(N, D, Hp)[:, :d, :H]; o += D * Hp
         b1 = g[:, o:o + Hp][:, :H]; o += Hp
@@ -279,6 +287,24 @@ class DenseNativePlan:
             W3s = torch.cat([(t * b3).sum(0, keepdim=True), W3r.sum(0)], 0)
             grad.copy_(torch.cat([W1s.reshape(-1), b1.sum(0), W2s.reshape(-1), b2.sum(0), W3s.reshape(-1), b3.sum(0)]))
         return grad
+
+    def _gather_index(self):
+        """Padded position (inside one per-step partial gradient of hjbd_bwd_kernel) of every real parameter of a set, in the
+        DenseNet's registration order W1, b1, W2, b2, W3, b3 (weights (in, out); W2 rows [x | h1], W3 rows [x | h1 | h2])."""
+        H, d, D, Hp = self.H, self.s.d, self.d_pad, self.H_pad
+        ar = lambda n: torch.arange(n, device=self.dev)
+        o, parts = 0, []
+        parts.append((o + ar(d).view(-1, 1) * Hp + ar(H).view(1, -1)).reshape(-1)); o += D * Hp
+        parts.append(o + ar(H)); o += Hp
+        rows2 = torch.cat([ar(d), D + ar(H)])
+        parts.append((o + rows2.view(-1, 1) * Hp + ar(H).view(1, -1)).reshape(-1)); o += (D + Hp) * Hp
+        parts.append(o + ar(H)); o += Hp
+        rows3 = torch.cat([ar(d), D + ar(H), D + Hp + ar(H)])
+        parts.append((o + rows3.view(-1, 1) * D + ar(d).view(1, -1)).reshape(-1)); o += (D + 2 * Hp) * D
+        parts.append(o + ar(d))
+        idx = torch.cat(parts)
+        assert idx.numel() == self.Pset, (idx.numel(), self.Pset)
+        return idx
 
     def _gradient(self, w):
         if self.kernel_bwd:

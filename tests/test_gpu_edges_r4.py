@@ -82,7 +82,9 @@ def test_scale_sweep_matches_oracle(kind, mode, loss):
         # (X_0 = 1, dt = 1e-6: the reference logs 0.0048828125 = 5 * 2^-10 for a variance of 2.98e-4)
         Dd = D.double()
         l64 = float((Dd ** 2).mean() - Dd.mean() ** 2) if loss == "log-variance" else float((Dd ** 2).mean())
-        assert math.isclose(model.loss_log[0], l64, rel_tol=1e-5, abs_tol=1e-12), (x0, dt, ws, model.loss_log[0], l64)
+        # (X_0 = 1000 next to dt = 1e-6: mean(D^2) / var(D) = 3e11 -- even the fp64 form of mean(D^2) - mean(D)^2 keeps five digits)
+        cond64 = float((Dd ** 2).mean()) / max(abs(l64), 1e-300)
+        assert math.isclose(model.loss_log[0], l64, rel_tol=max(1e-5, 64 * 2.2e-16 * cond64), abs_tol=1e-12), (x0, dt, ws, model.loss_log[0], l64)
         lref = ref["loss_log"][0]
         cond = float((D_ref.double() ** 2).mean()) / max(abs(lref), 1e-30)
         if 4 * 6e-8 * cond <= 1e-3:
