@@ -170,9 +170,21 @@ __device__ __forceinline__ f32x4 image_get_T(const float* base, int o32, int o16
 
 // PHILOX: on-device noise decided at launch -- no supplied-noise loads (and no join behind them) in the time loop
 // X3 (psp_gen_config.mlp_dtype = PSP_MLP_F16X3): the nine value-net products per step as split f16 products, fp32-grade
-template <int D, int H, bool BF16 = false, bool PHILOX = false, bool X3 = false>
-__global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a) {
-    PSP_COND_EXIT(a);
+// SPECK >= 0 (round 4): the problem switches as compile-time constants -- SPECK = drift_kind | h_kind << 4 on an UNBOUNDED domain,
+// non-adaptive forward process, path store on, no per-step value output: the training launch of the parabolic notebooks' problems
+// (DoubleWell_multidim_for_general_solver 'HJB': DRIFT_DWELL | GH_QUAD << 4, BASELINE configs[2]; AllenCahn: DRIFT_ZERO |
+// GH_ALLEN_CAHN << 4).  The general instance tests every one of them per step and per state block: scalar branches that cut the
+// time loop into basic blocks (hjb_kernels.h, hjb_fwd_kernel FAST_ = 2).
+template <int D, int H, bool BF16 = false, bool PHILOX = false, bool X3 = false, int SPECK = -1>
+__global__ __launch_bounds__(512) void gen_fwd_kernel(const GenArgs a_) {
+    PSP_COND_EXIT(a_);
+    constexpr bool SPEC = SPECK >= 0;
+    // a by-value copy of the arguments whose switches are constants in a specialised instance
+    GenArgs a = a_;
+    if constexpr (SPEC) {
+        a.drift_kind = SPECK & 15; a.h_kind = (SPECK >> 4) & 15; a.domain_kind = DOM_NONE; a.adaptive = 0; a.store_path = 1;
+        a.Vsteps = nullptr; a.Ysteps = nullptr;
+    }
     using G = GGeo<D, H>;
     constexpr int DI = G::DI, DBI = G::DBI, KSI = G::KSI, HB = G::HB, KSH = G::KSH;
     constexpr int MODE = X3 ? 2 : (BF16 ? 1 : 0);
@@ -1596,7 +1608,26 @@ struct GenLaunch {
     static hipError_t fwd(const GenArgs& a, int grid, int block, hipStream_t s) {
         return a.noise_mode == NOISE_PHILOX ? fwd_as<false, true>(a, grid, block, s) : fwd_as<false, false>(a, grid, block, s);
     }
+    // specialised problem kinds (gen_fwd_kernel SPECK): unbounded, non-adaptive, path store on, no per-step value output
+    static int spec_kind(const GenArgs& a) {
+        if (a.noise_mode != NOISE_PHILOX || a.domain_kind != DOM_NONE || a.adaptive || a.store_path != 1 || a.Vsteps != nullptr) return -1;
+        if (a.drift_kind == DRIFT_DWELL && a.h_kind == GH_QUAD) return DRIFT_DWELL | (GH_QUAD << 4);
+        if (a.drift_kind == DRIFT_ZERO && a.h_kind == GH_ALLEN_CAHN) return DRIFT_ZERO | (GH_ALLEN_CAHN << 4);
+        return -1;
+    }
+    template <bool BF16, bool X3, int SPECK>
+    static hipError_t fwd_spec(const GenArgs& a, int grid, int block, hipStream_t s) {
+        const int bytes = X3 ? G::fwd_x3_lds_floats() * 4 : fwd_lds();
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_fwd_kernel<D, H, BF16, true, X3, SPECK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gen_fwd_kernel<D, H, BF16, true, X3, SPECK>), dim3(grid), dim3(block), bytes, s, a);
+        return hipGetLastError();
+    }
     static hipError_t fwd_bf16(const GenArgs& a, int grid, int block, hipStream_t s) {
+        const int sk = spec_kind(a);
+        if (sk == (DRIFT_DWELL | (GH_QUAD << 4))) return fwd_spec<true, false, DRIFT_DWELL | (GH_QUAD << 4)>(a, grid, block, s);
+        if (sk == (DRIFT_ZERO | (GH_ALLEN_CAHN << 4))) return fwd_spec<true, false, DRIFT_ZERO | (GH_ALLEN_CAHN << 4)>(a, grid, block, s);
         return a.noise_mode == NOISE_PHILOX ? fwd_as<true, true>(a, grid, block, s) : fwd_as<true, false>(a, grid, block, s);
     }
     static int bwd2_x3_lds() { return (G::gW2hr + SplitGeo<G::KSH, G::HB>::floats(G::HB) + 2 * 4 * G::EXT * 256) * 4; }
@@ -1618,6 +1649,9 @@ struct GenLaunch {
         return hipGetLastError();
     }
     static hipError_t fwd_x3(const GenArgs& a, int grid, int block, hipStream_t s) {
+        const int sk = spec_kind(a);
+        if (sk == (DRIFT_DWELL | (GH_QUAD << 4))) return fwd_spec<false, true, DRIFT_DWELL | (GH_QUAD << 4)>(a, grid, block, s);
+        if (sk == (DRIFT_ZERO | (GH_ALLEN_CAHN << 4))) return fwd_spec<false, true, DRIFT_ZERO | (GH_ALLEN_CAHN << 4)>(a, grid, block, s);
         return a.noise_mode == NOISE_PHILOX ? fwd_x3_as<true>(a, grid, block, s) : fwd_x3_as<false>(a, grid, block, s);
     }
 #ifdef PSP_LEGACY_BWD

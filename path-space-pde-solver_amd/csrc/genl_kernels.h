@@ -285,8 +285,11 @@ __device__ __forceinline__ void genl_input_gradient(KArgs a, const f32x4 (&Rr)[G
 // LDS: A, G (TB blocks each), 1 KiB per block
 __host__ __device__ inline int genl_fwd_lds_bytes(int TB) { return 2 * TB * 1024; }
 
+// (NW = 4: two workgroups per CU at 256 registers a wave -- the step chain of a tile is bound by the L2 latency of its table
+//  operands and by its barriers, not by the matrix pipe, so two tiles in flight per CU are worth more than eight waves on one
+//  once the batch fills the chip; NW = 8 for small batches, where the latency of ONE tile is what counts)
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void genl_fwd_kernel(const GenlArgs ga_) {
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) void genl_fwd_kernel(const GenlArgs ga_) {
     PSP_COND_EXIT(ga_.g);
     const KArgs ga = &ga_;
     const KGen a = &ga->g;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64 * NW) void genl_fwd_kernel(const GenlArgs ga_) {
             for (int b = 0; b < GENL_MAXDB; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (b == TBq && r == TRq && q == TQq) X[b][r] = tv;
+                    if (b == TBq && r == TRq && opaque_i(q) == TQq) X[b][r] = tv;
         }
     };
     auto put_state = [&]() {
@@ -348,6 +351,9 @@ __global__ __launch_bounds__(64 * NW) void genl_fwd_kernel(const GenlArgs ga_) {
         // every trajectory of the tile frozen: nothing changes any more (solver.py:1093-1097 / :742-744 leave the loop); all the
         // waves of the tile carry the same state, so the verdict is uniform over the workgroup
         if (__builtin_amdgcn_ballot_w64(!stopped) == 0ull) { nex = n; break; }
+        // (feature masks (16 b + 4 r + q < D) are invariant over the time loop: hoisted, they are ~60 SGPR pairs, all spilled to VGPR
+        //  lanes; an opaque copy of q per step keeps them as one v_cmp where they are used)
+        const int qv = opaque_i(q);
         put_state();
         const float Vnow = genl_value<NW>(ga, A, Rr, lane, q, wave);
         if (n == 0) Y = Vnow;                                        // solver.py:1081 / :721
@@ -360,23 +366,23 @@ __global__ __launch_bounds__(64 * NW) void genl_fwd_kernel(const GenlArgs ga_) {
             } else {
                 const float* xrow = a->xi + ((size_t)n * a->K_local + (kvalid ? k : 0)) * D;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const int f = 16 * b + 4 * r + q; xi[r] = xrow[f < D ? f : D - 1]; }
+                for (int r = 0; r < 4; ++r) { const int f = 16 * b + 4 * r + qv; xi[r] = xrow[f < D ? f : D - 1]; }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xi[r] = ((16 * b + 4 * r + q) < D && kvalid) ? xi[r] : 0.f;
+            for (int r = 0; r < 4; ++r) xi[r] = ((16 * b + 4 * r + qv) < D && kvalid) ? xi[r] : 0.f;
             return xi;
         };
         auto z_block = [&](int b) __attribute__((always_inline)) {       // Z = sigma^T grad_x V, sigma = s I (solver.py:1104)
             const f32x4 gx = img_get(G, b, lane);
             f32x4 Z;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Z[r] = ((16 * b + 4 * r + q) < D) ? sig * gx[r] : 0.f;
+            for (int r = 0; r < 4; ++r) Z[r] = ((16 * b + 4 * r + qv) < D) ? sig * gx[r] : 0.f;
             return Z;
         };
         auto drift_vec = [&](int b) __attribute__((always_inline)) {
             f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const int f = 16 * b + 4 * r + q; v[r] = (f < D && a->drift_kind != DRIFT_ZERO) ? vdr[f] : 0.f; }
+            for (int r = 0; r < 4; ++r) { const int f = 16 * b + 4 * r + qv; v[r] = (f < D && a->drift_kind != DRIFT_ZERO) ? vdr[f] : 0.f; }
             return v;
         };
         auto move_block = [&](int b, const f32x4& Z, const f32x4& xi) __attribute__((always_inline)) {
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(64 * NW) void genl_fwd_kernel(const GenlArgs ga_) {
             for (int b = 0; b < GENL_MAXDB; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (b < DB0 && (16 * b + 4 * r + q) < D) rr = fmaf(X[b][r], X[b][r], rr);
+                    if (b < DB0 && (16 * b + 4 * r + qv) < D) rr = fmaf(X[b][r], X[b][r], rr);
             rr = qsum(rr);
         }
         bool inside = true;
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(64 * NW) void genl_fwd_kernel(const GenlArgs ga_) {
                     const f32x4 Xp = X[b] + move_block(b, z_block(b), xi);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if ((16 * b + 4 * r + q) < D) {
+                        if ((16 * b + 4 * r + qv) < D) {
                             const bool lo_ok = a->domain_kind != DOM_BOX || Xp[r] >= a->dom_a, hi_ok = Xp[r] <= a->dom_b;
                             n_out += (lo_ok && hi_ok) ? 0.f : 1.f;
                             n_le += hi_ok ? 1.f : 0.f;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(64 * NW) void genl_fwd_kernel(const GenlArgs ga_) {
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool fx = (16 * b + 4 * r + q) < D;
+                    const bool fx = (16 * b + 4 * r + qv) < D;
                     X[b][r] = (fx && act) ? X[b][r] + step[r] : X[b][r];
                 }
             }

@@ -705,9 +705,19 @@ struct Geo {
 // every step waited right behind its burst of 28 X-image stores for them to be acknowledged before the first product
 // started.  Worth 1.3 % here (4.78 -> 4.72 ms, same-box A/B), 2 % in hjbs_fwd_kernel, 5 % in hjbq_fwd_kernel, whose steps
 // are short; the larger part of the path store's cost stays (finding 7).
-template <int D, int H, int MODE = 0, bool FAST = false>
+// FAST_ = 2 (round 4): a FAST instance whose problem switches are COMPILE-TIME too -- dense drift, dense sigma, adaptive process,
+// no running cost, store_path 4, not the relative-entropy loss: the LLGC configuration of every BASELINE config.  The time loop of
+// the general instance tests those wave-uniform switches at run time: ~100 scalar branches per step, each one a basic-block
+// boundary that the scheduler cannot move the path stores, the Philox slices or the operand prefetches across.
+template <int D, int H, int MODE = 0, int FAST_ = 0>
 __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     PSP_COND_EXIT(a);
+    constexpr bool FAST = FAST_ != 0, SPEC = FAST_ == 2;
+    // the problem switches: kernel arguments in the general instances, constants in the specialised one
+    const int k_drift = SPEC ? (int)DRIFT_DENSE : a.drift_kind, k_sigma = SPEC ? (int)SIGMA_DENSE : a.sigma_kind;
+    const int k_run = SPEC ? (int)RUN_ZERO : a.runcost_kind, k_loss = SPEC ? (int)LOSS_LOGVAR : a.loss_kind;
+    const int k_store = SPEC ? 4 : a.store_path;
+    const bool k_adaptive = SPEC ? true : (a.adaptive != 0);
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     constexpr int DB = G::DB, HB = G::HB, KSD = G::KSD, KSH = G::KSH;
@@ -740,15 +750,15 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
         stage_net(lds + oW3, DB, KSH, HB, w3src);
     }
     float* ldsA = lds + G::fA + VSH;
-    float* ldsB = ldsA + (a.drift_kind == DRIFT_DENSE ? (X3 ? G::xB_dense_off : G::fB_dense_off) : 0);
-    if (a.drift_kind == DRIFT_DENSE) {
+    float* ldsB = ldsA + (k_drift == DRIFT_DENSE ? (X3 ? G::xB_dense_off : G::fB_dense_off) : 0);
+    if (k_drift == DRIFT_DENSE) {
         const float dt = a.dt;
         const float* __restrict__ A = a.drift;
         auto asrc = [&](int row, int col) { return (row < D && col < D) ? dt * A[row * D + col] : 0.f; };
         if constexpr (X3) stage_aop_x3<KSD, DB>(ldsA, DB, tid, nthr, asrc);
         else stage_aop(ldsA, DB, KSD, tid, nthr, asrc);
     }
-    if (a.sigma_kind == SIGMA_DENSE) {
+    if (k_sigma == SIGMA_DENSE) {
         const float* __restrict__ B = a.sigma;
         auto bsrc = [&](int row, int col) { return (row < D && col < D) ? B[row * D + col] : 0.f; };
         if constexpr (X3) stage_aop_x3<KSD, DB>(ldsB, DB, tid, nthr, bsrc);
@@ -759,9 +769,9 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     stage_vec(lds + VSH + G::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
     stage_vec(lds + VSH + G::vb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
     stage_vec(lds + VSH + G::vdr, DB, tid, nthr, [&](int f) {
-        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+        return (f < D && (k_drift == DRIFT_DIAG || k_drift == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
     stage_vec(lds + VSH + G::vrun, DB, tid, nthr, [&](int f) {
-        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+        return (f < D && k_run == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
     stage_vec(lds + VSH + G::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
     __syncthreads();
 
@@ -772,11 +782,11 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     const uint32_t kglob = (uint32_t)(a.k_offset + k);
     const float dt = a.dt, sqdt = a.sqdt;
 
-    const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
-    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
+    const float store_cxi = (k_store == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
+    const float store_cz = (k_store == 3) ? 1.f : (k_store == 2 ? -a.sqdt : (k_adaptive ? 0.f : a.sqdt));
     // FAST instances always keep the path (the launcher sends store_path = 0 to the general instance): without the
     // wave-uniform branch the stores share a scheduling region with the products instead of standing as bursts of 28 - 32
-    const bool do_store = FAST ? true : (a.store_path != 0);
+    const bool do_store = FAST ? true : (k_store != 0);
     double sD = 0.0, sD2 = 0.0;
     if (wave_valid) {
         // per-lane-q views of the staged vectors
@@ -833,9 +843,9 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             // split products with a dense drift: the state panel is split ONCE for W1 x and (dt A) x (Tn = X + dt A X is formed
             // here, next to the first layer, instead of after the control)
             f32x4 Tn[DB];
-            const bool early_drift = X3 && a.drift_kind == DRIFT_DENSE;
+            const bool early_drift = X3 && k_drift == DRIFT_DENSE;
             if constexpr (X3) {
-                if (a.drift_kind == DRIFT_DENSE) {
+                if (k_drift == DRIFT_DENSE) {
                     f16x8 xh[DB / 2 > 0 ? DB / 2 : 1], xl[DB / 2 > 0 ? DB / 2 : 1];
                     constexpr int NU1 = (DB / 2) * HB, NU2 = (DB / 2) * DB;
                     split_panel8<DB>(X, xh, xl);
@@ -952,7 +962,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
                 }
-                if (do_store && a.store_path != 4) {   // (4: the backward regenerates xi from the Philox counters)
+                if (do_store && k_store != 4) {   // (4: the backward regenerates xi from the Philox counters)
                     // 1: xi, or xi + sqrt(dt) Z when the forward process is NOT adaptive (then dL/dZ_n = w (Z dt + xi sqrt(dt))
                     //    = w sqrt(dt) * image, the same expression the backward kernels evaluate); attached process (hjba_kernels.h):
                     // 2: xi - sqrt(dt) Z, 3: Z  -- the adjoint sweep replaces it by dL/dZ_n / sqrt(dt)
@@ -977,7 +987,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
                     }
                 }
                 // v = c dt + xi sqrt(dt), c = -Z (adaptive) or 0  (solver.py:451-456,471-472)
-                Z[b] = a.adaptive ? (sqdt * xi - dt * Z[b]) : (sqdt * xi);
+                Z[b] = k_adaptive ? (sqdt * xi - dt * Z[b]) : (sqdt * xi);
             }
             ULsum = fmaf(UL, dt, ULsum);
             S = qsum(S);
@@ -989,19 +999,19 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Tn[b] = X[b];
             }
-            if (a.drift_kind == DRIFT_DENSE) {
+            if (k_drift == DRIFT_DENSE) {
                 if constexpr (!X3) gemm_T<DB, KSD, DB>(Tn, ldsA, X, lane);     // + (dt A) X
-            } else if (a.drift_kind == DRIFT_DIAG) {
+            } else if (k_drift == DRIFT_DIAG) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Tn[b] += dt * (vdr[b * 4] * X[b]);
-            } else if (a.drift_kind == DRIFT_DWELL) {            // b = -4 kappa x (x^2 - 1), problems.py:311-315
+            } else if (k_drift == DRIFT_DWELL) {            // b = -4 kappa x (x^2 - 1), problems.py:311-315
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Tn[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
             }
-            if (a.sigma_kind == SIGMA_DENSE) {
+            if (k_sigma == SIGMA_DENSE) {
                 if constexpr (X3) gemm_Tx<DB, KSD, DB>(Tn, ldsB, Z, lane);
                 else gemm_T<DB, KSD, DB>(Tn, ldsB, Z, lane);     // + B v
-            } else if (a.sigma_kind == SIGMA_SCALE) {
+            } else if (k_sigma == SIGMA_SCALE) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Tn[b] += a.sigma_scale * Z[b];
             } else {
@@ -1014,7 +1024,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 
             // ---- running cost f(X_{n+1}) (h sees the UPDATED state, solver.py:477) and Y update
             float fX = 0.f;
-            if (a.runcost_kind == RUN_DIAGQ) {
+            if (k_run == RUN_DIAGQ) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) {
                     const f32x4 pv = vrun[b * 4];
@@ -1024,12 +1034,12 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
                 fX = qsum(fX);
             }
             // Y += (-h + Z.c) dt + Z.xi sqrt(dt);  -h = 0.5|Z|^2 + f ; Z.c = -|Z|^2 (adaptive) or 0
-            if (a.loss_kind == LOSS_RELENT) {
+            if (k_loss == LOSS_RELENT) {
                 // relative entropy (solver.py:179-180, 484-486): Y carries -Zsum = -sum (|Z|^2 / 2 + f(X_{n+1})) dt,
                 // so D = Y - g = -(Zsum + g) and the loss is -mean D
                 Y = Y - (0.5f * S + fX) * dt;
             } else {
-                const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
+                const float drift_y = k_adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
                 Y = Y + drift_y * dt + Pz * sqdt;
             }
             Fsum = fmaf(fX, dt, Fsum);
@@ -1905,7 +1915,7 @@ struct HjbLaunch {
     static int fwd_lds(int dk, int sk) { return G::fwd_lds_floats(dk, sk) * 4; }
     static int bwd_lds(int ad) { return G::bwd_lds_floats(ad) * 4; }
     static int fwd_x3_lds(int dk, int sk) { return G::fwd_x3_lds_floats(dk, sk) * 4; }
-    template <int MODE, bool FAST>
+    template <int MODE, int FAST>
     static hipError_t fwd_as(const HjbArgs& a, int grid, int block, hipStream_t s) {
         const int bytes = MODE == 2 ? fwd_x3_lds(a.drift_kind, a.sigma_kind) : fwd_lds(a.drift_kind, a.sigma_kind);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjb_fwd_kernel<D, H, MODE, FAST>),
@@ -1917,14 +1927,17 @@ struct HjbLaunch {
     // FAST (no vector-memory load in the time loop): Philox noise, no u_L2 log, no time-feature table -- every training launch
     static bool fast(const HjbArgs& a) { return a.noise_mode == NOISE_PHILOX && a.uref == nullptr && a.tfeat == nullptr && a.store_path != 0; }
     static hipError_t fwd(const HjbArgs& a, int grid, int block, hipStream_t s) {
-        return fast(a) ? fwd_as<0, true>(a, grid, block, s) : fwd_as<0, false>(a, grid, block, s);
+        return fast(a) ? fwd_as<0, 1>(a, grid, block, s) : fwd_as<0, 0>(a, grid, block, s);
     }
     static hipError_t fwd_bf16(const HjbArgs& a, int grid, int block, hipStream_t s) {
-        return fast(a) ? fwd_as<1, true>(a, grid, block, s) : fwd_as<1, false>(a, grid, block, s);
+        return fast(a) ? fwd_as<1, 1>(a, grid, block, s) : fwd_as<1, 0>(a, grid, block, s);
     }
     // every product fp32-grade on the f16 matrix pipe (gemm_Tx)
     static hipError_t fwd_x3(const HjbArgs& a, int grid, int block, hipStream_t s) {
-        return fast(a) ? fwd_as<2, true>(a, grid, block, s) : fwd_as<2, false>(a, grid, block, s);
+        // (the specialised instance: dense drift and sigma, adaptive, no running cost, store_path 4 -- hjb_fwd_kernel, FAST_ = 2)
+        const bool spec = fast(a) && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive && a.runcost_kind == RUN_ZERO &&
+                          a.store_path == 4 && a.loss_kind != LOSS_RELENT;
+        return spec ? fwd_as<2, 2>(a, grid, block, s) : fast(a) ? fwd_as<2, 1>(a, grid, block, s) : fwd_as<2, 0>(a, grid, block, s);
     }
 #ifdef PSP_LEGACY_BWD
     // hjb_bwd_kernel (the second backward version: two 4-wave workgroups per CU, every wave runs all phases) is superseded by

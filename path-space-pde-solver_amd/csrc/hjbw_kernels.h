@@ -547,9 +547,16 @@ __device__ __forceinline__ void gemm_regs_x3(f32x4 (&acc)[MB], const float* __re
 // sits on the 512-register limit and two more live accumulators cost the ordinary path 8 % (measured)
 // FAST: Philox noise and no time-feature table, decided at launch (no conditional loads and joins in the time loop; training)
 // X3: every product as split f16 products (psp_hjb_config.mlp_dtype = PSP_MLP_F16X3; tables built by hjbw_tables_kernel(.., 3))
-template <int D, int H, bool LOGU = false, bool FAST = false, bool X3 = false>
+// SPEC (round 4): the problem switches of the LLGC configurations -- dense drift, dense sigma, adaptive process, no running cost,
+// store_path 1, not the relative-entropy loss -- as compile-time constants (hjb_kernels.h, hjb_fwd_kernel FAST_ = 2): no scalar
+// branches on them inside the time loop and its rolled k-loops
+template <int D, int H, bool LOGU = false, bool FAST = false, bool X3 = false, bool SPEC = false>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const HjbArgs a) {
     PSP_COND_EXIT(a);
+    const int k_drift = SPEC ? (int)DRIFT_DENSE : a.drift_kind, k_sigma = SPEC ? (int)SIGMA_DENSE : a.sigma_kind;
+    const int k_run = SPEC ? (int)RUN_ZERO : a.runcost_kind, k_loss = SPEC ? (int)LOSS_LOGVAR : a.loss_kind;
+    const int k_store = SPEC ? 1 : a.store_path;
+    const bool k_adaptive = SPEC ? true : (a.adaptive != 0);
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
@@ -566,9 +573,9 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
     stage_vec(lds + W::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
     stage_vec(lds + W::vb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
     stage_vec(lds + W::vdr, DB, tid, nthr, [&](int f) {
-        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+        return (f < D && (k_drift == DRIFT_DIAG || k_drift == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
     stage_vec(lds + W::vrun, DB, tid, nthr, [&](int f) {
-        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+        return (f < D && k_run == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
     stage_vec(lds + W::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
     __syncthreads();
 
@@ -585,9 +592,9 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
     // 7.08 -> 5.96 ms; the other instances keep per-wave streams (gemm_img_x3)
     constexpr bool kShare = W::kShare;
     [[maybe_unused]] const f32x4 zero4x = {0.f, 0.f, 0.f, 0.f};
-    const bool store_path = a.store_path && wave_valid;
-    const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;
-    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
+    const bool store_path = k_store && wave_valid;
+    const float store_cxi = (k_store == 3) ? 0.f : 1.f;
+    const float store_cz = (k_store == 3) ? 1.f : (k_store == 2 ? -a.sqdt : (k_adaptive ? 0.f : a.sqdt));
 
     double sD = 0.0, sD2 = 0.0;
     {
@@ -662,15 +669,15 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
             else gemm_img<HB, KP>(h1, T + W::tW1, img, lane);
             PSP_STAMP(ws2);
             // ---- X_{n+1} = X + b(X) dt + sigma v (solver.py:471-472): the drift part now, while the image still holds X_n
-            if (a.drift_kind == DRIFT_DENSE) {
+            if (k_drift == DRIFT_DENSE) {
                 PSP_WIDE_SYNC();
                 if constexpr (X3 && kShare) gemm_img_x3s<DB, W::KS8>(X, T + W::xA, img, lds + W::fStage, lane, wave);
                 else if constexpr (X3) gemm_img_x3<DB, W::KS8>(X, T + W::xA, img, lane);
                 else gemm_img<DB, KP>(X, T + W::tA, img, lane);                  // X += (dt A) X_n
-            } else if (a.drift_kind == DRIFT_DIAG) {
+            } else if (k_drift == DRIFT_DIAG) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) X[b] += dt * (vdr[b * 4] * X[b]);
-            } else if (a.drift_kind == DRIFT_DWELL) {
+            } else if (k_drift == DRIFT_DWELL) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) X[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
             }
@@ -745,21 +752,21 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
                             UL = fmaf(e, e, UL);
                         }
                     }
-                    const f32x4 v = a.adaptive ? (sqdt * xi - dt * Zg[m]) : (sqdt * xi);
-                    if (a.sigma_kind == SIGMA_DENSE) {
+                    const f32x4 v = k_adaptive ? (sqdt * xi - dt * Zg[m]) : (sqdt * xi);
+                    if (k_sigma == SIGMA_DENSE) {
                         if constexpr (X3) vg[m] = v;
                         else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) img[(4 * b + r) * 64 + lane] = v[r];
                         }
-                    } else if (a.sigma_kind == SIGMA_SCALE) {
+                    } else if (k_sigma == SIGMA_SCALE) {
                         X[b] += a.sigma_scale * v;
                     } else {
                         X[b] += v;
                     }
                 }
                 if constexpr (X3) {                    // increment panel of this group as hi / lo packs (two S-steps per group)
-                    if (a.sigma_kind == SIGMA_DENSE) {
+                    if (k_sigma == SIGMA_DENSE) {
 #pragma unroll
                         for (int s2 = 0; s2 < (NB + 1) / 2; ++s2) {
                             f16x8 ph, pl;
@@ -776,7 +783,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
             Pz = qsum(Pz);
             if constexpr (LOGU) ULsum = fmaf(UL, dt, ULsum);
             PSP_STAMP(ws5);
-            if (a.sigma_kind == SIGMA_DENSE) {
+            if (k_sigma == SIGMA_DENSE) {
                 PSP_WIDE_SYNC();
                 if constexpr (X3 && kShare) gemm_img_x3s<DB, W::KS8>(X, T + W::xB, img, lds + W::fStage, lane, wave);
                 else if constexpr (X3) gemm_img_x3<DB, W::KS8>(X, T + W::xB, img, lane);
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
 
             // ---- running cost f(X_{n+1}) and Y update (solver.py:477-478)
             float fX = 0.f;
-            if (a.runcost_kind == RUN_DIAGQ) {
+            if (k_run == RUN_DIAGQ) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) {
                     const f32x4 pv = vrun[b * 4];
@@ -794,10 +801,10 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void hjbw_fwd_kernel(const
                 }
                 fX = qsum(fX);
             }
-            if (a.loss_kind == LOSS_RELENT) {
+            if (k_loss == LOSS_RELENT) {
                 Y = Y - (0.5f * S + fX) * dt;           // Y carries -Zsum (hjb_fwd_kernel)
             } else {
-                const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
+                const float drift_y = k_adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
                 Y = Y + drift_y * dt + Pz * sqdt;
             }
             Fsum = fmaf(fX, dt, Fsum);
@@ -1961,6 +1968,15 @@ struct HjbwLaunch {
         hipError_t e = tables(a, 3, s);
         if (e != hipSuccess) return e;
         const int bytes = W::fwd_x3_lds_floats * 4;
+        static const int want_spec = [] { const char* e = getenv("PSP_WIDE_SPEC"); return e ? (e[0] == '1') : 0; }();     // (A/B switch)
+        if (want_spec && a.noise_mode == NOISE_PHILOX && a.tfeat == nullptr && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive &&
+            a.runcost_kind == RUN_ZERO && a.store_path == 1 && a.loss_kind != LOSS_RELENT) {      // the LLGC training launch: SPEC
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, false, true, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((hjbw_fwd_kernel<D, H, false, true, true, true>), dim3(grid), dim3(block), bytes, s, a);
+            return hipGetLastError();
+        }
         if (a.noise_mode == NOISE_PHILOX && a.tfeat == nullptr) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, false, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
