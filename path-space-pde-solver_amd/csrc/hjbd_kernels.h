@@ -286,7 +286,9 @@ __global__ __launch_bounds__(256) void hjbd_tables_kernel(const DnetArgs a, int 
 
 // X3 (psp_hjb_config.mlp_dtype = PSP_MLP_F16X3): every product as split f16 products (gemm_img_x3 / gemm_regs_x3, hjbw_kernels.h) on
 // the tables of hjbd_tables_kernel(.., 2); the two images of a wave hold hi / lo packs
-template <int D, int H, bool X3 = false>
+// SPEC (round 4): dense drift, dense sigma, adaptive process, no running cost, Philox noise, not the relative-entropy loss as
+// compile-time constants -- the LLGC training launch of time_approx='outer' (hjb_kernels.h, hjb_fwd_kernel FAST_ = 2)
+template <int D, int H, bool X3 = false, bool SPEC = false>
 __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const DnetArgs da) {   // d <= 128: two workgroups per CU
     PSP_COND_EXIT(da.h);
     using W = DGeo<D, H>;
@@ -294,6 +296,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
     constexpr int oSets = X3 ? W::oSets_x : W::oSets, SETF = X3 ? W::set_floats_x3 : W::set_floats, IMGF = X3 ? W::IMGX : W::IMG;
     [[maybe_unused]] const f32x4 zero4x = {0.f, 0.f, 0.f, 0.f};
     const HjbArgs& a = da.h;
+    const int k_drift = SPEC ? (int)DRIFT_DENSE : a.drift_kind, k_sigma = SPEC ? (int)SIGMA_DENSE : a.sigma_kind;
+    const int k_run = SPEC ? (int)RUN_ZERO : a.runcost_kind, k_loss = SPEC ? (int)LOSS_LOGVAR : a.loss_kind;
+    const int k_noise = SPEC ? (int)NOISE_PHILOX : a.noise_mode;
+    const bool k_adaptive = SPEC ? true : (a.adaptive != 0);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6;
@@ -302,9 +308,9 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
     const int dr = da.d_real;
 
     stage_vec(lds + W::vdr, DB, tid, nthr, [&](int f) {
-        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+        return (f < D && (k_drift == DRIFT_DIAG || k_drift == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
     stage_vec(lds + W::vrun, DB, tid, nthr, [&](int f) {
-        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+        return (f < D && k_run == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
     stage_vec(lds + W::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
     __syncthreads();
 
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
     // image in the xi slot: c_xi xi + c_z Z.  store_path 1: xi, or xi + sqrt(dt) Z for a non-adaptive process; 2: xi - sqrt(dt) Z
     // and 3: Z for the adjoint sweep (attached forward process / relative entropy), as in hjb_fwd_kernel
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;
-    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
+    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (k_adaptive ? 0.f : a.sqdt));
     const int nsets_m1 = da.per_step ? a.N - 1 : 0;
     const float* Vbase = T + oSets + (long long)(nsets_m1 + 1) * SETF;
 
@@ -392,10 +398,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 for (int b = 0; b < DB; ++b) { xa[2 * HB + b] = Vn[(W::v3 / 16 + b) * 4]; xa[2 * HB + DB + b] = X[b]; }
                 if constexpr (X3) {
                     // (output blocks in groups of at most 8: a correction chain of 24 registers under the 256-register cap)
-                    if (a.drift_kind == DRIFT_DENSE) gemm_img_x3<W::NXB, W::KS8, W::NXB, 8>(xa, Ts + W::xXall, imgX, lane);
+                    if (k_drift == DRIFT_DENSE) gemm_img_x3<W::NXB, W::KS8, W::NXB, 8>(xa, Ts + W::xXall, imgX, lane);
                     else gemm_img_x3<2 * HB + DB, W::KS8, W::NXB, 8>(reinterpret_cast<f32x4 (&)[2 * HB + DB]>(xa), Ts + W::xXall, imgX, lane);
                 } else {
-                    if (a.drift_kind == DRIFT_DENSE) gemm_img<W::NXB, KP, W::NXB>(xa, Ts + W::tXall, imgX, lane);
+                    if (k_drift == DRIFT_DENSE) gemm_img<W::NXB, KP, W::NXB>(xa, Ts + W::tXall, imgX, lane);
                     else gemm_img<2 * HB + DB, KP, W::NXB>(reinterpret_cast<f32x4 (&)[2 * HB + DB]>(xa), Ts + W::tXall, imgX, lane);
                 }
 #pragma unroll
@@ -409,17 +415,17 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 else gemm_img<2 * HB, KP>(z12, Ts + W::tW12, imgX, lane);
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Xn[b] = X[b];
-                if (a.drift_kind == DRIFT_DENSE) {
+                if (k_drift == DRIFT_DENSE) {
                     if constexpr (X3) gemm_img_x3<DB, W::KS8>(Xn, T + W::oA_x, imgX, lane);
                     else gemm_img<DB, KP>(Xn, T + W::oA, imgX, lane);
                 }
             }
             // ---- drift part of X_{n+1} (solver.py:471): the dense product is done above
-            if (a.drift_kind == DRIFT_DENSE) {
-            } else if (a.drift_kind == DRIFT_DIAG) {
+            if (k_drift == DRIFT_DENSE) {
+            } else if (k_drift == DRIFT_DIAG) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Xn[b] += dt * (vdr[b * 4] * X[b]);
-            } else if (a.drift_kind == DRIFT_DWELL) {
+            } else if (k_drift == DRIFT_DWELL) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) Xn[b] -= dt * (4.0f * vdr[b * 4] * (X[b] * (X[b] * X[b] - 1.0f)));
             }
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 for (int m = 0; m < NB; ++m) {
                     const int b = 4 * g + m;
                     f32x4 xi;
-                    if (a.noise_mode == NOISE_PHILOX) {
+                    if (k_noise == NOISE_PHILOX) {
                         xi = philox_block(kglob, (uint32_t)n, (uint32_t)(4 * b + qn), a.iter, a.seed_lo, a.seed_hi);
                     } else {
                         const float* xrow = a.xi + ((size_t)(n + 1) * a.K_local + (kvalid ? k : 0)) * D;
@@ -523,21 +529,21 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                         S = fmaf(Zg[m][r], Zg[m][r], S);
                         Pz = fmaf(Zg[m][r], xi[r], Pz);
                     }
-                    const f32x4 v = a.adaptive ? (sqdt * xi - dt * Zg[m]) : (sqdt * xi);
-                    if (a.sigma_kind == SIGMA_DENSE) {
+                    const f32x4 v = k_adaptive ? (sqdt * xi - dt * Zg[m]) : (sqdt * xi);
+                    if (k_sigma == SIGMA_DENSE) {
                         if constexpr (X3) vg[m] = v;
                         else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) imgV[(4 * b + r) * 64 + lane] = v[r];
                         }
-                    } else if (a.sigma_kind == SIGMA_SCALE) {
+                    } else if (k_sigma == SIGMA_SCALE) {
                         Xn[b] += a.sigma_scale * v;
                     } else {
                         Xn[b] += v;
                     }
                 }
                 if constexpr (X3) {                    // increment panel of this group as hi / lo packs (two S-steps per group)
-                    if (a.sigma_kind == SIGMA_DENSE) {
+                    if (k_sigma == SIGMA_DENSE) {
 #pragma unroll
                         for (int s2 = 0; s2 < (NB + 1) / 2; ++s2) {
                             f16x8 ph, pl;
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
             if constexpr (DB % 4 != 0) z_group(std::integral_constant<int, DB % 4>{}, DB / 4);
             S = qsum(S);
             Pz = qsum(Pz);
-            if (a.sigma_kind == SIGMA_DENSE) {                                                // X += B v
+            if (k_sigma == SIGMA_DENSE) {                                                // X += B v
                 if constexpr (X3) gemm_img_x3<DB, W::KS8>(Xn, T + W::oB_x, imgV, lane);
                 else gemm_img<DB, KP>(Xn, T + W::oB, imgV, lane);
             }
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
             for (int b = 0; b < DB; ++b) X[b] = Xn[b];
             // ---- running cost f(X_{n+1}) and Y update (solver.py:477-478)
             float fX = 0.f;
-            if (a.runcost_kind == RUN_DIAGQ) {
+            if (k_run == RUN_DIAGQ) {
 #pragma unroll
                 for (int b = 0; b < DB; ++b) {
                     const f32x4 pv = vrun[b * 4];
@@ -569,10 +575,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void hjbd_fwd_kernel(const
                 }
                 fX = qsum(fX);
             }
-            if (a.loss_kind == LOSS_RELENT) {
+            if (k_loss == LOSS_RELENT) {
                 Y = Y - (0.5f * S + fX) * dt;           // Y carries -Zsum (hjb_fwd_kernel): D = -(Zsum + g), loss = -mean D
             } else {
-                const float drift_y = a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
+                const float drift_y = k_adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S);
                 Y = Y + drift_y * dt + Pz * sqdt;
             }
             Fsum = fmaf(fX, dt, Fsum);
@@ -1244,6 +1250,15 @@ struct DnetLaunch {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const int bytes = W::lds_floats_x3 * 4;
+        const HjbArgs& h = a.h;
+        if (h.noise_mode == NOISE_PHILOX && h.drift_kind == DRIFT_DENSE && h.sigma_kind == SIGMA_DENSE && h.adaptive && h.runcost_kind == RUN_ZERO &&
+            h.loss_kind != LOSS_RELENT && h.uref == nullptr && h.tfeat == nullptr) {            // the LLGC training launch: SPEC
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_fwd_kernel<D, H, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((hjbd_fwd_kernel<D, H, true, true>), dim3(grid), dim3(256), bytes, s, a);
+            return hipGetLastError();
+        }
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_fwd_kernel<D, H, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
