@@ -706,7 +706,7 @@ struct Geo {
 // started.  Worth 1.3 % here (4.78 -> 4.72 ms, same-box A/B), 2 % in hjbs_fwd_kernel, 5 % in hjbq_fwd_kernel, whose steps
 // are short; the larger part of the path store's cost stays (finding 7).
 // FAST_ = 2 (round 4): a FAST instance whose problem switches are COMPILE-TIME too -- dense drift, dense sigma, adaptive process,
-// no running cost, store_path 4, not the relative-entropy loss: the LLGC configuration of every BASELINE config.  The time loop of
+// no running cost, store_path 1 or 4, not the relative-entropy loss: the LLGC configuration of every BASELINE config.  The time loop of
 // the general instance tests those wave-uniform switches at run time: ~100 scalar branches per step, each one a basic-block
 // boundary that the scheduler cannot move the path stores, the Philox slices or the operand prefetches across.
 template <int D, int H, int MODE = 0, int FAST_ = 0>
@@ -716,7 +716,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     // the problem switches: kernel arguments in the general instances, constants in the specialised one
     const int k_drift = SPEC ? (int)DRIFT_DENSE : a.drift_kind, k_sigma = SPEC ? (int)SIGMA_DENSE : a.sigma_kind;
     const int k_run = SPEC ? (int)RUN_ZERO : a.runcost_kind, k_loss = SPEC ? (int)LOSS_LOGVAR : a.loss_kind;
-    const int k_store = SPEC ? 4 : a.store_path;
+    const int k_store = a.store_path;                             // (SPEC: 1 or 4 -- the xi image is kept or regenerated; ONE instance for both,
+                                                                  //  so that the two modes stay bit-identical: tests/test_gpu_path_noise.py)
     const bool k_adaptive = SPEC ? true : (a.adaptive != 0);
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
@@ -782,8 +783,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
     const uint32_t kglob = (uint32_t)(a.k_offset + k);
     const float dt = a.dt, sqdt = a.sqdt;
 
-    const float store_cxi = (k_store == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
-    const float store_cz = (k_store == 3) ? 1.f : (k_store == 2 ? -a.sqdt : (k_adaptive ? 0.f : a.sqdt));
+    const float store_cxi = SPEC ? 1.f : ((k_store == 3) ? 0.f : 1.f);     // image in the xi slot: c_xi xi + c_z Z
+    const float store_cz = SPEC ? 0.f : ((k_store == 3) ? 1.f : (k_store == 2 ? -a.sqdt : (k_adaptive ? 0.f : a.sqdt)));
     // FAST instances always keep the path (the launcher sends store_path = 0 to the general instance): without the
     // wave-uniform branch the stores share a scheduling region with the products instead of standing as bursts of 28 - 32
     const bool do_store = FAST ? true : (k_store != 0);
@@ -1934,9 +1935,9 @@ struct HjbLaunch {
     }
     // every product fp32-grade on the f16 matrix pipe (gemm_Tx)
     static hipError_t fwd_x3(const HjbArgs& a, int grid, int block, hipStream_t s) {
-        // (the specialised instance: dense drift and sigma, adaptive, no running cost, store_path 4 -- hjb_fwd_kernel, FAST_ = 2)
+        // (the specialised instance: dense drift and sigma, adaptive, no running cost, store_path 1 / 4 -- hjb_fwd_kernel, FAST_ = 2)
         const bool spec = fast(a) && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive && a.runcost_kind == RUN_ZERO &&
-                          a.store_path == 4 && a.loss_kind != LOSS_RELENT;
+                          (a.store_path == 4 || a.store_path == 1) && a.loss_kind != LOSS_RELENT;
         return spec ? fwd_as<2, 2>(a, grid, block, s) : fast(a) ? fwd_as<2, 1>(a, grid, block, s) : fwd_as<2, 0>(a, grid, block, s);
     }
 #ifdef PSP_LEGACY_BWD

@@ -59,8 +59,13 @@ __device__ __forceinline__ float bsum16(float v) {       // sum over the 16 bloc
 // FAST: on-device noise, no u_L2 log, no time-feature table (decided at launch).  The time loop of that instance has no
 // vector-memory LOAD: a load in a wave-uniform branch costs the common path an `s_waitcnt vmcnt(0)` at the join, and vmcnt
 // counts in order, so the wave would wait for its own path-store writes three times per step.
-template <int D, int H, bool FAST>
+template <int D, int H, int FAST_>
 __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArgs a) {
+    // FAST_ = 2: the problem switches of the LLGC configurations as compile-time constants (hjb_kernels.h, hjb_fwd_kernel)
+    constexpr bool FAST = FAST_ != 0, SPEC = FAST_ == 2;
+    const int k_drift = SPEC ? (int)DRIFT_DENSE : a.drift_kind, k_sigma = SPEC ? (int)SIGMA_DENSE : a.sigma_kind;
+    const int k_run = SPEC ? (int)RUN_ZERO : a.runcost_kind, k_loss = SPEC ? (int)LOSS_LOGVAR : a.loss_kind;
+    const bool k_adaptive = SPEC ? true : (a.adaptive != 0);
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     using Q = GeoQ<D, H>;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
     const int wrow = lane;                               // weight holder: row 4 blk + c of a slab, c = lane & 3
     const float* __restrict__ P = a.params;
     const float dt = a.dt, sqdt = a.sqdt;
-    const bool denseA = a.drift_kind == DRIFT_DENSE, denseB = a.sigma_kind == SIGMA_DENSE;
+    const bool denseA = k_drift == DRIFT_DENSE, denseB = k_sigma == SIGMA_DENSE;
 
     // ---- the state feature and the hidden unit this lane owns
     const int s = blk >> 2, r = blk & 3;
@@ -89,8 +94,8 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
     const bool mvalid = hslot && m < H;
     const int mc = mvalid ? m : 0;
     const float b3f = fvalid ? P[G::ob3 + fc] : 0.f;
-    const float vdrf = (fvalid && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[fc] : 0.f;
-    const float vrunf = (fvalid && a.runcost_kind == RUN_DIAGQ) ? a.runcost[fc] : 0.f;
+    const float vdrf = (fvalid && (k_drift == DRIFT_DIAG || k_drift == DRIFT_DWELL)) ? a.drift[fc] : 0.f;
+    const float vrunf = (fvalid && k_run == RUN_DIAGQ) ? a.runcost[fc] : 0.f;
     const float vtermf = fvalid ? a.term[fc] : 0.f;
     const float b1m = mvalid ? P[G::ob1 + mc] : 0.f;
     const float w1tm = mvalid ? P[G::oW1 + mc * (D + 1)] : 0.f;
@@ -199,7 +204,7 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
     const int offH = (4 * (m >> 4) + ((m >> 2) & 3)) * 64 + 16 * (m & 3) + j16;
     const bool storing = a.store_path != 0;
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
-    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
+    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (k_adaptive ? 0.f : a.sqdt));
 
     float x = 0.f;                                       // X_0 (solver.py:365-367)
     {
@@ -371,12 +376,12 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
             const float e = fvalid ? Z + a.uref[(size_t)n * D + fc] : 0.f;
             UL = e * e;
         }
-        const float v = a.adaptive ? (sqdt * xi - dt * Z) : (sqdt * xi);        // v = c dt + xi sqrt(dt)
+        const float v = k_adaptive ? (sqdt * xi - dt * Z) : (sqdt * xi);        // v = c dt + xi sqrt(dt)
         // X_{n+1} = X + b(X) dt + sigma v   (solver.py:471-472)
         float xn = x;
         if (denseA) xn += drs;
-        else if (a.drift_kind == DRIFT_DIAG) xn += dt * (vdrf * x);
-        else if (a.drift_kind == DRIFT_DWELL) xn -= dt * (4.0f * vdrf * (x * (x * x - 1.0f)));
+        else if (k_drift == DRIFT_DIAG) xn += dt * (vdrf * x);
+        else if (k_drift == DRIFT_DWELL) xn -= dt * (4.0f * vdrf * (x * (x * x - 1.0f)));
         if (denseB) {
             f32x4 bv[SD];
 #pragma unroll
@@ -394,7 +399,7 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
             PSP_ACC(5, qe0, qd1);   // wait at barrier 4
 #pragma unroll
             for (int p = 0; p < W; ++p) xn += partBV[p * RD * 4 + rdD];
-        } else if (a.sigma_kind == SIGMA_SCALE) {
+        } else if (k_sigma == SIGMA_SCALE) {
             xn += a.sigma_scale * v;
         } else {
             xn += v;
@@ -403,8 +408,8 @@ __global__ __launch_bounds__((GeoQ<D, H>::NT)) void hjbq_fwd_kernel(const HjbArg
         // running cost f(X_{n+1}) and this lane's share of the Y update (solver.py:477-478): linear in the row sums
         const float fX = vrunf * x * x;
         const float S = Z * Z;
-        const float term = (a.loss_kind == LOSS_RELENT) ? -(0.5f * S + fX) * dt          // Y carries -Zsum (hjb_fwd_kernel)
-                           : (a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S)) * dt + (Z * xi) * sqdt;
+        const float term = (k_loss == LOSS_RELENT) ? -(0.5f * S + fX) * dt          // Y carries -Zsum (hjb_fwd_kernel)
+                           : (k_adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S)) * dt + (Z * xi) * sqdt;
         Yw += term;
         Fw = fmaf(fX, dt, Fw);
         ULw = fmaf(UL, dt, ULw);
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(512) void hjbq_adj_kernel(const HjbArgs a) {
 template <int D, int H>
 struct HjbqLaunch {
     static int lds_bytes() { return GeoQ<D, H>::fits ? GeoQ<D, H>::lds_floats * 4 : (1 << 30); }
-    template <bool FAST>
+    template <int FAST>
     static hipError_t fwd_as(const HjbArgs& a, int grid, hipStream_t s) {
         const int bytes = lds_bytes();
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbq_fwd_kernel<D, H, FAST>),
@@ -768,7 +773,9 @@ struct HjbqLaunch {
     static hipError_t fwd(const HjbArgs& a, int grid, hipStream_t s) {
         if constexpr (GeoQ<D, H>::fits) {
             const bool fast = a.noise_mode == NOISE_PHILOX && a.uref == nullptr && a.tfeat == nullptr;
-            return fast ? fwd_as<true>(a, grid, s) : fwd_as<false>(a, grid, s);
+            const bool spec = fast && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive && a.runcost_kind == RUN_ZERO &&
+                              a.loss_kind != LOSS_RELENT;
+            return spec ? fwd_as<2>(a, grid, s) : fast ? fwd_as<1>(a, grid, s) : fwd_as<0>(a, grid, s);
         } else {
             return hipErrorInvalidValue;
         }

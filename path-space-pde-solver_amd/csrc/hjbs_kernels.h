@@ -37,8 +37,13 @@ struct GeoS {
 // FAST: on-device noise, no u_L2 log, no time-feature table (decided at launch).  The time loop of that instance has no
 // vector-memory LOAD: a load in a wave-uniform branch leaves an `s_waitcnt vmcnt(0)` at the join on the common path, and
 // vmcnt counts in order, so every step waited for its own path-store writes (hjbq_kernels.h has the same split).
-template <int D, int H, bool FAST>
+template <int D, int H, int FAST_>
 __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const HjbArgs a) {
+    // FAST_ = 2: the problem switches of the LLGC configurations as compile-time constants (hjb_kernels.h, hjb_fwd_kernel)
+    constexpr bool FAST = FAST_ != 0, SPEC = FAST_ == 2;
+    const int k_drift = SPEC ? (int)DRIFT_DENSE : a.drift_kind, k_sigma = SPEC ? (int)SIGMA_DENSE : a.sigma_kind;
+    const int k_run = SPEC ? (int)RUN_ZERO : a.runcost_kind, k_loss = SPEC ? (int)LOSS_LOGVAR : a.loss_kind;
+    const bool k_adaptive = SPEC ? true : (a.adaptive != 0);
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;       // wave-uniform scalar load
     using G = Geo<D, H>;
     using S_ = GeoS<D, H>;
@@ -55,16 +60,16 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
     stage_vec(lds + S_::vb2, HB, tid, nthr, [&](int f) { return f < H ? P[G::ob2 + f] : 0.f; });
     stage_vec(lds + S_::vb3, DB, tid, nthr, [&](int f) { return f < D ? P[G::ob3 + f] : 0.f; });
     stage_vec(lds + S_::vdr, DB, tid, nthr, [&](int f) {
-        return (f < D && (a.drift_kind == DRIFT_DIAG || a.drift_kind == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
+        return (f < D && (k_drift == DRIFT_DIAG || k_drift == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
     stage_vec(lds + S_::vrun, DB, tid, nthr, [&](int f) {
-        return (f < D && a.runcost_kind == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
+        return (f < D && k_run == RUN_DIAGQ) ? a.runcost[f] : 0.f; });
     stage_vec(lds + S_::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
 
     // ---- this wave's weight slices as A-operand fragments: lane (i, q) of fragment (block mb, k-step ks) holds
     //      W[16 mb + rowmap(i)][4 ks + q]  (rowmap as in stage_aop)
     const int ri = 4 * ((lane & 15) & 3) + ((lane & 15) >> 2);
     float w1r[NHo][KD], w2r[NHo][KH], w3r[NBo][KH], ar[NBo][KD], br[NBo][KD];
-    const bool denseA = a.drift_kind == DRIFT_DENSE, denseB = a.sigma_kind == SIGMA_DENSE;
+    const bool denseA = k_drift == DRIFT_DENSE, denseB = k_sigma == SIGMA_DENSE;
 #pragma unroll
     for (int io = 0; io < NHo; ++io) {
         const int row = 16 * (wave + W * io) + ri;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
         }
     float Yw = 0.f, Fw = 0.f, ULw = 0.f;               // this wave's partial of Y, of the running-cost integral and of u_L2
     const float store_cxi = (a.store_path == 3) ? 0.f : 1.f;                    // image in the xi slot: c_xi xi + c_z Z
-    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (a.adaptive ? 0.f : a.sqdt));
+    const float store_cz = (a.store_path == 3) ? 1.f : (a.store_path == 2 ? -a.sqdt : (k_adaptive ? 0.f : a.sqdt));
 
 #ifdef PSP_STAMPS
     unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -184,13 +189,13 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
                     for (int io = 0; io < NHo; ++io) h1[io] = mfma16(w1r[io][ks], bx[ks], h1[io]);
             }
         }
-        if (a.drift_kind == DRIFT_DIAG) {
+        if (k_drift == DRIFT_DIAG) {
 #pragma unroll
             for (int io = 0; io < NBo; ++io) {
                 const int sb = (wave + W * io) < DB ? (wave + W * io) : DB - 1;
                 X[io] += dt * (vdr[sb * 4] * X[io]);
             }
-        } else if (a.drift_kind == DRIFT_DWELL) {
+        } else if (k_drift == DRIFT_DWELL) {
 #pragma unroll
             for (int io = 0; io < NBo; ++io) {
                 const int sb = (wave + W * io) < DB ? (wave + W * io) : DB - 1;
@@ -308,11 +313,11 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
                         UL = fmaf(e, e, UL);
                     }
                 }
-                const f32x4 v = a.adaptive ? (sqdt * xi - dt * Z[io]) : (sqdt * xi);     // v = c dt + xi sqrt(dt)
+                const f32x4 v = k_adaptive ? (sqdt * xi - dt * Z[io]) : (sqdt * xi);     // v = c dt + xi sqrt(dt)
                 if (denseB) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) imgV[(4 * sb + r) * 64 + lane] = v[r];
-                } else if (a.sigma_kind == SIGMA_SCALE) {
+                } else if (k_sigma == SIGMA_SCALE) {
                     X[io] += a.sigma_scale * v;
                 } else {
                     X[io] += v;
@@ -336,7 +341,7 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
         // ---- running cost f(X_{n+1}) over the own blocks and the wave's partial of the Y update (solver.py:477-478):
         //      Y += (f -/+ 0.5 |Z|^2) dt + Z.xi sqrt(dt) is linear in the three row sums
         float fX = 0.f;
-        if (a.runcost_kind == RUN_DIAGQ) {
+        if (k_run == RUN_DIAGQ) {
 #pragma unroll
             for (int io = 0; io < NBo; ++io) {
                 const int sb = wave + W * io;
@@ -347,8 +352,8 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
                 }
             }
         }
-        const float term = (a.loss_kind == LOSS_RELENT) ? -(0.5f * S + fX) * dt        // Y carries -Zsum (hjb_fwd_kernel)
-                           : (a.adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S)) * dt + Pz * sqdt;
+        const float term = (k_loss == LOSS_RELENT) ? -(0.5f * S + fX) * dt        // Y carries -Zsum (hjb_fwd_kernel)
+                           : (k_adaptive ? (fX - 0.5f * S) : (fX + 0.5f * S)) * dt + Pz * sqdt;
         Yw += term;
         Fw = fmaf(fX, dt, Fw);
         ULw = fmaf(UL, dt, ULw);
@@ -421,7 +426,7 @@ __global__ __launch_bounds__((64 * GeoS<D, H>::W)) void hjbs_fwd_kernel(const Hj
 template <int D, int H>
 struct HjbsLaunch {
     static int lds_bytes() { return GeoS<D, H>::lds_floats * 4; }
-    template <bool FAST>
+    template <int FAST>
     static hipError_t fwd_as(const HjbArgs& a, int grid, hipStream_t s) {
         const int bytes = lds_bytes();
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbs_fwd_kernel<D, H, FAST>),
@@ -432,7 +437,9 @@ struct HjbsLaunch {
     }
     static hipError_t fwd(const HjbArgs& a, int grid, hipStream_t s) {
         const bool fast = a.noise_mode == NOISE_PHILOX && a.uref == nullptr && a.tfeat == nullptr;
-        return fast ? fwd_as<true>(a, grid, s) : fwd_as<false>(a, grid, s);
+        const bool spec = fast && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive && a.runcost_kind == RUN_ZERO &&
+                          a.loss_kind != LOSS_RELENT;
+        return spec ? fwd_as<2>(a, grid, s) : fast ? fwd_as<1>(a, grid, s) : fwd_as<0>(a, grid, s);
     }
 };
 

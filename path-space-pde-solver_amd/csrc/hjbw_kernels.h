@@ -1968,15 +1968,8 @@ struct HjbwLaunch {
         hipError_t e = tables(a, 3, s);
         if (e != hipSuccess) return e;
         const int bytes = W::fwd_x3_lds_floats * 4;
-        static const int want_spec = [] { const char* e = getenv("PSP_WIDE_SPEC"); return e ? (e[0] == '1') : 0; }();     // (A/B switch)
-        if (want_spec && a.noise_mode == NOISE_PHILOX && a.tfeat == nullptr && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive &&
-            a.runcost_kind == RUN_ZERO && a.store_path == 1 && a.loss_kind != LOSS_RELENT) {      // the LLGC training launch: SPEC
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, false, true, true, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((hjbw_fwd_kernel<D, H, false, true, true, true>), dim3(grid), dim3(block), bytes, s, a);
-            return hipGetLastError();
-        }
+        // (a SPEC instance -- hjbw_fwd_kernel's last template argument -- measured SLOWER here: the larger scheduling regions cost the
+        //  d = 500 kernel 158 spilled registers, 16.4 -> 18.6 ms, and leave d = 200 unchanged, 3.52 vs 3.56 ms; it is not instantiated)
         if (a.noise_mode == NOISE_PHILOX && a.tfeat == nullptr) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_fwd_kernel<D, H, false, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
