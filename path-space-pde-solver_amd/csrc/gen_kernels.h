@@ -1610,7 +1610,7 @@ struct GenLaunch {
     }
     // specialised problem kinds (gen_fwd_kernel SPECK): unbounded, non-adaptive, path store on, no per-step value output
     static int spec_kind(const GenArgs& a) {
-        if (a.noise_mode != NOISE_PHILOX || a.domain_kind != DOM_NONE || a.adaptive || a.store_path != 1 || a.Vsteps != nullptr) return -1;
+        if (!spec_enabled() || a.noise_mode != NOISE_PHILOX || a.domain_kind != DOM_NONE || a.adaptive || a.store_path != 1 || a.Vsteps != nullptr) return -1;
         if (a.drift_kind == DRIFT_DWELL && a.h_kind == GH_QUAD) return DRIFT_DWELL | (GH_QUAD << 4);
         if (a.drift_kind == DRIFT_ZERO && a.h_kind == GH_ALLEN_CAHN) return DRIFT_ZERO | (GH_ALLEN_CAHN << 4);
         return -1;

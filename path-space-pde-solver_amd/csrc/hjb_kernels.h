@@ -15,6 +15,7 @@
 // fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision), which is what lets
 // the loss match the reference's fp32 CPU path to ~1e-6.
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -87,6 +88,13 @@ struct GradCheck {
         }
     }
 };
+
+// A/B switch for the specialised forward instances (hjb_fwd_kernel FAST_ = 2 and its siblings): PSP_NO_SPEC=1 sends every launch
+// to the general instance (diagnostics; read once)
+inline bool spec_enabled() {
+    static const bool on = [] { const char* e = getenv("PSP_NO_SPEC"); return !(e && e[0] == '1'); }();
+    return on;
+}
 
 // ---- enums mirrored from include/psp.h (kept numeric here to avoid including C header in device code)
 enum { DRIFT_ZERO = 0, DRIFT_DENSE = 1, DRIFT_DIAG = 2, DRIFT_DWELL = 3 };
@@ -1936,7 +1944,7 @@ struct HjbLaunch {
     // every product fp32-grade on the f16 matrix pipe (gemm_Tx)
     static hipError_t fwd_x3(const HjbArgs& a, int grid, int block, hipStream_t s) {
         // (the specialised instance: dense drift and sigma, adaptive, no running cost, store_path 1 / 4 -- hjb_fwd_kernel, FAST_ = 2)
-        const bool spec = fast(a) && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive && a.runcost_kind == RUN_ZERO &&
+        const bool spec = spec_enabled() && fast(a) && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive && a.runcost_kind == RUN_ZERO &&
                           (a.store_path == 4 || a.store_path == 1) && a.loss_kind != LOSS_RELENT;
         return spec ? fwd_as<2, 2>(a, grid, block, s) : fast(a) ? fwd_as<2, 1>(a, grid, block, s) : fwd_as<2, 0>(a, grid, block, s);
     }

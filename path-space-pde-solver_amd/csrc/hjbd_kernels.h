@@ -1251,7 +1251,7 @@ struct DnetLaunch {
         if (e != hipSuccess) return e;
         const int bytes = W::lds_floats_x3 * 4;
         const HjbArgs& h = a.h;
-        if (h.noise_mode == NOISE_PHILOX && h.drift_kind == DRIFT_DENSE && h.sigma_kind == SIGMA_DENSE && h.adaptive && h.runcost_kind == RUN_ZERO &&
+        if (spec_enabled() && h.noise_mode == NOISE_PHILOX && h.drift_kind == DRIFT_DENSE && h.sigma_kind == SIGMA_DENSE && h.adaptive && h.runcost_kind == RUN_ZERO &&
             h.loss_kind != LOSS_RELENT && h.uref == nullptr && h.tfeat == nullptr) {            // the LLGC training launch: SPEC
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbd_fwd_kernel<D, H, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

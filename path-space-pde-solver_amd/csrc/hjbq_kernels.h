@@ -773,7 +773,7 @@ struct HjbqLaunch {
     static hipError_t fwd(const HjbArgs& a, int grid, hipStream_t s) {
         if constexpr (GeoQ<D, H>::fits) {
             const bool fast = a.noise_mode == NOISE_PHILOX && a.uref == nullptr && a.tfeat == nullptr;
-            const bool spec = fast && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive && a.runcost_kind == RUN_ZERO &&
+            const bool spec = spec_enabled() && fast && a.drift_kind == DRIFT_DENSE && a.sigma_kind == SIGMA_DENSE && a.adaptive && a.runcost_kind == RUN_ZERO &&
                               a.loss_kind != LOSS_RELENT;
             return spec ? fwd_as<2>(a, grid, s) : fast ? fwd_as<1>(a, grid, s) : fwd_as<0>(a, grid, s);
         } else {
