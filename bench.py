@@ -534,12 +534,15 @@ def mfma_roofline(fl2, fl3, issued, units, tiles_steps, ms, bf16_mlp, which):
 
 
 def load_counters(workload, kernel):
-    """Committed PMC means per launch of `kernel` in `workload` (profiles/r3_counters.json, written by
-    tools/r3/make_counters_json.py from the separate --pmc passes of tools/pmc_passes.sh), or {}."""
-    cpath = os.path.join(ROOT, "profiles", "r3_counters.json")
-    if not os.path.exists(cpath):
-        return {}
-    return json.load(open(cpath)).get(workload, {}).get(kernel, {}) or {}
+    """Committed PMC means per launch of `kernel` in `workload` (profiles/r4_counters.json -- this round's kernels --, else
+    profiles/r3_counters.json; written by tools/r3/make_counters_json.py from the separate --pmc passes of tools/pmc_passes.sh), or {}."""
+    for name in ("r4_counters.json", "r3_counters.json"):
+        cpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(cpath):
+            ent = json.load(open(cpath)).get(workload, {}).get(kernel, {})
+            if ent:
+                return ent
+    return {}
 
 
 def binder_of(mf_frac, hbm_alg_frac, hbm_store_frac, counters, tiles_steps):

@@ -72,6 +72,7 @@ struct GenlArgs {
     int n_tiles;                    // weight-gradient tiles: sum_i off[i + 1] * HB[i]
     int tcum[GENL_MAXL + 1];        // tiles of the layers below i
     long long P;
+    long long table_floats;         // size of the table region (TLDS instances copy it into LDS)
 };
 
 // padded feature index -> real index inside the concatenation a (or -1: padding)
@@ -232,8 +233,7 @@ __device__ __forceinline__ int genl_layer_of(KArgs a, int hb) {
 // r_i of ITS hidden blocks in Rr (slot s <-> hidden block wave + NW s); returns V.  Padded rows / features carry zero weights
 // and biases, so they stay exactly zero.
 template <int NW>
-__device__ __forceinline__ float genl_value(KArgs a, float* A, f32x4 (&Rr)[GenlGeo<NW>::MAXSLOT], int lane, int q, int wave) {
-    const float* __restrict__ T = a->tables;
+__device__ __forceinline__ float genl_value(KArgs a, const float* __restrict__ T, float* A, f32x4 (&Rr)[GenlGeo<NW>::MAXSLOT], int lane, int q, int wave) {
     for (int i = 0; i < a->L; ++i) {
         const int HBi = a->HB[i];
         const int seg = a->off[i + 1];                                // first block of this layer's output segment = its input blocks
@@ -259,9 +259,8 @@ __device__ __forceinline__ float genl_value(KArgs a, float* A, f32x4 (&Rr)[GenlG
 // ---- grad of V w.r.t. the input segment by the reverse sweep: G (TB blocks) <- w; for i = L..1: G_h *= phi1(r) in place (= gz),
 // G[0 .. seg) += W_i gz.  On return blocks 0 .. DB0 - 1 of G hold grad_{[x, t]} V.
 template <int NW>
-__device__ __forceinline__ void genl_input_gradient(KArgs a, const f32x4 (&Rr)[GenlGeo<NW>::MAXSLOT], float* G, int lane,
-                                                    int q, int wave) {
-    const float* __restrict__ T = a->tables;
+__device__ __forceinline__ void genl_input_gradient(KArgs a, const float* __restrict__ T, const f32x4 (&Rr)[GenlGeo<NW>::MAXSLOT], float* G,
+                                                    int lane, int q, int wave) {
     for (int b = wave; b < a->TB; b += NW) img_put(G, b, vec_get(T + a->vW, b, q), lane);
     tile_sync<NW>();
     for (int i = a->L - 1; i >= 0; --i) {
@@ -288,14 +287,25 @@ __host__ __device__ inline int genl_fwd_lds_bytes(int TB) { return 2 * TB * 1024
 // (NW = 4: two workgroups per CU at 256 registers a wave -- the step chain of a tile is bound by the L2 latency of its table
 //  operands and by its barriers, not by the matrix pipe, so two tiles in flight per CU are worth more than eight waves on one
 //  once the batch fills the chip; NW = 8 for small batches, where the latency of ONE tile is what counts)
-template <int NW>
+// TLDS (one-wave instances of small nets): the whole table region is copied into LDS behind the images at kernel start -- the step
+// chain of a small net is a sequence of ~20 tiny products, each of which otherwise opens with the full L2 latency of its first
+// operands (`Committor function.ipynb`'s net: 29 KB of tables, 15 us per step from L2)
+template <int NW, bool TLDS = false>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) void genl_fwd_kernel(const GenlArgs ga_) {
     PSP_COND_EXIT(ga_.g);
+    static_assert(!TLDS || NW == 1, "LDS-resident tables: one-wave instances only");
     const KArgs ga = &ga_;
     const KGen a = &ga->g;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* A = lds;
     float* G = A + ga->TB * 256;
+    const float* __restrict__ T = ga->tables;
+    if constexpr (TLDS) {
+        float* Tl = lds + 2 * ga->TB * 256;
+        for (long long i = threadIdx.x; i < ga->table_floats / 4; i += 64 * NW)
+            reinterpret_cast<f32x4*>(Tl)[i] = reinterpret_cast<const f32x4*>(ga->tables)[i];
+        T = Tl;
+    }
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool w0 = wave == 0;                                       // every wave carries the tile's state; wave 0 writes the outputs
@@ -355,9 +365,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) void genl_fwd_kernel(cons
         //  lanes; an opaque copy of q per step keeps them as one v_cmp where they are used)
         const int qv = opaque_i(q);
         put_state();
-        const float Vnow = genl_value<NW>(ga, A, Rr, lane, q, wave);
+        const float Vnow = genl_value<NW>(ga, T, A, Rr, lane, q, wave);
         if (n == 0) Y = Vnow;                                        // solver.py:1081 / :721
-        genl_input_gradient<NW>(ga, Rr, G, lane, q, wave);
+        genl_input_gradient<NW>(ga, T, Rr, G, lane, q, wave);
         const float alivef = stopped ? 0.f : 1.f;
         auto noise_block = [&](int b) __attribute__((always_inline)) {
             f32x4 xi;
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) void genl_fwd_kernel(cons
     }
     // final point: V(X_N, t_N) (solver.py:1163 / :799) as an extra value-only sample
     put_state();
-    const float VN = genl_value<NW>(ga, A, Rr, lane, q, wave);
+    const float VN = genl_value<NW>(ga, T, A, Rr, lane, q, wave);
     if (a->store_path && w0) {
         float* pblk = a->path + ((size_t)a->N * a->ntile16 + t16) * PBL + lane;
 #pragma unroll
@@ -522,9 +532,10 @@ __host__ __device__ inline int genl_bwd_lds_bytes(int TB, int DB0, int NW) {
     return (4 * TB - 2 * DB0 + 2) * 1024 + NW * 32 * 4;
 }
 
-template <int NW>
+template <int NW, bool TLDS = false>
 __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
     PSP_COND_EXIT(ga_.g);
+    static_assert(!TLDS || NW == 1, "LDS-resident tables: one-wave instances only");
     const KArgs ga = &ga_;
     const KGen a = &ga->g;
     const float* __restrict__ T = ga->tables;
@@ -537,6 +548,12 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
     float* AB = Ad + TB * 256;        // abar of hidden block hb at AB + 256 hb; zbar_i in place once layer i has been swept
     float* ABd = AB + (HBS + 1) * 256;    // abar' / zbar_i'
     int* tdesc = reinterpret_cast<int*>(ABd + (HBS + 1) * 256);
+    if constexpr (TLDS) {                                            // tables behind the tile descriptors (genl_fwd_kernel)
+        float* Tl = reinterpret_cast<float*>(tdesc + NW * GenlGeo<NW>::MAXT);
+        for (long long i = threadIdx.x; i < ga->table_floats / 4; i += 64 * NW)
+            reinterpret_cast<f32x4*>(Tl)[i] = reinterpret_cast<const f32x4*>(ga->tables)[i];
+        T = Tl;
+    }
     const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int Kpad = a->ntile16 * 16;
@@ -702,16 +719,16 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
 }
 
 // host side: launches (the dynamic LDS size exceeds the 64 KiB default)
-template <int NW> inline hipError_t genl_launch_fwd(const GenlArgs& a, int ntile16, int lds_bytes, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&genl_fwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+template <int NW, bool TLDS = false> inline hipError_t genl_launch_fwd(const GenlArgs& a, int ntile16, int lds_bytes, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&genl_fwd_kernel<NW, TLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(genl_fwd_kernel<NW>, dim3(ntile16), dim3(64 * NW), lds_bytes, st, a);
+    hipLaunchKernelGGL((genl_fwd_kernel<NW, TLDS>), dim3(ntile16), dim3(64 * NW), lds_bytes, st, a);
     return hipGetLastError();
 }
-template <int NW> inline hipError_t genl_launch_bwd(const GenlArgs& a, int grid, int groups, int lds_bytes, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&genl_bwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+template <int NW, bool TLDS = false> inline hipError_t genl_launch_bwd(const GenlArgs& a, int grid, int groups, int lds_bytes, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&genl_bwd_kernel<NW, TLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(genl_bwd_kernel<NW>, dim3(grid, groups), dim3(64 * NW), lds_bytes, st, a);
+    hipLaunchKernelGGL((genl_bwd_kernel<NW, TLDS>), dim3(grid, groups), dim3(64 * NW), lds_bytes, st, a);
     return hipGetLastError();
 }
 

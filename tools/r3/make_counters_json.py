@@ -11,7 +11,8 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-out_path = os.path.join(ROOT, "profiles", "r3_counters.json")
+import sys
+out_path = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r3_counters.json")     # r4: make_counters_json.py r4_counters.json
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 out["_comment"] = __doc__.strip().replace("\n", " ")
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "*_summary.txt"))):
