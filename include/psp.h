@@ -404,13 +404,19 @@ enum { PSP_ACT_RELU2 = 0,   /* h = relu(z)^2   (function_space.py:138)          
        PSP_ACT_TANH = 2 };  /* h = tanh(z)     (function_space.py:157)                        */
 
 typedef struct psp_genl_config {
-    psp_gen_config base;      /* d = state dimension; H, mlp_dtype, d_real, v_steps_out, y_steps_out, per_sample_weights, range_flag unused */
+    psp_gen_config base;      /* d = state dimension; H, mlp_dtype, d_real, range_flag unused */
     int32_t has_time;         /* 1: network input [x, t] (GeneralSolver), 0: [x] (EllipticSolver; base.T = +inf)                 */
     int32_t n_hidden;         /* L                                                                                              */
     int32_t widths[4];        /* H_1 .. H_L                                                                                     */
     int32_t activation;       /* PSP_ACT_*                                                                                      */
     int32_t linear_layout;    /* 0: weights stored (in, out) (DenseNet); 1: (out, in) (nn.Linear, DenseNet_tanh)                */
+    int32_t time_first;       /* 1: the net's input is [t, x] (Solver.Y_n, solver.py:338) instead of [x, t]: only the parameter
+                               * index map changes, the kernels keep the time in their last input row                          */
+    float time_scale;         /* the net sees time_scale * t (0 = 1): Solver's value-function ansatz feeds the STEP INDEX
+                               * n = t / dt as the time (solver.py:336, 439)                                                    */
 } psp_genl_config;
+/* base.v_steps_out / y_steps_out / per_sample_weights of the embedded psp_gen_config are honoured by psp_genl_rollout_fwd /
+ * psp_genl_rollout_bwd exactly as by the psp_gen_* entry points (Solver(approx_method='value_function'), plan_value_native.py) */
 
 typedef struct psp_genl_sizes {
     int64_t table_bytes;      /* scratch for the operand tables (rebuilt by every forward call)                                 */

@@ -73,6 +73,9 @@ struct GenlArgs {
     int tcum[GENL_MAXL + 1];        // tiles of the layers below i
     long long P;
     long long table_floats;         // size of the table region (TLDS instances copy it into LDS)
+    int time_first;                 // 1: the net's input is [t, x] (Solver's value-function ansatz, solver.py:338) -- the kernels keep the
+                                    // time in their LAST input row; only the parameter index map differs
+    float time_scale;               // the net sees time_scale * t (value-function ansatz: the step index n = t / dt, solver.py:336, 439)
 };
 
 // padded feature index -> real index inside the concatenation a (or -1: padding)
@@ -85,7 +88,14 @@ __device__ __forceinline__ int genl_real_feature(AP a, int pf) {
     for (int i = 1; i <= GENL_MAXL; ++i) if (i <= a->L && pb >= a->off[i]) s = i;
     const int c = pf - 16 * a->off[s];
     const int width = (s == 0) ? a->D0 : a->H[s - 1];
-    return c < width ? a->roff[s] + c : -1;
+    if (c >= width) return -1;
+    if (s == 0 && a->time_first) return c == a->d ? 0 : c + 1;       // kernel rows [x, t] <-> parameter rows [t, x]
+    return a->roff[s] + c;
+}
+// weight multiplier of a padded input feature: the time row carries time_scale (tables and gradients alike)
+template <class AP>
+__device__ __forceinline__ float genl_feature_scale(AP a, int pf) {
+    return (a->has_time && a->time_scale != 1.0f && pf == a->d) ? a->time_scale : 1.0f;
 }
 // flat parameter index of W_i[input feature rf][unit u] (i = L: the output layer, u = 0)
 template <class AP>
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(256) void genl_tables_kernel(const GenlArgs a) {
             const int ii = lane & 15, q = lane >> 4;
             const int row = 16 * mb + 4 * (ii & 3) + (ii >> 2);
             const int rf = genl_real_feature(&a, 4 * ks + q);
-            T[a.tF[i] + idx] = (row < Hi && rf >= 0) ? P[genl_w_index(&a, i, rf, row)] : 0.f;
+            T[a.tF[i] + idx] = (row < Hi && rf >= 0) ? genl_feature_scale(&a, 4 * ks + q) * P[genl_w_index(&a, i, rf, row)] : 0.f;
         }
         // reverse: [ob][ks / 4][lane][ks & 3], row = 16 ob + rowmap (a padded input feature), k = 4 ks + q (an output unit)
         for (long long idx = gtid; idx < (long long)inb * KSh * 64; idx += gn) {
@@ -121,9 +131,10 @@ __global__ __launch_bounds__(256) void genl_tables_kernel(const GenlArgs a) {
             const long long t = idx >> 8;
             const int ks = 4 * (int)(t % (KSh / 4)) + (int)(idx & 3), ob = (int)(t / (KSh / 4));
             const int ii = lane & 15, q = lane >> 4;
-            const int rf = genl_real_feature(&a, 16 * ob + 4 * (ii & 3) + (ii >> 2));
+            const int pfr = 16 * ob + 4 * (ii & 3) + (ii >> 2);
+            const int rf = genl_real_feature(&a, pfr);
             const int col = 4 * ks + q;
-            T[a.tR[i] + idx] = (col < Hi && rf >= 0) ? P[genl_w_index(&a, i, rf, col)] : 0.f;
+            T[a.tR[i] + idx] = (col < Hi && rf >= 0) ? genl_feature_scale(&a, pfr) * P[genl_w_index(&a, i, rf, col)] : 0.f;
         }
         // bias in T-layout vector staging: [(b * 4 + q) * 4 + r] <- v(16 b + 4 r + q)
         for (long long idx = gtid; idx < (long long)HBi * 16; idx += gn) {
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256) void genl_tables_kernel(const GenlArgs a) {
     for (long long idx = gtid; idx < (long long)a.TB * 16; idx += gn) {       // output layer over the padded concatenation
         const int r = (int)(idx & 3), q = (int)((idx >> 2) & 3), b = (int)(idx >> 4);
         const int rf = genl_real_feature(&a, 16 * b + 4 * r + q);
-        T[a.vW + idx] = rf >= 0 ? P[a.oW[a.L] + rf] : 0.f;
+        T[a.vW + idx] = rf >= 0 ? genl_feature_scale(&a, 16 * b + 4 * r + q) * P[a.oW[a.L] + rf] : 0.f;
     }
 }
 
@@ -367,6 +378,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 1 : 2) void genl_fwd_kernel(cons
         put_state();
         const float Vnow = genl_value<NW>(ga, T, A, Rr, lane, q, wave);
         if (n == 0) Y = Vnow;                                        // solver.py:1081 / :721
+        if (a->Vsteps && w0 && q == 0) {                             // Solver's value-function ansatz: sum_n (Y_n(X_n) - Y)^2 (solver.py:438-440)
+            a->Vsteps[(size_t)n * (a->ntile16 * 16) + k] = Vnow;
+            a->Ysteps[(size_t)n * (a->ntile16 * 16) + k] = Y;
+        }
         genl_input_gradient<NW>(ga, T, Rr, G, lane, q, wave);
         const float alivef = stopped ? 0.f : 1.f;
         auto noise_block = [&](int b) __attribute__((always_inline)) {
@@ -593,9 +608,11 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
         const bool fin = (n == a->N);
         if (!fin && ga->nexec && n >= ga->nexec[t16]) continue;        // the tile had left the time loop: nothing was stored
         const int k = t16 * 16 + j;
-        const float wy = a->wY[k], wv = a->wV[k], ah = a->ahat[(size_t)n * Kpad + k];
+        // per_sample (Solver's value-function ansatz): wY is (N + 1, Kpad) tangent weights and ahat holds the coefficient itself
+        const float wy = a->wY[(a->per_sample ? (size_t)n * Kpad : 0) + k], wv = a->per_sample ? 0.f : a->wV[k];
+        const float ah = a->ahat[(size_t)n * Kpad + k];
         const bool sval = k < a->K_local;
-        const float av = sval ? (fin ? wv : wy * ah) : 0.f;          // coefficient of grad_theta V
+        const float av = sval ? (a->per_sample ? ah : (fin ? wv : wy * ah)) : 0.f;          // coefficient of grad_theta V
         const float ws = (sval && !fin) ? wy : 0.f;                  // weight of the tangent part
         const float* pb = a->path + (size_t)blk * PBL + lane;
         tile_sync<NW>();                                             // the previous block's tiles have been read
@@ -692,7 +709,7 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rf = genl_real_feature(ga, 16 * ib + 4 * q + r);
-                if (rf >= 0 && u < Hi) gp[genl_w_index(ga, i, rf, u)] = accW[s][r];
+                if (rf >= 0 && u < Hi) gp[genl_w_index(ga, i, rf, u)] = genl_feature_scale(ga, 16 * ib + 4 * q + r) * accW[s][r];
             }
         }
     }

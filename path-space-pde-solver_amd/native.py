@@ -104,7 +104,7 @@ class GenSizes(C.Structure):
 
 class GenlConfig(C.Structure):
     _fields_ = [("base", GenConfig), ("has_time", C.c_int32), ("n_hidden", C.c_int32), ("widths", C.c_int32 * 4),
-                ("activation", C.c_int32), ("linear_layout", C.c_int32)]
+                ("activation", C.c_int32), ("linear_layout", C.c_int32), ("time_first", C.c_int32), ("time_scale", C.c_float)]
 
 
 class GenlSizes(C.Structure):

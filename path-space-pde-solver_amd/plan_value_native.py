@@ -56,9 +56,11 @@ def value_eligibility(solver):
         return 'y_n is not a single value net'
     V = nets[0]
     dims = getattr(V, 'nn_dims', None)
-    if not isinstance(V, DenseNet) or dims is None or len(dims) != 4 or dims[1] != dims[2] or dims[3] != 1 \
-            or dims[0] != s.d + 1:
-        return 'the value net is not a DenseNet(%d -> 1) with two equal hidden widths' % (s.d + 1)
+    deep = _deep_net(s, V)
+    if deep is None and (not isinstance(V, DenseNet) or dims is None or len(dims) != 4 or dims[1] != dims[2] or dims[3] != 1
+                         or dims[0] != s.d + 1):
+        return 'the value net is neither a DenseNet(%d -> 1) with two equal hidden widths nor a dense-concat net the ' \
+               'run-time-shaped kernels take (%s)' % (s.d + 1, _deep_net(s, V, why=True))
     spec_fn = getattr(s.problem, 'native_spec', None)
     spec = spec_fn() if spec_fn is not None else None
     if spec is None:
@@ -74,9 +76,30 @@ def value_eligibility(solver):
         return 'a running cost f(x) is not built into the value-net kernels (h = -|z|^2 / 2 is)'
     if not nat.is_built():
         raise nat.NativeLibraryError('libpsp_hip.so is not built; run __graft_entry__.build()')
-    if not shapes.gen_candidates(s.d, dims[1]):
+    if deep is None and not shapes.gen_candidates(s.d, dims[1]):
         return 'no compiled kernel instance covers d=%d, H=%d (see csrc/gen_instances.def)' % (s.d, dims[1])
     return None
+
+
+def _deep_net(solver, V, why=False):
+    """The dense-concat description of a value net that is NOT the two-equal-hidden-layer relu^2 DenseNet of the templated kernels
+    (any depth 1-4, widths <= 128, relu^2 / tanh^2 / tanh: csrc/genl_kernels.h), or None (why=True: the reason instead)."""
+    try:
+        from . import plan_general_deep as pgd
+    except ImportError:
+        import plan_general_deep as pgd
+    spec = pgd.value_net_spec(V, solver.d + 1)
+    if isinstance(spec, str):
+        return spec if why else None
+    dims = spec['dims']
+    templated = (isinstance(V, DenseNet) and len(dims) == 4 and dims[1] == dims[2] and spec['act'] == 'relu2'
+                 and bool(shapes.gen_candidates(solver.d, dims[1])))
+    if templated:
+        return 'the templated kernels take it' if why else None
+    L = len(dims) - 2
+    if L < 1 or L > 4 or max(dims[1:-1]) > 128 or dims[0] > 112:
+        return 'outside 1-4 hidden layers of <= 128 units, input <= 112' if why else None
+    return 'ok' if why else spec
 
 
 class ValueNativePlan:
@@ -96,10 +119,16 @@ class ValueNativePlan:
         self.net = s.y_n[0]
         self.key = None
         self.H = self.net.nn_dims[1]
-        self._flatten(self.net)
+        self.deep = _deep_net(s, self.net)              # value nets of other depths / activations: csrc/genl_kernels.h
+        self._flatten(self.net if self.deep is None else self.deep['params'])
         spec = s.problem.native_spec()
         self._keep = []
-        cfg = nat.GenConfig()
+        if self.deep is not None:
+            self.gcfg = nat.GenlConfig()
+            cfg = self.gcfg.base
+            cfg.d = s.d
+        else:
+            cfg = nat.GenConfig()
         cfg.K_local, cfg.N, cfg.k_offset = self.K_local, s.N, lo
         cfg.dt, cfg.sqrt_dt = float(s.delta_t.item()), float(s.sq_delta_t.item())
         cfg.T = float('inf')                              # no freezing: every trajectory takes all N steps (solver.py:440)
@@ -116,23 +145,48 @@ class ValueNativePlan:
         if drift_vec is not None:
             probe = drift_vec.detach().to(device=dev, dtype=torch.float32).contiguous()
             cfg.drift = nat.ptr(probe)
-        chosen, why = shapes.gen_choose(cfg, s.d, self.H)
-        if chosen is None:
-            raise PlanUnsupported(why)
-        self.d_pad, self.H_pad, sz = chosen
-        self.pad = shapes.GenParamPad(s.d, self.H, self.d_pad, self.H_pad, dev, time_input=True, time_first=True,
-                                      time_scale=1.0 / cfg.dt)
-        if drift_vec is not None:
-            t = self.pad.vec(drift_vec.detach().to(device=dev, dtype=torch.float32)).contiguous()
-            self._keep.append(t)
-            cfg.drift = nat.ptr(t)
-        assert sz.n_params == self.pad.Pp, (sz.n_params, self.pad.Pp)
-        self.sizes = sz
         f32 = torch.float32
         self.Kpad = 16 * ((self.K_local + 15) // 16)
-        self.flat_k = self.pad.new_padded_params()
+        if self.deep is not None:
+            try:
+                from .plan_general_deep import _ACT, _IdentityPad
+            except ImportError:
+                from plan_general_deep import _ACT, _IdentityPad
+            g, dims = self.gcfg, self.deep['dims']
+            g.has_time, g.n_hidden = 1, len(dims) - 2
+            for i, h in enumerate(dims[1:-1]):
+                g.widths[i] = int(h)
+            g.activation, g.linear_layout = _ACT[self.deep['act']], 1 if self.deep['linear'] else 0
+            g.time_first, g.time_scale = 1, 1.0 / cfg.dt               # input [t, x], and t is the step index (solver.py:336-338, 439)
+            if drift_vec is not None:
+                self._keep.append(probe)
+            sz = nat.GenlSizes()
+            rc = self.lib.psp_genl_query(C.byref(g), C.byref(sz))
+            if rc != 0:
+                raise PlanUnsupported(self.lib.psp_last_error().decode())
+            assert sz.n_params == self.P, (sz.n_params, self.P)
+            self.d_pad, self.H_pad = s.d, self.H
+            self.pad = _IdentityPad(self.P)
+            self.flat_k = self.flat
+            self.tables = torch.empty(sz.table_bytes // 4, dtype=f32, device=dev)
+            self.ahat_buf = torch.zeros((sz.ahat_bytes + 3) // 4, dtype=f32, device=dev)      # coefficients, then the tiles' step counts
+            self.ahat = self.ahat_buf[:(s.N + 1) * self.Kpad].view(s.N + 1, self.Kpad)
+        else:
+            chosen, why = shapes.gen_choose(cfg, s.d, self.H)
+            if chosen is None:
+                raise PlanUnsupported(why)
+            self.d_pad, self.H_pad, sz = chosen
+            self.pad = shapes.GenParamPad(s.d, self.H, self.d_pad, self.H_pad, dev, time_input=True, time_first=True,
+                                          time_scale=1.0 / cfg.dt)
+            if drift_vec is not None:
+                t = self.pad.vec(drift_vec.detach().to(device=dev, dtype=torch.float32)).contiguous()
+                self._keep.append(t)
+                cfg.drift = nat.ptr(t)
+            assert sz.n_params == self.pad.Pp, (sz.n_params, self.pad.Pp)
+            self.flat_k = self.pad.new_padded_params()
+            self.ahat = torch.zeros(s.N + 1, self.Kpad, dtype=f32, device=dev)       # written by the forward, then overwritten by AV
+        self.sizes = sz
         self.path = torch.empty(sz.path_bytes // 4, dtype=f32, device=dev)
-        self.ahat = torch.zeros(s.N + 1, self.Kpad, dtype=f32, device=dev)       # written by the forward, then overwritten by AV
         self.ws = torch.zeros(s.N + 1, self.Kpad, dtype=f32, device=dev)
         self.vsteps = torch.zeros(s.N, self.Kpad, dtype=f32, device=dev)
         self.ysteps = torch.zeros(s.N, self.Kpad, dtype=f32, device=dev)
@@ -147,7 +201,7 @@ class ValueNativePlan:
         self.kcount = torch.zeros(1, dtype=torch.int64, device=dev)
         self.t0 = torch.zeros(self.K_local, dtype=f32, device=dev)
         self.grad = torch.empty(self.P, dtype=f32, device=dev)
-        self.grad_k = torch.empty(self.pad.Pp, dtype=f32, device=dev)
+        self.grad_k = self.grad if self.deep is not None else torch.empty(self.pad.Pp, dtype=f32, device=dev)
         self.m = torch.zeros(self.P, dtype=f32, device=dev)
         self.v = torch.zeros(self.P, dtype=f32, device=dev)
         self.sums = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -156,7 +210,7 @@ class ValueNativePlan:
         self.events = None
 
     def _flatten(self, V):
-        params = list(V.W)                      # registration order W1,b1,W2,b2,W3,b3 (include/psp.h)
+        params = list(V) if isinstance(V, (list, tuple)) else list(V.W)      # registration order W1,b1,W2,b2,.. (include/psp.h)
         self.params = params
         self.P = sum(p.numel() for p in params)
         flat = torch.empty(self.P, dtype=torch.float32, device=self.dev)
@@ -196,16 +250,22 @@ class ValueNativePlan:
         else:
             X0 = self.x0_row.repeat(self.K_local, 1)
         x0 = self.pad.last_dim(X0.contiguous())
-        flat_k = self.pad.scatter_params(self.flat, self.flat_k)
+        flat_k = self.flat if self.deep is not None else self.pad.scatter_params(self.flat, self.flat_k)
         self.kcount.zero_()
         ev = None
         if self.events is not None:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
-        nat.check(lib.psp_gen_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(x0), nat.ptr(self.t0), nat.ptr(xi),
-                                          int(s.seed) & 0xFFFFFFFFFFFFFFFF, l, nat.ptr(self.path), nat.ptr(self.ahat),
-                                          nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN_k), nat.ptr(self.tN),
-                                          nat.ptr(self.kcount), st), 'psp_gen_rollout_fwd')
+        if self.deep is not None:
+            nat.check(lib.psp_genl_rollout_fwd(C.byref(self.gcfg), nat.ptr(self.flat), nat.ptr(x0), nat.ptr(self.t0), nat.ptr(xi),
+                                               int(s.seed) & 0xFFFFFFFFFFFFFFFF, l, nat.ptr(self.tables), nat.ptr(self.path),
+                                               nat.ptr(self.ahat_buf), nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN_k),
+                                               nat.ptr(self.tN), nat.ptr(self.kcount), st), 'psp_genl_rollout_fwd')
+        else:
+            nat.check(lib.psp_gen_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(x0), nat.ptr(self.t0), nat.ptr(xi),
+                                              int(s.seed) & 0xFFFFFFFFFFFFFFFF, l, nat.ptr(self.path), nat.ptr(self.ahat),
+                                              nat.ptr(self.VN), nat.ptr(self.YN), nat.ptr(self.XN_k), nat.ptr(self.tN),
+                                              nat.ptr(self.kcount), st), 'psp_gen_rollout_fwd')
         if ev is not None:
             ev[1].record()
         # ---- loss (solver.py:164-168, 499) and the per-sample weights
@@ -231,9 +291,14 @@ class ValueNativePlan:
         av[0, :self.K_local] = ws[0, :self.K_local]
         if ev is not None:
             ev[2].record()
-        nat.check(lib.psp_gen_rollout_bwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.path), nat.ptr(av), nat.ptr(ws), None,
-                                          nat.ptr(self.grad_partial), nat.ptr(self.grad_k), st), 'psp_gen_rollout_bwd')
-        self.pad.gather_grad(self.grad_k, self.grad)
+        if self.deep is not None:
+            nat.check(lib.psp_genl_rollout_bwd(C.byref(self.gcfg), nat.ptr(self.flat), nat.ptr(self.tables), nat.ptr(self.path),
+                                               nat.ptr(self.ahat_buf), nat.ptr(ws), None, nat.ptr(self.grad_partial),
+                                               nat.ptr(self.grad), st), 'psp_genl_rollout_bwd')
+        else:
+            nat.check(lib.psp_gen_rollout_bwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(self.path), nat.ptr(av), nat.ptr(ws), None,
+                                              nat.ptr(self.grad_partial), nat.ptr(self.grad_k), st), 'psp_gen_rollout_bwd')
+            self.pad.gather_grad(self.grad_k, self.grad)
         if ev is not None:
             ev[3].record()
             self.events.append(ev)

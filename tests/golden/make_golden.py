@@ -167,6 +167,8 @@ def run_solver_case(case):
         elif net["kind"] == "densenet":
             model.z_n = ref_fs.DenseNet(d_in=problem.d + 1, d_out=problem.d, lr=skw["lr"],
                                         arch=net["arch"], seed=net["seed"])
+        elif net["kind"] == "value_densenet":             # value-function ansatz with another value net (solver.py:97, 142-162)
+            model.y_n = [ref_fs.DenseNet(d_in=problem.d + 1, d_out=1, lr=skw["lr"], arch=net["arch"], seed=net["seed"])]
         model.update_Phis()
     vf = skw.get("approx_method") == "value_function"
     init_fp = param_fingerprint(model.y_n[0]) if vf else (param_fingerprint(model.z_n) if not isinstance(model.z_n, list) else None)
@@ -447,6 +449,12 @@ CASES = [
          solver=dict(approx_method="value_function", loss_method="log-variance", time_approx="inner",
                      adaptive_forward_process=True, detach_forward=True, early_stopping_time=None, L=4, lr=0.005, seed=42,
                      delta_t=0.01, K=96, u_l2_error_flag=False)),
+    dict(name="dw_d10_value_function_arch3", family="solver",          # a three-layer value net: the run-time-shaped kernels (genl)
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=10, d_1=5, d_2=5, T=0.2, eta=0.5, kappa=2.0)),
+         solver=dict(approx_method="value_function", loss_method="log-variance", time_approx="inner",
+                     adaptive_forward_process=True, detach_forward=True, early_stopping_time=None, L=4, lr=0.005, seed=42,
+                     delta_t=0.01, K=96, u_l2_error_flag=False),
+         net=dict(kind="value_densenet", arch=[20, 16, 12], seed=7)),
     dict(name="llgc_d8_diag_value_function_moment", family="solver",
          problem=dict(kind="LLGC", kwargs=dict(d=8, off_diag=0.0, T=0.4, seed=42)),
          solver=dict(approx_method="value_function", loss_method="moment", time_approx="inner",

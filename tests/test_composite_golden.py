@@ -10,7 +10,7 @@ from conftest import load_golden
 from util_cases import make_pkg_solver
 
 CASES = ["lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "llgc_d12_outer_relative_entropy_detached", "dw_d20_densenet_attached_moment", "lqgc_d6_densenet_attached_cross_entropy",
-                "lqgc_d3_value_function", "dw_d10_value_function", "llgc_d8_diag_value_function_moment", "dw_d20_value_function_randx0", "lqgc_d2_logvar", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h64_logvar", "llgc_d100_densenet64_logvar",
+                "lqgc_d3_value_function", "dw_d10_value_function", "llgc_d8_diag_value_function_moment", "dw_d20_value_function_randx0", "dw_d10_value_function_arch3", "lqgc_d2_logvar", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h64_logvar", "llgc_d100_densenet64_logvar",
          "dw_d10_logvar", "llgc_d20_diag_logvar", "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive",
          "lqgc_d2_outer", "lqgc_d2_variance", "lqgc_d2_variance_learn_y0", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
 

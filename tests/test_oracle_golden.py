@@ -14,7 +14,7 @@ from util_cases import general_oracle_run
 
 # approx_method='value_function' (solver.py:93-97, 334-339, 438-440): Z = sigma grad_x Y_n, extra loss sum_n (Y_n(X_n) - Y)^2
 VALUE_FUNCTION_CASES = ["lqgc_d3_value_function", "dw_d10_value_function", "llgc_d8_diag_value_function_moment",
-                        "dw_d20_value_function_randx0"]
+                        "dw_d20_value_function_randx0", "dw_d10_value_function_arch3"]
 SOLVER_CASES = VALUE_FUNCTION_CASES + ["lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "llgc_d12_outer_relative_entropy_detached", "dw_d20_densenet_attached_moment", "lqgc_d6_densenet_attached_cross_entropy",
                 "llgc_d12_outer_moment", "dw_d20_densenet_nonadaptive", "lqgc_d6_densenet_variance", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_logvar", "llgc_d200_h64_logvar",
                 "llgc_d500_h64_logvar",
@@ -72,6 +72,8 @@ def run_solver_case(rec):
     if net is not None:
         if net["kind"] == "tanh_mlp":
             z = orc.TanhMLP(prob.d + 1, prob.d, cfg.lr, seed=net["seed"], widths=net["widths"])
+        elif net["kind"] == "value_densenet":
+            z = orc.DenseNetOracle(prob.d + 1, 1, cfg.lr, arch=net["arch"], seed=net["seed"])
         else:
             z = orc.DenseNetOracle(prob.d + 1, prob.d, cfg.lr, arch=net["arch"], seed=net["seed"])
         models = (z, models[1], models[2])

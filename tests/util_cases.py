@@ -29,6 +29,8 @@ def make_pkg_solver(case, device, backend="auto", noise="reference", **over):
             model.z_n = psp.MySequential(prob.d + 1, prob.d, kw["lr"], seed=net["seed"], widths=widths)
         elif net["kind"] == "densenet":
             model.z_n = psp.DenseNet(d_in=prob.d + 1, d_out=prob.d, lr=kw["lr"], arch=net["arch"], seed=net["seed"])
+        elif net["kind"] == "value_densenet":
+            model.y_n = [psp.DenseNet(d_in=prob.d + 1, d_out=1, lr=kw["lr"], arch=net["arch"], seed=net["seed"]).to(device)]
         model.update_Phis()
     return model
 
@@ -47,6 +49,8 @@ def make_oracle(case, L=None):
     if net is not None:
         if net["kind"] == "tanh_mlp":
             z = orc.TanhMLP(prob.d + 1, prob.d, cfg.lr, seed=net["seed"], widths=net["widths"])
+        elif net["kind"] == "value_densenet":
+            z = orc.DenseNetOracle(prob.d + 1, 1, cfg.lr, arch=net["arch"], seed=net["seed"])
         else:
             z = orc.DenseNetOracle(prob.d + 1, prob.d, cfg.lr, arch=net["arch"], seed=net["seed"])
         models = (z, models[1], models[2])
