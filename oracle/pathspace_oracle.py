@@ -101,6 +101,19 @@ def problem_double_well(d=1, d_1=1, d_2=0, T=1, eta=1, kappa=1) -> OracleProblem
         g=cost, extra=dict(eta_=eta_, kappa_=kappa_))
 
 
+def problem_double_well_1d(d=1, T=1, eta=1, kappa=1) -> OracleProblem:
+    """problems.py:178-213 (DoubleWell, one-dimensional): the dynamics of the multidimensional class at d = 1, with the products
+    of grad V taken in the order written there."""
+    B = torch.eye(d)                                                 # :188
+    return OracleProblem(
+        kind="DoubleWell", d=d, T=T, X_0=-torch.ones(d), B=B,        # :189
+        b=lambda x: -(4.0 * kappa * x * (x ** 2 - 1)),               # :198-201
+        sigma=lambda x: B,                                           # :204
+        h=lambda t, x, y, z: -0.5 * torch.sum(z ** 2, dim=1),        # :210
+        f=lambda x, t: torch.zeros(x.shape[0]),                      # :207
+        g=lambda x: (eta * (x - 1) ** 2).squeeze(), extra={})        # :213
+
+
 def problem_double_well_general(d=1, d_1=1, d_2=0, T=1, eta=1, kappa=1, modus="HJB") -> OracleProblem:
     """problems.py:479-534 (DoubleWell_multidim_for_general_solver); f is the terminal value."""
     eta_, kappa_, grad_V, cost = _double_well_parts(d, d_1, d_2, eta, kappa)
@@ -240,6 +253,7 @@ PROBLEMS = {
     "ExponentialOnSphereNonlinearParabolic": problem_exp_sphere_nonlinear_parabolic,
     "QuadraticOnBox": problem_quadratic_on_box,
     "LLGC": problem_llgc, "LQGC": problem_lqgc, "DoubleWell_multidim": problem_double_well,
+    "DoubleWell": lambda **kw: problem_double_well_1d(**kw),
     "DoubleWell_multidim_for_general_solver": problem_double_well_general,
     "AllenCahn": problem_allen_cahn, "HeatEquation": problem_heat,
 }

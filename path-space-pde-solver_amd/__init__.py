@@ -10,7 +10,7 @@ The directory can be used in two ways:
 """
 from .function_space import (Affine, Constant, DenseNet, DenseNet_tanh, DenseNet_tanh_2, Linear, MySequential,  # noqa: F401
                              SingleParam)
-from .problems import (LLGC, LQGC, AllenCahn, DoubleWell_multidim,  # noqa: F401
+from .problems import (LLGC, LQGC, AllenCahn, DoubleWell, DoubleWell_multidim,  # noqa: F401
                        DoubleWell_multidim_for_general_solver, HeatEquation, ExponentialOnSphere,
                        ExponentialOnBallNonlinear, ExponentialOnBallNonlinearSin,
                        ExponentialOnSphereNonlinearParabolic, QuadraticOnBox, Committor)
@@ -23,6 +23,6 @@ from . import plan_native, plan_dense_native, plan_general_native, plan_value_na
 from .utilities import do_importance_sampling_me  # noqa: F401
 
 __all__ = ['Solver', 'GeneralSolver', 'EllipticSolver', 'ExponentialOnSphere', 'ExponentialOnBallNonlinear',
-           'ExponentialOnBallNonlinearSin', 'ExponentialOnSphereNonlinearParabolic', 'QuadraticOnBox', 'Committor', 'LLGC', 'LQGC', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
+           'ExponentialOnBallNonlinearSin', 'ExponentialOnSphereNonlinearParabolic', 'QuadraticOnBox', 'Committor', 'LLGC', 'LQGC', 'DoubleWell', 'DoubleWell_multidim', 'DoubleWell_multidim_for_general_solver',
            'AllenCahn', 'HeatEquation', 'MySequential', 'DenseNet', 'DenseNet_tanh', 'DenseNet_tanh_2', 'SingleParam',
            'Constant', 'Linear', 'Affine', 'PlanUnsupported', 'native']

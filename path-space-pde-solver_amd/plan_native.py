@@ -36,6 +36,12 @@ except ImportError:
     import sharding
 
 
+def _u_tables(problem):
+    """problem.u_true_tables() (the double wells' finite-difference reference control, problems.py) or None."""
+    fn = getattr(problem, 'u_true_tables', None)
+    return fn() if fn is not None else None
+
+
 def _overridden(problem):
     try:
         from .problems import coefficients_overridden
@@ -60,10 +66,11 @@ def native_eligibility(solver):
     if solver.burgers_drift:
         return 'burgers_drift is not native'
     if solver.u_l2_error_flag and getattr(solver.problem, 'u_true_x_independent', False) is not True \
-            and getattr(solver.problem, 'u_true_linear_in_x', False) is not True:
+            and getattr(solver.problem, 'u_true_linear_in_x', False) is not True and _u_tables(solver.problem) is None:
         return ('u_l2_error_flag=True evaluates problem.u_true(X_n, t_n) on the host every step '
                 '(reference solver.py:491-494); a u_true that does not depend on x (LLGC) is logged inside the kernels, one '
-                'that is linear in x (LQGC) from the path store -- pass u_l2_error_flag=False for the native plan otherwise')
+                'that is linear in x (LQGC) or tabulated per coordinate (the double wells) from the path store -- pass '
+                'u_l2_error_flag=False for the native plan otherwise')
     if solver.compute_gradient_variance > 0 or solver.log_gradient:
         return 'per-iteration diagnostics (gradient variance / gradient log) are not native'
     if solver.metastability_logs is not None:
@@ -232,7 +239,18 @@ class HjbNativePlan:
         self.x0_vec = dev_f32(pad.vec(solver.X_0.detach().to(dev)))
         self.ul2 = None
         self.ul2_gain = None
-        if solver.u_l2_error_flag and getattr(solver.problem, 'u_true_x_independent', False) is not True:
+        self.ul2_tab = None
+        if solver.u_l2_error_flag and _u_tables(solver.problem) is not None:
+            # u*(x, t) tabulated per coordinate on a grid (the double wells: problems.py u_true_tables, reference problems.py:
+            # 277-281, 399-404, 471-476): the tables go to the device once, the log is formed from the path store (_ul2_from_path)
+            import numpy as np
+            tb = _u_tables(solver.problem)
+            self.ul2_tab = dict(tables=[torch.tensor(np.asarray(t), dtype=torch.float32, device=dev) for t in tb['tables']],
+                                group=torch.tensor(tb['group_of_dim'], dtype=torch.long, device=dev),
+                                xb=float(tb['xb']), dx=float(tb['dx']),
+                                n_ref=[int(np.ceil(n * solver.delta_t_np / tb['delta_t'])) for n in range(solver.N)])
+            self.XN_k = torch.empty(self.K_local, self.d_pad, dtype=torch.float32, device=dev)
+        elif solver.u_l2_error_flag and getattr(solver.problem, 'u_true_x_independent', False) is not True:
             # u*(x, t_n) = M_n x (LQGC, problems.py:169-171): M_n once per plan by probing u_true with the unit vectors; the log
             # is then formed from the X_n and h2 images of the path store after the forward kernel (_ul2_from_path)
             import numpy as np
@@ -535,7 +553,7 @@ class HjbNativePlan:
         if want is False:
             return False
         ok = (self.world == 1 and self.noise == 'philox' and not self.s.random_X_0 and not self.generic_loss
-              and self.ul2 is None and self.ul2_gain is None and self.n_chunks == 1)
+              and self.ul2 is None and self.ul2_gain is None and self.ul2_tab is None and self.n_chunks == 1)
         if not ok:
             return False
         if want is True:
@@ -638,7 +656,8 @@ class HjbNativePlan:
         return loss_out[l]
 
     def _ul2_from_path(self):
-        """u_L2 log (solver.py:491-494) for a reference control that is linear in x: sum_k sum_n |-Z_n - M_n X_n|^2 dt / K over this
+        """u_L2 log (solver.py:491-494) for a reference control that is linear in x (LQGC) or tabulated per coordinate (the double
+        wells): sum_k sum_n |-Z_n - u*(X_{n+1}, t_n)|^2 dt / K over this
         rank's trajectories, from the register images the forward kernel left in the path store -- block (n, tile): X_n image at
         float 0, h2 image behind the h1 image; image float ks * 64 + 16 q + j holds feature 4 ks + q of sample j (csrc/hjb_kernels.h
         Geo::pX / pH2).  Z_n = W3 h2 + b3 with the net's own parameters.  A diagnostic: K N small products in torch, skipped
@@ -658,6 +677,22 @@ class HjbNativePlan:
         lin = self.net.linears[-1]
         with torch.no_grad():
             Z = h2 @ lin.weight.t() + lin.bias                                  # (N, K, d)
+            if self.ul2_tab is not None:
+                # the double wells: u*_i = table_{g(i)}[ceil(t_n / dt_ref), cell(x_i)], cell = floor((clamp(x) + xb) / dx) in fp32 as the
+                # reference computes it -- which also lowers the index of the LAST trajectory of the batch by two (problems.py:270)
+                tb = self.ul2_tab
+                cell = torch.floor((torch.clamp(X, -tb['xb'], tb['xb'] - 2 * tb['dx']) + tb['xb']) / tb['dx']).long()
+                if self.k_offset + self.K_local == s.K:
+                    cell[:, -1, :] -= 2
+                tot = torch.zeros((), dtype=torch.float32, device=self.dev)
+                for n in range(N):                                              # (per step: bounds the index tensors)
+                    u_ref = torch.empty(self.K_local, s.d, device=self.dev)
+                    for gi, tab in enumerate(tb['tables']):
+                        dims = torch.nonzero(tb['group'] == gi).flatten()
+                        if dims.numel():
+                            u_ref[:, dims] = tab[tb['n_ref'][n]][cell[n][:, dims]]
+                    tot = tot + ((-Z[n] - u_ref) ** 2).sum()
+                return tot * s.delta_t / float(s.K)
             u_ref = torch.bmm(X, self.ul2_gain.transpose(1, 2))                 # M_n X_n
             return ((-Z - u_ref) ** 2).sum() * s.delta_t / float(s.K)
 
@@ -741,7 +776,7 @@ class HjbNativePlan:
             ev[0].record()
         nat.check(lib.psp_hjb_rollout_fwd(C.byref(cfg), nat.ptr(flat_k), nat.ptr(x0_t), x0_stride, y0_ptr,
                                           nat.ptr(xi), seed, l, nat.ptr(self.path), nat.ptr(self.D),
-                                          nat.ptr(self.XN_k) if (self.attached or self.ul2_gain is not None) else None,
+                                          nat.ptr(self.XN_k) if (self.attached or self.ul2_gain is not None or self.ul2_tab is not None) else None,
                                           nat.ptr(self.Yn), nat.ptr(self.fwd_partial), st), 'psp_hjb_rollout_fwd')
         if ev is not None:
             ev[1].record()
@@ -764,7 +799,7 @@ class HjbNativePlan:
             m = (self.ul2.sum() / float(s.K)).reshape(1)
             sharding.allreduce_sum_(m)
             ul2_out[l:l + 1] = m
-        elif self.ul2_gain is not None and ul2_out is not None:
+        elif (self.ul2_gain is not None or self.ul2_tab is not None) and ul2_out is not None:
             m = self._ul2_from_path().reshape(1)
             sharding.allreduce_sum_(m)
             ul2_out[l:l + 1] = m

@@ -217,6 +217,178 @@ class _DoubleWellBase:
     def _well_cost(self, x):
         return (torch.sum(self.eta_ * (x - torch.ones(self.d).to(x.device)) ** 2, 1)).squeeze()
 
+    # ---- reference solution of the ONE-dimensional problem by finite differences (reference problems.py:216-281, 336-476) ---------
+    # psi = exp(-v) solves the linear backward equation d_t psi + L psi = 0, psi(T) = exp(-g), L = generator of dX = -V'(X) dt + dW
+    # (beta = 2): symmetrised as A = D^-1 L D with D = exp(beta V / 2), a tridiagonal matrix on nx cells of [-xb, xb] (reflecting
+    # ends), stepped backwards by implicit Euler; the optimal control is u* = -d_x v = (1 / psi) d_x psi taken as a forward
+    # difference of log psi.  Written here as array expressions (the reference fills the matrix entry by entry); the band of the
+    # implicit step and the FLOAT32 rounding of the control table -- the reference multiplies by its fp32 tensor B[0, 0], which
+    # makes every entry an fp32 number -- are kept, because u_L2 logs are compared with the reference's to the last digits.
+    def _fd_reference(self, potential, terminal, delta_t, xb, nx):
+        import numpy as np
+        from scipy.linalg import solve_banded
+        beta = 2
+        dx = 2.0 * xb / nx
+        cells = np.arange(nx)
+        mid = -xb + (cells + 0.5) * dx                                   # cell midpoints
+        lo_far, lo_edge = -xb + (cells - 0.5) * dx, -xb + cells * dx      # the neighbour below and the edge between
+        hi_far, hi_edge = -xb + (cells + 1.5) * dx, -xb + (cells + 1) * dx
+        V = potential
+        diag_lo = np.exp(beta * (V(mid) - V(lo_edge))) / dx ** 2
+        diag_hi = np.exp(beta * (V(mid) - V(hi_edge))) / dx ** 2
+        off_hi = np.exp(beta * 0.5 * (V(hi_far) + V(mid) - 2 * V(hi_edge))) / dx ** 2
+        main = np.where(cells > 0, diag_lo, 0.0) + np.where(cells < nx - 1, diag_hi, 0.0)
+        A_main, A_up = -main / beta, off_hi[:nx - 1] / beta              # A = -(.) / beta; A[i, i + 1] = +off_hi[i] / beta
+        n_steps = int(self.T / delta_t)
+        xvec = np.linspace(-xb, xb, nx, endpoint=True)
+        scale, unscale = np.exp(beta * V(xvec) / 2), np.exp(-beta * V(xvec) / 2)
+        band = -delta_t * np.vstack([np.append([0], A_up), A_main - n_steps / self.T, np.append(A_up, [0])])
+        psi = np.zeros([n_steps + 1, nx])
+        psi[n_steps] = np.exp(-terminal(xvec))
+        for n in range(n_steps - 1, -1, -1):
+            psi[n] = scale * solve_banded([1, 1], band, unscale * psi[n + 1])
+        diff = -np.log(psi[:, 1:]) + np.log(psi[:, :-1])
+        u = ((np.float32(-2 / beta) * np.float32(self.B[0, 0].item())) * diff.astype(np.float32) / np.float32(dx)).astype(np.float64)
+        return dict(xb=xb, nx=nx, dx=dx, delta_t=delta_t, xvec=xvec), psi, u
+
+    def _table_index(self, x_col):
+        """Grid cell of every entry of a (K,) column of states, as the reference computes it (fp32 arithmetic, states clamped to
+        the grid) -- including its decrement of the LAST entry's index by two (problems.py:270, 276)."""
+        x_col = x_col.detach().cpu().float().reshape(-1)
+        idx = torch.floor((torch.clamp(x_col, -self.xb, self.xb - 2 * self.dx) + self.xb) / self.dx).long()
+        idx[-1] -= 2
+        return idx
+
+    def _time_index(self, t):
+        import numpy as np
+        return int(np.ceil(float(t) / self.delta_t))
+
+    def _value_index(self, x_col):
+        """Grid cell for the VALUE tables (problems.py:392-394, 592-594): no clamp, same decrement of the last entry."""
+        x_col = x_col.detach().cpu().float().reshape(-1)
+        idx = torch.floor((x_col + self.xb) / self.dx).long()
+        idx[-1] -= 2
+        return idx
+
+    # ---- the two tables of the multidimensional classes: coordinates < d_1 use (kappa, eta), the others (1, 1) ----------------------
+    def V_2(self, x):
+        return (x ** 2 - 1) ** 2
+
+    def g_1(self, x_1):
+        return self.eta * (x_1 - 1) ** 2
+
+    def g_2(self, x_1):
+        return (x_1 - 1) ** 2
+
+    def _take_grid(self, grid):
+        self.xb, self.nx, self.dx, self.delta_t, self.xvec = grid['xb'], grid['nx'], grid['dx'], grid['delta_t'], grid['xvec']
+
+    def compute_reference_solution(self, delta_t=0.005, xb=2.5, nx=1000):
+        grid, self.psi, self.u = self._fd_reference(self.V, self.g_1, delta_t, xb, nx)
+        self._take_grid(grid)
+        self._publish_u_true()
+
+    def compute_reference_solution_2(self, delta_t=0.005, xb=2.5, nx=1000):
+        grid, self.psi_2, self.u_2 = self._fd_reference(self.V_2, self.g_2, delta_t, xb, nx)
+        self._take_grid(grid)
+        self._publish_u_true()
+
+    def _tables_ready(self):
+        return hasattr(self, 'u') and (self.d_2 == 0 or hasattr(self, 'u_2'))
+
+    def _publish_u_true(self):
+        if self._tables_ready():
+            self.ref_sol_is_defined = True
+            self.u_true = self._u_true
+
+    def _table_read(self, table, idx, t, transform=None):
+        import numpy as np
+        vals = table[self._time_index(t), idx.numpy()]
+        return np.array(vals if transform is None else transform(vals)).reshape([1, len(idx)])
+
+    def u_true_1(self, x, t):
+        return self._table_read(self.u, self._table_index(x), t)
+
+    def u_true_2(self, x, t):
+        return self._table_read(self.u_2, self._table_index(x), t)
+
+    def _value_transform(self):
+        import numpy as np
+        return None if getattr(self, 'modus', 'HJB') == 'linear' else (lambda p: -np.log(p))
+
+    def v_true_1(self, x, t):
+        return self._table_read(self.psi, self._value_index(x), t, self._value_transform())
+
+    def v_true_2(self, x, t):
+        return self._table_read(self.psi_2, self._value_index(x), t, self._value_transform())
+
+    def _u_true(self, x, t):
+        import numpy as np
+        cols = [self.u_true_1(x[:, i], t).T for i in range(self.d_1)] + [self.u_true_2(x[:, i], t).T for i in range(self.d_1, self.d)]
+        return np.concatenate(cols, 1).T
+
+    def u_true_tables(self):
+        """Tables and the coordinate -> table map for the native plan's device-side u_L2 log (plan_native._ul2_from_path)."""
+        if not self.ref_sol_is_defined:
+            return None
+        tables = [self.u] + ([self.u_2] if self.d_2 > 0 else [])
+        return dict(tables=tables, group_of_dim=[0] * self.d_1 + [1] * self.d_2, xb=self.xb, dx=self.dx, delta_t=self.delta_t)
+
+
+class DoubleWell(_DoubleWellBase):
+    """One-dimensional double-well potential (reference problems.py:178-283): dX = -V'(X) dt + dW, V = kappa (x^2 - 1)^2,
+    g = eta (x - 1)^2; ``compute_reference_solution()`` tabulates the optimal control, ``u_true`` / ``v_true`` read the table."""
+
+    def __init__(self, name='Double well', d=1, T=1, eta=1, kappa=1, device=None):
+        self.device = _resolve(device)
+        self.name, self.T = name, T
+        self._setup(d, d, 0, eta, kappa)
+        if d != 1:
+            print('The double well example is only implemented for d = 1.')
+
+    def h(self, t, x, y, z):
+        return -0.5 * torch.sum(z ** 2, dim=1)
+
+    def f(self, x, t):
+        return torch.zeros(x.shape[0]).to(x.device)
+
+    def g(self, x):
+        return (self.eta * (x - 1) ** 2).squeeze()
+
+    def grad_V(self, x):
+        return 4.0 * self.kappa * x * (x ** 2 - 1)
+
+    def compute_reference_solution(self, delta_t=0.005, xb=2.5, nx=1000):
+        grid, self.psi, self.u = self._fd_reference(self.V, lambda x: self.eta * (x - 1) ** 2, delta_t, xb, nx)
+        self.xb, self.nx, self.dx, self.delta_t, self.xvec = grid['xb'], grid['nx'], grid['dx'], grid['delta_t'], grid['xvec']
+        self.ref_sol_is_defined = True
+
+    def v_true(self, x, t):
+        import numpy as np
+        x = x.detach().cpu().float()
+        idx = torch.floor((x.squeeze(0) + self.xb) / self.dx).long()
+        idx[-1] -= 2
+        return np.array(-np.log(self.psi[self._time_index(t), idx.numpy()])).reshape([1, len(idx)])
+
+    def u_true(self, x, t):
+        import numpy as np
+        idx = self._table_index(x).reshape(x.shape) if x.dim() > 1 else self._table_index(x)
+        return np.array(self.u[self._time_index(t), idx.numpy()]).reshape([1, len(idx)])
+
+    def u_true_tables(self):
+        """What the native plan needs to log u_L2 on the device (plan_native._ul2_from_path): one table for all coordinates."""
+        if not self.ref_sol_is_defined:
+            return None
+        return dict(tables=[self.u], group_of_dim=[0] * self.d, xb=self.xb, dx=self.dx, delta_t=self.delta_t)
+
+    def native_spec(self):
+        return {
+            'drift': (_nat.DRIFT_DOUBLE_WELL, self.kappa_.float().contiguous()),
+            'sigma': (_nat.SIGMA_IDENTITY, None, 1.0),
+            'runcost': (_nat.RUNCOST_ZERO, None),
+            'term': (_nat.TERM_SHIFTED_QUAD, self.eta_.float().contiguous()),
+        }
+
 
 class DoubleWell_multidim(_DoubleWellBase):
     """Independent double-well potential in every coordinate, identity diffusion
@@ -236,6 +408,12 @@ class DoubleWell_multidim(_DoubleWellBase):
 
     def g(self, x):
         return self._well_cost(x)
+
+    # reference solution: the coordinates decouple -- one table for the first d_1 (kappa, eta), one for the others (1, 1)
+    # (reference problems.py:336-476; methods on _DoubleWellBase).  The reference defines u_true on the class, where it fails until
+    # both tables exist; here ``u_true`` appears with the tables, so a run without them logs no u_L2 instead of raising.
+    def v_true(self, x, t):
+        return None                                                      # problems.py:472-473
 
     def native_spec(self):
         return {
@@ -265,6 +443,20 @@ class DoubleWell_multidim_for_general_solver(_DoubleWellBase):
         if self.modus == 'linear':
             return torch.exp(-self._well_cost(x))
         return self._well_cost(x)
+
+    def v_true(self, x, t):
+        """Reference value from the per-coordinate tables (reference problems.py:682-685): the values add; in modus 'linear' the
+        tabulated psi = exp(-v) multiply."""
+        import numpy as np
+        cols = np.array([self.v_true_1(x[:, i], t).squeeze() for i in range(self.d_1)]
+                        + [self.v_true_2(x[:, i], t).squeeze() for i in range(self.d_1, self.d)])
+        return np.prod(cols, 0) if self.modus == 'linear' else np.sum(cols, 0)
+
+    def _publish_u_true(self):                                           # GeneralSolver never asks hasattr(problem, 'u_true')
+        self.ref_sol_is_defined = self._tables_ready()
+
+    def u_true(self, x, t):
+        return self._u_true(x, t)                                        # problems.py:687-688
 
     def general_native_spec(self):
         return {'drift': (_nat.DRIFT_DOUBLE_WELL, self.kappa_.float().contiguous()), 'sigma_scale': 1.0,

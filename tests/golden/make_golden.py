@@ -148,6 +148,8 @@ def make_problem(spec):
     pb = QuadraticOnBox(**kw) if kind == "QuadraticOnBox" else getattr(ref_pb, kind)(**kw)
     for k, v in spec.get("attrs", {}).items():      # attributes callers set on the instance (e.g. boundary_type)
         setattr(pb, k, v)
+    for call, kw in spec.get("calls", []):          # what the notebooks call before training (compute_reference_solution[_2])
+        getattr(pb, call)(**kw)
     return pb
 
 
@@ -179,7 +181,13 @@ def run_solver_case(case):
         with torch.no_grad():
             z = model.Z_n(xp, torch.tensor(t))
         probes.append({"t": t, "minus_Z": f32list(-z)})
+    ref_tables = None
+    if hasattr(problem, "u") and isinstance(getattr(problem, "u"), np.ndarray):
+        tabs = [problem.u] + ([problem.u_2] if hasattr(problem, "u_2") else [])
+        ref_tables = [{"shape": list(t.shape), "sum": float(t.sum()), "abs_sum": float(np.abs(t).sum()),
+                       "probe": [float(v) for v in t[::max(1, t.shape[0] // 3), ::max(1, t.shape[1] // 5)].reshape(-1)]} for t in tabs]
     res = {
+        "ref_tables": ref_tables,
         "N": model.N, "p": int(model.p),
         "loss_log": [float(v) for v in model.loss_log],
         "u_L2_loss": [float(v) for v in model.u_L2_loss],
@@ -465,6 +473,17 @@ CASES = [
          solver=dict(approx_method="value_function", loss_method="log-variance", time_approx="inner",
                      adaptive_forward_process=True, detach_forward=True, early_stopping_time=None, L=3, lr=0.002, seed=7,
                      delta_t=0.01, K=112, u_l2_error_flag=False, random_X_0=True)),
+    # the double wells with their finite-difference reference control (problems.py:216-281, 336-476) and the u_L2 log left ON -- what
+    # `Double well - 1d - high metastability.ipynb` and `Multidim. double well - mixed metastabilities.ipynb` run
+    dict(name="dw1d_logvar_ul2", family="solver",
+         problem=dict(kind="DoubleWell", kwargs=dict(d=1, T=0.4, eta=3.0, kappa=5.0),
+                      calls=[["compute_reference_solution", dict(nx=400)]]),
+         solver=dict(HJB, L=4, lr=0.005, seed=42, delta_t=0.01, K=112)),
+    dict(name="dw_d6_mixed_logvar_ul2", family="solver",
+         problem=dict(kind="DoubleWell_multidim", kwargs=dict(d=6, d_1=2, d_2=4, T=0.3, eta=0.5, kappa=2.0),
+                      calls=[["compute_reference_solution", dict(nx=500)], ["compute_reference_solution_2", dict(nx=500)]]),
+         solver=dict(HJB, L=4, lr=0.005, seed=42, delta_t=0.01, K=96),
+         net=dict(kind="tanh_mlp", widths=[40, 40], seed=123)),
     # importance-sampling evaluation of the learned control, standalone and in the loop
     dict(name="llgc_d20_is_eval", family="is",
          problem=dict(kind="LLGC", kwargs=dict(d=20, off_diag=0.0, T=0.3, seed=42)),

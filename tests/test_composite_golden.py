@@ -10,7 +10,7 @@ from conftest import load_golden
 from util_cases import make_pkg_solver
 
 CASES = ["lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "llgc_d12_outer_relative_entropy_detached", "dw_d20_densenet_attached_moment", "lqgc_d6_densenet_attached_cross_entropy",
-                "lqgc_d3_value_function", "dw_d10_value_function", "llgc_d8_diag_value_function_moment", "dw_d20_value_function_randx0", "dw_d10_value_function_arch3", "lqgc_d2_logvar", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h64_logvar", "llgc_d100_densenet64_logvar",
+                "lqgc_d3_value_function", "dw_d10_value_function", "llgc_d8_diag_value_function_moment", "dw_d20_value_function_randx0", "dw_d10_value_function_arch3", "lqgc_d2_logvar", "dw1d_logvar_ul2", "dw_d6_mixed_logvar_ul2", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h64_logvar", "llgc_d100_densenet64_logvar",
          "dw_d10_logvar", "llgc_d20_diag_logvar", "lqgc_d2_moment", "lqgc_d4_randx0", "llgc_d8_nonadaptive",
          "lqgc_d2_outer", "lqgc_d2_variance", "lqgc_d2_variance_learn_y0", "lqgc_d2_cross_entropy", "llgc_d8_cross_entropy_nonadaptive"]
 
@@ -41,6 +41,37 @@ def test_composite_plan_matches_reference(name):
                 u = -model.Z_n(xp, pr["t"])
             want = torch.tensor(pr["minus_Z"]).reshape(u.shape)
             assert torch.allclose(u, want, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["dw1d_logvar_ul2", "dw_d6_mixed_logvar_ul2"])
+def test_double_well_reference_tables_match_reference(name):
+    """compute_reference_solution[_2] (problems.py:216-262, 378-455): the finite-difference control tables the u_L2 log reads."""
+    import numpy as np
+    from util_cases import make_pkg_problem
+    rec = load_golden(name)
+    pb = make_pkg_problem(rec["case"]["problem"], "cpu")
+    tabs = [pb.u] + ([pb.u_2] if hasattr(pb, "u_2") else [])
+    want = rec["expected"]["ref_tables"]
+    assert len(tabs) == len(want)
+    for t, w in zip(tabs, want):
+        assert list(t.shape) == w["shape"]
+        probe = t[::max(1, t.shape[0] // 3), ::max(1, t.shape[1] // 5)].reshape(-1)
+        assert np.allclose(probe, np.array(w["probe"]), rtol=1e-6, atol=1e-9)
+        assert math.isclose(float(t.sum()), w["sum"], rel_tol=1e-6, abs_tol=1e-6)
+        assert math.isclose(float(np.abs(t).sum()), w["abs_sum"], rel_tol=1e-6)
+
+
+def test_u_true_appears_only_with_the_tables():
+    """The reference's multidimensional double well can only evaluate u_true once both tables exist (problems.py:475-476 read
+    self.u / self.u_2); the package publishes u_true at that point, so a run without tables logs no u_L2 instead of raising."""
+    import path_space_pde_solver_amd as psp
+    pb = psp.DoubleWell_multidim(d=3, d_1=1, d_2=2, T=0.2, eta=1.0, kappa=1.0)
+    assert not hasattr(pb, "u_true")
+    pb.compute_reference_solution(nx=100)
+    pb.compute_reference_solution_2(nx=100)
+    assert hasattr(pb, "u_true")
+    x = torch.tensor([[-1.0, 0.2, 0.5], [0.3, -0.4, 9.0]])
+    assert pb.u_true(x, 0.0).shape == (3, 2)
 
 
 def test_backend_native_refuses_cpu():

@@ -31,7 +31,9 @@ NATIVE_CASES = ["lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_l
                 # u_L2 logging on (the reference default): accumulated inside the forward kernels
                 "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2",
                 # ... and for a reference control that is LINEAR in x (LQGC, u* = M_n x): from the path store
-                "lqgc_d2_logvar"]
+                "lqgc_d2_logvar",
+                # ... and for one tabulated per coordinate (the double wells' finite-difference reference control): device tables
+                "dw1d_logvar_ul2", "dw_d6_mixed_logvar_ul2"]
 
 
 def dev():

@@ -16,7 +16,7 @@ from util_cases import general_oracle_run
 VALUE_FUNCTION_CASES = ["lqgc_d3_value_function", "dw_d10_value_function", "llgc_d8_diag_value_function_moment",
                         "dw_d20_value_function_randx0", "dw_d10_value_function_arch3"]
 SOLVER_CASES = VALUE_FUNCTION_CASES + ["lqgc_d2_outer_attached", "llgc_d12_outer_relative_entropy", "llgc_d12_outer_relative_entropy_detached", "dw_d20_densenet_attached_moment", "lqgc_d6_densenet_attached_cross_entropy",
-                "llgc_d12_outer_moment", "dw_d20_densenet_nonadaptive", "lqgc_d6_densenet_variance", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_logvar", "llgc_d200_h64_logvar",
+                "llgc_d12_outer_moment", "dw_d20_densenet_nonadaptive", "lqgc_d6_densenet_variance", "dw1d_logvar_ul2", "dw_d6_mixed_logvar_ul2", "llgc_d8_logvar_ul2", "llgc_d40_moment_ul2", "lqgc_d2_logvar_noul2", "llgc_d100_h30_logvar", "llgc_d100_h64_logvar", "llgc_d200_h64_logvar",
                 "llgc_d500_h64_logvar",
                 "llgc_d7_default_logvar", "lqgc_d33_h50_logvar", "dw_d70_h64_logvar", "llgc_d105_h64_logvar",
                 "llgc_d300_h40_logvar",

@@ -13,7 +13,10 @@ from oracle import pathspace_oracle as orc  # noqa: E402  (tests are allowed to 
 
 
 def make_pkg_problem(pspec, device):
-    return getattr(psp, pspec["kind"])(device=device, **pspec["kwargs"])
+    pb = getattr(psp, pspec["kind"])(device=device, **pspec["kwargs"])
+    for call, kw in pspec.get("calls", []):              # e.g. compute_reference_solution(nx=...) before training
+        getattr(pb, call)(**kw)
+    return pb
 
 
 def make_pkg_solver(case, device, backend="auto", noise="reference", **over):

@@ -18,9 +18,12 @@ for W in $WL; do
         hjb_llgc_d500_K131072_N200_h64|hjb_llgc_d200_Kglobal262144_N100_h64) STEPS=4; WARM=1;;
         hjb_llgc_d500_K1048576_N200_h64) STEPS=2; WARM=1;;
         diffusion_allencahn_d100_K200_N25_a110) STEPS=100; WARM=10;;
+        elliptic_committor_d10_K200) STEPS=20; WARM=3;;
+        elliptic_committor_d10_K65536) STEPS=5; WARM=2;;
     esac
     EXTRA="--no-cpu-baseline --no-secondary"; [ "$W" = hjb_llgc_d100_K65536_N100_h64 ] && EXTRA=""
     [ "$W" = diffusion_allencahn_d100_K200_N25_a110 ] && EXTRA=""
+    [ "$W" = elliptic_committor_d10_K200 ] && EXTRA=""
     timeout -k 10 900 python3 bench.py --workload $W --steps $STEPS --warmup $WARM $EXTRA > "$OUT/${W}_bench.json" 2> "$OUT/${W}_bench.err" || { echo "bench $W failed"; tail -3 "$OUT/${W}_bench.err"; exit 1; }
     echo "bench $W: $(python3 -c "import json,sys; j=json.loads(open('$OUT/${W}_bench.json').read().strip().splitlines()[-1]); print('%.4g units/s, %.3f ms/step, frac %.3f (issued %s)' % (j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline'].get('mfma_term',{}).get('frac_issued')))")"
     rm -rf /tmp/prof_$W
