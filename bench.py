@@ -780,7 +780,7 @@ def main():
                    "K_global": K_global, "N": N_t,
                    "mlp": ("%d x DenseNet %d-%d-%d-%d relu^2, one per time step (time_approx='outer')" % (N_t, w["d"], w["H"], w["H"], w["d"]))
                           if outer else "%d-%d-%d-%d tanh" % (w["d"] + 1, w["H"], w["H"], w["d"]),
-                   "loss": "log-variance", "noise": "on-device Philox4x32-10",
+                   "loss": "log-variance", "noise": "on-device Philox4x32-7",
                    "matrix_products": ("fp32-grade split products on the f16 matrix pipe: x = hi + lo/2048 (two f16 numbers), "
                                        "a.b = hi.hi + (hi.lo + lo.hi)/2048 as three v_mfma_f32_16x16x32_f16 with fp32 accumulation "
                                        "(product error 1.07x that of v_mfma_f32_16x16x4_f32; same parity bounds, "

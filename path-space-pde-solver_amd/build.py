@@ -85,20 +85,25 @@ def _build(force, jobs, verbose, only):
     dhdr = os.path.join(CSRC, "hjbd_kernels.h")
     ddef = os.path.join(CSRC, "dense_instances.def")
     dinst_src = os.path.join(CSRC, "hjbd_instance.hip")
-    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), [], [api_src, hdr, ghdr, whdr, dhdr, os.path.join(CSRC, "genl_kernels.h"), inc, idef, gdef, wdef, ddef])]
+    # The split of an fp32 operand into its f16 pair (hjb_kernels.h split8) costs two instructions per value only when the SLP
+    # vectoriser leaves its two fmas alone: every translation unit but the wide family's is compiled with it off (measured, same
+    # box: d = 100 forward -1.8 %, diffusion iteration -3 %, others unchanged; wide d = 500 backward +30 % from spills -- it keeps
+    # the round-3 form).
+    NOSLP, CLASSIC = ["-fno-slp-vectorize"], ["-DPSP_SPLIT_CLASSIC=1"]
+    tasks = [(api_src, os.path.join(OBJ, "psp_api.o"), NOSLP, [api_src, hdr, ghdr, whdr, dhdr, os.path.join(CSRC, "genl_kernels.h"), inc, idef, gdef, wdef, ddef])]
     for d, H in instances("dense_instances.def"):
         tasks.append((dinst_src, os.path.join(OBJ, "dnet_inst_%d_%d.o" % (d, H)),
-                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [dinst_src, dhdr, whdr, hdr]))
+                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + NOSLP, [dinst_src, dhdr, whdr, hdr]))
     for d, H in instances():
         tasks.append((inst_src, os.path.join(OBJ, "inst_%d_%d.o" % (d, H)),
-                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [inst_src, hdr, os.path.join(CSRC, "hjbs_kernels.h"), os.path.join(CSRC, "hjba_kernels.h"),
+                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + NOSLP, [inst_src, hdr, os.path.join(CSRC, "hjbs_kernels.h"), os.path.join(CSRC, "hjba_kernels.h"),
                        os.path.join(CSRC, "hjbq_kernels.h"), os.path.join(CSRC, "hjbx_kernels.h")]))
     for d, H in instances("wide_instances.def"):
         tasks.append((winst_src, os.path.join(OBJ, "wide_inst_%d_%d.o" % (d, H)),
-                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [winst_src, whdr, hdr]))
+                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + CLASSIC, [winst_src, whdr, hdr]))
     for d, H in instances("gen_instances.def"):
         tasks.append((ginst_src, os.path.join(OBJ, "gen_inst_%d_%d.o" % (d, H)),
-                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H], [ginst_src, ghdr, hdr]))
+                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + NOSLP, [ginst_src, ghdr, hdr]))
     jobs = jobs or min(6, os.cpu_count() or 2)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         results = list(ex.map(lambda t: _compile(t[0], t[1], t[2], t[3], force), tasks))

@@ -170,12 +170,22 @@ __device__ __forceinline__ const T* opaque(const T* p) {   // same pointer + opa
 #endif
 
 // ---------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011), counter = (global trajectory, step, call index, iteration)
+// Philox4x32-R (Salmon et al. 2011), counter = (global trajectory, step, call index, iteration)
+// R = 7 since round 4 (rounds 1 - 3: 10).  Philox4x32-7 is the paper's smallest Crush-resistant member of the family (SC'11,
+// section 4 / table 2: passes the whole of BigCrush; 10 is the "safety margin" default of Random123 and cuRAND).  The generator is
+// a third of the forward kernel's VALU issue time at d = 100 (two v_mad_u64_u32 + two v_bitop3_b32 per round, seven calls per
+// trajectory and step), and the regenerating backward producers pay it a second time; three rounds less = -30 % of that.
+// oracle/philox_oracle.py and the Random123 known-answer vectors of `philox4x32 7` (tests/test_philox_oracle.py) move with it;
+// -DPSP_PHILOX_ROUNDS=10 restores the old stream.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#ifndef PSP_PHILOX_ROUNDS
+#define PSP_PHILOX_ROUNDS 7
+#endif
+constexpr int kPhiloxRounds = PSP_PHILOX_ROUNDS;
+__device__ __forceinline__ void philox4x32_R(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                             uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < kPhiloxRounds; ++r) {
         // one 32x32->64 multiply per (hi, lo) pair: v_mad_u64_u32 instead of v_mul_hi_u32 + v_mul_lo_u32
         // (32-bit integer multiplies are quarter-rate VALU ops on CDNA)
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * (unsigned long long)c0;
@@ -226,7 +236,7 @@ __device__ __forceinline__ f32x4 normal4(const uint32_t (&r)[4]) {
 __device__ __forceinline__ f32x4 philox_block(uint32_t kglob, uint32_t step, uint32_t idx, uint32_t iter,
                                               uint32_t seed_lo, uint32_t seed_hi) {
     uint32_t r[4];
-    philox4x32_10(kglob, step, idx, iter, seed_lo, seed_hi, r);
+    philox4x32_R(kglob, step, idx, iter, seed_lo, seed_hi, r);
     return normal4(r);
 }
 
@@ -412,7 +422,26 @@ __device__ __forceinline__ void split4(const f32x4& u, f16x4& hi, f16x4& lo) {
         hi[e] = h; lo[e] = l;
     }
 }
+// Two values at a time (round 4): hi pair = ONE v_cvt_pk_f16_f32, 2048 x = one v_pk_mul_f32 for both, and each lo =
+// f16(fma(hi, -2048, 2048 x)) = one v_fma_mixlo/mixhi_f16 that reads its half of the hi pair directly -- two instructions per value
+// where the (x - float(hi)) * 2048 form compiles to four (convert back, subtract, multiply, convert).  The same value bit for bit:
+// x - hi is exact, 2048 (x - hi) has at most 13 significant bits, so the fma's fp32 rounding does nothing and the f16 rounding is
+// the one split_f16 applies.  Round 3 had this as inline asm and took it out (hazards the compiler does not see in asm); this is
+// plain C, selected by the compiler itself -- which needs -fno-slp-vectorize (build.py): the SLP vectoriser otherwise packs the two
+// fmas into a v_pk_fma_f32 behind two back-conversions.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_convertvector(v, f16x2);
+    const f32x2 s = v * kSplitScale;
+    lo[0] = (_Float16)__builtin_fmaf((float)hi[0], -kSplitScale, s[0]);
+    lo[1] = (_Float16)__builtin_fmaf((float)hi[1], -kSplitScale, s[1]);
+}
 __device__ __forceinline__ void split8(const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) {
+#if defined(PSP_SPLIT_CLASSIC) && PSP_SPLIT_CLASSIC
+    // (the wide family's translation units: hjbw_bwd_x3_kernel<500, 64> sits at 512 registers and spills 95 instead of 28 dwords with
+    //  the pair form and the SLP vectoriser off -- 5.2 -> 6.9 ms; they keep the round-3 form and flags, build.py)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         _Float16 h, l;
@@ -421,6 +450,13 @@ __device__ __forceinline__ void split8(const f32x4& u0, const f32x4& u1, f16x8& 
         split_f16(u1[e], h, l);
         hi[4 + e] = h; lo[4 + e] = l;
     }
+    return;
+#endif
+    f16x2 h, l;
+    split_pair(u0[0], u0[1], h, l); hi[0] = h[0]; hi[1] = h[1]; lo[0] = l[0]; lo[1] = l[1];
+    split_pair(u0[2], u0[3], h, l); hi[2] = h[0]; hi[3] = h[1]; lo[2] = l[0]; lo[3] = l[1];
+    split_pair(u1[0], u1[1], h, l); hi[4] = h[0]; hi[5] = h[1]; lo[4] = l[0]; lo[5] = l[1];
+    split_pair(u1[2], u1[3], h, l); hi[6] = h[0]; hi[7] = h[1]; lo[6] = l[0]; lo[7] = l[1];
 }
 // ... with the UNSCALED residual lo = f16(x - hi) (the weight-gradient outer products: one accumulator for all three terms)
 __device__ __forceinline__ void split8u(const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) {
@@ -879,7 +915,7 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
 #pragma unroll
             for (int m = 0; m < HB; ++m) h2[m] = vb2[m * 4];
             // Split-product FAST instances: the Brownian increments of this step are generated IN the W2 and W3 products --
-            // the 11 DB slices of the step's Philox calls (ten rounds and the Box-Muller finish per call) are dealt out over the
+            // the (R + 1) DB slices of the step's Philox calls (the R rounds and the Box-Muller finish per call) are dealt out over the
             // products' units and stand between their MFMAs.  An f16 MFMA stream hides three VALU instructions per MFMA
             // completely, even within one wave (tools/r3/ubench/mfma_valu_overlap.hip: 1 MFMA + 3 VALU 11.9 ns against 14.8 ns for
             // the MFMA alone); the noise was 22 % of the step standing by itself.  Bit-identical to philox_block.
@@ -887,10 +923,11 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             constexpr bool PREGEN = X3 && FAST && (NUH2 + NUH3 > 0);
             [[maybe_unused]] f32x4 xig[PREGEN ? DB : 1];
             [[maybe_unused]] uint32_t pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0;
+            constexpr int NSPC = kPhiloxRounds + 1;                                // slices per call: the rounds, then the Box-Muller finish
             auto philox_slice = [&](int sidx) __attribute__((always_inline)) {
-                const int b = sidx / 11, sub = sidx % 11;
+                const int b = sidx / NSPC, sub = sidx % NSPC;
                 if (sub == 0) { pc0 = kglob; pc1 = (uint32_t)n; pc2 = (uint32_t)(4 * b + q); pc3 = iter_now; }
-                if (sub < 10) {
+                if (sub < kPhiloxRounds) {
                     philox_round(pc0, pc1, pc2, pc3, a.seed_lo + (uint32_t)sub * 0x9E3779B9u, a.seed_hi + (uint32_t)sub * 0xBB67AE85u);
                     // (pins the round to this unit: pure arithmetic is otherwise sunk to its use in the noise phase, past the fences)
                     asm volatile("" : "+v"(pc0), "+v"(pc1), "+v"(pc2), "+v"(pc3));
@@ -908,8 +945,8 @@ __global__ __launch_bounds__(512) void hjb_fwd_kernel(const HjbArgs a) {
             auto philox_portion = [&](int u) __attribute__((always_inline)) {      // slices of unit u of the NUH2 + NUH3 units
                 if constexpr (PREGEN) {
 #pragma unroll
-                    for (int sidx = 0; sidx < 11 * DB; ++sidx)
-                        if (sidx >= u * (11 * DB) / (NUH2 + NUH3) && sidx < (u + 1) * (11 * DB) / (NUH2 + NUH3)) philox_slice(sidx);
+                    for (int sidx = 0; sidx < NSPC * DB; ++sidx)
+                        if (sidx >= u * (NSPC * DB) / (NUH2 + NUH3) && sidx < (u + 1) * (NSPC * DB) / (NUH2 + NUH3)) philox_slice(sidx);
                 }
             };
             // hidden activations for the backward pass (no recompute); split-product instances: h1 between the units of the

@@ -1,5 +1,6 @@
 """The on-device noise stream against its definition (oracle/philox_oracle.py).
-CPU: the numpy Philox4x32-10 reproduces the Random123 known-answer vectors, and its Box-Muller normals have the moments of N(0, 1).
+CPU: the numpy Philox4x32 reproduces the Random123 known-answer vectors of the 7-round generator the kernels run (and of the
+10-round one of rounds 1 - 3), and its Box-Muller normals have the moments of N(0, 1).
 GPU: psp_philox_normal_fill (the same device function the rollout kernels call: csrc/hjb_kernels.h philox_block) gives these
 normals -- counter layout, key, round count, uniform construction and feature mapping pinned; the tolerance covers the fp32
 hardware log / sqrt / sin / cos of the device against float64."""
@@ -12,9 +13,11 @@ import oracle.philox_oracle as po
 
 
 def test_numpy_philox_reproduces_the_random123_known_answers():
-    for ctr, key, want in po.KAT:
-        got = po.philox4x32_10(*[np.uint32(c) for c in ctr], key[0], key[1])
-        assert tuple(int(g) for g in got) == want, (ctr, key, [hex(int(g)) for g in got])
+    assert po.ROUNDS == 7
+    for rounds, kat in ((7, po.KAT7), (10, po.KAT)):
+        for ctr, key, want in kat:
+            got = po.philox4x32(*[np.uint32(c) for c in ctr], key[0], key[1], rounds=rounds)
+            assert tuple(int(g) for g in got) == want, (rounds, ctr, key, [hex(int(g)) for g in got])
 
 
 def test_numpy_normals_are_standard_normal():
