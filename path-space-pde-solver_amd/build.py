@@ -100,7 +100,7 @@ def _build(force, jobs, verbose, only):
                        os.path.join(CSRC, "hjbq_kernels.h"), os.path.join(CSRC, "hjbx_kernels.h")]))
     for d, H in instances("wide_instances.def"):
         tasks.append((winst_src, os.path.join(OBJ, "wide_inst_%d_%d.o" % (d, H)),
-                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + CLASSIC, [winst_src, whdr, hdr]))
+                      ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + CLASSIC, [winst_src, whdr, hdr, os.path.join(CSRC, "hjbc_kernels.h")]))
     for d, H in instances("gen_instances.def"):
         tasks.append((ginst_src, os.path.join(OBJ, "gen_inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + NOSLP, [ginst_src, ghdr, hdr]))

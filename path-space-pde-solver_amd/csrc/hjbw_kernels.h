@@ -347,9 +347,23 @@ __device__ __forceinline__ void gemm_img_x3(f32x4 (&acc)[MB], const float* __res
 #pragma unroll
             for (int m = 0; m < CH; m += 2) {                           // fresh SGPR base every 4 KiB (two output blocks)
                 if (c * CH + m < gn) {
+#if defined(PSP_ABL_WIDE) && (PSP_ABL_WIDE & 1)      // timing ablation: every S-step re-reads step 0's operands (L1 hits, same instruction stream)
+                    gptr8_t tp = sgpr_ptr8(tbl + ((size_t)(S & 0) * LD + g0 + c * CH + m) * 512);
+#elif defined(PSP_ABL_WIDE) && (PSP_ABL_WIDE & 2)    // ... every chunk re-reads ONE 4 KiB pair of blocks
+                    gptr8_t tp = sgpr_ptr8(tbl + ((size_t)(S & 0) * LD + ((g0 + c * CH + m) & 0)) * 512);
+#else
                     gptr8_t tp = sgpr_ptr8(tbl + ((size_t)S * LD + g0 + c * CH + m) * 512);
+#endif
+#if defined(PSP_ABL_WIDE) && (PSP_ABL_WIDE & 4)      // timing ablation: half the operand bytes (lo := hi, no second load)
+                    ah[st][m] = tp[ul]; al[st][m] = ah[st][m];
+                    if (m + 1 < CH && c * CH + m + 1 < gn) { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = ah[st][m + 1]; }
+#elif defined(PSP_ABL_WIDE) && (PSP_ABL_WIDE & 8)    // ... no operand loads inside the loop at all
+                    if (S == 0 && c == 0) { ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul]; if (m + 1 < CH) { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul]; } }
+                    else { asm volatile("" : "+v"(ah[st][m]), "+v"(al[st][m])); if (m + 1 < CH) asm volatile("" : "+v"(ah[st][m + 1]), "+v"(al[st][m + 1])); }
+#else
                     ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
                     if (m + 1 < CH && c * CH + m + 1 < gn) { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul]; }
+#endif
                 }
             }
         };
