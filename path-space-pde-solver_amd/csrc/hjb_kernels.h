@@ -1953,8 +1953,8 @@ struct HjbInstance {
     int (*bwd2_x3_lds_bytes)();                                                        // split-product backward, hjbx_kernels.h
     hipError_t (*launch_bwd2_x3)(const HjbArgs&, int grid, hipStream_t);               // (null: not built)
     hipError_t (*launch_adj_x3)(const HjbArgs&, int grid, int block, hipStream_t);     // split-product adjoint sweep (same LDS as the forward)
-    int (*coop_lds_bytes)();                                                           // hjbc_kernels.h: cooperative split-product forward of the wide
-    hipError_t (*launch_fwd_coop)(const HjbArgs&, int grid, hipStream_t);              // family, two tiles per 512-thread workgroup (null: not built)
+    int (*coop_lds_bytes)(int tiles);                                                  // hjbc_kernels.h: cooperative split-product forward of the wide
+    hipError_t (*launch_fwd_coop)(const HjbArgs&, int grid, int tiles, hipStream_t);   // family, 2 or 4 tiles per 512-thread workgroup (null: not built)
 };
 
 template <int D, int H>

@@ -26,113 +26,166 @@
 
 namespace psp {
 
-template <int D, int H>
+template <int D, int H, int NT_>
 struct GeoC {
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     static constexpr int DB = W::DB, HB = W::HB, KS8 = W::KS8;
-    static constexpr int NWV = 8, NT = 2, NB = 4, NP = 2;          // waves, tiles per workgroup, state blocks / S-steps per wave
+    static constexpr int NWV = 8, NT = NT_, NB = 4, NP = 2;        // waves, tiles per workgroup, state blocks / S-steps per wave
+    static_assert(NT == 2 || NT == 4, "two or four tiles per workgroup");
     static_assert(DB % 4 == 0 && DB <= NWV * NB, "the cooperative forward deals out whole groups of four state blocks");
     static constexpr int NOWN = DB / NB;                            // waves that own state blocks (the others only run the hidden layers)
+    static constexpr int NH = NT * HB / NWV;                        // hidden-layer outputs per wave: block w & 3 of tiles (w >> 2) NH + i
     static constexpr int IMG8 = KS8 * 2 * 64;                       // f16x8 elements of one tile's hi / lo image
-    // LDS (floats): the per-feature vectors of GeoW, then two image regions (state, increment), the h1 / h2 exchanges and the partial sums
-    static constexpr int cImg0 = W::fImg, cImg1 = cImg0 + NT * IMG8 * 4, cH1 = cImg1 + NT * IMG8 * 4, cH2 = cH1 + NT * HB * 256,
-                         cRed = cH2 + NT * HB * 256, lds_floats = cRed + 2 * NT * NWV * 16 + 64;
+    // Two tiles: separate regions for the state and the increment image and for the h1 / h2 exchanges (four barriers per step).
+    // Four tiles: ONE image region (4 x 32 KiB at d = 500) and one exchange buffer, with a barrier before each is overwritten (six).
+    static constexpr bool TWO = NT == 2;
+    // LDS (floats): the per-feature vectors of GeoW, the image region(s), the exchange(s), the partial sums
+    static constexpr int cImg0 = W::fImg, cImg1 = TWO ? cImg0 + NT * IMG8 * 4 : cImg0, cH1 = cImg1 + NT * IMG8 * 4,
+                         cH2 = TWO ? cH1 + NT * HB * 256 : cH1, cRed = cH2 + NT * HB * 256, lds_floats = cRed + 2 * NT * NWV * 16 + 64;
 };
 
-// acc[t][m] += T[S][b0 + m] . img[t][S] over all S-steps for the NB owned blocks of both tiles; WITHH: in the same loop
-// hacc += TH[S][hb] . img[htile][S] (the first hidden layer reads the same state image).  Rolled over S in pairs (static ring
-// indices), operands of the next S-step requested before the MFMAs of this one.
-template <int NB, int NT, int KS8, int LDT, bool WITHH, bool ALLOWN = false>
-__device__ __forceinline__ void coop_gemm(f32x4 (&acc)[NT][NB], const float* __restrict__ tbl, bool owner_, f32x4& hacc,
-                                          const float* __restrict__ tblh, int LDH, const f16x8* img8, int img_tile_stride, int htile,
-                                          int lane) {
-    static_assert(KS8 % 2 == 0 && NB % 2 == 0, "S-steps in pairs");
-    const bool owner = ALLOWN ? true : owner_;                          // (d = 500: every wave owns blocks -- no scalar branches in the k-loop)
+// acc[t][m] += T[S][b0 + m] . img[t][S] over all S-steps for the NB owned blocks of all NT tiles.  Rolled over S in pairs (static
+// ring indices); the A operands of S-step S + 1 are requested before the MFMAs of S, the B operands (LDS) one tile pair ahead.
+// `between(i)`: called once per S-step with i = 0 .. KS8 - 1 after the products of its first tile pair have been issued -- VALU work
+// of the caller that runs in the MFMAs' shadow (the step's Philox calls).
+struct NoCoopBetween { __device__ __forceinline__ void operator()(int) const {} };
+template <int NB, int NT, int KS8, int LDT, bool UNROLLED = false, class BT = NoCoopBetween>
+__device__ __forceinline__ void coop_gemm(f32x4 (&acc)[NT][NB], const float* __restrict__ tbl, const f16x8* img8, int img_tile_stride,
+                                          int lane, BT between = BT()) {
+    static_assert(KS8 % 2 == 0 && NB % 2 == 0 && NT % 2 == 0, "S-steps and tiles in pairs");
+    constexpr int NPAIR = NT / 2;
+    // B ring: two slots (a tile pair ahead) for two tiles; ONE for four tiles -- 16 accumulators more and a second slot spill
+    // (the pair's operands are re-requested into the same registers right behind its products; the partner wave covers the wait)
+    constexpr int BR = NT == 2 ? 2 : 1;
     const unsigned ul = (unsigned)lane;
     tbl = opaque_base(tbl);
-    tblh = opaque_base(tblh);
-    f16x8 ah[2][NB], al[2][NB], bh[2][NT], bl[2][NT];
-    [[maybe_unused]] f16x8 wh[2], wl[2];
+    f16x8 ah[2][NB], al[2][NB], bh[BR][2], bl[BR][2];
     f32x4 corr[NT][NB];
-    f32x4 hcorr = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < NB; ++m) corr[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto load = [&](int st, int S) __attribute__((always_inline)) {
-        if (owner) {
+    auto load_a = [&](int st, int S) __attribute__((always_inline)) {
 #pragma unroll
-            for (int m = 0; m < NB; m += 2) {                           // fresh SGPR base every 4 KiB (two output blocks)
-                gptr8_t tp = sgpr_ptr8(tbl + ((size_t)S * LDT + m) * 512);
-                ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
-                ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul];
+        for (int m = 0; m < NB; m += 2) {                               // fresh SGPR base every 4 KiB (two output blocks)
+            gptr8_t tp = sgpr_ptr8(tbl + ((size_t)S * LDT + m) * 512);
+            ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
+            ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul];
+        }
+    };
+    auto load_b = [&](int st, int S, int pr) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bh[st][i] = img8[(2 * pr + i) * img_tile_stride + (2 * S) * 64];
+            bl[st][i] = img8[(2 * pr + i) * img_tile_stride + (2 * S + 1) * 64];
+        }
+    };
+    auto products = [&](int sa, int sb, int pr) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < NB; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int t = 2 * pr + i;
+                acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[sa][m], bh[sb][i], acc[t][m], 0, 0, 0);
+                corr[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[sa][m], bl[sb][i], corr[t][m], 0, 0, 0);
+                corr[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[sa][m], bh[sb][i], corr[t][m], 0, 0, 0);
             }
-        }
-        if constexpr (WITHH) {
-            gptr8_t tp = sgpr_ptr8(tblh + (size_t)S * LDH * 512);
-            wh[st] = tp[ul]; wl[st] = tp[64 + ul];
-        }
+    };
+    // units u = S * NPAIR + pr; B ring index u & 1 (static: an S pair holds an even number of units), A ring index S & 1
+    load_a(0, 0);
+    load_b(0, 0, 0);
+    auto s_pair = [&](int S) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (owner || (WITHH && t == htile)) {
-                bh[st][t] = img8[t * img_tile_stride + (2 * S) * 64];
-                bl[st][t] = img8[t * img_tile_stride + (2 * S + 1) * 64];
+        for (int h = 0; h < 2; ++h) {
+            const int Sc = S + h;
+            const int Sn = Sc + 1 < KS8 ? Sc + 1 : KS8 - 1;             // past the end: re-read the last step (unused)
+            load_a((h + 1) & 1, Sn);
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                const int u = h * NPAIR + pr;                           // (parity of the unit within the S pair)
+                if constexpr (BR == 2) {
+                    if (pr + 1 < NPAIR) load_b((u + 1) & 1, Sc, pr + 1);
+                    else load_b((u + 1) & 1, Sn, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                products(h & 1, BR == 2 ? (u & 1) : 0, pr);
+                if (pr == 0) between(Sc);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (BR == 1) {
+                    if (pr + 1 < NPAIR) load_b(0, Sc, pr + 1);
+                    else load_b(0, Sn, 0);
+                }
             }
         }
     };
-    auto products = [&](int st) __attribute__((always_inline)) {
-        if (owner) {
+    if constexpr (UNROLLED) {                                           // (the caller's `between` needs the S-step as a constant)
 #pragma unroll
-            for (int m = 0; m < NB; ++m)
+        for (int S = 0; S < KS8; S += 2) s_pair(S);
+    } else {
+#pragma unroll 1
+        for (int S = 0; S < KS8; S += 2) s_pair(S);
+    }
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[st][m], bh[st][t], acc[t][m], 0, 0, 0);
-                    corr[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[st][m], bl[st][t], corr[t][m], 0, 0, 0);
-                    corr[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[st][m], bh[st][t], corr[t][m], 0, 0, 0);
-                }
-        }
-        if constexpr (WITHH) {
-            // the hidden block's tile: a bit select with a wave-uniform mask (a ?: here becomes a scalar branch inside the k-loop)
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const unsigned msk = htile == 0 ? 0u : ~0u;
-            const u32x4 h0 = __builtin_bit_cast(u32x4, bh[st][0]), h1 = __builtin_bit_cast(u32x4, bh[st][NT - 1]);
-            const u32x4 l0 = __builtin_bit_cast(u32x4, bl[st][0]), l1 = __builtin_bit_cast(u32x4, bl[st][NT - 1]);
-            const f16x8 xh = __builtin_bit_cast(f16x8, (h0 & ~msk) | (h1 & msk)), xl = __builtin_bit_cast(f16x8, (l0 & ~msk) | (l1 & msk));
-            hacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st], xh, hacc, 0, 0, 0);
-            hcorr = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st], xl, hcorr, 0, 0, 0);
-            hcorr = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[st], xh, hcorr, 0, 0, 0);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[t][m] = acc[t][m] + kSplitInv * corr[t][m];
+}
+
+// hacc[i] += TH[S][hb] . img[t0 + i][S]: the first hidden layer's block of this wave for its NH tiles (K = d: the same state image)
+template <int NH, int KS8, bool UNROLLED = false, class BT = NoCoopBetween>
+__device__ __forceinline__ void coop_hidden(f32x4 (&hacc)[NH], const float* __restrict__ tblh, int LDH, const f16x8* img8,
+                                            int img_tile_stride, int t0, int lane, BT between = BT()) {
+    const unsigned ul = (unsigned)lane;
+    tblh = opaque_base(tblh);
+    f16x8 wh[2], wl[2], bh[2][NH], bl[2][NH];
+    f32x4 corr[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) corr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int st, int S) __attribute__((always_inline)) {
+        gptr8_t tp = sgpr_ptr8(tblh + (size_t)S * LDH * 512);
+        wh[st] = tp[ul]; wl[st] = tp[64 + ul];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            bh[st][i] = img8[(t0 + i) * img_tile_stride + (2 * S) * 64];
+            bl[st][i] = img8[(t0 + i) * img_tile_stride + (2 * S + 1) * 64];
         }
     };
     load(0, 0);
+    auto s_pair = [&](int S) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int Sc = S + h;
+            load((h + 1) & 1, Sc + 1 < KS8 ? Sc + 1 : KS8 - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                hacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[h], bh[h][i], hacc[i], 0, 0, 0);
+                corr[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[h], bl[h][i], corr[i], 0, 0, 0);
+                corr[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[h], bh[h][i], corr[i], 0, 0, 0);
+            }
+            between(Sc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (UNROLLED) {
+#pragma unroll
+        for (int S = 0; S < KS8; S += 2) s_pair(S);
+    } else {
 #pragma unroll 1
-    for (int S = 0; S < KS8; S += 2) {
-        load(1, S + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        products(0);
-        __builtin_amdgcn_sched_barrier(0);
-        load(0, S + 2 < KS8 ? S + 2 : KS8 - 1);                         // past the end: re-read the last step (unused)
-        __builtin_amdgcn_sched_barrier(0);
-        products(1);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int S = 0; S < KS8; S += 2) s_pair(S);
     }
-    if (owner) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int m = 0; m < NB; ++m) acc[t][m] = acc[t][m] + kSplitInv * corr[t][m];
-    }
-    if constexpr (WITHH) hacc = hacc + kSplitInv * hcorr;
+    for (int i = 0; i < NH; ++i) hacc[i] = hacc[i] + kSplitInv * corr[i];
 }
 
-template <int D, int H>
+template <int D, int H, int NT_>
 __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
     PSP_COND_EXIT(a);
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
-    using C = GeoC<D, H>;
-    constexpr int DB = C::DB, HB = C::HB, KS8 = C::KS8, NT = C::NT, NB = C::NB, NP = C::NP, NWV = C::NWV;
-    static_assert(NT == 2, "two tiles per workgroup");
+    using C = GeoC<D, H, NT_>;
+    constexpr int DB = C::DB, HB = C::HB, KS8 = C::KS8, NT = C::NT, NB = C::NB, NP = C::NP, NWV = C::NWV, NH = C::NH;
     const int k_drift = a.drift_kind, k_sigma = a.sigma_kind, k_loss = a.loss_kind, k_store = a.store_path;
     const bool k_adaptive = a.adaptive != 0;
     const uint32_t iter_now = a.iter_dev ? *a.iter_dev : a.iter;
@@ -151,17 +204,17 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
         return (f < D && (k_drift == DRIFT_DIAG || k_drift == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
     stage_vec(lds + W::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
 
-    // ownership: state blocks b0 .. b0 + 3 (S-steps s0, s0 + 1) of both tiles; hidden block hb of tile ht
+    // ownership: state blocks b0 .. b0 + 3 (S-steps s0, s0 + 1) of all tiles; hidden block hb of tiles ht0 .. ht0 + NH - 1
     const bool owner = (C::NOWN == NWV) ? true : wave < C::NOWN;
     const int b0 = owner ? wave * NB : 0, s0 = owner ? wave * NP : 0;
-    const int hb = wave & 3, ht = wave >> 2;
+    const int hb = wave & 3, ht0 = (wave >> 2) * NH;
     int t16[NT], kk[NT];
     bool tvalid[NT], kvalid[NT];
     uint32_t kglob[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int raw = blockIdx.x * NT + t;
-        tvalid[t] = raw < a.ntile16;                     // the surplus tile of the last workgroup runs along on the last tile, stores nothing
+        tvalid[t] = raw < a.ntile16;                     // surplus tiles of the last workgroup run along on the last tile, store nothing
         t16[t] = tvalid[t] ? raw : a.ntile16 - 1;
         kk[t] = t16[t] * 16 + j;
         kvalid[t] = tvalid[t] && kk[t] < a.K_local;
@@ -169,15 +222,14 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
     }
     const float dt = a.dt, sqdt = a.sqdt;
     f16x8* img0 = reinterpret_cast<f16x8*>(lds + C::cImg0) + lane;      // state image   [tile][S][hi | lo][64]
-    f16x8* img1 = reinterpret_cast<f16x8*>(lds + C::cImg1) + lane;      // increment image
+    f16x8* img1 = reinterpret_cast<f16x8*>(lds + C::cImg1) + lane;      // increment image (four tiles: the same region)
     f32x4* hx1 = reinterpret_cast<f32x4*>(lds + C::cH1) + lane;         // h1 exchange [tile][block][64] of f32x4 (T layout: 4 r per lane)
-    f32x4* hx2 = reinterpret_cast<f32x4*>(lds + C::cH2) + lane;
+    f32x4* hx2 = reinterpret_cast<f32x4*>(lds + C::cH2) + lane;         // h2 exchange (four tiles: the same buffer)
     float* red = lds + C::cRed;                                         // [2][tile][wave][16]
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const float store_cxi = (k_store == 3) ? 0.f : 1.f;
     const float store_cz = (k_store == 3) ? 1.f : (k_store == 2 ? -a.sqdt : (k_adaptive ? 0.f : a.sqdt));
 
-    // ---- X_0 (solver.py:365-367): owned blocks of both tiles, T layout
+    // ---- X_0 (solver.py:365-367): owned blocks of all tiles, T layout
     f32x4 X[NT][NB];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -203,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
         }
     };
     write_image(img0, X);
-    float Y = a.y0 ? a.y0[0] : 0.f;                                      // (meaningful in waves 0 / 1: tile = wave)
+    float Y = a.y0 ? a.y0[0] : 0.f;                                      // (meaningful in waves 0 .. NT - 1: tile = wave)
     __syncthreads();
 
     const f32x4* vecs0 = reinterpret_cast<const f32x4*>(lds) + q;        // index by block * 4
@@ -237,14 +289,36 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
                     for (int e = 0; e < 4 * NB; ++e) PSP_PATH_STORE(px + e * 64 + ul, X[t][e >> 2][e & 3]);
                 }
         }
-        // ---- P12: x += (dt A) x_n on the owned blocks; first hidden layer, block hb of tile ht (function_space.py:190-195)
-        f32x4 h1 = vb1[hb * 4] + tn * vw1t[hb * 4];
-        if (k_drift == DRIFT_DENSE) {
-            coop_gemm<NB, NT, KS8, DB, true, C::NOWN == NWV>(X, T + W::xA + (size_t)b0 * 512, owner, h1, T + W::xW1 + (size_t)hb * 512, HB, img0, C::IMG8,
-                                              ht, lane);
-        } else {
-            f32x4 none[NT][NB];
-            coop_gemm<NB, NT, KS8, DB, true>(none, T + W::xA, false, h1, T + W::xW1 + (size_t)hb * 512, HB, img0, C::IMG8, ht, lane);
+        // ---- P2: x += (dt A) x_n on the owned blocks; the step's Brownian increments are generated in the shadow of its MFMAs
+        //      (one Philox call per S-step: NT NB calls, KS8 S-steps)
+        // (two tiles: the 8 calls run in the shadow of P2's MFMAs; four tiles: 64 more live registers there spill -- the 16 calls run
+        //  in the shadow of the first hidden layer's product, which comes AFTER P2 for that reason: both read the same state image)
+        constexpr bool XI_EARLY = NT == 2;
+        f32x4 xi[NT][NB];
+        auto xi_call = [&](int c) __attribute__((always_inline)) {      // call c = t * NB + m (compile-time after unrolling)
+            const int t = c / NB, m = c % NB, b = b0 + m;
+            f32x4 v = philox_block(kglob[t], (uint32_t)n, (uint32_t)(4 * b + qn), iter_now, a.seed_lo, a.seed_hi);
+            if (16 * (DB - 1) + 16 > D) {                               // partial last block: keep padded features at zero
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) v[r] = 0.f;
+            }
+            // (NOT pinned with an empty asm: the compiler sinks part of this arithmetic towards its use in P4; pinning it here keeps 16 - 64
+            //  more registers live across three phases and measured slower -- four tiles 12.0 -> 12.4 ms, two tiles unchanged)
+            xi[t][m] = v;
+        };
+        if (k_drift == DRIFT_DENSE && owner) {
+            // calls [Sc NC / KS8, (Sc + 1) NC / KS8) of the NC = NT NB calls stand behind S-step Sc (the S loop is unrolled: constants)
+            constexpr int NC = NT * NB;
+            if constexpr (XI_EARLY) {
+                coop_gemm<NB, NT, KS8, DB, true>(X, T + W::xA + (size_t)b0 * 512, img0, C::IMG8, lane, [&](int Sc) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (c >= Sc * NC / KS8 && c < (Sc + 1) * NC / KS8) xi_call(c);
+                });
+            } else {
+                coop_gemm<NB, NT, KS8, DB>(X, T + W::xA + (size_t)b0 * 512, img0, C::IMG8, lane);
+            }
+        } else if (owner) {
             if (k_drift == DRIFT_DIAG) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -257,70 +331,138 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
                     for (int m = 0; m < NB; ++m)
                         X[t][m] -= dt * (4.0f * vdr[(b0 + m) * 4] * (X[t][m] * (X[t][m] * X[t][m] - 1.0f)));
             }
-        }
-        PSP_STAMP(cs1);
-        h1 = tanh4(h1);
-        hx1[(ht * HB + hb) * 64] = h1;
-        if (k_store && tvalid[ht]) {
-            gwptr_t ph = pbase(ht, G::pH1 + hb * 256);
+            if constexpr (XI_EARLY) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) PSP_PATH_STORE(ph + r * 64 + ul, h1[r]);
+                for (int c = 0; c < NT * NB; ++c) xi_call(c);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PSP_STAMP(cs1);
+        // ---- P1: first hidden layer, block hb of this wave's NH tiles (function_space.py:190-195); tanh; exchange + path store
+        {
+            f32x4 h1[NH];
+#pragma unroll
+            for (int i = 0; i < NH; ++i) h1[i] = vb1[hb * 4] + tn * vw1t[hb * 4];
+            if constexpr (XI_EARLY) {
+                coop_hidden<NH, KS8>(h1, T + W::xW1 + (size_t)hb * 512, HB, img0, C::IMG8, ht0, lane);
+            } else {
+                constexpr int NC = NT * NB;
+                coop_hidden<NH, KS8, true>(h1, T + W::xW1 + (size_t)hb * 512, HB, img0, C::IMG8, ht0, lane, [&](int Sc) __attribute__((always_inline)) {
+                    if (owner) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            if (c >= Sc * NC / KS8 && c < (Sc + 1) * NC / KS8) xi_call(c);
+                    }
+                });
+            }
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                h1[i] = tanh4(h1[i]);
+                hx1[((ht0 + i) * HB + hb) * 64] = h1[i];
+                if (k_store && tvalid[ht0 + i]) {
+                    gwptr_t ph = pbase(ht0 + i, G::pH1 + hb * 256);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) PSP_PATH_STORE(ph + r * 64 + ul, h1[i][r]);
+                }
+            }
+        }
+        // the A operands of the two small products (W2: block hb; W3: the owned blocks; two S-steps each) do not depend on this step's
+        // activations: requested here, a barrier and a phase ahead of their use (P4 fetched them per tile, latency exposed every time)
+        f16x8 w2h[2], w2l[2], w3h[2][NB], w3l[2][NB];
+        {
+            const float* t2 = opaque_base(T + W::xW2 + (size_t)hb * 512);
+            const float* t3 = opaque_base(T + W::xW3 + (size_t)b0 * 512);
+#pragma unroll
+            for (int S = 0; S < 2; ++S) {
+                gptr8_t tp = sgpr_ptr8(t2 + (size_t)S * HB * 512);
+                w2h[S] = tp[ul]; w2l[S] = tp[64 + ul];
+                if (owner) {
+#pragma unroll
+                    for (int m = 0; m < NB; m += 2) {
+                        gptr8_t t3p = sgpr_ptr8(t3 + ((size_t)S * DB + m) * 512);
+                        w3h[S][m] = t3p[ul]; w3l[S][m] = t3p[64 + ul];
+                        w3h[S][m + 1] = t3p[128 + ul]; w3l[S][m + 1] = t3p[192 + ul];
+                    }
+                }
+            }
         }
         PSP_STAMP(cs2);
-        __syncthreads();                                                 // B
+        __syncthreads();                                                 // B: h1 exchange complete; every wave is done with the state image
         PSP_STAMP(cs3);
-        // ---- P3: second hidden layer, block hb of tile ht
+        // ---- P3: second hidden layer, block hb of this wave's tiles
         {
-            f32x4 hin[HB];
+            f32x4 h2[NH];
 #pragma unroll
-            for (int m = 0; m < HB; ++m) hin[m] = hx1[(ht * HB + m) * 64];
-            f32x4 h2[1] = {vb2[hb * 4]};
-            gemm_regs_x3<1, HB, HB>(h2, T + W::xW2 + (size_t)hb * 512, hin, lane);
-            h2[0] = tanh4(h2[0]);
-            hx2[(ht * HB + hb) * 64] = h2[0];
-            if (k_store && tvalid[ht]) {
-                gwptr_t ph = pbase(ht, G::pH2 + hb * 256);
+            for (int i = 0; i < NH; ++i) {
+                f32x4 hin[HB];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) PSP_PATH_STORE(ph + r * 64 + ul, h2[0][r]);
+                for (int m = 0; m < HB; ++m) hin[m] = hx1[((ht0 + i) * HB + m) * 64];
+                f32x4 acc1 = vb2[hb * 4], corr1 = {0.f, 0.f, 0.f, 0.f};       // (the order of gemm_regs_x3: S ascending, main, then the two corrections)
+#pragma unroll
+                for (int S = 0; S < 2; ++S) {
+                    f16x8 bh, bl;
+                    split_pack(hin[2 * S], hin[2 * S + 1], bh, bl);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[S], bh, acc1, 0, 0, 0);
+                    corr1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[S], bl, corr1, 0, 0, 0);
+                    corr1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[S], bh, corr1, 0, 0, 0);
+                }
+                h2[i] = tanh4(acc1 + kSplitInv * corr1);
+            }
+            if constexpr (!C::TWO) __syncthreads();                      // B2: every wave has read h1 -- h2 goes into the same buffer
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                hx2[((ht0 + i) * HB + hb) * 64] = h2[i];
+                if (k_store && tvalid[ht0 + i]) {
+                    gwptr_t ph = pbase(ht0 + i, G::pH2 + hb * 256);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) PSP_PATH_STORE(ph + r * 64 + ul, h2[i][r]);
+                }
             }
         }
         PSP_STAMP(cs4);
-        __syncthreads();                                                 // C
+        __syncthreads();                                                 // C: h2 exchange complete
         PSP_STAMP(cs5);
-        // ---- P4: Z = W3 h2 + b3 on the owned blocks, Brownian increment, row sums |Z|^2 and Z.xi (solver.py:477-478),
+        // ---- P4: Z = W3 h2 + b3 on the owned blocks, row sums |Z|^2 and Z.xi (solver.py:477-478),
         //      v = c dt + xi sqrt(dt) (c = -Z if adaptive, solver.py:451-456) -> increment image (dense sigma) or x += sigma v
-        f32x4 V[NT][NB];
         if (owner) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x4 hin[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m) hin[m] = hx2[(t * HB + m) * 64];
-                f32x4 Z[NB];
+                f32x4 Z[NB], zc[NB];
 #pragma unroll
-                for (int m = 0; m < NB; ++m) Z[m] = vb3[(b0 + m) * 4];
-                gemm_regs_x3<NB, HB, DB>(Z, T + W::xW3 + (size_t)b0 * 512, hin, lane);
+                for (int m = 0; m < NB; ++m) { Z[m] = vb3[(b0 + m) * 4]; zc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int S = 0; S < 2; ++S) {
+                    f16x8 bh, bl;
+                    split_pack(hin[2 * S], hin[2 * S + 1], bh, bl);
+#pragma unroll
+                    for (int m = 0; m < NB; ++m) {
+                        Z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3h[S][m], bh, Z[m], 0, 0, 0);
+                        zc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3h[S][m], bl, zc[m], 0, 0, 0);
+                        zc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3l[S][m], bh, zc[m], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < NB; ++m) Z[m] = Z[m] + kSplitInv * zc[m];
                 float S = 0.f, Pz = 0.f;
 #pragma unroll
                 for (int m = 0; m < NB; ++m) {
                     const int b = b0 + m;
-                    f32x4 xi = philox_block(kglob[t], (uint32_t)n, (uint32_t)(4 * b + qn), iter_now, a.seed_lo, a.seed_hi);
-                    if (16 * (DB - 1) + 16 > D) {                       // partial last block: keep padded features at zero
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) xi[r] = 0.f;
-                    }
+                    const f32x4 xv = xi[t][m];
                     if (k_store && tvalid[t]) {                         // image in the xi slot: c_xi xi + c_z Z (see hjb_fwd_kernel)
                         gwptr_t pxi = pbase(t, G::pXi + b * 256);
-                        const f32x4 wv = store_cxi * xi + store_cz * Z[m];
+                        const f32x4 wv = store_cxi * xv + store_cz * Z[m];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) PSP_PATH_STORE(pxi + r * 64 + ul, wv[r]);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         S = fmaf(Z[m][r], Z[m][r], S);
-                        Pz = fmaf(Z[m][r], xi[r], Pz);
+                        Pz = fmaf(Z[m][r], xv[r], Pz);
                     }
-                    V[t][m] = k_adaptive ? (sqdt * xi - dt * Z[m]) : (sqdt * xi);
+                    xi[t][m] = k_adaptive ? (sqdt * xv - dt * Z[m]) : (sqdt * xv);      // the increment v replaces xi
                 }
                 S = qsum(S);
                 Pz = qsum(Pz);
@@ -330,18 +472,18 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
                 }
             }
             if (k_sigma == SIGMA_DENSE) {
-                write_image(img1, V);
+                write_image(img1, xi);
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int m = 0; m < NB; ++m) X[t][m] += (k_sigma == SIGMA_SCALE ? a.sigma_scale : 1.0f) * V[t][m];
+                    for (int m = 0; m < NB; ++m) X[t][m] += (k_sigma == SIGMA_SCALE ? a.sigma_scale : 1.0f) * xi[t][m];
             }
         }
         PSP_STAMP(cs6);
-        __syncthreads();                                                 // D
+        __syncthreads();                                                 // D: increment image and partial sums complete
         PSP_STAMP(cs7);
-        // ---- Y += (-h + Z.c) dt + Z.xi sqrt(dt): waves 0 / 1 for tile 0 / 1, partials of the owning waves in a fixed order
+        // ---- Y += (-h + Z.c) dt + Z.xi sqrt(dt): wave t for tile t, partials of the owning waves in a fixed order
         if (wave < NT) {
             float S = 0.f, Pz = 0.f;
 #pragma unroll
@@ -357,20 +499,24 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
             }
         }
         // ---- P5: x += B v on the owned blocks, then the state image of the next step
-        if (k_sigma == SIGMA_DENSE) {
-            f32x4 nohid = zero4;
-            coop_gemm<NB, NT, KS8, DB, false, C::NOWN == NWV>(X, T + W::xB + (size_t)b0 * 512, owner, nohid, T, 0, img1, C::IMG8, 0, lane);
+        if (k_sigma == SIGMA_DENSE && owner)
+            coop_gemm<NB, NT, KS8, DB>(X, T + W::xB + (size_t)b0 * 512, img1, C::IMG8, lane);
+        if constexpr (!C::TWO) {
+            PSP_STAMP(cs8a);
+            __syncthreads();                                             // E: every wave is done with the increment image
+            PSP_STAMP(cs8b);
+            PSP_ACC(4, cs8b, cs8a);
         }
         write_image(img0, X);
         PSP_STAMP(cs8);
-        __syncthreads();                                                 // A (of the next step)
+        __syncthreads();                                                 // A (of the next step): state image complete
         PSP_STAMP(cs9);
-        PSP_ACC(0, cs1, cs0);   // X store + P12
+        PSP_ACC(0, cs1, cs0);   // X store + P2 (drift product [+ Philox])
         PSP_ACC(1, cs4, cs3);   // P3
         PSP_ACC(2, cs6, cs5);   // P4
-        PSP_ACC(3, cs8, cs7);   // Y + P5 + image
-        PSP_ACC(4, cs3, cs2); PSP_ACC(4, cs5, cs4); PSP_ACC(4, cs7, cs6); PSP_ACC(4, cs9, cs8);   // the four barriers
-        PSP_ACC(5, cs2, cs1);   // tanh + h1 exchange / store
+        PSP_ACC(3, cs8, cs7);   // Y + P5 + image (four tiles: with barrier E)
+        PSP_ACC(4, cs3, cs2); PSP_ACC(4, cs5, cs4); PSP_ACC(4, cs7, cs6); PSP_ACC(4, cs9, cs8);   // barriers B, C, D, A (+ E)
+        PSP_ACC(5, cs2, cs1);   // P1 (h1 [+ Philox])
         PSP_ACC(6, cs9, cs0);
     }
 #ifdef PSP_STAMPS
@@ -417,8 +563,10 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
 #pragma unroll
         for (int w = 0; w < C::NOWN; ++w) g += red[(wave * NWV + w) * 16 + j];
         const float Dk = Y - g;
-        const bool kv = wave == 0 ? kvalid[0] : kvalid[NT - 1];
-        const int k = wave == 0 ? kk[0] : kk[NT - 1];
+        bool kv = false;
+        int k = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) if (wave == t) { kv = kvalid[t]; k = kk[t]; }
         if (kv && q == 0) {
             a.D[k] = Dk;
             if (a.Fint) a.Fint[k] = 0.f;
@@ -441,17 +589,22 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
 
 template <int D, int H>
 struct HjbcLaunch {
-    using C = GeoC<D, H>;
-    static int lds_bytes() { return C::lds_floats * 4; }
-    // grid = ceil(ntile16 / 2) workgroups of 512 threads; the x3 tables of hjbw_tables_kernel(.., 3)
-    static hipError_t fwd(const HjbArgs& a, int grid, hipStream_t s) {
+    // tiles per workgroup: four when that still gives every CU a workgroup, else two
+    static int lds_bytes(int nt) { return (nt == 4 ? GeoC<D, H, 4>::lds_floats : GeoC<D, H, 2>::lds_floats) * 4; }
+    template <int NT>
+    static hipError_t fwd_nt(const HjbArgs& a, int grid, hipStream_t s) {
+        const int bytes = GeoC<D, H, NT>::lds_floats * 4;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbc_fwd_kernel<D, H, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((hjbc_fwd_kernel<D, H, NT>), dim3(grid), dim3(512), bytes, s, a);
+        return hipGetLastError();
+    }
+    // grid = ceil(ntile16 / nt) workgroups of 512 threads; the x3 tables of hjbw_tables_kernel(.., 3)
+    static hipError_t fwd(const HjbArgs& a, int grid, int nt, hipStream_t s) {
         hipError_t e = HjbwLaunch<D, H>::tables(a, 3, s);
         if (e != hipSuccess) return e;
-        const int bytes = C::lds_floats * 4;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbc_fwd_kernel<D, H>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((hjbc_fwd_kernel<D, H>), dim3(grid), dim3(512), bytes, s, a);
-        return hipGetLastError();
+        return nt == 4 ? fwd_nt<4>(a, grid, s) : fwd_nt<2>(a, grid, s);
     }
 };
 

@@ -104,7 +104,7 @@ constexpr int kMaxLds = 160 * 1024;
 struct Plan {
     psp::HjbInstance inst;
     int ntile16, fwd_waves, fwd_grid, bwd_waves, bwd_grid;
-    bool fwd_coop = false;   // wide family, split products, d > 256: hjbc_fwd_kernel (two tiles per 512-thread workgroup)
+    bool fwd_coop = false;   // wide family, split products, d > 256: hjbc_fwd_kernel (fwd_waves = 2 or 4 TILES per 512-thread workgroup)
     bool bwd_specialised;       // hjb_bwd2_kernel (producer / consumer waves) instead of hjb_bwd_kernel
     bool fwd_split;             // hjbs_fwd_kernel (four waves per tile) instead of hjb_fwd_kernel
     bool fwd_quad;              // hjbq_fwd_kernel (four trajectories per workgroup) for the smallest K
@@ -162,9 +162,11 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
     // (PSP_FWD_COOP=0 keeps the tile-per-wave kernel: A/B and parity tests of one against the other)
     {
         const char* fc = getenv("PSP_FWD_COOP");
-        p->fwd_coop = p->inst.wide && c->mlp_dtype == PSP_MLP_F16X3 && p->inst.launch_fwd_coop && p->inst.coop_lds_bytes() <= kMaxLds &&
+        // four tiles per workgroup while that still gives every CU one (a single round at K = 16 384), else two
+        const int nt = (fc && (fc[0] == '2' || fc[0] == '4')) ? fc[0] - '0' : (p->ntile16 >= 4 * cus ? 4 : 2);
+        p->fwd_coop = p->inst.wide && c->mlp_dtype == PSP_MLP_F16X3 && p->inst.launch_fwd_coop && p->inst.coop_lds_bytes(nt) <= kMaxLds &&
                       c->noise_mode == PSP_NOISE_PHILOX && c->runcost_kind == 0 && c->u_ref == nullptr && !(fc && fc[0] == '0');
-        if (p->fwd_coop) fw = 2;
+        if (p->fwd_coop) fw = nt;
     }
     p->fwd_waves = fw;
     p->fwd_grid = (p->ntile16 + fw - 1) / fw;
@@ -788,7 +790,7 @@ int psp_hjb_rollout_fwd(const psp_hjb_config* cfg, const float* params, const fl
         if (!p.inst.launch_fwd_bf16) return fail(-3, "the bf16 control-net mode exists for the narrow kernel family only");
         e = p.inst.launch_fwd_bf16(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);      // make_plan kept the tile-per-wave forward
     } else if (cfg->mlp_dtype == PSP_MLP_F16X3) {
-        e = p.fwd_coop ? p.inst.launch_fwd_coop(a, p.fwd_grid, (hipStream_t)stream)
+        e = p.fwd_coop ? p.inst.launch_fwd_coop(a, p.fwd_grid, p.fwd_waves, (hipStream_t)stream)
                        : p.inst.launch_fwd_x3(a, p.fwd_grid, p.fwd_waves * 64, (hipStream_t)stream);
         if (e == hipSuccess && cfg->range_flag) {
             // range guard: non-finite partials -> flag -> the fp32-MFMA forward of the same launch, predicated on the flag

@@ -36,8 +36,8 @@ for l in range(2):
 torch.cuda.synchronize()
 f = buf.cpu().double()[:fwg * 64].reshape(fwg, 8, 8)
 steps = f[:, :, 7].clamp(min=1)
-names = ["X store + P12 (drift product, h1)", "P3 (h2)", "P4 (Z, Philox, sums, v image)", "Y + P5 (sigma product) + image",
-         "four barriers", "tanh + h1 exchange", "whole step"]
+names = ["X store + P2 (drift product [+ Philox])", "P3 (h2)", "P4 (Z, [Philox,] sums, v image)", "Y + P5 (sigma product) [+ E] + image",
+         "barriers", "P1 (h1 [+ Philox]) + W2/W3 prefetch", "whole step"]
 tot = (f[:, :, 6] / steps).mean()
 print("workgroups %d; cycles per step (mean over waves) %.0f; MFMA floor per SIMD and step: 2 waves x 870 x 16 = %d" % (fwg, tot, 2 * 870 * 16))
 for i, n in enumerate(names):
