@@ -88,6 +88,8 @@ WORKLOADS = {
     # (118 GB / 946 GB) is bounded by the K-chunked two-pass plan (plan_native.py, path_budget_bytes)
     "hjb_llgc_d500_K131072_N200_h64": dict(d=500, H=64, K=131072, T=2.0, dt=0.01, off_diag=0.1 / 500 ** 0.5,
                                            path_budget_gb=32),
+    # ... and with the plan's own default budget (5/8 of the device memory): the per-GPU share fits the card whole (118 GB), one backward
+    "hjb_llgc_d500_K131072_N200_h64_resident": dict(d=500, H=64, K=131072, T=2.0, dt=0.01, off_diag=0.1 / 500 ** 0.5),
     "hjb_llgc_d500_K1048576_N200_h64": dict(d=500, H=64, K=1048576, T=2.0, dt=0.01, off_diag=0.1 / 500 ** 0.5,
                                             path_budget_gb=32),
     # the headline shape forced through the chunked plan (recompute overhead measured against the resident-store run)
