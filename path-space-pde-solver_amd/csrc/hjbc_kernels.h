@@ -31,15 +31,18 @@ struct GeoC {
     using G = Geo<D, H>;
     using W = GeoW<D, H>;
     static constexpr int DB = W::DB, HB = W::HB, KS8 = W::KS8;
-    static constexpr int NWV = 8, NT = NT_, NB = 4, NP = 2;        // waves, tiles per workgroup, state blocks / S-steps per wave
+    static constexpr int NWV = 8, NT = NT_;                         // waves, tiles per workgroup
     static_assert(NT == 2 || NT == 4, "two or four tiles per workgroup");
-    static_assert(DB % 4 == 0 && DB <= NWV * NB, "the cooperative forward deals out whole groups of four state blocks");
-    static constexpr int NOWN = DB / NB;                            // waves that own state blocks (the others only run the hidden layers)
+    // state blocks are dealt out in S-steps (pairs of blocks: one hi / lo pack of the images): NP S-steps = NB blocks per wave
+    static constexpr int NP = cdiv(KS8, NWV), NB = 2 * NP;          // d = 500: 2 / 4;  d = 192 .. 256: 1 / 2
+    static constexpr int NOWN = cdiv(KS8, NP);                      // waves that own state blocks (the others only run the hidden layers)
+    static constexpr bool MAYPAD = (DB % NB) != 0;                  // odd block count: the last owner's last block is padding (zero, never stored)
     static constexpr int NH = NT * HB / NWV;                        // hidden-layer outputs per wave: block w & 3 of tiles (w >> 2) NH + i
     static constexpr int IMG8 = KS8 * 2 * 64;                       // f16x8 elements of one tile's hi / lo image
-    // Two tiles: separate regions for the state and the increment image and for the h1 / h2 exchanges (four barriers per step).
-    // Four tiles: ONE image region (4 x 32 KiB at d = 500) and one exchange buffer, with a barrier before each is overwritten (six).
-    static constexpr bool TWO = NT == 2;
+    // Where they fit: separate regions for the state and the increment image and for the h1 / h2 exchanges (four barriers per step).
+    // Else (d = 500 with four tiles: 4 x 32 KiB per image): ONE image region and one exchange buffer, with a barrier before each is
+    // overwritten (six).
+    static constexpr bool TWO = (W::fImg + 2 * NT * IMG8 * 4 + 2 * NT * HB * 256 + 2 * NT * NWV * 16 + 64) * 4 <= 160 * 1024;
     // LDS (floats): the per-feature vectors of GeoW, the image region(s), the exchange(s), the partial sums
     static constexpr int cImg0 = W::fImg, cImg1 = TWO ? cImg0 + NT * IMG8 * 4 : cImg0, cH1 = cImg1 + NT * IMG8 * 4,
                          cH2 = TWO ? cH1 + NT * HB * 256 : cH1, cRed = cH2 + NT * HB * 256, lds_floats = cRed + 2 * NT * NWV * 16 + 64;
@@ -52,8 +55,8 @@ struct GeoC {
 struct NoCoopBetween { __device__ __forceinline__ void operator()(int) const {} };
 template <int NB, int NT, int KS8, int LDT, bool UNROLLED = false, class BT = NoCoopBetween>
 __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[NT][NB], const float* __restrict__ tbl, const f16x8* img8, int img_tile_stride,
-                                          int lane, BT between = BT()) {
-    static_assert(KS8 % 2 == 0 && NB % 2 == 0 && NT % 2 == 0, "S-steps and tiles in pairs");
+                                          int lane, BT between = BT(), bool padlast = false) {
+    static_assert(NB % 2 == 0 && NT % 2 == 0, "blocks and tiles in pairs");
     constexpr int NPAIR = NT / 2;
     // B ring: two slots (a tile pair ahead) for two tiles; ONE for four tiles -- 16 accumulators more and a second slot spill
     // (the pair's operands are re-requested into the same registers right behind its products; the partner wave covers the wait)
@@ -66,12 +69,16 @@ __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[NT][NB], const float* __r
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < NB; ++m) corr[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (a padding block -- the last owner's last block when the block count is odd -- re-reads its neighbour: no access past the table;
+    //  the caller zeroes its result)
+    const unsigned padofs = padlast ? 0u : 128u;
     auto load_a = [&](int st, int S) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < NB; m += 2) {                               // fresh SGPR base every 4 KiB (two output blocks)
             gptr8_t tp = sgpr_ptr8(tbl + ((size_t)S * LDT + m) * 512);
             ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
-            ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul];
+            if (m + 2 == NB) { ah[st][m + 1] = tp[padofs + ul]; al[st][m + 1] = tp[padofs + 64 + ul]; }
+            else { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul]; }
         }
     };
     auto load_b = [&](int st, int S, int pr) __attribute__((always_inline)) {
@@ -95,36 +102,33 @@ __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[NT][NB], const float* __r
     // units u = S * NPAIR + pr; B ring index u & 1 (static: an S pair holds an even number of units), A ring index S & 1
     load_a(0, 0);
     load_b(0, 0, 0);
-    auto s_pair = [&](int S) __attribute__((always_inline)) {
+    auto s_step = [&](int Sc, int h) __attribute__((always_inline)) {   // h = Sc & 1, as a constant
+        const int Sn = Sc + 1 < KS8 ? Sc + 1 : KS8 - 1;                 // past the end: re-read the last step (unused)
+        load_a((h + 1) & 1, Sn);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int Sc = S + h;
-            const int Sn = Sc + 1 < KS8 ? Sc + 1 : KS8 - 1;             // past the end: re-read the last step (unused)
-            load_a((h + 1) & 1, Sn);
-#pragma unroll
-            for (int pr = 0; pr < NPAIR; ++pr) {
-                const int u = h * NPAIR + pr;                           // (parity of the unit within the S pair)
-                if constexpr (BR == 2) {
-                    if (pr + 1 < NPAIR) load_b((u + 1) & 1, Sc, pr + 1);
-                    else load_b((u + 1) & 1, Sn, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                products(h & 1, BR == 2 ? (u & 1) : 0, pr);
-                if (pr == 0) between(Sc);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (BR == 1) {
-                    if (pr + 1 < NPAIR) load_b(0, Sc, pr + 1);
-                    else load_b(0, Sn, 0);
-                }
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            const int u = h * NPAIR + pr;                               // (parity of the unit within the S pair)
+            if constexpr (BR == 2) {
+                if (pr + 1 < NPAIR) load_b((u + 1) & 1, Sc, pr + 1);
+                else load_b((u + 1) & 1, Sn, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            products(h & 1, BR == 2 ? (u & 1) : 0, pr);
+            if (pr == 0) between(Sc);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (BR == 1) {
+                if (pr + 1 < NPAIR) load_b(0, Sc, pr + 1);
+                else load_b(0, Sn, 0);
             }
         }
     };
     if constexpr (UNROLLED) {                                           // (the caller's `between` needs the S-step as a constant)
 #pragma unroll
-        for (int S = 0; S < KS8; S += 2) s_pair(S);
+        for (int S = 0; S < KS8; ++S) s_step(S, S & 1);
     } else {
 #pragma unroll 1
-        for (int S = 0; S < KS8; S += 2) s_pair(S);
+        for (int S = 0; S + 1 < KS8; S += 2) { s_step(S, 0); s_step(S + 1, 1); }
+        if constexpr (KS8 & 1) s_step(KS8 - 1, 0);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -152,28 +156,25 @@ __device__ __forceinline__ void coop_hidden(f32x4 (&hacc)[NH], const float* __re
         }
     };
     load(0, 0);
-    auto s_pair = [&](int S) __attribute__((always_inline)) {
+    auto s_step = [&](int Sc, int h) __attribute__((always_inline)) {   // h = Sc & 1, as a constant
+        load((h + 1) & 1, Sc + 1 < KS8 ? Sc + 1 : KS8 - 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int Sc = S + h;
-            load((h + 1) & 1, Sc + 1 < KS8 ? Sc + 1 : KS8 - 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < NH; ++i) {
-                hacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[h], bh[h][i], hacc[i], 0, 0, 0);
-                corr[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[h], bl[h][i], corr[i], 0, 0, 0);
-                corr[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[h], bh[h][i], corr[i], 0, 0, 0);
-            }
-            between(Sc);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < NH; ++i) {
+            hacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[h], bh[h][i], hacc[i], 0, 0, 0);
+            corr[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[h], bl[h][i], corr[i], 0, 0, 0);
+            corr[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[h], bh[h][i], corr[i], 0, 0, 0);
         }
+        between(Sc);
+        __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (UNROLLED) {
 #pragma unroll
-        for (int S = 0; S < KS8; S += 2) s_pair(S);
+        for (int S = 0; S < KS8; ++S) s_step(S, S & 1);
     } else {
 #pragma unroll 1
-        for (int S = 0; S < KS8; S += 2) s_pair(S);
+        for (int S = 0; S + 1 < KS8; S += 2) { s_step(S, 0); s_step(S + 1, 1); }
+        if constexpr (KS8 & 1) s_step(KS8 - 1, 0);
     }
 #pragma unroll
     for (int i = 0; i < NH; ++i) hacc[i] = hacc[i] + kSplitInv * corr[i];
@@ -204,9 +205,17 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
         return (f < D && (k_drift == DRIFT_DIAG || k_drift == DRIFT_DWELL)) ? a.drift[f] : 0.f; });
     stage_vec(lds + W::vterm, DB, tid, nthr, [&](int f) { return f < D ? a.term[f] : 0.f; });
 
-    // ownership: state blocks b0 .. b0 + 3 (S-steps s0, s0 + 1) of all tiles; hidden block hb of tiles ht0 .. ht0 + NH - 1
+    // ownership: state blocks b0 .. b0 + NB - 1 (S-steps s0 .. s0 + NP - 1) of all tiles; hidden block hb of tiles ht0 .. ht0 + NH - 1
     const bool owner = (C::NOWN == NWV) ? true : wave < C::NOWN;
     const int b0 = owner ? wave * NB : 0, s0 = owner ? wave * NP : 0;
+    const bool padlast = C::MAYPAD && (b0 + NB > DB);                    // this wave's last block is padding: clamp its reads, zero its values, no stores
+    auto blk = [&](int m) __attribute__((always_inline)) { return (C::MAYPAD && m == NB - 1 && padlast) ? b0 + m - 1 : b0 + m; };
+    auto zero_pad = [&](f32x4 (&V)[NT][NB]) __attribute__((always_inline)) {
+        if (C::MAYPAD && padlast) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) V[t][NB - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
     const int hb = wave & 3, ht0 = (wave >> 2) * NH;
     int t16[NT], kk[NT];
     bool tvalid[NT], kvalid[NT];
@@ -286,7 +295,8 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
                 if (tvalid[t]) {
                     gwptr_t px = pbase(t, G::pX + b0 * 256);
 #pragma unroll
-                    for (int e = 0; e < 4 * NB; ++e) PSP_PATH_STORE(px + e * 64 + ul, X[t][e >> 2][e & 3]);
+                    for (int e = 0; e < 4 * NB; ++e)
+                        if (!(C::MAYPAD && (e >> 2) == NB - 1 && padlast)) PSP_PATH_STORE(px + e * 64 + ul, X[t][e >> 2][e & 3]);
                 }
         }
         // ---- P2: x += (dt A) x_n on the owned blocks; the step's Brownian increments are generated in the shadow of its MFMAs
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
         auto xi_call = [&](int c) __attribute__((always_inline)) {      // call c = t * NB + m (compile-time after unrolling)
             const int t = c / NB, m = c % NB, b = b0 + m;
             f32x4 v = philox_block(kglob[t], (uint32_t)n, (uint32_t)(4 * b + qn), iter_now, a.seed_lo, a.seed_hi);
-            if (16 * (DB - 1) + 16 > D) {                               // partial last block: keep padded features at zero
+            if (16 * (DB - 1) + 16 > D || C::MAYPAD) {                  // partial last block / padding block: keep padded features at zero
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) v[r] = 0.f;
             }
@@ -314,22 +324,23 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c)
                         if (c >= Sc * NC / KS8 && c < (Sc + 1) * NC / KS8) xi_call(c);
-                });
+                }, padlast);
             } else {
-                coop_gemm<NB, NT, KS8, DB>(X, T + W::xA + (size_t)b0 * 512, img0, C::IMG8, lane);
+                coop_gemm<NB, NT, KS8, DB>(X, T + W::xA + (size_t)b0 * 512, img0, C::IMG8, lane, NoCoopBetween(), padlast);
             }
+            zero_pad(X);
         } else if (owner) {
             if (k_drift == DRIFT_DIAG) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int m = 0; m < NB; ++m) X[t][m] += dt * (vdr[(b0 + m) * 4] * X[t][m]);
+                    for (int m = 0; m < NB; ++m) X[t][m] += dt * (vdr[blk(m) * 4] * X[t][m]);
             } else if (k_drift == DRIFT_DWELL) {                        // b = -4 kappa x (x^2 - 1), problems.py:311-315
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int m = 0; m < NB; ++m)
-                        X[t][m] -= dt * (4.0f * vdr[(b0 + m) * 4] * (X[t][m] * (X[t][m] * X[t][m] - 1.0f)));
+                        X[t][m] -= dt * (4.0f * vdr[blk(m) * 4] * (X[t][m] * (X[t][m] * X[t][m] - 1.0f)));
             }
             if constexpr (XI_EARLY) {
 #pragma unroll
@@ -380,8 +391,9 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                     for (int m = 0; m < NB; m += 2) {
                         gptr8_t t3p = sgpr_ptr8(t3 + ((size_t)S * DB + m) * 512);
+                        const unsigned o2 = (m + 2 == NB && padlast) ? 0u : 128u;
                         w3h[S][m] = t3p[ul]; w3l[S][m] = t3p[64 + ul];
-                        w3h[S][m + 1] = t3p[128 + ul]; w3l[S][m + 1] = t3p[192 + ul];
+                        w3h[S][m + 1] = t3p[o2 + ul]; w3l[S][m + 1] = t3p[o2 + 64 + ul];
                     }
                 }
             }
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
                 for (int m = 0; m < HB; ++m) hin[m] = hx2[(t * HB + m) * 64];
                 f32x4 Z[NB], zc[NB];
 #pragma unroll
-                for (int m = 0; m < NB; ++m) { Z[m] = vb3[(b0 + m) * 4]; zc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int m = 0; m < NB; ++m) { Z[m] = vb3[blk(m) * 4]; zc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                 for (int S = 0; S < 2; ++S) {
                     f16x8 bh, bl;
@@ -446,12 +458,13 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
                 }
 #pragma unroll
                 for (int m = 0; m < NB; ++m) Z[m] = Z[m] + kSplitInv * zc[m];
+                if (C::MAYPAD && padlast) Z[NB - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 float S = 0.f, Pz = 0.f;
 #pragma unroll
                 for (int m = 0; m < NB; ++m) {
                     const int b = b0 + m;
                     const f32x4 xv = xi[t][m];
-                    if (k_store && tvalid[t]) {                         // image in the xi slot: c_xi xi + c_z Z (see hjb_fwd_kernel)
+                    if (k_store && tvalid[t] && !(C::MAYPAD && m == NB - 1 && padlast)) {   // image in the xi slot: c_xi xi + c_z Z (see hjb_fwd_kernel)
                         gwptr_t pxi = pbase(t, G::pXi + b * 256);
                         const f32x4 wv = store_cxi * xv + store_cz * Z[m];
 #pragma unroll
@@ -500,7 +513,8 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
         }
         // ---- P5: x += B v on the owned blocks, then the state image of the next step
         if (k_sigma == SIGMA_DENSE && owner)
-            coop_gemm<NB, NT, KS8, DB>(X, T + W::xB + (size_t)b0 * 512, img1, C::IMG8, lane);
+            coop_gemm<NB, NT, KS8, DB>(X, T + W::xB + (size_t)b0 * 512, img1, C::IMG8, lane, NoCoopBetween(), padlast);
+        zero_pad(X);
         if constexpr (!C::TWO) {
             PSP_STAMP(cs8a);
             __syncthreads();                                             // E: every wave is done with the increment image
@@ -534,7 +548,8 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
             float g = 0.f;
 #pragma unroll
             for (int m = 0; m < NB; ++m) {
-                const f32x4 tv = vterm[(b0 + m) * 4];
+                if (C::MAYPAD && m == NB - 1 && padlast) continue;       // (a padding block has no terminal cost: (0 - 1)^2 tv is not zero)
+                const f32x4 tv = vterm[blk(m) * 4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float x = X[t][m][r];

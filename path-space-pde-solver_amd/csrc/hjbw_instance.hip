@@ -4,10 +4,10 @@
 #ifndef PSP_D
 #error "compile with -DPSP_D=<d> -DPSP_H=<H>"
 #endif
-// d > 256 with whole groups of four state blocks: the cooperative split-product forward (hjbc_kernels.h) beside the tile-per-wave one
+// six or more 32-feature steps (d > 160): the cooperative split-product forward (hjbc_kernels.h) beside the tile-per-wave one
 template <int D_, int H_>
 static void psp_add_coop(psp::HjbInstance& r) {
-    if constexpr (D_ > 256 && psp::GeoW<D_, H_>::DB % 4 == 0) {
+    if constexpr (psp::GeoW<D_, H_>::KS8 >= 6) {
         r.coop_lds_bytes = &psp::HjbcLaunch<D_, H_>::lds_bytes;
         r.launch_fwd_coop = &psp::HjbcLaunch<D_, H_>::fwd;
     }
