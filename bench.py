@@ -693,7 +693,8 @@ def main():
         issued_x3 = None
     else:
         quad = plan.family != 2 and 4 * ntile <= cus and not bf16_mlp and os.environ.get("PSP_FWD_VARIANT") in (None, "3")
-        fwd_name = "hjbw_fwd_kernel" if plan.family == 2 else (
+        coop = int(getattr(plan.sizes, "fwd_coop_tiles", 0) or 0)     # cooperative wide forward (csrc/hjbc_kernels.h): tiles per workgroup
+        fwd_name = ("hjbc_fwd_kernel" if coop else "hjbw_fwd_kernel") if plan.family == 2 else (
             "hjbq_fwd_kernel" if quad else ("hjbs_fwd_kernel" if ntile <= 2 * cus else "hjb_fwd_kernel"))
         bwd_name = ("hjbw_bwd2_kernel" if plan.d_pad <= 256 else "hjbw_bwd_kernel") if plan.family == 2 else "hjb_bwd2_kernel"
         issued = issued_mfma_per_tile_step(plan.d_pad, plan.H_pad, dense, plan.family, bf16_mlp)
@@ -791,6 +792,9 @@ def main():
                                           if (getattr(plan, "family", 1) == 2 and plan.d_pad <= 256) else "")) if x3 else
                                       ("v_mfma_f32_16x16x32_bf16 for the control net, v_mfma_f32_16x16x4_f32 elsewhere" if bf16_mlp
                                        else "v_mfma_f32_16x16x4_f32"),
+                   "kernels": {"forward": fwd_name + (" (%d tiles per 512-thread workgroup)" % int(getattr(plan.sizes, "fwd_coop_tiles", 0))
+                                                       if (not outer and int(getattr(plan.sizes, "fwd_coop_tiles", 0) or 0)) else ""),
+                               "backward": bwd_name},
                    "launch": "hipGraph replay of the captured iteration" if graph else "eager launches",
                    "parallelism": "trajectory-sharded x%d (%s)" % (world, "gloo rehearsal on one GPU" if rehearsal else
                                                                     ("RCCL" if world > 1 else "single process")),

@@ -139,7 +139,8 @@ typedef struct psp_hjb_sizes {
     int32_t n_params;         /* p = (d+1)H+H + H*H+H + H*d+d                         */
     int32_t fwd_workgroups;
     int32_t bwd_workgroups;
-    int32_t reserved;
+    int32_t fwd_coop_tiles;   /* 0.4.0 (the former `reserved`): 2 or 4 when psp_hjb_rollout_fwd runs the cooperative wide forward
+                               * (hjbc_fwd_kernel: that many 16-trajectory tiles per 512-thread workgroup), else 0 */
 } psp_hjb_sizes;
 
 int psp_version(void);

@@ -764,6 +764,7 @@ int psp_hjb_query(const psp_hjb_config* cfg, psp_hjb_sizes* out) {
     out->n_params = p.inst.n_params;
     out->fwd_workgroups = p.fwd_grid;
     out->bwd_workgroups = p.bwd_grid;
+    out->fwd_coop_tiles = p.fwd_coop ? p.fwd_waves : 0;
     out->path_bytes = cfg->store_path
         ? (int64_t)cfg->N * p.ntile16 * (int64_t)p.inst.path_floats_per_tile_step * 4 : 0;
     // the wide family keeps its A-operand tables behind the partial sums in the same caller-owned scratch

@@ -62,7 +62,7 @@ class HjbSizes(C.Structure):
     _fields_ = [
         ("path_bytes", C.c_int64), ("fwd_partial_bytes", C.c_int64), ("grad_partial_bytes", C.c_int64),
         ("n_params", C.c_int32), ("fwd_workgroups", C.c_int32), ("bwd_workgroups", C.c_int32),
-        ("reserved", C.c_int32),
+        ("fwd_coop_tiles", C.c_int32),
     ]
 
 
@@ -98,7 +98,7 @@ class GenSizes(C.Structure):
     _fields_ = [
         ("path_bytes", C.c_int64), ("ahat_bytes", C.c_int64), ("grad_partial_bytes", C.c_int64),
         ("n_params", C.c_int32), ("fwd_workgroups", C.c_int32), ("bwd_workgroups", C.c_int32),
-        ("reserved", C.c_int32),
+        ("fwd_coop_tiles", C.c_int32),
     ]
 
 

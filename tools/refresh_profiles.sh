@@ -15,7 +15,7 @@ for W in $WL; do
     STEPS=20; WARM=5
     case $W in
         hjb_llgc_d100_K1024_N50_h64|hjb_llgc_d100_K4096_N50_h64) STEPS=200; WARM=20;;
-        hjb_llgc_d500_K131072_N200_h64|hjb_llgc_d200_Kglobal262144_N100_h64) STEPS=4; WARM=1;;
+        hjb_llgc_d500_K131072_N200_h64|hjb_llgc_d500_K131072_N200_h64_resident|hjb_llgc_d200_Kglobal262144_N100_h64) STEPS=4; WARM=1;;
         hjb_llgc_d500_K1048576_N200_h64) STEPS=2; WARM=1;;
         diffusion_allencahn_d100_K200_N25_a110) STEPS=100; WARM=10;;
         elliptic_committor_d10_K200) STEPS=20; WARM=3;;
