@@ -42,7 +42,9 @@ extern "C" {
 
 #define PSP_VERSION 400 /* 0.3.0: range_flag in psp_hjb_config / psp_gen_config (guarded split-product mode); 0.3.1: store_path 4;
                          * 0.4.0: PSP_DOM_ANNULUS; psp_genl_config.activation / linear_layout, psp_genl_rollout_bwd replaces
-                         *        psp_genl_adjoints (hand-written weight gradient), psp_genl_sizes re-laid out */
+                         *        psp_genl_adjoints (hand-written weight gradient), psp_genl_sizes re-laid out; the backward side of
+                         *        the range guard; psp_hjb_sizes.fwd_coop_tiles (the former `reserved`); the on-device noise is
+                         *        Philox4x32-7 (psp_philox_normal_fill and every rollout kernel: 10 rounds before) */
 
 /* drift b(x): reference problems.py:36-37,154-155 (dense), :311-315 (double well) */
 enum { PSP_DRIFT_ZERO = 0, PSP_DRIFT_DENSE = 1, PSP_DRIFT_DIAG = 2, PSP_DRIFT_DOUBLE_WELL = 3 };
