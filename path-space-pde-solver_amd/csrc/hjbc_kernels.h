@@ -60,7 +60,7 @@ __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[NT][NB], const float* __r
     constexpr int NPAIR = NT / 2;
     // B ring: two slots (a tile pair ahead) for two tiles; ONE for four tiles -- 16 accumulators more and a second slot spill
     // (the pair's operands are re-requested into the same registers right behind its products; the partner wave covers the wait)
-    constexpr int BR = NT == 2 ? 2 : 1;
+    constexpr int BR = (NT == 2 || NB == 2) ? 2 : 1;                  // (d = 500, four tiles, two slots: 12.08 -> 12.33 ms; d = 256: 4.01 -> 3.98)
     const unsigned ul = (unsigned)lane;
     tbl = opaque_base(tbl);
     f16x8 ah[2][NB], al[2][NB], bh[BR][2], bl[BR][2];
