@@ -312,8 +312,12 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (16 * b + 4 * r + q >= D) v[r] = 0.f;
             }
+#if defined(PSP_XI_PIN) && PSP_XI_PIN
+            asm volatile("" : "+v"(v));            // (A/B switch)
+#endif
             // (NOT pinned with an empty asm: the compiler sinks part of this arithmetic towards its use in P4; pinning it here keeps 16 - 64
-            //  more registers live across three phases and measured slower -- four tiles 12.0 -> 12.4 ms, two tiles unchanged)
+            //  more registers live across three phases and measured slower -- four tiles 11.9 -> 12.3 ms, two tiles unchanged: the
+            //  "shadow" of the hidden layer's product is not free, the vector issue port is as busy there as in P4)
             xi[t][m] = v;
         };
         if (k_drift == DRIFT_DENSE && owner) {
@@ -379,14 +383,14 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
         }
         // the A operands of the two small products (W2: block hb; W3: the owned blocks; two S-steps each) do not depend on this step's
         // activations: requested here, a barrier and a phase ahead of their use (P4 fetched them per tile, latency exposed every time)
+        // (W3 early only where its 16 NB registers fit beside the increments: with four tiles of four blocks they are requested at the
+        //  top of P4 instead -- d = 500: 12.08 -> 11.9 ms)
+        constexpr bool W3_EARLY = !(NT == 4 && NB == 4);
         f16x8 w2h[2], w2l[2], w3h[2][NB], w3l[2][NB];
-        {
-            const float* t2 = opaque_base(T + W::xW2 + (size_t)hb * 512);
+        auto load_w3 = [&]() __attribute__((always_inline)) {
             const float* t3 = opaque_base(T + W::xW3 + (size_t)b0 * 512);
 #pragma unroll
             for (int S = 0; S < 2; ++S) {
-                gptr8_t tp = sgpr_ptr8(t2 + (size_t)S * HB * 512);
-                w2h[S] = tp[ul]; w2l[S] = tp[64 + ul];
                 if (owner) {
 #pragma unroll
                     for (int m = 0; m < NB; m += 2) {
@@ -397,6 +401,15 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
                     }
                 }
             }
+        };
+        {
+            const float* t2 = opaque_base(T + W::xW2 + (size_t)hb * 512);
+#pragma unroll
+            for (int S = 0; S < 2; ++S) {
+                gptr8_t tp = sgpr_ptr8(t2 + (size_t)S * HB * 512);
+                w2h[S] = tp[ul]; w2l[S] = tp[64 + ul];
+            }
+            if constexpr (W3_EARLY) load_w3();
         }
         PSP_STAMP(cs2);
         __syncthreads();                                                 // B: h1 exchange complete; every wave is done with the state image
@@ -437,6 +450,7 @@ __global__ __launch_bounds__(512, 2) void hjbc_fwd_kernel(const HjbArgs a) {
         // ---- P4: Z = W3 h2 + b3 on the owned blocks, row sums |Z|^2 and Z.xi (solver.py:477-478),
         //      v = c dt + xi sqrt(dt) (c = -Z if adaptive, solver.py:451-456) -> increment image (dense sigma) or x += sigma v
         if (owner) {
+            if constexpr (!W3_EARLY) load_w3();
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x4 hin[HB];
