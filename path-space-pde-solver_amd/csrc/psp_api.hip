@@ -165,8 +165,10 @@ int make_plan(const psp_hjb_config* c, Plan* p) {
         // four tiles per workgroup while that still gives every CU one (a single round at K = 16 384), else two
         const int nt = (fc && (fc[0] == '2' || fc[0] == '4')) ? fc[0] - '0' : (p->ntile16 >= 4 * cus ? 4 : 2);
         // measured (same box, K = 32 768): d = 200 tile-per-wave 3.53, two tiles 3.81, four tiles 3.27 ms; d = 256: 5.47 / 4.59 / 3.98; d = 500
-        // (K = 16 384): 16.9 / 12.5 / 11.9 -- four tiles wherever they fill the chip, two tiles only from d = 256 up
-        const bool coop_default = nt == 4 || c->d >= 256;
+        // (K = 16 384): 16.9 / 12.5 / 11.9.  The KERNEL must not depend on the launch size -- a K-chunked run reproduces the resident
+        // run's D bit for bit (tests/test_gpu_full_size.py), and two and four tiles sum in the same order while the tile-per-wave
+        // kernel does not -- so the cooperative kernel serves every size where it exists (8 % slower at d = 200 below K = 16 384)
+        const bool coop_default = true;
         p->fwd_coop = p->inst.wide && c->mlp_dtype == PSP_MLP_F16X3 && p->inst.launch_fwd_coop && p->inst.coop_lds_bytes(nt) <= kMaxLds &&
                       c->noise_mode == PSP_NOISE_PHILOX && c->runcost_kind == 0 && c->u_ref == nullptr && !(fc && fc[0] == '0') &&
                       (coop_default || (fc && fc[0] != '0'));
