@@ -414,14 +414,7 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // software wait states that the compiler inserts only for its own instructions.  (a) gave a 2e-4 gradient error and NaN at
 // d > 256, (c) run-to-run different gradients (499 entries, 6e-5) in gen_bwd2_kernel<.., X3>; the variant that avoids all three
 // needs extra moves and saves half an instruction per value (1 - 2 % of a kernel) -- not worth an unprovable rule set.
-__device__ __forceinline__ void split4(const f32x4& u, f16x4& hi, f16x4& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        _Float16 h, l;
-        split_f16(u[e], h, l);
-        hi[e] = h; lo[e] = l;
-    }
-}
+
 // Two values at a time (round 4): hi pair = ONE v_cvt_pk_f16_f32, 2048 x = one v_pk_mul_f32 for both, and each lo =
 // f16(fma(hi, -2048, 2048 x)) = one v_fma_mixlo/mixhi_f16 that reads its half of the hi pair directly -- two instructions per value
 // where the (x - float(hi)) * 2048 form compiles to four (convert back, subtract, multiply, convert).  The same value bit for bit:
@@ -437,6 +430,20 @@ __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& l
     const f32x2 s = v * kSplitScale;
     lo[0] = (_Float16)__builtin_fmaf((float)hi[0], -kSplitScale, s[0]);
     lo[1] = (_Float16)__builtin_fmaf((float)hi[1], -kSplitScale, s[1]);
+}
+__device__ __forceinline__ void split4(const f32x4& u, f16x4& hi, f16x4& lo) {
+#if defined(PSP_SPLIT_CLASSIC) && PSP_SPLIT_CLASSIC
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split_f16(u[e], h, l);
+        hi[e] = h; lo[e] = l;
+    }
+    return;
+#endif
+    f16x2 h, l;
+    split_pair(u[0], u[1], h, l); hi[0] = h[0]; hi[1] = h[1]; lo[0] = l[0]; lo[1] = l[1];
+    split_pair(u[2], u[3], h, l); hi[2] = h[0]; hi[3] = h[1]; lo[2] = l[0]; lo[3] = l[1];
 }
 __device__ __forceinline__ void split8(const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) {
 #if defined(PSP_SPLIT_CLASSIC) && PSP_SPLIT_CLASSIC
@@ -458,8 +465,16 @@ __device__ __forceinline__ void split8(const f32x4& u0, const f32x4& u1, f16x8& 
     split_pair(u1[0], u1[1], h, l); hi[4] = h[0]; hi[5] = h[1]; lo[4] = l[0]; lo[5] = l[1];
     split_pair(u1[2], u1[3], h, l); hi[6] = h[0]; hi[7] = h[1]; lo[6] = l[0]; lo[7] = l[1];
 }
-// ... with the UNSCALED residual lo = f16(x - hi) (the weight-gradient outer products: one accumulator for all three terms)
+// ... with the UNSCALED residual lo = f16(x - hi) (the weight-gradient outer products: one accumulator for all three terms); the pair
+// form: lo = f16(fma(hi, -1, x)), one v_fma_mixlo/hi_f16 per value (x - hi is exact: the same bits)
+__device__ __forceinline__ void split_pair_u(float a, float b, f16x2& hi, f16x2& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_convertvector(v, f16x2);
+    lo[0] = (_Float16)__builtin_fmaf((float)hi[0], -1.0f, v[0]);
+    lo[1] = (_Float16)__builtin_fmaf((float)hi[1], -1.0f, v[1]);
+}
 __device__ __forceinline__ void split8u(const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) {
+#if defined(PSP_SPLIT_CLASSIC) && PSP_SPLIT_CLASSIC
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         _Float16 h = (_Float16)u0[e];
@@ -467,6 +482,13 @@ __device__ __forceinline__ void split8u(const f32x4& u0, const f32x4& u1, f16x8&
         h = (_Float16)u1[e];
         hi[4 + e] = h; lo[4 + e] = (_Float16)(u1[e] - (float)h);
     }
+    return;
+#endif
+    f16x2 h, l;
+    split_pair_u(u0[0], u0[1], h, l); hi[0] = h[0]; hi[1] = h[1]; lo[0] = l[0]; lo[1] = l[1];
+    split_pair_u(u0[2], u0[3], h, l); hi[2] = h[0]; hi[3] = h[1]; lo[2] = l[0]; lo[3] = l[1];
+    split_pair_u(u1[0], u1[1], h, l); hi[4] = h[0]; hi[5] = h[1]; lo[4] = l[0]; lo[5] = l[1];
+    split_pair_u(u1[2], u1[3], h, l); hi[6] = h[0]; hi[7] = h[1]; lo[6] = l[0]; lo[7] = l[1];
 }
 template <int KS, int INB, class F>
 __device__ __forceinline__ void stage_aop_x3(float* dstf, int MB, int tid, int nthr, F src) {

@@ -312,15 +312,10 @@ __device__ __forceinline__ gptr8_t sgpr_ptr8(const float* p) {
 }
 // (the compiler's own split code here, not hjb_kernels.h's split8: with this family's rolled loops and 512-register waves the
 // inline-asm version measured 3 % slower at d = 500 -- A/B on one box, round 3)
+// (round 4: split8 itself -- the classic form in the wide translation units (-DPSP_SPLIT_CLASSIC), the two-instruction pair form in
+// the DenseNet-control units, which include this header and are compiled without the SLP vectoriser)
 __device__ __forceinline__ void split_pack(const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        _Float16 h, l;
-        split_f16(u0[e], h, l);
-        hi[e] = h; lo[e] = l;
-        split_f16(u1[e], h, l);
-        hi[4 + e] = h; lo[4 + e] = l;
-    }
+    split8(u0, u1, hi, lo);
 }
 // acc[MB] += T . img over KS8 S-steps; img: this wave's LDS image of hi / lo packs.  Rolled over S; within an S-step the output
 // blocks run in chunks of CH with the operands of the next chunk (or of the next S-step's first chunk) requested one chunk ahead.
