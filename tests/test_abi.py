@@ -61,6 +61,29 @@ def test_query_sizes_without_gpu(lib):
     assert s.grad_partial_bytes == s.bwd_workgroups * p * 4
 
 
+def test_query_reports_the_cooperative_wide_forward(lib, monkeypatch):
+    """psp_hjb_sizes.fwd_coop_tiles (0.4.0): d > 160 in split-product mode with on-device noise runs hjbc_fwd_kernel -- four tiles per
+    workgroup where that fills the chip, else two; the grid counts those workgroups; PSP_FWD_COOP=0 keeps the tile-per-wave kernel
+    (host-only calls: no GPU needed)."""
+    monkeypatch.delenv("PSP_FWD_COOP", raising=False)
+    for d, K, want in ((500, 16384, 4), (500, 4096, 2), (200, 32768, 4), (200, 1024, 2), (100, 65536, 0), (128, 65536, 0)):
+        c = _cfg()
+        c.d, c.K_local, c.mlp_dtype, c.noise_mode = d, K, nat.MLP_F16X3, nat.NOISE_PHILOX
+        s = nat.query(c)
+        assert s.fwd_coop_tiles == want, (d, K, s.fwd_coop_tiles)
+        if want:
+            assert s.fwd_workgroups == -(-(K // 16) // want)
+    c = _cfg()
+    c.d, c.K_local, c.mlp_dtype, c.noise_mode = 500, 16384, nat.MLP_F16X3, nat.NOISE_PHILOX
+    monkeypatch.setenv("PSP_FWD_COOP", "0")
+    assert nat.query(c).fwd_coop_tiles == 0
+    monkeypatch.setenv("PSP_FWD_COOP", "2")
+    assert nat.query(c).fwd_coop_tiles == 2
+    monkeypatch.delenv("PSP_FWD_COOP")
+    c.noise_mode = nat.NOISE_SUPPLIED                    # the cooperative kernel generates its increments on the device
+    assert nat.query(c).fwd_coop_tiles == 0
+
+
 def test_unsupported_shape_reports_error(lib):
     with pytest.raises(nat.NativeCallError) as e:
         nat.query(_cfg(d=3, H=7))
