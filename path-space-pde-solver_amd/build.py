@@ -101,6 +101,11 @@ def _build(force, jobs, verbose, only):
     for d, H in instances("wide_instances.def"):
         tasks.append((winst_src, os.path.join(OBJ, "wide_inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + CLASSIC, [winst_src, whdr, hdr, os.path.join(CSRC, "hjbc_kernels.h")]))
+    wxinst_src = os.path.join(CSRC, "hjbwx_instance.hip")
+    for d, H in instances("wide_instances.def"):
+        if d <= 256:        # the split-product role-specialised backward of these instances: its own unit, SLP vectoriser off
+            tasks.append((wxinst_src, os.path.join(OBJ, "widex_inst_%d_%d.o" % (d, H)),
+                          ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + NOSLP, [wxinst_src, os.path.join(CSRC, "hjbwx_kernels.h"), whdr, hdr]))
     for d, H in instances("gen_instances.def"):
         tasks.append((ginst_src, os.path.join(OBJ, "gen_inst_%d_%d.o" % (d, H)),
                       ["-DPSP_D=%d" % d, "-DPSP_H=%d" % H] + NOSLP, [ginst_src, ghdr, hdr]))

@@ -431,6 +431,19 @@ __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& l
     lo[0] = (_Float16)__builtin_fmaf((float)hi[0], -kSplitScale, s[0]);
     lo[1] = (_Float16)__builtin_fmaf((float)hi[1], -kSplitScale, s[1]);
 }
+// (four values whose packs feed v_mfma_f32_16x16x16f16 DIRECTLY -- the trailing 16-feature step of an odd block count -- keep the
+//  classic form: with the pair form below, v_fma_mixlo/hi_f16 writing the halves of the operand registers right in front of that
+//  MFMA gave run-to-run different results on gfx950 (the first output block's rows, d = 200: tools/r4/det_check.py) -- a hazard the
+//  compiler does not cover for this pair of instructions; packs that are combined into f16x8 operands of the 16x16x32 MFMAs first
+//  are not affected: every determinism test of those paths is bitwise stable)
+__device__ __forceinline__ void split4c(const f32x4& u, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split_f16(u[e], h, l);
+        hi[e] = h; lo[e] = l;
+    }
+}
 __device__ __forceinline__ void split4(const f32x4& u, f16x4& hi, f16x4& lo) {
 #if defined(PSP_SPLIT_CLASSIC) && PSP_SPLIT_CLASSIC
 #pragma unroll
@@ -585,7 +598,7 @@ __device__ __forceinline__ void gemm_Tx(f32x4 (&acc)[MB], const float* wlds, con
     }
     if constexpr (SG::ODD_H16) {
         f16x4 bh, bl;
-        split4(in[INB - 1], bh, bl);
+        split4c(in[INB - 1], bh, bl);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const f16x4* p = reinterpret_cast<const f16x4*>(wlds + mb * SG::per_mb + NS * 512) + lane;
@@ -648,7 +661,7 @@ __device__ __forceinline__ void gemm_Txs(f32x4 (&acc)[MB], const float* wlds, co
     }
     if constexpr (SG::ODD_H16) {
         f16x4 b4h, b4l;
-        split4(last, b4h, b4l);
+        split4c(last, b4h, b4l);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const f16x4* p = reinterpret_cast<const f16x4*>(wlds + mb * SG::per_mb + NS * 512) + lane;

@@ -52,8 +52,10 @@ struct GeoX {
 template <int NB>
 __device__ __forceinline__ void split_panel(const f32x4 (&v)[NB], f16x4 (&hi)[NB], f16x4 (&lo)[NB]) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-        split4(v[b], hi[b], lo[b]);
+    for (int b = 0; b < NB; ++b) {
+        if ((NB & 1) && b == NB - 1) split4c(v[b], hi[b], lo[b]);       // (a trailing odd block may feed 16x16x16 MFMAs directly: hjb_kernels.h split4c)
+        else split4(v[b], hi[b], lo[b]);
+    }
 }
 
 // gemm_Tx with the input panel already split (hi / lo per 16-feature block; `last` = the fp32 value in[INB-1][0] for the exact
