@@ -195,10 +195,15 @@ def issued_mfma_x3(d_pad, H_pad, dense, family=1):
 
     if family == 2:
         # wide family (hjbw_fwd_kernel<.., X3>): S-steps of 32 features over whole 16-blocks (KS8 = ceil(DB / 2)), three MFMAs per
-        # (S, output block); its backward kernels stay on fp32 MFMA
+        # (S, output block)
         ks8 = _cdiv(DB, 2)
         n = 3 * (ks8 * HB + 2 * HB + 2 * DB + (2 * ks8 * DB if dense else 0))
-        return {"f16_32": n, "f16_16": 0, "f32": 0}, None
+        bwd = None                                        # (d > 256: hjbw_bwd_x3_kernel, priced on the algorithmic flops only)
+        if d_pad <= 256 and HB == 4:
+            # hjbw_bwd2x_kernel (csrc/hjbwx_kernels.h), per sample block: producers W3^T G (prod(d, HB)) and W2^T dz2; consumers,
+            # per PAIR of blocks, four waves x (2 DB + HB) tiles x three MFMAs
+            bwd = add(prod(d_pad, HB), prod(H_pad, HB), {"f16_32": 4 * 3 * (2 * DB + HB) / 2.0, "f16_16": 0, "f32": 0})
+        return {"f16_32": n, "f16_16": 0, "f32": 0}, bwd
     fwd = add(prod(d_pad, HB), prod(H_pad, HB), prod(H_pad, DB), *([prod(d_pad, DB)] * (2 if dense else 0)))
     # backward: producers W3^T G and W2^T dz2 per block; consumers, per PAIR of blocks and wave, three MFMAs per owned tile
     # (dW3: DB, dW2: HB, dW1: HB x ceil(DB / 4)), four waves
@@ -703,7 +708,11 @@ def main():
                 bwd_name = "hjb_bwd3_kernel"
             elif plan.d_pad > 256:
                 bwd_name = "hjbw_bwd_x3_kernel"
+            elif os.environ.get("PSP_WIDE_BWD_X3", "1")[:1] != "0":
+                bwd_name = "hjbw_bwd2x_kernel"
             issued_x3 = issued_mfma_x3(plan.d_pad, plan.H_pad, dense, plan.family)
+            if plan.family == 2 and bwd_name == "hjbw_bwd2_kernel":      # (A/B switch: the fp32-MFMA backward)
+                issued_x3 = (issued_x3[0], None)
         if quad:
             issued = (issued_mfma_quad_kernel(plan.d_pad, plan.H_pad, dense), 0, issued[2])
     bwd_dominant = bwd_ms >= fwd_ms

@@ -106,7 +106,7 @@ typedef struct psp_hjb_config {
                            * fp32 matrix rate); same parity bounds as PSP_MLP_FP32 (D within 2e-5, gradient 2e-4, loss 1e-4 of the
                            * reference; observed 1e-6), operands must stay below 65504 in magnitude.  Narrow family: forward
                            * (hjb_fwd_kernel mode 2, tile-per-wave kernel only), adjoint sweep and backward (hjb_bwd3_kernel); wide
-                           * family: forward, adjoint sweep and the d > 256 backward (hjbw_bwd_x3_kernel; hjbw_bwd2_kernel, d <= 256, runs fp32 MFMA); DenseNet
+                           * family: forward, adjoint sweep and backward (d > 256: hjbw_bwd_x3_kernel; d <= 256: hjbw_bwd2x_kernel); DenseNet
                            * controls (psp_dnet_*): forward and adjoint sweep; -3 where an instance does not have the mode or its
                            * tables do not fit the LDS.  The weight-carrying operands of the backward passes (~1 / K) are scaled by
                            * a power of two inside the kernels and the results scaled back (exact).

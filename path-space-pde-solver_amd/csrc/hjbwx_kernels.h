@@ -16,6 +16,10 @@
 #pragma once
 #include "hjbw_kernels.h"
 
+#ifndef PSP_ABL_WX
+#define PSP_ABL_WX 0   // measurement only (tools/r4): 1 = consumers without their MFMAs (operands stay live)
+#endif
+
 namespace psp {
 
 template <int D, int H>
@@ -26,7 +30,11 @@ struct GeoBX {
     static constexpr int tbl2F = SplitGeo<KSH, HB>::floats(HB);         // split W2^T table (producers)
     static constexpr int oZ1 = 4 * HB * 64, oWts = 2 * 4 * HB * 64, EXQ = oWts + 64;   // per block: dz2 and dz1 k-step images, 16 weights
     static constexpr int bufs = tblF + tbl2F, oScan = bufs + 2 * 4 * EXQ, lds_floats = oScan + 16;
-    static constexpr int RD = 8;                                        // ring depth in item PAIRS (two f32x4 each)
+#ifdef PSP_WX_RD
+    static constexpr int RD = PSP_WX_RD;                                // (measurement builds)
+#else
+    static constexpr int RD = DB <= 13 ? 10 : 8;                        // ring depth in item PAIRS (two f32x4 each): what the consumer's
+#endif                                                                  // 4 (2 DB + HB) accumulator registers leave room for without spills
     static constexpr int NIP = 2 * DB + 2;                              // items of a pair: h2, h1, DB xi tiles, DB X tiles
     static constexpr int NIR = ((2 * NIP + RD - 1) / RD) * RD;          // items of a round, padded to a multiple of RD
     static constexpr int RS = 16 * DB + 3 * 16 * HB;                    // per-producer bias-sum slots: G | dz2 | dz1 | t dz1
@@ -51,10 +59,6 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
     const float* __restrict__ P = a.params;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-#ifdef PSP_DIAG_ZERO_LDS
-    for (int i = tid; i < BX::lds_floats; i += nthr) lds[i] = 0.f;
-    __syncthreads();
-#endif
     stage_aop_x3<KSD, DB>(lds, HB, tid, nthr, [&](int row, int col) {   // W3^T as a split A-operand table (producers)
         return (row < H && col < D) ? P[G::oW3 + col * H + row] : 0.f; });
     stage_aop_x3<KSH, HB>(lds + BX::tblF, HB, tid, nthr, [&](int row, int col) {   // W2^T likewise: dz1[i] = sum_o W2[o][i] dz2[o]
@@ -116,7 +120,11 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xin[b][r] = pb[G::pXi + (4 * b + r) * 64];
         }
+#ifdef PSP_STAMPS
+        unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         for (int it = 0; it <= R; ++it) {
+            PSP_STAMP(tp0);
             if (it < R) {
                 const long long blk0 = own_block(it);
                 const bool bvalid = blk0 >= 0;
@@ -140,17 +148,6 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
                 for (int m = 0; m < HB; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) h2[m][r] = pb[G::pH2 + (4 * m + r) * 64];
-                {
-                    const long long n0 = own_block(it + 1);
-                    const long long nblk1 = n0 >= 0 ? n0 : nblk - 1;
-                    const float* pn = a.path + (size_t)nblk1 * (size_t)G::PB + lane;
-                    const int k1 = (int)(nblk1 % a.ntile16) * 16 + j;
-                    dkn = a.D[k1 < a.K_local ? k1 : 0];
-#pragma unroll
-                    for (int b = 0; b < DB; ++b)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) xin[b][r] = pn[G::pXi + (4 * b + r) * 64];
-                }
                 if (q == 0) ex[BX::oWts + j] = wks;   // the consumers weight their h2 operand with it
                 f32x4 dz2[HB];
 #pragma unroll
@@ -161,6 +158,20 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 4 * HB; ++ks) ex[ks * 64 + lane] = dz2[ks >> 2][ks & 3];
                 __builtin_amdgcn_sched_barrier(0);        // (G is dead from here: its registers take h1 and dz1)
+                {                                         // the next round's xi tiles: requested once G is dead (the dz1 half of
+                                                          // the round and the barrier cover their latency), so that xin and G
+                                                          // never hold 2 DB tiles at the same time
+                    const long long n0 = own_block(it + 1);
+                    const long long nblk1 = n0 >= 0 ? n0 : nblk - 1;
+                    const float* pn = a.path + (size_t)nblk1 * (size_t)G::PB + lane;
+                    const int k1 = (int)(nblk1 % a.ntile16) * 16 + j;
+                    dkn = a.D[k1 < a.K_local ? k1 : 0];
+#pragma unroll
+                    for (int b = 0; b < DB; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xin[b][r] = pn[G::pXi + (4 * b + r) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 f32x4 h1[HB], dz1[HB];
 #pragma unroll
                 for (int m = 0; m < HB; ++m)
@@ -175,8 +186,17 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 4 * HB; ++ks) ex[BX::oZ1 + ks * 64 + lane] = dz1[ks >> 2][ks & 3];
             }
+            PSP_STAMP(tp1);
             __syncthreads();                              // swap the exchange buffers (pairs with the consumer loop)
+            PSP_STAMP(tp2);
+            PSP_ACC(0, tp1, tp0); PSP_ACC(1, tp2, tp1);
         }
+#ifdef PSP_STAMPS
+        if (a.dbg && lane == 0) {
+            stamps[7] = (unsigned long long)R;
+            for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+        }
+#endif
         float* red = bufs + sub * RS;                     // bias sums -> LDS (the exchange area is free after the last barrier)
 #pragma unroll
         for (int b = 0; b < DB; ++b)
@@ -235,6 +255,9 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
     };
     auto pack = [&](const f32x4& u0, const f32x4& u1, f16x8& hi, f16x8& lo) __attribute__((always_inline)) { split8u(u0, u1, hi, lo); };
     auto mma3 = [&](f32x4& acc, const f16x8& Ah, const f16x8& Al, const f16x8& Bh, const f16x8& Bl) __attribute__((always_inline)) {
+#if (PSP_ABL_WX & 1)
+        acc[0] += (float)Ah[0] + (float)Al[1] + (float)Bh[2] + (float)Bl[3]; return;   // ablation: operands stay live, no MFMA
+#endif
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, acc, 0, 0, 0);
@@ -244,7 +267,11 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
     static_for<0, RD - 1>([&](auto gi) { item_load(gi); });             // (inside the first pair: RD - 1 <= NIP)
     static_assert(RD - 1 <= NIP, "prologue stays inside the first pair");
     __syncthreads();                                      // pairs with producer iteration 0
+#ifdef PSP_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int it = 1; it <= R; ++it) {
+        PSP_STAMP(tc0);
         const int rb = (blockIdx.x + (it - 1) * gridDim.x) * 4;
         const float* exch = bufs + ((it - 1) & 1) * 4 * EXQ;
         bb[0] = blk_at(rb); bb[1] = blk_at((long long)rb + 1); bb[2] = blk_at((long long)rb + 2); bb[3] = blk_at((long long)rb + 3);
@@ -297,8 +324,17 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
         // padding items of the round (re-reads; keep the ring's slot arithmetic): their loads are issued, nothing consumes them
         static_for<2 * NIP, NIR>([&](auto gc) { item_load(std::integral_constant<int, decltype(gc)::value + RD - 1>{}); });
         // the ring now holds the first RD - 1 items of the next round's first pair
+        PSP_STAMP(tc1);
         __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
+        PSP_STAMP(tc2);
+        PSP_ACC(0, tc1, tc0); PSP_ACC(1, tc2, tc1);
     }
+#ifdef PSP_STAMPS
+    if (a.dbg && lane == 0) {
+        stamps[7] = (unsigned long long)R;
+        for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+    }
+#endif
 
     // ---- flush: same mapping as hjbw_bwd2_kernel (tile rows = 16 ob + 4 qq + rr, columns = 16 ib + col), scaled back
     float* gp = a.grad_partial + (size_t)blockIdx.x * G::P;
