@@ -6,7 +6,7 @@
 //     v_mfma_f32_16x16x32_f16 on ONE accumulator (operands split with unscaled residuals, as in hjbw_bwd_x3_kernel and
 //     hjbd_bwd_kernel<.., X3>): dW3 += xi^T (w h2), dW2 += dz2^T h1, dW1 += dz1^T X_n; dz1 = (W2^T dz2)(1 - h1^2) moves to the
 //     producers (a second split table, 24 f16 MFMAs; the consumers kept its W2 block in 16 registers and ran it as 16 fp32 MFMAs);
-//   * the trajectory weights carry a power of two that maps  max_k |w_k| sqrt(dt) 8  (one scan of D per workgroup) into [2^6, 2^7):
+//   * the trajectory weights carry a power of two that maps  max_k |w_k| sqrt(dt) 8  (one scan of D per workgroup) into [2^10, 2^11):
 //     every weighted operand (G, dz2, dz1, w h2) then has normal f16 residuals; all accumulators are scaled back when they are
 //     written (exact);
 //   * the streamed tiles (h2, h1, then the xi and X_n tiles of both blocks of a pair) run through one register ring of RD item pairs
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
         for (int w = 1; w < 8; ++w) m8 = fmaxf(m8, scan[w]);
         const float amax = m8 * a.sqdt * 8.0f;
         const unsigned e = (__float_as_uint(amax) >> 23) & 0xFFu;
-        const bool ok = e >= 7u && e <= 253u;                            // zero / tiny / non-finite weights: no scaling
-        const float sc = ok ? __uint_as_float((260u - e) << 23) : 1.0f;
-        ginv = ok ? __uint_as_float((e - 6u) << 23) : 1.0f;
+        const bool ok = e >= 11u && e <= 253u;                           // zero / tiny / non-finite weights: no scaling
+        const float sc = ok ? __uint_as_float((264u - e) << 23) : 1.0f;  // largest |w| sqrt(dt) 8 -> [2^10, 2^11): hjbw_bwd_x3_kernel's scale
+        ginv = ok ? __uint_as_float((e - 10u) << 23) : 1.0f;
         gs = a.sqdt * sc;
     }
     const long long nblk = (long long)a.N * a.ntile16;

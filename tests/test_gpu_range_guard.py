@@ -234,6 +234,37 @@ def test_bwd3_gradient_scale_comes_from_all_weights(kind):
     assert float((g3 - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
 
 
+@pytest.mark.parametrize("kind", ["zero_first_round", "outlier_1e5"])
+def test_wide_split_backward_gradient_scale_comes_from_all_weights(kind):
+    """hjbw_bwd2x_kernel (wide family, d <= 256) scales the trajectory weights by one power of two per launch, taken from a scan of
+    ALL weights: a workgroup whose first round carries zero weights, and one weight 1e5 x the others, against the fp32-MFMA
+    kernel per workgroup and against the oracle's gradient of sum_k w_k D_k."""
+    case = load_golden("llgc_d200_h64_logvar")["case"]
+    K = 1040
+    model = make_pkg_solver(case, dev(), backend="native", noise="philox", L=1, K=K, mlp_dtype="f16x3")
+    from util_cases import flat_params
+    params0 = flat_params(model.z_n).to(dev())
+    model.train()
+    plan = model._native_plan
+    assert plan.matrix_mode == "f16x3" and plan.family == 2 and plan.pad.identity
+    g = torch.Generator(device="cpu").manual_seed(7)
+    w = (torch.randn(K, generator=g) * (2.0 / K)).to(dev())
+    if kind == "zero_first_round":
+        w[:64] = 0.0
+    else:
+        w[777] = 1.0e5 * (2.0 / K)
+    g3, rows3 = _bwd(plan, model, params0, w, nat.MLP_F16X3)
+    g2, rows2 = _bwd(plan, model, params0, w, nat.MLP_FP32)
+    assert torch.isfinite(g3).all() and not torch.equal(g3, g2)
+    scale = float(g2.abs().max())
+    assert float((g3 - g2).abs().max()) <= 2e-5 * scale, float((g3 - g2).abs().max()) / scale
+    rs = rows2.abs().max(dim=1).values.clamp_min(1e-30)
+    rel = ((rows3 - rows2).abs().max(dim=1).values / rs)
+    assert float(rel.max()) <= 1e-4, (int(rel.argmax()), float(rel.max()))
+    g_ref = _oracle_weighted_gradient(case, K, model, w).to(dev())
+    assert float((g3 - g_ref).abs().max()) <= 2e-4 * float(g_ref.abs().max())
+
+
 # ---- backward side of the guard (round 4, ADVICE r3): the forward stays finite, the split-product BACKWARD does not ------------
 def test_backward_overflow_with_a_finite_forward_is_caught():
     """relu^2 pre-activations around 200: h = r^2 = 4e4 is a finite f16 forward operand, so the forward raises no flag -- but the
