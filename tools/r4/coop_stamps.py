@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase cycle breakdown of hjbc_fwd_kernel (d = 500) from in-kernel s_memtime stamps.
+"""Diagnostic: per-phase cycle breakdown of hjbc_fwd_kernel (default d = 500; usage: coop_stamps.py [d] [K] [N]) from in-kernel s_memtime stamps.
 Needs csrc/libpsp_hip_stamps.so (python tools/r4/coop_stamps.py builds the wide instance with -DPSP_STAMPS if missing)."""
 import importlib.util
 import os
@@ -20,7 +20,9 @@ import torch  # noqa: E402
 import path_space_pde_solver_amd as psp  # noqa: E402
 
 dev = torch.device("cuda:0")
-d, K, N = 500, 16384, 200
+d = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 prob = psp.LLGC(d=d, off_diag=0.01, T=N * 0.005, seed=42, device=dev)
 model = psp.Solver("coop", prob, lr=1e-3, L=4, K=K, delta_t=0.005, loss_method="log-variance", time_approx="inner",
                    adaptive_forward_process=True, detach_forward=True, u_l2_error_flag=False, verbose=False, seed=42, device=dev,
