@@ -1614,6 +1614,17 @@ __global__ __launch_bounds__(512) void hjbw_bwd2_kernel(const HjbArgs a) {
     }
 }
 
+// LDS layout of hjbw_bwd_x3_kernel (floats)
+template <int D, int H>
+struct BwdX3Lds {
+    using W = GeoW<D, H>;
+    static constexpr int oA1 = 4 * W::EXB, oWts = oA1 + 4 * W::HB * 256, oTbl = oWts + 128;
+    static constexpr int perS = W::HB * 512;                            // one S-step of the split W3^T table
+    static constexpr int room = (160 * 1024 / 4 - oTbl) / perS;
+    static constexpr int KSL = room < W::KS8 ? room : W::KS8;           // S-steps of the table held in LDS
+    static constexpr int floats = oTbl + KSL * perS;
+};
+
 // =======================================================================================
 // hjbw_bwd_x3_kernel: split-product version of hjbw_bwd_kernel for d > 256 (one wave per SIMD, 512 registers).  Same phases:
 //   phase A  wave w, block 4 round + w:  dz2 = (W3^T G)(1 - h2^2) with G = w sqrt(dt) xi split on the fly per 32-feature step
@@ -1695,7 +1706,19 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
 #pragma unroll
     for (int i = 0; i < OBW; ++i) bs3[i] = 0.f;
 
-    float* wts = lds + 2 * 4 * EXB + 4 * 16 * DB + 4 * HB * 256;        // [2 rounds][4 blocks][16] scaled trajectory weights
+    // LDS: one exchange buffer (a wave that runs ahead into the next round's phase A writes it while the others are in phase
+    // B2, which does not read it: the two barriers of a round order every other access), the dz1 tiles, the weights of two
+    // rounds, then the first KSL S-steps of the split W3^T table (all of it up to d = 480; d = 500: 15 of 16).  Phase A was
+    // 46 % of the round while every wave streamed the 128 KB table through its vector-memory path with two stages in flight
+    // (tools/r4/wbx3_stamps.py): 5.45 -> 4.60 ms at d = 500.  (A separate, deeper ring for the xi dwords measured slower: 4.85 /
+    // 5.11 ms with 4 / 6 slots -- spills.)
+    using XL = BwdX3Lds<D, H>;
+    constexpr int KSL = XL::KSL;
+    float* wts = lds + XL::oWts;                                        // [2 rounds][4 blocks][16] scaled trajectory weights
+    float* tblL = lds + XL::oTbl;
+    for (int i = tid; i < KSL * HB * 128; i += 256)
+        reinterpret_cast<f32x4*>(tblL)[i] = reinterpret_cast<const f32x4*>(T)[i];
+    __syncthreads();
     float w2b[16];                                                      // B operands of the dz1 products: W2[4 ks + q][16 ib + j]
 #pragma unroll                                                          // (512 registers here: kept for the whole kernel)
     for (int ks = 0; ks < 16; ++ks) {
@@ -1703,9 +1726,13 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
         w2b[ks] = (o < H && i < H) ? P[G::oW2 + o * H + i] : 0.f;
     }
     int par = 0;
+#ifdef PSP_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #pragma unroll 1
     for (long long round = blockIdx.x; round < nround; round += gridDim.x, par ^= 1) {
-        float* exch = lds + par * 4 * EXB;
+        PSP_STAMP(tx0);
+        float* exch = lds;
         // ------------------------------------------------------------------ phase A: own block
         {
             const long long blk0 = round * 4 + wave;
@@ -1735,9 +1762,17 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
                 }
 #pragma unroll
                 for (int m = 0; m < HB; m += 2) {
-                    gptr8_t tp = sgpr_ptr8(T + ((size_t)S * HB + m) * 512);
-                    ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
-                    if (m + 1 < HB) { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul]; }
+                    if (S < KSL) {                         // (S is a compile-time constant after unrolling)
+                        unsigned so = (unsigned)((S * HB + m) * 2048);      // byte offset as a scalar the compiler cannot fold:
+                        asm volatile("" : "+s"(so));                       // one v_add at the use instead of 32 hoisted (and
+                        const f16x8* tl = reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(tblL) + so);   // spilled) address registers
+                        ah[st][m] = tl[ul]; al[st][m] = tl[64 + ul];
+                        if (m + 1 < HB) { ah[st][m + 1] = tl[128 + ul]; al[st][m + 1] = tl[192 + ul]; }
+                    } else {
+                        gptr8_t tp = sgpr_ptr8(T + ((size_t)S * HB + m) * 512);
+                        ah[st][m] = tp[ul]; al[st][m] = tp[64 + ul];
+                        if (m + 1 < HB) { ah[st][m + 1] = tp[128 + ul]; al[st][m + 1] = tp[192 + ul]; }
+                    }
                 }
             };
             auto fma_stage = [&](int st, int S) __attribute__((always_inline)) {
@@ -1774,9 +1809,11 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
                 for (int r = 0; r < 4; ++r) ex[(4 * m + r) * 64] = dz2[m][r];
             }
         }
+        PSP_STAMP(tx1);
         __syncthreads();
+        PSP_STAMP(tx2);
         // ------------------------------------------------------------------ phase B1: wave = hidden block ib -- dz1 tiles, dW2
-        float* a1x = lds + 2 * 4 * EXB + 4 * 16 * DB;                   // [4 blocks][HB] dz1 tiles (f32x4 per lane), shared below
+        float* a1x = lds + XL::oA1;                                     // [4 blocks][HB] dz1 tiles (f32x4 per lane), shared below
 #pragma unroll 1
         for (int pr = 0; pr < 2; ++pr) {
             const long long c0 = round * 4 + 2 * pr;
@@ -1818,7 +1855,9 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
             reinterpret_cast<f32x4*>(a1x)[((2 * pr) * HB + wave) * 64 + lane] = a10;
             reinterpret_cast<f32x4*>(a1x)[((2 * pr + 1) * HB + wave) * 64 + lane] = a11;
         }
+        PSP_STAMP(tx3);
         __syncthreads();
+        PSP_STAMP(tx4);
         // ------------------------------------------------------------------ phase B2: wave owns the state blocks ob = wave + 4 o and ALL
         // hidden blocks: each xi / X tile of the pair is loaded and split by ONE wave (a quarter of the loads and of the VALU work
         // of a per-hidden-block stream), the h2 tiles and the dz1 tiles (LDS) of the four hidden blocks are its B / A operands
@@ -1891,7 +1930,16 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        PSP_STAMP(tx5);
+        PSP_ACC(0, tx1, tx0); PSP_ACC(1, tx3, tx2); PSP_ACC(2, tx5, tx4); PSP_ACC(3, tx2, tx1); PSP_ACC(3, tx4, tx3); PSP_ACC(6, tx5, tx0);
+#ifdef PSP_STAMPS
+        stamps[7] += 1;
+#endif
     }
+#ifdef PSP_STAMPS
+    if (a.dbg && lane == 0)
+        for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = stamps[i];
+#endif
     __syncthreads();
 
     // ---- write-out (layout of hjbw_bwd_kernel), scaled back by the weights' power of two
@@ -2022,7 +2070,7 @@ struct HjbwLaunch {
         } else {
             hipError_t e = tables(a, 5, s);
             if (e != hipSuccess) return e;
-            const int bytes = (W::bwd_lds_floats + 4 * W::HB * 256 + 128) * 4;   // + the shared dz1 tiles and the weights of a round
+            const int bytes = BwdX3Lds<D, H>::floats * 4;
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hjbw_bwd_x3_kernel<D, H>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return e;

@@ -70,3 +70,35 @@ def test_split_backward_survives_a_large_weight_spread():
     assert torch.equal(D0, D1)
     assert float(D0.abs().max()) / max(1e-30, float(D0.abs().min())) > 1e2
     assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
+
+
+@pytest.mark.parametrize("d,K,N", [(320, 2048, 12), (500, 2064, 10), (512, 1500, 16)])
+def test_streaming_backward_above_256_against_fp32_on_the_same_store(d, K, N):
+    """hjbw_bwd_x3_kernel (d > 256: four waves, the split W3^T table resident in LDS, ONE exchange buffer per workgroup -- a wave
+    that runs ahead into the next round writes it while the others are still in the last phase of the current one) against the
+    fp32-MFMA backward on the same path store with caller-supplied trajectory weights: several rounds per workgroup, a ragged
+    last tile, per workgroup and in total; three runs bit-equal."""
+    from test_gpu_range_guard import _bwd, nat
+    from util_cases import flat_params
+    dev = torch.device("cuda:0")
+    prob = psp.LLGC(d=d, off_diag=0.1 / d ** 0.5, T=N * 0.01, seed=42, device=dev)
+    m = psp.Solver("wx", prob, lr=1e-3, L=1, K=K, delta_t=0.01, loss_method="log-variance", time_approx="inner",
+                   adaptive_forward_process=True, detach_forward=True, u_l2_error_flag=False, verbose=False, seed=42,
+                   device=dev, backend="native", noise="philox", widths=(64, 64), mlp_dtype="f16x3")
+    params0 = flat_params(m.z_n).to(dev)
+    m.train()
+    plan = m._native_plan
+    assert plan.matrix_mode == "f16x3" and plan.family == 2
+    g = torch.Generator(device="cpu").manual_seed(11)
+    w = (torch.randn(K, generator=g) * (2.0 / K)).to(dev)
+    g3, rows3 = _bwd(plan, m, params0, w, nat.MLP_F16X3)
+    g2, rows2 = _bwd(plan, m, params0, w, nat.MLP_FP32)
+    assert rows3.shape[0] * 4 < N * ((K + 15) // 16), "every workgroup should run more than one round"
+    scale = float(g2.abs().max())
+    assert torch.isfinite(g3).all() and not torch.equal(g3, g2)
+    assert float((g3 - g2).abs().max()) <= 2e-5 * scale
+    rs = rows2.abs().max(dim=1).values.clamp_min(1e-30)
+    assert float(((rows3 - rows2).abs().max(dim=1).values / rs).max()) <= 1e-4
+    for _ in range(2):
+        g3b, rows3b = _bwd(plan, m, params0, w, nat.MLP_F16X3)
+        assert torch.equal(g3b, g3) and torch.equal(rows3b, rows3)
