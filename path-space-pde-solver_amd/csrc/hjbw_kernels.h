@@ -1710,14 +1710,14 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
     // B2, which does not read it: the two barriers of a round order every other access), the dz1 tiles, the weights of two
     // rounds, then the first KSL S-steps of the split W3^T table (all of it up to d = 480; d = 500: 15 of 16).  Phase A was
     // 46 % of the round while every wave streamed the 128 KB table through its vector-memory path with two stages in flight
-    // (tools/r4/wbx3_stamps.py): 5.45 -> 4.60 ms at d = 500.  (A separate, deeper ring for the xi dwords measured slower: 4.85 /
-    // 5.11 ms with 4 / 6 slots -- spills.)
+    // (tools/r4/wbx3_stamps.py): 5.45 -> 4.60 ms at d = 500; with the xi dwords in their own ring of seven slots and the table
+    // operands one step ahead 4.47 ms (3 / 5 / 8 / 9 / 11 slots: 4.55 / 4.67 / 4.65 / 4.80 / 4.84).
     using XL = BwdX3Lds<D, H>;
     constexpr int KSL = XL::KSL;
     float* wts = lds + XL::oWts;                                        // [2 rounds][4 blocks][16] scaled trajectory weights
     float* tblL = lds + XL::oTbl;
-    for (int i = tid; i < KSL * HB * 128; i += 256)
-        reinterpret_cast<f32x4*>(tblL)[i] = reinterpret_cast<const f32x4*>(T)[i];
+    for (int i = tid; i < KSL * HB * 128; i += 256)                     // (the LAST KSL S-steps: see phase A)
+        reinterpret_cast<f32x4*>(tblL)[i] = reinterpret_cast<const f32x4*>(T + (size_t)(KS8 - KSL) * HB * 512)[i];
     __syncthreads();
     float w2b[16];                                                      // B operands of the dz1 products: W2[4 ks + q][16 ib + j]
 #pragma unroll                                                          // (512 registers here: kept for the whole kernel)
@@ -1751,19 +1751,28 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
 #pragma unroll
             for (int m = 0; m < HB; ++m) { dz2[m] = zero4; dzc[m] = zero4; }
             const float* xip = pb + G::pXi;
-            constexpr int NSTG = 3;
-            float xb[NSTG][8];
-            f16x8 ah[NSTG][HB], al[NSTG][HB];
-            auto load = [&](int st, int S) __attribute__((always_inline)) {
+#ifndef PSP_WBX_NX
+#define PSP_WBX_NX 7
+#endif
+            // two rings: the xi dwords of an S-step are requested NX - 1 steps ahead (global memory), its table operands one step
+            // ahead (LDS; the KG <= 1 leading S-steps that did not fit are read from global memory in the prologue, where their
+            // latency hides behind the first xi requests)
+            constexpr int NX = PSP_WBX_NX, TS = 2, KG = KS8 - KSL;
+            static_assert(KG <= 1, "at most the first S-step of the table outside the LDS");
+            float xb[NX][8];
+            f16x8 ah[TS][HB], al[TS][HB];
+            auto load_x = [&](int st, int S) __attribute__((always_inline)) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int b = 2 * S + (e >> 2);            // block 2 S (e < 4) or 2 S + 1; past the last block: re-read it (zeroed below)
                     xb[st][e] = xip[(size_t)(4 * (b < DB ? b : DB - 1) + (e & 3)) * 64];
                 }
+            };
+            auto load_t = [&](int st, int S) __attribute__((always_inline)) {
 #pragma unroll
                 for (int m = 0; m < HB; m += 2) {
-                    if (S < KSL) {                         // (S is a compile-time constant after unrolling)
-                        unsigned so = (unsigned)((S * HB + m) * 2048);      // byte offset as a scalar the compiler cannot fold:
+                    if (S >= KG) {                         // (S is a compile-time constant after unrolling)
+                        unsigned so = (unsigned)(((S - KG) * HB + m) * 2048);   // byte offset as a scalar the compiler cannot fold:
                         asm volatile("" : "+s"(so));                       // one v_add at the use instead of 32 hoisted (and
                         const f16x8* tl = reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(tblL) + so);   // spilled) address registers
                         ah[st][m] = tl[ul]; al[st][m] = tl[64 + ul];
@@ -1775,13 +1784,14 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
                     }
                 }
             };
-            auto fma_stage = [&](int st, int S) __attribute__((always_inline)) {
+            // (splitting step S + 1's increments between the MFMAs of step S -- one scheduling region -- measured slower: 4.54 -> 4.77 ms)
+            auto fma_stage = [&](int sx, int st, int S) __attribute__((always_inline)) {
                 f16x8 bh, bl;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const bool inb = (2 * S + (e >> 2)) < DB;
                     _Float16 h, l;
-                    split_f16(inb ? wks * xb[st][e] : 0.f, h, l);
+                    split_f16(inb ? wks * xb[sx][e] : 0.f, h, l);
                     bh[e] = h; bl[e] = l;
                 }
 #pragma unroll
@@ -1791,13 +1801,16 @@ __global__ __launch_bounds__(256, 1) void hjbw_bwd_x3_kernel(const HjbArgs a) {
                     dzc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[st][m], bh, dzc[m], 0, 0, 0);
                 }
             };
-            load(0, 0);
-            if (KS8 > 1) load(1, 1);
+            load_t(0, 0);
+#pragma unroll
+            for (int S = 0; S < NX - 1; ++S)
+                if (S < KS8) load_x(S, S);
 #pragma unroll
             for (int S = 0; S < KS8; ++S) {
-                if (S + NSTG - 1 < KS8) load((S + NSTG - 1) % NSTG, S + NSTG - 1);
+                if (S + NX - 1 < KS8) load_x((S + NX - 1) % NX, S + NX - 1);
+                if (S + 1 < KS8) load_t((S + 1) % TS, S + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                fma_stage(S % NSTG, S);
+                fma_stage(S % NX, S % TS, S);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (q == 0) wts[par * 64 + wave * 16 + j] = wks;      // the block's 16 scaled weights, for phase B2 (no loads of D there)
