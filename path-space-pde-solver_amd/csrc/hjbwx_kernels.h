@@ -17,7 +17,8 @@
 #include "hjbw_kernels.h"
 
 #ifndef PSP_ABL_WX
-#define PSP_ABL_WX 0   // measurement only (tools/r4): 1 = consumers without their MFMAs (operands stay live)
+#define PSP_ABL_WX 0   // measurement only (tools/r4): 1 = consumers without their MFMAs (operands stay live); 4 = producers without
+                       // their xi reads (what fetching xi once could save at most: d = 200 1.85 -> 1.71 ms)
 #endif
 
 namespace psp {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512) void hjbw_bwd2x_kernel(const HjbArgs a) {
 #pragma unroll
                     for (int b = 0; b < DB; ++b)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) xin[b][r] = pn[G::pXi + (4 * b + r) * 64];
+                        for (int r = 0; r < 4; ++r) xin[b][r] = (PSP_ABL_WX & 4) ? 0.25f * (float)(b + r) : pn[G::pXi + (4 * b + r) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 h1[HB], dz1[HB];
