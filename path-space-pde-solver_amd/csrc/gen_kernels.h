@@ -52,6 +52,7 @@ struct GenArgs {
     uint32_t seed_lo, seed_hi, iter;
     const int* cond;      // launch predicate of the guarded split-product mode (hjb_kernels.h PSP_COND_EXIT)
     int cond_want;
+    unsigned long long* dbg;   // diagnostic builds (-DPSP_STAMPS): per-wave cycle sums of gen_bwd2_kernel (tools/r4/gen_stamps.py)
 };
 
 template <int D, int H>
@@ -933,6 +934,12 @@ __global__ __launch_bounds__(256, 2) void gen_bwd_kernel(const GenArgs a) {
 // f16 range, where the UNSCALED residual lo = f16(x - hi) is a normal number (for the unweighted O(1) operands a subnormal lo
 // costs at most 3e-8 absolute: fp32's own epsilon), so a.b = hi_a hi_b + hi_a lo_b + lo_a hi_b runs on ONE accumulator with no
 // 2048 anywhere.  Range: weighted adjoints stay below 65504 as long as the network factors (w3 phi', W2 products) stay below 256.
+// (Tried and dropped, round 4: stamps (tools/r4/gen_stamps.py) show the X3 consumers at 20.2 k cycles of work per round and the
+//  producers at 9.3 k + 11.4 k of barrier wait.  Moving the h rows of dW2 (4 of the consumers' 11 row items per block) to the
+//  producer waves -- producer p for column block p, on the buffer the consumers are reading, a four-slot ring of their own --
+//  is correct on all 172 value-net tests and levels the roles (17.5 k / 21.1 k), but the backward goes 4.25 -> 4.33-4.44 ms: a
+//  producer and a consumer wave share each SIMD, and what looked like idle producer time is what lets the consumers run at the
+//  CU's full load / issue rate.  The sum of the work per CU binds, not the longer role.)
 // (Tried and dropped: the role cut of hjb_bwd3_kernel -- producers writing the four adjoint panels pre-split as pair images,
 //  consumers owning ROW items for all column blocks so that each row operand is loaded and split by one wave only: 656 instead of
 //  2 111 VALU instructions per round in the consumers, correct on all 59 tests, but 20 accumulator tiles + three row items'
@@ -1011,7 +1018,11 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
             }
         };
         prefetch_block(0);
+#ifdef PSP_STAMPS
+        unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         for (int it = 0; it <= R; ++it) {
+            PSP_STAMP(tp0);
             if (it < R) {
                 const long long round = blockIdx.x + (long long)it * gridDim.x;
                 const long long rb = round * 4;
@@ -1104,8 +1115,17 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
 
                 asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]), "v"(touch[4]));
             }
+            PSP_STAMP(tp1);
             __syncthreads();                              // swap the exchange buffers (pairs with the consumer loop)
+            PSP_STAMP(tp2);
+            PSP_ACC(0, tp1, tp0); PSP_ACC(1, tp2, tp1);
         }
+#ifdef PSP_STAMPS
+        if (a.dbg && lane == 0) {
+            stamps[7] = (unsigned long long)R;
+            for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + (tid >> 6)) * 8 + i] = stamps[i];
+        }
+#endif
         // T-layout partial sums of dW3 (h2 rows) and db3: reduce over the 16 trajectory lanes, then over the 4 producers
         float* red = bufs;                                // [4][HB*16 + 1]; the exchange area is free after the last barrier
 #pragma unroll
@@ -1232,7 +1252,11 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
             }
         }
         __syncthreads();                                      // pairs with producer iteration 0
+#ifdef PSP_STAMPS
+        unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         for (int it = 1; it <= R; ++it) {
+            PSP_STAMP(tc0);
             const float* exch = bufs + ((it - 1) & 1) * 4 * (EXT * 256);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -1307,8 +1331,17 @@ __global__ __launch_bounds__(512) void gen_bwd2_kernel(const GenArgs a) {
                     }
                 }
             }
+            PSP_STAMP(tc1);
             __syncthreads();                                  // swap the exchange buffers (pairs with the producer loop)
+            PSP_STAMP(tc2);
+            PSP_ACC(0, tc1, tc0); PSP_ACC(1, tc2, tc1);
         }
+#ifdef PSP_STAMPS
+        if (a.dbg && lane == 0) {
+            stamps[7] = (unsigned long long)R;
+            for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + (tid >> 6)) * 8 + i] = stamps[i];
+        }
+#endif
     } else if constexpr (BF16) {
         // bf16 outer products (v_mfma_f32_16x16x32_bf16): the 32-deep k-step is the sample index of TWO sample blocks --
         // lane (row / col, qq) holds samples 4qq..4qq+3 of either block in both operands, so a k-step is a pack of the two

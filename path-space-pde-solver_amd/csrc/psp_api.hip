@@ -1092,6 +1092,7 @@ int psp_gen_rollout_bwd(const psp_gen_config* cfg, const float* params, const fl
     fill_gen_args(cfg, p, &a);
     a.params = params; a.path = const_cast<float*>(path); a.ahat = const_cast<float*>(ahat);
     a.wY = wY; a.wV = wV; a.grad_partial = grad_partial;
+    a.dbg = (g_dbg && g_dbg_n >= (long long)p.bwd_grid * 8 * 8) ? g_dbg : nullptr;      // (-DPSP_STAMPS builds; the kernels ignore it otherwise)
     if (cfg->mlp_dtype < PSP_MLP_FP32 || cfg->mlp_dtype > PSP_MLP_F16X3) return fail(-1, "mlp_dtype out of range");
     if (cfg->mlp_dtype == PSP_MLP_BF16 && !p.bwd_specialised)
         return fail(-3, "the bf16 backward exists for the role-specialised kernel only (LDS budget / PSP_BWD_VARIANT)");
