@@ -2076,8 +2076,9 @@ struct HjbwLaunch {
     }
     // split-product backward for the instances that run hjbw_bwd_kernel (d > 256: one wave per SIMD)
     static hipError_t bwd2_x3(const HjbArgs& a, int grid, hipStream_t s) {
-        // (d <= 256 keeps the fp32 role-specialised kernel even in split-product mode: hjbw_bwd_x3_kernel at d = 200 measured
-        // 3.11 against 2.74 ms, round 3)
+        // (d <= 256: THIS entry keeps the fp32 role-specialised kernel -- hjbw_bwd_x3_kernel at d = 200 measured 3.11 against
+        // 2.74 ms, round 3; hjbw_instance.hip replaces it with the split-product role-specialised kernel of hjbwx_kernels.h
+        // where that one exists, round 4: 1.87 ms)
         if constexpr (kRoles || D <= 256) {
             return bwd2(a, grid, s);
         } else {
