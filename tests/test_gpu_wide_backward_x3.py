@@ -72,7 +72,7 @@ def test_split_backward_survives_a_large_weight_spread():
     assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
 
 
-@pytest.mark.parametrize("d,K,N", [(320, 2048, 12), (500, 2064, 10), (512, 1500, 16)])
+@pytest.mark.parametrize("d,K,N", [(320, 2048, 12), (384, 1040, 20), (448, 1100, 18), (500, 2064, 10), (512, 1500, 16)])
 def test_streaming_backward_above_256_against_fp32_on_the_same_store(d, K, N):
     """hjbw_bwd_x3_kernel (d > 256: four waves, the split W3^T table resident in LDS, ONE exchange buffer per workgroup -- a wave
     that runs ahead into the next round writes it while the others are still in the last phase of the current one) against the
