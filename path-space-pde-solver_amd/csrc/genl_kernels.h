@@ -547,7 +547,12 @@ __host__ __device__ inline int genl_bwd_lds_bytes(int TB, int DB0, int NW) {
     return (4 * TB - 2 * DB0 + 2) * 1024 + NW * 32 * 4;
 }
 
-template <int NW, bool TLDS = false>
+// MS = register slots for the hidden blocks a wave owns (hidden block hb -> wave hb mod NW, slot hb / NW): GenlGeo<NW>::MAXSLOT
+// serves every net the kernels accept; the eight-wave instance with MS = 3 (sum of the hidden blocks <= 24: the Allen-Cahn notebook's
+// net has 18) keeps 12 registers less per array and requests its table operands two k-step groups ahead instead of four: 37
+// instead of 97 spilled dwords -- the weight-tile accumulators that lived in scratch no longer do -- and the backward of that net
+// goes 3.98 -> 3.29 ms at K = 16 384 (same-box A/B).
+template <int NW, bool TLDS = false, int MS = GenlGeo<NW>::MAXSLOT>
 __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
     PSP_COND_EXIT(ga_.g);
     static_assert(!TLDS || NW == 1, "LDS-resident tables: one-wave instances only");
@@ -595,13 +600,13 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
     }
     tile_sync<NW>();
     f32x4 accW[MAXT];                 // weight tiles of this wave: slot s <-> tile tile0 + wave + NW s
-    f32x4 accB[Geo::MAXSLOT];         // bias gradients of the wave's hidden blocks (summed over the 16 sample lanes at the end)
-    f32x4 Rr[Geo::MAXSLOT], Zr[Geo::MAXSLOT];
+    f32x4 accB[MS];         // bias gradients of the wave's hidden blocks (summed over the 16 sample lanes at the end)
+    f32x4 Rr[MS], Zr[MS];
     float accb = 0.f;
 #pragma unroll
     for (int s = 0; s < MAXT; ++s) accW[s] = zero4;
 #pragma unroll
-    for (int s = 0; s < Geo::MAXSLOT; ++s) { accB[s] = zero4; Rr[s] = zero4; Zr[s] = zero4; }
+    for (int s = 0; s < MS; ++s) { accB[s] = zero4; Rr[s] = zero4; Zr[s] = zero4; }
     const long long nblk = (long long)(a->N + 1) * a->ntile16;
     for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int n = (int)(blk / a->ntile16), t16 = (int)(blk % a->ntile16);
@@ -623,11 +628,11 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
             const int seg = ga->off[i + 1];
             const int KSin = 4 * seg, HBi = ga->HB[i], hoff = seg - DB0;
 #pragma unroll
-            for (int s = 0; s < Geo::MAXSLOT; ++s) {
+            for (int s = 0; s < MS; ++s) {
                 const int mb = wave + NW * s - hoff;
                 if (mb >= 0 && mb < HBi) {
                     f32x4 acc = vec_get(T + ga->vB[i], mb, q), acd = zero4;
-                    genl_gemm1x2<4>(acc, acd, T + ga->tF[i] + (size_t)mb * KSin * 64, KSin, A, Ad, lane);
+                    genl_gemm1x2<(MS < GenlGeo<NW>::MAXSLOT ? 2 : 4)>(acc, acd, T + ga->tF[i] + (size_t)mb * KSin * 64, KSin, A, Ad, lane);
                     const f32x4 r = gact_r(ga->act, acc);
                     Rr[s] = r; Zr[s] = acd;
                     img_put(A, seg + mb, gact_h(ga->act, r), lane);
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
             img_put(ABd, HBS, f32x4{q == 0 ? ws : 0.f, 0.f, 0.f, 0.f}, lane);
         }
 #pragma unroll
-        for (int s = 0; s < Geo::MAXSLOT; ++s) {
+        for (int s = 0; s < MS; ++s) {
             const int hb = wave + NW * s;
             if (hb < HBS) {
                 const f32x4 w = vec_get(T + ga->vW, DB0 + hb, q);
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
             const int seg = ga->off[i + 1];
             const int HBi = ga->HB[i], KSh = 4 * HBi, hoff = seg - DB0;
 #pragma unroll
-            for (int s = 0; s < Geo::MAXSLOT; ++s) {
+            for (int s = 0; s < MS; ++s) {
                 const int hb = wave + NW * s;
                 if (hb >= hoff && hb < hoff + HBi) {
                     const f32x4 gh = img_get(AB, hb, lane), ghd = img_get(ABd, hb, lane);
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
                 // hidden segments below layer i only; two products with the same reverse table: abar += W zbar, abar' += W zbar'
                 for (int ohb = wave; ohb < hoff; ohb += NW) {
                     f32x4 acc = img_get(AB, ohb, lane), acd = img_get(ABd, ohb, lane);
-                    genl_gemm1x2<4>(acc, acd, T + ga->tR[i] + (size_t)(DB0 + ohb) * KSh * 64, KSh, AB + hoff * 256, ABd + hoff * 256, lane);
+                    genl_gemm1x2<(MS < GenlGeo<NW>::MAXSLOT ? 2 : 4)>(acc, acd, T + ga->tR[i] + (size_t)(DB0 + ohb) * KSh * 64, KSh, AB + hoff * 256, ABd + hoff * 256, lane);
                     img_put(AB, ohb, acc, lane); img_put(ABd, ohb, acd, lane);
                 }
                 tile_sync<NW>();
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(64 * NW) void genl_bwd_kernel(const GenlArgs ga_) {
     }
     if (g0) {
 #pragma unroll
-        for (int s = 0; s < Geo::MAXSLOT; ++s) {
+        for (int s = 0; s < MS; ++s) {
             const int hb = wave + NW * s;
             if (hb < HBS) {
                 const int i = genl_layer_of(ga, hb);
@@ -742,10 +747,10 @@ template <int NW, bool TLDS = false> inline hipError_t genl_launch_fwd(const Gen
     hipLaunchKernelGGL((genl_fwd_kernel<NW, TLDS>), dim3(ntile16), dim3(64 * NW), lds_bytes, st, a);
     return hipGetLastError();
 }
-template <int NW, bool TLDS = false> inline hipError_t genl_launch_bwd(const GenlArgs& a, int grid, int groups, int lds_bytes, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&genl_bwd_kernel<NW, TLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+template <int NW, bool TLDS = false, int MS = GenlGeo<NW>::MAXSLOT> inline hipError_t genl_launch_bwd(const GenlArgs& a, int grid, int groups, int lds_bytes, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&genl_bwd_kernel<NW, TLDS, MS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((genl_bwd_kernel<NW, TLDS>), dim3(grid, groups), dim3(64 * NW), lds_bytes, st, a);
+    hipLaunchKernelGGL((genl_bwd_kernel<NW, TLDS, MS>), dim3(grid, groups), dim3(64 * NW), lds_bytes, st, a);
     return hipGetLastError();
 }
 

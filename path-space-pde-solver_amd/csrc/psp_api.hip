@@ -1288,7 +1288,8 @@ int psp_genl_rollout_bwd(const psp_genl_config* cfg, const float* params, const 
     g.params = params; g.path = const_cast<float*>(path); g.ahat = const_cast<float*>(ahat); g.wY = wY; g.wV = wV;
     g.per_sample = cfg->base.per_sample_weights ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = p.nw_bwd == 1 ? (p.tlds ? psp::genl_launch_bwd<1, true>(p.a, p.bwd_grid, p.bwd_groups, p.bwd_lds, st) : psp::genl_launch_bwd<1>(p.a, p.bwd_grid, p.bwd_groups, p.bwd_lds, st)) : psp::genl_launch_bwd<8>(p.a, p.bwd_grid, p.bwd_groups, p.bwd_lds, st);
+    hipError_t e = p.nw_bwd == 1 ? (p.tlds ? psp::genl_launch_bwd<1, true>(p.a, p.bwd_grid, p.bwd_groups, p.bwd_lds, st) : psp::genl_launch_bwd<1>(p.a, p.bwd_grid, p.bwd_groups, p.bwd_lds, st)) : (p.a.HBsum <= 24 ? psp::genl_launch_bwd<8, false, 3>(p.a, p.bwd_grid, p.bwd_groups, p.bwd_lds, st)
+                           : psp::genl_launch_bwd<8>(p.a, p.bwd_grid, p.bwd_groups, p.bwd_lds, st));     // (three slots per wave suffice: genl_kernels.h)
     if (e != hipSuccess) return fail_hip(e, "genl_bwd_kernel launch");
     const int P = (int)p.n_params;
     hipLaunchKernelGGL(reduce_grad_kernel, dim3((P + 31) / 32), dim3(256), 0, st, grad_partial, p.bwd_grid, P, grad_out);
